@@ -1,0 +1,211 @@
+/*
+ * risesdf_hip.h -- C ABI of librisesdf_hip.so, the MI355X (gfx950) implementation of
+ * RISE-SDF's ray-marched SDF volume-rendering hot path.
+ *
+ * Conventions (mirror what the reference's in-tree native ops guarantee at the Python
+ * surface, lib/nerfacc/cuda/csrc/include/helpers_cuda.h:20-32):
+ *   - every pointer is a DEVICE pointer to contiguous memory unless marked "host";
+ *   - the library never allocates, frees, or synchronises: the caller owns outputs and
+ *     scratch (the Python host allocates them through torch's caching allocator);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); kernels are
+ *     enqueued on it and the call returns immediately;
+ *   - return value 0 = success, otherwise a hipError_t (kernel-launch error) or
+ *     RSDF_EINVAL for a rejected argument; rsdf_last_error() gives a message;
+ *   - fp32 everywhere, ray indices int64 and packed_info int32 as in nerfacc.
+ *
+ * Each entry point names the reference interface it replaces (file:line relative to the
+ * upstream dehezhang2/RISE-SDF tree).  INTEGRATION.md shows the reference-side binding.
+ */
+#ifndef RISESDF_HIP_H
+#define RISESDF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSDF_ABI_VERSION 1
+#define RSDF_EINVAL 10001
+#define RSDF_MAX_LEVELS 32
+
+/* activation ids for rsdf_linear_* (models/network_utils.py:152-157, models/utils.py:71-99) */
+#define RSDF_ACT_NONE 0
+#define RSDF_ACT_RELU 1
+#define RSDF_ACT_SOFTPLUS100 2 /* nn.Softplus(beta=100, threshold=20) */
+#define RSDF_ACT_SIGMOID 3
+
+int rsdf_abi_version(void);
+const char *rsdf_last_error(void);
+
+/* ---- M1: ray/AABB slab test ----------------------------------------------------------------
+ * replaces _C.ray_aabb_intersect  (lib/nerfacc/cuda/csrc/intersection.cu:93-133, pybind.cu) and
+ * nerfacc.ray_aabb_intersect.  aabb = {xmin,ymin,zmin,xmax,ymax,zmax}; miss => both 1e10;
+ * t_min clamped to >= 0. */
+int rsdf_ray_aabb_intersect(const float *rays_o, const float *rays_d, const float *aabb,
+                            int64_t n_rays, float *t_min, float *t_max, void *stream);
+
+/* ---- M3/M4: occupancy-grid marcher ----------------------------------------------------------
+ * replaces _C.ray_marching (lib/nerfacc/cuda/csrc/ray_marching.cu:194-289) as an explicit
+ * count -> scan -> write sequence with no host synchronisation inside the library.
+ * `binary` is the bool/uint8 grid [res_x,res_y,res_z] (C order), `roi` 6 floats.
+ * AABB contraction only (the only type the hot path uses, models/split_mixed_occ.py:66). */
+int rsdf_march_count(const float *rays_o, const float *rays_d, const float *t_min,
+                     const float *t_max, const float *roi, const uint8_t *binary, int res_x,
+                     int res_y, int res_z, float step_size, float cone_angle, int64_t n_rays,
+                     int32_t *num_steps, void *stream);
+/* packed_info[r] = {exclusive prefix of counts, counts[r]}; *total (device int32) = sum.
+ * scratch: >= rsdf_scan_scratch_bytes(n) bytes. */
+int64_t rsdf_scan_scratch_bytes(int64_t n);
+int rsdf_pack_from_counts(const int32_t *counts, int64_t n, int32_t *packed_info, int32_t *total,
+                          void *scratch, void *stream);
+int rsdf_march_write(const float *rays_o, const float *rays_d, const float *t_min,
+                     const float *t_max, const float *roi, const uint8_t *binary, int res_x,
+                     int res_y, int res_z, float step_size, float cone_angle, int64_t n_rays,
+                     const int32_t *packed_info, int64_t *ray_indices, float *t_starts,
+                     float *t_ends, void *stream);
+/* replaces _C.query_occ (ray_marching.cu:295-358); cell (nullable) gets the linear cell index,
+ * -1 outside the box. */
+int rsdf_query_occ(const float *samples, const float *roi, const uint8_t *binary, int res_x,
+                   int res_y, int res_z, int64_t n, uint8_t *occ, int32_t *cell, void *stream);
+
+/* ---- M5/M6: pack / unpack / compaction ------------------------------------------------------
+ * replaces pack_info (lib/nerfacc/pack.py:47-78), _C.unpack_info (pack.cu:7-28) and the
+ * boolean-mask compaction of lib/nerfacc/ray_marching.py:213-218.
+ * ray_indices must be sorted (as the marcher emits them). counts: int32 [n_rays] scratch. */
+int rsdf_counts_from_ray_indices(const int64_t *ray_indices, int64_t n_samples, int64_t n_rays,
+                                 int32_t *counts, void *stream);
+int rsdf_unpack_info(const int32_t *packed_info, int64_t n_rays, int64_t *ray_indices,
+                     void *stream);
+/* keep[i] != 0 -> sample survives.  offsets: int32 [n] scratch (exclusive scan of keep, filled
+ * by the call); *n_kept device int32. Outputs sized by the caller (>= n). */
+int rsdf_compact_samples(const uint8_t *keep, const int64_t *ray_indices, const float *t_starts,
+                         const float *t_ends, int64_t n, int32_t *offsets, int32_t *n_kept,
+                         void *scan_scratch, int64_t *ray_indices_out, float *t_starts_out,
+                         float *t_ends_out, void *stream);
+
+/* ---- C1: transmittance / weights from alpha ---------------------------------------------------
+ * replaces nerfacc.render_weight_from_alpha / render_transmittance_from_alpha
+ * (call site models/volrend.py:851-855; spec lib/nerfacc/cuda/csrc/render_weight.cu:86-153,
+ * render_transmittance.cu:85-145, render_transmittance_cub.cu:111-166).  One wavefront per ray,
+ * wave64 multiplicative scan.  T_i = prod_{j<i}(1-a_j), w_i = a_i T_i. */
+int rsdf_weight_from_alpha_fwd(const int32_t *packed_info, const float *alphas, int64_t n_rays,
+                               float *weights, float *trans, void *stream);
+int rsdf_weight_from_alpha_bwd(const int32_t *packed_info, const float *alphas,
+                               const float *weights, const float *trans,
+                               const float *grad_weights, int64_t n_rays, float *grad_alphas,
+                               void *stream);
+int rsdf_transmittance_from_alpha_bwd(const int32_t *packed_info, const float *alphas,
+                                      const float *trans, const float *grad_trans,
+                                      int64_t n_rays, float *grad_alphas, void *stream);
+/* visibility mask (lib/nerfacc/vol_rendering.py:503-520): keep = T >= eps && (thre<=0 || a >= thre) */
+int rsdf_visibility_from_alpha(const int32_t *packed_info, const float *alphas, int64_t n_rays,
+                               float early_stop_eps, float alpha_thre, uint8_t *keep,
+                               void *stream);
+
+/* ---- C2: accumulate along rays ----------------------------------------------------------------
+ * replaces nerfacc.accumulate_along_rays (call sites models/volrend.py:871-885; spec
+ * lib/nerfacc/vol_rendering.py:174-198).  values nullable (=> D must be 1, out = sum of weights).
+ * Every ray's row of `out` is written (zeros for empty rays): no pre-zeroing needed. */
+int rsdf_accumulate_fwd(const int32_t *packed_info, const float *weights, const float *values,
+                        int64_t n_rays, int D, float *out, void *stream);
+int rsdf_accumulate_bwd(const int32_t *packed_info, const float *weights, const float *values,
+                        const float *grad_out, int64_t n_rays, int D, float *grad_weights,
+                        float *grad_values, void *stream);
+
+/* ---- H1: multiresolution hash-grid encoding ----------------------------------------------------
+ * replaces tcnn.Encoding(3, {otype: HashGrid, ...}) forward/backward (constructed
+ * models/network_utils.py:47-50, called :59; tiny-cuda-nn is not vendored).  The level table is
+ * passed by value from the host. Table layout [level][entry][feature] fp32. */
+typedef struct rsdf_grid_meta {
+    uint32_t n_levels;
+    uint32_t n_features; /* 1, 2 or 4 */
+    float scale[RSDF_MAX_LEVELS];
+    uint32_t res[RSDF_MAX_LEVELS];
+    uint32_t offset[RSDF_MAX_LEVELS]; /* entries */
+    uint32_t size[RSDF_MAX_LEVELS];   /* entries */
+} rsdf_grid_meta;
+
+/* host helper: fills meta exactly as the oracle does; returns the parameter count */
+int64_t rsdf_grid_meta_init(rsdf_grid_meta *meta /*host*/, int n_levels, int n_features,
+                            int log2_hashmap_size, int base_resolution, double per_level_scale);
+
+/* x [n,3] in [0,1].  out row stride ld_out floats, features written at column col_off.
+ * Levels >= n_active_levels are written as zeros without being fetched (H2: the progressive mask
+ * of models/network_utils.py:58-68).  If write_xyz != 0 columns [0,3) get x*xyz_scale+xyz_offset
+ * (CompositeEncoding include_xyz, models/network_utils.py:78-79; then col_off must be 3). */
+int rsdf_hashgrid_fwd(const float *x, const float *table, const rsdf_grid_meta *meta /*host*/,
+                      int64_t n, int n_active_levels, float *out, int ld_out, int col_off,
+                      int write_xyz, float xyz_scale, float xyz_offset, void *stream);
+/* dtable += scatter(w * dout); dout row stride ld_dout, features at column col_off.
+ * dtable must be zeroed (or hold a running sum) by the caller. */
+int rsdf_hashgrid_bwd(const float *x, const float *dout, const rsdf_grid_meta *meta /*host*/,
+                      int64_t n, int n_active_levels, int ld_dout, int col_off, float *dtable,
+                      void *stream);
+
+/* ---- H3: VanillaMLP layers on the fp32 matrix cores --------------------------------------------
+ * replaces nn.Linear (+ activation) inside VanillaMLP (models/network_utils.py:109-157).
+ * y[n,N] = act(x[n,K] @ w[N,K]^T + b[N]); row strides ldx / ldy.  K,N <= 128. */
+int rsdf_linear_fwd(const float *x, int ldx, const float *w, const float *b, int64_t n, int K,
+                    int N, int act, float *y, int ldy, void *stream);
+/* dz = dy * act'(y) (written to dz, may alias dy; row stride lddy for both);
+ * dx[n, k0:k0+Kout] = dz @ w[:, k0:k0+Kout]  (dx nullable; dx has row stride lddx and receives
+ * Kout columns starting at its column 0). */
+int rsdf_linear_bwd_input(const float *dy, const float *y, int lddy, const float *w, int64_t n,
+                          int K, int N, int act, int k0, int Kout, float *dz, float *dx, int lddx,
+                          void *stream);
+/* dw[N,K] += dz^T @ x ; db[N] += colsum(dz).  Accumulates with fp32 atomics: zero first. */
+int rsdf_linear_bwd_weight(const float *dz, int lddz, const float *x, int ldx, int64_t n, int K,
+                           int N, float *dw, float *db, void *stream);
+/* weight_norm (torch.nn.utils.weight_norm dim=0): w = g * v / ||v||_row */
+int rsdf_weight_norm_fwd(const float *g, const float *v, int N, int K, float *w, void *stream);
+int rsdf_weight_norm_bwd(const float *g, const float *v, const float *dw, int N, int K, float *dg,
+                         float *dv, void *stream);
+
+/* ---- P1/H4/A1: sample positions, finite-difference normals, NeuS alpha ---------------------------
+ * rsdf_fd_points: positions = o[ri] + d[ri]*(t0+t1)/2 (models/split_mixed_occ.py:229-231), the six
+ * taps x +- eps*e_k clamped to +-radius (models/geometry.py:229-241) and the AABB contraction
+ * (x+r)/(2r) (geometry.py:17-19, models/utils.py:109-114).  x_unit [n,7,3]: tap 0 = centre, then
+ * +x,-x,+y,-y,+z,-z.  positions (nullable) [n,3] world space. */
+int rsdf_fd_points(const float *rays_o, const float *rays_d, const int64_t *ray_indices,
+                   const float *t_starts, const float *t_ends, int64_t n, float radius, float eps,
+                   float *x_unit, float *positions, void *stream);
+/* Same taps from explicit world-space points (VolumeSDF.forward(points), models/geometry.py:206). */
+int rsdf_fd_taps(const float *points, int64_t n, float radius, float eps, float *x_unit,
+                 void *stream);
+/* grad = 0.5*(f+ - f-)/eps from the 7 tap values (models/geometry.py:243); sdf nullable.
+ * Backward writes column 0 of d_sdf7 rows (the other columns are left untouched). */
+int rsdf_fd_gradient_fwd(const float *sdf7, int ld, float eps, int64_t n, float *sdf, float *grad,
+                         void *stream);
+int rsdf_fd_gradient_bwd(const float *d_sdf, const float *d_grad, float eps, int64_t n,
+                         float *d_sdf7, int ld, void *stream);
+/* sdf7 [n,7] (column 0 of the MLP output for the 7 taps, row stride ld) ->
+ * sdf, grad = 0.5*(f+ - f-)/eps (geometry.py:243), normal = grad/max(|grad|,1e-6)
+ * (split_mixed_occ.py:237), alpha (split_mixed_occ.py:151-177).  variance: device scalar,
+ * inv_s = clip(exp(10 v),1e-6,1e6).  dirs are gathered from rays_d by ray index; dists = t1-t0. */
+int rsdf_neus_alpha_fd_fwd(const float *sdf7, int ld, const float *rays_d,
+                           const int64_t *ray_indices, const float *t_starts,
+                           const float *t_ends, const float *variance, float cos_anneal_ratio,
+                           float eps, int64_t n, float *sdf, float *grad, float *normal,
+                           float *alpha, void *stream);
+/* backward: given d_alpha, d_normal, d_sdf, d_grad (each nullable) -> d_sdf7 [n,7] (row stride ld,
+ * fully written) and d_variance += (device scalar, atomically accumulated: zero first). */
+int rsdf_neus_alpha_fd_bwd(const float *sdf7, int ld, const float *rays_d,
+                           const int64_t *ray_indices, const float *t_starts,
+                           const float *t_ends, const float *variance, float cos_anneal_ratio,
+                           float eps, int64_t n, const float *d_alpha, const float *d_normal,
+                           const float *d_sdf, const float *d_grad, float *d_sdf7, int ld_out,
+                           float *d_variance, void *stream);
+/* get_alpha with explicit normals/dirs/dists (the reference signature, split_mixed_occ.py:151) */
+int rsdf_neus_alpha_fwd(const float *sdf, const float *normal, const float *dirs,
+                        const float *dists, const float *variance, float cos_anneal_ratio,
+                        int64_t n, float *alpha, void *stream);
+int rsdf_neus_alpha_bwd(const float *sdf, const float *normal, const float *dirs,
+                        const float *dists, const float *variance, float cos_anneal_ratio,
+                        int64_t n, const float *d_alpha, float *d_sdf, float *d_normal,
+                        float *d_variance, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RISESDF_HIP_H */

@@ -1,0 +1,404 @@
+/*
+ * oracle/risesdf_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * A plain-C, single-threaded CPU restatement of the per-ray / per-sample
+ * loops on RISE-SDF's ray-marched SDF volume-rendering hot path.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; the
+ * shipped HIP path never does.
+ *
+ * Each function cites the reference file:line (relative to the upstream
+ * dehezhang2/RISE-SDF tree) whose algorithm it restates.  Nothing here is
+ * copied: the reference is CUDA with float3 helper types, this is scalar C.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fPIC -shared (see oracle/Makefile).
+ * -ffp-contract=off matters: the marcher's voxel index is an integer function
+ * of fp32 arithmetic, and the HIP kernels are built with the same flag so the
+ * two agree bit for bit.  Fused multiply-adds appear only where written
+ * explicitly as fmaf().
+ *
+ * PARITY PIN STATUS
+ *   - compositing (C1): pinned by the reference's docstring known-answer
+ *     vectors, lib/nerfacc/vol_rendering.py:303-307, 430-434, 493-500.
+ *   - marcher (M1/M3/M4): the vendored CUDA needs cuda_runtime.h and torch
+ *     headers, so it is unbuildable in this image; pinned by hand-derived
+ *     cases only (tests/test_oracle_marcher.py).
+ *   - hash grid (H1): tiny-cuda-nn is not vendored and not version-pinned by
+ *     the reference => PARITY UNPINNED; this file fixes the build's own
+ *     definition (documented in DESIGN.md).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------- */
+/* M1: ray / AABB slab test.  lib/nerfacc/cuda/csrc/intersection.cu:16-91    */
+/* ------------------------------------------------------------------------- */
+static void ray_aabb_one(const float *o, const float *d, const float *aabb,
+                         float *near_, float *far_)
+{
+    float tmin = (aabb[0] - o[0]) / d[0];
+    float tmax = (aabb[3] - o[0]) / d[0];
+    if (tmin > tmax) { float c = tmin; tmin = tmax; tmax = c; }
+
+    float tymin = (aabb[1] - o[1]) / d[1];
+    float tymax = (aabb[4] - o[1]) / d[1];
+    if (tymin > tymax) { float c = tymin; tymin = tymax; tymax = c; }
+
+    if (tmin > tymax || tymin > tmax) { *near_ = 1e10f; *far_ = 1e10f; return; }
+    if (tymin > tmin) tmin = tymin;
+    if (tymax < tmax) tmax = tymax;
+
+    float tzmin = (aabb[2] - o[2]) / d[2];
+    float tzmax = (aabb[5] - o[2]) / d[2];
+    if (tzmin > tzmax) { float c = tzmin; tzmin = tzmax; tzmax = c; }
+
+    if (tmin > tzmax || tzmin > tmax) { *near_ = 1e10f; *far_ = 1e10f; return; }
+    if (tzmin > tmin) tmin = tzmin;
+    if (tzmax < tmax) tmax = tzmax;
+    *near_ = tmin;
+    *far_ = tmax;
+}
+
+void orc_ray_aabb_intersect(int64_t n, const float *rays_o, const float *rays_d,
+                            const float *aabb, float *t_min, float *t_max)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        ray_aabb_one(rays_o + 3 * i, rays_d + 3 * i, aabb, t_min + i, t_max + i);
+        /* intersection.cu:88-89: clamp the near hit to the ray origin */
+        t_min[i] = t_min[i] > 0.f ? t_min[i] : 0.f;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* M3: occupancy-grid cell index.  ray_marching.cu:16-45,                    */
+/*     helpers_contraction.h:16-21 (roi_to_unit)                             */
+/* ------------------------------------------------------------------------- */
+static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+static inline int grid_idx_at(float ux, float uy, float uz, const int *res)
+{
+    /* int() truncation of unit*res, then clamp to the grid (ray_marching.cu:20-24) */
+    int ix = clampi((int)(ux * (float)res[0]), 0, res[0] - 1);
+    int iy = clampi((int)(uy * (float)res[1]), 0, res[1] - 1);
+    int iz = clampi((int)(uz * (float)res[2]), 0, res[2] - 1);
+    return ix * (res[1] * res[2]) + iy * res[2] + iz;
+}
+
+static inline int grid_occupied_at(float x, float y, float z, const float *roi,
+                                   const int *res, const uint8_t *binary, int *cell)
+{
+    /* AABB contraction: outside the (inclusive) box is empty (ray_marching.cu:34-40) */
+    if (x < roi[0] || x > roi[3] || y < roi[1] || y > roi[4] || z < roi[2] || z > roi[5]) {
+        if (cell) *cell = -1;
+        return 0;
+    }
+    float ux = (x - roi[0]) / (roi[3] - roi[0]);
+    float uy = (y - roi[1]) / (roi[4] - roi[1]);
+    float uz = (z - roi[2]) / (roi[5] - roi[2]);
+    int idx = grid_idx_at(ux, uy, uz, res);
+    if (cell) *cell = idx;
+    return binary[idx] != 0;
+}
+
+/* query_occ: ray_marching.cu:295-358 (AABB contraction only) */
+void orc_query_occ(int64_t n, const float *xyz, const float *roi, const int *res,
+                   const uint8_t *binary, uint8_t *occ, int32_t *cell_idx)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        int cell;
+        occ[i] = (uint8_t)grid_occupied_at(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2],
+                                           roi, res, binary, &cell);
+        if (cell_idx) cell_idx[i] = cell;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* M4: the marcher.  ray_marching.cu:9-14 (calc_dt), 48-57                   */
+/*     (distance_to_next_voxel), 59-75 (advance_to_next_voxel), 81-192       */
+/* ------------------------------------------------------------------------- */
+static inline float clampf(float f, float a, float b) { return fmaxf(a, fminf(f, b)); }
+static inline float calc_dt(float t, float cone, float dt_min, float dt_max)
+{
+    return clampf(t * cone, dt_min, dt_max);
+}
+
+static inline float dist_to_next_voxel_axis(float p, float dir, float inv_dir,
+                                            float rmin, float rmax, int res)
+{
+    /* ((floor(x*res + 0.5 + 0.5*sign(d)) - x*res) * inv_d) / res * (max-min) */
+    float r = (float)res;
+    float u = (p - rmin) / (rmax - rmin) * r;
+    float s = copysignf(1.0f, dir);
+    return ((floorf(u + 0.5f + 0.5f * s) - u) * inv_dir) / r * (rmax - rmin);
+}
+
+static inline float advance_to_next_voxel(float t, float dt_min, const float *xyz,
+                                          const float *dir, const float *inv_dir,
+                                          const float *roi, const int *res, float far_)
+{
+    float tx = dist_to_next_voxel_axis(xyz[0], dir[0], inv_dir[0], roi[0], roi[3], res[0]);
+    float ty = dist_to_next_voxel_axis(xyz[1], dir[1], inv_dir[1], roi[1], roi[4], res[1]);
+    float tz = dist_to_next_voxel_axis(xyz[2], dir[2], inv_dir[2], roi[2], roi[5], res[2]);
+    float tt = fminf(fminf(tx, ty), tz);
+    float t_target = t + fmaxf(tt, 0.0f);
+    t_target = fminf(t_target, far_);
+    /* data-dependent float accumulation: must stay a loop (ray_marching.cu:69-74) */
+    float _t = t;
+    do { _t += dt_min; } while (_t < t_target);
+    return _t;
+}
+
+/*
+ * One pass over all rays.  packed_info == NULL: count pass (writes num_steps).
+ * Otherwise the write pass, exactly the two-pass protocol of
+ * ray_marching.cu:234-286.
+ */
+void orc_ray_marching(int64_t n_rays, const float *rays_o, const float *rays_d,
+                      const float *t_min, const float *t_max, const float *roi,
+                      const int *res, const uint8_t *binary, float step_size,
+                      float cone_angle, const int32_t *packed_info,
+                      int32_t *num_steps, int64_t *ray_indices, float *t_starts,
+                      float *t_ends)
+{
+    for (int64_t i = 0; i < n_rays; ++i) {
+        const float *o = rays_o + 3 * i, *d = rays_d + 3 * i;
+        const float inv_dir[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
+        const float near_ = t_min[i], far_ = t_max[i];
+        const float dt_min = step_size, dt_max = 1e10f;
+        int64_t base = packed_info ? packed_info[2 * i] : 0;
+
+        int j = 0;
+        float t0 = near_;
+        float dt = calc_dt(t0, cone_angle, dt_min, dt_max);
+        float t1 = t0 + dt;
+        float t_mid = (t0 + t1) * 0.5f;
+        while (t_mid < far_) {
+            float xyz[3] = {o[0] + t_mid * d[0], o[1] + t_mid * d[1], o[2] + t_mid * d[2]};
+            if (grid_occupied_at(xyz[0], xyz[1], xyz[2], roi, res, binary, NULL)) {
+                if (packed_info) {
+                    t_starts[base + j] = t0;
+                    t_ends[base + j] = t1;
+                    ray_indices[base + j] = i;
+                }
+                ++j;
+                t0 = t1;
+                t1 = t0 + calc_dt(t0, cone_angle, dt_min, dt_max);
+                t_mid = (t0 + t1) * 0.5f;
+            } else {
+                t_mid = advance_to_next_voxel(t_mid, dt_min, xyz, d, inv_dir, roi, res, far_);
+                dt = calc_dt(t_mid, cone_angle, dt_min, dt_max);
+                t0 = t_mid - dt * 0.5f;
+                t1 = t_mid + dt * 0.5f;
+            }
+        }
+        if (!packed_info) num_steps[i] = j;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* M6: pack / unpack.  lib/nerfacc/pack.py:47-78, pack.cu:7-28               */
+/* ------------------------------------------------------------------------- */
+void orc_pack_info(int64_t n_samples, const int64_t *ray_indices, int64_t n_rays,
+                   int32_t *packed_info)
+{
+    memset(packed_info, 0, sizeof(int32_t) * 2 * (size_t)n_rays);
+    for (int64_t s = 0; s < n_samples; ++s) packed_info[2 * ray_indices[s] + 1] += 1;
+    int32_t cum = 0;
+    for (int64_t r = 0; r < n_rays; ++r) {
+        packed_info[2 * r] = cum;
+        cum += packed_info[2 * r + 1];
+    }
+}
+
+void orc_unpack_info(int64_t n_rays, const int32_t *packed_info, int64_t *ray_indices)
+{
+    for (int64_t r = 0; r < n_rays; ++r) {
+        int base = packed_info[2 * r], steps = packed_info[2 * r + 1];
+        for (int j = 0; j < steps; ++j) ray_indices[base + j] = r;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* C1: transmittance / weights from alpha, forward and backward.             */
+/*     render_transmittance.cu:85-145, render_weight.cu:86-153               */
+/* ------------------------------------------------------------------------- */
+void orc_transmittance_from_alpha_fwd(int64_t n_rays, const int32_t *packed_info,
+                                      const float *alphas, float *trans)
+{
+    for (int64_t r = 0; r < n_rays; ++r) {
+        int base = packed_info[2 * r], steps = packed_info[2 * r + 1];
+        float T = 1.0f;
+        for (int j = 0; j < steps; ++j) {
+            trans[base + j] = T;
+            T *= (1.0f - alphas[base + j]);
+        }
+    }
+}
+
+void orc_transmittance_from_alpha_bwd(int64_t n_rays, const int32_t *packed_info,
+                                      const float *alphas, const float *trans,
+                                      const float *trans_grad, float *alphas_grad)
+{
+    for (int64_t r = 0; r < n_rays; ++r) {
+        int base = packed_info[2 * r], steps = packed_info[2 * r + 1];
+        float cumsum = 0.0f;
+        for (int j = steps - 1; j >= 0; --j) {
+            alphas_grad[base + j] = cumsum / fmaxf(1.0f - alphas[base + j], 1e-10f);
+            cumsum += -trans_grad[base + j] * trans[base + j];
+        }
+    }
+}
+
+void orc_weight_from_alpha_fwd(int64_t n_rays, const int32_t *packed_info,
+                               const float *alphas, float *weights)
+{
+    for (int64_t r = 0; r < n_rays; ++r) {
+        int base = packed_info[2 * r], steps = packed_info[2 * r + 1];
+        float T = 1.0f;
+        for (int j = 0; j < steps; ++j) {
+            float a = alphas[base + j];
+            weights[base + j] = a * T;
+            T *= (1.0f - a);
+        }
+    }
+}
+
+void orc_weight_from_alpha_bwd(int64_t n_rays, const int32_t *packed_info,
+                               const float *alphas, const float *weights,
+                               const float *grad_weights, float *grad_alphas)
+{
+    for (int64_t r = 0; r < n_rays; ++r) {
+        int base = packed_info[2 * r], steps = packed_info[2 * r + 1];
+        float accum = 0.0f;
+        for (int j = 0; j < steps; ++j) accum += grad_weights[base + j] * weights[base + j];
+        float T = 1.0f;
+        for (int j = 0; j < steps; ++j) {
+            float a = alphas[base + j];
+            grad_alphas[base + j] =
+                (grad_weights[base + j] * T - accum) / fmaxf(1.0f - a, 1e-10f);
+            accum -= grad_weights[base + j] * weights[base + j];
+            T *= (1.0f - a);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* H1 / H1b: multiresolution hash-grid encoding (3-D input).                 */
+/* Reference call sites: models/network_utils.py:47-50,59 (tcnn.Encoding,    */
+/* otype HashGrid).  tiny-cuda-nn itself is absent from the reference tree   */
+/* and unpinned (README.md:56): PARITY UNPINNED.  This restates the          */
+/* published Instant-NGP algorithm with the build's own fixed definition:    */
+/*   pos   = fmaf(scale_l, x, 0.5);  cell = floor(pos);  w = pos - cell      */
+/*   index = dense x + y*res + z*res^2 when res^3 <= size_l, else            */
+/*           (x*1 ^ y*2654435761 ^ z*805459861), always taken mod size_l     */
+/*   out   = sum over the 8 corners in corner order 0..7 of fmaf(w_c, v_c, .)*/
+/*   w_c   = prod over dims 0,1,2 of (bit ? w : 1 - w)                       */
+/* Feature layout [S][L*F] level-major; table layout [level][entry][F].      */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    uint32_t n_levels;
+    uint32_t n_features;
+    float scale[32];
+    uint32_t res[32];
+    uint32_t offset[32]; /* in entries */
+    uint32_t size[32];   /* in entries */
+} orc_grid_meta;
+
+static inline uint32_t hg_index(uint32_t x, uint32_t y, uint32_t z, uint32_t res,
+                                uint32_t size)
+{
+    uint64_t dense = (uint64_t)res * res * res;
+    uint32_t idx;
+    if (dense <= (uint64_t)size)
+        idx = x + y * res + z * res * res;
+    else
+        idx = (x * 1u) ^ (y * 2654435761u) ^ (z * 805459861u);
+    return idx % size;
+}
+
+void orc_hashgrid_fwd(int64_t n, const float *x, const float *table,
+                      const orc_grid_meta *m, float *out)
+{
+    const uint32_t L = m->n_levels, F = m->n_features;
+    for (int64_t s = 0; s < n; ++s) {
+        for (uint32_t l = 0; l < L; ++l) {
+            float w[3];
+            uint32_t c[3];
+            for (int dI = 0; dI < 3; ++dI) {
+                float pos = fmaf(m->scale[l], x[3 * s + dI], 0.5f);
+                float fl = floorf(pos);
+                c[dI] = (uint32_t)(int32_t)fl;
+                w[dI] = pos - fl;
+            }
+            const float *tl = table + (size_t)m->offset[l] * F;
+            float acc[8] = {0};
+            for (int corner = 0; corner < 8; ++corner) {
+                float wc = 1.0f;
+                uint32_t p[3];
+                for (int dI = 0; dI < 3; ++dI) {
+                    if (corner & (1 << dI)) { wc *= w[dI]; p[dI] = c[dI] + 1u; }
+                    else { wc *= 1.0f - w[dI]; p[dI] = c[dI]; }
+                }
+                uint32_t idx = hg_index(p[0], p[1], p[2], m->res[l], m->size[l]);
+                for (uint32_t f = 0; f < F; ++f)
+                    acc[f] = fmaf(wc, tl[(size_t)idx * F + f], acc[f]);
+            }
+            for (uint32_t f = 0; f < F; ++f) out[(size_t)s * L * F + l * F + f] = acc[f];
+        }
+    }
+}
+
+/* d(table) += w_c * d(out); accumulated in double so that the oracle is an   */
+/* order-independent reference for the GPU's fp32 atomics.                    */
+void orc_hashgrid_bwd(int64_t n, const float *x, const float *dout,
+                      const orc_grid_meta *m, double *dtable)
+{
+    const uint32_t L = m->n_levels, F = m->n_features;
+    for (int64_t s = 0; s < n; ++s) {
+        for (uint32_t l = 0; l < L; ++l) {
+            float w[3];
+            uint32_t c[3];
+            for (int dI = 0; dI < 3; ++dI) {
+                float pos = fmaf(m->scale[l], x[3 * s + dI], 0.5f);
+                float fl = floorf(pos);
+                c[dI] = (uint32_t)(int32_t)fl;
+                w[dI] = pos - fl;
+            }
+            double *tl = dtable + (size_t)m->offset[l] * F;
+            for (int corner = 0; corner < 8; ++corner) {
+                float wc = 1.0f;
+                uint32_t p[3];
+                for (int dI = 0; dI < 3; ++dI) {
+                    if (corner & (1 << dI)) { wc *= w[dI]; p[dI] = c[dI] + 1u; }
+                    else { wc *= 1.0f - w[dI]; p[dI] = c[dI]; }
+                }
+                uint32_t idx = hg_index(p[0], p[1], p[2], m->res[l], m->size[l]);
+                for (uint32_t f = 0; f < F; ++f)
+                    tl[(size_t)idx * F + f] +=
+                        (double)wc * (double)dout[(size_t)s * L * F + l * F + f];
+            }
+        }
+    }
+}
+
+/* indices only: the bit-exact part of H1 (used by index-parity tests) */
+void orc_hashgrid_indices(int64_t n, const float *x, const orc_grid_meta *m,
+                          uint32_t *idx_out /* [n][L][8] */)
+{
+    const uint32_t L = m->n_levels;
+    for (int64_t s = 0; s < n; ++s)
+        for (uint32_t l = 0; l < L; ++l) {
+            uint32_t c[3];
+            for (int dI = 0; dI < 3; ++dI) {
+                float pos = fmaf(m->scale[l], x[3 * s + dI], 0.5f);
+                c[dI] = (uint32_t)(int32_t)floorf(pos);
+            }
+            for (int corner = 0; corner < 8; ++corner) {
+                uint32_t p[3];
+                for (int dI = 0; dI < 3; ++dI) p[dI] = c[dI] + ((corner >> dI) & 1u);
+                idx_out[((size_t)s * L + l) * 8 + corner] =
+                    m->offset[l] + hg_index(p[0], p[1], p[2], m->res[l], m->size[l]);
+            }
+        }
+}

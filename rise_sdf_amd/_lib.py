@@ -1,0 +1,144 @@
+"""ctypes binding of librisesdf_hip.so (the C ABI declared in include/risesdf_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing, ``lib()`` raises.  Build it
+with ``python __graft_entry__.py`` (or ``make -C rise_sdf_amd/csrc``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "librisesdf_hip.so")
+MAX_LEVELS = 32
+
+ACT_NONE, ACT_RELU, ACT_SOFTPLUS100, ACT_SIGMOID = 0, 1, 2, 3
+ACT_IDS = {"none": ACT_NONE, None: ACT_NONE, "relu": ACT_RELU, "softplus100": ACT_SOFTPLUS100,
+           "sigmoid": ACT_SIGMOID}
+
+
+class GridMeta(ctypes.Structure):
+    """struct rsdf_grid_meta"""
+    _fields_ = [
+        ("n_levels", ctypes.c_uint32),
+        ("n_features", ctypes.c_uint32),
+        ("scale", ctypes.c_float * MAX_LEVELS),
+        ("res", ctypes.c_uint32 * MAX_LEVELS),
+        ("offset", ctypes.c_uint32 * MAX_LEVELS),
+        ("size", ctypes.c_uint32 * MAX_LEVELS),
+    ]
+
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_L = ctypes.c_int64
+_F = ctypes.c_float
+
+# name -> argtypes (restype is int unless listed in _RESTYPES)
+_SIGNATURES = {
+    "rsdf_abi_version": [],
+    "rsdf_last_error": [],
+    "rsdf_ray_aabb_intersect": [_P, _P, _P, _L, _P, _P, _P],
+    "rsdf_march_count": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _L, _P, _P],
+    "rsdf_scan_scratch_bytes": [_L],
+    "rsdf_pack_from_counts": [_P, _L, _P, _P, _P, _P],
+    "rsdf_march_write": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _L, _P, _P, _P, _P, _P],
+    "rsdf_query_occ": [_P, _P, _P, _I, _I, _I, _L, _P, _P, _P],
+    "rsdf_counts_from_ray_indices": [_P, _L, _L, _P, _P],
+    "rsdf_unpack_info": [_P, _L, _P, _P],
+    "rsdf_compact_samples": [_P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P],
+    "rsdf_weight_from_alpha_fwd": [_P, _P, _L, _P, _P, _P],
+    "rsdf_weight_from_alpha_bwd": [_P, _P, _P, _P, _P, _L, _P, _P],
+    "rsdf_transmittance_from_alpha_bwd": [_P, _P, _P, _P, _L, _P, _P],
+    "rsdf_visibility_from_alpha": [_P, _P, _L, _F, _F, _P, _P],
+    "rsdf_accumulate_fwd": [_P, _P, _P, _L, _I, _P, _P],
+    "rsdf_accumulate_bwd": [_P, _P, _P, _P, _L, _I, _P, _P, _P],
+    "rsdf_grid_meta_init": [ctypes.POINTER(GridMeta), _I, _I, _I, _I, ctypes.c_double],
+    "rsdf_hashgrid_fwd": [_P, _P, ctypes.POINTER(GridMeta), _L, _I, _P, _I, _I, _I, _F, _F, _P],
+    "rsdf_hashgrid_bwd": [_P, _P, ctypes.POINTER(GridMeta), _L, _I, _I, _I, _P, _P],
+    "rsdf_linear_fwd": [_P, _I, _P, _P, _L, _I, _I, _I, _P, _I, _P],
+    "rsdf_linear_bwd_input": [_P, _P, _I, _P, _L, _I, _I, _I, _I, _I, _P, _P, _I, _P],
+    "rsdf_linear_bwd_weight": [_P, _I, _P, _I, _L, _I, _I, _P, _P, _P],
+    "rsdf_weight_norm_fwd": [_P, _P, _I, _I, _P, _P],
+    "rsdf_weight_norm_bwd": [_P, _P, _P, _I, _I, _P, _P, _P],
+    "rsdf_fd_points": [_P, _P, _P, _P, _P, _L, _F, _F, _P, _P, _P],
+    "rsdf_fd_taps": [_P, _L, _F, _F, _P, _P],
+    "rsdf_fd_gradient_fwd": [_P, _I, _F, _L, _P, _P, _P],
+    "rsdf_fd_gradient_bwd": [_P, _P, _F, _L, _P, _I, _P],
+    "rsdf_neus_alpha_fd_fwd": [_P, _I, _P, _P, _P, _P, _P, _F, _F, _L, _P, _P, _P, _P, _P],
+    "rsdf_neus_alpha_fd_bwd": [_P, _I, _P, _P, _P, _P, _P, _F, _F, _L, _P, _P, _P, _P, _P, _I, _P, _P],
+    "rsdf_neus_alpha_fwd": [_P, _P, _P, _P, _P, _F, _L, _P, _P],
+    "rsdf_neus_alpha_bwd": [_P, _P, _P, _P, _P, _F, _L, _P, _P, _P, _P, _P],
+}
+_RESTYPES = {"rsdf_last_error": ctypes.c_char_p, "rsdf_scan_scratch_bytes": ctypes.c_int64,
+             "rsdf_grid_meta_init": ctypes.c_int64}
+
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+class RiseSdfHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RiseSdfHipError(
+                f"{SO_PATH} is missing: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()' or make -C rise_sdf_amd/csrc). "
+                "rise_sdf_amd has no CPU fallback.")
+        l = ctypes.CDLL(SO_PATH)
+        for name, argtypes in _SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPES.get(name, ctypes.c_int)
+        if l.rsdf_abi_version() != 1:
+            raise RiseSdfHipError("librisesdf_hip.so ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().rsdf_last_error()
+        raise RiseSdfHipError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    """The current torch HIP stream as a hipStream_t: kernels are enqueued where torch's are
+    (the reference ops use at::cuda::getCurrentCUDAStream(), ray_marching.cu:235)."""
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_device(*tensors):
+    """Same contract as the reference's CHECK_INPUT (helpers_cuda.h:20-25): device + contiguous."""
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RiseSdfHipError("rise_sdf_amd ops only accept device (HIP) tensors; there is no "
+                                  "CPU path")
+        if not t.is_contiguous():
+            raise RiseSdfHipError("rise_sdf_amd ops need contiguous tensors")
+
+
+def make_grid_meta(n_levels, n_features, log2_hashmap_size, base_resolution, per_level_scale):
+    """Host-side level table via the library's own rsdf_grid_meta_init. Returns (meta, n_params)."""
+    m = GridMeta()
+    n_params = lib().rsdf_grid_meta_init(ctypes.byref(m), int(n_levels), int(n_features),
+                                         int(log2_hashmap_size), int(base_resolution),
+                                         float(per_level_scale))
+    if n_params < 0:
+        raise RiseSdfHipError("rsdf_grid_meta_init rejected the configuration")
+    return m, int(n_params)

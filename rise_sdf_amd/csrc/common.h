@@ -1,0 +1,85 @@
+// Shared host/device helpers for librisesdf_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/risesdf_hip.h"
+
+#define RSDF_WAVE 64
+
+extern "C" void rsdf_set_error(const char *msg);
+
+#define RSDF_CHECK_ARG(cond, msg)        \
+    do {                                 \
+        if (!(cond)) {                   \
+            rsdf_set_error(msg);         \
+            return RSDF_EINVAL;          \
+        }                                \
+    } while (0)
+
+// Launch-error check only: never synchronises (hipGetLastError is host-side state).
+#define RSDF_RETURN_LAUNCH()                              \
+    do {                                                  \
+        hipError_t e_ = hipGetLastError();                \
+        if (e_ != hipSuccess) {                           \
+            rsdf_set_error(hipGetErrorString(e_));        \
+            return (int)e_;                               \
+        }                                                 \
+        return 0;                                         \
+    } while (0)
+
+static inline unsigned rsdf_blocks(int64_t n, int threads) { return (unsigned)((n + threads - 1) / threads); }
+
+// ---- wave64 primitives -------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// inclusive scans across the 64 lanes (Hillis-Steele over ds_bpermute shuffles)
+__device__ __forceinline__ float wave_incl_prod(float v)
+{
+    const int l = lane_id();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float u = __shfl_up(v, o, 64);
+        if (l >= o) v *= u;
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_incl_sum(float v)
+{
+    const int l = lane_id();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float u = __shfl_up(v, o, 64);
+        if (l >= o) v += u;
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_incl_sum_i(int v)
+{
+    const int l = lane_id();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int u = __shfl_up(v, o, 64);
+        if (l >= o) v += u;
+    }
+    return v;
+}
+// inclusive SUFFIX sum: lane l gets sum over lanes >= l
+__device__ __forceinline__ float wave_suffix_sum(float v)
+{
+    const int l = lane_id();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float u = __shfl_down(v, o, 64);
+        if (l + o < 64) v += u;
+    }
+    return v;
+}

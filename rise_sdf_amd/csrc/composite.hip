@@ -1,0 +1,232 @@
+// C1 / C2: per-ray transmittance compositing -- one wavefront per ray, wave64 scans.
+//
+// Specification followed (paths relative to the upstream RISE-SDF tree):
+//   lib/nerfacc/cuda/csrc/render_weight.cu:86-153           w_i = a_i T_i and its closed-form backward
+//   lib/nerfacc/cuda/csrc/render_transmittance.cu:85-145    T_i = prod_{j<i}(1-a_j), backward
+//   lib/nerfacc/cuda/csrc/render_transmittance_cub.cu:111-166  (the scan-by-key formulation replaced)
+//   lib/nerfacc/vol_rendering.py:174-198                    accumulate_along_rays
+//   lib/nerfacc/vol_rendering.py:503-520                    render_visibility
+//
+// The reference runs one THREAD per ray (serial loop) or a device-wide CUB scan keyed by int64 ray
+// ids.  Here a ray's samples are contiguous, so a wavefront walks its ray in 64-sample chunks,
+// scanning each chunk across lanes and carrying the running product / suffix sum in a scalar.
+#include "common.h"
+
+namespace {
+
+constexpr int THREADS = 256;  // 4 rays per workgroup
+
+__device__ __forceinline__ int64_t ray_of_wave() { return ((int64_t)blockIdx.x * THREADS + threadIdx.x) >> 6; }
+
+// MODE 0: weights + trans; MODE 1: visibility mask
+template <int MODE>
+__global__ void __launch_bounds__(THREADS)
+weight_fwd_kernel(const int32_t *__restrict__ packed, const float *__restrict__ alphas,
+                  int64_t n_rays, float *__restrict__ weights, float *__restrict__ trans,
+                  float eps, float alpha_thre, uint8_t *__restrict__ keep)
+{
+    const int64_t r = ray_of_wave();
+    if (r >= n_rays) return;
+    const int base = packed[2 * r], steps = packed[2 * r + 1];
+    const int lane = lane_id();
+    float carry = 1.0f;
+    for (int c = 0; c < steps; c += 64) {
+        const int j = c + lane;
+        const float a = j < steps ? alphas[base + j] : 0.0f;
+        const float incl = wave_incl_prod(1.0f - a);
+        float excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 1.0f;
+        const float T = carry * excl;
+        if (j < steps) {
+            if (MODE == 0) {
+                weights[base + j] = a * T;
+                if (trans) trans[base + j] = T;
+            } else {
+                bool v = T >= eps;
+                if (alpha_thre > 0.0f) v = v && (a >= alpha_thre);
+                keep[base + j] = v ? 1 : 0;
+            }
+        }
+        carry *= __shfl(incl, 63, 64);
+    }
+}
+
+// ga_j = (gw_j T_j - sum_{k>=j} gw_k w_k) / max(1 - a_j, 1e-10)   (render_weight.cu:139-151)
+__global__ void __launch_bounds__(THREADS)
+weight_bwd_kernel(const int32_t *__restrict__ packed, const float *__restrict__ alphas,
+                  const float *__restrict__ weights, const float *__restrict__ trans,
+                  const float *__restrict__ gw, int64_t n_rays, float *__restrict__ ga)
+{
+    const int64_t r = ray_of_wave();
+    if (r >= n_rays) return;
+    const int base = packed[2 * r], steps = packed[2 * r + 1];
+    const int lane = lane_id();
+    float carry = 0.0f;  // sum over later chunks
+    const int n_chunks = (steps + 63) >> 6;
+    for (int ci = n_chunks - 1; ci >= 0; --ci) {
+        const int j = ci * 64 + lane;
+        const bool ok = j < steps;
+        const float g = ok ? gw[base + j] : 0.0f;
+        const float w = ok ? weights[base + j] : 0.0f;
+        const float suf = wave_suffix_sum(g * w);
+        if (ok) {
+            const float a = alphas[base + j];
+            ga[base + j] = (g * trans[base + j] - (suf + carry)) / fmaxf(1.0f - a, 1e-10f);
+        }
+        carry += __shfl(suf, 0, 64);
+    }
+}
+
+// ga_j = (sum_{k>j} -gT_k T_k) / max(1 - a_j, 1e-10)   (render_transmittance.cu:137-142)
+__global__ void __launch_bounds__(THREADS)
+trans_bwd_kernel(const int32_t *__restrict__ packed, const float *__restrict__ alphas,
+                 const float *__restrict__ trans, const float *__restrict__ gt, int64_t n_rays,
+                 float *__restrict__ ga)
+{
+    const int64_t r = ray_of_wave();
+    if (r >= n_rays) return;
+    const int base = packed[2 * r], steps = packed[2 * r + 1];
+    const int lane = lane_id();
+    float carry = 0.0f;
+    const int n_chunks = (steps + 63) >> 6;
+    for (int ci = n_chunks - 1; ci >= 0; --ci) {
+        const int j = ci * 64 + lane;
+        const bool ok = j < steps;
+        const float v = ok ? -gt[base + j] * trans[base + j] : 0.0f;
+        const float suf = wave_suffix_sum(v);  // inclusive of j
+        if (ok) ga[base + j] = (suf - v + carry) / fmaxf(1.0f - alphas[base + j], 1e-10f);
+        carry += __shfl(suf, 0, 64);
+    }
+}
+
+// out[r,d] = sum_i w_i v[i,d]
+template <int D_TILE>
+__global__ void __launch_bounds__(THREADS)
+accumulate_fwd_kernel(const int32_t *__restrict__ packed, const float *__restrict__ weights,
+                      const float *__restrict__ values, int64_t n_rays, int D,
+                      float *__restrict__ out)
+{
+    const int64_t r = ray_of_wave();
+    if (r >= n_rays) return;
+    const int base = packed[2 * r], steps = packed[2 * r + 1];
+    const int lane = lane_id();
+    for (int d0 = 0; d0 < D; d0 += D_TILE) {
+        float acc[D_TILE];
+#pragma unroll
+        for (int d = 0; d < D_TILE; ++d) acc[d] = 0.0f;
+        for (int j = lane; j < steps; j += 64) {
+            const float w = weights[base + j];
+            if (values) {
+                const float *v = values + (int64_t)(base + j) * D + d0;
+#pragma unroll
+                for (int d = 0; d < D_TILE; ++d)
+                    if (d0 + d < D) acc[d] = fmaf(w, v[d], acc[d]);
+            } else {
+                acc[0] += w;
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < D_TILE; ++d) {
+            const float s = wave_sum(acc[d]);
+            if (lane == 0 && d0 + d < D) out[r * D + d0 + d] = s;
+        }
+    }
+}
+
+// gw_i = sum_d go[r,d] v[i,d];  gv[i,d] = w_i go[r,d]
+__global__ void __launch_bounds__(THREADS)
+accumulate_bwd_kernel(const int32_t *__restrict__ packed, const float *__restrict__ weights,
+                      const float *__restrict__ values, const float *__restrict__ go,
+                      int64_t n_rays, int D, float *__restrict__ gw, float *__restrict__ gv)
+{
+    const int64_t r = ray_of_wave();
+    if (r >= n_rays) return;
+    const int base = packed[2 * r], steps = packed[2 * r + 1];
+    const int lane = lane_id();
+    const float *g = go + r * D;
+    for (int j = lane; j < steps; j += 64) {
+        const int64_t s = base + j;
+        if (values) {
+            const float w = weights[s];
+            float acc = 0.0f;
+            for (int d = 0; d < D; ++d) {
+                const float gd = g[d];
+                acc = fmaf(gd, values[s * D + d], acc);
+                if (gv) gv[s * D + d] = w * gd;
+            }
+            if (gw) gw[s] = acc;
+        } else if (gw) {
+            gw[s] = g[0];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int rsdf_weight_from_alpha_fwd(const int32_t *packed_info, const float *alphas, int64_t n_rays,
+                               float *weights, float *trans, void *stream)
+{
+    if (n_rays <= 0) return 0;
+    weight_fwd_kernel<0><<<rsdf_blocks(n_rays * 64, THREADS), THREADS, 0, (hipStream_t)stream>>>(
+        packed_info, alphas, n_rays, weights, trans, 0.f, 0.f, nullptr);
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_visibility_from_alpha(const int32_t *packed_info, const float *alphas, int64_t n_rays,
+                               float early_stop_eps, float alpha_thre, uint8_t *keep, void *stream)
+{
+    if (n_rays <= 0) return 0;
+    weight_fwd_kernel<1><<<rsdf_blocks(n_rays * 64, THREADS), THREADS, 0, (hipStream_t)stream>>>(
+        packed_info, alphas, n_rays, nullptr, nullptr, early_stop_eps, alpha_thre, keep);
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_weight_from_alpha_bwd(const int32_t *packed_info, const float *alphas,
+                               const float *weights, const float *trans,
+                               const float *grad_weights, int64_t n_rays, float *grad_alphas,
+                               void *stream)
+{
+    if (n_rays <= 0) return 0;
+    weight_bwd_kernel<<<rsdf_blocks(n_rays * 64, THREADS), THREADS, 0, (hipStream_t)stream>>>(
+        packed_info, alphas, weights, trans, grad_weights, n_rays, grad_alphas);
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_transmittance_from_alpha_bwd(const int32_t *packed_info, const float *alphas,
+                                      const float *trans, const float *grad_trans, int64_t n_rays,
+                                      float *grad_alphas, void *stream)
+{
+    if (n_rays <= 0) return 0;
+    trans_bwd_kernel<<<rsdf_blocks(n_rays * 64, THREADS), THREADS, 0, (hipStream_t)stream>>>(
+        packed_info, alphas, trans, grad_trans, n_rays, grad_alphas);
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_accumulate_fwd(const int32_t *packed_info, const float *weights, const float *values,
+                        int64_t n_rays, int D, float *out, void *stream)
+{
+    RSDF_CHECK_ARG(D >= 1, "accumulate_fwd: D must be >= 1");
+    RSDF_CHECK_ARG(values || D == 1, "accumulate_fwd: values == NULL requires D == 1");
+    if (n_rays <= 0) return 0;
+    const unsigned grid = rsdf_blocks(n_rays * 64, THREADS);
+    hipStream_t st = (hipStream_t)stream;
+    if (D <= 1) accumulate_fwd_kernel<1><<<grid, THREADS, 0, st>>>(packed_info, weights, values, n_rays, D, out);
+    else if (D <= 4) accumulate_fwd_kernel<4><<<grid, THREADS, 0, st>>>(packed_info, weights, values, n_rays, D, out);
+    else accumulate_fwd_kernel<8><<<grid, THREADS, 0, st>>>(packed_info, weights, values, n_rays, D, out);
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_accumulate_bwd(const int32_t *packed_info, const float *weights, const float *values,
+                        const float *grad_out, int64_t n_rays, int D, float *grad_weights,
+                        float *grad_values, void *stream)
+{
+    RSDF_CHECK_ARG(D >= 1, "accumulate_bwd: D must be >= 1");
+    if (n_rays <= 0) return 0;
+    accumulate_bwd_kernel<<<rsdf_blocks(n_rays * 64, THREADS), THREADS, 0, (hipStream_t)stream>>>(
+        packed_info, weights, values, grad_out, n_rays, D, grad_weights, grad_values);
+    RSDF_RETURN_LAUNCH();
+}
+
+}  // extern "C"

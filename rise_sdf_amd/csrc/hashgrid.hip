@@ -1,0 +1,258 @@
+// H1 / H1b / H2: multiresolution hash-grid encoding, forward gather and backward scatter.
+//
+// Replaces tcnn.Encoding(3, {otype: HashGrid}) as constructed at models/network_utils.py:47-50 and
+// called at :59 (and the progressive level mask of :58-68, fused here as n_active_levels).
+// tiny-cuda-nn is not part of the reference tree; the definition implemented here is the build's
+// own statement of the Instant-NGP encoding, identical to oracle/risesdf_oracle.c:
+//   pos = fmaf(scale_l, x, 0.5); cell = floor(pos); w = pos - cell
+//   index = x + y*res + z*res^2 if res^3 <= size_l else x ^ y*2654435761 ^ z*805459861; mod size_l
+//   out_f = sum_{corner 0..7} fmaf(w_c, table[index_c][f], .)   w_c = prod_d (bit_d ? w_d : 1-w_d)
+// With -ffp-contract=off and the explicit fmaf chain the forward is bit-identical to the oracle.
+//
+// Mapping: blockIdx.y = level, threads along samples.  A wavefront therefore gathers 64 neighbouring
+// samples of one level: at coarse levels (and for the 7 finite-difference taps of one sample, which
+// the caller lays out adjacently) most lanes hit the same few table lines and the texture-address
+// unit merges them; at the hashed fine levels every lane is a random 8-byte read and the kernel is
+// bound by L2 / Infinity-Cache line traffic (the whole 55 MiB table is MALL resident).
+#include "common.h"
+
+namespace {
+
+constexpr int THREADS = 256;
+
+struct LevelInfo {
+    float scale;
+    uint32_t res, offset, size;
+    bool dense;
+};
+
+__device__ __forceinline__ LevelInfo level_info(const rsdf_grid_meta &m, int l)
+{
+    LevelInfo li;
+    li.scale = m.scale[l];
+    li.res = m.res[l];
+    li.offset = m.offset[l];
+    li.size = m.size[l];
+    li.dense = (uint64_t)li.res * li.res * li.res <= (uint64_t)li.size;
+    return li;
+}
+
+__device__ __forceinline__ uint32_t grid_index(uint32_t x, uint32_t y, uint32_t z, const LevelInfo &li)
+{
+    uint32_t idx = li.dense ? (x + y * li.res + z * li.res * li.res)
+                            : ((x * 1u) ^ (y * 2654435761u) ^ (z * 805459861u));
+    return idx % li.size;
+}
+
+template <int F>
+struct Feat;
+template <>
+struct Feat<1> { using T = float; };
+template <>
+struct Feat<2> { using T = float2; };
+template <>
+struct Feat<4> { using T = float4; };
+
+template <int F>
+__global__ void __launch_bounds__(THREADS)
+hashgrid_fwd_kernel(const float *__restrict__ x, const float *__restrict__ table,
+                    const rsdf_grid_meta meta, int64_t n, int n_active, float *__restrict__ out,
+                    int ld_out, int col_off, int write_xyz, float xyz_scale, float xyz_offset)
+{
+    const int64_t s = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (s >= n) return;
+    const int l = blockIdx.y;
+    float *o = out + s * ld_out + col_off + l * F;
+    const float px = x[3 * s], py = x[3 * s + 1], pz = x[3 * s + 2];
+    if (write_xyz && l == 0) {
+        // CompositeEncoding include_xyz: x * xyz_scale + xyz_offset (separate mul, add)
+        float *ox = out + s * ld_out;
+        ox[0] = px * xyz_scale + xyz_offset;
+        ox[1] = py * xyz_scale + xyz_offset;
+        ox[2] = pz * xyz_scale + xyz_offset;
+    }
+    if (l >= n_active) {
+#pragma unroll
+        for (int f = 0; f < F; ++f) o[f] = 0.0f;
+        return;
+    }
+    const LevelInfo li = level_info(meta, l);
+    const float posx = fmaf(li.scale, px, 0.5f), posy = fmaf(li.scale, py, 0.5f),
+                posz = fmaf(li.scale, pz, 0.5f);
+    const float fx = floorf(posx), fy = floorf(posy), fz = floorf(posz);
+    const uint32_t cx = (uint32_t)(int32_t)fx, cy = (uint32_t)(int32_t)fy, cz = (uint32_t)(int32_t)fz;
+    const float wx = posx - fx, wy = posy - fy, wz = posz - fz;
+    using V = typename Feat<F>::T;
+    const V *tl = reinterpret_cast<const V *>(table) + li.offset;
+
+    V v[8];
+    float wc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        float w = 1.0f;
+        w *= (c & 1) ? wx : 1.0f - wx;
+        w *= (c & 2) ? wy : 1.0f - wy;
+        w *= (c & 4) ? wz : 1.0f - wz;
+        wc[c] = w;
+        const uint32_t idx = grid_index(cx + (c & 1), cy + ((c >> 1) & 1), cz + ((c >> 2) & 1), li);
+        v[c] = tl[idx];
+    }
+    float acc[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) acc[f] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float *vf = reinterpret_cast<const float *>(&v[c]);
+#pragma unroll
+        for (int f = 0; f < F; ++f) acc[f] = fmaf(wc[c], vf[f], acc[f]);
+    }
+#pragma unroll
+    for (int f = 0; f < F; ++f) o[f] = acc[f];
+}
+
+// Backward scatter.  RUNS: lanes whose neighbours target the same table entry (the FD taps of one
+// sample, or consecutive samples of a ray at a coarse level) first combine their contributions with
+// a segmented wave scan; only the last lane of each run issues the atomic.  Atomic traffic is the
+// bound for this kernel (MI355X float atomics: ~1.3 TB/s of added bytes when well shaped, an order
+// of magnitude less for 64 scattered rows per instruction), so every merged add is a direct win.
+template <int F, bool RUNS>
+__global__ void __launch_bounds__(THREADS)
+hashgrid_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dout,
+                    const rsdf_grid_meta meta, int64_t n, int ld_dout, int col_off,
+                    float *__restrict__ dtable)
+{
+    const int64_t s = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    const int l = blockIdx.y;
+    const bool valid = s < n;
+    if (!RUNS && !valid) return;
+    const LevelInfo li = level_info(meta, l);
+    float g[F];
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (valid) {
+        px = x[3 * s]; py = x[3 * s + 1]; pz = x[3 * s + 2];
+        const float *d = dout + s * ld_dout + col_off + l * F;
+#pragma unroll
+        for (int f = 0; f < F; ++f) g[f] = d[f];
+    } else {
+#pragma unroll
+        for (int f = 0; f < F; ++f) g[f] = 0.0f;
+    }
+    const float posx = fmaf(li.scale, px, 0.5f), posy = fmaf(li.scale, py, 0.5f),
+                posz = fmaf(li.scale, pz, 0.5f);
+    const float fx = floorf(posx), fy = floorf(posy), fz = floorf(posz);
+    const uint32_t cx = (uint32_t)(int32_t)fx, cy = (uint32_t)(int32_t)fy, cz = (uint32_t)(int32_t)fz;
+    const float wx = posx - fx, wy = posy - fy, wz = posz - fz;
+    float *tl = dtable + (size_t)li.offset * F;
+    const int lane = lane_id();
+
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        float w = 1.0f;
+        w *= (c & 1) ? wx : 1.0f - wx;
+        w *= (c & 2) ? wy : 1.0f - wy;
+        w *= (c & 4) ? wz : 1.0f - wz;
+        uint32_t idx = grid_index(cx + (c & 1), cy + ((c >> 1) & 1), cz + ((c >> 2) & 1), li);
+        float v[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) v[f] = w * g[f];
+        if (RUNS) {
+            if (!valid) idx = 0xffffffffu;  // never equals a real index (size <= 2^31)
+            const uint32_t prev = __shfl_up(idx, 1, 64);
+            int head = (lane == 0 || prev != idx) ? 1 : 0;
+            // segmented inclusive sum over runs of equal idx
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                float u[F];
+#pragma unroll
+                for (int f = 0; f < F; ++f) u[f] = __shfl_up(v[f], o, 64);
+                const int hu = __shfl_up(head, o, 64);
+                if (lane >= o && !head) {
+#pragma unroll
+                    for (int f = 0; f < F; ++f) v[f] += u[f];
+                    head = hu;
+                }
+            }
+            const uint32_t next = __shfl_down(idx, 1, 64);
+            const bool tail = (lane == 63 || next != idx);
+            if (valid && tail) {
+#pragma unroll
+                for (int f = 0; f < F; ++f) atomicAdd(tl + (size_t)idx * F + f, v[f]);
+            }
+        } else {
+#pragma unroll
+            for (int f = 0; f < F; ++f) atomicAdd(tl + (size_t)idx * F + f, v[f]);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t rsdf_grid_meta_init(rsdf_grid_meta *meta, int n_levels, int n_features, int log2_hashmap_size,
+                            int base_resolution, double per_level_scale)
+{
+    if (!meta || n_levels < 1 || n_levels > RSDF_MAX_LEVELS) return -1;
+    meta->n_levels = (uint32_t)n_levels;
+    meta->n_features = (uint32_t)n_features;
+    uint64_t off = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        // fp64 on the host, rounded once to fp32
+        const double sc = exp2((double)l * log2(per_level_scale)) * (double)base_resolution - 1.0;
+        const float scale = (float)sc;
+        const uint32_t res = (uint32_t)ceilf(scale) + 1u;
+        uint64_t size = (uint64_t)res * res * res;
+        size = (size + 7) / 8 * 8;
+        const uint64_t cap = 1ull << log2_hashmap_size;
+        if (size > cap) size = cap;
+        meta->scale[l] = scale;
+        meta->res[l] = res;
+        meta->offset[l] = (uint32_t)off;
+        meta->size[l] = (uint32_t)size;
+        off += size;
+    }
+    return (int64_t)off * n_features;
+}
+
+int rsdf_hashgrid_fwd(const float *x, const float *table, const rsdf_grid_meta *meta, int64_t n,
+                      int n_active_levels, float *out, int ld_out, int col_off, int write_xyz,
+                      float xyz_scale, float xyz_offset, void *stream)
+{
+    RSDF_CHECK_ARG(meta != nullptr, "hashgrid_fwd: meta is NULL");
+    const int L = (int)meta->n_levels, F = (int)meta->n_features;
+    RSDF_CHECK_ARG(F == 1 || F == 2 || F == 4, "hashgrid_fwd: n_features must be 1, 2 or 4");
+    RSDF_CHECK_ARG(ld_out >= col_off + L * F, "hashgrid_fwd: ld_out too small");
+    RSDF_CHECK_ARG(!write_xyz || col_off >= 3, "hashgrid_fwd: write_xyz needs col_off >= 3");
+    if (n <= 0) return 0;
+    if (n_active_levels < 0 || n_active_levels > L) n_active_levels = L;
+    dim3 grid(rsdf_blocks(n, THREADS), L);
+    hipStream_t st = (hipStream_t)stream;
+    switch (F) {
+    case 1: hashgrid_fwd_kernel<1><<<grid, THREADS, 0, st>>>(x, table, *meta, n, n_active_levels, out, ld_out, col_off, write_xyz, xyz_scale, xyz_offset); break;
+    case 2: hashgrid_fwd_kernel<2><<<grid, THREADS, 0, st>>>(x, table, *meta, n, n_active_levels, out, ld_out, col_off, write_xyz, xyz_scale, xyz_offset); break;
+    default: hashgrid_fwd_kernel<4><<<grid, THREADS, 0, st>>>(x, table, *meta, n, n_active_levels, out, ld_out, col_off, write_xyz, xyz_scale, xyz_offset); break;
+    }
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_hashgrid_bwd(const float *x, const float *dout, const rsdf_grid_meta *meta, int64_t n,
+                      int n_active_levels, int ld_dout, int col_off, float *dtable, void *stream)
+{
+    RSDF_CHECK_ARG(meta != nullptr, "hashgrid_bwd: meta is NULL");
+    const int L = (int)meta->n_levels, F = (int)meta->n_features;
+    RSDF_CHECK_ARG(F == 1 || F == 2 || F == 4, "hashgrid_bwd: n_features must be 1, 2 or 4");
+    RSDF_CHECK_ARG(ld_dout >= col_off + L * F, "hashgrid_bwd: ld_dout too small");
+    if (n <= 0) return 0;
+    if (n_active_levels < 0 || n_active_levels > L) n_active_levels = L;
+    if (n_active_levels == 0) return 0;
+    dim3 grid(rsdf_blocks(n, THREADS), n_active_levels);
+    hipStream_t st = (hipStream_t)stream;
+    switch (F) {
+    case 1: hashgrid_bwd_kernel<1, true><<<grid, THREADS, 0, st>>>(x, dout, *meta, n, ld_dout, col_off, dtable); break;
+    case 2: hashgrid_bwd_kernel<2, true><<<grid, THREADS, 0, st>>>(x, dout, *meta, n, ld_dout, col_off, dtable); break;
+    default: hashgrid_bwd_kernel<4, true><<<grid, THREADS, 0, st>>>(x, dout, *meta, n, ld_dout, col_off, dtable); break;
+    }
+    RSDF_RETURN_LAUNCH();
+}
+
+}  // extern "C"

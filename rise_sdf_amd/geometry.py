@@ -1,0 +1,139 @@
+"""Host-side mirror of the reference's ``models/geometry.py`` for the SDF field on the hot path.
+
+  contract_to_unisphere   models/geometry.py:17-29 (AABB branch)
+  VolumeSDF               models/geometry.py:193-327 (``volume-sdf``)
+
+Out of scope here: MarchingCubeHelper / isosurface (mesh export),
+VolumeDensity (background model), the analytic-gradient and curvature branches (config[4]).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .nerfacc import ContractionType
+from .network_utils import get_encoding, get_mlp, update_module_step
+from .registry import register
+
+
+def scale_anything(dat, inp_scale, tgt_scale):
+    """models/utils.py:109-114."""
+    if inp_scale is None:
+        inp_scale = [dat.min(), dat.max()]
+    dat = (dat - inp_scale[0]) / (inp_scale[1] - inp_scale[0])
+    return dat * (tgt_scale[1] - tgt_scale[0]) + tgt_scale[0]
+
+
+def contract_to_unisphere(x, radius, contraction_type):
+    if contraction_type == ContractionType.AABB:
+        return scale_anything(x, (-radius, radius), (0, 1))
+    raise NotImplementedError("only ContractionType.AABB is used by the shipped configs "
+                              "(models/split_mixed_occ.py:66)")
+
+
+class BaseModel(nn.Module):
+    """models/base.py:6-32."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.rank = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        self.setup()
+        if self.config.get("weights", None):
+            self.load_state_dict(torch.load(self.config.weights))
+
+    def setup(self):
+        raise NotImplementedError
+
+    def update_step(self, epoch, global_step, *args):
+        pass
+
+    def regularizations(self, out):
+        return {}
+
+    @torch.no_grad()
+    def export(self, export_config):
+        return {}
+
+
+@register("volume-sdf")
+class VolumeSDF(BaseModel):
+    def setup(self):
+        self.n_output_dims = self.config.feature_dim
+        self.radius = self.config.radius
+        self.contraction_type = ContractionType.AABB  # the reference assigns this from the model
+        self.encoding = get_encoding(3, self.config.xyz_encoding_config)
+        self.network = get_mlp(self.encoding.n_output_dims, self.n_output_dims,
+                               self.config.mlp_network_config)
+        self.grad_type = self.config.grad_type
+        if self.grad_type != "finite_difference":
+            raise NotImplementedError(
+                "grad_type='analytic' needs the hash grid's input gradient (SURVEY.md 8a H5, "
+                "config[4]); the RISE-SDF config uses finite_difference "
+                "(configs/split-mixed-occ-tensoir.yaml)")
+        for key in ("sdf_activation", "feature_activation"):
+            if key in self.config and str(self.config[key]).lower() not in ("none",):
+                raise NotImplementedError(f"{key} other than none")
+        self._finite_difference_eps = None
+        self.finite_difference_eps = self.config.get("finite_difference_eps", 1e-3)
+        if self.encoding.include_xyz and hasattr(self.network, "input_grad_cols"):
+            # positions are not differentiated under FD normals: skip d/d(xyz) in the first layer
+            self.network.input_grad_cols = (3, self.encoding.n_output_dims - 3)
+
+    # -- the fused entry the renderer uses: 7 taps per sample straight from the ray batch ---------
+    def field7_from_rays(self, rays_o, rays_d, ray_indices, t_starts, t_ends):
+        """-> out7 [7S, feature_dim]: rows 7i..7i+6 are the MLP outputs at sample i's centre and its
+        six clamped finite-difference taps (+x,-x,+y,-y,+z,-z)."""
+        x7 = ops.fd_points(rays_o, rays_d, ray_indices, t_starts, t_ends, self.radius,
+                           self._finite_difference_eps)
+        return self.network(self.encoding(x7.view(-1, 3)))
+
+    def forward(self, points, with_grad=True, with_feature=True, with_laplace=False):
+        """models/geometry.py:206-292.  points [..., 3] in world space."""
+        if with_laplace:
+            raise NotImplementedError("curvature term (SURVEY.md 8a H5) is config[4] scope")
+        shape = points.shape[:-1]
+        pts = points.reshape(-1, 3)
+        with torch.set_grad_enabled(self.training):
+            if with_grad:
+                eps = self._finite_difference_eps
+                x7 = ops.fd_taps(pts, self.radius, eps)
+                out7 = self.network(self.encoding(x7.view(-1, 3)))
+                sdf, grad = ops.fd_gradient(out7, eps)
+                feature = out7.view(-1, 7, self.n_output_dims)[:, 0]
+            else:
+                x = contract_to_unisphere(pts, self.radius, self.contraction_type)
+                feature = self.network(self.encoding(x))
+                sdf, grad = feature[..., 0], None
+        rv = [sdf.view(*shape)]
+        if with_grad:
+            rv.append(grad.view(*shape, 3))
+        if with_feature:
+            rv.append(feature.reshape(*shape, self.n_output_dims))
+        rv = [v if self.training else v.detach() for v in rv]
+        return rv[0] if len(rv) == 1 else rv
+
+    def forward_level(self, points):
+        x = contract_to_unisphere(points.reshape(-1, 3), self.radius, self.contraction_type)
+        return self.network(self.encoding(x))[..., 0].view(*points.shape[:-1])
+
+    def update_step(self, epoch, global_step):
+        update_module_step(self.encoding, epoch, global_step)
+        update_module_step(self.network, epoch, global_step)
+        if isinstance(self.finite_difference_eps, float):
+            self._finite_difference_eps = self.finite_difference_eps
+        elif self.finite_difference_eps == "progressive":
+            hg = self.config.xyz_encoding_config
+            assert hg.otype == "ProgressiveBandHashGrid", \
+                "finite_difference_eps='progressive' only works with ProgressiveBandHashGrid"
+            level = min(hg.start_level + max(global_step - hg.start_step, 0) // hg.update_steps,
+                        hg.n_levels)
+            grid_res = hg.base_resolution * hg.per_level_scale ** (level - 1)
+            self._finite_difference_eps = 2 * self.config.radius / grid_res
+        else:
+            raise ValueError(f"Unknown finite_difference_eps={self.finite_difference_eps}")
+
+    def regularizations(self, out):
+        return {"normal_orientation": out["normals_orientation_loss_map"].mean()} \
+            if "normals_orientation_loss_map" in out else {}

@@ -1,0 +1,281 @@
+"""Drop-in for the nerfacc surface RISE-SDF uses, backed by librisesdf_hip.so.
+
+Two API generations are mirrored, because the reference uses both:
+
+* nerfacc 0.5.3 (pip, ``requirements.txt:4``) -- the names the live models import
+  (``models/split_mixed_occ.py:12-15``, ``models/neus.py:11-17``, ``models/volrend.py:10-14``):
+  ``OccGridEstimator``, ``render_weight_from_alpha``, ``accumulate_along_rays``,
+  ``ray_aabb_intersect``.  Its traversal kernel is not vendored, so the sample placement follows
+  the vendored 0.3.5 marcher (the only one with source) behind the 0.5.3 signatures.
+* vendored nerfacc 0.3.5 (``lib/nerfacc``): ``ContractionType``, ``OccupancyGrid``,
+  ``ray_marching``, ``pack_info``, ``unpack_info``, ``render_visibility``,
+  ``render_transmittance_from_alpha``.
+
+Random numbers: the reference draws stratified jitter and cell jitter on device
+(``lib/nerfacc/ray_marching.py:157-158``, ``grid.py:184-186,215-217``).  Every entry point here
+accepts the random tensors explicitly (``stratified_u=``, ``cell_jitter=``) so that parity tests can
+feed identical numbers to the oracle; when omitted they are drawn with torch on the device.
+"""
+from __future__ import annotations
+
+from enum import Enum
+from typing import Callable, List, Optional, Union
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import (accumulate_along_rays, pack_info, ray_aabb_intersect,  # noqa: F401
+                  render_transmittance_from_alpha, render_visibility, render_weight_from_alpha,
+                  unpack_info)
+
+
+class ContractionType(Enum):
+    """lib/nerfacc/contraction.py:13-64 (only AABB is on the hot path)."""
+    AABB = 0
+    UN_BOUNDED_TANH = 1
+    UN_BOUNDED_SPHERE = 2
+
+
+def _meshgrid3d(res):
+    rx, ry, rz = [int(r) for r in res]
+    return torch.stack(torch.meshgrid(torch.arange(rx), torch.arange(ry), torch.arange(rz),
+                                      indexing="ij"), dim=-1)
+
+
+class OccupancyGrid(nn.Module):
+    """lib/nerfacc/grid.py:113-294.  State: ``occs`` fp32 [cells], ``_binary`` bool [rx,ry,rz]."""
+
+    NUM_DIM = 3
+
+    def __init__(self, roi_aabb, resolution: Union[int, List[int], torch.Tensor] = 128,
+                 contraction_type: ContractionType = ContractionType.AABB):
+        super().__init__()
+        if contraction_type != ContractionType.AABB:
+            raise NotImplementedError("only ContractionType.AABB is on the RISE-SDF hot path")
+        if isinstance(resolution, int):
+            resolution = [resolution] * 3
+        resolution = torch.as_tensor(resolution, dtype=torch.int32)
+        roi_aabb = torch.as_tensor(roi_aabb, dtype=torch.float32)
+        assert resolution.shape == (3,) and roi_aabb.shape == (6,)
+        self.num_cells = int(resolution.prod().item())
+        self._contraction_type = contraction_type
+        self.register_buffer("_roi_aabb", roi_aabb)
+        self.register_buffer("_binary", torch.zeros(resolution.tolist(), dtype=torch.bool))
+        self.register_buffer("resolution", resolution)
+        self.register_buffer("occs", torch.zeros(self.num_cells))
+        self.register_buffer("grid_coords", _meshgrid3d(resolution).reshape(self.num_cells, 3),
+                             persistent=False)
+        self.register_buffer("grid_indices", torch.arange(self.num_cells), persistent=False)
+
+    @property
+    def device(self):
+        return self._roi_aabb.device
+
+    @property
+    def roi_aabb(self):
+        return self._roi_aabb
+
+    @property
+    def binary(self):
+        return self._binary
+
+    @property
+    def contraction_type(self):
+        return self._contraction_type
+
+    @torch.no_grad()
+    def _sample_uniform_and_occupied_cells(self, n: int) -> torch.Tensor:
+        uniform = torch.randint(self.num_cells, (n,), device=self.device)
+        occupied = torch.nonzero(self._binary.flatten())[:, 0]
+        if n < len(occupied):
+            occupied = occupied[torch.randint(len(occupied), (n,), device=self.device)]
+        return torch.cat([uniform, occupied], dim=0)
+
+    @torch.no_grad()
+    def _update(self, step: int, occ_eval_fn: Callable, occ_thre: float = 0.01,
+                ema_decay: float = 0.95, warmup_steps: int = 256, indices=None, cell_jitter=None):
+        """EMA update (grid.py:196-239).  ``indices`` / ``cell_jitter`` may be supplied for
+        reproducible tests; otherwise they are drawn as the reference does."""
+        if indices is None:
+            indices = self.grid_indices if step < warmup_steps else \
+                self._sample_uniform_and_occupied_cells(self.num_cells // 4)
+        coords = self.grid_coords[indices]
+        if cell_jitter is None:
+            cell_jitter = torch.rand(coords.shape, dtype=torch.float32, device=coords.device)
+        x = (coords + cell_jitter) / self.resolution
+        # AABB inverse contraction: [0,1]^3 -> world (helpers_contraction.h:23-28)
+        roi = self._roi_aabb
+        x = x * (roi[3:] - roi[:3]) + roi[:3]
+        occ = occ_eval_fn(x).squeeze(-1)
+        self.occs[indices] = torch.maximum(self.occs[indices] * ema_decay, occ)
+        self._binary = (self.occs > torch.clamp(self.occs.mean(), max=occ_thre)).view(
+            self._binary.shape)
+
+    @torch.no_grad()
+    def every_n_step(self, step: int, occ_eval_fn: Callable, occ_thre: float = 1e-2,
+                     ema_decay: float = 0.95, warmup_steps: int = 256, n: int = 16):
+        if not self.training:
+            raise RuntimeError("every_n_step() is a training-time call; use _update() directly "
+                               "during inference")
+        if step % n == 0:
+            self._update(step, occ_eval_fn, occ_thre, ema_decay, warmup_steps)
+
+    @torch.no_grad()
+    def query_occ(self, samples: torch.Tensor) -> torch.Tensor:
+        return ops.query_occ(samples, self._roi_aabb, self._binary)
+
+
+@torch.no_grad()
+def ray_marching(rays_o, rays_d, t_min=None, t_max=None, scene_aabb=None, grid=None,
+                 sigma_fn=None, alpha_fn=None, early_stop_eps: float = 1e-4,
+                 alpha_thre: float = 0.0, near_plane=None, far_plane=None,
+                 render_step_size: float = 1e-3, stratified: bool = False,
+                 cone_angle: float = 0.0, stratified_u: Optional[torch.Tensor] = None,
+                 return_packed_info: bool = False):
+    """lib/nerfacc/ray_marching.py:13-222 (same argument meaning and error behaviour).
+
+    Returns (ray_indices int64 [S], t_starts [S,1], t_ends [S,1]) like the vendored 0.3.5 API.
+    """
+    if not rays_o.is_cuda:
+        raise NotImplementedError("Only support cuda inputs.")
+    if alpha_fn is not None and sigma_fn is not None:
+        raise ValueError("Only one of `alpha_fn` and `sigma_fn` should be provided.")
+    if t_min is None or t_max is None:
+        if scene_aabb is not None:
+            t_min, t_max = ray_aabb_intersect(rays_o, rays_d, scene_aabb)
+        else:
+            t_min = torch.zeros_like(rays_o[..., 0])
+            t_max = torch.ones_like(rays_o[..., 0]) * 1e10
+    if near_plane is not None:
+        t_min = torch.clamp(t_min, min=near_plane)
+    if far_plane is not None:
+        t_max = torch.clamp(t_max, max=far_plane)
+    if stratified or stratified_u is not None:
+        u = torch.rand_like(t_min) if stratified_u is None else stratified_u.to(t_min)
+        t_min = t_min + u * render_step_size
+    if grid is not None:
+        roi, binary = grid.roi_aabb, grid.binary
+    else:
+        roi = torch.tensor([-1e10, -1e10, -1e10, 1e10, 1e10, 1e10], dtype=torch.float32,
+                           device=rays_o.device)
+        binary = torch.ones([1, 1, 1], dtype=torch.bool, device=rays_o.device)
+    packed_info, ray_indices, t_starts, t_ends = ops.march(
+        rays_o, rays_d, t_min, t_max, roi, binary, render_step_size, cone_angle)
+
+    if sigma_fn is not None or alpha_fn is not None:
+        ts1, te1 = t_starts[:, None], t_ends[:, None]
+        if sigma_fn is not None:
+            sigmas = sigma_fn(ts1, te1, ray_indices)
+            assert sigmas.shape == ts1.shape, f"sigmas must have shape of (N, 1)! Got {sigmas.shape}"
+            alphas = 1.0 - torch.exp(-sigmas * (te1 - ts1))
+        else:
+            alphas = alpha_fn(ts1, te1, ray_indices)
+            assert alphas.shape == ts1.shape, f"alphas must have shape of (N, 1)! Got {alphas.shape}"
+        keep = render_visibility(alphas.reshape(-1), packed_info=packed_info,
+                                 early_stop_eps=early_stop_eps, alpha_thre=alpha_thre)
+        ray_indices, t_starts, t_ends = ops.compact_samples(keep, ray_indices, t_starts, t_ends)
+        packed_info = None
+    out = (ray_indices, t_starts[:, None], t_ends[:, None])
+    return out + (packed_info,) if return_packed_info else out
+
+
+class OccGridEstimator(nn.Module):
+    """nerfacc 0.5.3 estimator surface used at models/split_mixed_occ.py:83-86,126-131,200-208,
+    264-272 and models/neus.py:75-78,122,231-238.
+
+    Buffers keep the 0.5.3 names/shapes (one level): ``aabbs`` [1,6], ``occs`` [cells],
+    ``binaries`` bool [1,rx,ry,rz], ``resolution`` [3].
+    """
+
+    DIM = 3
+
+    def __init__(self, roi_aabb, resolution: Union[int, List[int], torch.Tensor] = 128,
+                 levels: int = 1):
+        super().__init__()
+        if levels != 1:
+            raise NotImplementedError("RISE-SDF uses a single-level grid")
+        if isinstance(resolution, int):
+            resolution = [resolution] * 3
+        resolution = torch.as_tensor(resolution, dtype=torch.int32)
+        roi_aabb = torch.as_tensor(roi_aabb, dtype=torch.float32)
+        self.levels = 1
+        self.cells_per_lvl = int(resolution.prod().item())
+        self.register_buffer("resolution", resolution)
+        self.register_buffer("aabbs", roi_aabb[None, :].clone())
+        self.register_buffer("occs", torch.zeros(self.cells_per_lvl))
+        self.register_buffer("binaries", torch.zeros([1] + resolution.tolist(), dtype=torch.bool))
+        self.register_buffer("grid_coords", _meshgrid3d(resolution).reshape(self.cells_per_lvl, 3),
+                             persistent=False)
+        self.register_buffer("grid_indices", torch.arange(self.cells_per_lvl), persistent=False)
+
+    @property
+    def device(self):
+        return self.aabbs.device
+
+    @torch.no_grad()
+    def sampling(self, rays_o, rays_d, sigma_fn=None, alpha_fn=None, near_plane: float = 0.0,
+                 far_plane: float = 1e10, t_min=None, t_max=None, render_step_size: float = 1e-3,
+                 early_stop_eps: float = 1e-4, alpha_thre: float = 0.0, stratified: bool = False,
+                 cone_angle: float = 0.0, stratified_u: Optional[torch.Tensor] = None):
+        """-> (ray_indices int64 [S], t_starts [S], t_ends [S]); ``alpha_fn(t_starts, t_ends,
+        ray_indices) -> [S]`` prunes by visibility exactly like the vendored marcher does."""
+        near = None if near_plane is None else float(near_plane)
+        far = None if far_plane is None else float(far_plane)
+        if t_min is None or t_max is None:
+            t_min, t_max = ray_aabb_intersect(rays_o, rays_d, self.aabbs[0])
+        if near is not None:
+            t_min = torch.clamp(t_min, min=near)
+        if far is not None:
+            t_max = torch.clamp(t_max, max=far)
+        if stratified or stratified_u is not None:
+            u = torch.rand_like(t_min) if stratified_u is None else stratified_u.to(t_min)
+            t_min = t_min + u * render_step_size
+        packed_info, ray_indices, t_starts, t_ends = ops.march(
+            rays_o, rays_d, t_min, t_max, self.aabbs[0], self.binaries[0], render_step_size,
+            cone_angle)
+        if (sigma_fn is not None or alpha_fn is not None) and ray_indices.numel() > 0:
+            if sigma_fn is not None:
+                sigmas = sigma_fn(t_starts, t_ends, ray_indices)
+                alphas = 1.0 - torch.exp(-sigmas * (t_ends - t_starts))
+            else:
+                alphas = alpha_fn(t_starts, t_ends, ray_indices)
+            assert alphas.shape == t_starts.shape, \
+                f"alphas must have shape of (N,)! Got {alphas.shape}"
+            keep = render_visibility(alphas, packed_info=packed_info,
+                                     early_stop_eps=early_stop_eps, alpha_thre=alpha_thre)
+            ray_indices, t_starts, t_ends = ops.compact_samples(keep, ray_indices, t_starts, t_ends)
+        return ray_indices, t_starts, t_ends
+
+    @torch.no_grad()
+    def _sample_uniform_and_occupied_cells(self, n: int):
+        uniform = torch.randint(self.cells_per_lvl, (n,), device=self.device)
+        occupied = torch.nonzero(self.binaries[0].flatten())[:, 0]
+        if n < len(occupied):
+            occupied = occupied[torch.randint(len(occupied), (n,), device=self.device)]
+        return torch.cat([uniform, occupied], dim=0)
+
+    @torch.no_grad()
+    def _update(self, step: int, occ_eval_fn: Callable, occ_thre: float = 0.01,
+                ema_decay: float = 0.95, warmup_steps: int = 256, indices=None, cell_jitter=None):
+        if indices is None:
+            indices = self.grid_indices if step < warmup_steps else \
+                self._sample_uniform_and_occupied_cells(self.cells_per_lvl // 4)
+        coords = self.grid_coords[indices]
+        if cell_jitter is None:
+            cell_jitter = torch.rand(coords.shape, dtype=torch.float32, device=coords.device)
+        x = (coords + cell_jitter) / self.resolution
+        roi = self.aabbs[0]
+        x = x * (roi[3:] - roi[:3]) + roi[:3]
+        occ = occ_eval_fn(x).squeeze(-1)
+        self.occs[indices] = torch.maximum(self.occs[indices] * ema_decay, occ)
+        thre = torch.clamp(self.occs.mean(), max=occ_thre)
+        self.binaries = (self.occs > thre).view(self.binaries.shape)
+
+    @torch.no_grad()
+    def update_every_n_steps(self, step: int, occ_eval_fn: Callable, occ_thre: float = 1e-2,
+                             ema_decay: float = 0.95, warmup_steps: int = 256, n: int = 16):
+        if not self.training:
+            raise RuntimeError("update_every_n_steps() is a training-time call")
+        if step % n == 0:
+            self._update(step, occ_eval_fn, occ_thre, ema_decay, warmup_steps)

@@ -1,0 +1,199 @@
+"""Host-side mirror of the reference's NeuS geometry renderer.
+
+  VarianceNetwork   models/neus.py:21-49 (== models/split_mixed_occ.py:21-56)
+  NeuSModel         models/neus.py:52-351 (``neus``), with the finite-difference-normal
+                    ``alpha_fn`` of models/split_mixed_occ.py:228-240 and the per-ray
+                    compositing of models/volrend.py:851-886.
+
+This is BASELINE.json config[1]: hash-grid SDF + NeuS alpha + transmittance compositing of
+opacity / depth / normals, forward and backward.  The radiance branch (``volume-radiance``
+texture, split-sum PBR) is the next row of SURVEY.md 8a and is attached through ``self.texture``
+when configured; the learned-background branch is disabled in both shipped configs and not built.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .geometry import BaseModel
+from .nerfacc import OccGridEstimator
+from .network_utils import update_module_step
+from .registry import make, register
+
+
+class VarianceNetwork(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.init_val = self.config.init_val
+        self.register_parameter("variance", nn.Parameter(torch.tensor(float(self.config.init_val))))
+        self.modulate = self.config.get("modulate", False)
+        if self.modulate:
+            self.mod_start_steps = self.config.mod_start_steps
+            self.reach_max_steps = self.config.reach_max_steps
+            self.max_inv_s = self.config.max_inv_s
+            self.do_mod = False
+
+    @property
+    def inv_s(self):
+        val = torch.exp(self.variance * 10.0)
+        if self.modulate and self.do_mod:
+            val = val.clamp_max(self.mod_val)
+        return val
+
+    def forward(self, x):
+        return torch.ones([len(x), 1], device=self.variance.device) * self.inv_s
+
+    def update_step(self, epoch, global_step):
+        if self.modulate:
+            self.do_mod = global_step > self.mod_start_steps
+            if not self.do_mod:
+                self.prev_inv_s = self.inv_s.item()
+            else:
+                self.mod_val = min((global_step / self.reach_max_steps)
+                                   * (self.max_inv_s - self.prev_inv_s) + self.prev_inv_s,
+                                   self.max_inv_s)
+
+
+def chunk_batch(func, chunk_size, move_to_cpu, *args, **kwargs):
+    """models/utils.py:14-51 for dict-returning functions."""
+    B = next(a.shape[0] for a in args if isinstance(a, torch.Tensor))
+    out = {}
+    for i in range(0, B, chunk_size):
+        chunk = func(*[a[i:i + chunk_size] if isinstance(a, torch.Tensor) else a for a in args],
+                     **kwargs)
+        for k, v in chunk.items():
+            v = v if torch.is_grad_enabled() else v.detach()
+            out.setdefault(k, []).append(v.cpu() if move_to_cpu else v)
+    return {k: torch.cat(v, dim=0) for k, v in out.items()}
+
+
+@register("neus")
+class NeuSModel(BaseModel):
+    def setup(self):
+        self.geometry = make(self.config.geometry.name, self.config.geometry)
+        tex = self.config.get("texture", None)
+        self.texture = make(tex.name, tex) if tex is not None else None
+        if self.config.get("learned_background", False):
+            raise NotImplementedError("learned_background is disabled in both shipped configs")
+        self.variance = VarianceNetwork(self.config.variance)
+        r = float(self.config.radius)
+        self.register_buffer("scene_aabb", torch.tensor([-r, -r, -r, r, r, r], dtype=torch.float32))
+        self.grid_prune = bool(self.config.get("grid_prune", True))
+        self.occupancy_grid = OccGridEstimator(roi_aabb=self.scene_aabb, resolution=128)
+        if not self.grid_prune:
+            # dense marching: every cell occupied (config[0]/[1] of BASELINE.json)
+            self.occupancy_grid.binaries.fill_(True)
+        self.randomized = self.config.get("randomized", True)
+        self.background_color = None
+        self.render_step_size = 1.732 * 2 * self.config.radius / self.config.num_samples_per_ray
+        self.cos_anneal_ratio = 1.0
+        # split_mixed_occ prunes candidates by visibility (alpha_fn inside sampling); neus.py does not
+        self.prune_by_visibility = bool(self.config.get("prune_by_visibility", False))
+
+    # ---- per-step schedule: models/neus.py:93-122 ------------------------------------------------
+    def update_step(self, epoch, global_step):
+        update_module_step(self.geometry, epoch, global_step)
+        if self.texture is not None:
+            update_module_step(self.texture, epoch, global_step)
+        update_module_step(self.variance, epoch, global_step)
+        cos_anneal_end = self.config.get("cos_anneal_end", 0)
+        self.cos_anneal_ratio = 1.0 if cos_anneal_end == 0 else min(1.0, global_step / cos_anneal_end)
+        if self.training and self.grid_prune:
+            self.occupancy_grid.update_every_n_steps(
+                step=global_step, occ_eval_fn=self.occ_eval_fn,
+                occ_thre=self.config.get("grid_prune_occ_thre", 0.01))
+
+    def occ_eval_fn(self, x):
+        """models/neus.py:101-111 (A2): alpha with cos == -1 and delta == render_step_size."""
+        sdf = self.geometry(x, with_grad=False, with_feature=False)
+        inv_s = self.variance(torch.zeros([1, 3]))[:, :1].clip(1e-6, 1e6)
+        inv_s = inv_s.expand(sdf.shape[0], 1)
+        next_sdf = sdf[..., None] - self.render_step_size * 0.5
+        prev_sdf = sdf[..., None] + self.render_step_size * 0.5
+        prev_cdf, next_cdf = torch.sigmoid(prev_sdf * inv_s), torch.sigmoid(next_sdf * inv_s)
+        return ((prev_cdf - next_cdf + 1e-5) / (prev_cdf + 1e-5)).view(-1, 1).clip(0.0, 1.0)
+
+    def get_alpha(self, sdf, normal, dirs, dists):
+        """models/neus.py:128-150."""
+        return ops.neus_alpha(sdf, normal, dirs, dists, self.variance.variance,
+                              self.cos_anneal_ratio)
+
+    # ---- one ray batch ------------------------------------------------------------------------------
+    def _alpha_fn(self, rays_o, rays_d):
+        def alpha_fn(t_starts, t_ends, ray_indices):
+            if ray_indices.numel() == 0:
+                return torch.zeros((0,), device=rays_o.device)
+            with torch.no_grad():
+                out7 = self.geometry.field7_from_rays(rays_o, rays_d, ray_indices, t_starts, t_ends)
+                return ops.neus_alpha_fd(out7, self.variance.variance, rays_d, ray_indices,
+                                         t_starts, t_ends, self.cos_anneal_ratio,
+                                         self.geometry._finite_difference_eps)[3]
+        return alpha_fn
+
+    def forward_(self, rays, stratified_u=None):
+        n_rays = rays.shape[0]
+        rays_o, rays_d = rays[:, 0:3].contiguous(), rays[:, 3:6].contiguous()
+        with torch.no_grad():
+            ray_indices, t_starts, t_ends = self.occupancy_grid.sampling(
+                rays_o, rays_d,
+                alpha_fn=self._alpha_fn(rays_o, rays_d) if self.prune_by_visibility else None,
+                render_step_size=self.render_step_size,
+                stratified=self.randomized and stratified_u is None, stratified_u=stratified_u,
+                cone_angle=0.0, alpha_thre=0.0)
+        return self.render_samples(rays_o, rays_d, ray_indices, t_starts, t_ends, n_rays)
+
+    def render_samples(self, rays_o, rays_d, ray_indices, t_starts, t_ends, n_rays):
+        """Field query -> NeuS alpha -> composite for a marched sample set (models/neus.py:240-317,
+        models/volrend.py:851-886)."""
+        dev = rays_o.device
+        S = ray_indices.numel()
+        packed = ops.pack_info(ray_indices, n_rays)
+        if S == 0:
+            alpha = torch.zeros((0,), device=dev)
+            sdf, sdf_grad = torch.zeros((0,), device=dev), torch.zeros((0, 3), device=dev)
+            normal = torch.zeros((0, 3), device=dev)
+        else:
+            out7 = self.geometry.field7_from_rays(rays_o, rays_d, ray_indices, t_starts, t_ends)
+            sdf, sdf_grad, normal, alpha = ops.neus_alpha_fd(
+                out7, self.variance.variance, rays_d, ray_indices, t_starts, t_ends,
+                self.cos_anneal_ratio, self.geometry._finite_difference_eps)
+        midpoints = (t_starts + t_ends)[..., None] / 2.0
+        weights, _ = ops.render_weight_from_alpha(alpha, packed_info=packed)
+        opacity = ops.accumulate_along_rays(weights, None, packed_info=packed)
+        depth = ops.accumulate_along_rays(weights, midpoints, packed_info=packed)
+        comp_normal = ops.accumulate_along_rays(weights, normal, packed_info=packed)
+        out = {
+            "comp_normal_raw": comp_normal,
+            "comp_normal": F.normalize(comp_normal, p=2, dim=-1),
+            "opacity": opacity,
+            "depth": depth,
+            "rays_valid": opacity > 0,
+            "num_samples": torch.as_tensor([S], dtype=torch.int32, device=dev),
+        }
+        if self.training:
+            out.update({"sdf_samples": sdf, "sdf_grad_samples": sdf_grad,
+                        "weights": weights.view(-1), "points": midpoints.view(-1),
+                        "intervals": (t_ends - t_starts).view(-1),
+                        "ray_indices": ray_indices.view(-1)})
+        return out
+
+    def forward(self, rays, **kw):
+        if self.training:
+            out = self.forward_(rays, **kw)
+        else:
+            out = chunk_batch(self.forward_, self.config.get("ray_chunk", 4096), False, rays)
+        return {**out, "inv_s": self.variance.inv_s}
+
+    def train(self, mode=True):
+        self.randomized = mode and self.config.get("randomized", True)
+        return super().train(mode=mode)
+
+    def eval(self):
+        self.randomized = False
+        return super().eval()
+
+    def regularizations(self, out):
+        return {}

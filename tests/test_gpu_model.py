@@ -1,0 +1,182 @@
+"""GPU parity of the assembled path (config[0]-sized): NeuSModel on HIP vs the oracle's
+neus_geometry_render on identical parameters, rays and jitter; plus the reference-generated
+VolumeSDF fixture through the HIP field.
+
+Tolerances.  The finite-difference normal divides an fp32 difference by eps (1e-2 here, 3.7e-4 at the
+finest level), so one ulp of SDF disagreement (different fp32 summation order in the MLP) is amplified
+by ~1/eps in the gradient: grad is compared at 2e-3 relative to |grad|~1 for eps=1e-2-class taps.
+Composited radiance-like outputs (opacity, depth, normals) are held to the north_star's 1e-4
+relative (plus 2e-5 absolute for near-zero pixels).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from helpers import camera_rays, rel_err, sphere_binary
+
+pytestmark = pytest.mark.gpu
+
+
+def model_config(n_levels=4, hidden=32, feat=13, grid_prune=False, base=16, log2_T=14):
+    from rise_sdf_amd import Config
+    return Config({
+        "name": "neus", "radius": 1.5, "num_samples_per_ray": 1024, "randomized": True,
+        "ray_chunk": 4096, "cos_anneal_end": 0, "learned_background": False, "grid_prune": grid_prune,
+        "variance": {"init_val": 0.3, "modulate": False},
+        "geometry": {
+            "name": "volume-sdf", "radius": 1.5, "feature_dim": feat, "grad_type": "finite_difference",
+            "finite_difference_eps": "progressive",
+            "xyz_encoding_config": {"otype": "ProgressiveBandHashGrid", "n_levels": n_levels,
+                                    "n_features_per_level": 2, "log2_hashmap_size": log2_T,
+                                    "base_resolution": base, "per_level_scale": 1.5,
+                                    "include_xyz": True, "start_level": n_levels, "start_step": 0,
+                                    "update_steps": 1},
+            "mlp_network_config": {"otype": "VanillaMLP", "activation": "ReLU",
+                                   "output_activation": "none", "n_neurons": hidden,
+                                   "n_hidden_layers": 2, "sphere_init": True,
+                                   "sphere_init_radius": 0.5, "weight_norm": True},
+        },
+    })
+
+
+def oracle_params(model):
+    """Pull the HIP model's parameters into the oracle's plain structures."""
+    geo = model.geometry
+    enc = geo.encoding.encoding.encoding  # CompositeEncoding -> ProgressiveBandHashGrid -> tcnn.Encoding
+    meta, n_params = oracle.grid_meta(enc.n_levels, enc.n_features_per_level, enc.log2_hashmap_size,
+                                      enc.base_resolution, enc.per_level_scale)
+    table = enc.params.detach().cpu().clone().requires_grad_(True)
+    mlp = []
+    for m in geo.network.layers:
+        if isinstance(m, torch.nn.Linear):
+            mlp.append({"g": m.weight_g.detach().cpu().clone().requires_grad_(True),
+                        "v": m.weight_v.detach().cpu().clone().requires_grad_(True),
+                        "b": m.bias.detach().cpu().clone().requires_grad_(True)})
+    var = model.variance.variance.detach().cpu().clone().requires_grad_(True)
+    return meta, table, mlp, var
+
+
+@pytest.mark.parametrize("prune", [False, True])
+def test_neus_render_matches_oracle(dev, prune):
+    import rise_sdf_amd as R
+    torch.manual_seed(0)
+    cfg = model_config(grid_prune=prune)
+    model = R.make("neus", cfg).to(dev)
+    model.train()
+    # larger table values than the 1e-4 init so that the hash features matter
+    with torch.no_grad():
+        model.geometry.encoding.encoding.encoding.params.mul_(300.0)
+        # sphere init zeroes the first layer's hash-feature columns (network_utils.py:138-141):
+        # un-zero them so that the table receives a gradient
+        l0 = model.geometry.network.layers[0]
+        l0.weight_v[:, 3:] = torch.randn_like(l0.weight_v[:, 3:]) * 0.3
+    if prune:
+        model.occupancy_grid.binaries = sphere_binary(128, 0.3, 0.75).to(dev)[None]
+    model.geometry.update_step(0, 0)
+    model.cos_anneal_ratio = 1.0
+    rays = camera_rays(24, 24, seed=1)
+    u = torch.rand(rays.shape[0], generator=torch.Generator().manual_seed(2))
+
+    out = model.forward_(rays.to(dev), stratified_u=u.to(dev))
+    ri, S = out["ray_indices"], int(out["num_samples"])
+    assert S > 5000
+
+    # oracle: same marcher policy on CPU must produce the identical sample set (bit exact)
+    roi = torch.tensor([-1.5, -1.5, -1.5, 1.5, 1.5, 1.5])
+    binary = model.occupancy_grid.binaries[0].cpu()
+    ri_o, ts_o, te_o = oracle.ray_marching(rays[:, :3].contiguous(), rays[:, 3:].contiguous(),
+                                           scene_aabb=roi, grid_roi=roi, grid_binary=binary,
+                                           near_plane=0.0, far_plane=1e10,
+                                           render_step_size=model.render_step_size, stratified_u=u)
+    assert torch.equal(ri.cpu(), ri_o), "sample set differs from the oracle marcher"
+    assert torch.equal(out["points"].cpu(), ((ts_o + te_o) / 2.0))
+
+    meta, table, mlp, var = oracle_params(model)
+    eps = model.geometry._finite_difference_eps
+    ref = oracle.neus_geometry_render(rays, ri_o, ts_o, te_o, table, meta, mlp, var, radius=1.5,
+                                      fd_eps=eps)
+    # fp32 radiance-like outputs: 1e-4 relative (north_star) + 2e-5 absolute
+    for k in ("opacity", "depth"):
+        assert torch.allclose(out[k].cpu(), ref[k], rtol=1e-4, atol=2e-5), k
+    assert torch.allclose(out["comp_normal_raw"].cpu(), ref["comp_normal"], rtol=1e-4, atol=1e-4)
+    assert rel_err(out["sdf_samples"], ref["sdf"]) < 1e-5
+    assert rel_err(out["sdf_grad_samples"], ref["sdf_grad"]) < 2e-3  # FD amplification, see docstring
+
+    # backward: same scalar loss on both sides
+    g = torch.Generator().manual_seed(3)
+    go, gd, gn = torch.randn(ref["opacity"].shape, generator=g), torch.randn(ref["depth"].shape, generator=g), \
+        torch.randn(ref["comp_normal"].shape, generator=g)
+    loss_o = (ref["opacity"] * go).sum() + (ref["depth"] * gd).sum() + (ref["comp_normal"] * gn).sum() \
+        + 0.1 * ((ref["sdf_grad"].norm(dim=-1) - 1) ** 2).mean()
+    loss_o.backward()
+    loss_g = (out["opacity"] * go.to(dev)).sum() + (out["depth"] * gd.to(dev)).sum() \
+        + (out["comp_normal_raw"] * gn.to(dev)).sum() \
+        + 0.1 * ((out["sdf_grad_samples"].norm(dim=-1) - 1) ** 2).mean()
+    loss_g.backward()
+    assert abs(float(loss_g) - float(loss_o)) < 1e-3 * abs(float(loss_o)) + 1e-3
+    enc = model.geometry.encoding.encoding.encoding
+    gt = enc.params.grad.cpu()
+    # hash-table gradient: fp32 atomics + FD amplification: 2e-2 of the largest row
+    assert float((gt - table.grad).abs().max()) < 2e-2 * float(table.grad.abs().max())
+    cos = torch.nn.functional.cosine_similarity(gt[None], table.grad[None]).item()
+    assert cos > 0.9999
+    lin = [m for m in model.geometry.network.layers if isinstance(m, torch.nn.Linear)]
+    for m, p in zip(lin, mlp):
+        for name, ref_t in (("weight_v", p["v"]), ("weight_g", p["g"]), ("bias", p["b"])):
+            got = getattr(m, name).grad.cpu()
+            assert rel_err(got, ref_t.grad) < 2e-2, name
+            c = torch.nn.functional.cosine_similarity(got.reshape(1, -1), ref_t.grad.reshape(1, -1)).item()
+            assert c > 0.9999, (name, c)
+    assert abs(float(model.variance.variance.grad) - float(var.grad)) < 2e-2 * abs(float(var.grad)) + 1e-4
+
+
+def test_volume_sdf_reference_fixture(dev, golden_dir):
+    """VolumeSDF.forward of the REFERENCE (geometry.py:206-244; fixture volume_sdf_fd.npz, where the
+    reference's tcnn.Encoding was the oracle hash grid) vs the HIP VolumeSDF with the same weights."""
+    import rise_sdf_amd as R
+    z = np.load(os.path.join(golden_dir, "volume_sdf_fd.npz"))
+    cfg = R.Config({
+        "name": "volume-sdf", "radius": 1.5, "feature_dim": 13, "grad_type": "finite_difference",
+        "finite_difference_eps": "progressive",
+        "xyz_encoding_config": {"otype": "ProgressiveBandHashGrid", "n_levels": 6,
+                                "n_features_per_level": 2, "log2_hashmap_size": 12,
+                                "base_resolution": 8, "per_level_scale": 1.5, "include_xyz": True,
+                                "start_level": 3, "start_step": 0, "update_steps": 100},
+        "mlp_network_config": {"otype": "VanillaMLP", "activation": "ReLU", "output_activation": "none",
+                               "n_neurons": 32, "n_hidden_layers": 2, "sphere_init": True,
+                               "sphere_init_radius": 0.5, "weight_norm": True},
+    })
+    geo = R.make("volume-sdf", cfg).to(dev)
+    sd = {k[3:].replace("encoding_encoding_encoding_params", "encoding.encoding.encoding.params"): v
+          for k, v in z.items() if k.startswith("p__")}
+    with torch.no_grad():
+        geo.encoding.encoding.encoding.params.copy_(torch.tensor(sd["encoding.encoding.encoding.params"]))
+        for i in (0, 2, 4):
+            for n in ("bias", "weight_g", "weight_v"):
+                getattr(geo.network.layers[i], n).copy_(torch.tensor(z[f"p__network_layers_{i}_{n}"]))
+    geo.train()
+    pts = torch.tensor(z["pts"], device=dev)
+    for step in z["steps"]:
+        geo.update_step(0, int(step))
+        assert abs(geo._finite_difference_eps - float(z[f"s{step}_eps"])) < 1e-12
+        assert geo.encoding.encoding.current_level == int(z[f"s{step}_level"])
+        for p in geo.parameters():
+            p.grad = None
+        sdf, grad, feat = geo(pts, with_grad=True, with_feature=True)
+        assert rel_err(sdf, torch.tensor(z[f"s{step}_sdf"])) < 1e-5
+        assert rel_err(feat, torch.tensor(z[f"s{step}_feature"])) < 1e-5
+        eps = float(z[f"s{step}_eps"])
+        assert rel_err(grad, torch.tensor(z[f"s{step}_grad"])) < 1e-5 / eps * 2  # FD amplification
+        gs, gg = torch.tensor(z[f"s{step}_gs"], device=dev), torch.tensor(z[f"s{step}_gg"], device=dev)
+        loss = (sdf * gs).sum() + (grad * gg).sum() + (feat ** 2).sum() * 0.1
+        loss.backward()
+        got = geo.encoding.encoding.encoding.params.grad.cpu()
+        ref = torch.tensor(z[f"s{step}_grad__encoding_encoding_encoding_params"])
+        assert float((got - ref).abs().max()) < 2e-3 * float(ref.abs().max()) + 1e-6
+        for i in (0, 2, 4):
+            for n in ("bias", "weight_g", "weight_v"):
+                ref = torch.tensor(z[f"s{step}_grad__network_layers_{i}_{n}"])
+                assert rel_err(getattr(geo.network.layers[i], n).grad, ref) < 5e-3, (step, i, n)

@@ -1,0 +1,350 @@
+"""GPU parity: every C-ABI op against the CPU oracle on identical seeded inputs.
+
+Bars (BASELINE.json north_star): integer / index results bit-exact; fp32 values within 1e-4
+relative; hash-table gradients (fp32 atomics, order-dependent) within 1e-3 rel of the fp64-accumulated
+oracle.  Tolerances are written at each assert.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from helpers import camera_rays, rel_err, small_field, sphere_binary
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from rise_sdf_amd import ops as o
+    return o
+
+
+def test_library_is_loaded(dev):
+    from rise_sdf_amd import _lib
+    assert _lib.lib().rsdf_abi_version() == 1
+
+
+# ---- M1 -------------------------------------------------------------------------------------------
+def test_ray_aabb_bit_exact(dev, ops):
+    rays = camera_rays(64, 64, seed=3)
+    g = torch.Generator().manual_seed(0)
+    extra_o = (torch.rand(500, 3, generator=g) * 2 - 1) * 3
+    extra_d = torch.nn.functional.normalize(torch.randn(500, 3, generator=g), dim=-1)
+    extra_d[:20, 0] = 0.0  # axis-parallel rays: division by zero must behave like the reference
+    extra_d[20:40, 1] = 0.0
+    o = torch.cat([rays[:, :3], extra_o])
+    d = torch.cat([rays[:, 3:], extra_d])
+    aabb = torch.tensor([-1.5, -1.5, -1.5, 1.5, 1.5, 1.5])
+    tn, tf = oracle.ray_aabb_intersect(o, d, aabb)
+    gn, gf = ops.ray_aabb_intersect(o.to(dev), d.to(dev), aabb.to(dev))
+    assert torch.equal(gn.cpu(), tn) and torch.equal(gf.cpu(), tf)
+
+
+# ---- M3 / M4 --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("res,step", [(32, 0.00507421875), (128, 0.00507421875), (16, 0.05)])
+def test_marcher_bit_exact(dev, ops, res, step):
+    rays = camera_rays(48, 48, seed=res)
+    o, d = rays[:, :3].contiguous(), rays[:, 3:].contiguous()
+    roi = torch.tensor([-1.5, -1.5, -1.5, 1.5, 1.5, 1.5])
+    binary = sphere_binary(res)
+    tn, tf = oracle.ray_aabb_intersect(o, d, roi)
+    u = torch.rand(o.shape[0], generator=torch.Generator().manual_seed(2))
+    tn = tn + u * step
+    pk, ri, ts, te = oracle.ray_marching_packed(o, d, tn, tf, roi, binary, step)
+    gpk, gri, gts, gte = ops.march(o.to(dev), d.to(dev), tn.to(dev), tf.to(dev), roi.to(dev),
+                                   binary.to(dev), step)
+    assert ri.numel() > 1000
+    assert torch.equal(gpk.cpu(), pk), "packed_info differs"
+    assert torch.equal(gri.cpu(), ri), "ray_indices differ"
+    assert torch.equal(gts.cpu(), ts) and torch.equal(gte.cpu(), te), "sample intervals differ"
+
+
+def test_marcher_dense_and_empty(dev, ops):
+    rays = camera_rays(16, 16, seed=9)
+    o, d = rays[:, :3].contiguous(), rays[:, 3:].contiguous()
+    roi = torch.tensor([-1e10] * 3 + [1e10] * 3)
+    ones = torch.ones(1, 1, 1, dtype=torch.bool)
+    aabb = torch.tensor([-1.5, -1.5, -1.5, 1.5, 1.5, 1.5])
+    tn, tf = oracle.ray_aabb_intersect(o, d, aabb)
+    pk, ri, ts, te = oracle.ray_marching_packed(o, d, tn, tf, roi, ones, 0.00507421875)
+    gpk, gri, gts, gte = ops.march(o.to(dev), d.to(dev), tn.to(dev), tf.to(dev), roi.to(dev),
+                                   ones.to(dev), 0.00507421875)
+    assert torch.equal(gpk.cpu(), pk) and torch.equal(gts.cpu(), ts) and torch.equal(gte.cpu(), te)
+    # all-empty grid -> zero samples, shapes still valid
+    zeros = torch.zeros(8, 8, 8, dtype=torch.bool)
+    gpk, gri, gts, gte = ops.march(o.to(dev), d.to(dev), tn.to(dev), tf.to(dev), aabb.to(dev),
+                                   zeros.to(dev), 0.01)
+    assert gri.numel() == 0 and int(gpk[:, 1].sum()) == 0
+
+
+def test_query_occ_cells_bit_exact(dev, ops):
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand(20000, 3, generator=g) * 2 - 1) * 1.6
+    # points exactly on cell faces and on the box boundary
+    grid = torch.linspace(-1.5, 1.5, 33)
+    x[:33, 0] = grid
+    x[33:66, 1] = grid
+    roi = torch.tensor([-1.5, -1.5, -1.5, 1.5, 1.5, 1.5])
+    binary = sphere_binary(32)
+    occ, cell = oracle.query_occ(x, roi, binary)
+    gocc, gcell = ops.query_occ(x.to(dev), roi.to(dev), binary.to(dev), return_cell=True)
+    assert torch.equal(gcell.cpu(), cell) and torch.equal(gocc.cpu(), occ)
+
+
+# ---- M5 / M6 --------------------------------------------------------------------------------------
+def _ragged(n_rays, max_len, seed, empty_every=5):
+    g = torch.Generator().manual_seed(seed)
+    counts = torch.randint(0, max_len, (n_rays,), generator=g)
+    counts[::empty_every] = 0
+    ri = torch.repeat_interleave(torch.arange(n_rays), counts)
+    return counts, ri
+
+
+def test_pack_unpack_compact(dev, ops):
+    counts, ri = _ragged(1000, 300, 1)
+    pk = oracle.pack_info(ri, 1000)
+    gpk = ops.pack_info(ri.to(dev), 1000)
+    assert torch.equal(gpk.cpu(), pk)
+    assert torch.equal(ops.unpack_info(gpk, ri.numel()).cpu(), ri)
+    g = torch.Generator().manual_seed(2)
+    keep = torch.rand(ri.numel(), generator=g) > 0.4
+    ts = torch.rand(ri.numel(), generator=g)
+    te = ts + 0.1
+    r2, s2, e2 = ops.compact_samples(keep.to(dev), ri.to(dev), ts.to(dev), te.to(dev))
+    assert torch.equal(r2.cpu(), ri[keep]) and torch.equal(s2.cpu(), ts[keep]) and torch.equal(e2.cpu(), te[keep])
+    # nothing kept / empty input
+    r3, _, _ = ops.compact_samples(torch.zeros_like(keep).to(dev), ri.to(dev), ts.to(dev), te.to(dev))
+    assert r3.numel() == 0
+    assert ops.pack_info(torch.zeros(0, dtype=torch.int64, device=dev), 7).cpu().tolist() == [[0, 0]] * 7
+
+
+# ---- C1 / C2 --------------------------------------------------------------------------------------
+def test_compositing_kat(dev, ops):
+    """Docstring known answers: lib/nerfacc/vol_rendering.py:303-307, 430-434, 493-500."""
+    a = torch.tensor([0.4, 0.8, 0.1, 0.8, 0.1, 0.0, 0.9], device=dev)
+    ri = torch.tensor([0, 0, 0, 1, 1, 2, 2], device=dev)
+    w, t = ops.render_weight_from_alpha(a, ray_indices=ri, n_rays=3)
+    assert torch.allclose(t.cpu(), torch.tensor([1.0, 0.6, 0.12, 1.0, 0.2, 1.0, 1.0]), atol=1e-6)
+    assert torch.allclose(w.cpu(), torch.tensor([0.4, 0.48, 0.012, 0.8, 0.02, 0.0, 0.9]), atol=1e-6)
+    vis = ops.render_visibility(a, ray_indices=ri, n_rays=3, early_stop_eps=0.3, alpha_thre=0.2)
+    assert vis.cpu().tolist() == [True, True, False, True, False, False, True]
+
+
+@pytest.mark.parametrize("max_len", [40, 700])
+def test_weights_fwd_bwd(dev, ops, max_len):
+    counts, ri = _ragged(300, max_len, 3)
+    g = torch.Generator().manual_seed(4)
+    a = torch.rand(ri.numel(), generator=g) * 0.3
+    a[::97] = 1.0  # fully opaque samples: the 1e-10 clamp path of the backward
+    a[5::131] = 0.0
+    gw = torch.randn(ri.numel(), generator=g)
+    a_o = a.clone().requires_grad_(True)
+    w_o, t_o = oracle.render_weight_from_alpha(a_o, ray_indices=ri, n_rays=300)
+    (w_o * gw).sum().backward()
+    a_g = a.to(dev).requires_grad_(True)
+    w_g, t_g = ops.render_weight_from_alpha(a_g, ray_indices=ri.to(dev), n_rays=300)
+    (w_g * gw.to(dev)).sum().backward()
+    # fp32, scan order differs from the serial reference loop: 1e-5 relative
+    assert rel_err(w_g, w_o) < 1e-5 and rel_err(t_g, t_o) < 1e-5
+    # At alpha == 1 exactly the reference computes (gw*T - sum_{k>=j} gw_k w_k) / 1e-10 where the
+    # numerator is 0 in exact arithmetic: its value there is fp32 rounding residue x 1e10 (the serial
+    # oracle shows +-600), i.e. noise, so those entries are only required to be finite.
+    mask = a < 1.0
+    assert torch.allclose(a_g.grad.cpu()[mask], a_o.grad[mask], rtol=1e-4, atol=1e-5)
+    assert bool(torch.isfinite(a_g.grad).all())
+    # transmittance backward
+    a_o2 = a.clone().requires_grad_(True)
+    (oracle.render_transmittance_from_alpha(a_o2, ray_indices=ri, n_rays=300) * gw).sum().backward()
+    a_g2 = a.to(dev).requires_grad_(True)
+    (ops.render_transmittance_from_alpha(a_g2, ray_indices=ri.to(dev), n_rays=300) * gw.to(dev)).sum().backward()
+    assert torch.allclose(a_g2.grad.cpu()[mask], a_o2.grad[mask], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("D", [1, 3, 7, 24])
+def test_accumulate_fwd_bwd(dev, ops, D):
+    counts, ri = _ragged(200, 150, 6)
+    g = torch.Generator().manual_seed(7)
+    w = torch.rand(ri.numel(), generator=g)
+    v = torch.randn(ri.numel(), D, generator=g)
+    go = torch.randn(200, D, generator=g)
+    w_o, v_o = w.clone().requires_grad_(True), v.clone().requires_grad_(True)
+    out_o = oracle.accumulate_along_rays(w_o, v_o, ray_indices=ri, n_rays=200)
+    (out_o * go).sum().backward()
+    w_g, v_g = w.to(dev).requires_grad_(True), v.to(dev).requires_grad_(True)
+    out_g = ops.accumulate_along_rays(w_g, v_g, ray_indices=ri.to(dev), n_rays=200)
+    (out_g * go.to(dev)).sum().backward()
+    assert torch.allclose(out_g.cpu(), out_o, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(w_g.grad.cpu(), w_o.grad, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(v_g.grad.cpu(), v_o.grad, rtol=1e-6, atol=1e-6)
+    if D == 1:  # values=None path
+        o2 = ops.accumulate_along_rays(w.to(dev), None, ray_indices=ri.to(dev), n_rays=200)
+        assert torch.allclose(o2.cpu(), oracle.accumulate_along_rays(w, None, ray_indices=ri, n_rays=200),
+                              rtol=1e-5, atol=1e-5)
+
+
+# ---- H1 -------------------------------------------------------------------------------------------
+GRIDS = [dict(n_levels=4, n_features=2, log2_hashmap_size=14, base_resolution=16, per_level_scale=1.5),
+         dict(n_levels=16, n_features=2, log2_hashmap_size=19, base_resolution=32,
+              per_level_scale=1.447269237440378)]
+
+
+@pytest.mark.parametrize("gi", [0, 1])
+def test_hashgrid_forward_bit_exact(dev, ops, gi):
+    from rise_sdf_amd import _lib
+    cfg = GRIDS[gi]
+    meta_o, n_params = oracle.grid_meta(**cfg)
+    meta_g, n_params_g = _lib.make_grid_meta(**cfg)
+    assert n_params == n_params_g
+    g = torch.Generator().manual_seed(11)
+    table = (torch.rand(n_params, generator=g) * 2 - 1) * 1e-4
+    x = torch.rand(5000, 3, generator=g)
+    x[:4] = torch.tensor([[0, 0, 0], [1, 1, 1], [0.5, 0.5, 0.5], [1, 0, 1]])  # box corners / faces
+    ref = oracle.hashgrid_encode(x, table, meta_o)
+    out = ops.hashgrid_encode(x.to(dev), table.to(dev), meta_g)
+    assert torch.equal(out.cpu(), ref), f"max abs diff {float((out.cpu() - ref).abs().max())}"
+    # progressive mask + include_xyz (H2)
+    ref2 = oracle.composite_encoding(x, table, meta_o, n_active_levels=3)
+    out2 = ops.hashgrid_encode(x.to(dev), table.to(dev), meta_g, n_active_levels=3, include_xyz=True)
+    assert torch.equal(out2.cpu(), ref2)
+
+
+@pytest.mark.parametrize("gi", [0, 1])
+def test_hashgrid_backward(dev, ops, gi):
+    from rise_sdf_amd import _lib
+    cfg = GRIDS[gi]
+    meta_o, n_params = oracle.grid_meta(**cfg)
+    meta_g, _ = _lib.make_grid_meta(**cfg)
+    g = torch.Generator().manual_seed(12)
+    table = (torch.rand(n_params, generator=g) * 2 - 1) * 1e-4
+    # ray-like coherent points (runs of equal cells) plus random ones
+    t = torch.linspace(0, 1, 3000)[:, None]
+    x = torch.cat([0.1 + 0.8 * t * torch.tensor([[0.7, 0.5, 0.3]]), torch.rand(2000, 3, generator=g)])
+    gout = torch.randn(x.shape[0], meta_o.n_levels * 2, generator=g)
+    t_o = table.clone().requires_grad_(True)
+    (oracle.hashgrid_encode(x, t_o, meta_o) * gout).sum().backward()
+    t_g = table.to(dev).requires_grad_(True)
+    (ops.hashgrid_encode(x.to(dev), t_g, meta_g) * gout.to(dev)).sum().backward()
+    # fp32 atomics vs fp64-accumulated oracle: 1e-3 relative to the largest row, 1e-7 absolute
+    scale = float(t_o.grad.abs().max())
+    assert float((t_g.grad.cpu() - t_o.grad).abs().max()) < 1e-5 * scale + 1e-7
+    assert int((t_g.grad.cpu() != 0).sum()) == int((t_o.grad != 0).sum())
+
+
+# ---- H3 -------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("K,N,act", [(35, 64, "softplus100"), (64, 64, "softplus100"), (64, 48, "none"),
+                                     (35, 128, "softplus100"), (128, 128, "relu"), (128, 48, "none"),
+                                     (11, 32, "softplus100"), (32, 13, "none"), (84, 128, "relu"),
+                                     (128, 3, "sigmoid")])
+def test_linear_fwd_bwd(dev, ops, K, N, act):
+    g = torch.Generator().manual_seed(K * 1000 + N)
+    n = 1000  # not a multiple of the 128-row tile
+    x = torch.randn(n, K, generator=g) * 0.5
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g) * 0.1
+    gy = torch.randn(n, N, generator=g)
+
+    def ref_act(z):
+        return {"softplus100": lambda t: torch.nn.functional.softplus(t, beta=100),
+                "relu": torch.relu, "none": lambda t: t, "sigmoid": torch.sigmoid}[act](z)
+
+    xo, wo, bo = [t.clone().double().requires_grad_(True) for t in (x, w, b)]
+    yo = ref_act(torch.nn.functional.linear(xo, wo, bo))
+    (yo * gy.double()).sum().backward()
+    xg, wg, bg = [t.to(dev).requires_grad_(True) for t in (x, w, b)]
+    yg = ops.linear(xg, wg, bg, act=act)
+    (yg * gy.to(dev)).sum().backward()
+    # fp32 MFMA (exact fp32 fma chain) vs an fp64 reference: 1e-5 relative to the tensor's scale
+    assert rel_err(yg, yo) < 1e-5
+    assert rel_err(xg.grad, xo.grad) < 1e-5
+    assert rel_err(wg.grad, wo.grad) < 2e-5  # fp32 atomics over 1000 rows
+    assert rel_err(bg.grad, bo.grad) < 2e-5
+
+
+def test_linear_column_window(dev, ops):
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(300, 35, generator=g)
+    w = torch.randn(64, 35, generator=g) / 6
+    b = torch.zeros(64)
+    gy = torch.randn(300, 64, generator=g)
+    xo = x.clone().requires_grad_(True)
+    (torch.nn.functional.softplus(torch.nn.functional.linear(xo, w, b), beta=100) * gy).sum().backward()
+    xg = x.to(dev).requires_grad_(True)
+    (ops.linear(xg, w.to(dev), b.to(dev), act="softplus100", dx_cols=(3, 32)) * gy.to(dev)).sum().backward()
+    assert torch.allclose(xg.grad.cpu()[:, 3:], xo.grad[:, 3:], rtol=1e-4, atol=1e-5)
+    assert float(xg.grad[:, :3].abs().max()) == 0.0
+
+
+def test_weight_norm(dev, ops):
+    g = torch.Generator().manual_seed(2)
+    v = torch.randn(64, 35, generator=g)
+    gg = torch.rand(64, 1, generator=g) + 0.5
+    dw = torch.randn(64, 35, generator=g)
+    vo, go = v.clone().requires_grad_(True), gg.clone().requires_grad_(True)
+    (oracle.weight_norm_effective(go, vo) * dw).sum().backward()
+    vg, g2 = v.to(dev).requires_grad_(True), gg.to(dev).requires_grad_(True)
+    w = ops.weight_norm(g2, vg)
+    (w * dw.to(dev)).sum().backward()
+    assert torch.allclose(w.cpu(), oracle.weight_norm_effective(gg, v), rtol=1e-6, atol=1e-7)
+    assert torch.allclose(vg.grad.cpu(), vo.grad, rtol=1e-4, atol=1e-6)
+    assert torch.allclose(g2.grad.cpu(), go.grad, rtol=1e-4, atol=1e-6)
+
+
+# ---- golden fixtures through the HIP path ------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_vanilla_mlp_golden(dev, ops, golden_dir, tag):
+    """Reference VanillaMLP outputs/grads (tests/golden/make_golden.py) vs the HIP layers."""
+    import os
+    z = np.load(os.path.join(golden_dir, f"vanilla_mlp_{tag}.npz"))
+    x = torch.tensor(z["x"], device=dev, requires_grad=True)
+    P = {}
+    for i in (0, 2, 4):
+        P[i] = [torch.tensor(z[f"layers_{i}_{n}"], device=dev, requires_grad=True)
+                for n in ("weight_g", "weight_v", "bias")]
+    h = x
+    for i in (0, 2, 4):
+        gpar, v, b = P[i]
+        h = ops.linear(h, ops.weight_norm(gpar, v), b, act="none" if i == 4 else "softplus100")
+    assert rel_err(h, torch.tensor(z["y"])) < 1e-5
+    (h * torch.tensor(z["gy"], device=dev)).sum().backward()
+    assert rel_err(x.grad, torch.tensor(z["gx"])) < 1e-4
+    for i in (0, 2, 4):
+        for t, n in zip(P[i], ("weight_g", "weight_v", "bias")):
+            assert rel_err(t.grad, torch.tensor(z[f"grad_layers_{i}_{n}"])) < 1e-4, (i, n)
+
+
+def test_get_alpha_golden(dev, ops, golden_dir):
+    import os
+    z = np.load(os.path.join(golden_dir, "get_alpha.npz"))
+    sdf, nrm, dirs, dists = [torch.tensor(z[k], device=dev) for k in ("sdf", "normal", "dirs", "dists")]
+    for vi, v in enumerate(z["variances"]):
+        for ci, c in enumerate(z["cos_anneal"]):
+            a = ops.neus_alpha(sdf, nrm, dirs, dists, torch.tensor(float(v), device=dev), float(c))
+            ref = torch.tensor(z[f"alpha_v{vi}_c{ci}"])
+            # 1e-4 relative (north_star) on values that are not clipped to 0
+            assert torch.allclose(a.cpu(), ref, rtol=1e-4, atol=1e-6), (vi, ci)
+
+
+# ---- A1 / H4 backward --------------------------------------------------------------------------------
+def test_neus_alpha_backward(dev, ops):
+    g = torch.Generator().manual_seed(8)
+    S = 4000
+    sdf = torch.randn(S, generator=g) * 0.05
+    nrm = torch.nn.functional.normalize(torch.randn(S, 3, generator=g), dim=-1)
+    dirs = torch.nn.functional.normalize(torch.randn(S, 3, generator=g), dim=-1)
+    dists = torch.full((S, 1), 0.005) * (1 + torch.rand(S, 1, generator=g))
+    ga = torch.randn(S, generator=g)
+    for car in (1.0, 0.3):
+        var = torch.tensor(0.3)
+        so, no, vo = sdf.clone().requires_grad_(True), nrm.clone().requires_grad_(True), var.clone().requires_grad_(True)
+        a_o = oracle.get_alpha(so, no, dirs, dists, oracle.inv_s_from_variance(vo), car)
+        (a_o * ga).sum().backward()
+        sg, ng, vg = sdf.to(dev).requires_grad_(True), nrm.to(dev).requires_grad_(True), var.to(dev).requires_grad_(True)
+        a_g = ops.neus_alpha(sg, ng, dirs.to(dev), dists.to(dev), vg, car)
+        (a_g * ga.to(dev)).sum().backward()
+        assert torch.allclose(a_g.cpu(), a_o, rtol=1e-4, atol=1e-6)
+        assert rel_err(sg.grad, so.grad) < 1e-4
+        assert rel_err(ng.grad, no.grad) < 1e-4
+        assert abs(float(vg.grad) - float(vo.grad)) < 1e-3 * abs(float(vo.grad)) + 1e-4
