@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""bench.py -- ray-marched SDF samples/sec (fwd+bwd), BASELINE.json config[1].
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload ("c1"): one synthetic 800x800 pinhole view per rank (640,000 rays) of the
+[-1.5,1.5]^3 box, dense marching (no occupancy pruning, 1024 samples per box diagonal), L=16 F=2
+T=2^19 base-32 hash grid (14,533,536 fp32 params, U(-1e-4,1e-4)), 2x64 weight-normalised
+Softplus(100) SDF MLP -> 48 features with the reference's sphere initialisation, finite-difference
+normals (7 field evaluations per sample, eps = 3/8192), NeuS alpha, per-ray transmittance
+compositing of opacity / depth / normals, and the full backward to every parameter.
+
+A "step" is one pass over the rank's 640,000 rays in chunks of --chunk rays (forward + backward per
+chunk, gradients accumulated), followed for N>1 by the RCCL mean-all-reduce of all gradients -- the
+reference's DDP step (launch.py:84-97).  Weak scaling: every rank renders its own view.
+A "sample" is one marched interval that is field-queried and composited (the reference's
+``num_samples``, models/split_mixed_occ.py:349-351).
+
+Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for the roofline definitions.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: fp32 matrix peak
+
+
+def c1_config(hidden=64, n_levels=16, log2_T=19, base=32, feat=48):
+    from rise_sdf_amd import Config
+    return Config({
+        "name": "neus", "radius": 1.5, "num_samples_per_ray": 1024, "randomized": True,
+        "ray_chunk": 4096, "cos_anneal_end": 0, "learned_background": False, "grid_prune": False,
+        "variance": {"init_val": 0.3, "modulate": False},
+        "geometry": {
+            "name": "volume-sdf", "radius": 1.5, "feature_dim": feat,
+            "grad_type": "finite_difference", "finite_difference_eps": "progressive",
+            "xyz_encoding_config": {
+                "otype": "ProgressiveBandHashGrid", "n_levels": n_levels, "n_features_per_level": 2,
+                "log2_hashmap_size": log2_T, "base_resolution": base,
+                "per_level_scale": 1.447269237440378, "include_xyz": True,
+                "start_level": n_levels, "start_step": 0, "update_steps": 1},
+            "mlp_network_config": {
+                "otype": "VanillaMLP", "activation": "ReLU", "output_activation": "none",
+                "n_neurons": hidden, "n_hidden_layers": 2, "sphere_init": True,
+                "sphere_init_radius": 0.5, "weight_norm": True},
+        },
+    })
+
+
+def build_model(dev, args):
+    import rise_sdf_amd as R
+    torch.manual_seed(0)
+    model = R.make("neus", c1_config(hidden=args.hidden)).to(dev)
+    enc = model.geometry.encoding.encoding.encoding
+    gen = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        enc.params.copy_(((torch.rand(enc.params.numel(), generator=gen) * 2 - 1) * 1e-4).to(dev))
+        # The reference's sphere init zeroes the first layer's hash-feature columns; give them small
+        # random values so that table gradients are non-trivial (same work either way).
+        l0 = model.geometry.network.layers[0]
+        l0.weight_v[:, 3:] = (torch.randn(l0.weight_v[:, 3:].shape, generator=gen) * 0.05).to(dev)
+    model.train()
+    model.geometry.update_step(0, 0)
+    model.cos_anneal_ratio = 1.0
+    return model
+
+
+def run_step(model, rays, jitter, cot, chunk):
+    """One pass over all rays: fwd+bwd per chunk.  Returns the number of samples."""
+    n = rays.shape[0]
+    total = 0
+    for s in range(0, n, chunk):
+        e = min(s + chunk, n)
+        out = model.forward_(rays[s:e], stratified_u=jitter[s:e])
+        total += int(out["ray_indices"].numel())
+        torch.autograd.backward([out["opacity"], out["depth"], out["comp_normal_raw"]],
+                                [cot[0][s:e], cot[1][s:e], cot[2][s:e]])
+    return total
+
+
+def cpu_baseline(model, rays_cpu, jitter_cpu, n_rays_sample):
+    """The oracle (a port of the reference path) timed on this host's cores, fwd+bwd, on a bounded
+    slice of the same view: the middle rows of the image."""
+    import oracle
+    from test_gpu_model import oracle_params
+    torch.set_num_threads(os.cpu_count() or 1)
+    n = rays_cpu.shape[0]
+    s0 = (n // 2 // 800) * 800
+    rays = rays_cpu[s0:s0 + n_rays_sample].contiguous()
+    u = jitter_cpu[s0:s0 + n_rays_sample].contiguous()
+    meta, table, mlp, var = oracle_params(model)
+    roi = torch.tensor([-1.5, -1.5, -1.5, 1.5, 1.5, 1.5])
+    t0 = time.perf_counter()
+    ri, ts, te = oracle.ray_marching(rays[:, :3].contiguous(), rays[:, 3:].contiguous(), scene_aabb=roi,
+                                     near_plane=0.0, far_plane=1e10,
+                                     render_step_size=model.render_step_size, stratified_u=u)
+    ref = oracle.neus_geometry_render(rays, ri, ts, te, table, meta, mlp, var, radius=1.5,
+                                      fd_eps=model.geometry._finite_difference_eps)
+    (ref["opacity"].sum() + ref["depth"].sum() + ref["comp_normal"].sum()).backward()
+    dt = time.perf_counter() - t0
+    S = int(ri.numel())
+    return {"value": S / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_rays_sample} rays of the same 800x800 view (pixels {s0}..{s0 + n_rays_sample - 1}), "
+                      f"{S} samples, fwd+bwd {dt:.1f} s; hash grid in scalar C (1 thread), MLP in torch "
+                      f"({torch.get_num_threads()} threads)"}
+
+
+def roofline_from(summary, steps):
+    """Pick the entry point with the most device time and price it against its roofline."""
+    def cost(name, a):
+        # scalar args in ABI order (see include/risesdf_hip.h)
+        if name == "rsdf_hashgrid_fwd":      # n, n_active, ld_out, col_off, write_xyz, scale, offset
+            n, L = a[0], 16
+            return "hbm", n * (L * 8 * 2 * 4 + 12 + L * 2 * 4)
+        if name == "rsdf_hashgrid_bwd":      # n, n_active, ld, col_off
+            n, L = a[0], 16
+            return "hbm", n * (L * 8 * 2 * 4 + 12 + L * 2 * 4)
+        if name == "rsdf_linear_fwd":        # ldx, n, K, N, act, ldy
+            return "mfma", 2.0 * a[1] * a[2] * a[3]
+        if name == "rsdf_linear_bwd_input":  # lddy, n, K, N, act, k0, Kout, lddx
+            return "mfma", 2.0 * a[1] * a[3] * a[6]
+        if name == "rsdf_linear_bwd_weight":  # lddz, ldx, n, K, N
+            return "mfma", 2.0 * a[2] * a[3] * a[4]
+        return None, 0.0
+
+    best = max(summary.items(), key=lambda kv: kv[1]["ms"])
+    name, d = best
+    bound, _ = cost(name, d["args"][0])
+    breakdown = {k: {"calls": v["calls"], "ms_per_step": round(v["ms"] / steps, 3)}
+                 for k, v in sorted(summary.items(), key=lambda kv: -kv[1]["ms"])}
+    if bound is None:
+        return {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                "traffic": None, "kernel": name}, breakdown
+    work = sum(cost(name, a)[1] for a in d["args"])
+    secs = d["ms"] / 1e3
+    if bound == "hbm":
+        ach, peak, unit = work / secs / 1e9, HBM_PEAK_GBS, "GB/s"
+    else:
+        ach, peak, unit = work / secs / 1e12, MFMA_F32_PEAK_TF, "TFLOP/s"
+    return {"bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
+            "frac": round(ach / peak, 4), "traffic": None, "kernel": name,
+            "avg_launch_ms": round(d["ms"] / d["calls"], 4), "launches": d["calls"]}, breakdown
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--chunk", type=int, default=8192, help="rays per forward/backward chunk")
+    ap.add_argument("--width", type=int, default=800)
+    ap.add_argument("--height", type=int, default=800)
+    ap.add_argument("--hidden", type=int, default=64)
+    ap.add_argument("--cpu-rays", type=int, default=512, help="rays in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    from rise_sdf_amd import dist as rdist
+    rank, local, world = rdist.init_from_env()
+    assert world == args.gpus or world == 1 and args.gpus == 1, \
+        f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the product path)"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    from helpers import camera_rays
+    from rise_sdf_amd import _lib
+    model = build_model(dev, args)
+    rays_cpu = camera_rays(args.width, args.height, seed=rdist.rank_seed(0, rank))
+    n_rays = rays_cpu.shape[0]
+    g = torch.Generator().manual_seed(2 + rank)
+    jitter_cpu = torch.rand(n_rays, generator=g)
+    rays, jitter = rays_cpu.to(dev), jitter_cpu.to(dev)
+    cot = [torch.randn(n_rays, 1, generator=g).to(dev), torch.randn(n_rays, 1, generator=g).to(dev),
+           torch.randn(n_rays, 3, generator=g).to(dev)]
+    buckets = rdist.GradBuckets(model.parameters())
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        S = run_step(model, rays, jitter, cot, args.chunk)
+        buckets.all_reduce_mean(world)
+        return S
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    timer = None
+    if rank == 0 and not args.no_kernel_timing:
+        timer = _lib.KernelTimer()
+        _lib.set_timer(timer)
+    barrier()
+    t0 = time.perf_counter()
+    samples = 0
+    for _ in range(args.steps):
+        samples += step()
+    barrier()
+    dt = time.perf_counter() - t0
+    _lib.set_timer(None)
+
+    tt = torch.tensor([dt, float(samples)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = tt[0:1].clone()
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        ssum = tt[1:2].clone()
+        torch.distributed.all_reduce(ssum, op=torch.distributed.ReduceOp.SUM)
+        dt, samples = float(tmax), float(ssum)
+
+    if rank == 0:
+        roof, breakdown = (None, None)
+        if timer is not None:
+            roof, breakdown = roofline_from(timer.summary(), args.steps)
+        cpu = None
+        if args.cpu_rays > 0:
+            cpu = cpu_baseline(model, rays_cpu, jitter_cpu, args.cpu_rays)
+        line = {
+            "metric": "ray-marched SDF samples/sec (fwd+bwd), 800x800 rays, L=16 hashgrid",
+            "value": samples / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "c1: toaster-sized 800x800 view per GPU, dense marching, L=16 T=2^19 "
+                                   f"hash grid + 2x{args.hidden} SDF MLP (7 FD taps), NeuS alpha + composite, fwd+bwd",
+                       "rays_per_gpu": n_rays, "chunk_rays": args.chunk,
+                       "samples_per_step": samples / args.steps,
+                       "field_evals_per_sec": 7 * samples / dt, "parallelism": f"ray-parallel x{world}"},
+            "roofline": roof, "cpu_baseline": cpu, "kernel_breakdown": breakdown,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

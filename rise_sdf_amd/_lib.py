@@ -101,7 +101,59 @@ def lib():
         if l.rsdf_abi_version() != 1:
             raise RiseSdfHipError("librisesdf_hip.so ABI version mismatch")
         _lib = l
+    if _timer is not None:
+        return _TimedLib(_lib, _timer)
     return _lib
+
+
+class KernelTimer:
+    """Optional per-entry-point timing with HIP events on the launch stream (torch's current
+    stream, which is where every rsdf_* call enqueues).  Used by bench.py for the roofline object;
+    never active unless installed with ``set_timer``."""
+
+    def __init__(self):
+        self.records = []  # (name, scalar args, start event, end event)
+
+    def summary(self):
+        """name -> dict(calls, ms, args=[...]) after a device synchronise."""
+        out = {}
+        for name, args, e0, e1 in self.records:
+            d = out.setdefault(name, {"calls": 0, "ms": 0.0, "args": []})
+            d["calls"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["args"].append(args)
+        return out
+
+
+class _TimedLib:
+    def __init__(self, l, timer):
+        self._l, self._t = l, timer
+
+    def __getattr__(self, name):
+        fn = getattr(self._l, name)
+        if not name.startswith("rsdf_") or name in ("rsdf_last_error", "rsdf_abi_version",
+                                                   "rsdf_scan_scratch_bytes", "rsdf_grid_meta_init"):
+            return fn
+        timer = self._t
+
+        def timed(*args):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*args)
+            e1.record()
+            timer.records.append((name, tuple(a for a in args if isinstance(a, (int, float))), e0, e1))
+            return rc
+        return timed
+
+
+_timer = None
+
+
+def set_timer(timer):
+    """Install (or with None remove) a KernelTimer."""
+    global _timer
+    _timer = timer
 
 
 def check(rc: int, what: str):
