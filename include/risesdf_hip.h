@@ -143,6 +143,18 @@ int rsdf_hashgrid_bwd(const float *x, const float *dout, const rsdf_grid_meta *m
                       int64_t n, int n_active_levels, int ld_dout, int col_off, float *dtable,
                       void *stream);
 
+/* Backward specialised for the finite-difference stencil (models/geometry.py:229-244): x7 [n,7,3] are
+ * the centre + six taps of each sample (rsdf_fd_points layout), dout [7n, ld_dout].  The taps'
+ * contributions are merged in registers, binned by table slice through LDS and reduced in LDS: no
+ * per-corner global atomics.  eps_unit = eps / (2*radius) sizes the queues (results do not depend
+ * on it).  scratch >= rsdf_hashgrid_bwd_fd7_scratch_bytes(...) bytes.  n_features must be 2. */
+int64_t rsdf_hashgrid_bwd_fd7_scratch_bytes(const rsdf_grid_meta *meta /*host*/, int64_t n_samples,
+                                            int n_active_levels, float eps_unit);
+int rsdf_hashgrid_bwd_fd7(const float *x7, const float *dout, const rsdf_grid_meta *meta /*host*/,
+                          int64_t n_samples, int n_active_levels, int ld_dout, int col_off,
+                          float eps_unit, float *dtable, void *scratch, int64_t scratch_bytes,
+                          void *stream);
+
 /* ---- H3: VanillaMLP layers on the fp32 matrix cores --------------------------------------------
  * replaces nn.Linear (+ activation) inside VanillaMLP (models/network_utils.py:109-157).
  * y[n,N] = act(x[n,K] @ w[N,K]^T + b[N]); row strides ldx / ldy.  K,N <= 128. */

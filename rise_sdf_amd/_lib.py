@@ -58,6 +58,8 @@ _SIGNATURES = {
     "rsdf_grid_meta_init": [ctypes.POINTER(GridMeta), _I, _I, _I, _I, ctypes.c_double],
     "rsdf_hashgrid_fwd": [_P, _P, ctypes.POINTER(GridMeta), _L, _I, _P, _I, _I, _I, _F, _F, _P],
     "rsdf_hashgrid_bwd": [_P, _P, ctypes.POINTER(GridMeta), _L, _I, _I, _I, _P, _P],
+    "rsdf_hashgrid_bwd_fd7_scratch_bytes": [ctypes.POINTER(GridMeta), _L, _I, _F],
+    "rsdf_hashgrid_bwd_fd7": [_P, _P, ctypes.POINTER(GridMeta), _L, _I, _I, _I, _F, _P, _P, _L, _P],
     "rsdf_linear_fwd": [_P, _I, _P, _P, _L, _I, _I, _I, _P, _I, _P],
     "rsdf_linear_bwd_input": [_P, _P, _I, _P, _L, _I, _I, _I, _I, _I, _P, _P, _I, _P],
     "rsdf_linear_bwd_weight": [_P, _I, _P, _I, _L, _I, _I, _P, _P, _P],
@@ -73,7 +75,8 @@ _SIGNATURES = {
     "rsdf_neus_alpha_bwd": [_P, _P, _P, _P, _P, _F, _L, _P, _P, _P, _P, _P],
 }
 _RESTYPES = {"rsdf_last_error": ctypes.c_char_p, "rsdf_scan_scratch_bytes": ctypes.c_int64,
-             "rsdf_grid_meta_init": ctypes.c_int64}
+             "rsdf_grid_meta_init": ctypes.c_int64,
+             "rsdf_hashgrid_bwd_fd7_scratch_bytes": ctypes.c_int64}
 
 EXPORTS = tuple(_SIGNATURES)
 
@@ -132,7 +135,8 @@ class _TimedLib:
     def __getattr__(self, name):
         fn = getattr(self._l, name)
         if not name.startswith("rsdf_") or name in ("rsdf_last_error", "rsdf_abi_version",
-                                                   "rsdf_scan_scratch_bytes", "rsdf_grid_meta_init"):
+                                                   "rsdf_scan_scratch_bytes", "rsdf_grid_meta_init",
+                                                   "rsdf_hashgrid_bwd_fd7_scratch_bytes"):
             return fn
         timer = self._t
 

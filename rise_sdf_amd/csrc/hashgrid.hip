@@ -15,34 +15,11 @@
 // unit merges them; at the hashed fine levels every lane is a random 8-byte read and the kernel is
 // bound by L2 / Infinity-Cache line traffic (the whole 55 MiB table is MALL resident).
 #include "common.h"
+#include "hashgrid_common.h"
 
 namespace {
 
 constexpr int THREADS = 256;
-
-struct LevelInfo {
-    float scale;
-    uint32_t res, offset, size;
-    bool dense;
-};
-
-__device__ __forceinline__ LevelInfo level_info(const rsdf_grid_meta &m, int l)
-{
-    LevelInfo li;
-    li.scale = m.scale[l];
-    li.res = m.res[l];
-    li.offset = m.offset[l];
-    li.size = m.size[l];
-    li.dense = (uint64_t)li.res * li.res * li.res <= (uint64_t)li.size;
-    return li;
-}
-
-__device__ __forceinline__ uint32_t grid_index(uint32_t x, uint32_t y, uint32_t z, const LevelInfo &li)
-{
-    uint32_t idx = li.dense ? (x + y * li.res + z * li.res * li.res)
-                            : ((x * 1u) ^ (y * 2654435761u) ^ (z * 805459861u));
-    return idx % li.size;
-}
 
 template <int F>
 struct Feat;
@@ -119,10 +96,10 @@ template <int F, bool RUNS>
 __global__ void __launch_bounds__(THREADS)
 hashgrid_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dout,
                     const rsdf_grid_meta meta, int64_t n, int ld_dout, int col_off,
-                    float *__restrict__ dtable)
+                    float *__restrict__ dtable, int level_begin)
 {
     const int64_t s = (int64_t)blockIdx.x * THREADS + threadIdx.x;
-    const int l = blockIdx.y;
+    const int l = level_begin + blockIdx.y;
     const bool valid = s < n;
     if (!RUNS && !valid) return;
     const LevelInfo li = level_info(meta, l);
@@ -235,6 +212,23 @@ int rsdf_hashgrid_fwd(const float *x, const float *table, const rsdf_grid_meta *
     RSDF_RETURN_LAUNCH();
 }
 
+// internal (not in the public header): atomic scatter for a contiguous range of levels; used by
+// hashgrid_fd7.hip for the dense coarse levels
+int rsdf_internal_hashgrid_bwd_levels(const float *x, const float *dout, const rsdf_grid_meta *meta,
+                                      int64_t n, int ld_dout, int col_off, float *dtable,
+                                      int level_begin, int level_count, void *stream)
+{
+    if (n <= 0 || level_count <= 0) return 0;
+    dim3 grid(rsdf_blocks(n, THREADS), level_count);
+    hipStream_t st = (hipStream_t)stream;
+    switch ((int)meta->n_features) {
+    case 1: hashgrid_bwd_kernel<1, true><<<grid, THREADS, 0, st>>>(x, dout, *meta, n, ld_dout, col_off, dtable, level_begin); break;
+    case 2: hashgrid_bwd_kernel<2, true><<<grid, THREADS, 0, st>>>(x, dout, *meta, n, ld_dout, col_off, dtable, level_begin); break;
+    default: hashgrid_bwd_kernel<4, true><<<grid, THREADS, 0, st>>>(x, dout, *meta, n, ld_dout, col_off, dtable, level_begin); break;
+    }
+    RSDF_RETURN_LAUNCH();
+}
+
 int rsdf_hashgrid_bwd(const float *x, const float *dout, const rsdf_grid_meta *meta, int64_t n,
                       int n_active_levels, int ld_dout, int col_off, float *dtable, void *stream)
 {
@@ -248,9 +242,9 @@ int rsdf_hashgrid_bwd(const float *x, const float *dout, const rsdf_grid_meta *m
     dim3 grid(rsdf_blocks(n, THREADS), n_active_levels);
     hipStream_t st = (hipStream_t)stream;
     switch (F) {
-    case 1: hashgrid_bwd_kernel<1, true><<<grid, THREADS, 0, st>>>(x, dout, *meta, n, ld_dout, col_off, dtable); break;
-    case 2: hashgrid_bwd_kernel<2, true><<<grid, THREADS, 0, st>>>(x, dout, *meta, n, ld_dout, col_off, dtable); break;
-    default: hashgrid_bwd_kernel<4, true><<<grid, THREADS, 0, st>>>(x, dout, *meta, n, ld_dout, col_off, dtable); break;
+    case 1: hashgrid_bwd_kernel<1, true><<<grid, THREADS, 0, st>>>(x, dout, *meta, n, ld_dout, col_off, dtable, 0); break;
+    case 2: hashgrid_bwd_kernel<2, true><<<grid, THREADS, 0, st>>>(x, dout, *meta, n, ld_dout, col_off, dtable, 0); break;
+    default: hashgrid_bwd_kernel<4, true><<<grid, THREADS, 0, st>>>(x, dout, *meta, n, ld_dout, col_off, dtable, 0); break;
     }
     RSDF_RETURN_LAUNCH();
 }

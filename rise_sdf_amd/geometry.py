@@ -87,7 +87,10 @@ class VolumeSDF(BaseModel):
         six clamped finite-difference taps (+x,-x,+y,-y,+z,-z)."""
         x7 = ops.fd_points(rays_o, rays_d, ray_indices, t_starts, t_ends, self.radius,
                            self._finite_difference_eps)
-        return self.network(self.encoding(x7.view(-1, 3)))
+        return self.network(self.encoding(x7.view(-1, 3), fd7_eps_unit=self._eps_unit()))
+
+    def _eps_unit(self):
+        return self._finite_difference_eps / (2.0 * self.radius)
 
     def forward(self, points, with_grad=True, with_feature=True, with_laplace=False):
         """models/geometry.py:206-292.  points [..., 3] in world space."""
@@ -99,7 +102,7 @@ class VolumeSDF(BaseModel):
             if with_grad:
                 eps = self._finite_difference_eps
                 x7 = ops.fd_taps(pts, self.radius, eps)
-                out7 = self.network(self.encoding(x7.view(-1, 3)))
+                out7 = self.network(self.encoding(x7.view(-1, 3), fd7_eps_unit=self._eps_unit()))
                 sdf, grad = ops.fd_gradient(out7, eps)
                 feature = out7.view(-1, 7, self.n_output_dims)[:, 0]
             else:

@@ -73,12 +73,13 @@ class CompositeEncoding(nn.Module):
             return e, None
         return None, None
 
-    def forward(self, x, *args):
+    def forward(self, x, *args, fd7_eps_unit=None):
         grid, n_active = self._hash()
         if grid is not None:
             return ops.hashgrid_encode(x.reshape(-1, 3), grid.params, grid.meta,
                                        n_active_levels=n_active, include_xyz=self.include_xyz,
-                                       xyz_scale=self.xyz_scale, xyz_offset=self.xyz_offset)
+                                       xyz_scale=self.xyz_scale, xyz_offset=self.xyz_offset,
+                                       fd7_eps_unit=fd7_eps_unit)
         enc = self.encoding(x, *args)
         if not self.include_xyz:
             return enc

@@ -274,7 +274,7 @@ def accumulate_along_rays(weights, values=None, *, ray_indices=None, packed_info
 # ------------------------------------------------------------------------------------------------
 class _HashGrid(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, table, meta, n_active, include_xyz, xyz_scale, xyz_offset):
+    def forward(ctx, x, table, meta, n_active, include_xyz, xyz_scale, xyz_offset, fd7_eps_unit):
         xf, tb = _f32c(x), table.detach()
         require_device(xf, tb)
         assert tb.dtype == torch.float32 and tb.is_contiguous()
@@ -287,6 +287,7 @@ class _HashGrid(torch.autograd.Function):
                                       float(xyz_offset), stream_ptr()), "hashgrid_fwd")
         ctx.save_for_backward(xf)
         ctx.meta, ctx.n_active, ctx.col, ctx.n_params = meta, n_active, col, tb.numel()
+        ctx.fd7 = fd7_eps_unit
         return out
 
     @staticmethod
@@ -294,18 +295,34 @@ class _HashGrid(torch.autograd.Function):
         (xf,) = ctx.saved_tensors
         g = _f32c(gout)
         dt = torch.zeros(ctx.n_params, dtype=torch.float32, device=xf.device)
-        check(lib().rsdf_hashgrid_bwd(ptr(xf), ptr(g), ctypes.byref(ctx.meta), xf.shape[0],
-                                      ctx.n_active, g.shape[1], ctx.col, ptr(dt), stream_ptr()),
-              "hashgrid_bwd")
+        n = xf.shape[0]
+        if ctx.fd7 is not None and ctx.meta.n_features == 2 and n % 7 == 0:
+            # x holds [S,7,3] stencil taps: merge them in registers and reduce through LDS
+            S = n // 7
+            nbytes = int(lib().rsdf_hashgrid_bwd_fd7_scratch_bytes(ctypes.byref(ctx.meta), S,
+                                                                   ctx.n_active, float(ctx.fd7)))
+            if nbytes < 0:
+                raise L.RiseSdfHipError("hashgrid_bwd_fd7: unsupported level layout")
+            scratch = torch.empty(nbytes, dtype=torch.uint8, device=xf.device)
+            check(lib().rsdf_hashgrid_bwd_fd7(ptr(xf), ptr(g), ctypes.byref(ctx.meta), S, ctx.n_active,
+                                              g.shape[1], ctx.col, float(ctx.fd7), ptr(dt),
+                                              ptr(scratch), nbytes, stream_ptr()), "hashgrid_bwd_fd7")
+        else:
+            check(lib().rsdf_hashgrid_bwd(ptr(xf), ptr(g), ctypes.byref(ctx.meta), n, ctx.n_active,
+                                          g.shape[1], ctx.col, ptr(dt), stream_ptr()), "hashgrid_bwd")
         # d/dx is not provided: finite-difference-normal configurations never ask for it
-        return None, dt, None, None, None, None, None
+        return None, dt, None, None, None, None, None, None
 
 
 def hashgrid_encode(x, table, meta, n_active_levels=None, include_xyz=False, xyz_scale=2.0,
-                    xyz_offset=-1.0):
-    """x [S,3] in [0,1] -> [S, (3 +) L*F].  Differentiable w.r.t. ``table``."""
+                    xyz_offset=-1.0, fd7_eps_unit=None):
+    """x [S,3] in [0,1] -> [S, (3 +) L*F].  Differentiable w.r.t. ``table``.
+
+    ``fd7_eps_unit`` (= eps / (2 radius)): promise that x is the [S/7, 7, 3] finite-difference
+    stencil written by ``fd_points`` / ``fd_taps``; the backward then uses the stencil-merging,
+    atomic-free scatter (rsdf_hashgrid_bwd_fd7)."""
     na = meta.n_levels if n_active_levels is None else int(n_active_levels)
-    return _HashGrid.apply(x, table, meta, na, bool(include_xyz), xyz_scale, xyz_offset)
+    return _HashGrid.apply(x, table, meta, na, bool(include_xyz), xyz_scale, xyz_offset, fd7_eps_unit)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -348,3 +348,36 @@ def test_neus_alpha_backward(dev, ops):
         assert rel_err(sg.grad, so.grad) < 1e-4
         assert rel_err(ng.grad, no.grad) < 1e-4
         assert abs(float(vg.grad) - float(vo.grad)) < 1e-3 * abs(float(vo.grad)) + 1e-4
+
+
+# ---- H1b, finite-difference stencil variant (bin + LDS reduce, no per-corner atomics) ----------------
+@pytest.mark.parametrize("gi,eps_unit", [(1, 1.0 / 8192), (1, 1.0 / 1291), (0, 1.0 / 54), (1, 3.0 / 8192)])
+def test_hashgrid_backward_fd7(dev, ops, gi, eps_unit):
+    """Same gradient as the generic scatter on [S,7,3] stencil points: compared with the oracle's
+    fp64-accumulated backward.  eps = one finest cell (the progressive schedule), a mid level's cell,
+    and 3 finest cells (taps more than one cell away: the slow-path branch)."""
+    from rise_sdf_amd import _lib
+    cfg = GRIDS[gi]
+    meta_o, n_params = oracle.grid_meta(**cfg)
+    meta_g, _ = _lib.make_grid_meta(**cfg)
+    g = torch.Generator().manual_seed(21)
+    table = (torch.rand(n_params, generator=g) * 2 - 1) * 1e-4
+    S = 3000
+    t = torch.linspace(0, 1, S // 2)[:, None]
+    centre = torch.cat([0.05 + 0.9 * t * torch.tensor([[0.9, 0.6, 0.35]]),
+                        torch.rand(S - S // 2, 3, generator=g)])
+    centre[:3] = torch.tensor([[0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [0.5, 0.0, 1.0]])  # clamped taps
+    offs = torch.tensor([[0, 0, 0], [1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]],
+                        dtype=torch.float32) * eps_unit
+    x7 = (centre[:, None, :] + offs[None]).clamp(0.0, 1.0).reshape(-1, 3).contiguous()
+    LF = meta_o.n_levels * 2
+    gout = torch.randn(x7.shape[0], 3 + LF, generator=g)
+    t_o = table.clone().requires_grad_(True)
+    (oracle.hashgrid_encode(x7, t_o, meta_o) * gout[:, 3:]).sum().backward()
+    t_g = table.to(dev).requires_grad_(True)
+    enc = ops.hashgrid_encode(x7.to(dev), t_g, meta_g, include_xyz=True, fd7_eps_unit=eps_unit)
+    (enc * gout.to(dev)).sum().backward()
+    scale = float(t_o.grad.abs().max())
+    err = float((t_g.grad.cpu() - t_o.grad).abs().max())
+    assert err < 1e-5 * scale + 1e-7, (err, scale)
+    assert int((t_g.grad.cpu() != 0).sum()) == int((t_o.grad != 0).sum())
