@@ -169,6 +169,25 @@ int rsdf_linear_bwd_input(const float *dy, const float *y, int lddy, const float
 /* dw[N,K] += dz^T @ x ; db[N] += colsum(dz).  Accumulates with fp32 atomics: zero first. */
 int rsdf_linear_bwd_weight(const float *dz, int lddz, const float *x, int ldx, int64_t n, int K,
                            int N, float *dw, float *db, void *stream);
+/* Fused SDF network for the finite-difference stencil: Linear(K0,H) -> Softplus(100) -> Linear(H,H)
+ * -> Softplus(100) -> Linear(H,N2) (VanillaMLP with n_hidden_layers=2, models/network_utils.py:
+ * 109-157) on rows 7i..7i+6 = centre + six taps of sample i.  Activations stay on the CU.
+ * Supported: K0 <= 35, H in {32, 64}, N2 <= 64 (rsdf_sdfmlp_fd7_supported).
+ * fwd: sdf7 [7n] = output column 0 of every row; feature [n, N2] (nullable) = full output of the
+ *      centre rows.
+ * bwd: from d_sdf7 [7n] only (feature gradients use the per-layer kernels): d_enc receives the input
+ *      columns [k0w, k0w+kw) (row stride lddx; nullable); dw0 [H,K0], db0 [H], dw1 [H,H], db1 [H],
+ *      dw2 [N2,H] (row 0 written), db2 [N2] (element 0) are accumulated atomically: zero first. */
+int rsdf_sdfmlp_fd7_supported(int K0, int H, int N2);
+int rsdf_sdfmlp_fd7_fwd(const float *enc, int ldx, int K0, int H, int N2, const float *w0,
+                        const float *b0, const float *w1, const float *b1, const float *w2,
+                        const float *b2, int64_t n_samples, float *sdf7, float *feature,
+                        void *stream);
+int rsdf_sdfmlp_fd7_bwd(const float *enc, int ldx, int K0, int H, int N2, const float *w0,
+                        const float *b0, const float *w1, const float *b1, const float *w2,
+                        const float *b2, int64_t n_samples, const float *d_sdf7, int k0w, int kw,
+                        float *d_enc, int lddx, float *dw0, float *db0, float *dw1, float *db1,
+                        float *dw2, float *db2, void *stream);
 /* weight_norm (torch.nn.utils.weight_norm dim=0): w = g * v / ||v||_row */
 int rsdf_weight_norm_fwd(const float *g, const float *v, int N, int K, float *w, void *stream);
 int rsdf_weight_norm_bwd(const float *g, const float *v, const float *dw, int N, int K, float *dg,

@@ -63,6 +63,10 @@ _SIGNATURES = {
     "rsdf_linear_fwd": [_P, _I, _P, _P, _L, _I, _I, _I, _P, _I, _P],
     "rsdf_linear_bwd_input": [_P, _P, _I, _P, _L, _I, _I, _I, _I, _I, _P, _P, _I, _P],
     "rsdf_linear_bwd_weight": [_P, _I, _P, _I, _L, _I, _I, _P, _P, _P],
+    "rsdf_sdfmlp_fd7_supported": [_I, _I, _I],
+    "rsdf_sdfmlp_fd7_fwd": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P],
+    "rsdf_sdfmlp_fd7_bwd": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _P, _I,
+                            _P, _P, _P, _P, _P, _P, _P],
     "rsdf_weight_norm_fwd": [_P, _P, _I, _I, _P, _P],
     "rsdf_weight_norm_bwd": [_P, _P, _P, _I, _I, _P, _P, _P],
     "rsdf_fd_points": [_P, _P, _P, _P, _P, _L, _F, _F, _P, _P, _P],
@@ -136,7 +140,7 @@ class _TimedLib:
         fn = getattr(self._l, name)
         if not name.startswith("rsdf_") or name in ("rsdf_last_error", "rsdf_abi_version",
                                                    "rsdf_scan_scratch_bytes", "rsdf_grid_meta_init",
-                                                   "rsdf_hashgrid_bwd_fd7_scratch_bytes"):
+                                                   "rsdf_hashgrid_bwd_fd7_scratch_bytes", "rsdf_sdfmlp_fd7_supported"):
             return fn
         timer = self._t
 

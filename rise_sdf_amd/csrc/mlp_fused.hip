@@ -1,0 +1,514 @@
+// H3 fused: the whole SDF VanillaMLP (Linear -> Softplus(100) -> Linear -> Softplus(100) -> Linear,
+// models/network_utils.py:109-157 with n_hidden_layers = 2) in one kernel each way, for the
+// finite-difference stencil layout (rows 7i..7i+6 = centre + six taps of sample i).
+//
+// Why: run layer by layer (mlp.hip) the MLP moves ~5.5 KB of activations per evaluation through HBM
+// and is memory bound at ~10 % of the fp32 MFMA rate (r01b profile).  Here activations never leave
+// the CU:
+//   * every layer is computed TRANSPOSED, D[n][row] = sum_k W[n][k] * act[k][row], so a layer's
+//     accumulator registers (lane = row, register = output feature) are directly the next layer's
+//     MFMA B operand: v_mfma_f32_32x32x2_f32 may visit k in any order, and step r pairs the two k
+//     values register r holds in the two lane halves (n_lo(r) and n_lo(r)+4);
+//   * the backward recomputes the two hidden layers instead of reading them back, chains
+//     d(act) through the same register trick, and forms the weight gradients from LDS-transposed
+//     [feature][row] tiles with MFMA (sum over rows = the MFMA k dimension), accumulating them in
+//     registers across the workgroup's whole row loop and flushing once with atomics;
+//   * the taps only need output column 0 (the SDF), so their last layer is a 64-term dot product on
+//     the vector ALU instead of a 32-wide MFMA tile; the full feature row is produced for centre
+//     rows only.
+// fp32 throughout (exact fp32 FMA chains); summation order differs from a row-major GEMM, which is
+// within the 1e-5 relative tolerance of the parity tests.
+#include "common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int THREADS = 256;
+constexpr int WAVES = 4;
+constexpr int K0P = 36;       // padded input width (3 + 2*16 = 35 -> 36)
+constexpr int LDX = K0P + 1;  // 37: odd LDS row stride
+constexpr int LDT = 33;       // [feature][row] transposed tiles
+
+__device__ __forceinline__ int n_lo(int r) { return (r & 3) + 8 * (r >> 2); }
+
+// Softplus(beta=100, threshold=20) and its derivative sigmoid(100 z) expressed through y
+__device__ __forceinline__ float softplus100(float z)
+{
+    const float t = 100.0f * z;
+    // max(z,0) + log1p(exp(-|t|))/100 : same value as torch's thresholded form to < 1e-9 absolute
+    const float e = __expf(-fabsf(t));
+    return fmaxf(z, 0.0f) + __logf(1.0f + e) * 0.01f;
+}
+__device__ __forceinline__ float softplus100_grad_from_z(float z)
+{
+    return 1.0f / (1.0f + __expf(-100.0f * z));
+}
+
+template <int H>
+struct Smem {
+    static constexpr int NT = H / 32;
+    static constexpr int LDW1 = H + 1;
+    // weights (shared by the workgroup)
+    static constexpr int W0 = 0;                         // [H][LDX]
+    static constexpr int W1 = W0 + H * LDX;              // [H][LDW1]
+    static constexpr int W2 = W1 + H * LDW1;             // [64][LDW1]  (N2 <= 64 rows)
+    static constexpr int B0 = W2 + 64 * LDW1;            // [H]
+    static constexpr int B1 = B0 + H;                    // [H]
+    static constexpr int B2 = B1 + H;                    // [64]
+    static constexpr int SHARED = B2 + 64;
+    // per wave
+    static constexpr int XS = 0;                         // [32][LDX]
+    static constexpr int TA = XS + 32 * LDX;             // [H][LDT]
+    static constexpr int TD = TA + H * LDT;              // [H][LDT]
+    static constexpr int PER_WAVE_FWD = 32 * LDX + 32 * 65;  // X tile + feature transpose [32][65]
+    static constexpr int PER_WAVE_BWD = TD + H * LDT;
+};
+
+template <int H>
+__device__ __forceinline__ void stage_all_weights(float *sm, const float *__restrict__ w0,
+                                                  const float *__restrict__ b0,
+                                                  const float *__restrict__ w1,
+                                                  const float *__restrict__ b1,
+                                                  const float *__restrict__ w2,
+                                                  const float *__restrict__ b2, int K0, int N2)
+{
+    using S = Smem<H>;
+    for (int e = threadIdx.x; e < H * K0P; e += THREADS) {
+        const int r = e / K0P, c = e - r * K0P;
+        sm[S::W0 + r * LDX + c] = c < K0 ? w0[r * K0 + c] : 0.0f;
+    }
+    for (int e = threadIdx.x; e < H * H; e += THREADS) {
+        const int r = e / H, c = e - r * H;
+        sm[S::W1 + r * S::LDW1 + c] = w1[e];
+    }
+    for (int e = threadIdx.x; e < 64 * H; e += THREADS) {
+        const int r = e / H, c = e - r * H;
+        sm[S::W2 + r * S::LDW1 + c] = r < N2 ? w2[r * H + c] : 0.0f;
+    }
+    for (int e = threadIdx.x; e < H; e += THREADS) {
+        sm[S::B0 + e] = b0[e];
+        sm[S::B1 + e] = b1[e];
+    }
+    for (int e = threadIdx.x; e < 64; e += THREADS) sm[S::B2 + e] = e < N2 ? b2[e] : 0.0f;
+}
+
+// rows (s0 + r)*7 + tap, r = 0..31, of enc [R, ldx] -> Xs [32][LDX] (zero padded)
+__device__ __forceinline__ void stage_x_tile(float *Xs, const float *__restrict__ enc, int ldx, int K0,
+                                             int64_t s0, int tap, int64_t n_samples, int lane)
+{
+    for (int e = lane; e < 32 * K0P; e += 64) {
+        const int r = e / K0P, c = e - r * K0P;
+        const int64_t s = s0 + r;
+        Xs[r * LDX + c] = (s < n_samples && c < K0) ? enc[(s * 7 + tap) * (int64_t)ldx + c] : 0.0f;
+    }
+}
+
+// hidden layers 1 and 2, transposed: h[t][r] holds feature t*32 + n_lo(r) + 4*lh of row (lane & 31)
+template <int H>
+__device__ __forceinline__ void hidden_forward(const float *sm, const float *Xs, int li, int lh,
+                                               f32x16 (&z1)[H / 32], f32x16 (&z2)[H / 32],
+                                               f32x16 (&h1)[H / 32], f32x16 (&h2)[H / 32])
+{
+    using S = Smem<H>;
+    constexpr int NT = H / 32;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z1[t][r] = sm[S::B0 + t * 32 + n_lo(r) + 4 * lh];
+    for (int k0 = 0; k0 < K0P; k0 += 2) {
+        const float b = Xs[li * LDX + k0 + lh];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float a = sm[S::W0 + (t * 32 + li) * LDX + k0 + lh];
+            z1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, z1[t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h1[t][r] = softplus100(z1[t][r]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z2[t][r] = sm[S::B1 + t * 32 + n_lo(r) + 4 * lh];
+#pragma unroll
+    for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = tk * 32 + n_lo(r) + 4 * lh;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float a = sm[S::W1 + (t * 32 + li) * S::LDW1 + k];
+                z2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, h1[tk][r], z2[t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h2[t][r] = softplus100(z2[t][r]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward: enc [7S, ldx] -> sdf7 [7S], feature [S, N2] (nullable; centre rows only)
+// ------------------------------------------------------------------------------------------------
+template <int H>
+__global__ void __launch_bounds__(THREADS)
+sdfmlp_fwd_kernel(const float *__restrict__ enc, int ldx, int K0, const float *__restrict__ w0,
+                  const float *__restrict__ b0, const float *__restrict__ w1,
+                  const float *__restrict__ b1, const float *__restrict__ w2,
+                  const float *__restrict__ b2, int N2, int64_t n_samples, float *__restrict__ sdf7,
+                  float *__restrict__ feature)
+{
+    using S = Smem<H>;
+    constexpr int NT = H / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+    float *Xs = smem + S::SHARED + wave * S::PER_WAVE_FWD;
+    float *Fs = Xs + 32 * LDX;  // [32][65]
+    stage_all_weights<H>(smem, w0, b0, w1, b1, w2, b2, K0, N2);
+    __syncthreads();
+
+    const int64_t n_groups = (n_samples + 31) / 32;  // 32 samples per wave iteration
+    for (int64_t g = (int64_t)blockIdx.x * WAVES + wave; g < n_groups; g += (int64_t)gridDim.x * WAVES) {
+        const int64_t s0 = g * 32;
+        for (int tap = 0; tap < 7; ++tap) {
+            stage_x_tile(Xs, enc, ldx, K0, s0, tap, n_samples, lane);
+            f32x16 z1[NT], z2[NT], h1[NT], h2[NT];
+            hidden_forward<H>(smem, Xs, li, lh, z1, z2, h1, h2);
+            const int64_t s = s0 + li;
+            if (tap == 0 && feature != nullptr) {
+                // full last layer on the matrix cores: out[n2][row]
+                f32x16 o[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[t][r] = smem[S::B2 + t * 32 + n_lo(r) + 4 * lh];
+#pragma unroll
+                for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int k = tk * 32 + n_lo(r) + 4 * lh;
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            if (t * 32 < N2) {
+                                const float a = smem[S::W2 + (t * 32 + li) * S::LDW1 + k];
+                                o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, h2[tk][r], o[t], 0, 0, 0);
+                            }
+                        }
+                    }
+                // transpose through LDS for coalesced row stores
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) Fs[li * 65 + t * 32 + n_lo(r) + 4 * lh] = o[t][r];
+                for (int e = lane; e < 32 * N2; e += 64) {
+                    const int r = e / N2, c = e - r * N2;
+                    if (s0 + r < n_samples) feature[(s0 + r) * N2 + c] = Fs[r * 65 + c];
+                }
+                if (lh == 0 && s < n_samples) sdf7[s * 7] = o[0][0];
+            } else {
+                // SDF only: dot(W2[0,:], h2[:,row]) on the vector ALU, k split over the lane halves
+                float acc = 0.0f;
+#pragma unroll
+                for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc = fmaf(smem[S::W2 + tk * 32 + n_lo(r) + 4 * lh], h2[tk][r], acc);
+                acc += __shfl_xor(acc, 32, 64);
+                if (lh == 0 && s < n_samples) sdf7[s * 7 + tap] = acc + smem[S::B2];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward: d_sdf7 [7S] -> d_enc window [7S, lddx] (columns k0w .. k0w+kw of the input),
+//           dW0, db0, dW1, db1, dW2 row 0, db2[0]   (atomically accumulated: zero first)
+// ------------------------------------------------------------------------------------------------
+template <int H>
+__global__ void __launch_bounds__(THREADS)
+sdfmlp_bwd_kernel(const float *__restrict__ enc, int ldx, int K0, const float *__restrict__ w0,
+                  const float *__restrict__ b0, const float *__restrict__ w1,
+                  const float *__restrict__ b1, const float *__restrict__ w2,
+                  const float *__restrict__ b2, int N2, int64_t n_samples,
+                  const float *__restrict__ d_sdf7, int k0w, int kw, float *__restrict__ d_enc,
+                  int lddx, float *__restrict__ dw0, float *__restrict__ db0,
+                  float *__restrict__ dw1, float *__restrict__ db1, float *__restrict__ dw2,
+                  float *__restrict__ db2)
+{
+    using S = Smem<H>;
+    constexpr int NT = H / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+    float *Xs = smem + S::SHARED + wave * S::PER_WAVE_BWD + S::XS;
+    float *Ta = smem + S::SHARED + wave * S::PER_WAVE_BWD + S::TA;
+    float *Td = smem + S::SHARED + wave * S::PER_WAVE_BWD + S::TD;
+    stage_all_weights<H>(smem, w0, b0, w1, b1, w2, b2, K0, N2);
+    __syncthreads();
+
+    // gradient accumulators that live across the whole row loop
+    f32x16 gw1[NT][NT];  // dW1[n tile][k tile]
+    f32x16 gw0[NT];      // dW0[n tile][input columns 0..31]
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gw0[a][r] = 0.0f;
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gw1[a][b][r] = 0.0f;
+    }
+    // per-lane partials, lane f (< H) owns feature f
+    float gb1 = 0.0f, gb0 = 0.0f, gw2 = 0.0f, gb2 = 0.0f;
+    float gw0_tail[4] = {0.f, 0.f, 0.f, 0.f};  // dW0[f][32..35]
+
+    const int64_t n_groups = (n_samples + 31) / 32;
+    for (int64_t g = (int64_t)blockIdx.x * WAVES + wave; g < n_groups; g += (int64_t)gridDim.x * WAVES) {
+        const int64_t s0 = g * 32;
+        for (int tap = 0; tap < 7; ++tap) {
+            stage_x_tile(Xs, enc, ldx, K0, s0, tap, n_samples, lane);
+            f32x16 z1[NT], z2[NT], h1[NT], h2[NT];
+            hidden_forward<H>(smem, Xs, li, lh, z1, z2, h1, h2);
+            const int64_t s = s0 + li;
+            const float dsdf = s < n_samples ? d_sdf7[s * 7 + tap] : 0.0f;
+
+            // ---- layer 3 (SDF column only): dh2 = W2[0,:] * dsdf ; dW2[0,:] += dsdf * h2 ---------
+            // h2 -> Ta as [feature][row]
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Ta[(t * 32 + n_lo(r) + 4 * lh) * LDT + li] = h2[t][r];
+            // dsdf per row -> first row of Td's scratch line (reuse Xs pad column is too small)
+            Td[H * LDT - 33 + li] = dsdf;  // last LDT-sized line of Td is overwritten later; used now
+            // (each lane f < H) dW2[0][f] += sum_row dsdf[row] * h2[f][row]
+            if (lane < H) {
+                float acc = 0.0f;
+#pragma unroll 8
+                for (int row = 0; row < 32; ++row) acc = fmaf(Td[H * LDT - 33 + row], Ta[lane * LDT + row], acc);
+                gw2 += acc;
+            }
+            gb2 += (lh == 0) ? dsdf : 0.0f;
+            // dz2 = dh2 * sigmoid(100 z2)
+            f32x16 dz2[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int k = t * 32 + n_lo(r) + 4 * lh;
+                    dz2[t][r] = smem[S::W2 + k] * dsdf * softplus100_grad_from_z(z2[t][r]);
+                }
+
+            // ---- layer 2: dW1 += dz2^T h1 ; db1 += colsum(dz2) ; dh1 = W1^T dz2 -------------------
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    Td[(t * 32 + n_lo(r) + 4 * lh) * LDT + li] = dz2[t][r];
+                    Ta[(t * 32 + n_lo(r) + 4 * lh) * LDT + li] = h1[t][r];
+                }
+            for (int rs = 0; rs < 32; rs += 2) {  // MFMA k = row
+                float av[NT], bv[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    av[t] = Td[(t * 32 + li) * LDT + rs + lh];
+                    bv[t] = Ta[(t * 32 + li) * LDT + rs + lh];
+                }
+#pragma unroll
+                for (int a = 0; a < NT; ++a)
+#pragma unroll
+                    for (int b = 0; b < NT; ++b)
+                        gw1[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], gw1[a][b], 0, 0, 0);
+            }
+            if (lane < H) {
+                float acc = 0.0f;
+#pragma unroll 8
+                for (int row = 0; row < 32; ++row) acc += Td[lane * LDT + row];
+                gb1 += acc;
+            }
+            f32x16 dz1[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dz1[t][r] = 0.0f;
+#pragma unroll
+            for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int k2 = tk * 32 + n_lo(r) + 4 * lh;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        // A[i = k1][k = k2] = W1[k2][k1]
+                        const float a = smem[S::W1 + k2 * S::LDW1 + t * 32 + li];
+                        dz1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, dz2[tk][r], dz1[t], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dz1[t][r] *= softplus100_grad_from_z(z1[t][r]);
+
+            // ---- layer 1: dW0 += dz1^T x ; db0 += colsum(dz1) ; dx = W0^T dz1 (column window) ------
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Td[(t * 32 + n_lo(r) + 4 * lh) * LDT + li] = dz1[t][r];
+            for (int rs = 0; rs < 32; rs += 2) {
+                const float bx = Xs[(rs + lh) * LDX + li];  // B[k = row][j = input column li]
+#pragma unroll
+                for (int a = 0; a < NT; ++a) {
+                    const float av = Td[(a * 32 + li) * LDT + rs + lh];
+                    gw0[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bx, gw0[a], 0, 0, 0);
+                }
+            }
+            if (lane < H) {
+                float acc = 0.0f, t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+#pragma unroll 8
+                for (int row = 0; row < 32; ++row) {
+                    const float d = Td[lane * LDT + row];
+                    acc += d;
+                    t0 = fmaf(d, Xs[row * LDX + 32], t0);
+                    t1 = fmaf(d, Xs[row * LDX + 33], t1);
+                    t2 = fmaf(d, Xs[row * LDX + 34], t2);
+                    t3 = fmaf(d, Xs[row * LDX + 35], t3);
+                }
+                gb0 += acc;
+                gw0_tail[0] += t0; gw0_tail[1] += t1; gw0_tail[2] += t2; gw0_tail[3] += t3;
+            }
+            if (d_enc != nullptr) {
+                f32x16 dx;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dx[r] = 0.0f;
+#pragma unroll
+                for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int k1 = tk * 32 + n_lo(r) + 4 * lh;
+                        // A[i = c][k = k1] = W0[k1][k0w + c]   (c < kw, else the zero pad)
+                        const int col = k0w + li;
+                        const float a = (li < kw && col < K0P) ? smem[S::W0 + k1 * LDX + col] : 0.0f;
+                        dx = __builtin_amdgcn_mfma_f32_32x32x2f32(a, dz1[tk][r], dx, 0, 0, 0);
+                    }
+                // dx[c][row] -> Ta as [row][c] -> coalesced 128-byte row stores
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Ta[li * LDT + n_lo(r) + 4 * lh] = dx[r];
+                for (int e = lane; e < 32 * kw; e += 64) {
+                    const int r = e / kw, c = e - r * kw;
+                    if (s0 + r < n_samples)
+                        d_enc[((s0 + r) * 7 + tap) * (int64_t)lddx + c] = Ta[r * LDT + c];
+                }
+            }
+        }
+    }
+
+    // ---- flush the accumulated parameter gradients ------------------------------------------------
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = a * 32 + n_lo(r) + 4 * lh, k = b * 32 + li;
+                atomicAdd(&dw1[n * H + k], gw1[a][b][r]);
+            }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = a * 32 + n_lo(r) + 4 * lh, k = li;
+            if (k < K0) atomicAdd(&dw0[n * K0 + k], gw0[a][r]);
+        }
+    }
+    if (lane < H) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (32 + c < K0) atomicAdd(&dw0[lane * K0 + 32 + c], gw0_tail[c]);
+        atomicAdd(&db0[lane], gb0);
+        atomicAdd(&db1[lane], gb1);
+        atomicAdd(&dw2[lane], gw2);  // row 0 of dW2 [N2, H]
+    }
+    gb2 = wave_sum(gb2);
+    if (lane == 0) atomicAdd(&db2[0], gb2);
+}
+
+template <int H>
+size_t fwd_lds() { return (size_t)(Smem<H>::SHARED + WAVES * Smem<H>::PER_WAVE_FWD) * sizeof(float); }
+template <int H>
+size_t bwd_lds() { return (size_t)(Smem<H>::SHARED + WAVES * Smem<H>::PER_WAVE_BWD) * sizeof(float); }
+
+template <typename K>
+int set_lds(K kern, size_t bytes)
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) { rsdf_set_error(hipGetErrorString(e)); return (int)e; }
+    return 0;
+}
+
+unsigned persistent_grid(int64_t n_samples)
+{
+    const int64_t groups = (n_samples + 31) / 32;
+    const int64_t want = (groups + WAVES - 1) / WAVES;
+    return (unsigned)(want < 512 ? (want > 0 ? want : 1) : 512);
+}
+
+}  // namespace
+
+extern "C" {
+
+int rsdf_sdfmlp_fd7_supported(int K0, int H, int N2)
+{
+    return (K0 >= 1 && K0 <= 35 && (H == 32 || H == 64) && N2 >= 1 && N2 <= 64) ? 1 : 0;
+}
+
+int rsdf_sdfmlp_fd7_fwd(const float *enc, int ldx, int K0, int H, int N2, const float *w0,
+                        const float *b0, const float *w1, const float *b1, const float *w2,
+                        const float *b2, int64_t n_samples, float *sdf7, float *feature, void *stream)
+{
+    RSDF_CHECK_ARG(rsdf_sdfmlp_fd7_supported(K0, H, N2), "sdfmlp_fd7_fwd: unsupported layer sizes");
+    RSDF_CHECK_ARG(ldx >= K0, "sdfmlp_fd7_fwd: ldx < K0");
+    if (n_samples <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = persistent_grid(n_samples);
+    int rc;
+    if (H == 64) {
+        if ((rc = set_lds(sdfmlp_fwd_kernel<64>, fwd_lds<64>()))) return rc;
+        sdfmlp_fwd_kernel<64><<<grid, THREADS, fwd_lds<64>(), st>>>(enc, ldx, K0, w0, b0, w1, b1, w2, b2,
+                                                                     N2, n_samples, sdf7, feature);
+    } else {
+        if ((rc = set_lds(sdfmlp_fwd_kernel<32>, fwd_lds<32>()))) return rc;
+        sdfmlp_fwd_kernel<32><<<grid, THREADS, fwd_lds<32>(), st>>>(enc, ldx, K0, w0, b0, w1, b1, w2, b2,
+                                                                     N2, n_samples, sdf7, feature);
+    }
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_sdfmlp_fd7_bwd(const float *enc, int ldx, int K0, int H, int N2, const float *w0,
+                        const float *b0, const float *w1, const float *b1, const float *w2,
+                        const float *b2, int64_t n_samples, const float *d_sdf7, int k0w, int kw,
+                        float *d_enc, int lddx, float *dw0, float *db0, float *dw1, float *db1,
+                        float *dw2, float *db2, void *stream)
+{
+    RSDF_CHECK_ARG(rsdf_sdfmlp_fd7_supported(K0, H, N2), "sdfmlp_fd7_bwd: unsupported layer sizes");
+    RSDF_CHECK_ARG(ldx >= K0, "sdfmlp_fd7_bwd: ldx < K0");
+    if (d_enc) {
+        RSDF_CHECK_ARG(k0w >= 0 && kw >= 1 && kw <= 32 && k0w + kw <= K0 && lddx >= kw,
+                       "sdfmlp_fd7_bwd: bad input-gradient column window");
+    }
+    if (n_samples <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = persistent_grid(n_samples);
+    int rc;
+    if (H == 64) {
+        if ((rc = set_lds(sdfmlp_bwd_kernel<64>, bwd_lds<64>()))) return rc;
+        sdfmlp_bwd_kernel<64><<<grid, THREADS, bwd_lds<64>(), st>>>(
+            enc, ldx, K0, w0, b0, w1, b1, w2, b2, N2, n_samples, d_sdf7, k0w, kw, d_enc, lddx, dw0, db0,
+            dw1, db1, dw2, db2);
+    } else {
+        if ((rc = set_lds(sdfmlp_bwd_kernel<32>, bwd_lds<32>()))) return rc;
+        sdfmlp_bwd_kernel<32><<<grid, THREADS, bwd_lds<32>(), st>>>(
+            enc, ldx, K0, w0, b0, w1, b1, w2, b2, N2, n_samples, d_sdf7, k0w, kw, d_enc, lddx, dw0, db0,
+            dw1, db1, dw2, db2);
+    }
+    RSDF_RETURN_LAUNCH();
+}
+
+}  // extern "C"

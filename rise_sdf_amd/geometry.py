@@ -89,6 +89,31 @@ class VolumeSDF(BaseModel):
                            self._finite_difference_eps)
         return self.network(self.encoding(x7.view(-1, 3), fd7_eps_unit=self._eps_unit()))
 
+    def fused_field_available(self):
+        """True when the fused stencil kernels cover this configuration (hash grid with xyz
+        pass-through + 2x{32,64} Softplus(100) MLP)."""
+        from . import fused
+        from .network_utils import VanillaMLP
+        grid, _ = self.encoding._hash()
+        net = self.network
+        return (grid is not None and self.encoding.include_xyz and isinstance(net, VanillaMLP)
+                and fused.supported(self.encoding.n_output_dims, net.n_neurons, self.n_output_dims,
+                                    net.n_hidden_layers, net.hidden_act, net.output_act,
+                                    grid.n_features_per_level))
+
+    def sdf7_from_rays(self, rays_o, rays_d, ray_indices, t_starts, t_ends, want_feature=False):
+        """Fused fast path: -> (sdf7 [7S, 1], feature [S, feature_dim] or None).  Gradients flow
+        through the SDF values only."""
+        from . import fused
+        x7 = ops.fd_points(rays_o, rays_d, ray_indices, t_starts, t_ends, self.radius,
+                           self._finite_difference_eps)
+        grid, n_active = self.encoding._hash()
+        sdf7, feature = fused.sdf_field_fd7(
+            x7, grid.params, self.network.effective_weights(), grid.meta,
+            grid.n_levels if n_active is None else n_active, self.encoding.xyz_scale,
+            self.encoding.xyz_offset, self._eps_unit(), want_feature)
+        return sdf7.view(-1, 1), feature
+
     def _eps_unit(self):
         return self._finite_difference_eps / (2.0 * self.radius)
 

@@ -20,10 +20,10 @@ from helpers import camera_rays, rel_err, sphere_binary
 pytestmark = pytest.mark.gpu
 
 
-def model_config(n_levels=4, hidden=32, feat=13, grid_prune=False, base=16, log2_T=14):
+def model_config(n_levels=4, hidden=32, feat=13, grid_prune=False, base=16, log2_T=14, fused=True):
     from rise_sdf_amd import Config
     return Config({
-        "name": "neus", "radius": 1.5, "num_samples_per_ray": 1024, "randomized": True,
+        "name": "neus", "radius": 1.5, "fused": fused, "num_samples_per_ray": 1024, "randomized": True,
         "ray_chunk": 4096, "cos_anneal_end": 0, "learned_background": False, "grid_prune": grid_prune,
         "variance": {"init_val": 0.3, "modulate": False},
         "geometry": {
@@ -59,11 +59,13 @@ def oracle_params(model):
     return meta, table, mlp, var
 
 
-@pytest.mark.parametrize("prune", [False, True])
-def test_neus_render_matches_oracle(dev, prune):
+@pytest.mark.parametrize("prune,fused,hidden,n_levels", [(False, True, 32, 4), (True, True, 64, 6),
+                                                         (False, False, 32, 4), (True, False, 64, 4)])
+def test_neus_render_matches_oracle(dev, prune, fused, hidden, n_levels):
     import rise_sdf_amd as R
     torch.manual_seed(0)
-    cfg = model_config(grid_prune=prune)
+    cfg = model_config(grid_prune=prune, fused=fused, hidden=hidden, n_levels=n_levels)
+    assert fused == (R.make("volume-sdf", cfg.geometry).fused_field_available() and fused)
     model = R.make("neus", cfg).to(dev)
     model.train()
     # larger table values than the 1e-4 init so that the hash features matter
