@@ -28,6 +28,7 @@ extern "C" {
 #define RSDF_ABI_VERSION 1
 #define RSDF_EINVAL 10001
 #define RSDF_MAX_LEVELS 32
+#define RSDF_TAP_MAJOR (-1)
 
 /* activation ids for rsdf_linear_* (models/network_utils.py:152-157, models/utils.py:71-99) */
 #define RSDF_ACT_NONE 0
@@ -143,17 +144,23 @@ int rsdf_hashgrid_bwd(const float *x, const float *dout, const rsdf_grid_meta *m
                       int64_t n, int n_active_levels, int ld_dout, int col_off, float *dtable,
                       void *stream);
 
-/* Backward specialised for the finite-difference stencil (models/geometry.py:229-244): x7 [n,7,3] are
- * the centre + six taps of each sample (rsdf_fd_points layout), dout [7n, ld_dout].  The taps'
- * contributions are merged in registers, binned by table slice through LDS and reduced in LDS: no
- * per-corner global atomics.  eps_unit = eps / (2*radius) sizes the queues (results do not depend
- * on it).  scratch >= rsdf_hashgrid_bwd_fd7_scratch_bytes(...) bytes.  n_features must be 2. */
+/* ---- H1/H1b for the finite-difference stencil (models/geometry.py:229-244) -------------------------
+ * Tap-major structure-of-arrays layouts (n = number of samples):
+ *   x7t    [7][n][3]     tap t of sample s, unit cube; tap 0 = centre, then +x,-x,+y,-y,+z,-z
+ *                        (rsdf_fd_points with tap_major = 1)
+ *   planes [L][7][n][2]  encoding (or its gradient) of level l, tap t, sample s  (n_features = 2)
+ * fwd: gathers each sample's centre cell once plus 4 corners per displaced tap and evaluates the 7
+ *      interpolations from registers; bit-identical to rsdf_hashgrid_fwd on the same points.
+ * bwd: merges the taps' contributions in registers, bins them by table slice through LDS and reduces
+ *      in LDS: no per-corner global atomics.  eps_unit = eps / (2*radius) only sizes the queues.
+ *      scratch >= rsdf_hashgrid_bwd_fd7_scratch_bytes(...) bytes; dtable is accumulated into. */
+int rsdf_hashgrid_fwd_fd7(const float *x7t, const float *table, const rsdf_grid_meta *meta /*host*/,
+                          int64_t n_samples, int n_active_levels, float *planes, void *stream);
 int64_t rsdf_hashgrid_bwd_fd7_scratch_bytes(const rsdf_grid_meta *meta /*host*/, int64_t n_samples,
                                             int n_active_levels, float eps_unit);
-int rsdf_hashgrid_bwd_fd7(const float *x7, const float *dout, const rsdf_grid_meta *meta /*host*/,
-                          int64_t n_samples, int n_active_levels, int ld_dout, int col_off,
-                          float eps_unit, float *dtable, void *scratch, int64_t scratch_bytes,
-                          void *stream);
+int rsdf_hashgrid_bwd_fd7(const float *x7t, const float *dplanes, const rsdf_grid_meta *meta /*host*/,
+                          int64_t n_samples, int n_active_levels, float eps_unit, float *dtable,
+                          void *scratch, int64_t scratch_bytes, void *stream);
 
 /* ---- H3: VanillaMLP layers on the fp32 matrix cores --------------------------------------------
  * replaces nn.Linear (+ activation) inside VanillaMLP (models/network_utils.py:109-157).
@@ -169,25 +176,28 @@ int rsdf_linear_bwd_input(const float *dy, const float *y, int lddy, const float
 /* dw[N,K] += dz^T @ x ; db[N] += colsum(dz).  Accumulates with fp32 atomics: zero first. */
 int rsdf_linear_bwd_weight(const float *dz, int lddz, const float *x, int ldx, int64_t n, int K,
                            int N, float *dw, float *db, void *stream);
-/* Fused SDF network for the finite-difference stencil: Linear(K0,H) -> Softplus(100) -> Linear(H,H)
- * -> Softplus(100) -> Linear(H,N2) (VanillaMLP with n_hidden_layers=2, models/network_utils.py:
- * 109-157) on rows 7i..7i+6 = centre + six taps of sample i.  Activations stay on the CU.
- * Supported: K0 <= 35, H in {32, 64}, N2 <= 64 (rsdf_sdfmlp_fd7_supported).
- * fwd: sdf7 [7n] = output column 0 of every row; feature [n, N2] (nullable) = full output of the
- *      centre rows.
- * bwd: from d_sdf7 [7n] only (feature gradients use the per-layer kernels): d_enc receives the input
- *      columns [k0w, k0w+kw) (row stride lddx; nullable); dw0 [H,K0], db0 [H], dw1 [H,H], db1 [H],
- *      dw2 [N2,H] (row 0 written), db2 [N2] (element 0) are accumulated atomically: zero first. */
+/* Fused SDF network for the finite-difference stencil: [x*xyz_scale+xyz_offset | planes] ->
+ * Linear(K0,H) -> Softplus(100) -> Linear(H,H) -> Softplus(100) -> Linear(H,N2), K0 = 3 + 2*n_levels
+ * (CompositeEncoding include_xyz + VanillaMLP n_hidden_layers=2, models/network_utils.py:71-157) on
+ * the tap-major buffers above.  Activations stay on the CU; levels >= n_active_levels read as zero.
+ * Supported: n_levels <= 16, H in {32, 64}, N2 <= 64 (rsdf_sdfmlp_fd7_supported(K0, H, N2)).
+ * fwd: sdf7t [7][n] = output column 0 of every tap; feature [n, N2] (nullable) = full output of
+ *      the centre taps.
+ * bwd: from d_sdf7t [7][n] only (feature gradients use the per-layer kernels): d_planes (nullable)
+ *      receives d/d(hash features); dw0 [H,K0], db0 [H], dw1 [H,H], db1 [H], dw2 [N2,H] (row 0),
+ *      db2 [N2] (element 0) are accumulated atomically: zero first. */
 int rsdf_sdfmlp_fd7_supported(int K0, int H, int N2);
-int rsdf_sdfmlp_fd7_fwd(const float *enc, int ldx, int K0, int H, int N2, const float *w0,
+int rsdf_sdfmlp_fd7_fwd(const float *x7t, const float *planes, int n_levels, int n_active_levels,
+                        float xyz_scale, float xyz_offset, int H, int N2, const float *w0,
                         const float *b0, const float *w1, const float *b1, const float *w2,
-                        const float *b2, int64_t n_samples, float *sdf7, float *feature,
+                        const float *b2, int64_t n_samples, float *sdf7t, float *feature,
                         void *stream);
-int rsdf_sdfmlp_fd7_bwd(const float *enc, int ldx, int K0, int H, int N2, const float *w0,
+int rsdf_sdfmlp_fd7_bwd(const float *x7t, const float *planes, int n_levels, int n_active_levels,
+                        float xyz_scale, float xyz_offset, int H, int N2, const float *w0,
                         const float *b0, const float *w1, const float *b1, const float *w2,
-                        const float *b2, int64_t n_samples, const float *d_sdf7, int k0w, int kw,
-                        float *d_enc, int lddx, float *dw0, float *db0, float *dw1, float *db1,
-                        float *dw2, float *db2, void *stream);
+                        const float *b2, int64_t n_samples, const float *d_sdf7t, float *d_planes,
+                        float *dw0, float *db0, float *dw1, float *db1, float *dw2, float *db2,
+                        void *stream);
 /* weight_norm (torch.nn.utils.weight_norm dim=0): w = g * v / ||v||_row */
 int rsdf_weight_norm_fwd(const float *g, const float *v, int N, int K, float *w, void *stream);
 int rsdf_weight_norm_bwd(const float *g, const float *v, const float *dw, int N, int K, float *dg,
@@ -196,11 +206,11 @@ int rsdf_weight_norm_bwd(const float *g, const float *v, const float *dw, int N,
 /* ---- P1/H4/A1: sample positions, finite-difference normals, NeuS alpha ---------------------------
  * rsdf_fd_points: positions = o[ri] + d[ri]*(t0+t1)/2 (models/split_mixed_occ.py:229-231), the six
  * taps x +- eps*e_k clamped to +-radius (models/geometry.py:229-241) and the AABB contraction
- * (x+r)/(2r) (geometry.py:17-19, models/utils.py:109-114).  x_unit [n,7,3]: tap 0 = centre, then
- * +x,-x,+y,-y,+z,-z.  positions (nullable) [n,3] world space. */
+ * (x+r)/(2r) (geometry.py:17-19, models/utils.py:109-114).  x_unit [n,7,3] (tap_major = 0) or
+ * [7,n,3] (tap_major = 1): tap 0 = centre, then +x,-x,+y,-y,+z,-z.  positions (nullable) [n,3]. */
 int rsdf_fd_points(const float *rays_o, const float *rays_d, const int64_t *ray_indices,
                    const float *t_starts, const float *t_ends, int64_t n, float radius, float eps,
-                   float *x_unit, float *positions, void *stream);
+                   float *x_unit, float *positions, int tap_major, void *stream);
 /* Same taps from explicit world-space points (VolumeSDF.forward(points), models/geometry.py:206). */
 int rsdf_fd_taps(const float *points, int64_t n, float radius, float eps, float *x_unit,
                  void *stream);
@@ -210,7 +220,8 @@ int rsdf_fd_gradient_fwd(const float *sdf7, int ld, float eps, int64_t n, float 
                          void *stream);
 int rsdf_fd_gradient_bwd(const float *d_sdf, const float *d_grad, float eps, int64_t n,
                          float *d_sdf7, int ld, void *stream);
-/* sdf7 [n,7] (column 0 of the MLP output for the 7 taps, row stride ld) ->
+/* sdf7: column 0 of the MLP output for the 7 taps: rows 7i+t of a [7n, ld] matrix (ld > 0), or the
+ * tap-major [7][n] array when ld = -1 (RSDF_TAP_MAJOR) ->
  * sdf, grad = 0.5*(f+ - f-)/eps (geometry.py:243), normal = grad/max(|grad|,1e-6)
  * (split_mixed_occ.py:237), alpha (split_mixed_occ.py:151-177).  variance: device scalar,
  * inv_s = clip(exp(10 v),1e-6,1e6).  dirs are gathered from rays_d by ray index; dists = t1-t0. */

@@ -59,17 +59,18 @@ _SIGNATURES = {
     "rsdf_hashgrid_fwd": [_P, _P, ctypes.POINTER(GridMeta), _L, _I, _P, _I, _I, _I, _F, _F, _P],
     "rsdf_hashgrid_bwd": [_P, _P, ctypes.POINTER(GridMeta), _L, _I, _I, _I, _P, _P],
     "rsdf_hashgrid_bwd_fd7_scratch_bytes": [ctypes.POINTER(GridMeta), _L, _I, _F],
-    "rsdf_hashgrid_bwd_fd7": [_P, _P, ctypes.POINTER(GridMeta), _L, _I, _I, _I, _F, _P, _P, _L, _P],
+    "rsdf_hashgrid_fwd_fd7": [_P, _P, ctypes.POINTER(GridMeta), _L, _I, _P, _P],
+    "rsdf_hashgrid_bwd_fd7": [_P, _P, ctypes.POINTER(GridMeta), _L, _I, _F, _P, _P, _L, _P],
     "rsdf_linear_fwd": [_P, _I, _P, _P, _L, _I, _I, _I, _P, _I, _P],
     "rsdf_linear_bwd_input": [_P, _P, _I, _P, _L, _I, _I, _I, _I, _I, _P, _P, _I, _P],
     "rsdf_linear_bwd_weight": [_P, _I, _P, _I, _L, _I, _I, _P, _P, _P],
     "rsdf_sdfmlp_fd7_supported": [_I, _I, _I],
-    "rsdf_sdfmlp_fd7_fwd": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P],
-    "rsdf_sdfmlp_fd7_bwd": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _I, _I, _P, _I,
+    "rsdf_sdfmlp_fd7_fwd": [_P, _P, _I, _I, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P],
+    "rsdf_sdfmlp_fd7_bwd": [_P, _P, _I, _I, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P,
                             _P, _P, _P, _P, _P, _P, _P],
     "rsdf_weight_norm_fwd": [_P, _P, _I, _I, _P, _P],
     "rsdf_weight_norm_bwd": [_P, _P, _P, _I, _I, _P, _P, _P],
-    "rsdf_fd_points": [_P, _P, _P, _P, _P, _L, _F, _F, _P, _P, _P],
+    "rsdf_fd_points": [_P, _P, _P, _P, _P, _L, _F, _F, _P, _P, _I, _P],
     "rsdf_fd_taps": [_P, _L, _F, _F, _P, _P],
     "rsdf_fd_gradient_fwd": [_P, _I, _F, _L, _P, _P, _P],
     "rsdf_fd_gradient_bwd": [_P, _P, _F, _L, _P, _I, _P],

@@ -1,79 +1,212 @@
-// H1b specialised for the finite-difference stencil: backward scatter of the 7 taps of each sample
-// (centre, +-x, +-y, +-z; models/geometry.py:229-244) WITHOUT per-corner global atomics.
+// H1 / H1b specialised for the finite-difference stencil (models/geometry.py:229-244): the centre
+// of a sample and its six taps x +- eps e_k are encoded / back-propagated together.
 //
-// Why: MI355X executes float atomics at the memory side at ~2e10 64-byte requests/s chip-wide
-// (MI355X_MICROARCH.md "Global float atomics"); a scattered 4-byte add costs a whole request, and the
-// stencil produces 7 x 16 x 8 x 2 = 1792 adds per sample.  The first version of this kernel (one
-// atomic per corner, r01a profile) spent 49 % of the whole step here at 0.04 TB/s of added bytes.
+// Layouts (tap-major structure-of-arrays, so that every kernel reads and writes full cache lines):
+//   x7t    [7][S][3]        tap t of sample s (tap 0 = centre, then +x,-x,+y,-y,+z,-z), unit cube
+//   planes [L][7][S][2]     encoding (or its gradient) of level l, tap t, sample s, F = 2 features
 //
-// How (hashed levels; dense coarse levels keep the run-merging atomic kernel of hashgrid.hip):
-//   1. PRODUCE: one thread per (sample, level).  The six taps sit eps away from the centre, at most
-//      one cell (eps = one finest-level cell under the progressive schedule), so their corners are
-//      merged in registers into the centre cell's 8 corners plus at most 4 new corners per displaced
-//      tap.  Each merged (entry, value) record is binned by table range (16384 entries = one LDS-
-//      sized slice), counting-sorted inside the workgroup through LDS and appended to its bin's
-//      queue in HBM with coalesced stores.
-//   2. REDUCE: one workgroup per (level, bin, split) streams its queue, accumulates into a 128 KiB
-//      LDS image of the table slice with ds_add_f32, then adds the slice to dtable with contiguous
-//      (full-rate) global atomics.
-// HBM traffic: ~200 records x 12 B per sample each way instead of ~400 x 64-byte atomic requests.
+// FORWARD.  One thread per (sample, level).  Under the progressive-eps schedule eps is one cell of
+// the finest ACTIVE level, so a tap is at most one cell away from the centre: the thread gathers
+// the centre cell's 8 corners plus 4 new corners per displaced tap (8..32 gathers instead of 56) and
+// evaluates the 7 trilinear interpolations from registers, each as the same corner-ordered fmaf
+// chain as the generic kernel (bit-identical results).
+//
+// BACKWARD.  MI355X executes float atomics at the memory side at ~2e10 64-byte requests/s chip-wide
+// (MI355X_MICROARCH.md "Global float atomics"): a scattered 4-byte add costs a whole request and
+// the stencil produces 1792 of them per sample (the r01a profile: 49 % of the step).  Instead:
+//   1. PRODUCE: one thread per (sample, level) merges the taps' contributions in registers into
+//      the same 8..32 corners, bins the (entry, value) records by table slice (<= 16384 entries, one
+//      LDS image), counting-sorts them by bin inside the workgroup through LDS and appends each bin's
+//      run to its queue in HBM with coalesced 12-byte stores.
+//   2. REDUCE: one workgroup per (level, bin, split) streams its queue (4 records in flight per
+//      thread), accumulates into a 128 KiB LDS image with ds_add_f32 and adds the image to dtable
+//      with contiguous (full-rate) global atomics.
+// Hashed levels bin by the high index bits; dense levels bin by idx % n_bins so that a spatially
+// compact batch of rays still loads all bins evenly.
 #include "hashgrid_common.h"
-
-extern "C" int rsdf_internal_hashgrid_bwd_levels(const float *x, const float *dout,
-                                                 const rsdf_grid_meta *meta, int64_t n, int ld_dout,
-                                                 int col_off, float *dtable, int level_begin,
-                                                 int level_count, void *stream);
 
 namespace {
 
 constexpr int BIN_SHIFT = 14;
 constexpr int BIN_ENTRIES = 1 << BIN_SHIFT;  // 16384 entries x 2 floats = 128 KiB of LDS
-constexpr int MAX_BINS = 64;                 // log2_hashmap_size <= 20
-constexpr int P_THREADS = 256;               // producer: samples per workgroup
-constexpr int ROUND_RECS = 8;                // records a thread may stage per round
+constexpr int MAX_BINS = 64;
+constexpr int P_THREADS = 256;  // producer / forward: samples per workgroup
+constexpr int ROUND_RECS = 8;
 constexpr int STAGE_CAP = P_THREADS * ROUND_RECS;
-constexpr int R_THREADS = 1024;              // reducer
+constexpr int R_THREADS = 1024;  // reducer
+constexpr int R_UNROLL = 4;
 
 struct Record {
     uint32_t idx;  // entry index within the level
     float v0, v1;
 };
 
-struct HashedLevels {
-    int count;
-    int level[RSDF_MAX_LEVELS];
+struct LevelPlan {
+    int count;                       // active levels
     int n_bins[RSDF_MAX_LEVELS];
-    int64_t cap[RSDF_MAX_LEVELS];        // records per bin queue
-    int64_t queue_off[RSDF_MAX_LEVELS];  // first record of this level's bin 0 (in records)
-    int counter_off[RSDF_MAX_LEVELS];    // first counter of this level
+    int interleaved[RSDF_MAX_LEVELS];  // 1: bin = idx % n_bins (dense levels), 0: bin = idx >> 14
+    int64_t cap[RSDF_MAX_LEVELS];      // records per bin queue
+    int64_t queue_off[RSDF_MAX_LEVELS];
+    int counter_off[RSDF_MAX_LEVELS];
 };
 
-// hashed levels have size = 2^log2_hashmap_size, so "mod size" is a mask (checked in plan())
-__device__ __forceinline__ uint32_t hash_index(uint32_t x, uint32_t y, uint32_t z, uint32_t size)
+struct LevelGeom {
+    float scale;
+    uint32_t res, size, mask;
+    bool dense;
+};
+
+__device__ __forceinline__ LevelGeom level_geom(const rsdf_grid_meta &m, int l)
 {
-    return ((x * 1u) ^ (y * 2654435761u) ^ (z * 805459861u)) & (size - 1u);
+    LevelGeom g;
+    g.scale = m.scale[l];
+    g.res = m.res[l];
+    g.size = m.size[l];
+    g.dense = (uint64_t)g.res * g.res * g.res <= (uint64_t)g.size;
+    g.mask = g.size - 1u;
+    return g;
 }
 
-// Stage up to ROUND_RECS records per thread, counting-sort them by bin in LDS, append to the queues.
+// identical index function to hashgrid.hip / the oracle; hashed sizes are powers of two (mask)
+__device__ __forceinline__ uint32_t entry_index(uint32_t x, uint32_t y, uint32_t z, const LevelGeom &g)
+{
+    if (g.dense) return (x + y * g.res + z * g.res * g.res) % g.size;
+    return ((x * 1u) ^ (y * 2654435761u) ^ (z * 805459861u)) & g.mask;
+}
+
+// compact index 0..3 of the two axes other than a
+__device__ __forceinline__ int other_bits(int c, int a)
+{
+    const int o1 = (a == 0) ? 1 : 0, o2 = (a == 2) ? 1 : 2;
+    return ((c >> o1) & 1) | (((c >> o2) & 1) << 1);
+}
+
+// coordinates of the k-th new corner of axis a: k < 4 -> +side (c0_a + 2), k >= 4 -> -side (c0_a - 1)
+__device__ __forceinline__ uint32_t extra_index(const CellFrac &c0, int a, int k, const LevelGeom &g)
+{
+    const int o1 = (a == 0) ? 1 : 0, o2 = (a == 2) ? 1 : 2;
+    uint32_t cc[3] = {c0.c[0], c0.c[1], c0.c[2]};
+    cc[a] += (k < 4) ? 2u : 0xffffffffu;
+    cc[o1] += (uint32_t)(k & 1);
+    cc[o2] += (uint32_t)((k >> 1) & 1);
+    return entry_index(cc[0], cc[1], cc[2], g);
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(P_THREADS)
+fd7_fwd_kernel(const float *__restrict__ x7t, const float *__restrict__ table,
+               const rsdf_grid_meta meta, int64_t S, float2 *__restrict__ planes)
+{
+    const int64_t s = (int64_t)blockIdx.x * P_THREADS + threadIdx.x;
+    if (s >= S) return;
+    const int l = blockIdx.y;
+    const LevelGeom g = level_geom(meta, l);
+    const float2 *tl = reinterpret_cast<const float2 *>(table) + meta.offset[l];
+
+    CellFrac cf[7];
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {
+        const float *p = x7t + ((int64_t)t * S + s) * 3;
+        cf[t] = cell_frac(p[0], p[1], p[2], g.scale);
+    }
+    const CellFrac &c0 = cf[0];
+    int da[7];
+    bool plus[3] = {false, false, false}, minus[3] = {false, false, false};
+    da[0] = 0;
+#pragma unroll
+    for (int t = 1; t < 7; ++t) {
+        const int a = (t - 1) >> 1;
+        da[t] = (int32_t)(cf[t].c[a] - c0.c[a]);
+        if (da[t] == 1) plus[a] = true;
+        if (da[t] == -1) minus[a] = true;
+    }
+    float2 v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        v[c] = tl[entry_index(c0.c[0] + (c & 1), c0.c[1] + ((c >> 1) & 1), c0.c[2] + ((c >> 2) & 1), g)];
+    float2 ex[3][8];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            ex[a][k] = make_float2(0.f, 0.f);
+            if ((k < 4) ? plus[a] : minus[a]) ex[a][k] = tl[extra_index(c0, a, k, g)];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {
+        const int a = t == 0 ? 0 : (t - 1) >> 1;
+        float2 acc = make_float2(0.f, 0.f);
+        if (t == 0 || da[t] == 0) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float w = corner_weight(cf[t], c);
+                acc.x = fmaf(w, v[c].x, acc.x);
+                acc.y = fmaf(w, v[c].y, acc.y);
+            }
+        } else if (da[t] == 1) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float w = corner_weight(cf[t], c);
+                const float2 val = (((c >> a) & 1) == 0) ? v[c | (1 << a)] : ex[a][other_bits(c, a)];
+                acc.x = fmaf(w, val.x, acc.x);
+                acc.y = fmaf(w, val.y, acc.y);
+            }
+        } else if (da[t] == -1) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float w = corner_weight(cf[t], c);
+                const float2 val = (((c >> a) & 1) == 1) ? v[c & ~(1 << a)] : ex[a][4 + other_bits(c, a)];
+                acc.x = fmaf(w, val.x, acc.x);
+                acc.y = fmaf(w, val.y, acc.y);
+            }
+        } else {  // tap more than one cell away: gather its own 8 corners
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float w = corner_weight(cf[t], c);
+                const float2 val = tl[entry_index(cf[t].c[0] + (c & 1), cf[t].c[1] + ((c >> 1) & 1),
+                                                  cf[t].c[2] + ((c >> 2) & 1), g)];
+                acc.x = fmaf(w, val.x, acc.x);
+                acc.y = fmaf(w, val.y, acc.y);
+            }
+        }
+        planes[((int64_t)l * 7 + t) * S + s] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward: produce
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int bin_of(uint32_t idx, int n_bins, int interleaved)
+{
+    return interleaved ? (int)(idx % (uint32_t)n_bins) : (int)(idx >> BIN_SHIFT);
+}
+
 __device__ __forceinline__ void emit_round(const uint32_t (&ridx)[ROUND_RECS],
                                            const float2 (&rval)[ROUND_RECS], uint32_t valid_mask,
-                                           int n_bins, int64_t cap, Record *__restrict__ queue,
-                                           int *__restrict__ qcount, float *__restrict__ dlevel,
-                                           int *s_cnt, int *s_off, int *s_gbase, Record *s_stage)
+                                           int n_bins, int interleaved, int64_t cap,
+                                           Record *__restrict__ queue, int *__restrict__ qcount,
+                                           float *__restrict__ dlevel, int *s_cnt, int *s_off,
+                                           int *s_gbase, Record *s_stage)
 {
     const int tid = threadIdx.x;
-    // does any thread of the workgroup have a record this round?
     if (!__syncthreads_or(valid_mask != 0)) return;
     if (tid < n_bins) s_cnt[tid] = 0;
     __syncthreads();
-    int slot[ROUND_RECS];
+    int slot[ROUND_RECS], bin[ROUND_RECS];
 #pragma unroll
     for (int r = 0; r < ROUND_RECS; ++r) {
         slot[r] = 0;
-        if (valid_mask & (1u << r)) slot[r] = atomicAdd(&s_cnt[ridx[r] >> BIN_SHIFT], 1);
+        bin[r] = 0;
+        if (valid_mask & (1u << r)) {
+            bin[r] = bin_of(ridx[r], n_bins, interleaved);
+            slot[r] = atomicAdd(&s_cnt[bin[r]], 1);
+        }
     }
     __syncthreads();
-    if (tid < 64) {  // first wavefront: exclusive scan of the bin counts + global reservations
+    if (tid < 64) {  // first wavefront: exclusive scan of the bin counts + queue reservations
         const int c = tid < n_bins ? s_cnt[tid] : 0;
         const int incl = wave_incl_sum_i(c);
         if (tid < n_bins) {
@@ -84,21 +217,17 @@ __device__ __forceinline__ void emit_round(const uint32_t (&ridx)[ROUND_RECS],
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < ROUND_RECS; ++r) {
-        if (valid_mask & (1u << r)) {
-            const int pos = s_off[ridx[r] >> BIN_SHIFT] + slot[r];
-            s_stage[pos] = Record{ridx[r], rval[r].x, rval[r].y};
-        }
-    }
+    for (int r = 0; r < ROUND_RECS; ++r)
+        if (valid_mask & (1u << r)) s_stage[s_off[bin[r]] + slot[r]] = Record{ridx[r], rval[r].x, rval[r].y};
     __syncthreads();
     const int total = s_off[MAX_BINS];
     for (int i = tid; i < total; i += P_THREADS) {
         const Record rec = s_stage[i];
-        const int b = rec.idx >> BIN_SHIFT;
-        const int64_t g = (int64_t)s_gbase[b] + (i - s_off[b]);
-        if (g < cap) {
-            queue[(int64_t)b * cap + g] = rec;
-        } else {  // queue full (capacity is sized with slack; never silently drop)
+        const int b = bin_of(rec.idx, n_bins, interleaved);
+        const int64_t gpos = (int64_t)s_gbase[b] + (i - s_off[b]);
+        if (gpos < cap) {
+            queue[(int64_t)b * cap + gpos] = rec;
+        } else {  // queue full (capacity carries slack; never drop a contribution)
             atomicAdd(dlevel + 2 * (size_t)rec.idx, rec.v0);
             atomicAdd(dlevel + 2 * (size_t)rec.idx + 1, rec.v1);
         }
@@ -107,9 +236,9 @@ __device__ __forceinline__ void emit_round(const uint32_t (&ridx)[ROUND_RECS],
 }
 
 __global__ void __launch_bounds__(P_THREADS)
-fd7_produce_kernel(const float *__restrict__ x7, const float *__restrict__ dout,
-                   const rsdf_grid_meta meta, const HashedLevels hl, int64_t n_samples, int ld,
-                   int col_off, Record *__restrict__ queues, int *__restrict__ counters,
+fd7_produce_kernel(const float *__restrict__ x7t, const float2 *__restrict__ dplanes,
+                   const rsdf_grid_meta meta, const LevelPlan plan, int64_t S,
+                   Record *__restrict__ queues, int *__restrict__ counters,
                    float *__restrict__ dtable)
 {
     __shared__ int s_cnt[MAX_BINS];
@@ -117,21 +246,19 @@ fd7_produce_kernel(const float *__restrict__ x7, const float *__restrict__ dout,
     __shared__ int s_gbase[MAX_BINS];
     __shared__ Record s_stage[STAGE_CAP];
 
-    const int h = blockIdx.y;
-    const int l = hl.level[h];
-    const float scale = meta.scale[l];
-    const uint32_t size = meta.size[l];
+    const int l = blockIdx.y;
+    const LevelGeom g = level_geom(meta, l);
     float *dlevel = dtable + (size_t)meta.offset[l] * 2;
-    Record *queue = queues + hl.queue_off[h];
-    int *qcount = counters + hl.counter_off[h];
-    const int n_bins = hl.n_bins[h];
-    const int64_t cap = hl.cap[h];
+    Record *queue = queues + plan.queue_off[l];
+    int *qcount = counters + plan.counter_off[l];
+    const int n_bins = plan.n_bins[l], interleaved = plan.interleaved[l];
+    const int64_t cap = plan.cap[l];
 
     const int64_t s = (int64_t)blockIdx.x * P_THREADS + threadIdx.x;
-    const bool active = s < n_samples;
+    const bool active = s < S;
 
     float2 acc[8];
-    float2 ex[3][8];  // [axis][0..3: +side new corners, 4..7: -side new corners]
+    float2 ex[3][8];
     bool plus[3] = {false, false, false}, minus[3] = {false, false, false};
     CellFrac c0;
 #pragma unroll
@@ -143,45 +270,42 @@ fd7_produce_kernel(const float *__restrict__ x7, const float *__restrict__ dout,
     c0.c[0] = c0.c[1] = c0.c[2] = 0;
 
     if (active) {
-        const float *xs = x7 + s * 21;
-        const float *ds = dout + (s * 7) * (int64_t)ld + col_off + 2 * l;
-        c0 = cell_frac(xs[0], xs[1], xs[2], scale);
         {
-            const float2 g = make_float2(ds[0], ds[1]);
+            const float *p = x7t + s * 3;
+            c0 = cell_frac(p[0], p[1], p[2], g.scale);
+            const float2 gr = dplanes[((int64_t)l * 7) * S + s];
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const float w = corner_weight(c0, c);
-                acc[c].x = w * g.x;
-                acc[c].y = w * g.y;
+                acc[c].x = w * gr.x;
+                acc[c].y = w * gr.y;
             }
         }
 #pragma unroll
         for (int t = 1; t < 7; ++t) {
             const int a = (t - 1) >> 1;
-            const CellFrac ct = cell_frac(xs[3 * t], xs[3 * t + 1], xs[3 * t + 2], scale);
-            const float2 g = make_float2(ds[(int64_t)t * ld], ds[(int64_t)t * ld + 1]);
+            const float *p = x7t + ((int64_t)t * S + s) * 3;
+            const CellFrac ct = cell_frac(p[0], p[1], p[2], g.scale);
+            const float2 gr = dplanes[((int64_t)l * 7 + t) * S + s];
             const int32_t da = (int32_t)(ct.c[a] - c0.c[a]);
             if (da == 0) {
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     const float w = corner_weight(ct, c);
-                    acc[c].x += w * g.x;
-                    acc[c].y += w * g.y;
+                    acc[c].x += w * gr.x;
+                    acc[c].y += w * gr.y;
                 }
             } else if (da == 1) {
-                // tap cell = centre cell + 1 along a: its low face is the centre's high face
                 plus[a] = true;
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     const float w = corner_weight(ct, c);
                     if (((c >> a) & 1) == 0) {
-                        acc[c | (1 << a)].x += w * g.x;
-                        acc[c | (1 << a)].y += w * g.y;
+                        acc[c | (1 << a)].x += w * gr.x;
+                        acc[c | (1 << a)].y += w * gr.y;
                     } else {
-                        const int o1 = (a == 0) ? 1 : 0, o2 = (a == 2) ? 1 : 2;
-                        const int k = ((c >> o1) & 1) | (((c >> o2) & 1) << 1);
-                        ex[a][k].x += w * g.x;
-                        ex[a][k].y += w * g.y;
+                        ex[a][other_bits(c, a)].x += w * gr.x;
+                        ex[a][other_bits(c, a)].y += w * gr.y;
                     }
                 }
             } else if (da == -1) {
@@ -190,65 +314,57 @@ fd7_produce_kernel(const float *__restrict__ x7, const float *__restrict__ dout,
                 for (int c = 0; c < 8; ++c) {
                     const float w = corner_weight(ct, c);
                     if (((c >> a) & 1) == 1) {
-                        acc[c & ~(1 << a)].x += w * g.x;
-                        acc[c & ~(1 << a)].y += w * g.y;
+                        acc[c & ~(1 << a)].x += w * gr.x;
+                        acc[c & ~(1 << a)].y += w * gr.y;
                     } else {
-                        const int o1 = (a == 0) ? 1 : 0, o2 = (a == 2) ? 1 : 2;
-                        const int k = ((c >> o1) & 1) | (((c >> o2) & 1) << 1);
-                        ex[a][4 + k].x += w * g.x;
-                        ex[a][4 + k].y += w * g.y;
+                        ex[a][4 + other_bits(c, a)].x += w * gr.x;
+                        ex[a][4 + other_bits(c, a)].y += w * gr.y;
                     }
                 }
-            } else {
-                // tap more than one cell away (eps larger than a cell): rare slow path
+            } else {  // tap more than one cell away (eps larger than a cell): rare slow path
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     const float w = corner_weight(ct, c);
-                    const uint32_t idx = hash_index(ct.c[0] + (c & 1), ct.c[1] + ((c >> 1) & 1),
-                                                    ct.c[2] + ((c >> 2) & 1), size);
-                    atomicAdd(dlevel + 2 * (size_t)idx, w * g.x);
-                    atomicAdd(dlevel + 2 * (size_t)idx + 1, w * g.y);
+                    const uint32_t idx = entry_index(ct.c[0] + (c & 1), ct.c[1] + ((c >> 1) & 1),
+                                                     ct.c[2] + ((c >> 2) & 1), g);
+                    atomicAdd(dlevel + 2 * (size_t)idx, w * gr.x);
+                    atomicAdd(dlevel + 2 * (size_t)idx + 1, w * gr.y);
                 }
             }
         }
     }
 
     uint32_t ridx[ROUND_RECS];
-    // round 0: the centre cell's 8 corners
 #pragma unroll
     for (int c = 0; c < 8; ++c)
-        ridx[c] = hash_index(c0.c[0] + (c & 1), c0.c[1] + ((c >> 1) & 1), c0.c[2] + ((c >> 2) & 1), size);
-    emit_round(ridx, acc, active ? 0xffu : 0u, n_bins, cap, queue, qcount, dlevel, s_cnt, s_off,
-               s_gbase, s_stage);
-    // rounds 1..3: new corners of displaced taps, one axis per round
+        ridx[c] = entry_index(c0.c[0] + (c & 1), c0.c[1] + ((c >> 1) & 1), c0.c[2] + ((c >> 2) & 1), g);
+    emit_round(ridx, acc, active ? 0xffu : 0u, n_bins, interleaved, cap, queue, qcount, dlevel, s_cnt,
+               s_off, s_gbase, s_stage);
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        const int o1 = (a == 0) ? 1 : 0, o2 = (a == 2) ? 1 : 2;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            uint32_t cc[3] = {c0.c[0], c0.c[1], c0.c[2]};
-            cc[a] += (k < 4) ? 2u : 0xffffffffu;  // +2 or -1
-            cc[o1] += (uint32_t)(k & 1);
-            cc[o2] += (uint32_t)((k >> 1) & 1);
-            ridx[k] = hash_index(cc[0], cc[1], cc[2], size);
-        }
+        for (int k = 0; k < 8; ++k) ridx[k] = extra_index(c0, a, k, g);
         const uint32_t mask = (active && plus[a] ? 0x0fu : 0u) | (active && minus[a] ? 0xf0u : 0u);
-        emit_round(ridx, ex[a], mask, n_bins, cap, queue, qcount, dlevel, s_cnt, s_off, s_gbase,
-                   s_stage);
+        emit_round(ridx, ex[a], mask, n_bins, interleaved, cap, queue, qcount, dlevel, s_cnt, s_off,
+                   s_gbase, s_stage);
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// backward: reduce
+// ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(R_THREADS)
-fd7_reduce_kernel(const rsdf_grid_meta meta, const HashedLevels hl, const Record *__restrict__ queues,
+fd7_reduce_kernel(const rsdf_grid_meta meta, const LevelPlan plan, const Record *__restrict__ queues,
                   const int *__restrict__ counters, int n_split, float *__restrict__ dtable)
 {
     extern __shared__ __attribute__((aligned(16))) float s_acc[];  // [BIN_ENTRIES][2]
-    const int h = blockIdx.y;
+    const int l = blockIdx.y;
     const int b = blockIdx.x / n_split, part = blockIdx.x % n_split;
-    if (b >= hl.n_bins[h]) return;
-    const int l = hl.level[h];
-    const int64_t cap = hl.cap[h];
-    int64_t count = counters[hl.counter_off[h] + b];
+    const int n_bins = plan.n_bins[l];
+    if (b >= n_bins) return;
+    const int interleaved = plan.interleaved[l];
+    const int64_t cap = plan.cap[l];
+    int64_t count = counters[plan.counter_off[l] + b];
     if (count > cap) count = cap;
     const int64_t per = (count + n_split - 1) / n_split;
     const int64_t r0 = part * per;
@@ -256,26 +372,43 @@ fd7_reduce_kernel(const rsdf_grid_meta meta, const HashedLevels hl, const Record
     if (r1 > count) r1 = count;
     if (r0 >= r1) return;
     const uint32_t size = meta.size[l];
-    const int entries = size < (uint32_t)BIN_ENTRIES ? (int)size : BIN_ENTRIES;
+    // entries this bin owns
+    const int entries = interleaved ? (int)((size - (uint32_t)b + (uint32_t)n_bins - 1u) / (uint32_t)n_bins)
+                                    : (int)(size < (uint32_t)BIN_ENTRIES ? size : (uint32_t)BIN_ENTRIES);
 
     for (int i = threadIdx.x; i < entries * 2; i += R_THREADS) s_acc[i] = 0.0f;
     __syncthreads();
-    const Record *q = queues + hl.queue_off[h] + (int64_t)b * cap;
-    for (int64_t i = r0 + threadIdx.x; i < r1; i += R_THREADS) {
-        const Record rec = q[i];
-        const uint32_t e = rec.idx & (BIN_ENTRIES - 1);
-        atomicAdd(&s_acc[2 * e], rec.v0);
-        atomicAdd(&s_acc[2 * e + 1], rec.v1);
+    const Record *q = queues + plan.queue_off[l] + (int64_t)b * cap;
+    for (int64_t i0 = r0 + threadIdx.x; i0 < r1; i0 += (int64_t)R_THREADS * R_UNROLL) {
+        Record rec[R_UNROLL];
+#pragma unroll
+        for (int u = 0; u < R_UNROLL; ++u) {
+            const int64_t i = i0 + (int64_t)u * R_THREADS;
+            rec[u] = i < r1 ? q[i] : Record{0u, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < R_UNROLL; ++u) {
+            if (i0 + (int64_t)u * R_THREADS < r1) {
+                const uint32_t e = interleaved ? rec[u].idx / (uint32_t)n_bins
+                                               : (rec[u].idx & (uint32_t)(BIN_ENTRIES - 1));
+                atomicAdd(&s_acc[2 * e], rec[u].v0);
+                atomicAdd(&s_acc[2 * e + 1], rec[u].v1);
+            }
+        }
     }
     __syncthreads();
-    float *dst = dtable + ((size_t)meta.offset[l] + (size_t)b * BIN_ENTRIES) * 2;
+    float *dlevel = dtable + (size_t)meta.offset[l] * 2;
     for (int i = threadIdx.x; i < entries * 2; i += R_THREADS) {
-        const float v = s_acc[i];
-        if (v != 0.0f) atomicAdd(dst + i, v);
+        const float val = s_acc[i];
+        if (val != 0.0f) {
+            const size_t e = (size_t)(i >> 1);
+            const size_t idx = interleaved ? e * (size_t)n_bins + (size_t)b : (size_t)b * BIN_ENTRIES + e;
+            atomicAdd(dlevel + 2 * idx + (i & 1), val);
+        }
     }
 }
 
-// Expected records per (sample, level): 8 for the centre cell + 4 per displaced tap, where a tap is
+// Expected records per (sample, level): 8 for the centre cell + 4 per displaced tap, a tap being
 // displaced with probability ~min(1, eps_unit * scale).
 double expected_records(float scale, float eps_unit)
 {
@@ -284,31 +417,26 @@ double expected_records(float scale, float eps_unit)
     return 8.0 + 24.0 * p;
 }
 
-int plan(const rsdf_grid_meta *meta, int64_t n_samples, int n_active, float eps_unit, HashedLevels *hl,
-         int *n_dense, int64_t *total_records, int *total_counters)
+int make_plan(const rsdf_grid_meta *meta, int64_t S, int n_active, float eps_unit, LevelPlan *plan,
+              int64_t *total_records, int *total_counters)
 {
-    hl->count = 0;
-    *n_dense = 0;
+    plan->count = n_active;
     int64_t qoff = 0;
     int coff = 0;
     for (int l = 0; l < n_active; ++l) {
+        const uint32_t size = meta->size[l];
         const uint64_t dense = (uint64_t)meta->res[l] * meta->res[l] * meta->res[l];
-        if (dense <= meta->size[l]) {
-            if (hl->count != 0) return -1;  // dense levels must precede hashed ones
-            ++*n_dense;
-            continue;
-        }
-        if (meta->size[l] & (meta->size[l] - 1)) return -3;  // hashed level sizes are powers of two
-        const int h = hl->count++;
-        const int nb = (int)((meta->size[l] + BIN_ENTRIES - 1) >> BIN_SHIFT);
+        const bool is_dense = dense <= size;
+        if (!is_dense && (size & (size - 1u))) return -3;  // hashed sizes must be powers of two
+        const int nb = (int)((size + BIN_ENTRIES - 1) >> BIN_SHIFT);
         if (nb > MAX_BINS) return -2;
-        hl->level[h] = l;
-        hl->n_bins[h] = nb;
-        const double per_bin = (double)n_samples * expected_records(meta->scale[l], eps_unit) / nb;
-        hl->cap[h] = (int64_t)(per_bin * 1.15) + 16384;
-        hl->queue_off[h] = qoff;
-        hl->counter_off[h] = coff;
-        qoff += hl->cap[h] * nb;
+        plan->n_bins[l] = nb;
+        plan->interleaved[l] = is_dense ? 1 : 0;
+        const double per_bin = (double)S * expected_records(meta->scale[l], eps_unit) / nb;
+        plan->cap[l] = (int64_t)(per_bin * 1.15) + 16384;
+        plan->queue_off[l] = qoff;
+        plan->counter_off[l] = coff;
+        qoff += plan->cap[l] * nb;
         coff += nb;
     }
     *total_records = qoff;
@@ -316,60 +444,76 @@ int plan(const rsdf_grid_meta *meta, int64_t n_samples, int n_active, float eps_
     return 0;
 }
 
+int64_t scratch_need(int64_t n_rec, int n_cnt)
+{
+    const int64_t cbytes = (((int64_t)n_cnt * (int64_t)sizeof(int)) + 255) / 256 * 256;
+    return cbytes + n_rec * (int64_t)sizeof(Record) + 256;
+}
+
 }  // namespace
 
 extern "C" {
+
+int rsdf_hashgrid_fwd_fd7(const float *x7t, const float *table, const rsdf_grid_meta *meta,
+                          int64_t n_samples, int n_active_levels, float *planes, void *stream)
+{
+    RSDF_CHECK_ARG(meta != nullptr, "hashgrid_fwd_fd7: meta is NULL");
+    RSDF_CHECK_ARG(meta->n_features == 2, "hashgrid_fwd_fd7: n_features must be 2");
+    if (n_samples <= 0) return 0;
+    int na = n_active_levels;
+    if (na < 0 || na > (int)meta->n_levels) na = (int)meta->n_levels;
+    if (na == 0) return 0;
+    for (int l = 0; l < na; ++l) {
+        const uint64_t dense = (uint64_t)meta->res[l] * meta->res[l] * meta->res[l];
+        RSDF_CHECK_ARG(dense <= meta->size[l] || (meta->size[l] & (meta->size[l] - 1u)) == 0,
+                       "hashgrid_fwd_fd7: hashed level sizes must be powers of two");
+    }
+    dim3 grid(rsdf_blocks(n_samples, P_THREADS), na);
+    fd7_fwd_kernel<<<grid, P_THREADS, 0, (hipStream_t)stream>>>(x7t, table, *meta, n_samples,
+                                                                 reinterpret_cast<float2 *>(planes));
+    RSDF_RETURN_LAUNCH();
+}
 
 int64_t rsdf_hashgrid_bwd_fd7_scratch_bytes(const rsdf_grid_meta *meta, int64_t n_samples,
                                             int n_active_levels, float eps_unit)
 {
     if (!meta) return -1;
-    HashedLevels hl;
-    int n_dense, n_cnt;
+    LevelPlan plan;
+    int n_cnt;
     int64_t n_rec;
     int na = n_active_levels;
     if (na < 0 || na > (int)meta->n_levels) na = (int)meta->n_levels;
-    if (plan(meta, n_samples, na, eps_unit, &hl, &n_dense, &n_rec, &n_cnt) != 0) return -1;
-    return n_rec * (int64_t)sizeof(Record) + (int64_t)(n_cnt + 64) * (int64_t)sizeof(int) + 256;
+    if (make_plan(meta, n_samples, na, eps_unit, &plan, &n_rec, &n_cnt) != 0) return -1;
+    return scratch_need(n_rec, n_cnt);
 }
 
-int rsdf_hashgrid_bwd_fd7(const float *x7, const float *dout, const rsdf_grid_meta *meta,
-                          int64_t n_samples, int n_active_levels, int ld_dout, int col_off,
-                          float eps_unit, float *dtable, void *scratch, int64_t scratch_bytes,
-                          void *stream)
+int rsdf_hashgrid_bwd_fd7(const float *x7t, const float *dplanes, const rsdf_grid_meta *meta,
+                          int64_t n_samples, int n_active_levels, float eps_unit, float *dtable,
+                          void *scratch, int64_t scratch_bytes, void *stream)
 {
     RSDF_CHECK_ARG(meta != nullptr, "hashgrid_bwd_fd7: meta is NULL");
     RSDF_CHECK_ARG(meta->n_features == 2, "hashgrid_bwd_fd7: n_features must be 2");
-    const int L = (int)meta->n_levels;
-    RSDF_CHECK_ARG(ld_dout >= col_off + 2 * L, "hashgrid_bwd_fd7: ld_dout too small");
     if (n_samples <= 0) return 0;
     int na = n_active_levels;
-    if (na < 0 || na > L) na = L;
-    HashedLevels hl;
-    int n_dense, n_cnt;
+    if (na < 0 || na > (int)meta->n_levels) na = (int)meta->n_levels;
+    if (na == 0) return 0;
+    LevelPlan plan;
+    int n_cnt;
     int64_t n_rec;
-    RSDF_CHECK_ARG(plan(meta, n_samples, na, eps_unit, &hl, &n_dense, &n_rec, &n_cnt) == 0,
+    RSDF_CHECK_ARG(make_plan(meta, n_samples, na, eps_unit, &plan, &n_rec, &n_cnt) == 0,
                    "hashgrid_bwd_fd7: unsupported level layout");
-    const int64_t need = n_rec * (int64_t)sizeof(Record) + (int64_t)(n_cnt + 64) * (int64_t)sizeof(int) + 256;
-    RSDF_CHECK_ARG(scratch != nullptr && scratch_bytes >= need, "hashgrid_bwd_fd7: scratch too small");
+    RSDF_CHECK_ARG(scratch != nullptr && scratch_bytes >= scratch_need(n_rec, n_cnt),
+                   "hashgrid_bwd_fd7: scratch too small");
     hipStream_t st = (hipStream_t)stream;
-
-    if (n_dense > 0) {
-        int rc = rsdf_internal_hashgrid_bwd_levels(x7, dout, meta, n_samples * 7, ld_dout, col_off, dtable,
-                                                   0, n_dense, stream);
-        if (rc) return rc;
-    }
-    if (hl.count == 0) return 0;
-    // scratch layout: [counters (n_cnt ints, padded)] [records]
     int *counters = (int *)scratch;
     const size_t cbytes = (((size_t)n_cnt * sizeof(int)) + 255) / 256 * 256;
     Record *queues = (Record *)((char *)scratch + cbytes);
     (void)hipMemsetAsync(counters, 0, cbytes, st);
-    dim3 pgrid(rsdf_blocks(n_samples, P_THREADS), hl.count);
-    fd7_produce_kernel<<<pgrid, P_THREADS, 0, st>>>(x7, dout, *meta, hl, n_samples, ld_dout, col_off,
-                                                    queues, counters, dtable);
+    dim3 pgrid(rsdf_blocks(n_samples, P_THREADS), na);
+    fd7_produce_kernel<<<pgrid, P_THREADS, 0, st>>>(x7t, reinterpret_cast<const float2 *>(dplanes), *meta,
+                                                    plan, n_samples, queues, counters, dtable);
     int max_bins = 0;
-    for (int h = 0; h < hl.count; ++h) max_bins = hl.n_bins[h] > max_bins ? hl.n_bins[h] : max_bins;
+    for (int l = 0; l < na; ++l) max_bins = plan.n_bins[l] > max_bins ? plan.n_bins[l] : max_bins;
     const int n_split = 2;
     const size_t lds = (size_t)BIN_ENTRIES * 2 * sizeof(float);
     static bool attr_set = false;
@@ -378,8 +522,8 @@ int rsdf_hashgrid_bwd_fd7(const float *x7, const float *dout, const rsdf_grid_me
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    dim3 rgrid(max_bins * n_split, hl.count);
-    fd7_reduce_kernel<<<rgrid, R_THREADS, lds, st>>>(*meta, hl, queues, counters, n_split, dtable);
+    dim3 rgrid(max_bins * n_split, na);
+    fd7_reduce_kernel<<<rgrid, R_THREADS, lds, st>>>(*meta, plan, queues, counters, n_split, dtable);
     RSDF_RETURN_LAUNCH();
 }
 

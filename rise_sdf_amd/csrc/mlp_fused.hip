@@ -93,15 +93,42 @@ __device__ __forceinline__ void stage_all_weights(float *sm, const float *__rest
     for (int e = threadIdx.x; e < 64; e += THREADS) sm[S::B2 + e] = e < N2 ? b2[e] : 0.0f;
 }
 
-// rows (s0 + r)*7 + tap, r = 0..31, of enc [R, ldx] -> Xs [32][LDX] (zero padded)
-__device__ __forceinline__ void stage_x_tile(float *Xs, const float *__restrict__ enc, int ldx, int K0,
-                                             int64_t s0, int tap, int64_t n_samples, int lane)
+// Input tile of one (32-sample group, tap): [32 rows][K0P] = [xyz*scale+offset | L*2 hash features | 0]
+// read from the tap-major SoA buffers (x7t [7][S][3], planes [L][7][S][2]) with full-line loads:
+// per level the 32 samples' float2 are 256 contiguous bytes.  The tile is first fetched into 18
+// registers per lane (so the loads of tile i+1 fly while tile i is computed), then written to LDS.
+struct TileSrc {
+    const float *x7t;
+    const float *planes;
+    int64_t S;
+    int n_levels, n_active;
+    float xyz_scale, xyz_offset;
+};
+
+__device__ __forceinline__ void fetch_tile(float (&pre)[18], const TileSrc &src, int64_t s0, int tap,
+                                           int lane)
 {
-    for (int e = lane; e < 32 * K0P; e += 64) {
-        const int r = e / K0P, c = e - r * K0P;
-        const int64_t s = s0 + r;
-        Xs[r * LDX + c] = (s < n_samples && c < K0) ? enc[(s * 7 + tap) * (int64_t)ldx + c] : 0.0f;
+    const int r = lane >> 1;
+    const bool ok = s0 + r < src.S;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) {
+        float v = 0.0f;
+        if (l < src.n_active && ok) v = src.planes[(((int64_t)l * 7 + tap) * src.S + s0) * 2 + lane];
+        pre[l] = v;
     }
+    const float *xb = src.x7t + ((int64_t)tap * src.S + s0) * 3;
+    pre[16] = (s0 + lane / 3 < src.S) ? xb[lane] : 0.5f;
+    pre[17] = (lane < 32 && s0 + (lane + 64) / 3 < src.S) ? xb[lane + 64] : 0.5f;
+}
+
+__device__ __forceinline__ void store_tile(float *Xs, const float (&pre)[18], const TileSrc &src, int lane)
+{
+    const int r = lane >> 1, f = lane & 1;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) Xs[r * LDX + 3 + 2 * l + f] = pre[l];
+    Xs[(lane / 3) * LDX + lane % 3] = pre[16] * src.xyz_scale + src.xyz_offset;
+    if (lane < 32) Xs[((lane + 64) / 3) * LDX + (lane + 64) % 3] = pre[17] * src.xyz_scale + src.xyz_offset;
+    if (lane < 32) Xs[lane * LDX + 35] = 0.0f;
 }
 
 // hidden layers 1 and 2, transposed: h[t][r] holds feature t*32 + n_lo(r) + 4*lh of row (lane & 31)
@@ -154,12 +181,14 @@ __device__ __forceinline__ void hidden_forward(const float *sm, const float *Xs,
 // ------------------------------------------------------------------------------------------------
 template <int H>
 __global__ void __launch_bounds__(THREADS)
-sdfmlp_fwd_kernel(const float *__restrict__ enc, int ldx, int K0, const float *__restrict__ w0,
+sdfmlp_fwd_kernel(const TileSrc src, const float *__restrict__ w0,
                   const float *__restrict__ b0, const float *__restrict__ w1,
                   const float *__restrict__ b1, const float *__restrict__ w2,
-                  const float *__restrict__ b2, int N2, int64_t n_samples, float *__restrict__ sdf7,
+                  const float *__restrict__ b2, int N2, float *__restrict__ sdf7,
                   float *__restrict__ feature)
 {
+    const int64_t n_samples = src.S;
+    const int K0 = 3 + 2 * src.n_levels;
     using S = Smem<H>;
     constexpr int NT = H / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -170,10 +199,18 @@ sdfmlp_fwd_kernel(const float *__restrict__ enc, int ldx, int K0, const float *_
     __syncthreads();
 
     const int64_t n_groups = (n_samples + 31) / 32;  // 32 samples per wave iteration
-    for (int64_t g = (int64_t)blockIdx.x * WAVES + wave; g < n_groups; g += (int64_t)gridDim.x * WAVES) {
+    const int64_t g_first = (int64_t)blockIdx.x * WAVES + wave, g_step = (int64_t)gridDim.x * WAVES;
+    float pre[18];
+    if (g_first < n_groups) fetch_tile(pre, src, g_first * 32, 0, lane);
+    for (int64_t g = g_first; g < n_groups; g += g_step) {
         const int64_t s0 = g * 32;
         for (int tap = 0; tap < 7; ++tap) {
-            stage_x_tile(Xs, enc, ldx, K0, s0, tap, n_samples, lane);
+            store_tile(Xs, pre, src, lane);
+            {   // prefetch the next tile of this wave
+                const int ntap = tap == 6 ? 0 : tap + 1;
+                const int64_t ng = tap == 6 ? g + g_step : g;
+                if (ng < n_groups) fetch_tile(pre, src, ng * 32, ntap, lane);
+            }
             f32x16 z1[NT], z2[NT], h1[NT], h2[NT];
             hidden_forward<H>(smem, Xs, li, lh, z1, z2, h1, h2);
             const int64_t s = s0 + li;
@@ -206,7 +243,7 @@ sdfmlp_fwd_kernel(const float *__restrict__ enc, int ldx, int K0, const float *_
                     const int r = e / N2, c = e - r * N2;
                     if (s0 + r < n_samples) feature[(s0 + r) * N2 + c] = Fs[r * 65 + c];
                 }
-                if (lh == 0 && s < n_samples) sdf7[s * 7] = o[0][0];
+                if (lh == 0 && s < n_samples) sdf7[s] = o[0][0];
             } else {
                 // SDF only: dot(W2[0,:], h2[:,row]) on the vector ALU, k split over the lane halves
                 float acc = 0.0f;
@@ -216,7 +253,7 @@ sdfmlp_fwd_kernel(const float *__restrict__ enc, int ldx, int K0, const float *_
                     for (int r = 0; r < 16; ++r)
                         acc = fmaf(smem[S::W2 + tk * 32 + n_lo(r) + 4 * lh], h2[tk][r], acc);
                 acc += __shfl_xor(acc, 32, 64);
-                if (lh == 0 && s < n_samples) sdf7[s * 7 + tap] = acc + smem[S::B2];
+                if (lh == 0 && s < n_samples) sdf7[(int64_t)tap * n_samples + s] = acc + smem[S::B2];
             }
         }
     }
@@ -228,15 +265,18 @@ sdfmlp_fwd_kernel(const float *__restrict__ enc, int ldx, int K0, const float *_
 // ------------------------------------------------------------------------------------------------
 template <int H>
 __global__ void __launch_bounds__(THREADS)
-sdfmlp_bwd_kernel(const float *__restrict__ enc, int ldx, int K0, const float *__restrict__ w0,
+sdfmlp_bwd_kernel(const TileSrc src, const float *__restrict__ w0,
                   const float *__restrict__ b0, const float *__restrict__ w1,
                   const float *__restrict__ b1, const float *__restrict__ w2,
-                  const float *__restrict__ b2, int N2, int64_t n_samples,
-                  const float *__restrict__ d_sdf7, int k0w, int kw, float *__restrict__ d_enc,
-                  int lddx, float *__restrict__ dw0, float *__restrict__ db0,
+                  const float *__restrict__ b2, int N2,
+                  const float *__restrict__ d_sdf7, float *__restrict__ d_planes,
+                  float *__restrict__ dw0, float *__restrict__ db0,
                   float *__restrict__ dw1, float *__restrict__ db1, float *__restrict__ dw2,
                   float *__restrict__ db2)
 {
+    const int64_t n_samples = src.S;
+    const int K0 = 3 + 2 * src.n_levels;
+    const int k0w = 3, kw = 2 * src.n_levels;
     using S = Smem<H>;
     constexpr int NT = H / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -264,14 +304,22 @@ sdfmlp_bwd_kernel(const float *__restrict__ enc, int ldx, int K0, const float *_
     float gw0_tail[4] = {0.f, 0.f, 0.f, 0.f};  // dW0[f][32..35]
 
     const int64_t n_groups = (n_samples + 31) / 32;
-    for (int64_t g = (int64_t)blockIdx.x * WAVES + wave; g < n_groups; g += (int64_t)gridDim.x * WAVES) {
+    const int64_t g_first = (int64_t)blockIdx.x * WAVES + wave, g_step = (int64_t)gridDim.x * WAVES;
+    float pre[18];
+    if (g_first < n_groups) fetch_tile(pre, src, g_first * 32, 0, lane);
+    for (int64_t g = g_first; g < n_groups; g += g_step) {
         const int64_t s0 = g * 32;
         for (int tap = 0; tap < 7; ++tap) {
-            stage_x_tile(Xs, enc, ldx, K0, s0, tap, n_samples, lane);
+            store_tile(Xs, pre, src, lane);
+            {
+                const int ntap = tap == 6 ? 0 : tap + 1;
+                const int64_t ng = tap == 6 ? g + g_step : g;
+                if (ng < n_groups) fetch_tile(pre, src, ng * 32, ntap, lane);
+            }
             f32x16 z1[NT], z2[NT], h1[NT], h2[NT];
             hidden_forward<H>(smem, Xs, li, lh, z1, z2, h1, h2);
             const int64_t s = s0 + li;
-            const float dsdf = s < n_samples ? d_sdf7[s * 7 + tap] : 0.0f;
+            const float dsdf = s < n_samples ? d_sdf7[(int64_t)tap * n_samples + s] : 0.0f;
 
             // ---- layer 3 (SDF column only): dh2 = W2[0,:] * dsdf ; dW2[0,:] += dsdf * h2 ---------
             // h2 -> Ta as [feature][row]
@@ -375,7 +423,7 @@ sdfmlp_bwd_kernel(const float *__restrict__ enc, int ldx, int K0, const float *_
                 gb0 += acc;
                 gw0_tail[0] += t0; gw0_tail[1] += t1; gw0_tail[2] += t2; gw0_tail[3] += t3;
             }
-            if (d_enc != nullptr) {
+            if (d_planes != nullptr) {
                 f32x16 dx;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dx[r] = 0.0f;
@@ -392,10 +440,11 @@ sdfmlp_bwd_kernel(const float *__restrict__ enc, int ldx, int K0, const float *_
                 // dx[c][row] -> Ta as [row][c] -> coalesced 128-byte row stores
 #pragma unroll
                 for (int r = 0; r < 16; ++r) Ta[li * LDT + n_lo(r) + 4 * lh] = dx[r];
-                for (int e = lane; e < 32 * kw; e += 64) {
-                    const int r = e / kw, c = e - r * kw;
-                    if (s0 + r < n_samples)
-                        d_enc[((s0 + r) * 7 + tap) * (int64_t)lddx + c] = Ta[r * LDT + c];
+                // level planes [L][7][S][2]: per level 32 samples x float2 = 256 contiguous bytes
+                if (s0 + (lane >> 1) < n_samples) {
+                    for (int l = 0; l < src.n_active; ++l)
+                        d_planes[(((int64_t)l * 7 + tap) * n_samples + s0) * 2 + lane] =
+                            Ta[(lane >> 1) * LDT + 2 * l + (lane & 1)];
                 }
             }
         }
@@ -459,54 +508,58 @@ int rsdf_sdfmlp_fd7_supported(int K0, int H, int N2)
     return (K0 >= 1 && K0 <= 35 && (H == 32 || H == 64) && N2 >= 1 && N2 <= 64) ? 1 : 0;
 }
 
-int rsdf_sdfmlp_fd7_fwd(const float *enc, int ldx, int K0, int H, int N2, const float *w0,
+int rsdf_sdfmlp_fd7_fwd(const float *x7t, const float *planes, int n_levels, int n_active_levels,
+                        float xyz_scale, float xyz_offset, int H, int N2, const float *w0,
                         const float *b0, const float *w1, const float *b1, const float *w2,
-                        const float *b2, int64_t n_samples, float *sdf7, float *feature, void *stream)
+                        const float *b2, int64_t n_samples, float *sdf7t, float *feature, void *stream)
 {
+    const int K0 = 3 + 2 * n_levels;
+    RSDF_CHECK_ARG(n_levels >= 1 && n_levels <= 16, "sdfmlp_fd7_fwd: n_levels must be in [1,16]");
     RSDF_CHECK_ARG(rsdf_sdfmlp_fd7_supported(K0, H, N2), "sdfmlp_fd7_fwd: unsupported layer sizes");
-    RSDF_CHECK_ARG(ldx >= K0, "sdfmlp_fd7_fwd: ldx < K0");
     if (n_samples <= 0) return 0;
+    if (n_active_levels < 0 || n_active_levels > n_levels) n_active_levels = n_levels;
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = persistent_grid(n_samples);
+    const TileSrc src{x7t, planes, n_samples, n_levels, n_active_levels, xyz_scale, xyz_offset};
     int rc;
     if (H == 64) {
         if ((rc = set_lds(sdfmlp_fwd_kernel<64>, fwd_lds<64>()))) return rc;
-        sdfmlp_fwd_kernel<64><<<grid, THREADS, fwd_lds<64>(), st>>>(enc, ldx, K0, w0, b0, w1, b1, w2, b2,
-                                                                     N2, n_samples, sdf7, feature);
+        sdfmlp_fwd_kernel<64><<<grid, THREADS, fwd_lds<64>(), st>>>(src, w0, b0, w1, b1, w2, b2, N2, sdf7t,
+                                                                     feature);
     } else {
         if ((rc = set_lds(sdfmlp_fwd_kernel<32>, fwd_lds<32>()))) return rc;
-        sdfmlp_fwd_kernel<32><<<grid, THREADS, fwd_lds<32>(), st>>>(enc, ldx, K0, w0, b0, w1, b1, w2, b2,
-                                                                     N2, n_samples, sdf7, feature);
+        sdfmlp_fwd_kernel<32><<<grid, THREADS, fwd_lds<32>(), st>>>(src, w0, b0, w1, b1, w2, b2, N2, sdf7t,
+                                                                     feature);
     }
     RSDF_RETURN_LAUNCH();
 }
 
-int rsdf_sdfmlp_fd7_bwd(const float *enc, int ldx, int K0, int H, int N2, const float *w0,
+int rsdf_sdfmlp_fd7_bwd(const float *x7t, const float *planes, int n_levels, int n_active_levels,
+                        float xyz_scale, float xyz_offset, int H, int N2, const float *w0,
                         const float *b0, const float *w1, const float *b1, const float *w2,
-                        const float *b2, int64_t n_samples, const float *d_sdf7, int k0w, int kw,
-                        float *d_enc, int lddx, float *dw0, float *db0, float *dw1, float *db1,
-                        float *dw2, float *db2, void *stream)
+                        const float *b2, int64_t n_samples, const float *d_sdf7t, float *d_planes,
+                        float *dw0, float *db0, float *dw1, float *db1, float *dw2, float *db2,
+                        void *stream)
 {
+    const int K0 = 3 + 2 * n_levels;
+    RSDF_CHECK_ARG(n_levels >= 1 && n_levels <= 16, "sdfmlp_fd7_bwd: n_levels must be in [1,16]");
     RSDF_CHECK_ARG(rsdf_sdfmlp_fd7_supported(K0, H, N2), "sdfmlp_fd7_bwd: unsupported layer sizes");
-    RSDF_CHECK_ARG(ldx >= K0, "sdfmlp_fd7_bwd: ldx < K0");
-    if (d_enc) {
-        RSDF_CHECK_ARG(k0w >= 0 && kw >= 1 && kw <= 32 && k0w + kw <= K0 && lddx >= kw,
-                       "sdfmlp_fd7_bwd: bad input-gradient column window");
-    }
     if (n_samples <= 0) return 0;
+    if (n_active_levels < 0 || n_active_levels > n_levels) n_active_levels = n_levels;
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = persistent_grid(n_samples);
+    const TileSrc src{x7t, planes, n_samples, n_levels, n_active_levels, xyz_scale, xyz_offset};
     int rc;
     if (H == 64) {
         if ((rc = set_lds(sdfmlp_bwd_kernel<64>, bwd_lds<64>()))) return rc;
-        sdfmlp_bwd_kernel<64><<<grid, THREADS, bwd_lds<64>(), st>>>(
-            enc, ldx, K0, w0, b0, w1, b1, w2, b2, N2, n_samples, d_sdf7, k0w, kw, d_enc, lddx, dw0, db0,
-            dw1, db1, dw2, db2);
+        sdfmlp_bwd_kernel<64><<<grid, THREADS, bwd_lds<64>(), st>>>(src, w0, b0, w1, b1, w2, b2, N2,
+                                                                     d_sdf7t, d_planes, dw0, db0, dw1, db1,
+                                                                     dw2, db2);
     } else {
         if ((rc = set_lds(sdfmlp_bwd_kernel<32>, bwd_lds<32>()))) return rc;
-        sdfmlp_bwd_kernel<32><<<grid, THREADS, bwd_lds<32>(), st>>>(
-            enc, ldx, K0, w0, b0, w1, b1, w2, b2, N2, n_samples, d_sdf7, k0w, kw, d_enc, lddx, dw0, db0,
-            dw1, db1, dw2, db2);
+        sdfmlp_bwd_kernel<32><<<grid, THREADS, bwd_lds<32>(), st>>>(src, w0, b0, w1, b1, w2, b2, N2,
+                                                                     d_sdf7t, d_planes, dw0, db0, dw1, db1,
+                                                                     dw2, db2);
     }
     RSDF_RETURN_LAUNCH();
 }

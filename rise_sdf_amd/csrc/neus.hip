@@ -20,7 +20,7 @@ __global__ void __launch_bounds__(THREADS)
 fd_points_kernel(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
                  const int64_t *__restrict__ ri, const float *__restrict__ ts,
                  const float *__restrict__ te, int64_t n, float radius, float eps,
-                 float *__restrict__ xu, float *__restrict__ positions)
+                 float *__restrict__ xu, float *__restrict__ positions, int tap_major)
 {
     const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
     if (i >= n) return;
@@ -35,7 +35,9 @@ fd_points_kernel(const float *__restrict__ rays_o, const float *__restrict__ ray
         for (int k = 0; k < 3; ++k) positions[3 * i + k] = p[k];
     }
     const float two_r = radius - (-radius);
-    float *o = xu + i * 21;
+    // interleaved [n][7][3] or tap-major [7][n][3]
+    const int64_t tstride = tap_major ? n * 3 : 3;
+    float *o = xu + (tap_major ? i * 3 : i * 21);
 #pragma unroll
     for (int k = 0; k < 3; ++k) o[k] = (p[k] - (-radius)) / two_r;
 #pragma unroll
@@ -46,7 +48,7 @@ fd_points_kernel(const float *__restrict__ rays_o, const float *__restrict__ ray
         for (int k = 0; k < 3; ++k) {
             float q = p[k] + (k == axis ? off : 0.0f);
             q = fminf(fmaxf(q, -radius), radius);
-            o[3 + 3 * t + k] = (q - (-radius)) / two_r;
+            o[(t + 1) * tstride + k] = (q - (-radius)) / two_r;
         }
     }
 }
@@ -83,11 +85,12 @@ fd_gradient_fwd_kernel(const float *__restrict__ sdf7, int ld, float eps, int64_
 {
     const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
     if (i >= n) return;
-    const float *s = sdf7 + i * 7 * (int64_t)ld;
+    const int64_t tstr = ld < 0 ? n : (int64_t)ld, ss = ld < 0 ? 1 : 7 * (int64_t)ld;
+    const float *s = sdf7 + i * ss;
     if (sdf) sdf[i] = s[0];
 #pragma unroll
     for (int k = 0; k < 3; ++k)
-        grad[3 * i + k] = 0.5f * (s[(1 + 2 * k) * (int64_t)ld] - s[(2 + 2 * k) * (int64_t)ld]) / eps;
+        grad[3 * i + k] = 0.5f * (s[(1 + 2 * k) * tstr] - s[(2 + 2 * k) * tstr]) / eps;
 }
 
 __global__ void __launch_bounds__(THREADS)
@@ -96,14 +99,15 @@ fd_gradient_bwd_kernel(const float *__restrict__ d_sdf, const float *__restrict_
 {
     const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
     if (i >= n) return;
-    float *o = d_sdf7 + i * 7 * (int64_t)ld;
+    const int64_t tstr = ld < 0 ? n : (int64_t)ld, ss = ld < 0 ? 1 : 7 * (int64_t)ld;
+    float *o = d_sdf7 + i * ss;
     o[0] = d_sdf ? d_sdf[i] : 0.0f;
     const float c = 0.5f / eps;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const float g = d_grad ? d_grad[3 * i + k] : 0.0f;
-        o[(1 + 2 * k) * (int64_t)ld] = c * g;
-        o[(2 + 2 * k) * (int64_t)ld] = -c * g;
+        o[(1 + 2 * k) * tstr] = c * g;
+        o[(2 + 2 * k) * tstr] = -c * g;
     }
 }
 
@@ -163,11 +167,12 @@ alpha_fd_fwd_kernel(const float *__restrict__ sdf7, int ld, const float *__restr
 {
     const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
     if (i >= n) return;
-    const float *s = sdf7 + i * 7 * (int64_t)ld;
+    const int64_t tstr = ld < 0 ? n : (int64_t)ld, ss = ld < 0 ? 1 : 7 * (int64_t)ld;
+    const float *s = sdf7 + i * ss;
     const float sdf = s[0];
     float g[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) g[k] = 0.5f * (s[(1 + 2 * k) * (int64_t)ld] - s[(2 + 2 * k) * (int64_t)ld]) / eps;
+    for (int k = 0; k < 3; ++k) g[k] = 0.5f * (s[(1 + 2 * k) * tstr] - s[(2 + 2 * k) * tstr]) / eps;
     const float nrm = fmaxf(sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]), 1e-6f);
     const float nx = g[0] / nrm, ny = g[1] / nrm, nz = g[2] / nrm;
     const int64_t ray = ri[i];
@@ -192,12 +197,13 @@ alpha_fd_bwd_kernel(const float *__restrict__ sdf7, int ld, const float *__restr
     const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
     float d_inv_s = 0.0f;
     if (i < n) {
-        const float *s = sdf7 + i * 7 * (int64_t)ld;
+        const int64_t tstr = ld < 0 ? n : (int64_t)ld, ss = ld < 0 ? 1 : 7 * (int64_t)ld;
+    const float *s = sdf7 + i * ss;
         const float sdf = s[0];
         float g[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k)
-            g[k] = 0.5f * (s[(1 + 2 * k) * (int64_t)ld] - s[(2 + 2 * k) * (int64_t)ld]) / eps;
+            g[k] = 0.5f * (s[(1 + 2 * k) * tstr] - s[(2 + 2 * k) * tstr]) / eps;
         const float len = sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
         const float nrm = fmaxf(len, 1e-6f);
         const float nv[3] = {g[0] / nrm, g[1] / nrm, g[2] / nrm};
@@ -227,13 +233,14 @@ alpha_fd_bwd_kernel(const float *__restrict__ sdf7, int ld, const float *__restr
 #pragma unroll
             for (int k = 0; k < 3; ++k) dg[k] += d_grad_in[3 * i + k];
         }
-        float *o = d_sdf7 + i * 7 * (int64_t)ld_out;
+        const int64_t tso = ld_out < 0 ? n : (int64_t)ld_out, sso = ld_out < 0 ? 1 : 7 * (int64_t)ld_out;
+        float *o = d_sdf7 + i * sso;
         o[0] = d_sdf;
         const float c = 0.5f / eps;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            o[(1 + 2 * k) * (int64_t)ld_out] = c * dg[k];
-            o[(2 + 2 * k) * (int64_t)ld_out] = -c * dg[k];
+            o[(1 + 2 * k) * tso] = c * dg[k];
+            o[(2 + 2 * k) * tso] = -c * dg[k];
         }
     }
     if (d_variance) {
@@ -310,12 +317,12 @@ extern "C" {
 
 int rsdf_fd_points(const float *rays_o, const float *rays_d, const int64_t *ray_indices,
                    const float *t_starts, const float *t_ends, int64_t n, float radius, float eps,
-                   float *x_unit, float *positions, void *stream)
+                   float *x_unit, float *positions, int tap_major, void *stream)
 {
     RSDF_CHECK_ARG(radius > 0.f, "fd_points: radius must be > 0");
     if (n <= 0) return 0;
     fd_points_kernel<<<rsdf_blocks(n, THREADS), THREADS, 0, (hipStream_t)stream>>>(
-        rays_o, rays_d, ray_indices, t_starts, t_ends, n, radius, eps, x_unit, positions);
+        rays_o, rays_d, ray_indices, t_starts, t_ends, n, radius, eps, x_unit, positions, tap_major);
     RSDF_RETURN_LAUNCH();
 }
 
@@ -331,7 +338,7 @@ int rsdf_fd_taps(const float *points, int64_t n, float radius, float eps, float 
 int rsdf_fd_gradient_fwd(const float *sdf7, int ld, float eps, int64_t n, float *sdf, float *grad,
                          void *stream)
 {
-    RSDF_CHECK_ARG(eps > 0.f && ld >= 1, "fd_gradient_fwd: bad eps or ld");
+    RSDF_CHECK_ARG(eps > 0.f && ld != 0, "fd_gradient_fwd: bad eps or ld");
     if (n <= 0) return 0;
     fd_gradient_fwd_kernel<<<rsdf_blocks(n, THREADS), THREADS, 0, (hipStream_t)stream>>>(sdf7, ld, eps, n,
                                                                                       sdf, grad);
@@ -341,7 +348,7 @@ int rsdf_fd_gradient_fwd(const float *sdf7, int ld, float eps, int64_t n, float 
 int rsdf_fd_gradient_bwd(const float *d_sdf, const float *d_grad, float eps, int64_t n, float *d_sdf7,
                          int ld, void *stream)
 {
-    RSDF_CHECK_ARG(eps > 0.f && ld >= 1, "fd_gradient_bwd: bad eps or ld");
+    RSDF_CHECK_ARG(eps > 0.f && ld != 0, "fd_gradient_bwd: bad eps or ld");
     if (n <= 0) return 0;
     fd_gradient_bwd_kernel<<<rsdf_blocks(n, THREADS), THREADS, 0, (hipStream_t)stream>>>(d_sdf, d_grad, eps,
                                                                                       n, d_sdf7, ld);
@@ -353,7 +360,7 @@ int rsdf_neus_alpha_fd_fwd(const float *sdf7, int ld, const float *rays_d, const
                            float cos_anneal_ratio, float eps, int64_t n, float *sdf, float *grad,
                            float *normal, float *alpha, void *stream)
 {
-    RSDF_CHECK_ARG(eps > 0.f && ld >= 1, "neus_alpha_fd_fwd: bad eps or ld");
+    RSDF_CHECK_ARG(eps > 0.f && ld != 0, "neus_alpha_fd_fwd: bad eps or ld");
     if (n <= 0) return 0;
     alpha_fd_fwd_kernel<<<rsdf_blocks(n, THREADS), THREADS, 0, (hipStream_t)stream>>>(
         sdf7, ld, rays_d, ray_indices, t_starts, t_ends, variance, cos_anneal_ratio, eps, n, sdf, grad,
@@ -367,7 +374,7 @@ int rsdf_neus_alpha_fd_bwd(const float *sdf7, int ld, const float *rays_d, const
                            const float *d_normal, const float *d_sdf, const float *d_grad,
                            float *d_sdf7, int ld_out, float *d_variance, void *stream)
 {
-    RSDF_CHECK_ARG(eps > 0.f && ld >= 1 && ld_out >= 1, "neus_alpha_fd_bwd: bad eps or ld");
+    RSDF_CHECK_ARG(eps > 0.f && ld != 0 && ld_out != 0, "neus_alpha_fd_bwd: bad eps or ld");
     if (n <= 0) return 0;
     alpha_fd_bwd_kernel<<<rsdf_blocks(n, THREADS), THREADS, 0, (hipStream_t)stream>>>(
         sdf7, ld, rays_d, ray_indices, t_starts, t_ends, variance, cos_anneal_ratio, eps, n, d_alpha,

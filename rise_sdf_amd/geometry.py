@@ -102,17 +102,16 @@ class VolumeSDF(BaseModel):
                                     grid.n_features_per_level))
 
     def sdf7_from_rays(self, rays_o, rays_d, ray_indices, t_starts, t_ends, want_feature=False):
-        """Fused fast path: -> (sdf7 [7S, 1], feature [S, feature_dim] or None).  Gradients flow
-        through the SDF values only."""
+        """Fused fast path: -> (sdf7t [7, S] tap-major SDF stencil, feature [S, feature_dim] or
+        None).  Gradients flow through the SDF values only."""
         from . import fused
-        x7 = ops.fd_points(rays_o, rays_d, ray_indices, t_starts, t_ends, self.radius,
-                           self._finite_difference_eps)
+        x7t = ops.fd_points(rays_o, rays_d, ray_indices, t_starts, t_ends, self.radius,
+                            self._finite_difference_eps, tap_major=True)
         grid, n_active = self.encoding._hash()
-        sdf7, feature = fused.sdf_field_fd7(
-            x7, grid.params, self.network.effective_weights(), grid.meta,
+        return fused.sdf_field_fd7(
+            x7t, grid.params, self.network.effective_weights(), grid.meta,
             grid.n_levels if n_active is None else n_active, self.encoding.xyz_scale,
             self.encoding.xyz_offset, self._eps_unit(), want_feature)
-        return sdf7.view(-1, 1), feature
 
     def _eps_unit(self):
         return self._finite_difference_eps / (2.0 * self.radius)

@@ -123,23 +123,23 @@ class NeuSModel(BaseModel):
 
     # ---- one ray batch ------------------------------------------------------------------------------
     def _field7(self, rays_o, rays_d, ray_indices, t_starts, t_ends):
-        """[7S, ld] tensor whose column 0 holds the SDF at each sample's centre and six FD taps.
-        Uses the fused stencil kernels when they cover the configuration (``fused: false`` in the
-        model config forces the per-layer path)."""
+        """-> (stencil, tap_major): the SDF at each sample's centre and six FD taps, either the
+        tap-major [7, S] array of the fused stencil kernels or rows 7i+t (column 0) of the per-layer
+        path's [7S, feature_dim] output (``fused: false`` in the model config forces the latter)."""
         if self.config.get("fused", True) and self.texture is None \
                 and self.geometry.fused_field_available():
-            return self.geometry.sdf7_from_rays(rays_o, rays_d, ray_indices, t_starts, t_ends)[0]
-        return self.geometry.field7_from_rays(rays_o, rays_d, ray_indices, t_starts, t_ends)
+            return self.geometry.sdf7_from_rays(rays_o, rays_d, ray_indices, t_starts, t_ends)[0], True
+        return self.geometry.field7_from_rays(rays_o, rays_d, ray_indices, t_starts, t_ends), False
 
     def _alpha_fn(self, rays_o, rays_d):
         def alpha_fn(t_starts, t_ends, ray_indices):
             if ray_indices.numel() == 0:
                 return torch.zeros((0,), device=rays_o.device)
             with torch.no_grad():
-                out7 = self._field7(rays_o, rays_d, ray_indices, t_starts, t_ends)
+                out7, tm = self._field7(rays_o, rays_d, ray_indices, t_starts, t_ends)
                 return ops.neus_alpha_fd(out7, self.variance.variance, rays_d, ray_indices,
                                          t_starts, t_ends, self.cos_anneal_ratio,
-                                         self.geometry._finite_difference_eps)[3]
+                                         self.geometry._finite_difference_eps, tap_major=tm)[3]
         return alpha_fn
 
     def forward_(self, rays, stratified_u=None):
@@ -165,10 +165,10 @@ class NeuSModel(BaseModel):
             sdf, sdf_grad = torch.zeros((0,), device=dev), torch.zeros((0, 3), device=dev)
             normal = torch.zeros((0, 3), device=dev)
         else:
-            out7 = self._field7(rays_o, rays_d, ray_indices, t_starts, t_ends)
+            out7, tm = self._field7(rays_o, rays_d, ray_indices, t_starts, t_ends)
             sdf, sdf_grad, normal, alpha = ops.neus_alpha_fd(
                 out7, self.variance.variance, rays_d, ray_indices, t_starts, t_ends,
-                self.cos_anneal_ratio, self.geometry._finite_difference_eps)
+                self.cos_anneal_ratio, self.geometry._finite_difference_eps, tap_major=tm)
         midpoints = (t_starts + t_ends)[..., None] / 2.0
         weights, _ = ops.render_weight_from_alpha(alpha, packed_info=packed)
         opacity = ops.accumulate_along_rays(weights, None, packed_info=packed)

@@ -304,9 +304,15 @@ class _HashGrid(torch.autograd.Function):
             if nbytes < 0:
                 raise L.RiseSdfHipError("hashgrid_bwd_fd7: unsupported level layout")
             scratch = torch.empty(nbytes, dtype=torch.uint8, device=xf.device)
-            check(lib().rsdf_hashgrid_bwd_fd7(ptr(xf), ptr(g), ctypes.byref(ctx.meta), S, ctx.n_active,
-                                              g.shape[1], ctx.col, float(ctx.fd7), ptr(dt),
-                                              ptr(scratch), nbytes, stream_ptr()), "hashgrid_bwd_fd7")
+            # this entry point keeps the interleaved [S,7] row layout of the reference-shaped API;
+            # re-lay out to the tap-major planes the stencil kernels consume (the fused field path
+            # produces them directly)
+            Lv = ctx.meta.n_levels
+            x7t = xf.view(S, 7, 3).permute(1, 0, 2).contiguous()
+            dpl = g[:, ctx.col:ctx.col + 2 * Lv].reshape(S, 7, Lv, 2).permute(2, 1, 0, 3).contiguous()
+            check(lib().rsdf_hashgrid_bwd_fd7(ptr(x7t), ptr(dpl), ctypes.byref(ctx.meta), S, ctx.n_active,
+                                              float(ctx.fd7), ptr(dt), ptr(scratch), nbytes,
+                                              stream_ptr()), "hashgrid_bwd_fd7")
         else:
             check(lib().rsdf_hashgrid_bwd(ptr(xf), ptr(g), ctypes.byref(ctx.meta), n, ctx.n_active,
                                           g.shape[1], ctx.col, ptr(dt), stream_ptr()), "hashgrid_bwd")
@@ -413,16 +419,19 @@ def weight_norm(g, v):
 # P1 / H4 / A1
 # ------------------------------------------------------------------------------------------------
 @torch.no_grad()
-def fd_points(rays_o, rays_d, ray_indices, t_starts, t_ends, radius, eps, want_positions=False):
-    """Sample midpoints + six clamped FD taps, AABB-contracted to [0,1]: x_unit [S,7,3]."""
+def fd_points(rays_o, rays_d, ray_indices, t_starts, t_ends, radius, eps, want_positions=False,
+              tap_major=False):
+    """Sample midpoints + six clamped FD taps, AABB-contracted to [0,1]: x_unit [S,7,3], or the
+    tap-major [7,S,3] the fused stencil kernels consume."""
     o, d, ts, te = _f32c(rays_o), _f32c(rays_d), _f32c(t_starts), _f32c(t_ends)
     ri = ray_indices.contiguous()
     require_device(o, d, ri, ts, te)
     n = ri.numel()
-    xu = torch.empty(n, 7, 3, dtype=torch.float32, device=o.device)
+    shape = (7, n, 3) if tap_major else (n, 7, 3)
+    xu = torch.empty(shape, dtype=torch.float32, device=o.device)
     pos = torch.empty(n, 3, dtype=torch.float32, device=o.device) if want_positions else None
     check(lib().rsdf_fd_points(ptr(o), ptr(d), ptr(ri), ptr(ts), ptr(te), n, float(radius), float(eps),
-                               ptr(xu), ptr(pos), stream_ptr()), "fd_points")
+                               ptr(xu), ptr(pos), int(tap_major), stream_ptr()), "fd_points")
     return (xu, pos) if want_positions else xu
 
 
@@ -471,19 +480,26 @@ class _NeusAlphaFD(torch.autograd.Function):
     """sdf7 [7S, ld] (column 0 = SDF of the 7 taps) -> sdf [S], grad [S,3], normal [S,3], alpha [S]."""
 
     @staticmethod
-    def forward(ctx, out7, variance, rays_d, ray_indices, t_starts, t_ends, cos_anneal_ratio, eps):
+    def forward(ctx, out7, variance, rays_d, ray_indices, t_starts, t_ends, cos_anneal_ratio, eps,
+                tap_major):
         o7, var = out7.detach(), _f32c(variance).reshape(1)
         d, ri, ts, te = _f32c(rays_d), ray_indices.contiguous(), _f32c(t_starts), _f32c(t_ends)
         require_device(o7, var, d, ri, ts, te)
         assert o7.dtype == torch.float32 and o7.is_contiguous() and o7.dim() == 2
         n = ri.numel()
-        assert o7.shape[0] == 7 * n
+        if tap_major:
+            assert tuple(o7.shape) == (7, n), "tap-major SDF stencil must be [7, S]"
+            ld = -1  # RSDF_TAP_MAJOR
+        else:
+            assert o7.shape[0] == 7 * n
+            ld = o7.shape[1]
+        ctx.ld = ld
         dev = o7.device
         sdf = torch.empty(n, dtype=torch.float32, device=dev)
         grad = torch.empty(n, 3, dtype=torch.float32, device=dev)
         normal = torch.empty(n, 3, dtype=torch.float32, device=dev)
         alpha = torch.empty(n, dtype=torch.float32, device=dev)
-        check(lib().rsdf_neus_alpha_fd_fwd(ptr(o7), o7.shape[1], ptr(d), ptr(ri), ptr(ts), ptr(te),
+        check(lib().rsdf_neus_alpha_fd_fwd(ptr(o7), ld, ptr(d), ptr(ri), ptr(ts), ptr(te),
                                            ptr(var), float(cos_anneal_ratio), float(eps), n,
                                            ptr(sdf), ptr(grad), ptr(normal), ptr(alpha), stream_ptr()),
               "neus_alpha_fd_fwd")
@@ -495,8 +511,9 @@ class _NeusAlphaFD(torch.autograd.Function):
     def backward(ctx, g_sdf, g_grad, g_normal, g_alpha):
         o7, var, d, ri, ts, te = ctx.saved_tensors
         n = ri.numel()
-        ld = o7.shape[1]
-        d_out7 = torch.zeros_like(o7)  # only column 0 receives gradient
+        ld = ctx.ld
+        # interleaved: only column 0 receives gradient; tap-major: every element is written
+        d_out7 = torch.empty_like(o7) if ld < 0 else torch.zeros_like(o7)
         d_var = torch.zeros(1, dtype=torch.float32, device=o7.device)
         cg = lambda t: None if t is None else _f32c(t)
         gs, gg, gn, ga = cg(g_sdf), cg(g_grad), cg(g_normal), cg(g_alpha)
@@ -504,12 +521,14 @@ class _NeusAlphaFD(torch.autograd.Function):
                                            ctx.car, ctx.eps, n, ptr(ga), ptr(gn), ptr(gs), ptr(gg),
                                            ptr(d_out7), ld, ptr(d_var), stream_ptr()),
               "neus_alpha_fd_bwd")
-        return d_out7, d_var.view(ctx.vshape), None, None, None, None, None, None
+        return d_out7, d_var.view(ctx.vshape), None, None, None, None, None, None, None
 
 
-def neus_alpha_fd(out7, variance, rays_d, ray_indices, t_starts, t_ends, cos_anneal_ratio, eps):
+def neus_alpha_fd(out7, variance, rays_d, ray_indices, t_starts, t_ends, cos_anneal_ratio, eps,
+                  tap_major=False):
+    """out7: [7S, ld] rows 7i+t (column 0 = SDF), or with ``tap_major`` the [7, S] SDF stencil."""
     return _NeusAlphaFD.apply(out7, variance, rays_d, ray_indices, t_starts, t_ends,
-                              cos_anneal_ratio, eps)
+                              cos_anneal_ratio, eps, bool(tap_major))
 
 
 class _NeusAlpha(torch.autograd.Function):

@@ -381,3 +381,29 @@ def test_hashgrid_backward_fd7(dev, ops, gi, eps_unit):
     err = float((t_g.grad.cpu() - t_o.grad).abs().max())
     assert err < 1e-5 * scale + 1e-7, (err, scale)
     assert int((t_g.grad.cpu() != 0).sum()) == int((t_o.grad != 0).sum())
+
+
+def test_hashgrid_forward_fd7_bit_exact(dev, ops):
+    """Stencil-merged forward (one gather of the centre cell + 4 corners per displaced tap) must equal
+    the generic per-point encoding bit for bit, including taps clamped at the box and eps > one cell."""
+    import ctypes
+    from rise_sdf_amd import _lib
+    cfg = GRIDS[1]
+    meta_o, n_params = oracle.grid_meta(**cfg)
+    meta_g, _ = _lib.make_grid_meta(**cfg)
+    g = torch.Generator().manual_seed(31)
+    table = (torch.rand(n_params, generator=g) * 2 - 1) * 1e-4
+    S = 2500
+    for eps_unit in (1.0 / 8192, 1.0 / 1291, 3.0 / 8192):
+        centre = torch.rand(S, 3, generator=g)
+        centre[:3] = torch.tensor([[0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [0.5, 0.0, 1.0]])
+        offs = torch.tensor([[0, 0, 0], [1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]],
+                            dtype=torch.float32) * eps_unit
+        x7t = (centre[None, :, :] + offs[:, None, :]).clamp(0.0, 1.0).contiguous()  # [7,S,3]
+        ref = oracle.hashgrid_encode(x7t.reshape(-1, 3), table, meta_o).view(7, S, 16, 2)
+        planes = torch.empty(16, 7, S, 2, device=dev)
+        xg, tg = x7t.to(dev), table.to(dev)
+        rc = _lib.lib().rsdf_hashgrid_fwd_fd7(_lib.ptr(xg), _lib.ptr(tg), ctypes.byref(meta_g), S, 16,
+                                              _lib.ptr(planes), _lib.stream_ptr())
+        assert rc == 0
+        assert torch.equal(planes.cpu().permute(1, 2, 0, 3), ref), eps_unit
