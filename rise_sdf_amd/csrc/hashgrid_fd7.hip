@@ -45,6 +45,7 @@ struct LevelPlan {
     int count;                       // active levels
     int n_bins[RSDF_MAX_LEVELS];
     int interleaved[RSDF_MAX_LEVELS];  // 1: bin = idx % n_bins (dense levels), 0: bin = idx >> 14
+    int n_split[RSDF_MAX_LEVELS];      // reducer workgroups per bin (balances the per-level load)
     int64_t cap[RSDF_MAX_LEVELS];      // records per bin queue
     int64_t queue_off[RSDF_MAX_LEVELS];
     int counter_off[RSDF_MAX_LEVELS];
@@ -355,10 +356,11 @@ fd7_produce_kernel(const float *__restrict__ x7t, const float2 *__restrict__ dpl
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(R_THREADS)
 fd7_reduce_kernel(const rsdf_grid_meta meta, const LevelPlan plan, const Record *__restrict__ queues,
-                  const int *__restrict__ counters, int n_split, float *__restrict__ dtable)
+                  const int *__restrict__ counters, float *__restrict__ dtable)
 {
     extern __shared__ __attribute__((aligned(16))) float s_acc[];  // [BIN_ENTRIES][2]
     const int l = blockIdx.y;
+    const int n_split = plan.n_split[l];
     const int b = blockIdx.x / n_split, part = blockIdx.x % n_split;
     const int n_bins = plan.n_bins[l];
     if (b >= n_bins) return;
@@ -423,6 +425,11 @@ int make_plan(const rsdf_grid_meta *meta, int64_t S, int n_active, float eps_uni
     plan->count = n_active;
     int64_t qoff = 0;
     int coff = 0;
+    double total_exp = 0.0;
+    for (int l = 0; l < n_active; ++l) total_exp += (double)S * expected_records(meta->scale[l], eps_unit);
+    // aim at ~3 reducer workgroups per CU, each with the same number of records
+    double per_wg = total_exp / 768.0;
+    if (per_wg < 65536.0) per_wg = 65536.0;
     for (int l = 0; l < n_active; ++l) {
         const uint32_t size = meta->size[l];
         const uint64_t dense = (uint64_t)meta->res[l] * meta->res[l] * meta->res[l];
@@ -434,6 +441,8 @@ int make_plan(const rsdf_grid_meta *meta, int64_t S, int n_active, float eps_uni
         plan->interleaved[l] = is_dense ? 1 : 0;
         const double per_bin = (double)S * expected_records(meta->scale[l], eps_unit) / nb;
         plan->cap[l] = (int64_t)(per_bin * 1.15) + 16384;
+        int ns = (int)(per_bin / per_wg + 0.999);
+        plan->n_split[l] = ns < 1 ? 1 : (ns > 256 ? 256 : ns);
         plan->queue_off[l] = qoff;
         plan->counter_off[l] = coff;
         qoff += plan->cap[l] * nb;
@@ -512,9 +521,11 @@ int rsdf_hashgrid_bwd_fd7(const float *x7t, const float *dplanes, const rsdf_gri
     dim3 pgrid(rsdf_blocks(n_samples, P_THREADS), na);
     fd7_produce_kernel<<<pgrid, P_THREADS, 0, st>>>(x7t, reinterpret_cast<const float2 *>(dplanes), *meta,
                                                     plan, n_samples, queues, counters, dtable);
-    int max_bins = 0;
-    for (int l = 0; l < na; ++l) max_bins = plan.n_bins[l] > max_bins ? plan.n_bins[l] : max_bins;
-    const int n_split = 2;
+    int max_wgs = 0;
+    for (int l = 0; l < na; ++l) {
+        const int w = plan.n_bins[l] * plan.n_split[l];
+        max_wgs = w > max_wgs ? w : max_wgs;
+    }
     const size_t lds = (size_t)BIN_ENTRIES * 2 * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
@@ -522,8 +533,8 @@ int rsdf_hashgrid_bwd_fd7(const float *x7t, const float *dplanes, const rsdf_gri
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    dim3 rgrid(max_bins * n_split, na);
-    fd7_reduce_kernel<<<rgrid, R_THREADS, lds, st>>>(*meta, plan, queues, counters, n_split, dtable);
+    dim3 rgrid(max_wgs, na);
+    fd7_reduce_kernel<<<rgrid, R_THREADS, lds, st>>>(*meta, plan, queues, counters, dtable);
     RSDF_RETURN_LAUNCH();
 }
 
