@@ -125,6 +125,14 @@ def roofline_from(summary, steps):
         if name == "rsdf_hashgrid_bwd":      # n, n_active, ld, col_off
             n, L = a[0], 16
             return "hbm", n * (L * 8 * 2 * 4 + 12 + L * 2 * 4)
+        if name in ("rsdf_hashgrid_fwd_fd7", "rsdf_hashgrid_bwd_fd7"):   # n_samples, n_active, ...
+            return "hbm", 7 * a[0] * (16 * 8 * 2 * 4 + 12 + 16 * 2 * 4)   # 7 evaluations x 1164 B
+        if name == "rsdf_sdfmlp_fd7_fwd":    # L, n_active, xyz_scale, xyz_offset, H, N2, n_samples
+            K0, H, S = 3 + 2 * a[0], a[4], a[6]
+            return "mfma", 2.0 * 7 * S * (K0 * H + H * H + H)            # last layer: SDF column only
+        if name == "rsdf_sdfmlp_fd7_bwd":    # recompute (1x) + input/weight gradients (2x)
+            K0, H, S = 3 + 2 * a[0], a[4], a[6]
+            return "mfma", 3 * 2.0 * 7 * S * (K0 * H + H * H + H)
         if name == "rsdf_linear_fwd":        # ldx, n, K, N, act, ldy
             return "mfma", 2.0 * a[1] * a[2] * a[3]
         if name == "rsdf_linear_bwd_input":  # lddy, n, K, N, act, k0, Kout, lddx

@@ -15,11 +15,12 @@
 // (MI355X_MICROARCH.md "Global float atomics"): a scattered 4-byte add costs a whole request and
 // the stencil produces 1792 of them per sample (the r01a profile: 49 % of the step).  Instead:
 //   1. PRODUCE: one thread per (sample, level) merges the taps' contributions in registers into
-//      the same 8..32 corners, bins the (entry, value) records by table slice (<= 16384 entries, one
+//      the same 8..32 corners, bins the (entry, value) records by table slice (<= 8192 entries, one
 //      LDS image), counting-sorts them by bin inside the workgroup through LDS and appends each bin's
 //      run to its queue in HBM with coalesced 12-byte stores.
 //   2. REDUCE: one workgroup per (level, bin, split) streams its queue (4 records in flight per
-//      thread), accumulates into a 128 KiB LDS image with ds_add_f32 and adds the image to dtable
+//      thread), accumulates into a 128 KiB fp64 LDS image with ds_add_f64 (measured 18x the rate of
+//      ds_add_f32 on gfx950, tools/lds_atomic_bench.hip) and adds the image to dtable
 //      with contiguous (full-rate) global atomics.
 // Hashed levels bin by the high index bits; dense levels bin by idx % n_bins so that a spatially
 // compact batch of rays still loads all bins evenly.
@@ -27,10 +28,14 @@
 
 namespace {
 
-constexpr int BIN_SHIFT = 14;
-constexpr int BIN_ENTRIES = 1 << BIN_SHIFT;  // 16384 entries x 2 floats = 128 KiB of LDS
+constexpr int BIN_SHIFT = 13;
+constexpr int BIN_ENTRIES = 1 << BIN_SHIFT;  // 8192 entries x 2 doubles = 128 KiB of LDS
 constexpr int MAX_BINS = 64;
-constexpr int P_THREADS = 256;  // producer / forward: samples per workgroup
+constexpr int F_THREADS = 256;   // forward: samples per workgroup
+// producer: samples per workgroup.  Large on purpose: a workgroup appends one run per bin per round,
+// and HBM write efficiency follows the run length (256 threads: ~0.4 KB runs, 1.6 TB/s; 1024 threads:
+// ~1.5 KB runs) -- measured with the RSDF ablation in profiles/README.md.
+constexpr int P_THREADS = 1024;
 constexpr int ROUND_RECS = 8;
 constexpr int STAGE_CAP = P_THREADS * ROUND_RECS;
 constexpr int R_THREADS = 1024;  // reducer
@@ -96,11 +101,11 @@ __device__ __forceinline__ uint32_t extra_index(const CellFrac &c0, int a, int k
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(P_THREADS)
+__global__ void __launch_bounds__(F_THREADS)
 fd7_fwd_kernel(const float *__restrict__ x7t, const float *__restrict__ table,
                const rsdf_grid_meta meta, int64_t S, float2 *__restrict__ planes)
 {
-    const int64_t s = (int64_t)blockIdx.x * P_THREADS + threadIdx.x;
+    const int64_t s = (int64_t)blockIdx.x * F_THREADS + threadIdx.x;
     if (s >= S) return;
     const int l = blockIdx.y;
     const LevelGeom g = level_geom(meta, l);
@@ -192,10 +197,13 @@ __device__ __forceinline__ void emit_round(const uint32_t (&ridx)[ROUND_RECS],
                                            float *__restrict__ dlevel, int *s_cnt, int *s_off,
                                            int *s_gbase, Record *s_stage)
 {
+    // s_cnt is all zero on entry (zeroed by the kernel prologue / the previous round's scan).
+    // Three barriers per non-empty round, two per empty one:
+    //   slots -> A -> scan (+ re-zero counts) -> B -> stage -> C -> copy out.
+    // No barrier is needed after the copy-out: the next round's scan (which overwrites s_off /
+    // s_gbase) runs after its barrier A, and its stage writes after its barrier B, both of which
+    // every thread reaches only after finishing this copy-out.
     const int tid = threadIdx.x;
-    if (!__syncthreads_or(valid_mask != 0)) return;
-    if (tid < n_bins) s_cnt[tid] = 0;
-    __syncthreads();
     int slot[ROUND_RECS], bin[ROUND_RECS];
 #pragma unroll
     for (int r = 0; r < ROUND_RECS; ++r) {
@@ -206,22 +214,24 @@ __device__ __forceinline__ void emit_round(const uint32_t (&ridx)[ROUND_RECS],
             slot[r] = atomicAdd(&s_cnt[bin[r]], 1);
         }
     }
-    __syncthreads();
+    __syncthreads();  // A
     if (tid < 64) {  // first wavefront: exclusive scan of the bin counts + queue reservations
         const int c = tid < n_bins ? s_cnt[tid] : 0;
         const int incl = wave_incl_sum_i(c);
         if (tid < n_bins) {
             s_off[tid] = incl - c;
             s_gbase[tid] = c > 0 ? atomicAdd(&qcount[tid], c) : 0;
+            s_cnt[tid] = 0;
         }
         if (tid == 63) s_off[MAX_BINS] = incl;
     }
-    __syncthreads();
+    __syncthreads();  // B
+    const int total = s_off[MAX_BINS];
+    if (total == 0) return;  // uniform
 #pragma unroll
     for (int r = 0; r < ROUND_RECS; ++r)
         if (valid_mask & (1u << r)) s_stage[s_off[bin[r]] + slot[r]] = Record{ridx[r], rval[r].x, rval[r].y};
-    __syncthreads();
-    const int total = s_off[MAX_BINS];
+    __syncthreads();  // C
     for (int i = tid; i < total; i += P_THREADS) {
         const Record rec = s_stage[i];
         const int b = bin_of(rec.idx, n_bins, interleaved);
@@ -233,7 +243,6 @@ __device__ __forceinline__ void emit_round(const uint32_t (&ridx)[ROUND_RECS],
             atomicAdd(dlevel + 2 * (size_t)rec.idx + 1, rec.v1);
         }
     }
-    __syncthreads();
 }
 
 __global__ void __launch_bounds__(P_THREADS)
@@ -245,7 +254,9 @@ fd7_produce_kernel(const float *__restrict__ x7t, const float2 *__restrict__ dpl
     __shared__ int s_cnt[MAX_BINS];
     __shared__ int s_off[MAX_BINS + 1];
     __shared__ int s_gbase[MAX_BINS];
-    __shared__ Record s_stage[STAGE_CAP];
+    extern __shared__ __attribute__((aligned(16))) Record s_stage[];  // [STAGE_CAP]
+    if (threadIdx.x < MAX_BINS) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
 
     const int l = blockIdx.y;
     const LevelGeom g = level_geom(meta, l);
@@ -358,7 +369,7 @@ __global__ void __launch_bounds__(R_THREADS)
 fd7_reduce_kernel(const rsdf_grid_meta meta, const LevelPlan plan, const Record *__restrict__ queues,
                   const int *__restrict__ counters, float *__restrict__ dtable)
 {
-    extern __shared__ __attribute__((aligned(16))) float s_acc[];  // [BIN_ENTRIES][2]
+    extern __shared__ __attribute__((aligned(16))) double s_acc[];  // [BIN_ENTRIES][2], fp64: see below
     const int l = blockIdx.y;
     const int n_split = plan.n_split[l];
     const int b = blockIdx.x / n_split, part = blockIdx.x % n_split;
@@ -378,7 +389,7 @@ fd7_reduce_kernel(const rsdf_grid_meta meta, const LevelPlan plan, const Record 
     const int entries = interleaved ? (int)((size - (uint32_t)b + (uint32_t)n_bins - 1u) / (uint32_t)n_bins)
                                     : (int)(size < (uint32_t)BIN_ENTRIES ? size : (uint32_t)BIN_ENTRIES);
 
-    for (int i = threadIdx.x; i < entries * 2; i += R_THREADS) s_acc[i] = 0.0f;
+    for (int i = threadIdx.x; i < entries * 2; i += R_THREADS) s_acc[i] = 0.0;
     __syncthreads();
     const Record *q = queues + plan.queue_off[l] + (int64_t)b * cap;
     for (int64_t i0 = r0 + threadIdx.x; i0 < r1; i0 += (int64_t)R_THREADS * R_UNROLL) {
@@ -393,15 +404,15 @@ fd7_reduce_kernel(const rsdf_grid_meta meta, const LevelPlan plan, const Record 
             if (i0 + (int64_t)u * R_THREADS < r1) {
                 const uint32_t e = interleaved ? rec[u].idx / (uint32_t)n_bins
                                                : (rec[u].idx & (uint32_t)(BIN_ENTRIES - 1));
-                atomicAdd(&s_acc[2 * e], rec[u].v0);
-                atomicAdd(&s_acc[2 * e + 1], rec[u].v1);
+                atomicAdd(&s_acc[2 * e], (double)rec[u].v0);
+                atomicAdd(&s_acc[2 * e + 1], (double)rec[u].v1);
             }
         }
     }
     __syncthreads();
     float *dlevel = dtable + (size_t)meta.offset[l] * 2;
     for (int i = threadIdx.x; i < entries * 2; i += R_THREADS) {
-        const float val = s_acc[i];
+        const float val = (float)s_acc[i];
         if (val != 0.0f) {
             const size_t e = (size_t)(i >> 1);
             const size_t idx = interleaved ? e * (size_t)n_bins + (size_t)b : (size_t)b * BIN_ENTRIES + e;
@@ -477,8 +488,8 @@ int rsdf_hashgrid_fwd_fd7(const float *x7t, const float *table, const rsdf_grid_
         RSDF_CHECK_ARG(dense <= meta->size[l] || (meta->size[l] & (meta->size[l] - 1u)) == 0,
                        "hashgrid_fwd_fd7: hashed level sizes must be powers of two");
     }
-    dim3 grid(rsdf_blocks(n_samples, P_THREADS), na);
-    fd7_fwd_kernel<<<grid, P_THREADS, 0, (hipStream_t)stream>>>(x7t, table, *meta, n_samples,
+    dim3 grid(rsdf_blocks(n_samples, F_THREADS), na);
+    fd7_fwd_kernel<<<grid, F_THREADS, 0, (hipStream_t)stream>>>(x7t, table, *meta, n_samples,
                                                                  reinterpret_cast<float2 *>(planes));
     RSDF_RETURN_LAUNCH();
 }
@@ -519,14 +530,21 @@ int rsdf_hashgrid_bwd_fd7(const float *x7t, const float *dplanes, const rsdf_gri
     Record *queues = (Record *)((char *)scratch + cbytes);
     (void)hipMemsetAsync(counters, 0, cbytes, st);
     dim3 pgrid(rsdf_blocks(n_samples, P_THREADS), na);
-    fd7_produce_kernel<<<pgrid, P_THREADS, 0, st>>>(x7t, reinterpret_cast<const float2 *>(dplanes), *meta,
+    const size_t stage_bytes = (size_t)STAGE_CAP * sizeof(Record);
+    static bool pattr_set = false;
+    if (!pattr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fd7_produce_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_bytes);
+        pattr_set = true;
+    }
+    fd7_produce_kernel<<<pgrid, P_THREADS, stage_bytes, st>>>(x7t, reinterpret_cast<const float2 *>(dplanes), *meta,
                                                     plan, n_samples, queues, counters, dtable);
     int max_wgs = 0;
     for (int l = 0; l < na; ++l) {
         const int w = plan.n_bins[l] * plan.n_split[l];
         max_wgs = w > max_wgs ? w : max_wgs;
     }
-    const size_t lds = (size_t)BIN_ENTRIES * 2 * sizeof(float);
+    const size_t lds = (size_t)BIN_ENTRIES * 2 * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fd7_reduce_kernel),
