@@ -24,8 +24,10 @@ namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int THREADS = 256;
+constexpr int THREADS = 256;      // backward: 4 waves (408 VGPRs, one wave per SIMD)
 constexpr int WAVES = 4;
+constexpr int FWD_WAVES = 8;      // forward: 8 waves = two per SIMD, so one wave's Softplus overlaps the other's MFMAs
+constexpr int FWD_THREADS = FWD_WAVES * 64;
 constexpr int K0P = 36;       // padded input width (3 + 2*16 = 35 -> 36)
 constexpr int LDX = K0P + 1;  // 37: odd LDS row stride
 constexpr int LDT = 33;       // [feature][row] transposed tiles
@@ -40,9 +42,10 @@ __device__ __forceinline__ float softplus100(float z)
     const float e = __expf(-fabsf(t));
     return fmaxf(z, 0.0f) + __logf(1.0f + e) * 0.01f;
 }
-__device__ __forceinline__ float softplus100_grad_from_z(float z)
+// h = log(1 + e^{100 z}) / 100  =>  sigmoid(100 z) = 1 - e^{-100 h}: the backward needs only h
+__device__ __forceinline__ float softplus100_grad_from_h(float h)
 {
-    return 1.0f / (1.0f + __expf(-100.0f * z));
+    return 1.0f - __expf(-100.0f * h);
 }
 
 template <int H>
@@ -74,23 +77,24 @@ __device__ __forceinline__ void stage_all_weights(float *sm, const float *__rest
                                                   const float *__restrict__ b2, int K0, int N2)
 {
     using S = Smem<H>;
-    for (int e = threadIdx.x; e < H * K0P; e += THREADS) {
+    const int NTHR = blockDim.x;
+    for (int e = threadIdx.x; e < H * K0P; e += NTHR) {
         const int r = e / K0P, c = e - r * K0P;
         sm[S::W0 + r * LDX + c] = c < K0 ? w0[r * K0 + c] : 0.0f;
     }
-    for (int e = threadIdx.x; e < H * H; e += THREADS) {
+    for (int e = threadIdx.x; e < H * H; e += NTHR) {
         const int r = e / H, c = e - r * H;
         sm[S::W1 + r * S::LDW1 + c] = w1[e];
     }
-    for (int e = threadIdx.x; e < 64 * H; e += THREADS) {
+    for (int e = threadIdx.x; e < 64 * H; e += NTHR) {
         const int r = e / H, c = e - r * H;
         sm[S::W2 + r * S::LDW1 + c] = r < N2 ? w2[r * H + c] : 0.0f;
     }
-    for (int e = threadIdx.x; e < H; e += THREADS) {
+    for (int e = threadIdx.x; e < H; e += NTHR) {
         sm[S::B0 + e] = b0[e];
         sm[S::B1 + e] = b1[e];
     }
-    for (int e = threadIdx.x; e < 64; e += THREADS) sm[S::B2 + e] = e < N2 ? b2[e] : 0.0f;
+    for (int e = threadIdx.x; e < 64; e += NTHR) sm[S::B2 + e] = e < N2 ? b2[e] : 0.0f;
 }
 
 // Input tile of one (32-sample group, tap): [32 rows][K0P] = [xyz*scale+offset | L*2 hash features | 0]
@@ -134,7 +138,6 @@ __device__ __forceinline__ void store_tile(float *Xs, const float (&pre)[18], co
 // hidden layers 1 and 2, transposed: h[t][r] holds feature t*32 + n_lo(r) + 4*lh of row (lane & 31)
 template <int H>
 __device__ __forceinline__ void hidden_forward(const float *sm, const float *Xs, int li, int lh,
-                                               f32x16 (&z1)[H / 32], f32x16 (&z2)[H / 32],
                                                f32x16 (&h1)[H / 32], f32x16 (&h2)[H / 32])
 {
     using S = Smem<H>;
@@ -142,23 +145,23 @@ __device__ __forceinline__ void hidden_forward(const float *sm, const float *Xs,
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) z1[t][r] = sm[S::B0 + t * 32 + n_lo(r) + 4 * lh];
+        for (int r = 0; r < 16; ++r) h1[t][r] = sm[S::B0 + t * 32 + n_lo(r) + 4 * lh];
     for (int k0 = 0; k0 < K0P; k0 += 2) {
         const float b = Xs[li * LDX + k0 + lh];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const float a = sm[S::W0 + (t * 32 + li) * LDX + k0 + lh];
-            z1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, z1[t], 0, 0, 0);
+            h1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, h1[t], 0, 0, 0);
         }
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) h1[t][r] = softplus100(z1[t][r]);
+        for (int r = 0; r < 16; ++r) h1[t][r] = softplus100(h1[t][r]);
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) z2[t][r] = sm[S::B1 + t * 32 + n_lo(r) + 4 * lh];
+        for (int r = 0; r < 16; ++r) h2[t][r] = sm[S::B1 + t * 32 + n_lo(r) + 4 * lh];
 #pragma unroll
     for (int tk = 0; tk < NT; ++tk)
 #pragma unroll
@@ -167,20 +170,20 @@ __device__ __forceinline__ void hidden_forward(const float *sm, const float *Xs,
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const float a = sm[S::W1 + (t * 32 + li) * S::LDW1 + k];
-                z2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, h1[tk][r], z2[t], 0, 0, 0);
+                h2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, h1[tk][r], h2[t], 0, 0, 0);
             }
         }
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) h2[t][r] = softplus100(z2[t][r]);
+        for (int r = 0; r < 16; ++r) h2[t][r] = softplus100(h2[t][r]);
 }
 
 // ------------------------------------------------------------------------------------------------
 // forward: enc [7S, ldx] -> sdf7 [7S], feature [S, N2] (nullable; centre rows only)
 // ------------------------------------------------------------------------------------------------
 template <int H>
-__global__ void __launch_bounds__(THREADS)
+__global__ void __launch_bounds__(FWD_THREADS)
 sdfmlp_fwd_kernel(const TileSrc src, const float *__restrict__ w0,
                   const float *__restrict__ b0, const float *__restrict__ w1,
                   const float *__restrict__ b1, const float *__restrict__ w2,
@@ -199,7 +202,7 @@ sdfmlp_fwd_kernel(const TileSrc src, const float *__restrict__ w0,
     __syncthreads();
 
     const int64_t n_groups = (n_samples + 31) / 32;  // 32 samples per wave iteration
-    const int64_t g_first = (int64_t)blockIdx.x * WAVES + wave, g_step = (int64_t)gridDim.x * WAVES;
+    const int64_t g_first = (int64_t)blockIdx.x * FWD_WAVES + wave, g_step = (int64_t)gridDim.x * FWD_WAVES;
     float pre[18];
     if (g_first < n_groups) fetch_tile(pre, src, g_first * 32, 0, lane);
     for (int64_t g = g_first; g < n_groups; g += g_step) {
@@ -211,8 +214,8 @@ sdfmlp_fwd_kernel(const TileSrc src, const float *__restrict__ w0,
                 const int64_t ng = tap == 6 ? g + g_step : g;
                 if (ng < n_groups) fetch_tile(pre, src, ng * 32, ntap, lane);
             }
-            f32x16 z1[NT], z2[NT], h1[NT], h2[NT];
-            hidden_forward<H>(smem, Xs, li, lh, z1, z2, h1, h2);
+            f32x16 h1[NT], h2[NT];
+            hidden_forward<H>(smem, Xs, li, lh, h1, h2);
             const int64_t s = s0 + li;
             if (tap == 0 && feature != nullptr) {
                 // full last layer on the matrix cores: out[n2][row]
@@ -316,8 +319,8 @@ sdfmlp_bwd_kernel(const TileSrc src, const float *__restrict__ w0,
                 const int64_t ng = tap == 6 ? g + g_step : g;
                 if (ng < n_groups) fetch_tile(pre, src, ng * 32, ntap, lane);
             }
-            f32x16 z1[NT], z2[NT], h1[NT], h2[NT];
-            hidden_forward<H>(smem, Xs, li, lh, z1, z2, h1, h2);
+            f32x16 h1[NT], h2[NT];
+            hidden_forward<H>(smem, Xs, li, lh, h1, h2);
             const int64_t s = s0 + li;
             const float dsdf = s < n_samples ? d_sdf7[(int64_t)tap * n_samples + s] : 0.0f;
 
@@ -344,7 +347,7 @@ sdfmlp_bwd_kernel(const TileSrc src, const float *__restrict__ w0,
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int k = t * 32 + n_lo(r) + 4 * lh;
-                    dz2[t][r] = smem[S::W2 + k] * dsdf * softplus100_grad_from_z(z2[t][r]);
+                    dz2[t][r] = smem[S::W2 + k] * dsdf * softplus100_grad_from_h(h2[t][r]);
                 }
 
             // ---- layer 2: dW1 += dz2^T h1 ; db1 += colsum(dz2) ; dh1 = W1^T dz2 -------------------
@@ -394,7 +397,7 @@ sdfmlp_bwd_kernel(const TileSrc src, const float *__restrict__ w0,
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dz1[t][r] *= softplus100_grad_from_z(z1[t][r]);
+                for (int r = 0; r < 16; ++r) dz1[t][r] *= softplus100_grad_from_h(h1[t][r]);
 
             // ---- layer 1: dW0 += dz1^T x ; db0 += colsum(dz1) ; dx = W0^T dz1 (column window) ------
 #pragma unroll
@@ -479,7 +482,7 @@ sdfmlp_bwd_kernel(const TileSrc src, const float *__restrict__ w0,
 }
 
 template <int H>
-size_t fwd_lds() { return (size_t)(Smem<H>::SHARED + WAVES * Smem<H>::PER_WAVE_FWD) * sizeof(float); }
+size_t fwd_lds() { return (size_t)(Smem<H>::SHARED + FWD_WAVES * Smem<H>::PER_WAVE_FWD) * sizeof(float); }
 template <int H>
 size_t bwd_lds() { return (size_t)(Smem<H>::SHARED + WAVES * Smem<H>::PER_WAVE_BWD) * sizeof(float); }
 
@@ -492,10 +495,10 @@ int set_lds(K kern, size_t bytes)
     return 0;
 }
 
-unsigned persistent_grid(int64_t n_samples)
+unsigned persistent_grid(int64_t n_samples, int waves)
 {
     const int64_t groups = (n_samples + 31) / 32;
-    const int64_t want = (groups + WAVES - 1) / WAVES;
+    const int64_t want = (groups + waves - 1) / waves;
     return (unsigned)(want < 512 ? (want > 0 ? want : 1) : 512);
 }
 
@@ -519,16 +522,16 @@ int rsdf_sdfmlp_fd7_fwd(const float *x7t, const float *planes, int n_levels, int
     if (n_samples <= 0) return 0;
     if (n_active_levels < 0 || n_active_levels > n_levels) n_active_levels = n_levels;
     hipStream_t st = (hipStream_t)stream;
-    const unsigned grid = persistent_grid(n_samples);
+    const unsigned grid = persistent_grid(n_samples, FWD_WAVES);
     const TileSrc src{x7t, planes, n_samples, n_levels, n_active_levels, xyz_scale, xyz_offset};
     int rc;
     if (H == 64) {
         if ((rc = set_lds(sdfmlp_fwd_kernel<64>, fwd_lds<64>()))) return rc;
-        sdfmlp_fwd_kernel<64><<<grid, THREADS, fwd_lds<64>(), st>>>(src, w0, b0, w1, b1, w2, b2, N2, sdf7t,
+        sdfmlp_fwd_kernel<64><<<grid, FWD_THREADS, fwd_lds<64>(), st>>>(src, w0, b0, w1, b1, w2, b2, N2, sdf7t,
                                                                      feature);
     } else {
         if ((rc = set_lds(sdfmlp_fwd_kernel<32>, fwd_lds<32>()))) return rc;
-        sdfmlp_fwd_kernel<32><<<grid, THREADS, fwd_lds<32>(), st>>>(src, w0, b0, w1, b1, w2, b2, N2, sdf7t,
+        sdfmlp_fwd_kernel<32><<<grid, FWD_THREADS, fwd_lds<32>(), st>>>(src, w0, b0, w1, b1, w2, b2, N2, sdf7t,
                                                                      feature);
     }
     RSDF_RETURN_LAUNCH();
@@ -547,7 +550,7 @@ int rsdf_sdfmlp_fd7_bwd(const float *x7t, const float *planes, int n_levels, int
     if (n_samples <= 0) return 0;
     if (n_active_levels < 0 || n_active_levels > n_levels) n_active_levels = n_levels;
     hipStream_t st = (hipStream_t)stream;
-    const unsigned grid = persistent_grid(n_samples);
+    const unsigned grid = persistent_grid(n_samples, WAVES);
     const TileSrc src{x7t, planes, n_samples, n_levels, n_active_levels, xyz_scale, xyz_offset};
     int rc;
     if (H == 64) {
