@@ -188,7 +188,7 @@ sdfmlp_fwd_kernel(const TileSrc src, const float *__restrict__ w0,
                   const float *__restrict__ b0, const float *__restrict__ w1,
                   const float *__restrict__ b1, const float *__restrict__ w2,
                   const float *__restrict__ b2, int N2, float *__restrict__ sdf7,
-                  float *__restrict__ feature)
+                  float *__restrict__ feature, float *__restrict__ h2c)
 {
     const int64_t n_samples = src.S;
     const int K0 = 3 + 2 * src.n_levels;
@@ -218,6 +218,16 @@ sdfmlp_fwd_kernel(const TileSrc src, const float *__restrict__ w0,
             hidden_forward<H>(smem, Xs, li, lh, h1, h2);
             const int64_t s = s0 + li;
             if (tap == 0 && feature != nullptr) {
+                if (h2c != nullptr) {  // second hidden layer of the centre rows, for the dW2 of features
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) Fs[li * 65 + t * 32 + n_lo(r) + 4 * lh] = h2[t][r];
+                    for (int e = lane; e < 32 * H; e += 64) {
+                        const int r = e / H, c = e - r * H;
+                        if (s0 + r < n_samples) h2c[(s0 + r) * H + c] = Fs[r * 65 + c];
+                    }
+                }
                 // full last layer on the matrix cores: out[n2][row]
                 f32x16 o[2];
 #pragma unroll
@@ -272,7 +282,8 @@ sdfmlp_bwd_kernel(const TileSrc src, const float *__restrict__ w0,
                   const float *__restrict__ b0, const float *__restrict__ w1,
                   const float *__restrict__ b1, const float *__restrict__ w2,
                   const float *__restrict__ b2, int N2,
-                  const float *__restrict__ d_sdf7, float *__restrict__ d_planes,
+                  const float *__restrict__ d_sdf7, const float *__restrict__ d_feature,
+                  float *__restrict__ d_planes,
                   float *__restrict__ dw0, float *__restrict__ db0,
                   float *__restrict__ dw1, float *__restrict__ db1, float *__restrict__ dw2,
                   float *__restrict__ db2)
@@ -324,7 +335,30 @@ sdfmlp_bwd_kernel(const TileSrc src, const float *__restrict__ w0,
             const int64_t s = s0 + li;
             const float dsdf = s < n_samples ? d_sdf7[(int64_t)tap * n_samples + s] : 0.0f;
 
-            // ---- layer 3 (SDF column only): dh2 = W2[0,:] * dsdf ; dW2[0,:] += dsdf * h2 ---------
+            // ---- layer 3, feature part (centre rows): dh2 = W2^T d_feature on the matrix cores.  The
+            // matching dW2 += d_feature^T h2 is formed outside from the h2 the forward saved.
+            f32x16 dh2[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dh2[t][r] = 0.0f;
+            if (tap == 0 && d_feature != nullptr) {
+                float *Fs = Ta;  // [32][65] scratch over Ta|Td (both idle here)
+                for (int e = lane; e < 32 * 64; e += 64) {
+                    const int r = e >> 6, c = e & 63;
+                    Fs[r * 65 + c] = (s0 + r < n_samples && c < N2) ? d_feature[(s0 + r) * N2 + c] : 0.0f;
+                }
+                const int n2p = (N2 + 1) & ~1;
+                for (int n2 = 0; n2 < n2p; n2 += 2) {
+                    const float b = Fs[li * 65 + n2 + lh];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const float a = smem[S::W2 + (n2 + lh) * S::LDW1 + t * 32 + li];
+                        dh2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, dh2[t], 0, 0, 0);
+                    }
+                }
+            }
+            // ---- layer 3 (SDF column): dh2 += W2[0,:] * dsdf ; dW2[0,:] += dsdf * h2 ---------------
             // h2 -> Ta as [feature][row]
 #pragma unroll
             for (int t = 0; t < NT; ++t)
@@ -347,7 +381,7 @@ sdfmlp_bwd_kernel(const TileSrc src, const float *__restrict__ w0,
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int k = t * 32 + n_lo(r) + 4 * lh;
-                    dz2[t][r] = smem[S::W2 + k] * dsdf * softplus100_grad_from_h(h2[t][r]);
+                    dz2[t][r] = (smem[S::W2 + k] * dsdf + dh2[t][r]) * softplus100_grad_from_h(h2[t][r]);
                 }
 
             // ---- layer 2: dW1 += dz2^T h1 ; db1 += colsum(dz2) ; dh1 = W1^T dz2 -------------------
@@ -514,10 +548,12 @@ int rsdf_sdfmlp_fd7_supported(int K0, int H, int N2)
 int rsdf_sdfmlp_fd7_fwd(const float *x7t, const float *planes, int n_levels, int n_active_levels,
                         float xyz_scale, float xyz_offset, int H, int N2, const float *w0,
                         const float *b0, const float *w1, const float *b1, const float *w2,
-                        const float *b2, int64_t n_samples, float *sdf7t, float *feature, void *stream)
+                        const float *b2, int64_t n_samples, float *sdf7t, float *feature, float *h2c,
+                        void *stream)
 {
     const int K0 = 3 + 2 * n_levels;
     RSDF_CHECK_ARG(n_levels >= 1 && n_levels <= 16, "sdfmlp_fd7_fwd: n_levels must be in [1,16]");
+    RSDF_CHECK_ARG(h2c == nullptr || feature != nullptr, "sdfmlp_fd7_fwd: h2c needs feature");
     RSDF_CHECK_ARG(rsdf_sdfmlp_fd7_supported(K0, H, N2), "sdfmlp_fd7_fwd: unsupported layer sizes");
     if (n_samples <= 0) return 0;
     if (n_active_levels < 0 || n_active_levels > n_levels) n_active_levels = n_levels;
@@ -528,11 +564,11 @@ int rsdf_sdfmlp_fd7_fwd(const float *x7t, const float *planes, int n_levels, int
     if (H == 64) {
         if ((rc = set_lds(sdfmlp_fwd_kernel<64>, fwd_lds<64>()))) return rc;
         sdfmlp_fwd_kernel<64><<<grid, FWD_THREADS, fwd_lds<64>(), st>>>(src, w0, b0, w1, b1, w2, b2, N2, sdf7t,
-                                                                     feature);
+                                                                     feature, h2c);
     } else {
         if ((rc = set_lds(sdfmlp_fwd_kernel<32>, fwd_lds<32>()))) return rc;
         sdfmlp_fwd_kernel<32><<<grid, FWD_THREADS, fwd_lds<32>(), st>>>(src, w0, b0, w1, b1, w2, b2, N2, sdf7t,
-                                                                     feature);
+                                                                     feature, h2c);
     }
     RSDF_RETURN_LAUNCH();
 }
@@ -540,8 +576,8 @@ int rsdf_sdfmlp_fd7_fwd(const float *x7t, const float *planes, int n_levels, int
 int rsdf_sdfmlp_fd7_bwd(const float *x7t, const float *planes, int n_levels, int n_active_levels,
                         float xyz_scale, float xyz_offset, int H, int N2, const float *w0,
                         const float *b0, const float *w1, const float *b1, const float *w2,
-                        const float *b2, int64_t n_samples, const float *d_sdf7t, float *d_planes,
-                        float *dw0, float *db0, float *dw1, float *db1, float *dw2, float *db2,
+                        const float *b2, int64_t n_samples, const float *d_sdf7t, const float *d_feature,
+                        float *d_planes, float *dw0, float *db0, float *dw1, float *db1, float *dw2, float *db2,
                         void *stream)
 {
     const int K0 = 3 + 2 * n_levels;
@@ -556,13 +592,13 @@ int rsdf_sdfmlp_fd7_bwd(const float *x7t, const float *planes, int n_levels, int
     if (H == 64) {
         if ((rc = set_lds(sdfmlp_bwd_kernel<64>, bwd_lds<64>()))) return rc;
         sdfmlp_bwd_kernel<64><<<grid, THREADS, bwd_lds<64>(), st>>>(src, w0, b0, w1, b1, w2, b2, N2,
-                                                                     d_sdf7t, d_planes, dw0, db0, dw1, db1,
-                                                                     dw2, db2);
+                                                                     d_sdf7t, d_feature, d_planes, dw0, db0,
+                                                                     dw1, db1, dw2, db2);
     } else {
         if ((rc = set_lds(sdfmlp_bwd_kernel<32>, bwd_lds<32>()))) return rc;
         sdfmlp_bwd_kernel<32><<<grid, THREADS, bwd_lds<32>(), st>>>(src, w0, b0, w1, b1, w2, b2, N2,
-                                                                     d_sdf7t, d_planes, dw0, db0, dw1, db1,
-                                                                     dw2, db2);
+                                                                     d_sdf7t, d_feature, d_planes, dw0, db0,
+                                                                     dw1, db1, dw2, db2);
     }
     RSDF_RETURN_LAUNCH();
 }

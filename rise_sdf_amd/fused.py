@@ -7,8 +7,9 @@ cache lines and nothing 35 columns wide ever goes through autograd.
 
 Forward:  x7t -> planes (rsdf_hashgrid_fwd_fd7: one gather of the centre cell + 4 corners per displaced
           tap) -> sdf7t [7][S] (+ feature [S,N2] of the centre taps) (rsdf_sdfmlp_fd7_fwd).
-Backward: d_sdf7t -> rsdf_sdfmlp_fd7_bwd (recomputes the hidden layers; weight / bias gradients and
-          d_planes) -> rsdf_hashgrid_bwd_fd7 (merge, bin through LDS, reduce in LDS) -> d_table.
+Backward: d_sdf7t (+ d_feature) -> rsdf_sdfmlp_fd7_bwd (recomputes the hidden layers; weight / bias
+          gradients and d_planes) -> rsdf_hashgrid_bwd_fd7 (merge, bin through LDS, reduce in LDS) ->
+          d_table; the feature rows of dW2 come from rsdf_linear_bwd_weight on the saved centre h2.
 
 This is what VolumeSDF.forward does for finite-difference normals between ``points_d`` and
 ``points_d_sdf`` (models/geometry.py:229-244); the reference runs it as 7 encode + MLP passes.
@@ -49,10 +50,12 @@ class _SdfFieldFD7(torch.autograd.Function):
                                           st), "hashgrid_fwd_fd7")
         sdf7t = torch.empty(7, S, dtype=torch.float32, device=dev)
         feature = torch.empty(S, N2, dtype=torch.float32, device=dev) if want_feature else None
+        h2c = torch.empty(S, H, dtype=torch.float32, device=dev) if want_feature else None
         check(lib().rsdf_sdfmlp_fd7_fwd(ptr(xf), ptr(planes), Lv, n_active, float(xyz_scale),
                                         float(xyz_offset), H, N2, *[ptr(t) for t in ws], S, ptr(sdf7t),
-                                        ptr(feature), st), "sdfmlp_fd7_fwd")
+                                        ptr(feature), ptr(h2c), st), "sdfmlp_fd7_fwd")
         ctx.save_for_backward(xf, planes, *ws)
+        ctx.h2c = h2c
         ctx.meta, ctx.n_active, ctx.eps_unit, ctx.n_params = meta, n_active, float(eps_unit), tb.numel()
         ctx.xyz = (float(xyz_scale), float(xyz_offset))
         ctx.dims = (S, Lv, H, N2)
@@ -61,17 +64,15 @@ class _SdfFieldFD7(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_sdf7t, g_feature):
-        if g_feature is not None:
-            raise L.RiseSdfHipError(
-                "the fused stencil field only back-propagates through the SDF column; use "
-                "VolumeSDF.forward (per-layer kernels) when the feature vector needs a gradient")
-        if g_sdf7t is None:
+        if g_sdf7t is None and g_feature is None:
             return (None,) * 14
         xf, planes, w0, b0, w1, b1, w2, b2 = ctx.saved_tensors
         S, Lv, H, N2 = ctx.dims
         dev = xf.device
         st = stream_ptr()
-        g = g_sdf7t.detach().to(torch.float32).contiguous()
+        g = torch.zeros(7, S, dtype=torch.float32, device=dev) if g_sdf7t is None \
+            else g_sdf7t.detach().to(torch.float32).contiguous()
+        gf = None if g_feature is None else g_feature.detach().to(torch.float32).contiguous()
         need_table = ctx.needs_input_grad[1]
         d_planes = torch.empty_like(planes) if need_table else None
         dw0, db0 = torch.zeros_like(w0), torch.zeros_like(b0)
@@ -79,8 +80,12 @@ class _SdfFieldFD7(torch.autograd.Function):
         dw2, db2 = torch.zeros_like(w2), torch.zeros_like(b2)
         check(lib().rsdf_sdfmlp_fd7_bwd(ptr(xf), ptr(planes), Lv, ctx.n_active, ctx.xyz[0], ctx.xyz[1],
                                         H, N2, ptr(w0), ptr(b0), ptr(w1), ptr(b1), ptr(w2), ptr(b2), S,
-                                        ptr(g), ptr(d_planes), ptr(dw0), ptr(db0), ptr(dw1), ptr(db1),
-                                        ptr(dw2), ptr(db2), st), "sdfmlp_fd7_bwd")
+                                        ptr(g), ptr(gf), ptr(d_planes), ptr(dw0), ptr(db0), ptr(dw1),
+                                        ptr(db1), ptr(dw2), ptr(db2), st), "sdfmlp_fd7_bwd")
+        if gf is not None:
+            # feature rows of the last layer: dW2 += d_feature^T h2(centre), db2 += colsum(d_feature)
+            check(lib().rsdf_linear_bwd_weight(ptr(gf), N2, ptr(ctx.h2c), H, S, H, N2, ptr(dw2), ptr(db2), st),
+                  "linear_bwd_weight (feature rows)")
         dt = None
         if need_table:
             dt = torch.zeros(ctx.n_params, dtype=torch.float32, device=dev)

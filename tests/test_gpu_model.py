@@ -182,3 +182,51 @@ def test_volume_sdf_reference_fixture(dev, golden_dir):
             for n in ("bias", "weight_g", "weight_v"):
                 ref = torch.tensor(z[f"s{step}_grad__network_layers_{i}_{n}"])
                 assert rel_err(getattr(geo.network.layers[i], n).grad, ref) < 5e-3, (step, i, n)
+
+
+@pytest.mark.parametrize("hidden,n_levels", [(32, 4), (64, 16)])
+def test_fused_field_with_feature_gradients(dev, hidden, n_levels):
+    """Fused stencil field (hash gather + MLP in one node) with gradients through BOTH the SDF stencil and
+    the centre feature vector, vs the oracle's VolumeSDF restatement (models/geometry.py:206-244)."""
+    import rise_sdf_amd as R
+    from rise_sdf_amd import ops
+    torch.manual_seed(1)
+    log2_T = 14 if n_levels == 4 else 15
+    cfg = model_config(hidden=hidden, n_levels=n_levels, feat=48 if hidden == 64 else 13, log2_T=log2_T)
+    geo = R.make("volume-sdf", cfg.geometry).to(dev)
+    geo.train()
+    with torch.no_grad():
+        geo.encoding.encoding.encoding.params.mul_(300.0)
+        l0 = geo.network.layers[0]
+        l0.weight_v[:, 3:] = torch.randn_like(l0.weight_v[:, 3:]) * 0.3
+    geo.update_step(0, 0)
+    assert geo.fused_field_available()
+    rays = camera_rays(12, 12, seed=4)
+    ro, rd = rays[:, :3].contiguous(), rays[:, 3:].contiguous()
+    roi = torch.tensor([-1.5, -1.5, -1.5, 1.5, 1.5, 1.5])
+    ri, ts, te = oracle.ray_marching(ro, rd, scene_aabb=roi, render_step_size=0.02)
+    S = ri.numel()
+    eps = geo._finite_difference_eps
+    sdf7t, feat = geo.sdf7_from_rays(ro.to(dev), rd.to(dev), ri.to(dev), ts.to(dev), te.to(dev), want_feature=True)
+    sdf_g = sdf7t[0]
+    grad_g = torch.stack([0.5 * (sdf7t[1 + 2 * k] - sdf7t[2 + 2 * k]) / eps for k in range(3)], -1)
+
+    class M:  # adapter so that oracle_params() can read the parameters
+        geometry = geo
+        variance = type("V", (), {"variance": torch.tensor(0.3)})()
+    meta, table, mlp, _ = oracle_params(M)
+    pos = ro[ri] + rd[ri] * ((ts + te) / 2.0)[:, None]
+    sdf_o, grad_o, feat_o = oracle.volume_sdf(pos, table, meta, mlp, radius=1.5, fd_eps=eps)
+    assert rel_err(sdf_g, sdf_o) < 1e-5 and rel_err(feat, feat_o) < 1e-5
+    assert rel_err(grad_g, grad_o) < 1e-5 / eps * 2
+
+    g = torch.Generator().manual_seed(5)
+    gs, gg, gf = torch.randn(S, generator=g), torch.randn(S, 3, generator=g), torch.randn(feat_o.shape, generator=g)
+    ((sdf_o * gs).sum() + (grad_o * gg).sum() * 1e-2 + (feat_o * gf).sum()).backward()
+    ((sdf_g * gs.to(dev)).sum() + (grad_g * gg.to(dev)).sum() * 1e-2 + (feat * gf.to(dev)).sum()).backward()
+    gt = geo.encoding.encoding.encoding.params.grad.cpu()
+    assert float((gt - table.grad).abs().max()) < 5e-3 * float(table.grad.abs().max())
+    lin = [m for m in geo.network.layers if isinstance(m, torch.nn.Linear)]
+    for m, p in zip(lin, mlp):
+        for name, ref_t in (("weight_v", p["v"]), ("weight_g", p["g"]), ("bias", p["b"])):
+            assert rel_err(getattr(m, name).grad, ref_t.grad) < 5e-3, name
