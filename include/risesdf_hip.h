@@ -249,6 +249,34 @@ int rsdf_neus_alpha_bwd(const float *sdf, const float *normal, const float *dirs
                         int64_t n, const float *d_alpha, float *d_sdf, float *d_normal,
                         float *d_variance, void *stream);
 
+/* ---- T1/T2/S1/O1: per-sample kernels of the radiance branch -----------------------------------------
+ * rsdf_freq_encode: VanillaFrequency (models/network_utils.py:14-40): out[:, col_off + 6k + 3f + c] =
+ *   {sin,cos}_f(2^k (x_c*x_scale + x_offset)) * mask[k]   (mask nullable device [n_frequencies]).
+ * rsdf_sh_encode_*: tcnn.Encoding(otype SphericalHarmonics, degree <= 5) (models/network_utils.py:98-99;
+ *   call sites models/texture.py:312,348): real SH of 2*d01-1, degree^2 outputs; backward w.r.t. d01.
+ * rsdf_reflect_*: wi = -dirs, wo = 2(wi.n)n - wi, written as wo01 = (wo+1)/2, nov = n.wi
+ *   (models/texture.py:295-297,312); backward w.r.t. the normals.
+ * rsdf_split_color0_*: stage-0 output of VolumeMixedMipSplitOcc.forward (models/texture.py:303-327):
+ *   colors7 = [(1-blend) sigmoid(albedo6[:3]), blend sigmoid(spec3), blend], blend = sigmoid(metallic2[0]).
+ * rsdf_rgb_to_srgb_*: lib/pbr/utils/nvdiffrecmc_util.py:95-103 (elementwise, n = number of floats). */
+int rsdf_freq_encode(const float *x, int64_t n, int n_frequencies, float x_scale, float x_offset,
+                     const float *mask, float *out, int ld_out, int col_off, void *stream);
+int rsdf_sh_encode_fwd(const float *d01, int64_t n, int degree, float *out, int ld_out, int col_off,
+                       void *stream);
+int rsdf_sh_encode_bwd(const float *d01, const float *dout, int64_t n, int degree, int ld_dout,
+                       int col_off, float *d_d01, void *stream);
+int rsdf_reflect_fwd(const float *dirs, const float *normals, int64_t n, float *wo01, float *nov,
+                     void *stream);
+int rsdf_reflect_bwd(const float *dirs, const float *normals, int64_t n, const float *d_wo01,
+                     const float *d_nov, float *d_normals, void *stream);
+int rsdf_split_color0_fwd(const float *albedo6, const float *metallic2, const float *spec3, int64_t n,
+                          float *colors7, void *stream);
+int rsdf_split_color0_bwd(const float *albedo6, const float *metallic2, const float *spec3,
+                          const float *d_colors7, int64_t n, float *d_albedo6, float *d_metallic2,
+                          float *d_spec3, void *stream);
+int rsdf_rgb_to_srgb_fwd(const float *x, int64_t n, float *y, void *stream);
+int rsdf_rgb_to_srgb_bwd(const float *x, const float *dy, int64_t n, float *dx, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,6 +76,15 @@ _SIGNATURES = {
     "rsdf_fd_gradient_bwd": [_P, _P, _F, _L, _P, _I, _P],
     "rsdf_neus_alpha_fd_fwd": [_P, _I, _P, _P, _P, _P, _P, _F, _F, _L, _P, _P, _P, _P, _P],
     "rsdf_neus_alpha_fd_bwd": [_P, _I, _P, _P, _P, _P, _P, _F, _F, _L, _P, _P, _P, _P, _P, _I, _P, _P],
+    "rsdf_freq_encode": [_P, _L, _I, _F, _F, _P, _P, _I, _I, _P],
+    "rsdf_sh_encode_fwd": [_P, _L, _I, _P, _I, _I, _P],
+    "rsdf_sh_encode_bwd": [_P, _P, _L, _I, _I, _I, _P, _P],
+    "rsdf_reflect_fwd": [_P, _P, _L, _P, _P, _P],
+    "rsdf_reflect_bwd": [_P, _P, _L, _P, _P, _P, _P],
+    "rsdf_split_color0_fwd": [_P, _P, _P, _L, _P, _P],
+    "rsdf_split_color0_bwd": [_P, _P, _P, _P, _L, _P, _P, _P, _P],
+    "rsdf_rgb_to_srgb_fwd": [_P, _L, _P, _P],
+    "rsdf_rgb_to_srgb_bwd": [_P, _P, _L, _P, _P],
     "rsdf_neus_alpha_fwd": [_P, _P, _P, _P, _P, _F, _L, _P, _P],
     "rsdf_neus_alpha_bwd": [_P, _P, _P, _P, _P, _F, _L, _P, _P, _P, _P, _P],
 }

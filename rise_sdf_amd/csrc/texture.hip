@@ -1,0 +1,330 @@
+// T1 / T2 / S1 (stage 0): the small per-sample kernels of the radiance branch.
+//
+// Specification followed (paths relative to the upstream RISE-SDF tree):
+//   models/network_utils.py:14-40    VanillaFrequency: [sin(2^k x), cos(2^k x)] k = 0..n-1, freq-major
+//   models/network_utils.py:98-99    tcnn.Encoding(otype SphericalHarmonics, degree 5): tiny-cuda-nn is absent
+//                                    upstream; the published real-SH polynomial basis of (2 d - 1) is used
+//                                    (parity unpinned, identical to oracle/texture.py)
+//   models/texture.py:295-297        wi = -d, wo = 2 (wi.n) n - wi, NoV = n.wi
+//   models/texture.py:303-327        sigmoid activations + blend (stage 0 output [diff(3), spec(3), blend])
+//   lib/pbr/utils/nvdiffrecmc_util.py:95-103   rgb_to_srgb
+#include "common.h"
+
+namespace {
+
+constexpr int THREADS = 256;
+
+__global__ void __launch_bounds__(THREADS)
+freq_encode_kernel(const float *__restrict__ x, int64_t n, int n_freq, float x_scale, float x_offset,
+                   const float *__restrict__ mask, float *__restrict__ out, int ld, int col_off)
+{
+    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= n) return;
+    float v[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] = x[3 * i + c] * x_scale + x_offset;
+    float *o = out + i * ld + col_off;
+    float f = 1.0f;
+    for (int k = 0; k < n_freq; ++k, f *= 2.0f) {
+        const float m = mask ? mask[k] : 1.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float a = f * v[c];
+            o[k * 6 + c] = sinf(a) * m;
+            o[k * 6 + 3 + c] = cosf(a) * m;
+        }
+    }
+}
+
+// real SH basis, up to 5 bands; u = 2 d01 - 1
+__device__ __forceinline__ void sh_eval(float x, float y, float z, int degree, float *o)
+{
+    const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+    const float x4 = x2 * x2, y4 = y2 * y2, z4 = z2 * z2;
+    o[0] = 0.28209479177387814f;
+    if (degree <= 1) return;
+    o[1] = -0.48860251190291987f * y;
+    o[2] = 0.48860251190291987f * z;
+    o[3] = -0.48860251190291987f * x;
+    if (degree <= 2) return;
+    o[4] = 1.0925484305920792f * xy;
+    o[5] = -1.0925484305920792f * yz;
+    o[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+    o[7] = -1.0925484305920792f * xz;
+    o[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+    if (degree <= 3) return;
+    o[9] = 0.59004358992664352f * y * (-3.0f * x2 + y2);
+    o[10] = 2.8906114426405538f * xy * z;
+    o[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
+    o[12] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
+    o[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
+    o[14] = 1.4453057213202769f * z * (x2 - y2);
+    o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+    if (degree <= 4) return;
+    o[16] = 2.5033429417967046f * xy * (x2 - y2);
+    o[17] = 1.7701307697799304f * yz * (-3.0f * x2 + y2);
+    o[18] = 0.94617469575756008f * xy * (7.0f * z2 - 1.0f);
+    o[19] = 0.66904654355728921f * yz * (3.0f - 7.0f * z2);
+    o[20] = -3.1735664074561294f * z2 + 3.7024941420321507f * z4 + 0.31735664074561293f;
+    o[21] = 0.66904654355728921f * xz * (3.0f - 7.0f * z2);
+    o[22] = 0.47308734787878004f * (x2 - y2) * (7.0f * z2 - 1.0f);
+    o[23] = 1.7701307697799304f * xz * (-x2 + 3.0f * y2);
+    o[24] = -3.7550144126950569f * x2 * y2 + 0.62583573544917614f * x4 + 0.62583573544917614f * y4;
+}
+
+// (dx,dy,dz) += sum_i g[i] * d o_i / d(x,y,z)
+__device__ __forceinline__ void sh_grad(float x, float y, float z, int degree, const float *g, float &dx,
+                                        float &dy, float &dz)
+{
+    const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+    dx = dy = dz = 0.0f;
+    if (degree <= 1) return;
+    const float c1 = 0.48860251190291987f;
+    dy += -c1 * g[1];
+    dz += c1 * g[2];
+    dx += -c1 * g[3];
+    if (degree <= 2) return;
+    const float c2 = 1.0925484305920792f, c3 = 0.54627421529603959f;
+    dx += c2 * y * g[4];  dy += c2 * x * g[4];
+    dy += -c2 * z * g[5]; dz += -c2 * y * g[5];
+    dz += 2.0f * 0.94617469575755997f * z * g[6];
+    dx += -c2 * z * g[7]; dz += -c2 * x * g[7];
+    dx += 2.0f * c3 * x * g[8]; dy += -2.0f * c3 * y * g[8];
+    if (degree <= 3) return;
+    const float a = 0.59004358992664352f, b = 2.8906114426405538f, c = 0.45704579946446572f,
+                d = 0.3731763325901154f, e = 1.4453057213202769f;
+    dx += -6.0f * a * xy * g[9];            dy += a * (-3.0f * x2 + 3.0f * y2) * g[9];
+    dx += b * yz * g[10];                   dy += b * xz * g[10];              dz += b * xy * g[10];
+    dy += c * (1.0f - 5.0f * z2) * g[11];   dz += -10.0f * c * yz * g[11];
+    dz += d * (15.0f * z2 - 3.0f) * g[12];
+    dx += c * (1.0f - 5.0f * z2) * g[13];   dz += -10.0f * c * xz * g[13];
+    dx += 2.0f * e * xz * g[14];            dy += -2.0f * e * yz * g[14];      dz += e * (x2 - y2) * g[14];
+    dx += a * (-3.0f * x2 + 3.0f * y2) * g[15]; dy += 6.0f * a * xy * g[15];
+    if (degree <= 4) return;
+    const float f = 2.5033429417967046f, gg = 1.7701307697799304f, h = 0.94617469575756008f,
+                ii = 0.66904654355728921f, j = 0.47308734787878004f, k = 0.62583573544917614f;
+    dx += f * (3.0f * x2 * y - y2 * y) * g[16];      dy += f * (x2 * x - 3.0f * x * y2) * g[16];
+    dx += -6.0f * gg * xy * z * g[17];               dy += gg * z * (-3.0f * x2 + 3.0f * y2) * g[17];
+    dz += gg * y * (-3.0f * x2 + y2) * g[17];
+    dx += h * y * (7.0f * z2 - 1.0f) * g[18];        dy += h * x * (7.0f * z2 - 1.0f) * g[18];
+    dz += 14.0f * h * xy * z * g[18];
+    dy += ii * z * (3.0f - 7.0f * z2) * g[19];       dz += ii * y * (3.0f - 21.0f * z2) * g[19];
+    dz += (-6.3471328149122588f * z + 14.809976568128603f * z2 * z) * g[20];
+    dx += ii * z * (3.0f - 7.0f * z2) * g[21];       dz += ii * x * (3.0f - 21.0f * z2) * g[21];
+    dx += 2.0f * j * x * (7.0f * z2 - 1.0f) * g[22]; dy += -2.0f * j * y * (7.0f * z2 - 1.0f) * g[22];
+    dz += 14.0f * j * z * (x2 - y2) * g[22];
+    dx += gg * z * (-3.0f * x2 + 3.0f * y2) * g[23]; dy += 6.0f * gg * xy * z * g[23];
+    dz += gg * x * (-x2 + 3.0f * y2) * g[23];
+    dx += (-7.5100288253901138f * x * y2 + 4.0f * k * x2 * x) * g[24];
+    dy += (-7.5100288253901138f * x2 * y + 4.0f * k * y2 * y) * g[24];
+}
+
+__global__ void __launch_bounds__(THREADS)
+sh_fwd_kernel(const float *__restrict__ d01, int64_t n, int degree, float *__restrict__ out, int ld,
+              int col_off)
+{
+    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= n) return;
+    float o[25];
+    sh_eval(d01[3 * i] * 2.0f - 1.0f, d01[3 * i + 1] * 2.0f - 1.0f, d01[3 * i + 2] * 2.0f - 1.0f, degree, o);
+    float *dst = out + i * ld + col_off;
+    const int m = degree * degree;
+#pragma unroll
+    for (int k = 0; k < 25; ++k)
+        if (k < m) dst[k] = o[k];
+}
+
+__global__ void __launch_bounds__(THREADS)
+sh_bwd_kernel(const float *__restrict__ d01, const float *__restrict__ dout, int64_t n, int degree, int ld,
+              int col_off, float *__restrict__ dd01)
+{
+    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= n) return;
+    float g[25];
+    const float *src = dout + i * ld + col_off;
+    const int m = degree * degree;
+#pragma unroll
+    for (int k = 0; k < 25; ++k) g[k] = k < m ? src[k] : 0.0f;
+    float dx, dy, dz;
+    sh_grad(d01[3 * i] * 2.0f - 1.0f, d01[3 * i + 1] * 2.0f - 1.0f, d01[3 * i + 2] * 2.0f - 1.0f, degree, g,
+            dx, dy, dz);
+    dd01[3 * i] = 2.0f * dx;
+    dd01[3 * i + 1] = 2.0f * dy;
+    dd01[3 * i + 2] = 2.0f * dz;
+}
+
+// wo01 = (wo + 1) / 2 with wo = 2 (wi.n) n - wi, wi = -d ; nov = n.wi
+__global__ void __launch_bounds__(THREADS)
+reflect_fwd_kernel(const float *__restrict__ dirs, const float *__restrict__ normals, int64_t n,
+                   float *__restrict__ wo01, float *__restrict__ nov)
+{
+    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= n) return;
+    const float w[3] = {-dirs[3 * i], -dirs[3 * i + 1], -dirs[3 * i + 2]};
+    const float nn[3] = {normals[3 * i], normals[3 * i + 1], normals[3 * i + 2]};
+    const float dot = w[0] * nn[0] + w[1] * nn[1] + w[2] * nn[2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) wo01[3 * i + c] = ((dot * nn[c] * 2.0f - w[c]) + 1.0f) / 2.0f;
+    if (nov) nov[i] = dot;
+}
+
+__global__ void __launch_bounds__(THREADS)
+reflect_bwd_kernel(const float *__restrict__ dirs, const float *__restrict__ normals, int64_t n,
+                   const float *__restrict__ d_wo01, const float *__restrict__ d_nov,
+                   float *__restrict__ d_normals)
+{
+    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= n) return;
+    const float w[3] = {-dirs[3 * i], -dirs[3 * i + 1], -dirs[3 * i + 2]};
+    const float nn[3] = {normals[3 * i], normals[3 * i + 1], normals[3 * i + 2]};
+    const float dot = w[0] * nn[0] + w[1] * nn[1] + w[2] * nn[2];
+    float g[3] = {0.f, 0.f, 0.f};
+    if (d_wo01) { g[0] = d_wo01[3 * i] * 0.5f; g[1] = d_wo01[3 * i + 1] * 0.5f; g[2] = d_wo01[3 * i + 2] * 0.5f; }
+    // wo_c = 2 dot n_c - w_c ; d wo_c / d n_k = 2 w_k n_c + 2 dot delta_ck
+    const float gn = g[0] * nn[0] + g[1] * nn[1] + g[2] * nn[2];
+    const float dn = d_nov ? d_nov[i] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) d_normals[3 * i + k] = 2.0f * w[k] * gn + 2.0f * dot * g[k] + dn * w[k];
+}
+
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// stage 0: colors[7] = [(1-blend) sig(albedo6[0:3]), blend sig(spec3), blend], blend = sig(metallic2[0])
+__global__ void __launch_bounds__(THREADS)
+split_color0_fwd_kernel(const float *__restrict__ albedo6, const float *__restrict__ metallic2,
+                        const float *__restrict__ spec3, int64_t n, float *__restrict__ colors)
+{
+    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= n) return;
+    const float blend = sigm(metallic2[2 * i]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        colors[7 * i + c] = (1.0f - blend) * sigm(albedo6[6 * i + c]);
+        colors[7 * i + 3 + c] = blend * sigm(spec3[3 * i + c]);
+    }
+    colors[7 * i + 6] = blend;
+}
+
+__global__ void __launch_bounds__(THREADS)
+split_color0_bwd_kernel(const float *__restrict__ albedo6, const float *__restrict__ metallic2,
+                        const float *__restrict__ spec3, const float *__restrict__ d_colors, int64_t n,
+                        float *__restrict__ d_albedo6, float *__restrict__ d_metallic2,
+                        float *__restrict__ d_spec3)
+{
+    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= n) return;
+    const float blend = sigm(metallic2[2 * i]);
+    float d_blend = d_colors[7 * i + 6];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float sd = sigm(albedo6[6 * i + c]), ss = sigm(spec3[3 * i + c]);
+        const float gd = d_colors[7 * i + c], gs = d_colors[7 * i + 3 + c];
+        d_albedo6[6 * i + c] = gd * (1.0f - blend) * sd * (1.0f - sd);
+        d_albedo6[6 * i + 3 + c] = 0.0f;
+        d_spec3[3 * i + c] = gs * blend * ss * (1.0f - ss);
+        d_blend += -gd * sd + gs * ss;
+    }
+    d_metallic2[2 * i] = d_blend * blend * (1.0f - blend);
+    d_metallic2[2 * i + 1] = 0.0f;
+}
+
+__global__ void __launch_bounds__(THREADS)
+srgb_fwd_kernel(const float *__restrict__ x, int64_t n, float *__restrict__ y)
+{
+    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= n) return;
+    const float f = x[i];
+    y[i] = f <= 0.0031308f ? f * 12.92f : powf(fmaxf(f, 0.0031308f), 1.0f / 2.4f) * 1.055f - 0.055f;
+}
+
+__global__ void __launch_bounds__(THREADS)
+srgb_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy, int64_t n, float *__restrict__ dx)
+{
+    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= n) return;
+    const float f = x[i];
+    // torch.where + clamp: the power branch's clamp passes gradient for f >= 0.0031308
+    dx[i] = dy[i] * (f <= 0.0031308f ? 12.92f : 1.055f / 2.4f * powf(f, 1.0f / 2.4f - 1.0f));
+}
+
+}  // namespace
+
+#define LAUNCH1D(kern, n, ...) kern<<<rsdf_blocks(n, THREADS), THREADS, 0, (hipStream_t)stream>>>(__VA_ARGS__)
+
+extern "C" {
+
+int rsdf_freq_encode(const float *x, int64_t n, int n_frequencies, float x_scale, float x_offset,
+                     const float *mask, float *out, int ld_out, int col_off, void *stream)
+{
+    RSDF_CHECK_ARG(n_frequencies >= 1 && ld_out >= col_off + 6 * n_frequencies, "freq_encode: bad sizes");
+    if (n <= 0) return 0;
+    LAUNCH1D(freq_encode_kernel, n, x, n, n_frequencies, x_scale, x_offset, mask, out, ld_out, col_off);
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_sh_encode_fwd(const float *d01, int64_t n, int degree, float *out, int ld_out, int col_off,
+                       void *stream)
+{
+    RSDF_CHECK_ARG(degree >= 1 && degree <= 5 && ld_out >= col_off + degree * degree, "sh_encode_fwd: bad sizes");
+    if (n <= 0) return 0;
+    LAUNCH1D(sh_fwd_kernel, n, d01, n, degree, out, ld_out, col_off);
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_sh_encode_bwd(const float *d01, const float *dout, int64_t n, int degree, int ld_dout, int col_off,
+                       float *d_d01, void *stream)
+{
+    RSDF_CHECK_ARG(degree >= 1 && degree <= 5 && ld_dout >= col_off + degree * degree, "sh_encode_bwd: bad sizes");
+    if (n <= 0) return 0;
+    LAUNCH1D(sh_bwd_kernel, n, d01, dout, n, degree, ld_dout, col_off, d_d01);
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_reflect_fwd(const float *dirs, const float *normals, int64_t n, float *wo01, float *nov,
+                     void *stream)
+{
+    if (n <= 0) return 0;
+    LAUNCH1D(reflect_fwd_kernel, n, dirs, normals, n, wo01, nov);
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_reflect_bwd(const float *dirs, const float *normals, int64_t n, const float *d_wo01,
+                     const float *d_nov, float *d_normals, void *stream)
+{
+    if (n <= 0) return 0;
+    LAUNCH1D(reflect_bwd_kernel, n, dirs, normals, n, d_wo01, d_nov, d_normals);
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_split_color0_fwd(const float *albedo6, const float *metallic2, const float *spec3, int64_t n,
+                          float *colors7, void *stream)
+{
+    if (n <= 0) return 0;
+    LAUNCH1D(split_color0_fwd_kernel, n, albedo6, metallic2, spec3, n, colors7);
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_split_color0_bwd(const float *albedo6, const float *metallic2, const float *spec3,
+                          const float *d_colors7, int64_t n, float *d_albedo6, float *d_metallic2,
+                          float *d_spec3, void *stream)
+{
+    if (n <= 0) return 0;
+    LAUNCH1D(split_color0_bwd_kernel, n, albedo6, metallic2, spec3, d_colors7, n, d_albedo6, d_metallic2, d_spec3);
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_rgb_to_srgb_fwd(const float *x, int64_t n, float *y, void *stream)
+{
+    if (n <= 0) return 0;
+    LAUNCH1D(srgb_fwd_kernel, n, x, n, y);
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_rgb_to_srgb_bwd(const float *x, const float *dy, int64_t n, float *dx, void *stream)
+{
+    if (n <= 0) return 0;
+    LAUNCH1D(srgb_bwd_kernel, n, x, dy, n, dx);
+    RSDF_RETURN_LAUNCH();
+}
+
+}  // extern "C"

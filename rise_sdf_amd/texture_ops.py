@@ -1,0 +1,133 @@
+"""autograd wrappers for the radiance-branch kernels (csrc/texture.hip)."""
+from __future__ import annotations
+
+import torch
+
+from ._lib import check, lib, ptr, require_device, stream_ptr
+
+
+def _f(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+@torch.no_grad()
+def freq_encode(x, n_frequencies, x_scale=1.0, x_offset=0.0, mask=None, out=None, col_off=0):
+    """VanillaFrequency (models/network_utils.py:14-40).  Positions carry no gradient on the path.
+    With ``out`` [n, ld] the encoding is written at column ``col_off`` (no concatenation copy)."""
+    xf = _f(x).reshape(-1, 3)
+    m = None if mask is None else _f(mask).to(xf.device)
+    require_device(xf, m)
+    n = xf.shape[0]
+    if out is None:
+        out = torch.empty(n, 6 * n_frequencies, dtype=torch.float32, device=xf.device)
+        col_off = 0
+    check(lib().rsdf_freq_encode(ptr(xf), n, int(n_frequencies), float(x_scale), float(x_offset), ptr(m),
+                                 ptr(out), out.shape[1], int(col_off), stream_ptr()), "freq_encode")
+    return out
+
+
+class _SH(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, d01, degree):
+        d = _f(d01).reshape(-1, 3)
+        require_device(d)
+        out = torch.empty(d.shape[0], degree * degree, dtype=torch.float32, device=d.device)
+        check(lib().rsdf_sh_encode_fwd(ptr(d), d.shape[0], degree, ptr(out), out.shape[1], 0, stream_ptr()),
+              "sh_encode_fwd")
+        ctx.save_for_backward(d)
+        ctx.degree, ctx.shape = degree, d01.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (d,) = ctx.saved_tensors
+        g = _f(g)
+        dd = torch.empty_like(d)
+        check(lib().rsdf_sh_encode_bwd(ptr(d), ptr(g), d.shape[0], ctx.degree, g.shape[1], 0, ptr(dd),
+                                       stream_ptr()), "sh_encode_bwd")
+        return dd.view(ctx.shape), None
+
+
+def sh_encode(d01, degree):
+    """tcnn SphericalHarmonics encoding of directions given in [0,1]^3 -> [n, degree^2]."""
+    return _SH.apply(d01, int(degree))
+
+
+class _Reflect(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dirs, normals):
+        d, n = _f(dirs), _f(normals)
+        require_device(d, n)
+        wo01 = torch.empty_like(d)
+        nov = torch.empty(d.shape[0], 1, dtype=torch.float32, device=d.device)
+        check(lib().rsdf_reflect_fwd(ptr(d), ptr(n), d.shape[0], ptr(wo01), ptr(nov), stream_ptr()),
+              "reflect_fwd")
+        ctx.save_for_backward(d, n)
+        ctx.set_materialize_grads(False)
+        return wo01, nov
+
+    @staticmethod
+    def backward(ctx, g_wo01, g_nov):
+        d, n = ctx.saved_tensors
+        if g_wo01 is None and g_nov is None:
+            return None, None
+        gw = None if g_wo01 is None else _f(g_wo01)
+        gn = None if g_nov is None else _f(g_nov)
+        dn = torch.empty_like(n)
+        check(lib().rsdf_reflect_bwd(ptr(d), ptr(n), d.shape[0], ptr(gw), ptr(gn), ptr(dn), stream_ptr()),
+              "reflect_bwd")
+        return None, dn
+
+
+def reflect(dirs, normals):
+    """-> ((wo + 1) / 2 [n,3], NoV [n,1]) with wo = 2 (wi.n) n - wi, wi = -dirs (models/texture.py:295-297)."""
+    return _Reflect.apply(dirs, normals)
+
+
+class _SplitColor0(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, albedo6, metallic2, spec3):
+        a, m, s = _f(albedo6), _f(metallic2), _f(spec3)
+        require_device(a, m, s)
+        col = torch.empty(a.shape[0], 7, dtype=torch.float32, device=a.device)
+        check(lib().rsdf_split_color0_fwd(ptr(a), ptr(m), ptr(s), a.shape[0], ptr(col), stream_ptr()),
+              "split_color0_fwd")
+        ctx.save_for_backward(a, m, s)
+        return col
+
+    @staticmethod
+    def backward(ctx, g):
+        a, m, s = ctx.saved_tensors
+        g = _f(g)
+        da, dm, ds = torch.empty_like(a), torch.empty_like(m), torch.empty_like(s)
+        check(lib().rsdf_split_color0_bwd(ptr(a), ptr(m), ptr(s), ptr(g), a.shape[0], ptr(da), ptr(dm), ptr(ds),
+                                          stream_ptr()), "split_color0_bwd")
+        return da, dm, ds
+
+
+def split_color0(albedo6, metallic2, spec3):
+    return _SplitColor0.apply(albedo6, metallic2, spec3)
+
+
+class _Srgb(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        xf = _f(x)
+        require_device(xf)
+        y = torch.empty_like(xf)
+        check(lib().rsdf_rgb_to_srgb_fwd(ptr(xf), xf.numel(), ptr(y), stream_ptr()), "rgb_to_srgb_fwd")
+        ctx.save_for_backward(xf)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (xf,) = ctx.saved_tensors
+        g = _f(g)
+        dx = torch.empty_like(xf)
+        check(lib().rsdf_rgb_to_srgb_bwd(ptr(xf), ptr(g), xf.numel(), ptr(dx), stream_ptr()), "rgb_to_srgb_bwd")
+        return dx
+
+
+def rgb_to_srgb(x):
+    """lib/pbr/utils/nvdiffrecmc_util.py:95-103."""
+    return _Srgb.apply(x)

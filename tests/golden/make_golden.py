@@ -97,6 +97,12 @@ class _OracleEncoding(torch.nn.Module):
 
     def __init__(self, n_input_dims, cfg):
         super().__init__()
+        self.otype = cfg["otype"]
+        if self.otype == "SphericalHarmonics":
+            # tcnn's SH encoding is equally absent: stand in with the oracle's (unpinned) basis
+            self.n_input_dims, self.degree = n_input_dims, cfg["degree"]
+            self.n_output_dims = cfg["degree"] ** 2
+            return
         assert cfg["otype"] == "HashGrid"
         self.meta, n_params = oracle.grid_meta(cfg["n_levels"], cfg["n_features_per_level"],
                                                cfg["log2_hashmap_size"], cfg["base_resolution"],
@@ -107,6 +113,9 @@ class _OracleEncoding(torch.nn.Module):
         self.params = torch.nn.Parameter((torch.rand(n_params, generator=g) * 2 - 1) * 1e-1)
 
     def forward(self, x):
+        if self.otype == "SphericalHarmonics":
+            from oracle import texture as otex
+            return otex.sh_encode(x, self.degree)
         return oracle.hashgrid_encode(x, self.params, self.meta)
 
 
@@ -336,6 +345,44 @@ def main():
     save("rendering.npz", ray_indices=ri, t_starts=ts, t_ends=te, rgbs=rgbs, normals_in=nrm,
          alphas=alphas, colors=c, normals=n, opacities=o, depths=d, weights=ex["weights"],
          trans=ex["trans"])
+
+    # ---- VolumeMixedMipSplitOcc.forward, stage 0 (models/texture.py:292-327) --------------------------
+    # Reference code for the blend / activation logic, the five VanillaMLPs and VanillaFrequency; the SH
+    # direction encoding is the oracle's stand-in for tcnn (unpinned).  The FG LUT file is not in the
+    # repo (README.md:68) and is not touched at stage 0: np.fromfile is patched to return zeros.
+    from models import texture as rtex
+    orig_fromfile = np.fromfile
+    np.fromfile = lambda *a, **k: np.zeros(256 * 256 * 2, dtype=np.float32)
+    mlp_cfg = lambda n: {"otype": "VanillaMLP", "activation": "ReLU", "output_activation": "none",
+                         "n_neurons": 64, "n_hidden_layers": n}
+    tcfg = Cfg({
+        "name": "volume-mixed-mip-split-occ", "input_feature_dim": 13, "other_dim": 3, "sample_size": 8,
+        "dir_encoding_config": {"otype": "SphericalHarmonics", "degree": 5, "reflected": True},
+        "metallic_mlp_network_config": mlp_cfg(2), "albedo_mlp_network_config": mlp_cfg(4),
+        "spec_mlp_network_config": mlp_cfg(4), "roughness_mlp_network_config": mlp_cfg(2),
+        "secondary_mlp_network_config": mlp_cfg(4),
+        "xyz_encoding_config": {"otype": "VanillaFrequency", "n_frequencies": 6},
+        "color_activation": "sigmoid",
+    })
+    torch.cuda.device = _NoDev
+    torch.manual_seed(31)
+    tex = rtex.VolumeMixedMipSplitOcc(tcfg)
+    torch.cuda.device = orig_cuda_device
+    np.fromfile = orig_fromfile
+    S = 257
+    feats = torch.randn(S, 13, requires_grad=True)
+    dirs = torch.nn.functional.normalize(torch.randn(S, 3), dim=-1)
+    nrm = torch.nn.functional.normalize(torch.randn(S, 3), dim=-1).requires_grad_(True)
+    pos = (torch.rand(S, 3) * 2 - 1) * 1.5
+    col = tex(feats, dirs, nrm, pos, None, 0)
+    gcol = torch.randn_like(col)
+    tparams = list(tex.parameters())
+    tgrads = torch.autograd.grad(col, [feats, nrm] + tparams, gcol, allow_unused=True)
+    tsd = {"p__" + k.replace(".", "_"): v for k, v in tex.state_dict().items() if k != "FG_LUT"}
+    tg = {"g__" + n.replace(".", "_"): (g if g is not None else torch.zeros_like(p))
+          for (n, p), g in zip(tex.named_parameters(), tgrads[2:])}
+    save("texture_stage0.npz", features=feats, dirs=dirs, normals=nrm, positions=pos, colors=col, gcolors=gcol,
+         g_features=tgrads[0], g_normals=tgrads[1], **tsd, **tg)
 
     # ---- frequency encoding, sRGB, progressive eps ----------------------------------------------
     vf = nu.VanillaFrequency(3, {"n_frequencies": 6})
