@@ -1,0 +1,199 @@
+"""Host-side mirror of the reference's ``models/split_mixed_occ.py`` (``split-mixed-occ``).
+
+Built so far: occupancy update (M2, :98-136), visibility-pruned sampling (M4/M5,
+:264-272), field + FD normals + NeuS alpha (H1-H4, A1, :228-262), radiance branch at stage 0
+(T1-T3, :293-295), compositing (C1-C3, :274-289), secondary-ray occlusion (R1, :179-222,306-318),
+normal-orientation map (:383-401), background compose + sRGB (O1, :404-443).
+Not yet: stage 1 split-sum shading (S1-S4, E1), curvature term (H5), relighting third bounce.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from . import texture_ops as T
+from .geometry import BaseModel
+from .nerfacc import ContractionType, OccGridEstimator
+from .network_utils import update_module_step
+from .neus import VarianceNetwork, chunk_batch
+from .registry import make, register
+from .volrend import rendering_with_normals_sdf, secondary_rendering
+
+
+@register("split-mixed-occ")
+class SplitMixedOCCModel(BaseModel):
+    def setup(self):
+        self.geometry = make(self.config.geometry.name, self.config.geometry)
+        self.texture = make(self.config.texture.name, self.config.texture)
+        light = self.config.get("light", None)
+        self.emitter = make(light.name, light) if light is not None and light.name in _registry() else None
+        self.geometry.contraction_type = ContractionType.AABB
+        self.variance = VarianceNetwork(self.config.variance)
+        r = float(self.config.radius)
+        self.register_buffer("scene_aabb", torch.tensor([-r, -r, -r, r, r, r], dtype=torch.float32))
+        self.grid_prune = bool(self.config.get("grid_prune", True))
+        self.occupancy_grid = OccGridEstimator(roi_aabb=self.scene_aabb, resolution=128)
+        if not self.grid_prune:
+            self.occupancy_grid.binaries.fill_(True)
+        self.randomized = self.config.get("randomized", True)
+        self.background_color = None
+        self.render_step_size = 1.732 * 2 * self.config.radius / self.config.num_samples_per_ray
+        self.num_samples_per_secondary_ray = self.config.get("num_samples_per_secondary_ray", 96)
+        self.secondary_near_plane = self.config.get("secondary_near_plane", 0.05)
+        self.secondary_far_plane = self.config.get("secondary_far_plane", 1.5)
+        self.secondary_shader_chunk = self.config.get("secondary_shader_chunk", 160000)
+        self.cos_anneal_ratio = 1.0
+        self.stage = 0
+
+    # ---- per-step schedule (:98-136) ------------------------------------------------------------------
+    def update_step(self, epoch, global_step):
+        update_module_step(self.geometry, epoch, global_step)
+        update_module_step(self.texture, epoch, global_step)
+        update_module_step(self.variance, epoch, global_step)
+        cos_anneal_end = self.config.get("cos_anneal_end", 0)
+        self.cos_anneal_ratio = 1.0 if cos_anneal_end == 0 else min(1.0, global_step / cos_anneal_end)
+        if self.training and self.grid_prune:
+            self.occupancy_grid.update_every_n_steps(
+                step=global_step, occ_eval_fn=self.occ_eval_fn,
+                occ_thre=self.config.get("grid_prune_occ_thre", 0.01))
+        if global_step >= self.config.get("stage_switch_step", 10000) and self.stage == 0 \
+                and self.config.get("enable_stage1", False):
+            self.stage = 1
+
+    def occ_eval_fn(self, x):
+        sdf = self.geometry(x, with_grad=False, with_feature=False)
+        inv_s = self.variance(torch.zeros([1, 3]))[:, :1].clip(1e-6, 1e6).expand(sdf.shape[0], 1)
+        prev_cdf = torch.sigmoid((sdf[..., None] + self.render_step_size * 0.5) * inv_s)
+        next_cdf = torch.sigmoid((sdf[..., None] - self.render_step_size * 0.5) * inv_s)
+        return ((prev_cdf - next_cdf + 1e-5) / (prev_cdf + 1e-5)).view(-1, 1).clip(0.0, 1.0)
+
+    def get_alpha(self, sdf, normal, dirs, dists):
+        return ops.neus_alpha(sdf, normal, dirs, dists, self.variance.variance, self.cos_anneal_ratio)
+
+    # ---- field access -----------------------------------------------------------------------------------
+    def _stencil(self, rays_o, rays_d, ray_indices, t_starts, t_ends, want_feature):
+        """-> (sdf, sdf_grad, normal, alpha, feature or None) for a sample set."""
+        geo = self.geometry
+        eps = geo._finite_difference_eps
+        if self.config.get("fused", True) and geo.fused_field_available():
+            sdf7t, feature = geo.sdf7_from_rays(rays_o, rays_d, ray_indices, t_starts, t_ends,
+                                                want_feature=want_feature)
+            out = ops.neus_alpha_fd(sdf7t, self.variance.variance, rays_d, ray_indices, t_starts, t_ends,
+                                    self.cos_anneal_ratio, eps, tap_major=True)
+            return (*out, feature)
+        out7 = geo.field7_from_rays(rays_o, rays_d, ray_indices, t_starts, t_ends)
+        out = ops.neus_alpha_fd(out7, self.variance.variance, rays_d, ray_indices, t_starts, t_ends,
+                                self.cos_anneal_ratio, eps)
+        feature = out7.view(-1, 7, out7.shape[-1])[:, 0] if want_feature else None
+        return (*out, feature)
+
+    def _alpha_fn(self, rays_o, rays_d):
+        def alpha_fn(t_starts, t_ends, ray_indices):
+            if ray_indices.numel() == 0:
+                return torch.zeros((0,), device=rays_o.device)
+            with torch.no_grad():
+                return self._stencil(rays_o, rays_d, ray_indices, t_starts, t_ends, False)[3]
+        return alpha_fn
+
+    # ---- secondary-ray occlusion (R1, :179-222) -------------------------------------------------------------
+    def compute_indirect_radiance(self, rays_o, rays_d):
+        n_rays = rays_o.shape[0]
+        alpha_fn = self._alpha_fn(rays_o, rays_d)
+        with torch.no_grad():
+            step = (self.secondary_far_plane - self.secondary_near_plane) / (self.num_samples_per_secondary_ray - 1)
+            ray_indices, t_starts, t_ends = self.occupancy_grid.sampling(
+                rays_o, rays_d, alpha_fn=alpha_fn, near_plane=self.secondary_near_plane,
+                far_plane=self.secondary_far_plane, render_step_size=step, stratified=False)
+            acc_map, depth_map, _ = secondary_rendering(t_starts, t_ends, ray_indices=ray_indices, n_rays=n_rays,
+                                                        alpha_fn=alpha_fn, chunk_size=self.secondary_shader_chunk)
+        return 1.0 - acc_map, depth_map
+
+    # ---- one ray batch (:224-443) ------------------------------------------------------------------------------
+    def forward_(self, rays, relighting=False, stratified_u=None):
+        if self.stage != 0:
+            raise NotImplementedError("stage 1 (split-sum shading) is the next SURVEY 8a row")
+        n_rays = rays.shape[0]
+        rays_o, rays_d = rays[:, 0:3].contiguous(), rays[:, 3:6].contiguous()
+        dev = rays.device
+
+        def rgb_normal_alpha_fn(t_starts, t_ends, ray_indices):
+            sdf, sdf_grad, normal, alphas, feature = self._stencil(rays_o, rays_d, ray_indices, t_starts,
+                                                                   t_ends, True)
+            t_dirs = rays_d[ray_indices]
+            positions = rays_o[ray_indices] + t_dirs * (t_starts + t_ends)[..., None] / 2.0
+            colors = self.texture(feature, t_dirs, normal, positions, self.emitter, self.stage)
+            return colors, normal, alphas, sdf, sdf_grad
+
+        with torch.no_grad():
+            ray_indices, t_starts, t_ends = self.occupancy_grid.sampling(
+                rays_o, rays_d, alpha_fn=self._alpha_fn(rays_o, rays_d),
+                render_step_size=self.render_step_size,
+                stratified=self.randomized and stratified_u is None, stratified_u=stratified_u,
+                cone_angle=0.0, alpha_thre=0.0)
+        rgb_map, normal_map, acc_map, depth_map, extras = rendering_with_normals_sdf(
+            t_starts, t_ends, ray_indices=ray_indices, n_rays=n_rays, rgb_alpha_fn=rgb_normal_alpha_fn,
+            render_bkgd=None, has_laplace=False, color_dim=7)
+
+        diff_rgb_map, spec_rgb_map, blend_map = rgb_map[..., :3], rgb_map[..., 3:6], rgb_map[..., 6:7]
+        valid_indices = torch.nonzero(acc_map > 0.5)[..., 0]
+        if valid_indices.numel() > 0 and self.config.get("indirect_pred", False):
+            sec_o = rays_o[valid_indices] + depth_map[valid_indices] * rays_d[valid_indices]
+            wo = -rays_d[valid_indices]
+            nv = normal_map[valid_indices]
+            sec_d = 2 * torch.sum(wo * nv, dim=-1, keepdim=True) * nv - wo
+            tr, _sec_depth = self.compute_indirect_radiance(sec_o.detach().contiguous(), sec_d.detach().contiguous())
+            tr = tr.clamp(0, 1).detach()
+            sec_feature = self.geometry(sec_o, with_grad=False, with_feature=True)[1]
+            sec_rgb = self.texture.secondary_shading(sec_feature, sec_d, nv)
+            spec_rgb_map = spec_rgb_map.clone()
+            spec_rgb_map[valid_indices] = tr * spec_rgb_map[valid_indices] + (1 - tr) * sec_rgb
+        rgb = diff_rgb_map + spec_rgb_map
+
+        out = {"comp_rgb": rgb, "comp_diffuse_rgb": diff_rgb_map, "comp_spec_rgb": spec_rgb_map,
+               "comp_blend": blend_map, "comp_normal": normal_map, "opacity": acc_map, "depth": depth_map,
+               "rays_valid": acc_map > 0,
+               "num_samples": torch.as_tensor([len(t_starts)], dtype=torch.int32, device=dev)}
+        if self.training:
+            weights = extras["weights"]
+            out.update({"sdf_samples": extras["sdf"], "sdf_grad_samples": extras["sdf_grad"],
+                        "weights": weights.view(-1), "ray_indices": ray_indices.view(-1)})
+            if ray_indices.numel() > 0:
+                orient = torch.sum(rays_d[ray_indices] * extras["normals"], dim=-1, keepdim=True).clamp(min=0)
+                out["normals_orientation_loss_map"] = ops.accumulate_along_rays(
+                    weights, orient, packed_info=extras["packed_info"])
+            else:
+                out["normals_orientation_loss_map"] = torch.zeros_like(rgb[..., :1])
+        bg = self.background_color if self.background_color is not None else torch.ones(3, device=dev)
+        out_bg = {"comp_rgb": bg[None, :].expand(*rgb.shape), "num_samples": torch.zeros_like(out["num_samples"]),
+                  "rays_valid": torch.zeros_like(out["rays_valid"])}
+        out_full = {"comp_rgb": T.rgb_to_srgb(out["comp_rgb"] + out_bg["comp_rgb"] * (1.0 - out["opacity"])).clamp(0, 1),
+                    "num_samples": out["num_samples"] + out_bg["num_samples"],
+                    "rays_valid": out["rays_valid"] | out_bg["rays_valid"]}
+        return {**out, **{k + "_bg": v for k, v in out_bg.items()}, **{k + "_full": v for k, v in out_full.items()}}
+
+    def forward(self, rays, relighting=False, **kw):
+        if self.training:
+            out = self.forward_(rays, relighting=relighting, **kw)
+        else:
+            out = chunk_batch(self.forward_, self.config.get("ray_chunk", 4096), False, rays, relighting)
+        return {**out, "inv_s": self.variance.inv_s}
+
+    def train(self, mode=True):
+        self.randomized = mode and self.config.get("randomized", True)
+        return super().train(mode=mode)
+
+    def eval(self):
+        self.randomized = False
+        return super().eval()
+
+    def regularizations(self, out):
+        losses = {}
+        losses.update(self.geometry.regularizations(out))
+        losses.update(self.texture.regularizations(out))
+        return losses
+
+
+def _registry():
+    from .registry import models
+    return models

