@@ -277,6 +277,23 @@ int rsdf_split_color0_bwd(const float *albedo6, const float *metallic2, const fl
 int rsdf_rgb_to_srgb_fwd(const float *x, int64_t n, float *y, void *stream);
 int rsdf_rgb_to_srgb_bwd(const float *x, const float *dy, int64_t n, float *dx, void *stream);
 
+/* ---- S2/S3: bilinear 2-D grid_sample with first- and second-order gradients ------------------------
+ * replaces aten grid_sample / grid_sampler_2d_backward as used by utils/cuda_gridsample.py:25-73 and
+ * grad2_2d (lib/grid_sample_grad2/gridsample_cuda.cpp:26-37, kernel gridsample_cuda.cu:27-210).
+ * input [N,C,H,W], grid [N,Ho,Wo,2] (x,y in [-1,1]), output [N,C,Ho,Wo]; padding_border: 0 zeros, 1
+ * border; aten coordinate conventions.  grad_input / g_input are ATOMICALLY accumulated (zero first);
+ * nullable outputs are skipped.  bwd2 returns d/d(grad_output), d/d(input), d/d(grid) of
+ * <g2_input, grad_input> + <g2_grid, grad_grid>. */
+int rsdf_grid_sample2d_fwd(const float *input, const float *grid, int N, int C, int H, int W, int Ho,
+                           int Wo, int padding_border, int align_corners, float *output, void *stream);
+int rsdf_grid_sample2d_bwd(const float *grad_output, const float *input, const float *grid, int N, int C,
+                           int H, int W, int Ho, int Wo, int padding_border, int align_corners,
+                           float *grad_input, float *grad_grid, void *stream);
+int rsdf_grid_sample2d_bwd2(const float *g2_input, const float *g2_grid, const float *grad_output,
+                            const float *input, const float *grid, int N, int C, int H, int W, int Ho,
+                            int Wo, int padding_border, int align_corners, float *gg_out, float *g_input,
+                            float *g_grid, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

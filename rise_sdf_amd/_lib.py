@@ -85,6 +85,9 @@ _SIGNATURES = {
     "rsdf_split_color0_bwd": [_P, _P, _P, _P, _L, _P, _P, _P, _P],
     "rsdf_rgb_to_srgb_fwd": [_P, _L, _P, _P],
     "rsdf_rgb_to_srgb_bwd": [_P, _P, _L, _P, _P],
+    "rsdf_grid_sample2d_fwd": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
+    "rsdf_grid_sample2d_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "rsdf_grid_sample2d_bwd2": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "rsdf_neus_alpha_fwd": [_P, _P, _P, _P, _P, _F, _L, _P, _P],
     "rsdf_neus_alpha_bwd": [_P, _P, _P, _P, _P, _F, _L, _P, _P, _P, _P, _P],
 }
