@@ -277,6 +277,44 @@ int rsdf_split_color0_bwd(const float *albedo6, const float *metallic2, const fl
 int rsdf_rgb_to_srgb_fwd(const float *x, int64_t n, float *y, void *stream);
 int rsdf_rgb_to_srgb_bwd(const float *x, const float *dy, int64_t n, float *dx, void *stream);
 
+/* stage-1 split-sum shading (models/texture.py:329-345) on ACTIVATED material values (sigmoid already
+ * applied: albedo6 = [diff_rgb | albedo], metallic2 = [blend | metallic]); colors24 in the channel order of
+ * texture.py:345 (consumed by the slices at models/split_mixed_occ.py:293-304). */
+int rsdf_split_shade1_fwd(const float *albedo6, const float *roughness, const float *metallic2,
+                          const float *spec3, const float *diffuse_light, const float *specular_light,
+                          const float *fg, int64_t n, float *colors24, void *stream);
+int rsdf_split_shade1_bwd(const float *albedo6, const float *metallic2, const float *spec3,
+                          const float *diffuse_light, const float *specular_light, const float *fg,
+                          const float *d_colors24, int64_t n, float *d_albedo6, float *d_roughness,
+                          float *d_metallic2, float *d_spec3, float *d_diffuse_light,
+                          float *d_specular_light, float *d_fg, void *stream);
+
+/* ---- S4/E1: environment light ----------------------------------------------------------------------
+ * Prefilters replace the renderutils plugin (lib/renderutils/c_src/torch_bindings.cpp:740-890, kernels
+ * cubemap.cu:110-350; Python wrappers lib/renderutils/ops.py:391-458).  Cube maps are NHWC [6,R,R,3] fp32.
+ *   diffuse:  out = sum_L clamp(N.L,0,.999) area(L)/3.141592 c(L); bwd is the adjoint as a GATHER.
+ *   bounds:   [6,R,R,24] float (per face xmin,xmax,ymin,ymax of texels with L.V >= cos_cutoff).
+ *   specular: out4 = [sum w c (3), sum w]; bwd (gather over the same window) takes grad_out with
+ *             grad_channels floats per texel (first 3 used) and returns grad_cubemap [6,R,R,3].
+ *   avgpool:  2x2 average (cubemap_mip forward, lib/pbr/utils/light_utils.py:94-98).
+ * Cube lookups replace dr.texture(boundary_mode='cube') (lib/pbr/light.py:194-206; nvdiffrast absent:
+ * definition in oracle/envlight.py).  mips: HOST array of n_mips device pointers, level l is
+ * [6, R0>>l, R0>>l, C]; level (nullable => level 0) is the mip_level_bias per sample; linear between the
+ * two nearest levels.  bwd: grad_mips (host array, entries nullable) are accumulated atomically. */
+int rsdf_diffuse_cubemap_fwd(const float *cubemap, int R, float *out, void *stream);
+int rsdf_diffuse_cubemap_bwd(const float *grad_out, int R, float *grad_cubemap, void *stream);
+int rsdf_specular_bounds(int R, float cos_cutoff, float *bounds, void *stream);
+int rsdf_specular_cubemap_fwd(const float *cubemap, const float *bounds, int R, float roughness,
+                              float cos_cutoff, float *out4, void *stream);
+int rsdf_specular_cubemap_bwd(const float *grad_out, int grad_channels, const float *bounds, int R,
+                              float roughness, float cos_cutoff, float *grad_cubemap, void *stream);
+int rsdf_cubemap_avgpool(const float *cubemap, int R, int C, float *out, void *stream);
+int rsdf_cube_sample_fwd(const float *const *mips /*host array*/, int n_mips, int R0, int C,
+                         const float *dirs, const float *level, int64_t n, float *out, void *stream);
+int rsdf_cube_sample_bwd(const float *const *mips /*host array*/, float *const *grad_mips /*host array*/,
+                         int n_mips, int R0, int C, const float *dirs, const float *level, int64_t n,
+                         const float *grad_out, float *grad_dirs, float *grad_level, void *stream);
+
 /* ---- S2/S3: bilinear 2-D grid_sample with first- and second-order gradients ------------------------
  * replaces aten grid_sample / grid_sampler_2d_backward as used by utils/cuda_gridsample.py:25-73 and
  * grad2_2d (lib/grid_sample_grad2/gridsample_cuda.cpp:26-37, kernel gridsample_cuda.cu:27-210).

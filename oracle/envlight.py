@@ -1,0 +1,203 @@
+"""Oracle for the environment-light rows.  TEST INFRASTRUCTURE ONLY.
+
+  cube_to_dir / pixel_area / diffuse / specular prefilter   lib/renderutils/c_src/cubemap.cu:17-46,110-350 and
+                                                            lib/renderutils/ops.py:428-458 (pinned by restatement:
+                                                            the CUDA source is in the tree but needs cuda/torch
+                                                            headers, unbuildable here)
+  cubemap_mip                                               lib/pbr/utils/light_utils.py:94-109
+  build_mips / get_mip / eval_mip                           lib/pbr/light.py:169-206
+  cube texture sampling                                     nvdiffrast ``dr.texture(boundary_mode='cube')`` is
+                                                            absent upstream => PARITY UNPINNED.  Definition used
+                                                            here and in csrc/envlight.hip: major-axis face
+                                                            selection with the face orientation of cube_to_dir,
+                                                            texel centres at (i+1/2)/R, bilinear taps that leave
+                                                            the face are re-projected through their 3-D direction
+                                                            onto the neighbouring face (nearest texel); explicit
+                                                            mip stack, level = mip_level_bias, linear between
+                                                            the two nearest levels.
+  split-sum shading (stage 1)                               models/texture.py:329-345
+Dense O(texels^2) forms: use small resolutions.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+
+def face_dir(s, fx, fy):
+    """Unnormalised direction of face s at face coordinates (fx, fy) in [-1,1] (cubemap.cu:32-46)."""
+    one = torch.ones_like(fx)
+    return [torch.stack((one, -fy, -fx), -1), torch.stack((-one, -fy, fx), -1), torch.stack((fx, one, fy), -1),
+            torch.stack((fx, -one, -fy), -1), torch.stack((fx, -fy, one), -1), torch.stack((-fx, -fy, -one), -1)][s]
+
+
+def texel_dirs(R, dtype=torch.float32):
+    """[6,R,R,3] normalised directions of texel centres; index [s, y, x]."""
+    c = 2.0 * ((torch.arange(R, dtype=dtype) + 0.5) / R) - 1.0
+    fy, fx = torch.meshgrid(c, c, indexing="ij")
+    d = torch.stack([face_dir(s, fx, fy) for s in range(6)], 0)
+    return d / d.norm(dim=-1, keepdim=True)
+
+
+def pixel_area(R, dtype=torch.float32):
+    """[R,R] solid-angle weights (cubemap.cu:17-30): separable atan differences."""
+    if R <= 1:
+        return torch.ones(R, R, dtype=dtype)
+    H = R // 2
+    i = (torch.arange(R) - H).abs().to(dtype)
+    a = torch.atan((i + 1) / H) - torch.atan(i / H)
+    return a[:, None] * a[None, :]   # [y, x]
+
+
+def diffuse_cubemap(cubemap):
+    """cubemap [6,R,R,3] -> [6,R,R,3]: sum_L clamp(N.L, 0, 0.999) * area / 3.141592 * c(L)  (:110-139)."""
+    R = cubemap.shape[1]
+    D = texel_dirs(R, cubemap.dtype).reshape(-1, 3)
+    w = (D @ D.T).clamp(0.0, 0.999) * pixel_area(R, cubemap.dtype).reshape(1, -1).repeat(1, 6) / 3.141592
+    return (w @ cubemap.reshape(-1, 3)).reshape(6, R, R, 3)
+
+
+def ndf_cutoff(roughness, cutoff=0.99, n_samples=1000000):
+    """cos(theta) below which the GGX NDF lobe holds ``cutoff`` of its energy (ops.py:428-442)."""
+    a2 = roughness ** 4
+    ct = np.cos(np.linspace(0, np.pi / 2.0, n_samples))
+    c = np.clip(ct, 0.0, 1.0)
+    d = (c * a2 - c) * c + 1.0
+    D = np.cumsum(a2 / (d * d * np.pi))
+    return float(ct[np.argmax(D >= D[-1] * cutoff)])
+
+
+def specular_weights(R, roughness, cutoff=0.99, dtype=torch.float64, chunk=1024, cos_shift=0.0):
+    """Dense [6RR, 6RR] prefilter weights (row = output texel V, column = input texel L): texels with
+    L.V >= cos_cutoff get (L.V) * D_ggx(V.H) * area / 4  (:246-298)."""
+    D = texel_dirs(R, dtype).reshape(-1, 3)
+    area = pixel_area(R, dtype).reshape(1, -1).repeat(1, 6)
+    cosc = ndf_cutoff(roughness, cutoff) + cos_shift
+    a2 = (roughness * roughness) ** 2
+    rows = []
+    for i in range(0, D.shape[0], chunk):
+        V = D[i:i + chunk]
+        dot = V @ D.T
+        Hh = V[:, None, :] + D[None, :, :]
+        Hh = Hh / Hh.norm(dim=-1, keepdim=True).clamp_min(1e-20)
+        vh = (Hh * V[:, None, :]).sum(-1).clamp(0.0, 1.0)
+        dd = (vh * a2 - vh) * vh + 1.0
+        w = dot.clamp_min(0.0) * (a2 / (dd * dd * math.pi)) * area / 4.0
+        rows.append(torch.where(dot >= cosc, w, torch.zeros_like(w)))
+    return torch.cat(rows, 0)
+
+
+def specular_cubemap(cubemap, roughness, cutoff=0.99, cos_shift=0.0):
+    """GGX prefilter (:246-298 + ops.py:458): weighted sum normalised by the weight sum; differentiable
+    in ``cubemap``.  ``cos_shift`` moves the window threshold (tests bracket the fp32 threshold compare of a
+    texel whose L.V is within rounding of the cutoff)."""
+    R = cubemap.shape[1]
+    with torch.no_grad():
+        w = specular_weights(R, roughness, cutoff, cubemap.dtype, cos_shift=cos_shift)
+    col = w @ cubemap.reshape(-1, 3)
+    return (col / w.sum(-1, keepdim=True)).reshape(6, R, R, 3)
+
+
+# ---- cube texture sampling (definition in the module docstring) ----------------------------------------------
+def dir_to_face_uv(d):
+    """d [S,3] -> (face int64 [S], fx, fy in [-1,1])."""
+    ax = d.abs()
+    x, y, z = d[:, 0], d[:, 1], d[:, 2]
+    is_x = (ax[:, 0] >= ax[:, 1]) & (ax[:, 0] >= ax[:, 2])
+    is_y = (~is_x) & (ax[:, 1] >= ax[:, 2])
+    face = torch.where(is_x, torch.where(x > 0, 0, 1), torch.where(is_y, torch.where(y > 0, 2, 3),
+                                                                  torch.where(z > 0, 4, 5)))
+    ma = torch.where(is_x, ax[:, 0], torch.where(is_y, ax[:, 1], ax[:, 2])).clamp_min(1e-30)
+    fx = torch.stack([-z, z, x, x, x, -x], 0).gather(0, face[None])[0] / ma
+    fy = torch.stack([-y, -y, z, -z, -y, -y], 0).gather(0, face[None])[0] / ma
+    return face, fx, fy
+
+
+def _fetch(tex, face, xi, yi):
+    """Texel fetch with cube wrap: taps outside [0,R) are re-projected through their direction."""
+    R = tex.shape[1]
+    inside = (xi >= 0) & (xi < R) & (yi >= 0) & (yi < R)
+    fx = 2.0 * ((xi.to(tex.dtype) + 0.5) / R) - 1.0
+    fy = 2.0 * ((yi.to(tex.dtype) + 0.5) / R) - 1.0
+    d = torch.stack([face_dir(s, fx, fy) for s in range(6)], 0).gather(
+        0, face[None, :, None].expand(1, -1, 3))[0]
+    f2, gx, gy = dir_to_face_uv(d)
+    x2 = torch.floor((gx + 1.0) * 0.5 * R).clamp(0, R - 1).long()
+    y2 = torch.floor((gy + 1.0) * 0.5 * R).clamp(0, R - 1).long()
+    f = torch.where(inside, face, f2)
+    xx = torch.where(inside, xi, x2)
+    yy = torch.where(inside, yi, y2)
+    return tex[f, yy, xx]
+
+
+def cube_sample_linear(tex, dirs):
+    """tex [6,R,R,C], dirs [S,3] (need not be normalised) -> [S,C]; differentiable in tex and dirs."""
+    R = tex.shape[1]
+    face, fx, fy = dir_to_face_uv(dirs)
+    px = (fx + 1.0) * 0.5 * R - 0.5
+    py = (fy + 1.0) * 0.5 * R - 0.5
+    x0, y0 = torch.floor(px.detach()).long(), torch.floor(py.detach()).long()
+    tx, ty = (px - x0)[:, None], (py - y0)[:, None]
+    return (_fetch(tex, face, x0, y0) * (1 - tx) * (1 - ty) + _fetch(tex, face, x0 + 1, y0) * tx * (1 - ty)
+            + _fetch(tex, face, x0, y0 + 1) * (1 - tx) * ty + _fetch(tex, face, x0 + 1, y0 + 1) * tx * ty)
+
+
+def cube_sample_mip(mips, dirs, level):
+    """mips: list of [6,R_l,R_l,C]; level [S] float (mip_level_bias) -> [S,C], linear-mipmap-linear."""
+    n = len(mips)
+    lv = level.clamp(0.0, float(n - 1))
+    l0 = torch.floor(lv.detach()).clamp(max=n - 1).long()
+    l1 = (l0 + 1).clamp(max=n - 1)
+    t = (lv - l0)[:, None]
+    out = 0
+    for l in range(n):
+        s = cube_sample_linear(mips[l], dirs)
+        out = out + s * ((l0 == l)[:, None] * (1 - t)) + s * (((l1 == l) & (l1 != l0))[:, None] * t)
+    return out
+
+
+# ---- light.py / light_utils.py ----------------------------------------------------------------------------------
+class _CubemapMip(torch.autograd.Function):
+    """lib/pbr/utils/light_utils.py:94-109: forward = 2x2 average pool; backward = cube-linear lookup of
+    0.25*dout at the finer level's texel directions (NOT the exact adjoint -- restated as the reference)."""
+
+    @staticmethod
+    def forward(ctx, cubemap):
+        s, R = cubemap.shape[0], cubemap.shape[1]
+        return cubemap.reshape(s, R // 2, 2, R // 2, 2, -1).mean(dim=(2, 4))
+
+    @staticmethod
+    def backward(ctx, dout):
+        res = dout.shape[1] * 2
+        d = texel_dirs(res, dout.dtype).reshape(-1, 3)
+        return cube_sample_linear(dout * 0.25, d).reshape(6, res, res, -1)
+
+
+def cubemap_mip(cubemap):
+    return _CubemapMip.apply(cubemap)
+
+
+LIGHT_MIN_RES, MIN_ROUGHNESS, MAX_ROUGHNESS = 16, 0.08, 0.5
+
+
+def build_mips(base, cutoff=0.99):
+    """lib/pbr/light.py:169-180 -> (specular list, diffuse)."""
+    spec = [base]
+    while spec[-1].shape[1] > LIGHT_MIN_RES:
+        spec.append(cubemap_mip(spec[-1]))
+    diffuse = diffuse_cubemap(spec[-1])
+    for i in range(len(spec) - 1):
+        r = (i / (len(spec) - 2)) * (MAX_ROUGHNESS - MIN_ROUGHNESS) + MIN_ROUGHNESS
+        spec[i] = specular_cubemap(spec[i], r, cutoff)
+    spec[-1] = specular_cubemap(spec[-1], 1.0, cutoff)
+    return spec, diffuse
+
+
+def get_mip(roughness, n_mips):
+    """lib/pbr/light.py:182-185."""
+    return torch.where(roughness < MAX_ROUGHNESS,
+                       (roughness.clamp(MIN_ROUGHNESS, MAX_ROUGHNESS) - MIN_ROUGHNESS)
+                       / (MAX_ROUGHNESS - MIN_ROUGHNESS) * (n_mips - 2),
+                       (roughness.clamp(MAX_ROUGHNESS, 1.0) - MAX_ROUGHNESS) / (1.0 - MAX_ROUGHNESS) + n_mips - 2)

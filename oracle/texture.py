@@ -92,3 +92,41 @@ def texture_stage0(features, dirs, normals, positions, nets, n_frequencies=6, sh
 
 def rgb_to_srgb(f):
     return torch.where(f <= 0.0031308, f * 12.92, torch.pow(torch.clamp(f, 0.0031308), 1.0 / 2.4) * 1.055 - 0.055)
+
+
+def synthetic_fg_lut(res=256):
+    """Deterministic smooth stand-in [1,res,res,2] for the reference's load/bsdf/bsdf_256_256.bin (not in its
+    repository); used by the stage-1 golden fixture and its tests only.  [0, y(roughness), x(NoV), :]."""
+    c = (torch.arange(res, dtype=torch.float64) + 0.5) / res
+    v, u = torch.meshgrid(c, c, indexing="ij")
+    a = 1.0 - 0.6 * v * (1.0 - u) - 0.2 * (1 - u) ** 3
+    b = 0.25 * (1.0 - u) ** 2 * (1.0 - 0.5 * v) + 0.02 * torch.sin(7.0 * u + 3.0 * v)
+    return torch.stack([a, b], -1)[None].float()
+
+
+def texture_stage1(features, dirs, normals, positions, nets, fg_lut, eval_diffuse, eval_specular,
+                   n_frequencies=6, sh_degree=5):
+    """Stage-1 colours [S,24] (models/texture.py:292-345).  ``eval_diffuse(normals)`` and
+    ``eval_specular(wo, roughness)`` are the emitter lookups; fg_lut [1,H,W,2]."""
+    from . import gridsample as ogs
+    wo, nov = reflect_dirs(dirs, normals)
+    xyz = vanilla_frequency(positions, n_frequencies)
+    inp = torch.cat([features, xyz], -1)
+    albedo6 = torch.sigmoid(relu_mlp(inp, nets["albedo"]))
+    roughness = torch.sigmoid(relu_mlp(inp, nets["roughness"]))
+    metallic2 = torch.sigmoid(relu_mlp(inp, nets["metallic"]))
+    wo_enc = sh_encode((wo + 1.0) / 2.0, sh_degree)
+    spec = torch.sigmoid(relu_mlp(torch.cat([features, wo_enc], -1), nets["env"]))
+    diff_rgb, albedo = albedo6[..., :3], albedo6[..., 3:]
+    blend, metallic = metallic2[..., :1], metallic2[..., 1:]
+    spec_rgb = blend * spec
+    diff_rgb = (1 - blend) * diff_rgb
+    diff_pbr = (1 - metallic) * albedo * eval_diffuse(normals)
+    spec_albedo = 0.04 * (1 - metallic) + metallic * albedo
+    spec_light = eval_specular(wo, roughness)
+    uv = torch.cat([nov.clamp(0.0, 1.0), roughness.clamp(0.0, 1.0)], -1)
+    grid = (uv * 2.0 - 1.0).reshape(1, -1, 1, 2)
+    fg = ogs.grid_sample_2d(fg_lut.permute(0, 3, 1, 2).to(uv.dtype), grid, "border", False)[0, :, :, 0].t()
+    spec_ref = spec_albedo * fg[:, 0:1] + fg[:, 1:2]
+    return torch.cat([diff_rgb, spec_rgb, blend, diff_pbr, spec_ref * spec_light, spec_ref, spec_light, albedo,
+                      metallic, roughness], -1)

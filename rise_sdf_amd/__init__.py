@@ -15,7 +15,7 @@ from .config import Config, config_to_primitive, load_yaml  # noqa: F401
 
 
 def _register_all():
-    from . import geometry, neus, split_mixed_occ, texture  # noqa: F401
+    from . import envlight, geometry, neus, split_mixed_occ, texture  # noqa: F401
 
 
 _register_all()

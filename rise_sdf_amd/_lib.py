@@ -85,6 +85,16 @@ _SIGNATURES = {
     "rsdf_split_color0_bwd": [_P, _P, _P, _P, _L, _P, _P, _P, _P],
     "rsdf_rgb_to_srgb_fwd": [_P, _L, _P, _P],
     "rsdf_rgb_to_srgb_bwd": [_P, _P, _L, _P, _P],
+    "rsdf_split_shade1_fwd": [_P, _P, _P, _P, _P, _P, _P, _L, _P, _P],
+    "rsdf_split_shade1_bwd": [_P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P],
+    "rsdf_diffuse_cubemap_fwd": [_P, _I, _P, _P],
+    "rsdf_diffuse_cubemap_bwd": [_P, _I, _P, _P],
+    "rsdf_specular_bounds": [_I, _F, _P, _P],
+    "rsdf_specular_cubemap_fwd": [_P, _P, _I, _F, _F, _P, _P],
+    "rsdf_specular_cubemap_bwd": [_P, _I, _P, _I, _F, _F, _P, _P],
+    "rsdf_cubemap_avgpool": [_P, _I, _I, _P, _P],
+    "rsdf_cube_sample_fwd": [_P, _I, _I, _I, _P, _P, _L, _P, _P],
+    "rsdf_cube_sample_bwd": [_P, _P, _I, _I, _I, _P, _P, _L, _P, _P, _P, _P],
     "rsdf_grid_sample2d_fwd": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "rsdf_grid_sample2d_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "rsdf_grid_sample2d_bwd2": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],

@@ -1,0 +1,433 @@
+// S4 / E1: environment light -- cube-map prefilters (diffuse, GGX specular, mip chain) and cube texture
+// lookups (bilinear, explicit-mip trilinear) with their backward passes.
+//
+// Specification followed (paths relative to the upstream RISE-SDF tree):
+//   lib/renderutils/c_src/cubemap.cu:17-46      pixel_area, cube_to_dir (face orientation)
+//   lib/renderutils/c_src/cubemap.cu:110-169    DiffuseCubemapFwd/Bwd
+//   lib/renderutils/c_src/cubemap.cu:181-244    SpecularBoundsKernel (per-texel, per-face bbox of the lobe
+//                                               cone, 16x16-tile interval culling)
+//   lib/renderutils/c_src/cubemap.cu:246-350    SpecularCubemapFwd/Bwd (+ the /wsum of lib/renderutils/ops.py:458)
+//   lib/pbr/utils/light_utils.py:94-109         cubemap_mip (2x2 average; backward = cube-linear lookup of dout/4)
+//   lib/pbr/light.py:188-206                    eval_mip: dr.texture(..., boundary_mode='cube'), linear or
+//                                               linear-mipmap-linear with mip_level_bias
+// nvdiffrast is absent upstream: the cube lookup is this build's definition (oracle/envlight.py docstring).
+//
+// MI355X notes.  The reference's backward prefilters scatter with atomicAdd from every output texel.  The
+// prefilter weights depend on (L.V) and on the INPUT texel's solid angle only, so the backward is written
+// as a gather over the same lobe window (the cone around L is the set of outputs that saw L): no atomics,
+// deterministic, same traffic as the forward.  Per-texel directions are recomputed (one rsqrt) instead of
+// fetched; the separable solid-angle factor comes from a small LDS table.
+#include "common.h"
+
+namespace {
+
+constexpr int THREADS = 256;
+
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ float dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 normalize3(V3 a)
+{
+    const float l = sqrtf(fmaxf(dot3(a, a), 1e-20f));
+    return v3(a.x / l, a.y / l, a.z / l);
+}
+__device__ __forceinline__ V3 face_vec(int s, float fx, float fy)
+{
+    switch (s) {
+    case 0: return v3(1.f, -fy, -fx);
+    case 1: return v3(-1.f, -fy, fx);
+    case 2: return v3(fx, 1.f, fy);
+    case 3: return v3(fx, -1.f, -fy);
+    case 4: return v3(fx, -fy, 1.f);
+    default: return v3(-fx, -fy, -1.f);
+    }
+}
+__device__ __forceinline__ V3 cube_to_dir(int x, int y, int s, int N)
+{
+    const float fx = 2.0f * (((float)x + 0.5f) / (float)N) - 1.0f;
+    const float fy = 2.0f * (((float)y + 0.5f) / (float)N) - 1.0f;
+    return normalize3(face_vec(s, fx, fy));
+}
+// separable factor of pixel_area: area(x,y) = side(x) * side(y)
+__device__ __forceinline__ float area_side(int i, int N)
+{
+    if (N <= 1) return 1.0f;
+    const int H = N / 2;
+    const int a = abs(i - H);
+    // atan((a+1)/H) - atan(a/H) (cubemap.cu:24) as one atan: no cancellation at large H
+    return atanf((float)H / (float)(H * H + a * (a + 1)));
+}
+
+// ------------------------------------------------------------------------------------------------
+// diffuse (R is small: 16)
+// ------------------------------------------------------------------------------------------------
+template <bool BWD>
+__global__ void __launch_bounds__(THREADS)
+diffuse_kernel(const float *__restrict__ src, int R, float *__restrict__ dst)
+{
+    extern __shared__ float s_side[];  // [R]
+    for (int i = threadIdx.x; i < R; i += THREADS) s_side[i] = area_side(i, R);
+    __syncthreads();
+    const int idx = blockIdx.x * THREADS + threadIdx.x;
+    if (idx >= 6 * R * R) return;
+    const int s0 = idx / (R * R), y0 = (idx / R) % R, x0 = idx % R;
+    const V3 A = cube_to_dir(x0, y0, s0, R);
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    for (int s = 0; s < 6; ++s)
+        for (int y = 0; y < R; ++y)
+            for (int x = 0; x < R; ++x) {
+                const V3 B = cube_to_dir(x, y, s, R);
+                const float ct = fminf(fmaxf(dot3(A, B), 0.0f), 0.999f);
+                // forward: weight uses the INPUT texel's area; backward (gather at the input texel A): the
+                // area factor is A's own and is applied after the loop
+                const float w = BWD ? ct : ct * s_side[x] * s_side[y] / 3.141592f;
+                const float *p = src + ((s * R + y) * R + x) * 3;
+                c0 += p[0] * w; c1 += p[1] * w; c2 += p[2] * w;
+            }
+    if (BWD) {
+        const float a = s_side[x0] * s_side[y0] / 3.141592f;
+        c0 *= a; c1 *= a; c2 *= a;
+    }
+    float *o = dst + idx * 3;
+    o[0] = c0; o[1] = c1; o[2] = c2;
+}
+
+// ------------------------------------------------------------------------------------------------
+// specular bounds
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(THREADS)
+bounds_kernel(int R, float cos_cutoff, float *__restrict__ bounds)
+{
+    const int idx = blockIdx.x * THREADS + threadIdx.x;
+    if (idx >= 6 * R * R) return;
+    const int pz = idx / (R * R), py = (idx / R) % R, px = idx % R;
+    const V3 V = cube_to_dir(px, py, pz, R);
+    constexpr int TILE = 16;
+    const int nt = (R + TILE - 1) / TILE;
+    for (int s = 0; s < 6; ++s) {
+        int mnx = R - 1, mxx = 0, mny = R - 1, mxy = 0;
+        for (int tx = 0; tx < nt; ++tx)
+            for (int ty = 0; ty < nt; ++ty) {
+                const int tsx = tx * TILE, tsy = ty * TILE;
+                const int tex = min((tx + 1) * TILE, R), tey = min((ty + 1) * TILE, R);
+                const V3 L0 = cube_to_dir(tsx, tsy, s, R), L1 = cube_to_dir(tex, tsy, s, R);
+                const V3 L2 = cube_to_dir(tsx, tey, s, R), L3 = cube_to_dir(tex, tey, s, R);
+                const float minx = fminf(fminf(L0.x, L1.x), fminf(L2.x, L3.x)), maxx = fmaxf(fmaxf(L0.x, L1.x), fmaxf(L2.x, L3.x));
+                const float miny = fminf(fminf(L0.y, L1.y), fminf(L2.y, L3.y)), maxy = fmaxf(fmaxf(L0.y, L1.y), fmaxf(L2.y, L3.y));
+                const float minz = fminf(fminf(L0.z, L1.z), fminf(L2.z, L3.z)), maxz = fmaxf(fmaxf(L0.z, L1.z), fmaxf(L2.z, L3.z));
+                const float maxdp = fmaxf(minx * V.x, maxx * V.x) + fmaxf(miny * V.y, maxy * V.y) +
+                                    fmaxf(minz * V.z, maxz * V.z);
+                if (maxdp >= cos_cutoff) {
+                    for (int y = tsy; y < tey; ++y)
+                        for (int x = tsx; x < tex; ++x)
+                            if (dot3(cube_to_dir(x, y, s, R), V) >= cos_cutoff) {
+                                mnx = min(mnx, x); mxx = max(mxx, x);
+                                mny = min(mny, y); mxy = max(mxy, y);
+                            }
+                }
+            }
+        float *o = bounds + (size_t)idx * 24 + s * 4;
+        o[0] = (float)mnx; o[1] = (float)mxx; o[2] = (float)mny; o[3] = (float)mxy;
+    }
+}
+
+// GGX NDF at cos = V.H with H = normalize(A + B), A and B unit (bsdf.h ndf_ggx: a2 / (pi d^2), d = (c a2 - c) c + 1).
+// d = 1 - c^2 (1 - a2) cancels catastrophically in fp32 for narrow lobes (a2 ~ 4e-5 at roughness 0.08), so it is
+// evaluated as d = sin^2 (1 - a2) + a2 with sin^2 = |A x B|^2 / |A + B|^2 -- the same function, full precision.
+__device__ __forceinline__ float ndf_ggx_pair(float a2, V3 A, V3 B)
+{
+    const V3 c = v3(A.y * B.z - A.z * B.y, A.z * B.x - A.x * B.z, A.x * B.y - A.y * B.x);
+    const V3 h = v3(A.x + B.x, A.y + B.y, A.z + B.z);
+    const float s2 = fminf(dot3(c, c) / dot3(h, h), 1.0f);
+    const float d = fmaf(s2, 1.0f - a2, a2);
+    return a2 / (d * d * 3.14159265358979323846f);
+}
+
+// forward: out4 = [sum w c, sum w];  backward (gather): dcube[L] = area(L)/4 * sum_V g[V] (L.V) D(V.H)
+template <bool BWD>
+__global__ void __launch_bounds__(THREADS)
+specular_kernel(const float *__restrict__ src, int src_ch, const float *__restrict__ bounds, int R,
+                float roughness, float cos_cutoff, float *__restrict__ dst)
+{
+    extern __shared__ float s_side[];
+    for (int i = threadIdx.x; i < R; i += THREADS) s_side[i] = area_side(i, R);
+    __syncthreads();
+    const int idx = blockIdx.x * THREADS + threadIdx.x;
+    if (idx >= 6 * R * R) return;
+    const int s0 = idx / (R * R), y0 = (idx / R) % R, x0 = idx % R;
+    const V3 A = cube_to_dir(x0, y0, s0, R);
+    const float alpha = roughness * roughness, a2 = alpha * alpha;
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f, wsum = 0.f;
+    for (int s = 0; s < 6; ++s) {
+        const float *b = bounds + (size_t)idx * 24 + s * 4;
+        const int xmin = (int)b[0], xmax = (int)b[1], ymin = (int)b[2], ymax = (int)b[3];
+        if (xmin > xmax) continue;
+        for (int y = ymin; y <= ymax; ++y)
+            for (int x = xmin; x <= xmax; ++x) {
+                const V3 B = cube_to_dir(x, y, s, R);
+                const float d = dot3(B, A);
+                if (d < cos_cutoff) continue;
+                const float geom = fmaxf(d, 0.0f) * ndf_ggx_pair(a2, A, B);
+                const float w = BWD ? geom : geom * s_side[x] * s_side[y] / 4.0f;
+                const float *p = src + (size_t)((s * R + y) * R + x) * src_ch;
+                c0 += p[0] * w; c1 += p[1] * w; c2 += p[2] * w;
+                wsum += w;
+            }
+    }
+    if (BWD) {
+        const float a = s_side[x0] * s_side[y0] / 4.0f;
+        float *o = dst + (size_t)idx * 3;
+        o[0] = c0 * a; o[1] = c1 * a; o[2] = c2 * a;
+    } else {
+        float *o = dst + (size_t)idx * 4;
+        o[0] = c0; o[1] = c1; o[2] = c2; o[3] = wsum;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2x2 average pool of a [6,R,R,C] cube map
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(THREADS)
+avgpool_kernel(const float *__restrict__ src, int R, int C, float *__restrict__ dst)
+{
+    const int Rh = R / 2;
+    const int64_t idx = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (idx >= (int64_t)6 * Rh * Rh * C) return;
+    const int c = idx % C;
+    const int x = (idx / C) % Rh, y = (idx / ((int64_t)C * Rh)) % Rh, s = idx / ((int64_t)C * Rh * Rh);
+    const float *p = src + ((size_t)(s * R + 2 * y) * R + 2 * x) * C + c;
+    dst[idx] = (p[0] + p[C] + p[(size_t)R * C] + p[(size_t)R * C + C]) * 0.25f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// cube texture lookup
+// ------------------------------------------------------------------------------------------------
+struct FaceUV { int face; float fx, fy, ma; };
+
+__device__ __forceinline__ FaceUV dir_to_face(float x, float y, float z)
+{
+    const float ax = fabsf(x), ay = fabsf(y), az = fabsf(z);
+    FaceUV r;
+    if (ax >= ay && ax >= az) {
+        r.face = x > 0.f ? 0 : 1; r.ma = fmaxf(ax, 1e-30f);
+        r.fx = (x > 0.f ? -z : z) / r.ma; r.fy = -y / r.ma;
+    } else if (ay >= az) {
+        r.face = y > 0.f ? 2 : 3; r.ma = fmaxf(ay, 1e-30f);
+        r.fx = x / r.ma; r.fy = (y > 0.f ? z : -z) / r.ma;
+    } else {
+        r.face = z > 0.f ? 4 : 5; r.ma = fmaxf(az, 1e-30f);
+        r.fx = (z > 0.f ? x : -x) / r.ma; r.fy = -y / r.ma;
+    }
+    return r;
+}
+
+// resolve a (possibly out-of-face) texel to its storage offset (in texels) inside a [6,R,R] image
+__device__ __forceinline__ int texel_offset(int face, int xi, int yi, int R)
+{
+    if (xi >= 0 && xi < R && yi >= 0 && yi < R) return (face * R + yi) * R + xi;
+    const float fx = 2.0f * (((float)xi + 0.5f) / (float)R) - 1.0f;
+    const float fy = 2.0f * (((float)yi + 0.5f) / (float)R) - 1.0f;
+    const V3 d = face_vec(face, fx, fy);
+    const FaceUV f2 = dir_to_face(d.x, d.y, d.z);
+    const int x2 = min(max((int)floorf((f2.fx + 1.0f) * 0.5f * (float)R), 0), R - 1);
+    const int y2 = min(max((int)floorf((f2.fy + 1.0f) * 0.5f * (float)R), 0), R - 1);
+    return (f2.face * R + y2) * R + x2;
+}
+
+struct Bilin {
+    int off[4];
+    float w[4], dwx[4], dwy[4];
+};
+
+__device__ __forceinline__ Bilin bilin_setup(const FaceUV &f, int R)
+{
+    Bilin b;
+    const float px = (f.fx + 1.0f) * 0.5f * (float)R - 0.5f;
+    const float py = (f.fy + 1.0f) * 0.5f * (float)R - 0.5f;
+    const float flx = floorf(px), fly = floorf(py);
+    const int x0 = (int)flx, y0 = (int)fly;
+    const float tx = px - flx, ty = py - fly;
+    b.w[0] = (1.f - tx) * (1.f - ty); b.w[1] = tx * (1.f - ty); b.w[2] = (1.f - tx) * ty; b.w[3] = tx * ty;
+    b.dwx[0] = -(1.f - ty); b.dwx[1] = (1.f - ty); b.dwx[2] = -ty; b.dwx[3] = ty;
+    b.dwy[0] = -(1.f - tx); b.dwy[1] = -tx; b.dwy[2] = (1.f - tx); b.dwy[3] = tx;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) b.off[k] = texel_offset(f.face, x0 + (k & 1), y0 + (k >> 1), R);
+    return b;
+}
+
+struct MipStack {
+    const float *tex[8];
+    float *grad[8];
+    int n, R0, C;
+};
+
+__global__ void __launch_bounds__(THREADS)
+cube_sample_fwd_kernel(MipStack m, const float *__restrict__ dirs, const float *__restrict__ level, int64_t n,
+                       float *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= n) return;
+    const FaceUV f = dir_to_face(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
+    float lv = level ? fminf(fmaxf(level[i], 0.0f), (float)(m.n - 1)) : 0.0f;
+    const int l0 = min((int)floorf(lv), m.n - 1), l1 = min(l0 + 1, m.n - 1);
+    const float t = lv - (float)l0;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int l = pass == 0 ? l0 : l1;
+        const float wl = pass == 0 ? 1.0f - t : t;
+        if (pass == 1 && (l1 == l0 || wl == 0.0f)) break;
+        const int R = m.R0 >> l;
+        const Bilin b = bilin_setup(f, R);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float *p = m.tex[l] + (size_t)b.off[k] * m.C;
+            for (int c = 0; c < m.C; ++c) acc[c] += wl * b.w[k] * p[c];
+        }
+    }
+    for (int c = 0; c < m.C; ++c) out[i * m.C + c] = acc[c];
+}
+
+// d_out -> d_tex (atomics), d_dirs, d_level
+__global__ void __launch_bounds__(THREADS)
+cube_sample_bwd_kernel(MipStack m, const float *__restrict__ dirs, const float *__restrict__ level, int64_t n,
+                       const float *__restrict__ dout, float *__restrict__ d_dirs, float *__restrict__ d_level)
+{
+    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= n) return;
+    const float dx = dirs[3 * i], dy = dirs[3 * i + 1], dz = dirs[3 * i + 2];
+    const FaceUV f = dir_to_face(dx, dy, dz);
+    const float lraw = level ? level[i] : 0.0f;
+    const float lv = fminf(fmaxf(lraw, 0.0f), (float)(m.n - 1));
+    const int l0 = min((int)floorf(lv), m.n - 1), l1 = min(l0 + 1, m.n - 1);
+    const float t = lv - (float)l0;
+    float g[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < m.C; ++c) g[c] = dout[i * m.C + c];
+    float dfx = 0.f, dfy = 0.f, s0 = 0.f, s1 = 0.f;  // d/d(face coords), <g, sample(l0)>, <g, sample(l1)>
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int l = pass == 0 ? l0 : l1;
+        const float wl = pass == 0 ? 1.0f - t : t;
+        if (pass == 1 && l1 == l0) break;
+        const int R = m.R0 >> l;
+        const Bilin b = bilin_setup(f, R);
+        float sv = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float *p = m.tex[l] + (size_t)b.off[k] * m.C;
+            float gp = 0.f;
+            for (int c = 0; c < m.C; ++c) gp += g[c] * p[c];
+            sv += b.w[k] * gp;
+            // pixel coords px = (fx + 1) R/2 - 1/2  =>  d px / d fx = R/2
+            dfx += wl * b.dwx[k] * gp * 0.5f * (float)R;
+            dfy += wl * b.dwy[k] * gp * 0.5f * (float)R;
+            if (m.grad[l] && wl != 0.0f) {
+                float *q = m.grad[l] + (size_t)b.off[k] * m.C;
+                for (int c = 0; c < m.C; ++c) atomicAdd(q + c, wl * b.w[k] * g[c]);
+            }
+        }
+        if (pass == 0) s0 = sv; else s1 = sv;
+    }
+    if (d_level) d_level[i] = (level && lraw > 0.0f && lraw < (float)(m.n - 1) && l1 != l0) ? (s1 - s0) : 0.0f;
+    if (d_dirs) {
+        // fx = sx * comp_u / ma, fy = sy * comp_v / ma with ma = |major component|
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        const float ima = 1.0f / f.ma;
+        switch (f.face) {
+        case 0: gz = -dfx * ima; gy = -dfy * ima; gx = -(f.fx * dfx + f.fy * dfy) * ima; break;           // ma = x
+        case 1: gz = dfx * ima;  gy = -dfy * ima; gx = (f.fx * dfx + f.fy * dfy) * ima; break;            // ma = -x
+        case 2: gx = dfx * ima;  gz = dfy * ima;  gy = -(f.fx * dfx + f.fy * dfy) * ima; break;           // ma = y
+        case 3: gx = dfx * ima;  gz = -dfy * ima; gy = (f.fx * dfx + f.fy * dfy) * ima; break;            // ma = -y
+        case 4: gx = dfx * ima;  gy = -dfy * ima; gz = -(f.fx * dfx + f.fy * dfy) * ima; break;           // ma = z
+        default: gx = -dfx * ima; gy = -dfy * ima; gz = (f.fx * dfx + f.fy * dfy) * ima; break;           // ma = -z
+        }
+        d_dirs[3 * i] = gx; d_dirs[3 * i + 1] = gy; d_dirs[3 * i + 2] = gz;
+    }
+}
+
+MipStack make_stack(const float *const *tex, float *const *grad, int n, int R0, int C)
+{
+    MipStack m;
+    for (int l = 0; l < 8; ++l) {
+        m.tex[l] = l < n ? tex[l] : nullptr;
+        m.grad[l] = (grad && l < n) ? grad[l] : nullptr;
+    }
+    m.n = n; m.R0 = R0; m.C = C;
+    return m;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rsdf_diffuse_cubemap_fwd(const float *cubemap, int R, float *out, void *stream)
+{
+    RSDF_CHECK_ARG(R >= 1 && R <= 64, "diffuse_cubemap: R must be in [1,64] (all-pairs filter)");
+    diffuse_kernel<false><<<rsdf_blocks(6 * R * R, THREADS), THREADS, R * sizeof(float), (hipStream_t)stream>>>(cubemap, R, out);
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_diffuse_cubemap_bwd(const float *grad_out, int R, float *grad_cubemap, void *stream)
+{
+    RSDF_CHECK_ARG(R >= 1 && R <= 64, "diffuse_cubemap: R must be in [1,64] (all-pairs filter)");
+    diffuse_kernel<true><<<rsdf_blocks(6 * R * R, THREADS), THREADS, R * sizeof(float), (hipStream_t)stream>>>(grad_out, R, grad_cubemap);
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_specular_bounds(int R, float cos_cutoff, float *bounds, void *stream)
+{
+    RSDF_CHECK_ARG(R >= 1, "specular_bounds: bad resolution");
+    bounds_kernel<<<rsdf_blocks(6 * R * R, THREADS), THREADS, 0, (hipStream_t)stream>>>(R, cos_cutoff, bounds);
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_specular_cubemap_fwd(const float *cubemap, const float *bounds, int R, float roughness,
+                              float cos_cutoff, float *out4, void *stream)
+{
+    RSDF_CHECK_ARG(R >= 1 && R <= 4096, "specular_cubemap_fwd: bad resolution");
+    specular_kernel<false><<<rsdf_blocks(6 * R * R, THREADS), THREADS, R * sizeof(float), (hipStream_t)stream>>>(
+        cubemap, 3, bounds, R, roughness, cos_cutoff, out4);
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_specular_cubemap_bwd(const float *grad_out, int grad_channels, const float *bounds, int R,
+                              float roughness, float cos_cutoff, float *grad_cubemap, void *stream)
+{
+    RSDF_CHECK_ARG(R >= 1 && R <= 4096 && grad_channels >= 3, "specular_cubemap_bwd: bad arguments");
+    specular_kernel<true><<<rsdf_blocks(6 * R * R, THREADS), THREADS, R * sizeof(float), (hipStream_t)stream>>>(
+        grad_out, grad_channels, bounds, R, roughness, cos_cutoff, grad_cubemap);
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_cubemap_avgpool(const float *cubemap, int R, int C, float *out, void *stream)
+{
+    RSDF_CHECK_ARG(R >= 2 && (R % 2) == 0 && C >= 1, "cubemap_avgpool: R must be even");
+    const int64_t n = (int64_t)6 * (R / 2) * (R / 2) * C;
+    avgpool_kernel<<<rsdf_blocks(n, THREADS), THREADS, 0, (hipStream_t)stream>>>(cubemap, R, C, out);
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_cube_sample_fwd(const float *const *mips, int n_mips, int R0, int C, const float *dirs,
+                         const float *level, int64_t n, float *out, void *stream)
+{
+    RSDF_CHECK_ARG(n_mips >= 1 && n_mips <= 8 && C >= 1 && C <= 4 && (R0 >> (n_mips - 1)) >= 1,
+                   "cube_sample_fwd: bad mip stack");
+    if (n <= 0) return 0;
+    cube_sample_fwd_kernel<<<rsdf_blocks(n, THREADS), THREADS, 0, (hipStream_t)stream>>>(
+        make_stack(mips, nullptr, n_mips, R0, C), dirs, level, n, out);
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_cube_sample_bwd(const float *const *mips, float *const *grad_mips, int n_mips, int R0, int C,
+                         const float *dirs, const float *level, int64_t n, const float *grad_out,
+                         float *grad_dirs, float *grad_level, void *stream)
+{
+    RSDF_CHECK_ARG(n_mips >= 1 && n_mips <= 8 && C >= 1 && C <= 4 && (R0 >> (n_mips - 1)) >= 1,
+                   "cube_sample_bwd: bad mip stack");
+    if (n <= 0) return 0;
+    cube_sample_bwd_kernel<<<rsdf_blocks(n, THREADS), THREADS, 0, (hipStream_t)stream>>>(
+        make_stack(mips, grad_mips, n_mips, R0, C), dirs, level, n, grad_out, grad_dirs, grad_level);
+    RSDF_RETURN_LAUNCH();
+}
+
+}  // extern "C"

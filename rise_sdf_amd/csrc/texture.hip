@@ -228,6 +228,77 @@ split_color0_bwd_kernel(const float *__restrict__ albedo6, const float *__restri
     d_metallic2[2 * i + 1] = 0.0f;
 }
 
+// stage 1 (split-sum shading, models/texture.py:329-345) on ACTIVATED material values:
+//   a6 = sigmoid(albedo net) [diff_rgb(3) | albedo(3)], m2 = sigmoid(metallic net) [blend | metallic],
+//   r = sigmoid(roughness net), s3 = sigmoid(env net); Ld/Ls diffuse / specular light, fg the LUT lookup.
+// colors24 = [diff_rf(3), spec_rf(3), blend, diff_pbr(3), spec_pbr(3), spec_ref(3), Ls(3), albedo(3), metallic, r]
+__global__ void __launch_bounds__(THREADS)
+split_shade1_fwd_kernel(const float *__restrict__ a6, const float *__restrict__ r1,
+                        const float *__restrict__ m2, const float *__restrict__ s3,
+                        const float *__restrict__ Ld, const float *__restrict__ Ls,
+                        const float *__restrict__ fg, int64_t n, float *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= n) return;
+    const float blend = m2[2 * i], metal = m2[2 * i + 1];
+    const float fgx = fg[2 * i], fgy = fg[2 * i + 1];
+    float *o = out + 24 * i;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float alb = a6[6 * i + 3 + c];
+        const float sref = (0.04f * (1.0f - metal) + metal * alb) * fgx + fgy;
+        o[c] = (1.0f - blend) * a6[6 * i + c];
+        o[3 + c] = blend * s3[3 * i + c];
+        o[7 + c] = (1.0f - metal) * alb * Ld[3 * i + c];
+        o[10 + c] = sref * Ls[3 * i + c];
+        o[13 + c] = sref;
+        o[16 + c] = Ls[3 * i + c];
+        o[19 + c] = alb;
+    }
+    o[6] = blend;
+    o[22] = metal;
+    o[23] = r1[i];
+}
+
+__global__ void __launch_bounds__(THREADS)
+split_shade1_bwd_kernel(const float *__restrict__ a6, const float *__restrict__ m2,
+                        const float *__restrict__ s3, const float *__restrict__ Ld,
+                        const float *__restrict__ Ls, const float *__restrict__ fg,
+                        const float *__restrict__ g, int64_t n, float *__restrict__ d_a6,
+                        float *__restrict__ d_r1, float *__restrict__ d_m2, float *__restrict__ d_s3,
+                        float *__restrict__ d_Ld, float *__restrict__ d_Ls, float *__restrict__ d_fg)
+{
+    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= n) return;
+    const float blend = m2[2 * i], metal = m2[2 * i + 1];
+    const float fgx = fg[2 * i], fgy = fg[2 * i + 1];
+    const float *go = g + 24 * i;
+    float d_blend = go[6], d_metal = go[22], d_fgx = 0.f, d_fgy = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float alb = a6[6 * i + 3 + c], ld = Ld[3 * i + c], ls = Ls[3 * i + c];
+        const float salb = 0.04f * (1.0f - metal) + metal * alb;
+        const float sref = salb * fgx + fgy;
+        // d wrt sref: spec_pbr (x ls) + its own channel
+        const float d_sref = go[10 + c] * ls + go[13 + c];
+        d_Ls[3 * i + c] = go[10 + c] * sref + go[16 + c];
+        d_Ld[3 * i + c] = go[7 + c] * (1.0f - metal) * alb;
+        d_fgx += d_sref * salb;
+        d_fgy += d_sref;
+        const float d_salb = d_sref * fgx;
+        d_a6[6 * i + c] = go[c] * (1.0f - blend);
+        d_a6[6 * i + 3 + c] = go[7 + c] * (1.0f - metal) * ld + d_salb * metal + go[19 + c];
+        d_s3[3 * i + c] = go[3 + c] * blend;
+        d_blend += -go[c] * a6[6 * i + c] + go[3 + c] * s3[3 * i + c];
+        d_metal += -go[7 + c] * alb * ld + d_salb * (alb - 0.04f);
+    }
+    d_m2[2 * i] = d_blend;
+    d_m2[2 * i + 1] = d_metal;
+    d_r1[i] = go[23];
+    d_fg[2 * i] = d_fgx;
+    d_fg[2 * i + 1] = d_fgy;
+}
+
 __global__ void __launch_bounds__(THREADS)
 srgb_fwd_kernel(const float *__restrict__ x, int64_t n, float *__restrict__ y)
 {
@@ -310,6 +381,28 @@ int rsdf_split_color0_bwd(const float *albedo6, const float *metallic2, const fl
 {
     if (n <= 0) return 0;
     LAUNCH1D(split_color0_bwd_kernel, n, albedo6, metallic2, spec3, d_colors7, n, d_albedo6, d_metallic2, d_spec3);
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_split_shade1_fwd(const float *albedo6, const float *roughness, const float *metallic2,
+                          const float *spec3, const float *diffuse_light, const float *specular_light,
+                          const float *fg, int64_t n, float *colors24, void *stream)
+{
+    if (n <= 0) return 0;
+    LAUNCH1D(split_shade1_fwd_kernel, n, albedo6, roughness, metallic2, spec3, diffuse_light, specular_light, fg,
+             n, colors24);
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_split_shade1_bwd(const float *albedo6, const float *metallic2, const float *spec3,
+                          const float *diffuse_light, const float *specular_light, const float *fg,
+                          const float *d_colors24, int64_t n, float *d_albedo6, float *d_roughness,
+                          float *d_metallic2, float *d_spec3, float *d_diffuse_light,
+                          float *d_specular_light, float *d_fg, void *stream)
+{
+    if (n <= 0) return 0;
+    LAUNCH1D(split_shade1_bwd_kernel, n, albedo6, metallic2, spec3, diffuse_light, specular_light, fg, d_colors24,
+             n, d_albedo6, d_roughness, d_metallic2, d_spec3, d_diffuse_light, d_specular_light, d_fg);
     RSDF_RETURN_LAUNCH();
 }
 

@@ -1,0 +1,230 @@
+"""Host-side mirror of the reference's environment light (``lib/pbr/light.py`` EnvironmentLightMipCube,
+registered as ``envlight-mip-cube``) and of the renderutils / nvdiffrast entry points it calls, on the
+HIP kernels of csrc/envlight.hip.
+
+  diffuse_cubemap / specular_cubemap   lib/renderutils/ops.py:391-458
+  cubemap_mip                          lib/pbr/utils/light_utils.py:94-109
+  texture_cube (dr.texture, cube)      lib/pbr/light.py:194-206
+  EnvironmentLightMipCube              lib/pbr/light.py:127-210 (build_mips, get_mip, eval_mip, parameters)
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ._lib import check, lib, ptr, require_device, stream_ptr
+from .registry import register
+
+
+def _f(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+    return arr, ctypes.cast(arr, ctypes.c_void_p)
+
+
+# ---- prefilters ---------------------------------------------------------------------------------------
+class _DiffuseCubemap(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cubemap):
+        c = _f(cubemap)
+        require_device(c)
+        out = torch.empty_like(c)
+        check(lib().rsdf_diffuse_cubemap_fwd(ptr(c), c.shape[1], ptr(out), stream_ptr()), "diffuse_cubemap_fwd")
+        ctx.R = c.shape[1]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        g = _f(dout)
+        gc = torch.empty_like(g)
+        check(lib().rsdf_diffuse_cubemap_bwd(ptr(g), ctx.R, ptr(gc), stream_ptr()), "diffuse_cubemap_bwd")
+        return gc
+
+
+def diffuse_cubemap(cubemap):
+    return _DiffuseCubemap.apply(cubemap)
+
+
+def ndf_cutoff(roughness, cutoff, n_samples=1000000):
+    """cos(theta) keeping ``cutoff`` of the GGX NDF energy (lib/renderutils/ops.py:428-439; host side, cached)."""
+    a2 = roughness ** 4
+    ct = np.cos(np.linspace(0, np.pi / 2.0, n_samples))
+    c = np.clip(ct, 0.0, 1.0)
+    d = (c * a2 - c) * c + 1.0
+    D = np.cumsum(a2 / (d * d * np.pi))
+    return float(ct[np.argmax(D >= D[-1] * cutoff)])
+
+
+_bounds_cache = {}
+
+
+def specular_bounds(res, roughness, cutoff, device):
+    key = (res, roughness, cutoff, str(device))
+    if key not in _bounds_cache:
+        cosc = ndf_cutoff(roughness, cutoff)
+        b = torch.empty(6, res, res, 24, dtype=torch.float32, device=device)
+        check(lib().rsdf_specular_bounds(res, cosc, ptr(b), stream_ptr()), "specular_bounds")
+        _bounds_cache[key] = (cosc, b)
+    return _bounds_cache[key]
+
+
+class _SpecularCubemap(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cubemap, roughness, cosc, bounds):
+        c = _f(cubemap)
+        require_device(c, bounds)
+        R = c.shape[1]
+        out = torch.empty(6, R, R, 4, dtype=torch.float32, device=c.device)
+        check(lib().rsdf_specular_cubemap_fwd(ptr(c), ptr(bounds), R, float(roughness), float(cosc), ptr(out),
+                                              stream_ptr()), "specular_cubemap_fwd")
+        ctx.save_for_backward(bounds)
+        ctx.args = (R, float(roughness), float(cosc))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (bounds,) = ctx.saved_tensors
+        R, roughness, cosc = ctx.args
+        g = _f(dout)
+        gc = torch.empty(6, R, R, 3, dtype=torch.float32, device=g.device)
+        check(lib().rsdf_specular_cubemap_bwd(ptr(g), 4, ptr(bounds), R, roughness, cosc, ptr(gc), stream_ptr()),
+              "specular_cubemap_bwd")
+        return gc, None, None, None
+
+
+def specular_cubemap(cubemap, roughness, cutoff=0.99):
+    assert cubemap.shape[0] == 6 and cubemap.shape[1] == cubemap.shape[2], \
+        "Bad shape for cubemap tensor: %s" % str(cubemap.shape)
+    cosc, bounds = specular_bounds(cubemap.shape[1], roughness, cutoff, cubemap.device)
+    out = _SpecularCubemap.apply(cubemap, roughness, cosc, bounds)
+    return out[..., 0:3] / out[..., 3:]
+
+
+# ---- cube lookups ---------------------------------------------------------------------------------------
+class _CubeSample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dirs, level, n_mips, *mips):
+        d = _f(dirs)
+        lv = None if level is None else _f(level).reshape(-1)
+        ms = [_f(m) for m in mips]
+        require_device(d, lv, *ms)
+        R0, C = ms[0].shape[1], ms[0].shape[3]
+        out = torch.empty(d.shape[0], C, dtype=torch.float32, device=d.device)
+        arr, p = _ptr_array(ms)
+        check(lib().rsdf_cube_sample_fwd(p, len(ms), R0, C, ptr(d), ptr(lv), d.shape[0], ptr(out), stream_ptr()),
+              "cube_sample_fwd")
+        ctx.save_for_backward(d, lv if lv is not None else torch.empty(0, device=d.device), *ms)
+        ctx.has_level, ctx.dims = lv is not None, (R0, C)
+        ctx.level_shape = None if level is None else level.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        d, lv, *ms = ctx.saved_tensors
+        lv = lv if ctx.has_level else None
+        R0, C = ctx.dims
+        g = _f(dout)
+        need_tex = [ctx.needs_input_grad[3 + i] for i in range(len(ms))]
+        grads = [torch.zeros_like(m) if need else None for m, need in zip(ms, need_tex)]
+        gd = torch.empty_like(d) if ctx.needs_input_grad[0] else None
+        gl = torch.empty(d.shape[0], dtype=torch.float32, device=d.device) \
+            if (ctx.has_level and ctx.needs_input_grad[1]) else None
+        a1, p1 = _ptr_array(ms)
+        a2, p2 = _ptr_array(grads)
+        check(lib().rsdf_cube_sample_bwd(p1, p2, len(ms), R0, C, ptr(d), ptr(lv), d.shape[0], ptr(g), ptr(gd),
+                                         ptr(gl), stream_ptr()), "cube_sample_bwd")
+        if gl is not None:
+            gl = gl.view(ctx.level_shape)
+        return (gd, gl, None, *grads)
+
+
+def texture_cube(tex, dirs, mips=None, mip_level_bias=None):
+    """dr.texture(tex[None], dirs[None,:,None,:], mip=..., mip_level_bias=..., boundary_mode='cube') for
+    flat ``dirs`` [S,3]: 'linear' when ``mips`` is None, else 'linear-mipmap-linear' with level = bias."""
+    stack = [tex] + (list(mips) if mips is not None else [])
+    return _CubeSample.apply(dirs, mip_level_bias if mips is not None else None, len(stack), *stack)
+
+
+def _texel_dirs(R, device):
+    c = 2.0 * ((torch.arange(R, dtype=torch.float32, device=device) + 0.5) / R) - 1.0
+    fy, fx = torch.meshgrid(c, c, indexing="ij")
+    one = torch.ones_like(fx)
+    faces = [torch.stack((one, -fy, -fx), -1), torch.stack((-one, -fy, fx), -1), torch.stack((fx, one, fy), -1),
+             torch.stack((fx, -one, -fy), -1), torch.stack((fx, -fy, one), -1), torch.stack((-fx, -fy, -one), -1)]
+    return torch.stack(faces, 0)
+
+
+class cubemap_mip(torch.autograd.Function):
+    """lib/pbr/utils/light_utils.py:94-109."""
+
+    @staticmethod
+    def forward(ctx, cubemap):
+        c = _f(cubemap)
+        require_device(c)
+        R, C = c.shape[1], c.shape[3]
+        out = torch.empty(6, R // 2, R // 2, C, dtype=torch.float32, device=c.device)
+        check(lib().rsdf_cubemap_avgpool(ptr(c), R, C, ptr(out), stream_ptr()), "cubemap_avgpool")
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        res = dout.shape[1] * 2
+        d = _texel_dirs(res, dout.device).reshape(-1, 3)
+        with torch.no_grad():
+            return texture_cube(_f(dout) * 0.25, d).reshape(6, res, res, dout.shape[-1])
+
+
+@register("envlight-mip-cube")
+class EnvironmentLightMipCube(nn.Module):
+    LIGHT_MIN_RES = 16
+    MIN_ROUGHNESS = 0.08
+    MAX_ROUGHNESS = 0.5
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        ec = config.envlight_config
+        if ec.get("hdr_filepath", None) is not None:
+            raise NotImplementedError("loading an HDR lat-long map is I/O outside the hot path")
+        base = torch.rand(6, ec.base_res, ec.base_res, 3, dtype=torch.float32) * ec.scale + ec.bias
+        self.register_parameter("base", nn.Parameter(base))
+        self.specular, self.diffuse = None, None
+
+    def build_mips(self, cutoff=0.99):
+        self.specular = [self.base]
+        while self.specular[-1].shape[1] > self.LIGHT_MIN_RES:
+            self.specular += [cubemap_mip.apply(self.specular[-1])]
+        self.diffuse = diffuse_cubemap(self.specular[-1])
+        n = len(self.specular)
+        for idx in range(n - 1):
+            roughness = (idx / (n - 2)) * (self.MAX_ROUGHNESS - self.MIN_ROUGHNESS) + self.MIN_ROUGHNESS
+            self.specular[idx] = specular_cubemap(self.specular[idx], roughness, cutoff)
+        self.specular[-1] = specular_cubemap(self.specular[-1], 1.0, cutoff)
+
+    def get_mip(self, roughness):
+        n = len(self.specular)
+        return torch.where(
+            roughness < self.MAX_ROUGHNESS,
+            (torch.clamp(roughness, self.MIN_ROUGHNESS, self.MAX_ROUGHNESS) - self.MIN_ROUGHNESS)
+            / (self.MAX_ROUGHNESS - self.MIN_ROUGHNESS) * (n - 2),
+            (torch.clamp(roughness, self.MAX_ROUGHNESS, 1.0) - self.MAX_ROUGHNESS) / (1.0 - self.MAX_ROUGHNESS) + n - 2)
+
+    def eval_mip(self, directions, specular=False, roughness=None):
+        if specular:
+            assert roughness is not None
+            miplevel = self.get_mip(roughness)
+            return texture_cube(self.specular[0], directions, mips=self.specular[1:],
+                                mip_level_bias=miplevel[..., 0])
+        return texture_cube(self.diffuse, directions)
+
+    def parameters(self, recurse=True):
+        return [self.base]
+
+    def clamp_(self, min=None, max=None):
+        self.base.data.clamp_(min, max)

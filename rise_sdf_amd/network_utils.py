@@ -166,12 +166,14 @@ class VanillaMLP(nn.Module):
                 out.append((w, m.bias))
         return out
 
-    def forward(self, x):
+    def forward(self, x, out_act=None):
+        """``out_act`` overrides the configured output activation (lets a caller fuse e.g. the texture
+        networks' color_activation into the last layer's kernel)."""
         h = x.float()
         wb = self.effective_weights()
         for i, (w, b) in enumerate(wb):
             last = i == len(wb) - 1
-            h = ops.linear(h, w, b, act=self.output_act if last else self.hidden_act,
+            h = ops.linear(h, w, b, act=(out_act or self.output_act) if last else self.hidden_act,
                            dx_cols=self.input_grad_cols if i == 0 else None)
         return h
 

@@ -4,7 +4,9 @@ Built so far: occupancy update (M2, :98-136), visibility-pruned s
 :264-272), field + FD normals + NeuS alpha (H1-H4, A1, :228-262), radiance branch at stage 0
 (T1-T3, :293-295), compositing (C1-C3, :274-289), secondary-ray occlusion (R1, :179-222,306-318),
 normal-orientation map (:383-401), background compose + sRGB (O1, :404-443).
-Not yet: stage 1 split-sum shading (S1-S4, E1), curvature term (H5), relighting third bounce.
+Stage 1 (``split_sum_kick_in_step``): split-sum shading against the prefiltered environment light
+(S1-S4, E1; 24 composited channels, :295-303, 344-352, 416-432).
+Not yet: curvature term (H5), relighting third bounce (:322-331, evaluation only).
 """
 from __future__ import annotations
 
@@ -26,7 +28,7 @@ class SplitMixedOCCModel(BaseModel):
     def setup(self):
         self.geometry = make(self.config.geometry.name, self.config.geometry)
         self.texture = make(self.config.texture.name, self.config.texture)
-        light = self.config.get("light", None)
+        light = self.config.light if "light" in self.config else None
         self.emitter = make(light.name, light) if light is not None and light.name in _registry() else None
         self.geometry.contraction_type = ContractionType.AABB
         self.variance = VarianceNetwork(self.config.variance)
@@ -57,9 +59,7 @@ class SplitMixedOCCModel(BaseModel):
             self.occupancy_grid.update_every_n_steps(
                 step=global_step, occ_eval_fn=self.occ_eval_fn,
                 occ_thre=self.config.get("grid_prune_occ_thre", 0.01))
-        if global_step >= self.config.get("stage_switch_step", 10000) and self.stage == 0 \
-                and self.config.get("enable_stage1", False):
-            self.stage = 1
+        self.stage = 1 if global_step >= self.config.get("split_sum_kick_in_step", 1 << 62) else 0
 
     def occ_eval_fn(self, x):
         sdf = self.geometry(x, with_grad=False, with_feature=False)
@@ -111,8 +111,10 @@ class SplitMixedOCCModel(BaseModel):
 
     # ---- one ray batch (:224-443) ------------------------------------------------------------------------------
     def forward_(self, rays, relighting=False, stratified_u=None):
-        if self.stage != 0:
-            raise NotImplementedError("stage 1 (split-sum shading) is the next SURVEY 8a row")
+        if relighting:
+            raise NotImplementedError("relighting third bounce (models/split_mixed_occ.py:322-331) is evaluation-only")
+        if self.stage != 0 and self.emitter is None:
+            raise RuntimeError("stage 1 needs model.light (envlight-mip-cube)")
         n_rays = rays.shape[0]
         rays_o, rays_d = rays[:, 0:3].contiguous(), rays[:, 3:6].contiguous()
         dev = rays.device
@@ -133,9 +135,12 @@ class SplitMixedOCCModel(BaseModel):
                 cone_angle=0.0, alpha_thre=0.0)
         rgb_map, normal_map, acc_map, depth_map, extras = rendering_with_normals_sdf(
             t_starts, t_ends, ray_indices=ray_indices, n_rays=n_rays, rgb_alpha_fn=rgb_normal_alpha_fn,
-            render_bkgd=None, has_laplace=False, color_dim=7)
+            render_bkgd=None, has_laplace=False, color_dim=7 if self.stage == 0 else 24)
 
         diff_rgb_map, spec_rgb_map, blend_map = rgb_map[..., :3], rgb_map[..., 3:6], rgb_map[..., 6:7]
+        if self.stage != 0:
+            diff_rgb_pbr_map, spec_rgb_pbr_map = rgb_map[..., 7:10], rgb_map[..., 10:13]
+            albedo_map, metallic_map, roughness_map = rgb_map[..., 19:22], rgb_map[..., 22:23], rgb_map[..., 23:]
         valid_indices = torch.nonzero(acc_map > 0.5)[..., 0]
         if valid_indices.numel() > 0 and self.config.get("indirect_pred", False):
             sec_o = rays_o[valid_indices] + depth_map[valid_indices] * rays_d[valid_indices]
@@ -148,12 +153,19 @@ class SplitMixedOCCModel(BaseModel):
             sec_rgb = self.texture.secondary_shading(sec_feature, sec_d, nv)
             spec_rgb_map = spec_rgb_map.clone()
             spec_rgb_map[valid_indices] = tr * spec_rgb_map[valid_indices] + (1 - tr) * sec_rgb
+            if self.stage != 0:
+                spec_rgb_pbr_map = spec_rgb_pbr_map.clone()
+                spec_rgb_pbr_map[valid_indices] = tr * spec_rgb_pbr_map[valid_indices] + (1 - tr) * sec_rgb
         rgb = diff_rgb_map + spec_rgb_map
 
         out = {"comp_rgb": rgb, "comp_diffuse_rgb": diff_rgb_map, "comp_spec_rgb": spec_rgb_map,
                "comp_blend": blend_map, "comp_normal": normal_map, "opacity": acc_map, "depth": depth_map,
                "rays_valid": acc_map > 0,
                "num_samples": torch.as_tensor([len(t_starts)], dtype=torch.int32, device=dev)}
+        if self.stage != 0:
+            out.update({"comp_rgb_phys": diff_rgb_pbr_map + spec_rgb_pbr_map,
+                        "comp_diffuse_rgb_phys": diff_rgb_pbr_map, "comp_spec_rgb_phys": spec_rgb_pbr_map,
+                        "comp_albedo": albedo_map, "comp_metallic": metallic_map, "comp_roughness": roughness_map})
         if self.training:
             weights = extras["weights"]
             out.update({"sdf_samples": extras["sdf"], "sdf_grad_samples": extras["sdf_grad"],
@@ -170,6 +182,11 @@ class SplitMixedOCCModel(BaseModel):
         out_full = {"comp_rgb": T.rgb_to_srgb(out["comp_rgb"] + out_bg["comp_rgb"] * (1.0 - out["opacity"])).clamp(0, 1),
                     "num_samples": out["num_samples"] + out_bg["num_samples"],
                     "rays_valid": out["rays_valid"] | out_bg["rays_valid"]}
+        if self.stage != 0:
+            out_bg["comp_rgb_phys"] = out_bg["comp_rgb"]
+            comp = lambda k: T.rgb_to_srgb(out[k] + out_bg["comp_rgb"] * (1.0 - out["opacity"])).clamp(0, 1)
+            out_full.update({"comp_rgb_phys": comp("comp_rgb_phys"), "comp_spec_rgb": comp("comp_spec_rgb"),
+                             "comp_spec_rgb_phys": comp("comp_spec_rgb_phys")})
         return {**out, **{k + "_bg": v for k, v in out_bg.items()}, **{k + "_full": v for k, v in out_full.items()}}
 
     def forward(self, rays, relighting=False, **kw):

@@ -85,21 +85,39 @@ class VolumeMixedMipSplitOcc(nn.Module):
         self.metallic_network = get_mlp(f + x, 2, self.config.metallic_mlp_network_config)
         if str(self.config.get("color_activation", "sigmoid")).lower() != "sigmoid":
             raise NotImplementedError("color_activation other than sigmoid")
+        # precomputed microfacet integration (models/texture.py:285-287).  The reference loads
+        # load/bsdf/bsdf_256_256.bin, which is not part of its repository (README.md:68); when the file is
+        # absent the table is integrated analytically (split-sum GGX, see fg_lut.py).
+        from .fg_lut import load_or_build_fg_lut
+        self.register_buffer("FG_LUT", load_or_build_fg_lut(self.config.get("fg_lut_path", "load/bsdf/bsdf_256_256.bin")))
 
     def forward(self, features, dirs, normals, positions, emitter=None, stage=0, *args):
         if dirs.shape[0] == 0:
             return torch.zeros((0, 7 if stage == 0 else 24), device=features.device)
-        if stage != 0:
-            raise NotImplementedError("split-sum shading stage (SURVEY.md 8a S1-S4) is not built yet")
         feats = features.reshape(-1, features.shape[-1])
-        wo01, _nov = T.reflect(dirs, normals)
+        wo01, nov = T.reflect(dirs, normals)
         xyz = self.xyz_encoding(positions.reshape(-1, self.n_pos_dims))
         inp = torch.cat([feats, xyz], dim=-1)
-        albedo6 = self.albedo_network(inp)
-        metallic2 = self.metallic_network(inp)
         wo_enc = self.dir_encoding(wo01)
-        spec3 = self.env_network(torch.cat([feats, wo_enc], dim=-1))
-        return T.split_color0(albedo6, metallic2, spec3)
+        env_inp = torch.cat([feats, wo_enc], dim=-1)
+        if stage == 0:
+            albedo6 = self.albedo_network(inp)
+            metallic2 = self.metallic_network(inp)
+            spec3 = self.env_network(env_inp)
+            return T.split_color0(albedo6, metallic2, spec3)
+        # stage 1: split-sum shading (models/texture.py:329-345); color_activation (sigmoid) fused into the
+        # last layer of each material network
+        from .gridsample import fg_lut_lookup
+        albedo6 = self.albedo_network(inp, out_act="sigmoid")
+        roughness = self.roughness_network(inp, out_act="sigmoid")
+        metallic2 = self.metallic_network(inp, out_act="sigmoid")
+        spec3 = self.env_network(env_inp, out_act="sigmoid")
+        diffuse_light = emitter.eval_mip(normals)
+        wo = wo01 * 2.0 - 1.0
+        specular_light = emitter.eval_mip(wo, specular=True, roughness=roughness)
+        fg_uv = torch.cat([torch.clamp(nov, min=0.0, max=1.0), torch.clamp(roughness, min=0.0, max=1.0)], -1)
+        fg = fg_lut_lookup(self.FG_LUT, fg_uv)
+        return T.split_shade1(albedo6, roughness, metallic2, spec3, diffuse_light, specular_light, fg)
 
     def secondary_shading(self, features, rays_d, *args):
         dirs_embd = self.dir_encoding(((rays_d + 1.0) / 2.0).reshape(-1, self.n_dir_dims))

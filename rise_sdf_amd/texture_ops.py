@@ -131,3 +131,29 @@ class _Srgb(torch.autograd.Function):
 def rgb_to_srgb(x):
     """lib/pbr/utils/nvdiffrecmc_util.py:95-103."""
     return _Srgb.apply(x)
+
+
+class _SplitShade1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, albedo6, roughness, metallic2, spec3, Ld, Ls, fg):
+        ts = [_f(t) for t in (albedo6, roughness, metallic2, spec3, Ld, Ls, fg)]
+        require_device(*ts)
+        n = ts[0].shape[0]
+        out = torch.empty(n, 24, dtype=torch.float32, device=ts[0].device)
+        check(lib().rsdf_split_shade1_fwd(*[ptr(t) for t in ts], n, ptr(out), stream_ptr()), "split_shade1_fwd")
+        ctx.save_for_backward(*ts)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a6, r1, m2, s3, Ld, Ls, fg = ctx.saved_tensors
+        g = _f(g)
+        outs = [torch.empty_like(t) for t in (a6, r1, m2, s3, Ld, Ls, fg)]
+        check(lib().rsdf_split_shade1_bwd(ptr(a6), ptr(m2), ptr(s3), ptr(Ld), ptr(Ls), ptr(fg), ptr(g), a6.shape[0],
+                                          *[ptr(t) for t in outs], stream_ptr()), "split_shade1_bwd")
+        return tuple(outs)
+
+
+def split_shade1(albedo6, roughness, metallic2, spec3, diffuse_light, specular_light, fg):
+    """Stage-1 split-sum shading on activated material values -> colors [S,24] (models/texture.py:329-345)."""
+    return _SplitShade1.apply(albedo6, roughness, metallic2, spec3, diffuse_light, specular_light, fg)

@@ -384,6 +384,70 @@ def main():
     save("texture_stage0.npz", features=feats, dirs=dirs, normals=nrm, positions=pos, colors=col, gcolors=gcol,
          g_features=tgrads[0], g_normals=tgrads[1], **tsd, **tg)
 
+    # ---- stage 1: EnvironmentLightMipCube (lib/pbr/light.py:127-210) + split-sum shading
+    # (models/texture.py:329-345).  Reference code for build_mips / get_mip / eval_mip / cubemap_mip and the
+    # shading arithmetic; its CUDA-only callees are the oracle's restatements, evaluated in fp64:
+    #   ru.diffuse_cubemap / ru.specular_cubemap -> oracle.envlight (renderutils plugin, unbuildable here)
+    #   dr.texture                               -> oracle.envlight cube sampling / oracle.gridsample (nvdiffrast
+    #                                               is absent upstream: definition unpinned)
+    # The FG LUT file is not in the repository: np.fromfile returns oracle.texture.synthetic_fg_lut().
+    from oracle import envlight as oenv, gridsample as ogs, texture as otex
+    import nvdiffrast.torch as dr_stub
+
+    def dr_texture(tex, uv, mip=None, mip_level_bias=None, filter_mode="linear", boundary_mode="wrap"):
+        if boundary_mode == "cube":
+            d = uv.reshape(-1, 3).double()
+            if filter_mode == "linear":
+                out = oenv.cube_sample_linear(tex[0].double(), d)
+            else:
+                out = oenv.cube_sample_mip([tex[0].double()] + [m[0].double() for m in mip], d,
+                                           mip_level_bias.reshape(-1).double())
+            return out.float().reshape(*uv.shape[:-1], -1)
+        assert boundary_mode == "clamp" and filter_mode == "linear"
+        grid = (uv.double() * 2.0 - 1.0)
+        out = ogs.grid_sample_2d(tex.double().permute(0, 3, 1, 2), grid, "border", False)
+        return out.permute(0, 2, 3, 1).float()
+
+    dr_stub.texture = dr_texture
+    from lib.pbr import light as rlight
+    rlight.ru.diffuse_cubemap = lambda c: oenv.diffuse_cubemap(c.double()).float()
+    rlight.ru.specular_cubemap = lambda c, r, cutoff=0.99: oenv.specular_cubemap(c.double(), r, cutoff).float()
+    rlight.dr.texture = dr_texture
+    from lib.pbr.utils import light_utils as rlu
+    rlu.dr.texture = dr_texture
+    orig_rand, orig_linspace = torch.rand, torch.linspace
+
+    def _nodev(fn):
+        def f(*a, **k):
+            k.pop("device", None)
+            return fn(*a, **k)
+        return f
+
+    torch.rand, torch.zeros, torch.linspace = _nodev(orig_rand), _nodev(orig_zeros), _nodev(orig_linspace)
+    torch.manual_seed(41)
+    lcfg = Cfg({"envlight_config": {"scale": 0.5, "bias": 0.25, "base_res": 64, "hdr_filepath": None}})
+    light = rlight.EnvironmentLightMipCube(lcfg)
+    light.build_mips()
+    np.fromfile = lambda *a, **k: otex.synthetic_fg_lut().numpy().reshape(-1)
+    torch.cuda.device = _NoDev
+    torch.manual_seed(31)
+    tex1 = rtex.VolumeMixedMipSplitOcc(tcfg)
+    tex1.load_state_dict({k: v for k, v in tex.state_dict().items() if k != "FG_LUT"}, strict=False)
+    assert float(tex1.FG_LUT.abs().max()) > 0
+    torch.cuda.device = orig_cuda_device
+    np.fromfile = orig_fromfile
+    col1 = tex1(feats, dirs, nrm, pos, light, 1)
+    assert col1.shape == (S, 24)
+    gcol1 = torch.randn_like(col1)
+    t1params = list(tex1.parameters())
+    t1grads = torch.autograd.grad(col1, [feats, nrm, light.base] + t1params, gcol1, allow_unused=True)
+    torch.rand, torch.zeros, torch.linspace = orig_rand, orig_zeros, orig_linspace
+    t1g = {"g__" + n.replace(".", "_"): (g if g is not None else torch.zeros_like(p))
+           for (n, p), g in zip(tex1.named_parameters(), t1grads[3:])}
+    mips = {"spec%d" % i: m for i, m in enumerate(light.specular)}
+    save("texture_stage1.npz", base=light.base, diffuse=light.diffuse, **mips, colors=col1, gcolors=gcol1,
+         g_features=t1grads[0], g_normals=t1grads[1], g_base=t1grads[2], **t1g)
+
     # ---- frequency encoding, sRGB, progressive eps ----------------------------------------------
     vf = nu.VanillaFrequency(3, {"n_frequencies": 6})
     x = torch.randn(64, 3)

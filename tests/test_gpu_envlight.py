@@ -1,0 +1,163 @@
+"""GPU parity for the environment-light rows (S4/E1) and stage-1 shading (S1-S3): HIP kernels vs the
+oracle (oracle/envlight.py) on small cube maps, and vs the reference-code golden (texture_stage1.npz)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import envlight as E
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def test_diffuse_prefilter(dev):
+    from rise_sdf_amd.envlight import diffuse_cubemap
+    g = torch.Generator().manual_seed(0)
+    c = torch.rand(6, 16, 16, 3, generator=g)
+    go = torch.randn(6, 16, 16, 3, generator=g)
+    cg = c.to(dev).requires_grad_(True)
+    out = diffuse_cubemap(cg)
+    (gc,) = torch.autograd.grad(out, cg, go.to(dev))
+    c64 = c.double().requires_grad_(True)
+    ref = E.diffuse_cubemap(c64)
+    (rc,) = torch.autograd.grad(ref, c64, go.double())
+    assert torch.allclose(out.cpu().double(), ref, rtol=1e-5, atol=1e-6)
+    assert rel_err(gc, rc) < 1e-5
+
+
+@pytest.mark.parametrize("R,roughness", [(16, 1.0), (16, 0.5), (32, 0.29), (32, 0.08), (64, 0.08)])
+def test_specular_prefilter(dev, R, roughness):
+    from rise_sdf_amd.envlight import specular_cubemap
+    g = torch.Generator().manual_seed(R)
+    c = torch.rand(6, R, R, 3, generator=g)
+    go = torch.randn(6, R, R, 3, generator=g)
+    cg = c.to(dev).requires_grad_(True)
+    out = specular_cubemap(cg, roughness, 0.99)
+    (gc,) = torch.autograd.grad(out, cg, go.to(dev))
+    c64 = c.double().requires_grad_(True)
+    ref = E.specular_cubemap(c64, roughness, 0.99)
+    (rc,) = torch.autograd.grad(ref, c64, go.double())
+    # the window is the texels with L.V >= cutoff, compared in fp32 by the reference kernel and by ours: a texel
+    # whose L.V is within rounding of the cutoff may fall on either side.  Bracket the threshold by +-3e-7.
+    with torch.no_grad():
+        lo = E.specular_cubemap(c.double(), roughness, 0.99, cos_shift=-3e-7)
+        hi = E.specular_cubemap(c.double(), roughness, 0.99, cos_shift=3e-7)
+    err = (out.detach().cpu().double() - ref).abs()
+    assert bool((err <= (lo - hi).abs() + 2e-5 * ref.abs() + 1e-6).all()), float(err.max())
+    n_border = int(((lo - hi).abs() > 0).any(-1).sum())
+    assert n_border <= 6 * R * R // 20
+    if n_border == 0:
+        assert rel_err(gc, rc) < 2e-5
+    else:
+        assert float((gc.cpu().double() - rc).norm() / rc.norm()) < 2e-2
+
+
+def test_cubemap_mip(dev):
+    from rise_sdf_amd.envlight import cubemap_mip
+    g = torch.Generator().manual_seed(1)
+    c = torch.rand(6, 32, 32, 3, generator=g)
+    go = torch.randn(6, 16, 16, 3, generator=g)
+    cg = c.to(dev).requires_grad_(True)
+    out = cubemap_mip.apply(cg)
+    (gc,) = torch.autograd.grad(out, cg, go.to(dev))
+    c64 = c.double().requires_grad_(True)
+    ref = E.cubemap_mip(c64)
+    (rc,) = torch.autograd.grad(ref, c64, go.double())
+    assert torch.allclose(out.cpu().double(), ref, rtol=1e-6, atol=1e-7)
+    assert rel_err(gc, rc) < 1e-5
+
+
+def _dirs(n, g):
+    d = torch.randn(n, 3, generator=g)
+    d[:6] = torch.tensor([[1.0, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]])
+    d[6:9] = torch.tensor([[1.0, 0.999, 0.2], [0.3, -1.0, 0.9995], [-0.99, 0.995, 1.0]])   # near edges / a corner
+    d[9] = torch.tensor([2.5, -0.1, 0.3])                                                   # not normalised
+    return d
+
+
+def test_cube_sample_linear_and_mip(dev):
+    from rise_sdf_amd.envlight import texture_cube
+    g = torch.Generator().manual_seed(2)
+    mips = [torch.rand(6, r, r, 3, generator=g) for r in (32, 16, 8)]
+    d = _dirs(700, g)
+    lv = torch.rand(700, generator=g) * 2.6 - 0.3      # covers < 0 and > n-1 clamps
+    go = torch.randn(700, 3, generator=g)
+    # linear
+    tg, dg = mips[0].to(dev).requires_grad_(True), d.to(dev).requires_grad_(True)
+    out = texture_cube(tg, dg)
+    gt, gd = torch.autograd.grad(out, [tg, dg], go.to(dev))
+    t64, d64 = mips[0].double().requires_grad_(True), d.double().requires_grad_(True)
+    ref = E.cube_sample_linear(t64, d64)
+    rt, rd = torch.autograd.grad(ref, [t64, d64], go.double())
+    assert torch.allclose(out.cpu().double(), ref, rtol=1e-5, atol=1e-5)
+    assert rel_err(gt, rt) < 1e-5
+    assert float((gd.cpu().double() - rd).abs().max()) < 1e-3 * float(rd.abs().max())
+    # linear-mipmap-linear
+    ms = [m.to(dev).requires_grad_(True) for m in mips]
+    dg, lg = d.to(dev).requires_grad_(True), lv.to(dev).requires_grad_(True)
+    out = texture_cube(ms[0], dg, mips=ms[1:], mip_level_bias=lg)
+    grads = torch.autograd.grad(out, ms + [dg, lg], go.to(dev))
+    m64 = [m.double().requires_grad_(True) for m in mips]
+    d64, l64 = d.double().requires_grad_(True), lv.double().requires_grad_(True)
+    ref = E.cube_sample_mip(m64, d64, l64)
+    rgrads = torch.autograd.grad(ref, m64 + [d64, l64], go.double())
+    assert torch.allclose(out.cpu().double(), ref, rtol=1e-5, atol=1e-5)
+    for a, b in zip(grads[:3], rgrads[:3]):
+        assert rel_err(a, b) < 1e-5
+    assert float((grads[3].cpu().double() - rgrads[3]).abs().max()) < 1e-3 * float(rgrads[3].abs().max())
+    assert float((grads[4].cpu().double() - rgrads[4]).abs().max()) < 1e-4 * float(rgrads[4].abs().max())
+
+
+def _stage1_texture(dev, z0):
+    import rise_sdf_amd as R
+    from oracle import texture as otex
+    mlp = lambda n: {"otype": "VanillaMLP", "activation": "ReLU", "output_activation": "none", "n_neurons": 64,
+                     "n_hidden_layers": n}
+    cfg = R.Config({
+        "name": "volume-mixed-mip-split-occ", "input_feature_dim": 13, "other_dim": 3, "sample_size": 8,
+        "dir_encoding_config": {"otype": "SphericalHarmonics", "degree": 5, "reflected": True},
+        "metallic_mlp_network_config": mlp(2), "albedo_mlp_network_config": mlp(4),
+        "spec_mlp_network_config": mlp(4), "roughness_mlp_network_config": mlp(2),
+        "secondary_mlp_network_config": mlp(4),
+        "xyz_encoding_config": {"otype": "VanillaFrequency", "n_frequencies": 6}, "color_activation": "sigmoid"})
+    tex = R.make("volume-mixed-mip-split-occ", cfg).to(dev)
+    sd = {k[3:]: v for k, v in z0.items() if k.startswith("p__")}
+    with torch.no_grad():
+        for name, p in tex.named_parameters():
+            p.copy_(sd[name.replace(".", "_")])
+        tex.FG_LUT.copy_(otex.synthetic_fg_lut())
+    return tex
+
+
+def test_stage1_reference_fixture(dev, golden_dir):
+    """EnvironmentLightMipCube.build_mips + VolumeMixedMipSplitOcc.forward(stage=1): the reference's code
+    (tests/golden/texture_stage1.npz) vs the HIP mirror -- mip chain, 24 channels, all gradients."""
+    import rise_sdf_amd as R
+    z0 = {k: torch.tensor(v) for k, v in np.load(os.path.join(golden_dir, "texture_stage0.npz")).items()}
+    z = {k: torch.tensor(v) for k, v in np.load(os.path.join(golden_dir, "texture_stage1.npz")).items()}
+    light = R.make("envlight-mip-cube", R.Config(
+        {"envlight_config": {"scale": 0.5, "bias": 0.25, "base_res": 64, "hdr_filepath": None}})).to(dev)
+    with torch.no_grad():
+        light.base.copy_(z["base"])
+    light.build_mips()
+    assert len(light.specular) == 3
+    for i, m in enumerate(light.specular):
+        assert torch.allclose(m.detach().cpu(), z["spec%d" % i], rtol=1e-4, atol=1e-5), i
+    assert torch.allclose(light.diffuse.detach().cpu(), z["diffuse"], rtol=1e-4, atol=1e-5)
+    tex = _stage1_texture(dev, z0)
+    feats = z0["features"].to(dev).requires_grad_(True)
+    nrm = z0["normals"].to(dev).requires_grad_(True)
+    col = tex(feats, z0["dirs"].to(dev), nrm, z0["positions"].to(dev), light, 1)
+    assert col.shape == (257, 24)
+    # fp32 radiance within 1e-4 relative (north_star)
+    assert torch.allclose(col.cpu(), z["colors"], rtol=1e-4, atol=1e-5)
+    (col * z["gcolors"].to(dev)).sum().backward()
+    assert rel_err(feats.grad, z["g_features"]) < 1e-4
+    assert rel_err(nrm.grad, z["g_normals"]) < 1e-3
+    assert rel_err(light.base.grad, z["g_base"]) < 1e-4
+    for name, p in tex.named_parameters():
+        ref = z["g__" + name.replace(".", "_")]
+        got = torch.zeros_like(ref) if p.grad is None else p.grad.cpu()
+        assert float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-7, name
