@@ -162,6 +162,19 @@ int rsdf_hashgrid_bwd_fd7(const float *x7t, const float *dplanes, const rsdf_gri
                           int64_t n_samples, int n_active_levels, float eps_unit, float *dtable,
                           void *scratch, int64_t scratch_bytes, void *stream);
 
+/* H1 input gradient (what tcnn's autograd supplies to analytic normals, models/geometry.py:224-228, and to the
+ * curvature term, geometry.py:262-270) and its backward (tcnn double backward).  x in [0,1]; dx in the same
+ * unit-cube coordinates; levels >= n_active_levels contribute nothing.
+ *   rsdf_hashgrid_dx:      dx[n,3] = sum_l J_l(x)^T dy[:, col_off + l*F ...]
+ *   rsdf_hashgrid_dx_bwd:  given g_dx = dL/d(dx): d_dy (nullable; ld_ddy/col_off_ddy; masked levels zeroed),
+ *                          dtable (nullable, ACCUMULATES with float atomics), g_x[n,3] (nullable; the mixed
+ *                          second derivatives of the trilinear weights). */
+int rsdf_hashgrid_dx(const float *x, const float *table, const rsdf_grid_meta *meta /*host*/, int64_t n,
+                     int n_active_levels, const float *dy, int ld_dy, int col_off, float *dx, void *stream);
+int rsdf_hashgrid_dx_bwd(const float *x, const float *table, const rsdf_grid_meta *meta /*host*/, int64_t n,
+                         int n_active_levels, const float *dy, int ld_dy, int col_off, const float *g_dx,
+                         float *d_dy, int ld_ddy, int col_off_ddy, float *dtable, float *g_x, void *stream);
+
 /* ---- H3: VanillaMLP layers on the fp32 matrix cores --------------------------------------------
  * replaces nn.Linear (+ activation) inside VanillaMLP (models/network_utils.py:109-157).
  * y[n,N] = act(x[n,K] @ w[N,K]^T + b[N]); row strides ldx / ldy.  K,N <= 128. */

@@ -61,6 +61,8 @@ _SIGNATURES = {
     "rsdf_hashgrid_bwd_fd7_scratch_bytes": [ctypes.POINTER(GridMeta), _L, _I, _F],
     "rsdf_hashgrid_fwd_fd7": [_P, _P, ctypes.POINTER(GridMeta), _L, _I, _P, _P],
     "rsdf_hashgrid_bwd_fd7": [_P, _P, ctypes.POINTER(GridMeta), _L, _I, _F, _P, _P, _L, _P],
+    "rsdf_hashgrid_dx": [_P, _P, ctypes.POINTER(GridMeta), _L, _I, _P, _I, _I, _P, _P],
+    "rsdf_hashgrid_dx_bwd": [_P, _P, ctypes.POINTER(GridMeta), _L, _I, _P, _I, _I, _P, _P, _I, _I, _P, _P, _P],
     "rsdf_linear_fwd": [_P, _I, _P, _P, _L, _I, _I, _I, _P, _I, _P],
     "rsdf_linear_bwd_input": [_P, _P, _I, _P, _L, _I, _I, _I, _I, _I, _P, _P, _I, _P],
     "rsdf_linear_bwd_weight": [_P, _I, _P, _I, _L, _I, _I, _P, _P, _P],

@@ -3,13 +3,21 @@
   contract_to_unisphere   models/geometry.py:17-29 (AABB branch)
   VolumeSDF               models/geometry.py:193-327 (``volume-sdf``)
 
+Analytic normals (grad_type 'analytic', :224-228) and the curvature term (:246-282) are built as an explicit
+forward composition of once-differentiable HIP ops (hash-grid input gradient + transposed MLP chain) instead of
+``autograd.grad(create_graph=True)``; one ordinary backward then covers what the reference reaches through
+tcnn's double backward.
+
 Out of scope here: MarchingCubeHelper / isosurface (mesh export),
-VolumeDensity (background model), the analytic-gradient and curvature branches (config[4]).
+VolumeDensity (background model).
 """
 from __future__ import annotations
 
+import math
+
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import ops
 from .nerfacc import ContractionType
@@ -67,11 +75,8 @@ class VolumeSDF(BaseModel):
         self.network = get_mlp(self.encoding.n_output_dims, self.n_output_dims,
                                self.config.mlp_network_config)
         self.grad_type = self.config.grad_type
-        if self.grad_type != "finite_difference":
-            raise NotImplementedError(
-                "grad_type='analytic' needs the hash grid's input gradient (SURVEY.md 8a H5, "
-                "config[4]); the RISE-SDF config uses finite_difference "
-                "(configs/split-mixed-occ-tensoir.yaml)")
+        if self.grad_type not in ("finite_difference", "analytic"):
+            raise ValueError(f"Unknown grad_type={self.grad_type}")
         for key in ("sdf_activation", "feature_activation"):
             if key in self.config and str(self.config[key]).lower() not in ("none",):
                 raise NotImplementedError(f"{key} other than none")
@@ -116,19 +121,73 @@ class VolumeSDF(BaseModel):
     def _eps_unit(self):
         return self._finite_difference_eps / (2.0 * self.radius)
 
-    def forward(self, points, with_grad=True, with_feature=True, with_laplace=False):
+    # -- analytic gradient as a forward composition (geometry.py:224-228) ------------------------------
+    def field_with_analytic_grad(self, pts):
+        """pts [S,3] world -> (out [S,D], grad [S,3] = d out[:,0] / d pts).  ``grad`` is built from
+        once-differentiable ops, so it can be trained through (eikonal, curvature) and, when ``pts`` carries
+        a graph, differentiated w.r.t. the positions as well."""
+        from .network_utils import VanillaMLP
+        net, enc = self.network, self.encoding
+        grid, n_active = enc._hash()
+        if grid is None or not isinstance(net, VanillaMLP) or net.output_act != "none":
+            raise NotImplementedError("analytic gradient: hash grid + VanillaMLP (no output activation) only")
+        x = contract_to_unisphere(pts, self.radius, self.contraction_type)
+        col = 3 if enc.include_xyz else 0
+        h = ops.hashgrid_encode(x, grid.params, grid.meta, n_active_levels=n_active, include_xyz=enc.include_xyz,
+                                xyz_scale=enc.xyz_scale, xyz_offset=enc.xyz_offset)
+        wb = net.effective_weights()
+        slopes = []
+        for w, b in wb[:-1]:
+            z = ops.linear(h, w, b, act="none")
+            if net.hidden_act == "softplus100":
+                h, sl = F.softplus(z, beta=100), torch.sigmoid(100.0 * z)
+            else:
+                h, sl = F.relu(z), (z > 0).to(z.dtype)
+            slopes.append(sl)
+        w_last, b_last = wb[-1]
+        out = ops.linear(h, w_last, b_last, act="none")
+        # reverse sweep for output channel 0: u <- (u * act'(z_i)) @ W_i
+        u = w_last[0:1].expand(out.shape[0], -1)
+        for (w, _), sl in zip(reversed(wb[:-1]), reversed(slopes)):
+            u = ops.linear((u * sl).contiguous(), w.t().contiguous(), None, act="none")
+        g_unit = ops.hashgrid_dx(x, grid.params, u, grid.meta, n_active, col)
+        if col:
+            g_unit = g_unit + u[:, :3] * enc.xyz_scale
+        return out, g_unit / (2.0 * self.radius)
+
+    def curvature(self, pts, grad, rand_directions=None):
+        """geometry.py:246-282 (PermutoSDF curvature): angle / pi between the normal at x and the analytic normal
+        at x + 1e-4 * tangent, tangent = normal x random direction."""
+        eps = 1e-4
+        if rand_directions is None:
+            rand_directions = torch.rand_like(pts)
+        rd = F.normalize(rand_directions, dim=-1, eps=1e-6)
+        normal = F.normalize(grad, dim=-1, eps=1e-6)
+        pts_d = pts + eps * torch.cross(normal, rd, dim=-1)
+        _, grad_d = self.field_with_analytic_grad(pts_d)
+        dot = torch.sum(normal * F.normalize(grad_d, dim=-1, eps=1e-6), dim=-1)
+        return torch.acos(torch.clamp(dot, -1.0 + 1e-6, 1.0 - 1e-6)) / math.pi
+
+    def forward(self, points, with_grad=True, with_feature=True, with_laplace=False, rand_directions=None):
         """models/geometry.py:206-292.  points [..., 3] in world space."""
         if with_laplace:
-            raise NotImplementedError("curvature term (SURVEY.md 8a H5) is config[4] scope")
+            assert self.grad_type == "finite_difference", \
+                "Laplace computation is only supported with grad_type='finite_difference'"
         shape = points.shape[:-1]
         pts = points.reshape(-1, 3)
-        with torch.set_grad_enabled(self.training):
-            if with_grad:
+        laplace = None
+        with torch.set_grad_enabled(self.training or (with_grad and self.grad_type == "analytic")):
+            if with_grad and self.grad_type == "analytic":
+                feature, grad = self.field_with_analytic_grad(pts)
+                sdf = feature[..., 0]
+            elif with_grad:
                 eps = self._finite_difference_eps
                 x7 = ops.fd_taps(pts, self.radius, eps)
                 out7 = self.network(self.encoding(x7.view(-1, 3), fd7_eps_unit=self._eps_unit()))
                 sdf, grad = ops.fd_gradient(out7, eps)
                 feature = out7.view(-1, 7, self.n_output_dims)[:, 0]
+                if with_laplace:
+                    laplace = self.curvature(pts, grad, rand_directions)
             else:
                 x = contract_to_unisphere(pts, self.radius, self.contraction_type)
                 feature = self.network(self.encoding(x))
@@ -138,6 +197,8 @@ class VolumeSDF(BaseModel):
             rv.append(grad.view(*shape, 3))
         if with_feature:
             rv.append(feature.reshape(*shape, self.n_output_dims))
+        if with_laplace:
+            rv.append(laplace.view(*shape))
         rv = [v if self.training else v.detach() for v in rv]
         return rv[0] if len(rv) == 1 else rv
 

@@ -285,15 +285,16 @@ class _HashGrid(torch.autograd.Function):
         check(lib().rsdf_hashgrid_fwd(ptr(xf), ptr(tb), ctypes.byref(meta), n, n_active, ptr(out),
                                       col + LF, col, int(include_xyz), float(xyz_scale),
                                       float(xyz_offset), stream_ptr()), "hashgrid_fwd")
-        ctx.save_for_backward(xf)
+        ctx.save_for_backward(x if x.requires_grad else xf)
         ctx.meta, ctx.n_active, ctx.col, ctx.n_params = meta, n_active, col, tb.numel()
-        ctx.fd7 = fd7_eps_unit
+        ctx.fd7, ctx.xyz_scale = fd7_eps_unit, float(xyz_scale)
+        ctx.table = table if x.requires_grad else None   # the input-gradient path re-reads the table
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        (xf,) = ctx.saved_tensors
-        g = _f32c(gout)
+        (x_in,) = ctx.saved_tensors
+        xf, g = _f32c(x_in), _f32c(gout)
         dt = torch.zeros(ctx.n_params, dtype=torch.float32, device=xf.device)
         n = xf.shape[0]
         if ctx.fd7 is not None and ctx.meta.n_features == 2 and n % 7 == 0:
@@ -316,13 +317,57 @@ class _HashGrid(torch.autograd.Function):
         else:
             check(lib().rsdf_hashgrid_bwd(ptr(xf), ptr(g), ctypes.byref(ctx.meta), n, ctx.n_active,
                                           g.shape[1], ctx.col, ptr(dt), stream_ptr()), "hashgrid_bwd")
-        # d/dx is not provided: finite-difference-normal configurations never ask for it
-        return None, dt, None, None, None, None, None, None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            # analytic normals / curvature: differentiable again (tcnn double backward)
+            dx = _HashGridDx.apply(x_in, ctx.table, gout, ctx.meta, ctx.n_active, ctx.col)
+            if ctx.col:
+                dx = dx + gout[:, :3] * ctx.xyz_scale
+        return dx, dt, None, None, None, None, None, None
+
+
+class _HashGridDx(torch.autograd.Function):
+    """dx[S,3] = J_enc(x)^T dy over the active levels; backward = the hash grid's double backward."""
+
+    @staticmethod
+    def forward(ctx, x, table, dy, meta, n_active, col_off):
+        xf, tb, g = _f32c(x), table.detach(), _f32c(dy)
+        require_device(xf, tb, g)
+        n = xf.shape[0]
+        dx = torch.empty(n, 3, dtype=torch.float32, device=xf.device)
+        check(lib().rsdf_hashgrid_dx(ptr(xf), ptr(tb), ctypes.byref(meta), n, n_active, ptr(g), g.shape[1],
+                                     col_off, ptr(dx), stream_ptr()), "hashgrid_dx")
+        ctx.save_for_backward(xf, tb, g)
+        ctx.meta, ctx.n_active, ctx.col = meta, n_active, col_off
+        return dx
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gdx):
+        xf, tb, g = ctx.saved_tensors
+        gd = _f32c(gdx)
+        n = xf.shape[0]
+        need_x, need_t, need_dy = ctx.needs_input_grad[:3]
+        gx = torch.empty(n, 3, dtype=torch.float32, device=xf.device) if need_x else None
+        dt = torch.zeros_like(tb) if need_t else None
+        ddy = torch.zeros_like(g) if need_dy else None
+        check(lib().rsdf_hashgrid_dx_bwd(ptr(xf), ptr(tb), ctypes.byref(ctx.meta), n, ctx.n_active, ptr(g),
+                                         g.shape[1], ctx.col, ptr(gd), ptr(ddy), g.shape[1], ctx.col, ptr(dt),
+                                         ptr(gx), stream_ptr()), "hashgrid_dx_bwd")
+        return gx, dt, ddy, None, None, None
+
+
+def hashgrid_dx(x, table, dy, meta, n_active_levels=None, col_off=0):
+    """Input gradient of the hash-grid encoding: x [S,3] in [0,1], dy [S, col_off + L*F] -> [S,3] (unit-cube
+    coordinates).  Differentiable w.r.t. x, table and dy."""
+    na = meta.n_levels if n_active_levels is None else int(n_active_levels)
+    return _HashGridDx.apply(x, table, dy, meta, na, col_off)
 
 
 def hashgrid_encode(x, table, meta, n_active_levels=None, include_xyz=False, xyz_scale=2.0,
                     xyz_offset=-1.0, fd7_eps_unit=None):
-    """x [S,3] in [0,1] -> [S, (3 +) L*F].  Differentiable w.r.t. ``table``.
+    """x [S,3] in [0,1] -> [S, (3 +) L*F].  Differentiable w.r.t. ``table`` and (analytic-normal / curvature
+    paths) ``x``.
 
     ``fd7_eps_unit`` (= eps / (2 radius)): promise that x is the [S/7, 7, 3] finite-difference
     stencil written by ``fd_points`` / ``fd_taps``; the backward then uses the stencil-merging,

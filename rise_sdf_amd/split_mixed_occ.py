@@ -6,7 +6,8 @@ Built so far: occupancy update (M2, :98-136), visibility-pruned s
 normal-orientation map (:383-401), background compose + sRGB (O1, :404-443).
 Stage 1 (``split_sum_kick_in_step``): split-sum shading against the prefiltered environment light
 (S1-S4, E1; 24 composited channels, :295-303, 344-352, 416-432).
-Not yet: curvature term (H5), relighting third bounce (:322-331, evaluation only).
+Curvature samples (H5, ``sdf_laplace_samples``) through geometry.curvature.
+Not yet: relighting third bounce (:322-331, evaluation only).
 """
 from __future__ import annotations
 
@@ -110,7 +111,7 @@ class SplitMixedOCCModel(BaseModel):
         return 1.0 - acc_map, depth_map
 
     # ---- one ray batch (:224-443) ------------------------------------------------------------------------------
-    def forward_(self, rays, relighting=False, stratified_u=None):
+    def forward_(self, rays, relighting=False, stratified_u=None, curvature_dirs=None):
         if relighting:
             raise NotImplementedError("relighting third bounce (models/split_mixed_occ.py:322-331) is evaluation-only")
         if self.stage != 0 and self.emitter is None:
@@ -119,12 +120,20 @@ class SplitMixedOCCModel(BaseModel):
         rays_o, rays_d = rays[:, 0:3].contiguous(), rays[:, 3:6].contiguous()
         dev = rays.device
 
+        # the reference evaluates the curvature term whenever it trains with FD normals (:251, :287); the
+        # ``curvature`` key lets a config without lambda_curvature skip that extra field evaluation
+        has_laplace = (self.geometry.grad_type == "finite_difference" and self.training
+                       and bool(self.config.get("curvature", True)))
+
         def rgb_normal_alpha_fn(t_starts, t_ends, ray_indices):
             sdf, sdf_grad, normal, alphas, feature = self._stencil(rays_o, rays_d, ray_indices, t_starts,
                                                                    t_ends, True)
             t_dirs = rays_d[ray_indices]
             positions = rays_o[ray_indices] + t_dirs * (t_starts + t_ends)[..., None] / 2.0
             colors = self.texture(feature, t_dirs, normal, positions, self.emitter, self.stage)
+            if has_laplace:
+                return colors, normal, alphas, sdf, sdf_grad, self.geometry.curvature(positions, sdf_grad,
+                                                                                      curvature_dirs)
             return colors, normal, alphas, sdf, sdf_grad
 
         with torch.no_grad():
@@ -135,7 +144,7 @@ class SplitMixedOCCModel(BaseModel):
                 cone_angle=0.0, alpha_thre=0.0)
         rgb_map, normal_map, acc_map, depth_map, extras = rendering_with_normals_sdf(
             t_starts, t_ends, ray_indices=ray_indices, n_rays=n_rays, rgb_alpha_fn=rgb_normal_alpha_fn,
-            render_bkgd=None, has_laplace=False, color_dim=7 if self.stage == 0 else 24)
+            render_bkgd=None, has_laplace=has_laplace, color_dim=7 if self.stage == 0 else 24)
 
         diff_rgb_map, spec_rgb_map, blend_map = rgb_map[..., :3], rgb_map[..., 3:6], rgb_map[..., 6:7]
         if self.stage != 0:
@@ -170,6 +179,8 @@ class SplitMixedOCCModel(BaseModel):
             weights = extras["weights"]
             out.update({"sdf_samples": extras["sdf"], "sdf_grad_samples": extras["sdf_grad"],
                         "weights": weights.view(-1), "ray_indices": ray_indices.view(-1)})
+            if has_laplace:
+                out["sdf_laplace_samples"] = extras["sdf_laplace"]
             if ray_indices.numel() > 0:
                 orient = torch.sum(rays_d[ray_indices] * extras["normals"], dim=-1, keepdim=True).clamp(min=0)
                 out["normals_orientation_loss_map"] = ops.accumulate_along_rays(
