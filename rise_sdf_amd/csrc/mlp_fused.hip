@@ -26,7 +26,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int THREADS = 256;      // backward: 4 waves (408 VGPRs, one wave per SIMD)
 constexpr int WAVES = 4;
-constexpr int FWD_WAVES = 8;      // forward: 8 waves = two per SIMD, so one wave's Softplus overlaps the other's MFMAs
+constexpr int FWD_WAVES = 8;      // forward: 8 waves = two per SIMD
 constexpr int FWD_THREADS = FWD_WAVES * 64;
 constexpr int K0P = 36;       // padded input width (3 + 2*16 = 35 -> 36)
 constexpr int LDX = K0P + 1;  // 37: odd LDS row stride
@@ -64,7 +64,7 @@ struct Smem {
     static constexpr int XS = 0;                         // [32][LDX]
     static constexpr int TA = XS + 32 * LDX;             // [H][LDT]
     static constexpr int TD = TA + H * LDT;              // [H][LDT]
-    static constexpr int PER_WAVE_FWD = 32 * LDX + 32 * 65;  // X tile + feature transpose [32][65]
+    static constexpr int PER_WAVE_FWD = 32 * 65;             // X tile [32][LDX], overlaid by the feature transpose [32][65]
     static constexpr int PER_WAVE_BWD = TD + H * LDT;
 };
 
@@ -180,7 +180,222 @@ __device__ __forceinline__ void hidden_forward(const float *sm, const float *Xs,
 }
 
 // ------------------------------------------------------------------------------------------------
-// forward: enc [7S, ldx] -> sdf7 [7S], feature [S, N2] (nullable; centre rows only)
+// Split-bf16 matrix products.
+//
+// Measured on MI355X (tools/mfma_valu_overlap.hip): an fp32 MFMA occupies its SIMD for its whole 64 (32)
+// cycles -- vector-ALU work of the same or of another wave on that SIMD does not overlap with it, so a
+// kernel that mixes fp32 MFMAs with Softplus / transposes pays their SUM.  bf16 MFMAs run at 16x the rate
+// and hold the issue port for 8 of their 32 cycles only.  Every fp32 operand is therefore written as the
+// exact sum of three bf16 numbers (x = h + m + l: 8 + 8 + 8 mantissa bits, round-to-nearest at each step) and a
+// product a.b is evaluated as the six partial products of weight >= 2^-16,
+//     al.bh + ah.bl + am.bm + am.bh + ah.bm + ah.bh        (dropped: am.bl, al.bm, al.bl <= 2^-24 |a||b|)
+// each an exact bf16 x bf16 product accumulated in fp32 by v_mfma_f32_32x32x16_bf16, small terms first.  The
+// error per product is ~1e-7 |a||b|, the same order as one fp32 rounding, at 6/16 of the fp32-MFMA cost, and the
+// matrix pipe now runs in the shadow of the vector ALU work.
+//
+// Layouts (cdna_hip_programming.md, "An accumulator tile as the next MFMA's operand"): a 32x32 accumulator
+// tile D[n][row] keeps row = lane & 31 on the lane and feature (r & 3) + 8 (r >> 2) + 4 (lane >> 5) in register r.
+// Registers 8s .. 8s+7, packed pairwise to bf16, ARE the B fragment of k-step s of the next layer; the weights
+// are staged in LDS already permuted to that k order, one 16-byte A fragment per lane:
+//     Wp[part][n tile][k tile][s][lane >> 5][lane & 31][j]  =  W[32 nt + (lane & 31)][32 kt + 16 s + 8 (j >> 2) + 4 (lane >> 5) + (j & 3)]
+// ------------------------------------------------------------------------------------------------
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+
+struct Frag3 { u32x4 h, m, l; };
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b)  // v_cvt_pk_bf16_f32 (RNE); a -> low half
+{
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
+}
+__device__ __forceinline__ float bf16_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+
+__device__ __forceinline__ void split3_pair(float a, float b, unsigned &h, unsigned &m, unsigned &l)
+{
+    h = pack_bf16(a, b);
+    const float ra = a - bf16_lo(h), rb = b - bf16_hi(h);   // exact
+    m = pack_bf16(ra, rb);
+    l = pack_bf16(ra - bf16_lo(m), rb - bf16_hi(m));
+}
+// 8 consecutive fragment elements -> 3-part fragment
+__device__ __forceinline__ Frag3 split_frag(float v0, float v1, float v2, float v3, float v4, float v5, float v6,
+                                            float v7)
+{
+    unsigned h[4], m[4], l[4];
+    split3_pair(v0, v1, h[0], m[0], l[0]);
+    split3_pair(v2, v3, h[1], m[1], l[1]);
+    split3_pair(v4, v5, h[2], m[2], l[2]);
+    split3_pair(v6, v7, h[3], m[3], l[3]);
+    Frag3 f;
+    f.h = u32x4{h[0], h[1], h[2], h[3]};
+    f.m = u32x4{m[0], m[1], m[2], m[3]};
+    f.l = u32x4{l[0], l[1], l[2], l[3]};
+    return f;
+}
+__device__ __forceinline__ f32x16 mma_bf16(u32x4 a, u32x4 b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c,
+                                                    0, 0, 0);
+}
+// a (weights: LDS, three parts PART_STRIDE bytes apart) x b (activations), six partial products
+template <int PART_STRIDE_U4>
+__device__ __forceinline__ f32x16 mma6(const u32x4 *__restrict__ wa, const Frag3 &b, f32x16 c)
+{
+    const u32x4 ah = wa[0], am = wa[PART_STRIDE_U4], al = wa[2 * PART_STRIDE_U4];
+    c = mma_bf16(al, b.h, c);
+    c = mma_bf16(ah, b.l, c);
+    c = mma_bf16(am, b.m, c);
+    c = mma_bf16(am, b.h, c);
+    c = mma_bf16(ah, b.m, c);
+    c = mma_bf16(ah, b.h, c);
+    return c;
+}
+
+// Softplus(beta = 100, threshold = 20) on the raw exp2 / log2 units:  max(z, 0) + log2(1 + 2^(-|100 z| log2 e)) ln 2 / 100
+__device__ __forceinline__ float softplus100_fast(float z)
+{
+    const float e = __builtin_amdgcn_exp2f(-144.26950408889634f * fabsf(z));
+    return fmaf(__builtin_amdgcn_logf(1.0f + e), 0.0069314718055994531f, fmaxf(z, 0.0f));
+}
+// sigmoid(100 z) = 1 - 2^(-100 log2(e) h) from h = softplus(z)
+__device__ __forceinline__ float softplus100_grad_fast(float h)
+{
+    return 1.0f - __builtin_amdgcn_exp2f(-144.26950408889634f * h);
+}
+
+constexpr int LDXF = 36;   // fp32 X tile row stride: 16-byte aligned rows, conflict-free ds_read_b128 over 8 rows
+constexpr int KS0 = 3;     // layer-1 k-steps of 16 (K0 <= 35, column 35 = 1 carries the bias, 36..47 hit zero weights)
+
+// LDS image of the split weights (units: u32x4 = 16 bytes)
+template <int H>
+struct SmemS {
+    static constexpr int NT = H / 32;
+    static constexpr int W0_PART = NT * KS0 * 2 * 32;            // [nt][s][hf][c]
+    static constexpr int W1_PART = NT * NT * 2 * 2 * 32;         // [nt][kt][s][hf][c]
+    static constexpr int W2_PART = 2 * NT * 2 * 2 * 32;          // [n2 tile (2)][kt][s][hf][c]
+    static constexpr int W0 = 0;
+    static constexpr int W1 = W0 + 3 * W0_PART;
+    static constexpr int W2 = W1 + 3 * W1_PART;
+    static constexpr int END_U4 = W2 + 3 * W2_PART;
+    // fp32 tail (float index from the start of the tail)
+    static constexpr int B1 = 0;          // [H]
+    static constexpr int B2 = B1 + H;     // [64]
+    static constexpr int W2R0 = B2 + 64;  // [H]   row 0 of W2 (SDF) for the vector-ALU dot of the taps
+    static constexpr int TAIL_F = W2R0 + H;
+    static constexpr size_t SHARED_BYTES = (size_t)END_U4 * 16 + (size_t)TAIL_F * 4;
+    static constexpr int PER_WAVE_F = 32 * 65;   // X tile [32][LDXF] fp32, overlaid by the feature transpose [32][65]
+};
+
+__device__ __forceinline__ void store3(unsigned short *base, size_t part_stride_elems, size_t idx, float w)
+{
+    unsigned h, m, l;
+    split3_pair(w, 0.0f, h, m, l);
+    base[idx] = (unsigned short)(h & 0xffffu);
+    base[idx + part_stride_elems] = (unsigned short)(m & 0xffffu);
+    base[idx + 2 * part_stride_elems] = (unsigned short)(l & 0xffffu);
+}
+// k of element j of lane half hf in k-step s of a 32-feature activation tile
+__device__ __forceinline__ int frag_k(int s, int hf, int j) { return 16 * s + 8 * (j >> 2) + 4 * hf + (j & 3); }
+
+// Stage W0 (+ b0 as column 35), W1, W2 as split, fragment-ordered bf16; b1, b2, W2 row 0 in fp32.
+template <int H>
+__device__ __forceinline__ void stage_split_weights(unsigned char *smem, const float *__restrict__ w0,
+                                                    const float *__restrict__ b0, const float *__restrict__ w1,
+                                                    const float *__restrict__ b1, const float *__restrict__ w2,
+                                                    const float *__restrict__ b2, int K0, int N2)
+{
+    using S = SmemS<H>;
+    constexpr int NT = S::NT;
+    unsigned short *e16 = reinterpret_cast<unsigned short *>(smem);
+    const int NTHR = blockDim.x;
+    // W0: [nt][s][hf][c][j], natural k = 16 s + 8 hf + j (the X tile is read from LDS in that order)
+    for (int e = threadIdx.x; e < NT * KS0 * 2 * 32 * 8; e += NTHR) {
+        const int j = e & 7, c = (e >> 3) & 31, hf = (e >> 8) & 1, s = (e >> 9) % KS0, nt = (e >> 9) / KS0;
+        const int n = 32 * nt + c, k = 16 * s + 8 * hf + j;
+        const float w = k < K0 ? w0[n * K0 + k] : (k == 35 ? b0[n] : 0.0f);
+        store3(e16 + (size_t)S::W0 * 8, (size_t)S::W0_PART * 8, e, w);
+    }
+    for (int e = threadIdx.x; e < NT * NT * 2 * 2 * 32 * 8; e += NTHR) {
+        const int j = e & 7, c = (e >> 3) & 31, hf = (e >> 8) & 1, s = (e >> 9) & 1, kt = (e >> 10) % NT,
+                  nt = (e >> 10) / NT;
+        const int n = 32 * nt + c, k = 32 * kt + frag_k(s, hf, j);
+        store3(e16 + (size_t)S::W1 * 8, (size_t)S::W1_PART * 8, e, w1[n * H + k]);
+    }
+    for (int e = threadIdx.x; e < 2 * NT * 2 * 2 * 32 * 8; e += NTHR) {
+        const int j = e & 7, c = (e >> 3) & 31, hf = (e >> 8) & 1, s = (e >> 9) & 1, kt = (e >> 10) % NT,
+                  nt = (e >> 10) / NT;
+        const int n = 32 * nt + c, k = 32 * kt + frag_k(s, hf, j);
+        store3(e16 + (size_t)S::W2 * 8, (size_t)S::W2_PART * 8, e, n < N2 ? w2[n * H + k] : 0.0f);
+    }
+    float *tail = reinterpret_cast<float *>(smem + (size_t)S::END_U4 * 16);
+    for (int e = threadIdx.x; e < H; e += NTHR) {
+        tail[S::B1 + e] = b1[e];
+        tail[S::W2R0 + e] = w2[e];
+    }
+    for (int e = threadIdx.x; e < 64; e += NTHR) tail[S::B2 + e] = e < N2 ? b2[e] : 0.0f;
+}
+
+__device__ __forceinline__ void store_tile_f(float *Xs, const float (&pre)[18], const TileSrc &src, int lane)
+{
+    const int r = lane >> 1, f = lane & 1;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) Xs[r * LDXF + 3 + 2 * l + f] = pre[l];
+    Xs[(lane / 3) * LDXF + lane % 3] = pre[16] * src.xyz_scale + src.xyz_offset;
+    if (lane < 32) Xs[((lane + 64) / 3) * LDXF + (lane + 64) % 3] = pre[17] * src.xyz_scale + src.xyz_offset;
+    if (lane < 32) Xs[lane * LDXF + 35] = 1.0f;   // bias column
+}
+
+// hidden layers 1 and 2 of one 32-row tile; h[t][r]: feature 32 t + (r & 3) + 8 (r >> 2) + 4 hf of row c
+template <int H>
+__device__ __forceinline__ void hidden_forward_s(const unsigned char *smem, const float *Xs, int c, int hf,
+                                                 const float (&b1r)[H / 32][16], f32x16 (&h1)[H / 32],
+                                                 f32x16 (&h2)[H / 32])
+{
+    using S = SmemS<H>;
+    constexpr int NT = S::NT;
+    const u32x4 *wl = reinterpret_cast<const u32x4 *>(smem);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h1[t][r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < KS0; ++s) {
+        const float4 x0 = *reinterpret_cast<const float4 *>(Xs + c * LDXF + 16 * s + 8 * hf);
+        const float4 x1 = *reinterpret_cast<const float4 *>(Xs + c * LDXF + 16 * s + 8 * hf + 4);
+        const Frag3 xb = split_frag(x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            h1[t] = mma6<S::W0_PART>(wl + S::W0 + ((t * KS0 + s) * 2 + hf) * 32 + c, xb, h1[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h1[t][r] = softplus100_fast(h1[t][r]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h2[t][r] = b1r[t][r];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const Frag3 hb = split_frag(h1[kt][8 * s], h1[kt][8 * s + 1], h1[kt][8 * s + 2], h1[kt][8 * s + 3],
+                                        h1[kt][8 * s + 4], h1[kt][8 * s + 5], h1[kt][8 * s + 6], h1[kt][8 * s + 7]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                h2[t] = mma6<S::W1_PART>(wl + S::W1 + (((t * NT + kt) * 2 + s) * 2 + hf) * 32 + c, hb, h2[t]);
+        }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h2[t][r] = softplus100_fast(h2[t][r]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward: tap-major inputs -> sdf7t [7][S], feature [S, N2] (nullable; centre rows only), h2c (nullable)
 // ------------------------------------------------------------------------------------------------
 template <int H>
 __global__ void __launch_bounds__(FWD_THREADS)
@@ -192,14 +407,28 @@ sdfmlp_fwd_kernel(const TileSrc src, const float *__restrict__ w0,
 {
     const int64_t n_samples = src.S;
     const int K0 = 3 + 2 * src.n_levels;
-    using S = Smem<H>;
-    constexpr int NT = H / 32;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
-    float *Xs = smem + S::SHARED + wave * S::PER_WAVE_FWD;
-    float *Fs = Xs + 32 * LDX;  // [32][65]
-    stage_all_weights<H>(smem, w0, b0, w1, b1, w2, b2, K0, N2);
+    using S = SmemS<H>;
+    constexpr int NT = S::NT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 31, hf = lane >> 5;
+    float *tail = reinterpret_cast<float *>(smem_b + (size_t)S::END_U4 * 16);
+    float *Xs = reinterpret_cast<float *>(smem_b + S::SHARED_BYTES) + wave * S::PER_WAVE_F;
+    float *Fs = Xs;  // [32][65] over the X tile, which is dead once the first layer has read it
+    stage_split_weights<H>(smem_b, w0, b0, w1, b1, w2, b2, K0, N2);
+    for (int e = lane; e < S::PER_WAVE_F; e += 64) Xs[e] = 0.0f;   // pad columns must be finite
     __syncthreads();
+    const u32x4 *wl = reinterpret_cast<const u32x4 *>(smem_b);
+
+    float b1r[NT][16], w2r[NT][16];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hf;
+            b1r[t][r] = tail[S::B1 + f];
+            w2r[t][r] = tail[S::W2R0 + f];
+        }
+    const float b2_0 = tail[S::B2];
 
     const int64_t n_groups = (n_samples + 31) / 32;  // 32 samples per wave iteration
     const int64_t g_first = (int64_t)blockIdx.x * FWD_WAVES + wave, g_step = (int64_t)gridDim.x * FWD_WAVES;
@@ -208,24 +437,32 @@ sdfmlp_fwd_kernel(const TileSrc src, const float *__restrict__ w0,
     for (int64_t g = g_first; g < n_groups; g += g_step) {
         const int64_t s0 = g * 32;
         for (int tap = 0; tap < 7; ++tap) {
-            store_tile(Xs, pre, src, lane);
+            store_tile_f(Xs, pre, src, lane);
             {   // prefetch the next tile of this wave
                 const int ntap = tap == 6 ? 0 : tap + 1;
                 const int64_t ng = tap == 6 ? g + g_step : g;
                 if (ng < n_groups) fetch_tile(pre, src, ng * 32, ntap, lane);
             }
             f32x16 h1[NT], h2[NT];
-            hidden_forward<H>(smem, Xs, li, lh, h1, h2);
-            const int64_t s = s0 + li;
+            hidden_forward_s<H>(smem_b, Xs, c, hf, b1r, h1, h2);
+            const int64_t s = s0 + c;
+            // SDF: dot(W2[0,:], h2[:,row]) on the vector ALU, features split over the lane halves
+            float acc = 0.0f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc = fmaf(w2r[t][r], h2[t][r], acc);
+            acc += __shfl_xor(acc, 32, 64);
+            if (hf == 0 && s < n_samples) sdf7[(int64_t)tap * n_samples + s] = acc + b2_0;
             if (tap == 0 && feature != nullptr) {
                 if (h2c != nullptr) {  // second hidden layer of the centre rows, for the dW2 of features
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) Fs[li * 65 + t * 32 + n_lo(r) + 4 * lh] = h2[t][r];
+                        for (int r = 0; r < 16; ++r) Fs[c * 65 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf] = h2[t][r];
                     for (int e = lane; e < 32 * H; e += 64) {
-                        const int r = e / H, c = e - r * H;
-                        if (s0 + r < n_samples) h2c[(s0 + r) * H + c] = Fs[r * 65 + c];
+                        const int r = e / H, cc = e - r * H;
+                        if (s0 + r < n_samples) h2c[(s0 + r) * H + cc] = Fs[r * 65 + cc];
                     }
                 }
                 // full last layer on the matrix cores: out[n2][row]
@@ -233,40 +470,31 @@ sdfmlp_fwd_kernel(const TileSrc src, const float *__restrict__ w0,
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) o[t][r] = smem[S::B2 + t * 32 + n_lo(r) + 4 * lh];
+                    for (int r = 0; r < 16; ++r) o[t][r] = tail[S::B2 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf];
 #pragma unroll
-                for (int tk = 0; tk < NT; ++tk)
+                for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int k = tk * 32 + n_lo(r) + 4 * lh;
+                    for (int ss = 0; ss < 2; ++ss) {
+                        const Frag3 hb = split_frag(h2[kt][8 * ss], h2[kt][8 * ss + 1], h2[kt][8 * ss + 2],
+                                                    h2[kt][8 * ss + 3], h2[kt][8 * ss + 4], h2[kt][8 * ss + 5],
+                                                    h2[kt][8 * ss + 6], h2[kt][8 * ss + 7]);
 #pragma unroll
-                        for (int t = 0; t < 2; ++t) {
-                            if (t * 32 < N2) {
-                                const float a = smem[S::W2 + (t * 32 + li) * S::LDW1 + k];
-                                o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, h2[tk][r], o[t], 0, 0, 0);
-                            }
-                        }
+                        for (int t = 0; t < 2; ++t)
+                            if (t * 32 < N2)
+                                o[t] = mma6<S::W2_PART>(wl + S::W2 + (((t * NT + kt) * 2 + ss) * 2 + hf) * 32 + c, hb,
+                                                        o[t]);
                     }
                 // transpose through LDS for coalesced row stores
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) Fs[li * 65 + t * 32 + n_lo(r) + 4 * lh] = o[t][r];
+                    for (int r = 0; r < 16; ++r) Fs[c * 65 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf] = o[t][r];
                 for (int e = lane; e < 32 * N2; e += 64) {
-                    const int r = e / N2, c = e - r * N2;
-                    if (s0 + r < n_samples) feature[(s0 + r) * N2 + c] = Fs[r * 65 + c];
+                    const int r = e / N2, cc = e - r * N2;
+                    if (s0 + r < n_samples) feature[(s0 + r) * N2 + cc] = Fs[r * 65 + cc];
                 }
-                if (lh == 0 && s < n_samples) sdf7[s] = o[0][0];
-            } else {
-                // SDF only: dot(W2[0,:], h2[:,row]) on the vector ALU, k split over the lane halves
-                float acc = 0.0f;
-#pragma unroll
-                for (int tk = 0; tk < NT; ++tk)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        acc = fmaf(smem[S::W2 + tk * 32 + n_lo(r) + 4 * lh], h2[tk][r], acc);
-                acc += __shfl_xor(acc, 32, 64);
-                if (lh == 0 && s < n_samples) sdf7[(int64_t)tap * n_samples + s] = acc + smem[S::B2];
+                // the X tile region now holds feature rows: restore finite pad columns for the next tile
+                // (columns 36.. of a row alias the next row's data, which stays finite; nothing to do)
             }
         }
     }
@@ -516,7 +744,7 @@ sdfmlp_bwd_kernel(const TileSrc src, const float *__restrict__ w0,
 }
 
 template <int H>
-size_t fwd_lds() { return (size_t)(Smem<H>::SHARED + FWD_WAVES * Smem<H>::PER_WAVE_FWD) * sizeof(float); }
+size_t fwd_lds() { return SmemS<H>::SHARED_BYTES + (size_t)FWD_WAVES * SmemS<H>::PER_WAVE_F * sizeof(float); }
 template <int H>
 size_t bwd_lds() { return (size_t)(Smem<H>::SHARED + WAVES * Smem<H>::PER_WAVE_BWD) * sizeof(float); }
 
