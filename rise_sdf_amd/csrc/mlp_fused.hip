@@ -24,8 +24,8 @@ namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int THREADS = 256;      // backward: 4 waves (408 VGPRs, one wave per SIMD)
-constexpr int WAVES = 4;
+constexpr int BWD_WAVES = 4;      // backward: one wave per SIMD (register-resident weight fragments + accumulators)
+constexpr int BWD_THREADS = BWD_WAVES * 64;
 constexpr int FWD_WAVES = 8;      // forward: 8 waves = two per SIMD
 constexpr int FWD_THREADS = FWD_WAVES * 64;
 constexpr int K0P = 36;       // padded input width (3 + 2*16 = 35 -> 36)
@@ -501,15 +501,100 @@ sdfmlp_fwd_kernel(const TileSrc src, const float *__restrict__ w0,
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward: d_sdf7 [7S] -> d_enc window [7S, lddx] (columns k0w .. k0w+kw of the input),
-//           dW0, db0, dW1, db1, dW2 row 0, db2[0]   (atomically accumulated: zero first)
+// backward: d_sdf7t [7][S] (+ d_feature [S,N2], centre rows) -> d_planes [L][7][S][2], dW0, db0, dW1, db1,
+//           dW2 row 0, db2[0]   (atomically accumulated: zero first)
+//
+// One wave per SIMD (4 per workgroup, up to 512 registers each).  Per 32-row tile:
+//   recompute h1, h2                      split-bf16 products, weights from LDS (as the forward)
+//   dz2 = (W2^T d_out) sigma'(z2)         SDF column on the vector ALU; feature columns (centre tap) split-bf16 from LDS
+//   dz1 = (W1^T dz2) sigma'(z1), dx = W0^T dz1    split-bf16, the transposed weight fragments live in registers
+//   dW1 += dz2^T h1, dW0 += dz1^T x       fp32 MFMA over [feature][row] tiles in LDS (sum over rows = MFMA k),
+//                                         accumulated in registers across the whole row loop, flushed once
 // ------------------------------------------------------------------------------------------------
+constexpr int LDF = 68;   // d_feature staging [32][LDF] fp32: 16-byte aligned rows, conflict-free b128 reads
+
 template <int H>
-__global__ void __launch_bounds__(THREADS)
+struct SmemSB {
+    using F = SmemS<H>;
+    static constexpr int NT = H / 32;
+    static constexpr int W0 = 0;
+    static constexpr int W1 = W0 + 3 * F::W0_PART;
+    static constexpr int W2T = W1 + 3 * F::W1_PART;                 // [part][t][s][hf][c], s < steps2
+    static constexpr int w2t_part(int steps2) { return NT * steps2 * 2 * 32; }
+    static constexpr int end_u4(int steps2) { return W2T + 3 * w2t_part(steps2); }
+    // fp32 tail
+    static constexpr int B1 = 0;          // [H]
+    static constexpr int W2R0 = B1 + H;   // [H]
+    static constexpr int TAIL_F = W2R0 + H;
+    static constexpr size_t shared_bytes(int steps2) { return (size_t)end_u4(steps2) * 16 + (size_t)TAIL_F * 4; }
+    // per wave (floats)
+    static constexpr int XS = 0;                         // [32][LDXF]
+    static constexpr int TA = XS + 32 * LDXF;            // [H][LDT]
+    static constexpr int TD = TA + H * LDT;              // [H][LDT]
+    static constexpr int TILES_END = TD + H * LDT + 16;  // + slack for the pad-column over-read of the last row
+    static constexpr int FS_END = TA + 32 * LDF;         // d_feature staging overlays Ta|Td
+    static constexpr int PER_WAVE_F = TILES_END > FS_END ? TILES_END : FS_END;
+};
+
+template <int H>
+__device__ __forceinline__ void stage_split_weights_bwd(unsigned char *smem, const float *__restrict__ w0,
+                                                        const float *__restrict__ b0, const float *__restrict__ w1,
+                                                        const float *__restrict__ b1, const float *__restrict__ w2,
+                                                        int K0, int N2, int steps2)
+{
+    using S = SmemSB<H>;
+    using F = SmemS<H>;
+    constexpr int NT = S::NT;
+    unsigned short *e16 = reinterpret_cast<unsigned short *>(smem);
+    const int NTHR = blockDim.x;
+    for (int e = threadIdx.x; e < NT * KS0 * 2 * 32 * 8; e += NTHR) {
+        const int j = e & 7, c = (e >> 3) & 31, hf = (e >> 8) & 1, s = (e >> 9) % KS0, nt = (e >> 9) / KS0;
+        const int n = 32 * nt + c, k = 16 * s + 8 * hf + j;
+        const float w = k < K0 ? w0[n * K0 + k] : (k == 35 ? b0[n] : 0.0f);
+        store3(e16 + (size_t)S::W0 * 8, (size_t)F::W0_PART * 8, e, w);
+    }
+    for (int e = threadIdx.x; e < NT * NT * 2 * 2 * 32 * 8; e += NTHR) {
+        const int j = e & 7, c = (e >> 3) & 31, hf = (e >> 8) & 1, s = (e >> 9) & 1, kt = (e >> 10) % NT,
+                  nt = (e >> 10) / NT;
+        const int n = 32 * nt + c, k = 32 * kt + frag_k(s, hf, j);
+        store3(e16 + (size_t)S::W1 * 8, (size_t)F::W1_PART * 8, e, w1[n * H + k]);
+    }
+    // W2T: A[i = h2 feature 32 t + c][k = n2 = 16 s + 8 hf + j] = W2[n2][32 t + c]
+    for (int e = threadIdx.x; e < NT * steps2 * 2 * 32 * 8; e += NTHR) {
+        const int j = e & 7, c = (e >> 3) & 31, hf = (e >> 8) & 1, s = (e >> 9) % steps2, t = (e >> 9) / steps2;
+        const int n2 = 16 * s + 8 * hf + j;
+        store3(e16 + (size_t)S::W2T * 8, (size_t)S::w2t_part(steps2) * 8, e, n2 < N2 ? w2[n2 * H + 32 * t + c] : 0.0f);
+    }
+    float *tail = reinterpret_cast<float *>(smem + (size_t)S::end_u4(steps2) * 16);
+    for (int e = threadIdx.x; e < H; e += NTHR) {
+        tail[S::B1 + e] = b1[e];
+        tail[S::W2R0 + e] = w2[e];
+    }
+}
+
+// six partial products with the weight fragment in registers
+__device__ __forceinline__ f32x16 mma6r(const Frag3 &a, const Frag3 &b, f32x16 c)
+{
+    c = mma_bf16(a.l, b.h, c);
+    c = mma_bf16(a.h, b.l, c);
+    c = mma_bf16(a.m, b.m, c);
+    c = mma_bf16(a.m, b.h, c);
+    c = mma_bf16(a.h, b.m, c);
+    c = mma_bf16(a.h, b.h, c);
+    return c;
+}
+__device__ __forceinline__ Frag3 frag_of(const f32x16 &v, int s)
+{
+    return split_frag(v[8 * s], v[8 * s + 1], v[8 * s + 2], v[8 * s + 3], v[8 * s + 4], v[8 * s + 5], v[8 * s + 6],
+                      v[8 * s + 7]);
+}
+
+template <int H>
+__global__ void __launch_bounds__(BWD_THREADS)
 sdfmlp_bwd_kernel(const TileSrc src, const float *__restrict__ w0,
                   const float *__restrict__ b0, const float *__restrict__ w1,
                   const float *__restrict__ b1, const float *__restrict__ w2,
-                  const float *__restrict__ b2, int N2,
+                  const float *__restrict__ b2, int N2, int steps2,
                   const float *__restrict__ d_sdf7, const float *__restrict__ d_feature,
                   float *__restrict__ d_planes,
                   float *__restrict__ dw0, float *__restrict__ db0,
@@ -519,100 +604,133 @@ sdfmlp_bwd_kernel(const TileSrc src, const float *__restrict__ w0,
     const int64_t n_samples = src.S;
     const int K0 = 3 + 2 * src.n_levels;
     const int k0w = 3, kw = 2 * src.n_levels;
-    using S = Smem<H>;
-    constexpr int NT = H / 32;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
-    float *Xs = smem + S::SHARED + wave * S::PER_WAVE_BWD + S::XS;
-    float *Ta = smem + S::SHARED + wave * S::PER_WAVE_BWD + S::TA;
-    float *Td = smem + S::SHARED + wave * S::PER_WAVE_BWD + S::TD;
-    stage_all_weights<H>(smem, w0, b0, w1, b1, w2, b2, K0, N2);
+    using S = SmemSB<H>;
+    using F = SmemS<H>;
+    constexpr int NT = S::NT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 31, hf = lane >> 5;
+    const int li = c, lh = hf;
+    const float *tail = reinterpret_cast<const float *>(smem_b + (size_t)S::end_u4(steps2) * 16);
+    float *wbase = reinterpret_cast<float *>(smem_b + S::shared_bytes(steps2)) + wave * S::PER_WAVE_F;
+    float *Xs = wbase + S::XS, *Ta = wbase + S::TA, *Td = wbase + S::TD;
+    stage_split_weights_bwd<H>(smem_b, w0, b0, w1, b1, w2, K0, N2, steps2);
+    for (int e = lane; e < S::PER_WAVE_F; e += 64) wbase[e] = 0.0f;   // pad columns must be finite
     __syncthreads();
+    const u32x4 *wl = reinterpret_cast<const u32x4 *>(smem_b);
+
+    // transposed weight fragments, register resident for the whole kernel
+    //   w1t[t][kt][s]: A[i = k1 = 32 t + c][k2 = 32 kt + frag_k(s, hf, j)] = W1[k2][k1]
+    //   w0t[kt][s]:    A[i = hash column c][k1 = 32 kt + frag_k(s, hf, j)] = W0[k1][3 + c]
+    Frag3 w1t[NT][NT][2], w0t[NT][2];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float v[8];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = w1[(32 * kt + frag_k(s, hf, j)) * H + 32 * t + c];
+                w1t[t][kt][s] = split_frag(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = c < kw ? w0[(32 * kt + frag_k(s, hf, j)) * K0 + k0w + c] : 0.0f;
+            w0t[kt][s] = split_frag(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+        }
 
     // gradient accumulators that live across the whole row loop
     f32x16 gw1[NT][NT];  // dW1[n tile][k tile]
     f32x16 gw0[NT];      // dW0[n tile][input columns 0..31]
+    f32x16 gw2p[NT];     // per-lane (= per row slot) partial of dW2[0][feature]
 #pragma unroll
     for (int a = 0; a < NT; ++a) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) gw0[a][r] = 0.0f;
+        for (int r = 0; r < 16; ++r) { gw0[a][r] = 0.0f; gw2p[a][r] = 0.0f; }
 #pragma unroll
         for (int b = 0; b < NT; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) gw1[a][b][r] = 0.0f;
     }
-    // per-lane partials, lane f (< H) owns feature f
-    float gb1 = 0.0f, gb0 = 0.0f, gw2 = 0.0f, gb2 = 0.0f;
-    float gw0_tail[4] = {0.f, 0.f, 0.f, 0.f};  // dW0[f][32..35]
+    float gb1 = 0.0f, gb0 = 0.0f, gb2 = 0.0f;     // lane f (< H) owns feature f
+    float gw0_tail[4] = {0.f, 0.f, 0.f, 0.f};     // dW0[f][32..35]
 
     const int64_t n_groups = (n_samples + 31) / 32;
-    const int64_t g_first = (int64_t)blockIdx.x * WAVES + wave, g_step = (int64_t)gridDim.x * WAVES;
+    const int64_t g_first = (int64_t)blockIdx.x * BWD_WAVES + wave, g_step = (int64_t)gridDim.x * BWD_WAVES;
     float pre[18];
     if (g_first < n_groups) fetch_tile(pre, src, g_first * 32, 0, lane);
     for (int64_t g = g_first; g < n_groups; g += g_step) {
         const int64_t s0 = g * 32;
         for (int tap = 0; tap < 7; ++tap) {
-            store_tile(Xs, pre, src, lane);
+            store_tile_f(Xs, pre, src, lane);
             {
                 const int ntap = tap == 6 ? 0 : tap + 1;
                 const int64_t ng = tap == 6 ? g + g_step : g;
                 if (ng < n_groups) fetch_tile(pre, src, ng * 32, ntap, lane);
             }
-            f32x16 h1[NT], h2[NT];
-            hidden_forward<H>(smem, Xs, li, lh, h1, h2);
-            const int64_t s = s0 + li;
+            f32x16 h1[NT], dz2[NT];
+            const int64_t s = s0 + c;
             const float dsdf = s < n_samples ? d_sdf7[(int64_t)tap * n_samples + s] : 0.0f;
-
-            // ---- layer 3, feature part (centre rows): dh2 = W2^T d_feature on the matrix cores.  The
-            // matching dW2 += d_feature^T h2 is formed outside from the h2 the forward saved.
-            f32x16 dh2[NT];
+            {
+                f32x16 h2[NT];
+                float b1r[NT][16];
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+                for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dh2[t][r] = 0.0f;
-            if (tap == 0 && d_feature != nullptr) {
-                float *Fs = Ta;  // [32][65] scratch over Ta|Td (both idle here)
-                for (int e = lane; e < 32 * 64; e += 64) {
-                    const int r = e >> 6, c = e & 63;
-                    Fs[r * 65 + c] = (s0 + r < n_samples && c < N2) ? d_feature[(s0 + r) * N2 + c] : 0.0f;
+                    for (int r = 0; r < 16; ++r) b1r[t][r] = tail[S::B1 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hf];
+                {   // the forward's hidden layers, weights at this kernel's LDS offsets (same image order)
+                    static_assert(S::W0 == F::W0 && S::W1 == F::W1, "recompute shares the forward's weight image");
+                    hidden_forward_s<H>(smem_b, Xs, c, hf, b1r, h1, h2);
                 }
-                const int n2p = (N2 + 1) & ~1;
-                for (int n2 = 0; n2 < n2p; n2 += 2) {
-                    const float b = Fs[li * 65 + n2 + lh];
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        const float a = smem[S::W2 + (n2 + lh) * S::LDW1 + t * 32 + li];
-                        dh2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, dh2[t], 0, 0, 0);
+                gb2 += (hf == 0) ? dsdf : 0.0f;
+                // ---- layer 3: dh2 = W2^T d_out.  Output channel 0 is the SDF: on the centre tap with feature
+                // gradients d_sdf joins column 0 of d_feature and the whole product runs on the matrix cores;
+                // otherwise it is the rank-1 term W2[0,:] d_sdf on the vector ALU.
+                if (tap == 0 && d_feature != nullptr) {
+                    float *Fs = Ta;  // [32][LDF] over Ta|Td (both idle here)
+                    for (int e = lane; e < 32 * 64; e += 64) {
+                        const int r = e >> 6, cc = e & 63;
+                        float v = (s0 + r < n_samples && cc < N2) ? d_feature[(s0 + r) * N2 + cc] : 0.0f;
+                        Fs[r * LDF + cc] = v;
                     }
+                    if (hf == 0) Fs[c * LDF] += dsdf;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) dz2[t][r] = 0.0f;
+                    for (int ss = 0; ss < steps2; ++ss) {
+                        const float4 x0 = *reinterpret_cast<const float4 *>(Fs + c * LDF + 16 * ss + 8 * hf);
+                        const float4 x1 = *reinterpret_cast<const float4 *>(Fs + c * LDF + 16 * ss + 8 * hf + 4);
+                        const Frag3 fb = split_frag(x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w);
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            const u32x4 *wa = wl + S::W2T + ((t * steps2 + ss) * 2 + hf) * 32 + c;
+                            const int ps = S::w2t_part(steps2);
+                            const u32x4 ah = wa[0], am = wa[ps], al = wa[2 * ps];
+                            dz2[t] = mma_bf16(al, fb.h, dz2[t]);
+                            dz2[t] = mma_bf16(ah, fb.l, dz2[t]);
+                            dz2[t] = mma_bf16(am, fb.m, dz2[t]);
+                            dz2[t] = mma_bf16(am, fb.h, dz2[t]);
+                            dz2[t] = mma_bf16(ah, fb.m, dz2[t]);
+                            dz2[t] = mma_bf16(ah, fb.h, dz2[t]);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            dz2[t][r] = tail[S::W2R0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hf] * dsdf;
                 }
+                // dW2[0,:] += d_sdf h2 (per-lane partial) ; dz2 = dh2 sigma'(z2)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        gw2p[t][r] = fmaf(dsdf, h2[t][r], gw2p[t][r]);
+                        dz2[t][r] *= softplus100_grad_fast(h2[t][r]);
+                    }
             }
-            // ---- layer 3 (SDF column): dh2 += W2[0,:] * dsdf ; dW2[0,:] += dsdf * h2 ---------------
-            // h2 -> Ta as [feature][row]
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) Ta[(t * 32 + n_lo(r) + 4 * lh) * LDT + li] = h2[t][r];
-            // dsdf per row -> first row of Td's scratch line (reuse Xs pad column is too small)
-            Td[H * LDT - 33 + li] = dsdf;  // last LDT-sized line of Td is overwritten later; used now
-            // (each lane f < H) dW2[0][f] += sum_row dsdf[row] * h2[f][row]
-            if (lane < H) {
-                float acc = 0.0f;
-#pragma unroll 8
-                for (int row = 0; row < 32; ++row) acc = fmaf(Td[H * LDT - 33 + row], Ta[lane * LDT + row], acc);
-                gw2 += acc;
-            }
-            gb2 += (lh == 0) ? dsdf : 0.0f;
-            // dz2 = dh2 * sigmoid(100 z2)
-            f32x16 dz2[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int k = t * 32 + n_lo(r) + 4 * lh;
-                    dz2[t][r] = (smem[S::W2 + k] * dsdf + dh2[t][r]) * softplus100_grad_from_h(h2[t][r]);
-                }
-
-            // ---- layer 2: dW1 += dz2^T h1 ; db1 += colsum(dz2) ; dh1 = W1^T dz2 -------------------
+            // ---- layer 2: dW1 += dz2^T h1 ; db1 += colsum(dz2) ; dz1 = (W1^T dz2) sigma'(z1) -------------
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -620,7 +738,7 @@ sdfmlp_bwd_kernel(const TileSrc src, const float *__restrict__ w0,
                     Td[(t * 32 + n_lo(r) + 4 * lh) * LDT + li] = dz2[t][r];
                     Ta[(t * 32 + n_lo(r) + 4 * lh) * LDT + li] = h1[t][r];
                 }
-            for (int rs = 0; rs < 32; rs += 2) {  // MFMA k = row
+            for (int rs = 0; rs < 32; rs += 2) {  // fp32 MFMA, k = row
                 float av[NT], bv[NT];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
@@ -645,29 +763,25 @@ sdfmlp_bwd_kernel(const TileSrc src, const float *__restrict__ w0,
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dz1[t][r] = 0.0f;
 #pragma unroll
-            for (int tk = 0; tk < NT; ++tk)
+            for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int k2 = tk * 32 + n_lo(r) + 4 * lh;
+                for (int ss = 0; ss < 2; ++ss) {
+                    const Frag3 zb = frag_of(dz2[kt], ss);
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        // A[i = k1][k = k2] = W1[k2][k1]
-                        const float a = smem[S::W1 + k2 * S::LDW1 + t * 32 + li];
-                        dz1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, dz2[tk][r], dz1[t], 0, 0, 0);
-                    }
+                    for (int t = 0; t < NT; ++t) dz1[t] = mma6r(w1t[t][kt][ss], zb, dz1[t]);
                 }
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dz1[t][r] *= softplus100_grad_from_h(h1[t][r]);
+                for (int r = 0; r < 16; ++r) dz1[t][r] *= softplus100_grad_fast(h1[t][r]);
 
-            // ---- layer 1: dW0 += dz1^T x ; db0 += colsum(dz1) ; dx = W0^T dz1 (column window) ------
+            // ---- layer 1: dW0 += dz1^T x ; db0 += colsum(dz1) ; dx = W0^T dz1 (hash-feature columns) ------
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) Td[(t * 32 + n_lo(r) + 4 * lh) * LDT + li] = dz1[t][r];
             for (int rs = 0; rs < 32; rs += 2) {
-                const float bx = Xs[(rs + lh) * LDX + li];  // B[k = row][j = input column li]
+                const float bx = Xs[(rs + lh) * LDXF + li];  // B[k = row][j = input column li]
 #pragma unroll
                 for (int a = 0; a < NT; ++a) {
                     const float av = Td[(a * 32 + li) * LDT + rs + lh];
@@ -675,33 +789,26 @@ sdfmlp_bwd_kernel(const TileSrc src, const float *__restrict__ w0,
                 }
             }
             if (lane < H) {
-                float acc = 0.0f, t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+                float acc = 0.0f, t0 = 0.f, t1 = 0.f, t2 = 0.f;
 #pragma unroll 8
                 for (int row = 0; row < 32; ++row) {
                     const float d = Td[lane * LDT + row];
                     acc += d;
-                    t0 = fmaf(d, Xs[row * LDX + 32], t0);
-                    t1 = fmaf(d, Xs[row * LDX + 33], t1);
-                    t2 = fmaf(d, Xs[row * LDX + 34], t2);
-                    t3 = fmaf(d, Xs[row * LDX + 35], t3);
+                    t0 = fmaf(d, Xs[row * LDXF + 32], t0);
+                    t1 = fmaf(d, Xs[row * LDXF + 33], t1);
+                    t2 = fmaf(d, Xs[row * LDXF + 34], t2);
                 }
                 gb0 += acc;
-                gw0_tail[0] += t0; gw0_tail[1] += t1; gw0_tail[2] += t2; gw0_tail[3] += t3;
+                gw0_tail[0] += t0; gw0_tail[1] += t1; gw0_tail[2] += t2;
             }
             if (d_planes != nullptr) {
                 f32x16 dx;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dx[r] = 0.0f;
 #pragma unroll
-                for (int tk = 0; tk < NT; ++tk)
+                for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int k1 = tk * 32 + n_lo(r) + 4 * lh;
-                        // A[i = c][k = k1] = W0[k1][k0w + c]   (c < kw, else the zero pad)
-                        const int col = k0w + li;
-                        const float a = (li < kw && col < K0P) ? smem[S::W0 + k1 * LDX + col] : 0.0f;
-                        dx = __builtin_amdgcn_mfma_f32_32x32x2f32(a, dz1[tk][r], dx, 0, 0, 0);
-                    }
+                    for (int ss = 0; ss < 2; ++ss) dx = mma6r(w0t[kt][ss], frag_of(dz1[kt], ss), dx);
                 // dx[c][row] -> Ta as [row][c] -> coalesced 128-byte row stores
 #pragma unroll
                 for (int r = 0; r < 16; ++r) Ta[li * LDT + n_lo(r) + 4 * lh] = dx[r];
@@ -731,13 +838,21 @@ sdfmlp_bwd_kernel(const TileSrc src, const float *__restrict__ w0,
             if (k < K0) atomicAdd(&dw0[n * K0 + k], gw0[a][r]);
         }
     }
-    if (lane < H) {
+    // dW2[0][f]: sum the per-lane partials over the 32 row slots (transpose through Ta)
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (32 + c < K0) atomicAdd(&dw0[lane * K0 + 32 + c], gw0_tail[c]);
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Ta[(t * 32 + n_lo(r) + 4 * lh) * LDT + li] = gw2p[t][r];
+    if (lane < H) {
+        float acc = 0.0f;
+#pragma unroll 8
+        for (int row = 0; row < 32; ++row) acc += Ta[lane * LDT + row];
+        atomicAdd(&dw2[lane], acc);  // row 0 of dW2 [N2, H]
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc)
+            if (32 + cc < K0) atomicAdd(&dw0[lane * K0 + 32 + cc], gw0_tail[cc]);
         atomicAdd(&db0[lane], gb0);
         atomicAdd(&db1[lane], gb1);
-        atomicAdd(&dw2[lane], gw2);  // row 0 of dW2 [N2, H]
     }
     gb2 = wave_sum(gb2);
     if (lane == 0) atomicAdd(&db2[0], gb2);
@@ -746,7 +861,10 @@ sdfmlp_bwd_kernel(const TileSrc src, const float *__restrict__ w0,
 template <int H>
 size_t fwd_lds() { return SmemS<H>::SHARED_BYTES + (size_t)FWD_WAVES * SmemS<H>::PER_WAVE_F * sizeof(float); }
 template <int H>
-size_t bwd_lds() { return (size_t)(Smem<H>::SHARED + WAVES * Smem<H>::PER_WAVE_BWD) * sizeof(float); }
+size_t bwd_lds(int steps2)
+{
+    return SmemSB<H>::shared_bytes(steps2) + (size_t)BWD_WAVES * SmemSB<H>::PER_WAVE_F * sizeof(float);
+}
 
 template <typename K>
 int set_lds(K kern, size_t bytes)
@@ -814,19 +932,21 @@ int rsdf_sdfmlp_fd7_bwd(const float *x7t, const float *planes, int n_levels, int
     if (n_samples <= 0) return 0;
     if (n_active_levels < 0 || n_active_levels > n_levels) n_active_levels = n_levels;
     hipStream_t st = (hipStream_t)stream;
-    const unsigned grid = persistent_grid(n_samples, WAVES);
+    const unsigned grid = persistent_grid(n_samples, BWD_WAVES);
     const TileSrc src{x7t, planes, n_samples, n_levels, n_active_levels, xyz_scale, xyz_offset};
+    // k-steps (of 16 output channels) of the feature-gradient product staged in LDS
+    const int steps2 = d_feature != nullptr ? (N2 + 15) / 16 : 0;
     int rc;
     if (H == 64) {
-        if ((rc = set_lds(sdfmlp_bwd_kernel<64>, bwd_lds<64>()))) return rc;
-        sdfmlp_bwd_kernel<64><<<grid, THREADS, bwd_lds<64>(), st>>>(src, w0, b0, w1, b1, w2, b2, N2,
-                                                                     d_sdf7t, d_feature, d_planes, dw0, db0,
-                                                                     dw1, db1, dw2, db2);
+        if ((rc = set_lds(sdfmlp_bwd_kernel<64>, bwd_lds<64>(steps2)))) return rc;
+        sdfmlp_bwd_kernel<64><<<grid, BWD_THREADS, bwd_lds<64>(steps2), st>>>(src, w0, b0, w1, b1, w2, b2, N2, steps2,
+                                                                               d_sdf7t, d_feature, d_planes, dw0,
+                                                                               db0, dw1, db1, dw2, db2);
     } else {
-        if ((rc = set_lds(sdfmlp_bwd_kernel<32>, bwd_lds<32>()))) return rc;
-        sdfmlp_bwd_kernel<32><<<grid, THREADS, bwd_lds<32>(), st>>>(src, w0, b0, w1, b1, w2, b2, N2,
-                                                                     d_sdf7t, d_feature, d_planes, dw0, db0,
-                                                                     dw1, db1, dw2, db2);
+        if ((rc = set_lds(sdfmlp_bwd_kernel<32>, bwd_lds<32>(steps2)))) return rc;
+        sdfmlp_bwd_kernel<32><<<grid, BWD_THREADS, bwd_lds<32>(steps2), st>>>(src, w0, b0, w1, b1, w2, b2, N2, steps2,
+                                                                               d_sdf7t, d_feature, d_planes, dw0,
+                                                                               db0, dw1, db1, dw2, db2);
     }
     RSDF_RETURN_LAUNCH();
 }
