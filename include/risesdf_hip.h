@@ -345,6 +345,26 @@ int rsdf_grid_sample2d_bwd2(const float *g2_input, const float *g2_grid, const f
                             int Wo, int padding_border, int align_corners, float *gg_out, float *g_input,
                             float *g_grid, void *stream);
 
+/* ---- N2: ray generation + pixel gather (systems/split_occ.py:58-131 train branch, models/ray_utils.py:32-56) ----
+ * index [n_index] (n_index = 1: one view for the batch, else n), y/x [n] int64 pixel coordinates;
+ * directions [H,W,3] (dirs_per_view = 0) or [V,H,W,3]; c2w [V,3,4]; images [V,H,W,channels]; fg_masks [V,H,W].
+ * rays [n,6] = (c2w[:,3], normalize(R d)); rgb [n,channels] (nullable) = image pixel, with apply_mask
+ * rgb*m + rgb_to_srgb(bg*(1-m)) (:113-116); fg_mask [n] (nullable). */
+int rsdf_gen_rays(const int64_t *index, int64_t n_index, const int64_t *y, const int64_t *x,
+                  const float *directions, int dirs_per_view, const float *c2w, const float *images, int channels,
+                  const float *fg_masks, const float *background_color, int apply_mask, int H, int W, int64_t n,
+                  float *rays, float *rgb, float *fg_mask, void *stream);
+
+/* ---- M2: occupancy-grid update (lib/nerfacc/grid.py:196-239; live call models/split_mixed_occ.py:126-131) ----
+ * rsdf_occ_cell_points: x[n,3] = (cell_coords(indices or 0..n-1) + jitter) / res * (roi_max - roi_min) + roi_min.
+ * rsdf_occ_update: occs[idx] = max(occs[idx]*ema_decay, occ_i) (duplicates: max of their candidates), then
+ * binary[c] = occs[c] > min(mean(occs), occ_thre).  occ >= 0.  scratch: rsdf_occ_update_scratch_bytes(n_cells). */
+int rsdf_occ_cell_points(const int64_t *indices /*nullable: all cells*/, const float *jitter, const float *roi,
+                         int res_x, int res_y, int res_z, int64_t n, float *x, void *stream);
+int64_t rsdf_occ_update_scratch_bytes(int64_t n_cells);
+int rsdf_occ_update(const int64_t *indices /*nullable*/, const float *occ, int64_t n, float ema_decay,
+                    float occ_thre, int64_t n_cells, float *occs, uint8_t *binary, void *scratch, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

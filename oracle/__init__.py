@@ -88,10 +88,12 @@ def get_ray_directions(W, H, fx, fy, cx, cy):
 
 
 def get_rays(directions: torch.Tensor, c2w: torch.Tensor):
-    """directions (H,W,3) or (N,3); c2w (3,4).  Returns flat (N,3) origins, directions."""
+    """models/ray_utils.py:32-56.  directions (H,W,3) or (N,3); c2w (3,4) or, with (N,3) directions, a per-ray
+    stack (N,3,4) / (1,3,4).  Returns flat (N,3) origins, directions."""
     d = directions.reshape(-1, 3)
-    rays_d = (d[:, None, :] * c2w[None, :3, :3]).sum(-1)
-    rays_o = c2w[None, :, 3].expand(rays_d.shape)
+    m = c2w if c2w.ndim == 3 else c2w[None]
+    rays_d = (d[:, None, :] * m[:, :3, :3]).sum(-1)
+    rays_o = m[:, :, 3].expand(rays_d.shape)
     return rays_o.contiguous(), rays_d.contiguous()
 
 

@@ -61,6 +61,10 @@ _SIGNATURES = {
     "rsdf_hashgrid_bwd_fd7_scratch_bytes": [ctypes.POINTER(GridMeta), _L, _I, _F],
     "rsdf_hashgrid_fwd_fd7": [_P, _P, ctypes.POINTER(GridMeta), _L, _I, _P, _P],
     "rsdf_hashgrid_bwd_fd7": [_P, _P, ctypes.POINTER(GridMeta), _L, _I, _F, _P, _P, _L, _P],
+    "rsdf_gen_rays": [_P, _L, _P, _P, _P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _L, _P, _P, _P, _P],
+    "rsdf_occ_cell_points": [_P, _P, _P, _I, _I, _I, _L, _P, _P],
+    "rsdf_occ_update_scratch_bytes": [_L],
+    "rsdf_occ_update": [_P, _P, _L, _F, _F, _L, _P, _P, _P, _P],
     "rsdf_hashgrid_dx": [_P, _P, ctypes.POINTER(GridMeta), _L, _I, _P, _I, _I, _P, _P],
     "rsdf_hashgrid_dx_bwd": [_P, _P, ctypes.POINTER(GridMeta), _L, _I, _P, _I, _I, _P, _P, _I, _I, _P, _P, _P],
     "rsdf_linear_fwd": [_P, _I, _P, _P, _L, _I, _I, _I, _P, _I, _P],
@@ -105,7 +109,8 @@ _SIGNATURES = {
 }
 _RESTYPES = {"rsdf_last_error": ctypes.c_char_p, "rsdf_scan_scratch_bytes": ctypes.c_int64,
              "rsdf_grid_meta_init": ctypes.c_int64,
-             "rsdf_hashgrid_bwd_fd7_scratch_bytes": ctypes.c_int64}
+             "rsdf_hashgrid_bwd_fd7_scratch_bytes": ctypes.c_int64,
+             "rsdf_occ_update_scratch_bytes": ctypes.c_int64}
 
 EXPORTS = tuple(_SIGNATURES)
 
@@ -165,7 +170,8 @@ class _TimedLib:
         fn = getattr(self._l, name)
         if not name.startswith("rsdf_") or name in ("rsdf_last_error", "rsdf_abi_version",
                                                    "rsdf_scan_scratch_bytes", "rsdf_grid_meta_init",
-                                                   "rsdf_hashgrid_bwd_fd7_scratch_bytes", "rsdf_sdfmlp_fd7_supported"):
+                                                   "rsdf_hashgrid_bwd_fd7_scratch_bytes", "rsdf_sdfmlp_fd7_supported",
+                                                   "rsdf_occ_update_scratch_bytes"):
             return fn
         timer = self._t
 

@@ -100,17 +100,14 @@ class OccupancyGrid(nn.Module):
         if indices is None:
             indices = self.grid_indices if step < warmup_steps else \
                 self._sample_uniform_and_occupied_cells(self.num_cells // 4)
-        coords = self.grid_coords[indices]
+        all_cells = indices is self.grid_indices
         if cell_jitter is None:
-            cell_jitter = torch.rand(coords.shape, dtype=torch.float32, device=coords.device)
-        x = (coords + cell_jitter) / self.resolution
-        # AABB inverse contraction: [0,1]^3 -> world (helpers_contraction.h:23-28)
-        roi = self._roi_aabb
-        x = x * (roi[3:] - roi[:3]) + roi[:3]
+            cell_jitter = torch.rand((indices.numel(), 3), dtype=torch.float32, device=self.occs.device)
+        # cell -> world point (AABB inverse contraction, helpers_contraction.h:23-28), EMA + threshold: HIP
+        x = ops.occ_cell_points(None if all_cells else indices, cell_jitter, self._roi_aabb, self.resolution.tolist())
         occ = occ_eval_fn(x).squeeze(-1)
-        self.occs[indices] = torch.maximum(self.occs[indices] * ema_decay, occ)
-        self._binary = (self.occs > torch.clamp(self.occs.mean(), max=occ_thre)).view(
-            self._binary.shape)
+        ops.occ_update(self.occs, self._binary.view(torch.uint8).view(-1), None if all_cells else indices, occ,
+                       ema_decay, occ_thre)
 
     @torch.no_grad()
     def every_n_step(self, step: int, occ_eval_fn: Callable, occ_thre: float = 1e-2,
@@ -261,16 +258,13 @@ class OccGridEstimator(nn.Module):
         if indices is None:
             indices = self.grid_indices if step < warmup_steps else \
                 self._sample_uniform_and_occupied_cells(self.cells_per_lvl // 4)
-        coords = self.grid_coords[indices]
+        all_cells = indices is self.grid_indices
         if cell_jitter is None:
-            cell_jitter = torch.rand(coords.shape, dtype=torch.float32, device=coords.device)
-        x = (coords + cell_jitter) / self.resolution
-        roi = self.aabbs[0]
-        x = x * (roi[3:] - roi[:3]) + roi[:3]
+            cell_jitter = torch.rand((indices.numel(), 3), dtype=torch.float32, device=self.occs.device)
+        x = ops.occ_cell_points(None if all_cells else indices, cell_jitter, self.aabbs[0], self.resolution.tolist())
         occ = occ_eval_fn(x).squeeze(-1)
-        self.occs[indices] = torch.maximum(self.occs[indices] * ema_decay, occ)
-        thre = torch.clamp(self.occs.mean(), max=occ_thre)
-        self.binaries = (self.occs > thre).view(self.binaries.shape)
+        ops.occ_update(self.occs, self.binaries.view(torch.uint8).view(-1), None if all_cells else indices, occ,
+                       ema_decay, occ_thre)
 
     @torch.no_grad()
     def update_every_n_steps(self, step: int, occ_eval_fn: Callable, occ_thre: float = 1e-2,

@@ -605,3 +605,54 @@ class _NeusAlpha(torch.autograd.Function):
 def neus_alpha(sdf, normal, dirs, dists, variance, cos_anneal_ratio=1.0):
     """get_alpha (models/split_mixed_occ.py:151-177) with the VarianceNetwork folded in."""
     return _NeusAlpha.apply(sdf, normal, dirs, dists, variance, cos_anneal_ratio)
+
+
+# ------------------------------------------------------------------------------------------------
+# M2 / N2
+# ------------------------------------------------------------------------------------------------
+@torch.no_grad()
+def occ_cell_points(indices, jitter, roi, resolution):
+    """lib/nerfacc/grid.py:213-222: world-space sample point of each listed cell (all cells when ``indices`` is
+    None): (coords + jitter) / res * (roi_max - roi_min) + roi_min."""
+    j, r = _f32c(jitter), _f32c(roi)
+    idx = None if indices is None else indices.to(torch.int64).contiguous()
+    require_device(j, r, idx)
+    n = j.shape[0]
+    x = torch.empty(n, 3, dtype=torch.float32, device=j.device)
+    rx, ry, rz = (int(v) for v in resolution)
+    check(lib().rsdf_occ_cell_points(ptr(idx), ptr(j), ptr(r), rx, ry, rz, n, ptr(x), stream_ptr()), "occ_cell_points")
+    return x
+
+
+@torch.no_grad()
+def occ_update(occs, binary_u8, indices, occ, ema_decay, occ_thre):
+    """lib/nerfacc/grid.py:229-238 in place: occs[idx] = max(occs[idx] * decay, occ); binary = occs > min(mean, thre)."""
+    o = _f32c(occ).reshape(-1)
+    idx = None if indices is None else indices.to(torch.int64).contiguous()
+    require_device(occs, binary_u8, o, idx)
+    assert occs.dtype == torch.float32 and occs.is_contiguous() and binary_u8.dtype == torch.uint8
+    n_cells = occs.numel()
+    scratch = torch.empty(int(lib().rsdf_occ_update_scratch_bytes(n_cells)), dtype=torch.uint8, device=occs.device)
+    check(lib().rsdf_occ_update(ptr(idx), ptr(o), o.numel(), float(ema_decay), float(occ_thre), n_cells, ptr(occs),
+                                ptr(binary_u8), ptr(scratch), stream_ptr()), "occ_update")
+
+
+@torch.no_grad()
+def gen_rays(index, y, x, directions, c2w, images=None, fg_masks=None, background_color=None, apply_mask=False):
+    """systems/split_occ.py:66-81,103,113-116: -> (rays [n,6], rgb [n,C] or None, fg_mask [n] or None)."""
+    idx, yy, xx = (t.to(torch.int64).contiguous() for t in (index, y, x))
+    d, m = _f32c(directions), _f32c(c2w)
+    img = None if images is None else _f32c(images)
+    msk = None if fg_masks is None else _f32c(fg_masks)
+    bg = None if background_color is None else _f32c(background_color)
+    require_device(idx, yy, xx, d, m, img, msk, bg)
+    n = yy.numel()
+    H, W = d.shape[-3], d.shape[-2]
+    rays = torch.empty(n, 6, dtype=torch.float32, device=d.device)
+    C = 0 if img is None else img.shape[-1]
+    rgb = None if img is None else torch.empty(n, C, dtype=torch.float32, device=d.device)
+    fg = None if msk is None else torch.empty(n, dtype=torch.float32, device=d.device)
+    check(lib().rsdf_gen_rays(ptr(idx), idx.numel(), ptr(yy), ptr(xx), ptr(d), int(d.dim() == 4), ptr(m), ptr(img), C,
+                              ptr(msk), ptr(bg), int(bool(apply_mask)), H, W, n, ptr(rays), ptr(rgb), ptr(fg),
+                              stream_ptr()), "gen_rays")
+    return rays, rgb, fg

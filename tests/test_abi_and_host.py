@@ -122,21 +122,3 @@ def test_progressive_schedule_and_eps_on_cpu():
         assert int(g.mask.sum()) == 2 * lvl or step < 6500
     eps16 = 2 * 1.5 / (32 * 1.447269237440378 ** 15)
     assert abs(eps16 - 3.0 / 8192) < 1e-9
-
-
-def test_occupancy_grid_ema_update_on_cpu():
-    """M2 (lib/nerfacc/grid.py:196-239) on CPU buffers vs the oracle's restatement."""
-    import oracle
-    from rise_sdf_amd.nerfacc import OccGridEstimator
-    est = OccGridEstimator(torch.tensor([-1.5, -1.5, -1.5, 1.5, 1.5, 1.5]), resolution=8)
-    g = torch.Generator().manual_seed(0)
-    idx = torch.randperm(512, generator=g)[:200]
-    jit = torch.rand(200, 3, generator=g)
-    occ_fn = lambda x: (1.0 - x.norm(dim=-1, keepdim=True) / 3.0).clamp(0, 1) * 0.02
-    est.occs.copy_(torch.rand(512, generator=g) * 0.01)
-    occs0 = est.occs.clone()
-    est._update(step=1000, occ_eval_fn=occ_fn, occ_thre=0.01, indices=idx, cell_jitter=jit)
-    coords = est.grid_coords[idx]
-    x = (coords + jit) / 8 * 3.0 - 1.5
-    occs_ref, bin_ref = oracle.occ_grid_update(occs0, idx, occ_fn(x).squeeze(-1), (8, 8, 8), occ_thre=0.01)
-    assert torch.allclose(est.occs, occs_ref) and torch.equal(est.binaries[0], bin_ref)
