@@ -365,6 +365,25 @@ int64_t rsdf_occ_update_scratch_bytes(int64_t n_cells);
 int rsdf_occ_update(const int64_t *indices /*nullable*/, const float *occ, int64_t n, float ema_decay,
                     float occ_thre, int64_t n_cells, float *occs, uint8_t *binary, void *scratch, void *stream);
 
+/* ---- N1: loss tail on the path's outputs (systems/split_occ.py:163-215; criterions.py:155-159) -------------
+ * rays_fwd: raw fp64 sums [7] (ACCUMULATES: zero first) = { sum d^2, sum |d| over valid rays x 3 channels of
+ *   comp_rgb - target; the same two for comp_rgb_phys (nullable); number of valid rays; sum of mask-BCE terms
+ *   (fg_mask nullable); sum of "opaque" BCE terms } with opacity clamped to [1e-3, 1-1e-3].
+ * rays_bwd: coef6 (device) = { mse, l1, phys mse, phys l1 weights each / (3 valid), mask / N, opaque / N }.
+ * samples_fwd: sums [3] = { sum (||grad|| - 1)^2, sum exp(-scale |sdf|), sum |laplace| (nullable) };
+ * samples_bwd: coef3 (device) = weights / S. */
+int rsdf_loss_rays_fwd(const float *comp_rgb, const float *comp_rgb_phys, const float *target,
+                       const uint8_t *rays_valid, const float *opacity, const float *fg_mask, int64_t n,
+                       double *sums7, void *stream);
+int rsdf_loss_rays_bwd(const float *comp_rgb, const float *comp_rgb_phys, const float *target,
+                       const uint8_t *rays_valid, const float *opacity, const float *fg_mask, const float *coef6,
+                       int64_t n, float *d_comp_rgb, float *d_comp_rgb_phys, float *d_opacity, void *stream);
+int rsdf_loss_samples_fwd(const float *sdf, const float *sdf_grad, const float *laplace, float sparsity_scale,
+                          int64_t n, double *sums3, void *stream);
+int rsdf_loss_samples_bwd(const float *sdf, const float *sdf_grad, const float *laplace, float sparsity_scale,
+                          const float *coef3, int64_t n, float *d_sdf, float *d_sdf_grad, float *d_laplace,
+                          void *stream);
+
 #ifdef __cplusplus
 }
 #endif

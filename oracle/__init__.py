@@ -500,3 +500,37 @@ def neus_geometry_render(rays, ray_indices, t_starts, t_ends, table, meta, mlp_p
     return {"opacity": opacity, "depth": depth, "comp_normal": comp_normal, "weights": weights,
             "trans": trans, "alphas": alphas, "sdf": sdf, "sdf_grad": grad, "feature": feature,
             "normal": normal}
+
+
+# --------------------------------------------------------------------------------------
+# N1: loss tail.  systems/split_occ.py:163-215, systems/criterions.py:155-159
+# --------------------------------------------------------------------------------------
+def binary_cross_entropy(inp, target):
+    return -(target * torch.log(inp) + (1 - target) * torch.log(1 - inp)).mean()
+
+
+def loss_tail(out, batch, lambdas, sparsity_scale=1.0, has_mask=True, stage=0):
+    """-> (loss, dict of unweighted terms), the reference's expressions one by one."""
+    lam = lambda k: float(lambdas.get("lambda_" + k, 0.0))
+    valid = out["rays_valid_full"][..., 0]
+    t = {}
+    t["rgb_mse"] = F.mse_loss(out["comp_rgb_full"][valid], batch["rgb"][valid])
+    t["rgb_l1"] = F.l1_loss(out["comp_rgb_full"][valid], batch["rgb"][valid])
+    loss = t["rgb_mse"] * lam("rgb_mse") + t["rgb_l1"] * lam("rgb_l1")
+    if stage != 0:
+        t["rgb_phys_mse"] = F.mse_loss(out["comp_rgb_phys_full"][valid], batch["rgb"][valid])
+        t["rgb_phys_l1"] = F.l1_loss(out["comp_rgb_phys_full"][valid], batch["rgb"][valid])
+        loss = loss + t["rgb_phys_mse"] * lam("rgb_phys_mse") + t["rgb_phys_l1"] * lam("rgb_phys_l1")
+    t["eikonal"] = ((torch.linalg.norm(out["sdf_grad_samples"], ord=2, dim=-1) - 1.0) ** 2).mean()
+    loss = loss + t["eikonal"] * lam("eikonal")
+    opacity = torch.clamp(out["opacity"].squeeze(-1), 1.0e-3, 1.0 - 1.0e-3)
+    t["mask"] = binary_cross_entropy(opacity, batch["fg_mask"].float())
+    loss = loss + t["mask"] * (lam("mask") if has_mask else 0.0)
+    t["opaque"] = binary_cross_entropy(opacity, opacity)
+    loss = loss + t["opaque"] * lam("opaque")
+    t["sparsity"] = torch.exp(-sparsity_scale * out["sdf_samples"].abs()).mean()
+    loss = loss + t["sparsity"] * lam("sparsity")
+    if lam("curvature") > 0:
+        t["curvature"] = out["sdf_laplace_samples"].abs().mean()
+        loss = loss + t["curvature"] * lam("curvature")
+    return loss, t

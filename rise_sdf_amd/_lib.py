@@ -61,6 +61,10 @@ _SIGNATURES = {
     "rsdf_hashgrid_bwd_fd7_scratch_bytes": [ctypes.POINTER(GridMeta), _L, _I, _F],
     "rsdf_hashgrid_fwd_fd7": [_P, _P, ctypes.POINTER(GridMeta), _L, _I, _P, _P],
     "rsdf_hashgrid_bwd_fd7": [_P, _P, ctypes.POINTER(GridMeta), _L, _I, _F, _P, _P, _L, _P],
+    "rsdf_loss_rays_fwd": [_P, _P, _P, _P, _P, _P, _L, _P, _P],
+    "rsdf_loss_rays_bwd": [_P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P],
+    "rsdf_loss_samples_fwd": [_P, _P, _P, _F, _L, _P, _P],
+    "rsdf_loss_samples_bwd": [_P, _P, _P, _F, _P, _L, _P, _P, _P, _P],
     "rsdf_gen_rays": [_P, _L, _P, _P, _P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _L, _P, _P, _P, _P],
     "rsdf_occ_cell_points": [_P, _P, _P, _I, _I, _I, _L, _P, _P],
     "rsdf_occ_update_scratch_bytes": [_L],
