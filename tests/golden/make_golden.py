@@ -448,6 +448,16 @@ def main():
     save("texture_stage1.npz", base=light.base, diffuse=light.diffuse, **mips, colors=col1, gcolors=gcol1,
          g_features=t1grads[0], g_normals=t1grads[1], g_base=t1grads[2], **t1g)
 
+    # ---- N3: state_dict layout of the reference modules (names, shapes) for checkpoint compatibility ----------
+    import json
+    from models import split_mixed_occ as rsmo
+    var = rsmo.VarianceNetwork(Cfg({"init_val": 0.3, "modulate": False}))
+    layout = {prefix: {k: list(v.shape) for k, v in mod.state_dict().items()}
+              for prefix, mod in (("geometry", vsdf), ("texture", tex1), ("variance", var), ("emitter", light))}
+    with open(os.path.join(HERE, "state_dict_layout.json"), "w") as f:
+        json.dump(layout, f, indent=0, sort_keys=True)
+    print("wrote state_dict_layout.json", {k: len(v) for k, v in layout.items()})
+
     # ---- frequency encoding, sRGB, progressive eps ----------------------------------------------
     vf = nu.VanillaFrequency(3, {"n_frequencies": 6})
     x = torch.randn(64, 3)

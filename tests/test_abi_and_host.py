@@ -122,3 +122,38 @@ def test_progressive_schedule_and_eps_on_cpu():
         assert int(g.mask.sum()) == 2 * lvl or step < 6500
     eps16 = 2 * 1.5 / (32 * 1.447269237440378 ** 15)
     assert abs(eps16 - 3.0 / 8192) < 1e-9
+
+
+def test_state_dict_layout_matches_reference(golden_dir):
+    """N3: parameter / buffer names and shapes of the mirrors equal the reference modules' state_dict layout
+    (tests/golden/state_dict_layout.json, written by make_golden.py from the reference classes), so reference
+    checkpoints load with load_state_dict and vice versa."""
+    import json
+    import os
+    import rise_sdf_amd as R
+    ref = json.load(open(os.path.join(golden_dir, "state_dict_layout.json")))
+    mlp = lambda n: {"otype": "VanillaMLP", "activation": "ReLU", "output_activation": "none", "n_neurons": 64,
+                     "n_hidden_layers": n}
+    geometry = R.make("volume-sdf", R.Config({
+        "name": "volume-sdf", "radius": 1.5, "feature_dim": 13, "grad_type": "finite_difference",
+        "finite_difference_eps": "progressive",
+        "xyz_encoding_config": {"otype": "ProgressiveBandHashGrid", "n_levels": 6, "n_features_per_level": 2,
+                                "log2_hashmap_size": 12, "base_resolution": 8, "per_level_scale": 1.5,
+                                "include_xyz": True, "start_level": 3, "start_step": 0, "update_steps": 100},
+        "mlp_network_config": {"otype": "VanillaMLP", "activation": "ReLU", "output_activation": "none",
+                               "n_neurons": 32, "n_hidden_layers": 2, "sphere_init": True,
+                               "sphere_init_radius": 0.5, "weight_norm": True}}))
+    texture = R.make("volume-mixed-mip-split-occ", R.Config({
+        "name": "volume-mixed-mip-split-occ", "input_feature_dim": 13, "other_dim": 3, "sample_size": 8,
+        "dir_encoding_config": {"otype": "SphericalHarmonics", "degree": 5, "reflected": True},
+        "metallic_mlp_network_config": mlp(2), "albedo_mlp_network_config": mlp(4),
+        "spec_mlp_network_config": mlp(4), "roughness_mlp_network_config": mlp(2),
+        "secondary_mlp_network_config": mlp(4),
+        "xyz_encoding_config": {"otype": "VanillaFrequency", "n_frequencies": 6}, "color_activation": "sigmoid"}))
+    from rise_sdf_amd.neus import VarianceNetwork
+    variance = VarianceNetwork(R.Config({"init_val": 0.3, "modulate": False}))
+    emitter = R.make("envlight-mip-cube", R.Config(
+        {"envlight_config": {"scale": 0.5, "bias": 0.25, "base_res": 64, "hdr_filepath": None}}))
+    for prefix, mod in (("geometry", geometry), ("texture", texture), ("variance", variance), ("emitter", emitter)):
+        mine = {k: list(v.shape) for k, v in mod.state_dict().items()}
+        assert mine == ref[prefix], (prefix, sorted(set(mine) ^ set(ref[prefix])))
