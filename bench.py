@@ -171,7 +171,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--chunk", type=int, default=8192, help="rays per forward/backward chunk")
+    ap.add_argument("--chunk", type=int, default=32768,
+                    help="rays per forward/backward chunk (~5 KB of HBM scratch per sample: 32768 rays = ~100 GB)")
     ap.add_argument("--width", type=int, default=800)
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--hidden", type=int, default=64)

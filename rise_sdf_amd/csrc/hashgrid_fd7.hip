@@ -38,6 +38,9 @@ constexpr int F_THREADS = 256;   // forward: samples per workgroup
 constexpr int P_THREADS = 1024;
 constexpr int ROUND_RECS = 8;
 constexpr int STAGE_CAP = P_THREADS * ROUND_RECS;
+#ifndef MERGE_MAX_RUNS
+#define MERGE_MAX_RUNS 40
+#endif
 constexpr int R_THREADS = 1024;  // reducer
 constexpr int R_UNROLL = 4;
 
@@ -346,11 +349,45 @@ fd7_produce_kernel(const float *__restrict__ x7t, const float2 *__restrict__ dpl
         }
     }
 
+    // Cross-sample merge at coarse levels: consecutive samples of a ray (= consecutive lanes) share their centre
+    // cell for ~cell/step samples (18 at level 0 of the 32..2048 grid, < 2 from level 6 up).  When a wavefront holds
+    // few distinct cells, sum each run of equal cells with a segmented wave scan and let only the run's last lane
+    // emit: up to 18x fewer records for that level's queue traffic and reducer work.
+    bool emit0 = active;
+    {
+        const int lane = lane_id();
+        const uint32_t kx = active ? c0.c[0] : 0xffffffffu, ky = active ? c0.c[1] : (uint32_t)lane, kz = c0.c[2];
+        const uint32_t px = __shfl_up(kx, 1, 64), py = __shfl_up(ky, 1, 64), pz = __shfl_up(kz, 1, 64);
+        int head = (lane == 0 || px != kx || py != ky || pz != kz) ? 1 : 0;
+        const int n_runs = __popcll(__ballot(head));
+        if (n_runs <= MERGE_MAX_RUNS) {  // wave-uniform
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                float2 u[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    u[c].x = __shfl_up(acc[c].x, o, 64);
+                    u[c].y = __shfl_up(acc[c].y, o, 64);
+                }
+                const int hu = __shfl_up(head, o, 64);
+                if (lane >= o && !head) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        acc[c].x += u[c].x;
+                        acc[c].y += u[c].y;
+                    }
+                    head = hu;
+                }
+            }
+            const uint32_t nx = __shfl_down(kx, 1, 64), ny = __shfl_down(ky, 1, 64), nz = __shfl_down(kz, 1, 64);
+            emit0 = active && (lane == 63 || nx != kx || ny != ky || nz != kz);
+        }
+    }
     uint32_t ridx[ROUND_RECS];
 #pragma unroll
     for (int c = 0; c < 8; ++c)
         ridx[c] = entry_index(c0.c[0] + (c & 1), c0.c[1] + ((c >> 1) & 1), c0.c[2] + ((c >> 2) & 1), g);
-    emit_round(ridx, acc, active ? 0xffu : 0u, n_bins, interleaved, cap, queue, qcount, dlevel, s_cnt,
+    emit_round(ridx, acc, emit0 ? 0xffu : 0u, n_bins, interleaved, cap, queue, qcount, dlevel, s_cnt,
                s_off, s_gbase, s_stage);
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
