@@ -240,7 +240,7 @@ def main():
         if timer is not None:
             roof, breakdown = roofline_from(timer.summary(), args.steps)
         cpu = None
-        if args.cpu_rays > 0:
+        if args.cpu_rays > 0 and world == 1:   # reported at N = 1 only
             cpu = cpu_baseline(model, rays_cpu, jitter_cpu, args.cpu_rays)
         line = {
             "metric": "ray-marched SDF samples/sec (fwd+bwd), 800x800 rays, L=16 hashgrid",
