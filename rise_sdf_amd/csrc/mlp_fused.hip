@@ -1,23 +1,20 @@
 // H3 fused: the whole SDF VanillaMLP (Linear -> Softplus(100) -> Linear -> Softplus(100) -> Linear,
 // models/network_utils.py:109-157 with n_hidden_layers = 2) in one kernel each way, for the
-// finite-difference stencil layout (rows 7i..7i+6 = centre + six taps of sample i).
+// finite-difference stencil layout (tap-major: x7t [7][S][3], hash features planes [L][7][S][2]).
 //
 // Why: run layer by layer (mlp.hip) the MLP moves ~5.5 KB of activations per evaluation through HBM
 // and is memory bound at ~10 % of the fp32 MFMA rate (r01b profile).  Here activations never leave
 // the CU:
 //   * every layer is computed TRANSPOSED, D[n][row] = sum_k W[n][k] * act[k][row], so a layer's
 //     accumulator registers (lane = row, register = output feature) are directly the next layer's
-//     MFMA B operand: v_mfma_f32_32x32x2_f32 may visit k in any order, and step r pairs the two k
-//     values register r holds in the two lane halves (n_lo(r) and n_lo(r)+4);
+//     MFMA B operand once packed to bf16 (see "Split-bf16 matrix products" below);
 //   * the backward recomputes the two hidden layers instead of reading them back, chains
 //     d(act) through the same register trick, and forms the weight gradients from LDS-transposed
 //     [feature][row] tiles with MFMA (sum over rows = the MFMA k dimension), accumulating them in
 //     registers across the workgroup's whole row loop and flushing once with atomics;
 //   * the taps only need output column 0 (the SDF), so their last layer is a 64-term dot product on
-//     the vector ALU instead of a 32-wide MFMA tile; the full feature row is produced for centre
-//     rows only.
-// fp32 throughout (exact fp32 FMA chains); summation order differs from a row-major GEMM, which is
-// within the 1e-5 relative tolerance of the parity tests.
+//     the vector ALU instead of a matrix tile; the full feature row is produced for centre rows only.
+// All results are fp32-equivalent (parity tests: 1e-5 relative); summation order differs from a row-major GEMM.
 #include "common.h"
 
 namespace {
@@ -28,76 +25,11 @@ constexpr int BWD_WAVES = 4;      // backward: one wave per SIMD (register-resid
 constexpr int BWD_THREADS = BWD_WAVES * 64;
 constexpr int FWD_WAVES = 8;      // forward: 8 waves = two per SIMD
 constexpr int FWD_THREADS = FWD_WAVES * 64;
-constexpr int K0P = 36;       // padded input width (3 + 2*16 = 35 -> 36)
-constexpr int LDX = K0P + 1;  // 37: odd LDS row stride
 constexpr int LDT = 33;       // [feature][row] transposed tiles
 
 __device__ __forceinline__ int n_lo(int r) { return (r & 3) + 8 * (r >> 2); }
 
-// Softplus(beta=100, threshold=20) and its derivative sigmoid(100 z) expressed through y
-__device__ __forceinline__ float softplus100(float z)
-{
-    const float t = 100.0f * z;
-    // max(z,0) + log1p(exp(-|t|))/100 : same value as torch's thresholded form to < 1e-9 absolute
-    const float e = __expf(-fabsf(t));
-    return fmaxf(z, 0.0f) + __logf(1.0f + e) * 0.01f;
-}
-// h = log(1 + e^{100 z}) / 100  =>  sigmoid(100 z) = 1 - e^{-100 h}: the backward needs only h
-__device__ __forceinline__ float softplus100_grad_from_h(float h)
-{
-    return 1.0f - __expf(-100.0f * h);
-}
-
-template <int H>
-struct Smem {
-    static constexpr int NT = H / 32;
-    static constexpr int LDW1 = H + 1;
-    // weights (shared by the workgroup)
-    static constexpr int W0 = 0;                         // [H][LDX]
-    static constexpr int W1 = W0 + H * LDX;              // [H][LDW1]
-    static constexpr int W2 = W1 + H * LDW1;             // [64][LDW1]  (N2 <= 64 rows)
-    static constexpr int B0 = W2 + 64 * LDW1;            // [H]
-    static constexpr int B1 = B0 + H;                    // [H]
-    static constexpr int B2 = B1 + H;                    // [64]
-    static constexpr int SHARED = B2 + 64;
-    // per wave
-    static constexpr int XS = 0;                         // [32][LDX]
-    static constexpr int TA = XS + 32 * LDX;             // [H][LDT]
-    static constexpr int TD = TA + H * LDT;              // [H][LDT]
-    static constexpr int PER_WAVE_FWD = 32 * 65;             // X tile [32][LDX], overlaid by the feature transpose [32][65]
-    static constexpr int PER_WAVE_BWD = TD + H * LDT;
-};
-
-template <int H>
-__device__ __forceinline__ void stage_all_weights(float *sm, const float *__restrict__ w0,
-                                                  const float *__restrict__ b0,
-                                                  const float *__restrict__ w1,
-                                                  const float *__restrict__ b1,
-                                                  const float *__restrict__ w2,
-                                                  const float *__restrict__ b2, int K0, int N2)
-{
-    using S = Smem<H>;
-    const int NTHR = blockDim.x;
-    for (int e = threadIdx.x; e < H * K0P; e += NTHR) {
-        const int r = e / K0P, c = e - r * K0P;
-        sm[S::W0 + r * LDX + c] = c < K0 ? w0[r * K0 + c] : 0.0f;
-    }
-    for (int e = threadIdx.x; e < H * H; e += NTHR) {
-        const int r = e / H, c = e - r * H;
-        sm[S::W1 + r * S::LDW1 + c] = w1[e];
-    }
-    for (int e = threadIdx.x; e < 64 * H; e += NTHR) {
-        const int r = e / H, c = e - r * H;
-        sm[S::W2 + r * S::LDW1 + c] = r < N2 ? w2[r * H + c] : 0.0f;
-    }
-    for (int e = threadIdx.x; e < H; e += NTHR) {
-        sm[S::B0 + e] = b0[e];
-        sm[S::B1 + e] = b1[e];
-    }
-    for (int e = threadIdx.x; e < 64; e += NTHR) sm[S::B2 + e] = e < N2 ? b2[e] : 0.0f;
-}
-
-// Input tile of one (32-sample group, tap): [32 rows][K0P] = [xyz*scale+offset | L*2 hash features | 0]
+// Input tile of one (32-sample group, tap): [32 rows][36] = [xyz*scale+offset | L*2 hash features | 1 (bias column)]
 // read from the tap-major SoA buffers (x7t [7][S][3], planes [L][7][S][2]) with full-line loads:
 // per level the 32 samples' float2 are 256 contiguous bytes.  The tile is first fetched into 18
 // registers per lane (so the loads of tile i+1 fly while tile i is computed), then written to LDS.
@@ -123,60 +55,6 @@ __device__ __forceinline__ void fetch_tile(float (&pre)[18], const TileSrc &src,
     const float *xb = src.x7t + ((int64_t)tap * src.S + s0) * 3;
     pre[16] = (s0 + lane / 3 < src.S) ? xb[lane] : 0.5f;
     pre[17] = (lane < 32 && s0 + (lane + 64) / 3 < src.S) ? xb[lane + 64] : 0.5f;
-}
-
-__device__ __forceinline__ void store_tile(float *Xs, const float (&pre)[18], const TileSrc &src, int lane)
-{
-    const int r = lane >> 1, f = lane & 1;
-#pragma unroll
-    for (int l = 0; l < 16; ++l) Xs[r * LDX + 3 + 2 * l + f] = pre[l];
-    Xs[(lane / 3) * LDX + lane % 3] = pre[16] * src.xyz_scale + src.xyz_offset;
-    if (lane < 32) Xs[((lane + 64) / 3) * LDX + (lane + 64) % 3] = pre[17] * src.xyz_scale + src.xyz_offset;
-    if (lane < 32) Xs[lane * LDX + 35] = 0.0f;
-}
-
-// hidden layers 1 and 2, transposed: h[t][r] holds feature t*32 + n_lo(r) + 4*lh of row (lane & 31)
-template <int H>
-__device__ __forceinline__ void hidden_forward(const float *sm, const float *Xs, int li, int lh,
-                                               f32x16 (&h1)[H / 32], f32x16 (&h2)[H / 32])
-{
-    using S = Smem<H>;
-    constexpr int NT = H / 32;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) h1[t][r] = sm[S::B0 + t * 32 + n_lo(r) + 4 * lh];
-    for (int k0 = 0; k0 < K0P; k0 += 2) {
-        const float b = Xs[li * LDX + k0 + lh];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const float a = sm[S::W0 + (t * 32 + li) * LDX + k0 + lh];
-            h1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, h1[t], 0, 0, 0);
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) h1[t][r] = softplus100(h1[t][r]);
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) h2[t][r] = sm[S::B1 + t * 32 + n_lo(r) + 4 * lh];
-#pragma unroll
-    for (int tk = 0; tk < NT; ++tk)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int k = tk * 32 + n_lo(r) + 4 * lh;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const float a = sm[S::W1 + (t * 32 + li) * S::LDW1 + k];
-                h2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, h1[tk][r], h2[t], 0, 0, 0);
-            }
-        }
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) h2[t][r] = softplus100(h2[t][r]);
 }
 
 // ------------------------------------------------------------------------------------------------
