@@ -130,3 +130,21 @@ def texture_stage1(features, dirs, normals, positions, nets, fg_lut, eval_diffus
     spec_ref = spec_albedo * fg[:, 0:1] + fg[:, 1:2]
     return torch.cat([diff_rgb, spec_rgb, blend, diff_pbr, spec_ref * spec_light, spec_ref, spec_light, albedo,
                       metallic, roughness], -1)
+
+
+def secondary_shading_pbr(features, dirs, normals, positions, nets, fg_lut, eval_diffuse, eval_specular,
+                          n_frequencies=6):
+    """models/texture.py:386-427 -> [S,3]: split-sum shading with the specular lobe looked up along ``dirs``."""
+    from . import gridsample as ogs
+    _, nov = reflect_dirs(dirs, normals)
+    inp = torch.cat([features, vanilla_frequency(positions, n_frequencies)], -1)
+    albedo = torch.sigmoid(relu_mlp(inp, nets["albedo"]))[..., 3:]
+    roughness = torch.sigmoid(relu_mlp(inp, nets["roughness"]))
+    metallic = torch.sigmoid(relu_mlp(inp, nets["metallic"]))[..., 1:]
+    diff = (1 - metallic) * albedo * eval_diffuse(normals)
+    spec_albedo = 0.04 * (1 - metallic) + metallic * albedo
+    spec_light = eval_specular(dirs, roughness)
+    uv = torch.cat([nov.clamp(0.0, 1.0), roughness.clamp(0.0, 1.0)], -1)
+    grid = (uv * 2.0 - 1.0).reshape(1, -1, 1, 2)
+    fg = ogs.grid_sample_2d(fg_lut.permute(0, 3, 1, 2).to(uv.dtype), grid, "border", False)[0, :, :, 0].t()
+    return diff + (spec_albedo * fg[:, 0:1] + fg[:, 1:2]) * spec_light

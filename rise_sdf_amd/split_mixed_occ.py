@@ -7,7 +7,7 @@ normal-orientation map (:383-401), background compose + sRGB (O1, :404-443).
 Stage 1 (``split_sum_kick_in_step``): split-sum shading against the prefiltered environment light
 (S1-S4, E1; 24 composited channels, :295-303, 344-352, 416-432).
 Curvature samples (H5, ``sdf_laplace_samples``) through geometry.curvature.
-Not yet: relighting third bounce (:322-331, evaluation only).
+Relighting (:322-331): third-bounce shading of smooth pixels against a swapped environment (``relight``).
 """
 from __future__ import annotations
 
@@ -112,8 +112,6 @@ class SplitMixedOCCModel(BaseModel):
 
     # ---- one ray batch (:224-443) ------------------------------------------------------------------------------
     def forward_(self, rays, relighting=False, stratified_u=None, curvature_dirs=None):
-        if relighting:
-            raise NotImplementedError("relighting third bounce (models/split_mixed_occ.py:322-331) is evaluation-only")
         if self.stage != 0 and self.emitter is None:
             raise RuntimeError("stage 1 needs model.light (envlight-mip-cube)")
         n_rays = rays.shape[0]
@@ -149,6 +147,7 @@ class SplitMixedOCCModel(BaseModel):
         diff_rgb_map, spec_rgb_map, blend_map = rgb_map[..., :3], rgb_map[..., 3:6], rgb_map[..., 6:7]
         if self.stage != 0:
             diff_rgb_pbr_map, spec_rgb_pbr_map = rgb_map[..., 7:10], rgb_map[..., 10:13]
+            spec_ref_map, spec_light_map = rgb_map[..., 13:16], rgb_map[..., 16:19]
             albedo_map, metallic_map, roughness_map = rgb_map[..., 19:22], rgb_map[..., 22:23], rgb_map[..., 23:]
         valid_indices = torch.nonzero(acc_map > 0.5)[..., 0]
         if valid_indices.numel() > 0 and self.config.get("indirect_pred", False):
@@ -156,15 +155,29 @@ class SplitMixedOCCModel(BaseModel):
             wo = -rays_d[valid_indices]
             nv = normal_map[valid_indices]
             sec_d = 2 * torch.sum(wo * nv, dim=-1, keepdim=True) * nv - wo
-            tr, _sec_depth = self.compute_indirect_radiance(sec_o.detach().contiguous(), sec_d.detach().contiguous())
-            tr = tr.clamp(0, 1).detach()
+            tr, sec_depth = self.compute_indirect_radiance(sec_o.detach().contiguous(), sec_d.detach().contiguous())
+            tr, sec_depth = tr.clamp(0, 1).detach(), sec_depth.detach()
             sec_feature = self.geometry(sec_o, with_grad=False, with_feature=True)[1]
             sec_rgb = self.texture.secondary_shading(sec_feature, sec_d, nv)
             spec_rgb_map = spec_rgb_map.clone()
             spec_rgb_map[valid_indices] = tr * spec_rgb_map[valid_indices] + (1 - tr) * sec_rgb
-            if self.stage != 0:
+            if self.stage != 0 and not relighting:
                 spec_rgb_pbr_map = spec_rgb_pbr_map.clone()
                 spec_rgb_pbr_map[valid_indices] = tr * spec_rgb_pbr_map[valid_indices] + (1 - tr) * sec_rgb
+            elif self.stage != 0:
+                # relighting (:322-331): the learned secondary radiance belongs to the training light, so smooth
+                # pixels shade the point their reflection hits with the NEW environment (third bounce)
+                rmask = (roughness_map[valid_indices] <= self.config.relighting_threshold)[..., 0]
+                third_o = sec_o[rmask] + sec_depth[rmask] * sec_d[rmask]
+                _, third_grad, third_feature = self.geometry(third_o, with_grad=True, with_feature=True)
+                third_normal = F.normalize(third_grad, p=2, dim=-1, eps=1e-6)
+                third_rgb = self.texture.secondary_shading_pbr(third_feature, sec_d[rmask], third_normal, third_o,
+                                                               self.emitter)
+                light_valid = spec_light_map[valid_indices]
+                light_valid[rmask] = tr[rmask] * light_valid[rmask] + (1 - tr[rmask]) * third_rgb
+                spec_light_map = spec_light_map.clone()
+                spec_light_map[valid_indices] = light_valid
+                spec_rgb_pbr_map = spec_ref_map * spec_light_map
         rgb = diff_rgb_map + spec_rgb_map
 
         out = {"comp_rgb": rgb, "comp_diffuse_rgb": diff_rgb_map, "comp_spec_rgb": spec_rgb_map,
@@ -220,6 +233,28 @@ class SplitMixedOCCModel(BaseModel):
         losses.update(self.geometry.regularizations(out))
         losses.update(self.texture.regularizations(out))
         return losses
+
+
+@torch.no_grad()
+def relight(model, rays, emitter, reference=None, fg_mask=None):
+    """systems/split_occ.py:405-420: render ``rays`` under another environment light.  The emitter is swapped, its
+    mips rebuilt once, the model evaluated with ``relighting=True``, and (when a reference image is given) the
+    prediction rescaled per channel by the median ratio over the foreground, as the reference's test step does.
+    Everything stays on the device."""
+    old = model.emitter
+    model.emitter = emitter
+    try:
+        emitter.build_mips()
+        out = model(rays, relighting=True)
+    finally:
+        model.emitter = old
+    pred = out["comp_rgb_phys_full"]
+    if reference is not None:
+        m = fg_mask.bool() if fg_mask is not None else torch.ones(pred.shape[0], dtype=torch.bool, device=pred.device)
+        ratio, _ = (reference[m] / pred[m].clamp(min=1e-6)).median(dim=0)
+        pred = pred.clone()
+        pred[m] = (ratio * pred[m]).clamp(min=0.0, max=1.0)
+    return pred, out
 
 
 def _registry():

@@ -125,6 +125,26 @@ class VolumeMixedMipSplitOcc(nn.Module):
                         + [a.reshape(-1, a.shape[-1]) for a in args], dim=-1)
         return torch.sigmoid(self.secondary_network(inp))
 
+    def secondary_shading_pbr(self, features, dirs, normals, positions, emitter):
+        """models/texture.py:386-427: split-sum shading of the third-bounce point seen along ``dirs`` (relighting).
+        The specular lobe is looked up along ``dirs`` itself (:417), not along the reflection."""
+        if dirs.shape[0] == 0:
+            return torch.zeros((0, 3), device=dirs.device)
+        from .gridsample import fg_lut_lookup
+        feats = features.reshape(-1, features.shape[-1])
+        _wo01, nov = T.reflect(dirs, normals)
+        inp = torch.cat([feats, self.xyz_encoding(positions.reshape(-1, self.n_pos_dims))], dim=-1)
+        albedo6 = self.albedo_network(inp, out_act="sigmoid")
+        roughness = self.roughness_network(inp, out_act="sigmoid")
+        metallic2 = self.metallic_network(inp, out_act="sigmoid")
+        diffuse_light = emitter.eval_mip(normals)
+        specular_light = emitter.eval_mip(dirs, specular=True, roughness=roughness)
+        fg_uv = torch.cat([torch.clamp(nov, min=0.0, max=1.0), torch.clamp(roughness, min=0.0, max=1.0)], -1)
+        fg = fg_lut_lookup(self.FG_LUT, fg_uv)
+        shaded = T.split_shade1(albedo6, roughness, metallic2, torch.zeros_like(diffuse_light), diffuse_light,
+                                specular_light, fg)
+        return shaded[:, 7:10] + shaded[:, 10:13]
+
     def update_step(self, epoch, global_step):
         update_module_step(self.dir_encoding, epoch, global_step)
         update_module_step(self.xyz_encoding, epoch, global_step)

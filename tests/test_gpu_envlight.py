@@ -161,3 +161,28 @@ def test_stage1_reference_fixture(dev, golden_dir):
         ref = z["g__" + name.replace(".", "_")]
         got = torch.zeros_like(ref) if p.grad is None else p.grad.cpu()
         assert float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-7, name
+
+
+def test_secondary_shading_pbr_matches_oracle(dev, golden_dir):
+    """Third-bounce shading used by relighting (models/texture.py:386-427) vs the oracle, on the fixture's weights."""
+    import rise_sdf_amd as R
+    from oracle import texture as otex
+    from test_oracle_texture import nets_from
+    z0 = {k: torch.tensor(v) for k, v in np.load(os.path.join(golden_dir, "texture_stage0.npz")).items()}
+    z = {k: torch.tensor(v) for k, v in np.load(os.path.join(golden_dir, "texture_stage1.npz")).items()}
+    light = R.make("envlight-mip-cube", R.Config(
+        {"envlight_config": {"scale": 0.5, "bias": 0.25, "base_res": 64, "hdr_filepath": None}})).to(dev)
+    with torch.no_grad():
+        light.base.copy_(z["base"])
+        light.build_mips()
+    tex = _stage1_texture(dev, z0)
+    with torch.no_grad():
+        got = tex.secondary_shading_pbr(z0["features"].to(dev), z0["dirs"].to(dev), z0["normals"].to(dev),
+                                        z0["positions"].to(dev), light)
+    spec = [z["spec%d" % i].double() for i in range(3)]
+    ref = otex.secondary_shading_pbr(
+        z0["features"].double(), z0["dirs"].double(), z0["normals"].double(), z0["positions"].double(),
+        nets_from({k: v.double() for k, v in z0.items()}), otex.synthetic_fg_lut().double(),
+        lambda n: E.cube_sample_linear(z["diffuse"].double(), n),
+        lambda d, r: E.cube_sample_mip(spec, d, E.get_mip(r, 3)[:, 0]))
+    assert torch.allclose(got.cpu().double(), ref, rtol=2e-4, atol=1e-5)

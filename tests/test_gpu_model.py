@@ -381,3 +381,44 @@ def test_split_mixed_occ_stage1_runs_and_is_consistent(dev):
     out1["comp_rgb_phys_full"].sum().backward()
     assert model.emitter.base.grad is not None and float(model.emitter.base.grad.abs().max()) > 0
     assert model.geometry.encoding.encoding.encoding.params.grad is not None
+
+
+def test_relight_runs_with_third_bounce(dev):
+    """N4: evaluation render under a swapped environment (systems/split_occ.py:405-420, model :320-331)."""
+    import rise_sdf_amd as R
+    from rise_sdf_amd.split_mixed_occ import relight
+    torch.manual_seed(0)
+    cfg = split_config(indirect=True)
+    cfg["split_sum_kick_in_step"] = 0
+    cfg["relighting_threshold"] = 0.6
+    cfg["ray_chunk"] = 100
+    light_cfg = {"name": "envlight-mip-cube",
+                 "envlight_config": {"scale": 0.5, "bias": 0.25, "base_res": 64, "hdr_filepath": None}}
+    cfg["light"] = light_cfg
+    model = R.make("split-mixed-occ", cfg).to(dev)
+    with torch.no_grad():
+        model.variance.variance.fill_(0.6)
+    model.occupancy_grid.binaries = sphere_binary(128, 0.2, 0.9).to(dev)[None]
+    model.train()
+    model.grid_prune = False
+    model.update_step(0, 0)
+    assert model.stage == 1
+    model.eval()
+    model.background_color = torch.ones(3, device=dev)
+    rays = camera_rays(16, 16, seed=2).to(dev)
+    with torch.no_grad():
+        model.emitter.build_mips()
+        base = model(rays)
+    new_light = R.make("envlight-mip-cube", R.Config(light_cfg)).to(dev)
+    with torch.no_grad():
+        new_light.base.mul_(3.0)
+    ref_img = torch.rand(rays.shape[0], 3, device=dev)
+    mask = base["opacity"][:, 0] > 0.5
+    assert int(mask.sum()) > 4
+    pred, out = relight(model, rays, new_light, reference=ref_img, fg_mask=mask)
+    assert model.emitter is not new_light                       # restored
+    assert pred.shape == (rays.shape[0], 3) and bool(torch.isfinite(pred).all())
+    assert float((out["comp_rgb_phys_full"] - base["comp_rgb_phys_full"]).abs().max()) > 1e-3   # new light shows
+    ratio, _ = (ref_img[mask] / out["comp_rgb_phys_full"][mask].clamp(min=1e-6)).median(dim=0)
+    assert torch.allclose(pred[mask], (ratio * out["comp_rgb_phys_full"][mask]).clamp(0, 1))
+    assert torch.equal(pred[~mask], out["comp_rgb_phys_full"][~mask])
