@@ -505,10 +505,13 @@ class _FDGradient(torch.autograd.Function):
         check(lib().rsdf_fd_gradient_fwd(ptr(o7), o7.shape[1], float(eps), n, ptr(sdf), ptr(grad),
                                          stream_ptr()), "fd_gradient_fwd")
         ctx.eps, ctx.shape = float(eps), o7.shape
+        ctx.set_materialize_grads(False)
         return sdf, grad
 
     @staticmethod
     def backward(ctx, g_sdf, g_grad):
+        if g_sdf is None and g_grad is None:
+            return None, None
         d = torch.zeros(ctx.shape, dtype=torch.float32, device=(g_sdf if g_sdf is not None else g_grad).device)
         gs = None if g_sdf is None else _f32c(g_sdf)
         gg = None if g_grad is None else _f32c(g_grad)
@@ -550,10 +553,13 @@ class _NeusAlphaFD(torch.autograd.Function):
               "neus_alpha_fd_fwd")
         ctx.save_for_backward(o7, var, d, ri, ts, te)
         ctx.car, ctx.eps, ctx.vshape = float(cos_anneal_ratio), float(eps), variance.shape
+        ctx.set_materialize_grads(False)   # unused outputs arrive as None instead of [S]-sized zero fills
         return sdf, grad, normal, alpha
 
     @staticmethod
     def backward(ctx, g_sdf, g_grad, g_normal, g_alpha):
+        if g_sdf is None and g_grad is None and g_normal is None and g_alpha is None:
+            return (None,) * 9
         o7, var, d, ri, ts, te = ctx.saved_tensors
         n = ri.numel()
         ld = ctx.ld
