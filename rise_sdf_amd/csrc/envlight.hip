@@ -288,60 +288,92 @@ cube_sample_fwd_kernel(MipStack m, const float *__restrict__ dirs, const float *
     for (int c = 0; c < m.C; ++c) out[i * m.C + c] = acc[c];
 }
 
-// d_out -> d_tex (atomics), d_dirs, d_level
-__global__ void __launch_bounds__(THREADS)
-cube_sample_bwd_kernel(MipStack m, const float *__restrict__ dirs, const float *__restrict__ level, int64_t n,
-                       const float *__restrict__ dout, float *__restrict__ d_dirs, float *__restrict__ d_level)
+// d_out -> d_tex, d_dirs, d_level.
+// Texture gradients: every sample adds to 4 texels x C channels of one or two levels.  The small levels (the 16^2
+// diffuse map, the coarse specular mips) receive ALL samples on a few thousand texels: global float atomics on
+// them serialise at the memory side (measured 1.9 s for 7e7 samples).  Levels of at most LDS_LEVEL_FLOATS floats
+// are therefore accumulated in an LDS copy per workgroup (ds_add_f32) and flushed once; only the large levels,
+// where collisions are rare, use global atomics directly.
+constexpr int BWD_THREADS = 1024;
+constexpr int LDS_BUDGET_FLOATS = 24 * 1024;   // 96 KiB: 6*32^2*3 + 6*16^2*3 = 23040 floats
+
+struct LdsPlan {
+    int off[8];   // float offset of the level's LDS copy, -1 = global atomics
+    int total;
+};
+
+__global__ void __launch_bounds__(BWD_THREADS)
+cube_sample_bwd_kernel(MipStack m, LdsPlan plan, const float *__restrict__ dirs, const float *__restrict__ level,
+                       int64_t n, const float *__restrict__ dout, float *__restrict__ d_dirs,
+                       float *__restrict__ d_level)
 {
-    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
-    if (i >= n) return;
-    const float dx = dirs[3 * i], dy = dirs[3 * i + 1], dz = dirs[3 * i + 2];
-    const FaceUV f = dir_to_face(dx, dy, dz);
-    const float lraw = level ? level[i] : 0.0f;
-    const float lv = fminf(fmaxf(lraw, 0.0f), (float)(m.n - 1));
-    const int l0 = min((int)floorf(lv), m.n - 1), l1 = min(l0 + 1, m.n - 1);
-    const float t = lv - (float)l0;
-    float g[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int c = 0; c < m.C; ++c) g[c] = dout[i * m.C + c];
-    float dfx = 0.f, dfy = 0.f, s0 = 0.f, s1 = 0.f;  // d/d(face coords), <g, sample(l0)>, <g, sample(l1)>
+    extern __shared__ float s_grad[];
+    for (int e = threadIdx.x; e < plan.total; e += BWD_THREADS) s_grad[e] = 0.0f;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * BWD_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * BWD_THREADS) {
+        const float dx = dirs[3 * i], dy = dirs[3 * i + 1], dz = dirs[3 * i + 2];
+        const FaceUV f = dir_to_face(dx, dy, dz);
+        const float lraw = level ? level[i] : 0.0f;
+        const float lv = fminf(fmaxf(lraw, 0.0f), (float)(m.n - 1));
+        const int l0 = min((int)floorf(lv), m.n - 1), l1 = min(l0 + 1, m.n - 1);
+        const float t = lv - (float)l0;
+        float g[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < m.C; ++c) g[c] = dout[i * m.C + c];
+        float dfx = 0.f, dfy = 0.f, s0 = 0.f, s1 = 0.f;  // d/d(face coords), <g, sample(l0)>, <g, sample(l1)>
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        const int l = pass == 0 ? l0 : l1;
-        const float wl = pass == 0 ? 1.0f - t : t;
-        if (pass == 1 && l1 == l0) break;
-        const int R = m.R0 >> l;
-        const Bilin b = bilin_setup(f, R);
-        float sv = 0.f;
+        for (int pass = 0; pass < 2; ++pass) {
+            const int l = pass == 0 ? l0 : l1;
+            const float wl = pass == 0 ? 1.0f - t : t;
+            if (pass == 1 && l1 == l0) break;
+            const int R = m.R0 >> l;
+            const Bilin b = bilin_setup(f, R);
+            float sv = 0.f;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float *p = m.tex[l] + (size_t)b.off[k] * m.C;
-            float gp = 0.f;
-            for (int c = 0; c < m.C; ++c) gp += g[c] * p[c];
-            sv += b.w[k] * gp;
-            // pixel coords px = (fx + 1) R/2 - 1/2  =>  d px / d fx = R/2
-            dfx += wl * b.dwx[k] * gp * 0.5f * (float)R;
-            dfy += wl * b.dwy[k] * gp * 0.5f * (float)R;
-            if (m.grad[l] && wl != 0.0f) {
-                float *q = m.grad[l] + (size_t)b.off[k] * m.C;
-                for (int c = 0; c < m.C; ++c) atomicAdd(q + c, wl * b.w[k] * g[c]);
+            for (int k = 0; k < 4; ++k) {
+                const float *p = m.tex[l] + (size_t)b.off[k] * m.C;
+                float gp = 0.f;
+                for (int c = 0; c < m.C; ++c) gp += g[c] * p[c];
+                sv += b.w[k] * gp;
+                // pixel coords px = (fx + 1) R/2 - 1/2  =>  d px / d fx = R/2
+                dfx += wl * b.dwx[k] * gp * 0.5f * (float)R;
+                dfy += wl * b.dwy[k] * gp * 0.5f * (float)R;
+                if (m.grad[l] && wl != 0.0f) {
+                    if (plan.off[l] >= 0) {
+                        float *q = s_grad + plan.off[l] + b.off[k] * m.C;
+                        for (int c = 0; c < m.C; ++c) atomicAdd(q + c, wl * b.w[k] * g[c]);
+                    } else {
+                        float *q = m.grad[l] + (size_t)b.off[k] * m.C;
+                        for (int c = 0; c < m.C; ++c) atomicAdd(q + c, wl * b.w[k] * g[c]);
+                    }
+                }
             }
+            if (pass == 0) s0 = sv; else s1 = sv;
         }
-        if (pass == 0) s0 = sv; else s1 = sv;
+        if (d_level) d_level[i] = (level && lraw > 0.0f && lraw < (float)(m.n - 1) && l1 != l0) ? (s1 - s0) : 0.0f;
+        if (d_dirs) {
+            // fx = sx * comp_u / ma, fy = sy * comp_v / ma with ma = |major component|
+            float gx = 0.f, gy = 0.f, gz = 0.f;
+            const float ima = 1.0f / f.ma;
+            switch (f.face) {
+            case 0: gz = -dfx * ima; gy = -dfy * ima; gx = -(f.fx * dfx + f.fy * dfy) * ima; break;           // ma = x
+            case 1: gz = dfx * ima;  gy = -dfy * ima; gx = (f.fx * dfx + f.fy * dfy) * ima; break;            // ma = -x
+            case 2: gx = dfx * ima;  gz = dfy * ima;  gy = -(f.fx * dfx + f.fy * dfy) * ima; break;           // ma = y
+            case 3: gx = dfx * ima;  gz = -dfy * ima; gy = (f.fx * dfx + f.fy * dfy) * ima; break;            // ma = -y
+            case 4: gx = dfx * ima;  gy = -dfy * ima; gz = -(f.fx * dfx + f.fy * dfy) * ima; break;           // ma = z
+            default: gx = -dfx * ima; gy = -dfy * ima; gz = (f.fx * dfx + f.fy * dfy) * ima; break;           // ma = -z
+            }
+            d_dirs[3 * i] = gx; d_dirs[3 * i + 1] = gy; d_dirs[3 * i + 2] = gz;
+        }
     }
-    if (d_level) d_level[i] = (level && lraw > 0.0f && lraw < (float)(m.n - 1) && l1 != l0) ? (s1 - s0) : 0.0f;
-    if (d_dirs) {
-        // fx = sx * comp_u / ma, fy = sy * comp_v / ma with ma = |major component|
-        float gx = 0.f, gy = 0.f, gz = 0.f;
-        const float ima = 1.0f / f.ma;
-        switch (f.face) {
-        case 0: gz = -dfx * ima; gy = -dfy * ima; gx = -(f.fx * dfx + f.fy * dfy) * ima; break;           // ma = x
-        case 1: gz = dfx * ima;  gy = -dfy * ima; gx = (f.fx * dfx + f.fy * dfy) * ima; break;            // ma = -x
-        case 2: gx = dfx * ima;  gz = dfy * ima;  gy = -(f.fx * dfx + f.fy * dfy) * ima; break;           // ma = y
-        case 3: gx = dfx * ima;  gz = -dfy * ima; gy = (f.fx * dfx + f.fy * dfy) * ima; break;            // ma = -y
-        case 4: gx = dfx * ima;  gy = -dfy * ima; gz = -(f.fx * dfx + f.fy * dfy) * ima; break;           // ma = z
-        default: gx = -dfx * ima; gy = -dfy * ima; gz = (f.fx * dfx + f.fy * dfy) * ima; break;           // ma = -z
+    if (plan.total == 0) return;
+    __syncthreads();
+    for (int l = 0; l < m.n; ++l) {
+        if (plan.off[l] < 0 || !m.grad[l]) continue;
+        const int R = m.R0 >> l, cnt = 6 * R * R * m.C;
+        for (int e = threadIdx.x; e < cnt; e += BWD_THREADS) {
+            const float v = s_grad[plan.off[l] + e];
+            if (v != 0.0f) atomicAdd(m.grad[l] + e, v);
         }
-        d_dirs[3 * i] = gx; d_dirs[3 * i + 1] = gy; d_dirs[3 * i + 2] = gz;
     }
 }
 
@@ -425,8 +457,29 @@ int rsdf_cube_sample_bwd(const float *const *mips, float *const *grad_mips, int 
     RSDF_CHECK_ARG(n_mips >= 1 && n_mips <= 8 && C >= 1 && C <= 4 && (R0 >> (n_mips - 1)) >= 1,
                    "cube_sample_bwd: bad mip stack");
     if (n <= 0) return 0;
-    cube_sample_bwd_kernel<<<rsdf_blocks(n, THREADS), THREADS, 0, (hipStream_t)stream>>>(
-        make_stack(mips, grad_mips, n_mips, R0, C), dirs, level, n, grad_out, grad_dirs, grad_level);
+    const MipStack st = make_stack(mips, grad_mips, n_mips, R0, C);
+    LdsPlan plan;
+    plan.total = 0;
+    for (int l = 0; l < 8; ++l) plan.off[l] = -1;
+    for (int l = n_mips - 1; l >= 0; --l) {   // smallest levels first
+        const int R = R0 >> l, cnt = 6 * R * R * C;
+        if (!st.grad[l] || plan.total + cnt > LDS_BUDGET_FLOATS) break;
+        plan.off[l] = plan.total;
+        plan.total += cnt;
+    }
+    const size_t lds = (size_t)plan.total * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(cube_sample_bwd_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)(LDS_BUDGET_FLOATS * sizeof(float)));
+        if (e != hipSuccess) { rsdf_set_error(hipGetErrorString(e)); return (int)e; }
+        attr_set = true;
+    }
+    unsigned grid = rsdf_blocks(n, BWD_THREADS);
+    if (plan.total > 0 && grid > 512) grid = 512;   // persistent: one LDS copy (and one flush) per workgroup
+    cube_sample_bwd_kernel<<<grid, BWD_THREADS, lds, (hipStream_t)stream>>>(st, plan, dirs, level, n, grad_out,
+                                                                           grad_dirs, grad_level);
     RSDF_RETURN_LAUNCH();
 }
 

@@ -1,0 +1,95 @@
+"""config[2] measurement: c1 + radiance branch + split-sum shading (stage 1) on one MI355X, fwd+bwd.
+Not the bench.py metric (that is config[1]); prints samples/s and the per-entry-point breakdown.
+Usage: python tools/bench_c2.py [--width 800 --height 800 --chunk 8192 --stage 1 --tex-hidden 128]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--width", type=int, default=800)
+    ap.add_argument("--height", type=int, default=800)
+    ap.add_argument("--chunk", type=int, default=8192)
+    ap.add_argument("--stage", type=int, default=1)
+    ap.add_argument("--tex-hidden", type=int, default=128)
+    ap.add_argument("--steps", type=int, default=1)
+    args = ap.parse_args()
+    import rise_sdf_amd as R
+    from rise_sdf_amd import _lib
+    from helpers import camera_rays
+    import bench
+    dev = torch.device("cuda", 0)
+    cfg = bench.c1_config(hidden=64)
+    mlp = lambda n: {"otype": "VanillaMLP", "activation": "ReLU", "output_activation": "none",
+                     "n_neurons": args.tex_hidden, "n_hidden_layers": n}
+    feat = cfg["geometry"]["feature_dim"]
+    cfg.update({
+        "name": "split-mixed-occ", "indirect_pred": False, "curvature": False,
+        "split_sum_kick_in_step": 0 if args.stage else 1 << 60,
+        "texture": {"name": "volume-mixed-mip-split-occ", "input_feature_dim": feat, "other_dim": 3, "sample_size": 8,
+                    "dir_encoding_config": {"otype": "SphericalHarmonics", "degree": 5, "reflected": True},
+                    "metallic_mlp_network_config": mlp(2), "albedo_mlp_network_config": mlp(4),
+                    "spec_mlp_network_config": mlp(4), "roughness_mlp_network_config": mlp(2),
+                    "secondary_mlp_network_config": mlp(4),
+                    "xyz_encoding_config": {"otype": "VanillaFrequency", "n_frequencies": 6},
+                    "color_activation": "sigmoid"},
+        "light": {"name": "envlight-mip-cube",
+                  "envlight_config": {"scale": 0.5, "bias": 0.25, "base_res": 512, "hdr_filepath": None}},
+    })
+    torch.manual_seed(0)
+    model = R.make("split-mixed-occ", R.Config(cfg)).to(dev)
+    model.train()
+    model.grid_prune = False
+    model.occupancy_grid.binaries.fill_(True)
+    with torch.no_grad():
+        l0 = model.geometry.network.layers[0]
+        l0.weight_v[:, 3:] = torch.randn_like(l0.weight_v[:, 3:]) * 0.05
+    model.update_step(0, 0)
+    model.background_color = torch.ones(3, device=dev)
+    rays = camera_rays(args.width, args.height, seed=0).to(dev)
+    n = rays.shape[0]
+    g = torch.Generator().manual_seed(2)
+    u = torch.rand(n, generator=g).to(dev)
+    cot = torch.randn(n, 3, generator=g).to(dev)
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        if model.stage:
+            model.emitter.build_mips()
+        total = 0
+        for s in range(0, n, args.chunk):
+            out = model.forward_(rays[s:s + args.chunk], stratified_u=u[s:s + args.chunk])
+            total += int(out["num_samples"])
+            key = "comp_rgb_phys_full" if model.stage else "comp_rgb_full"
+            (out[key] * cot[s:s + args.chunk]).sum().backward(retain_graph=bool(model.stage))
+        return total
+
+    step()
+    timer = _lib.KernelTimer()
+    _lib.set_timer(timer)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    samples = sum(step() for _ in range(args.steps))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    _lib.set_timer(None)
+    summ = timer.summary()
+    top = {k: round(v["ms"] / args.steps, 1) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:14]}
+    print(json.dumps({"workload": f"c2 stage {model.stage}: split-mixed-occ, {args.width}x{args.height}, texture width "
+                                  f"{args.tex_hidden}, env 512^2", "samples_per_s": samples / dt,
+                      "ms_per_step": dt / args.steps * 1e3, "samples_per_step": samples / args.steps,
+                      "kernel_ms_total": round(sum(v["ms"] for v in summ.values()) / args.steps, 1), "top": top}))
+
+
+if __name__ == "__main__":
+    main()
