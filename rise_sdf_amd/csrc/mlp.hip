@@ -1,26 +1,23 @@
-// H3: VanillaMLP layers (models/network_utils.py:109-157) on the fp32 matrix cores.
+// H3 / T3: VanillaMLP layers (models/network_utils.py:109-157), one kernel per layer and direction.
 //
 // The reference MLPs are plain fp32 nn.Linear (+ weight_norm) with Softplus(beta=100) or ReLU, run
-// as cuBLAS GEMMs plus separate activation kernels.  Here each layer is one kernel built on
-// v_mfma_f32_32x32x2_f32: exact fp32 (a k-ordered fmaf chain seeded with the bias), bias and
-// activation fused into the epilogue, the backward's activation derivative fused into the operand
-// staging.  K and N are at most 128, so the whole weight matrix lives in LDS for the block.
-//
-// Operand maps of v_mfma_f32_32x32x2_f32 (cdna_hip_programming.md section 3), lane l:
-//   A[i = l&31][k = l>>5],  B[k = l>>5][j = l&31],
-//   C/D register r: row = (r&3) + 8*(r>>2) + 4*(l>>5), col = l&31.
-// LDS tiles are row-major with an odd row stride (KP+1), so the 32 lanes of a ds_read_b32 group
-// (32 consecutive rows, same column) fall on 32 distinct banks.
+// as cuBLAS GEMMs plus separate activation kernels.  Here:
+//   linear_fwd        y = act(x W^T + b)                 split-bf16 matrix products (fp32-equivalent, split_bf16.h)
+//   linear_bwd_input  dz = dy act'(y), dx = dz W[:, win]  split-bf16
+//   linear_bwd_weight dW += dz^T x, db += colsum(dz)     fp32 MFMA (sum over rows)
+// K and N are at most 128, so the whole weight matrix lives in LDS: forward and input-gradient kernels are
+// PERSISTENT (<= 512 workgroups loop over 32-row tiles), stage the weights once per workgroup as split,
+// fragment-ordered bf16 and compute TRANSPOSED, D[n][row] = sum_k W[n][k] x[row][k]: the x fragment of a lane
+// is 8 consecutive floats of its own row (read straight from global memory, no LDS tile) and an accumulator
+// register quad is 4 consecutive output features of that row (one 16-byte store).
+// Operand maps: split_bf16.h / cdna_hip_programming.md section 3.
 #include "common.h"
+#include "split_bf16.h"
 
 namespace {
 
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-
 constexpr int THREADS = 256;
 constexpr int WAVES = THREADS / 64;
-constexpr int ROWS_PER_WAVE = 32;
-constexpr int ROWS_PER_BLOCK = WAVES * ROWS_PER_WAVE;  // 128
 
 __device__ __forceinline__ float act_fwd(float z, int act)
 {
@@ -48,130 +45,180 @@ __device__ __forceinline__ float act_bwd_from_y(float y, int act)
     }
 }
 
-// W[N,K] (row-major, global) -> LDS [NP][ldw], zero padded
-__device__ __forceinline__ void stage_weights(const float *__restrict__ w, int N, int K, int NP,
-                                              int KP, int ldw, float *Ws)
+// ------------------------------------------------------------------------------------------------
+// split-bf16 per-layer kernels
+// ------------------------------------------------------------------------------------------------
+constexpr int S_WAVES = 8;                 // two waves per SIMD
+constexpr int S_THREADS = S_WAVES * 64;
+
+// LDS weight image (16-byte units): [part 3][out tile OT][k-step KS][hf 2][c 32], then OT*32 floats of bias
+__device__ __forceinline__ f32x16 mma6s(const u32x4 *__restrict__ wa, int part_stride, const Frag3 &b, f32x16 c)
 {
-    for (int e = threadIdx.x; e < NP * KP; e += THREADS) {
-        const int r = e / KP, c = e - r * KP;
-        Ws[r * ldw + c] = (r < N && c < K) ? w[r * K + c] : 0.0f;
+    const u32x4 ah = wa[0], am = wa[part_stride], al = wa[2 * part_stride];
+    c = mma_bf16(al, b.h, c);
+    c = mma_bf16(ah, b.l, c);
+    c = mma_bf16(am, b.m, c);
+    c = mma_bf16(am, b.h, c);
+    c = mma_bf16(ah, b.m, c);
+    c = mma_bf16(ah, b.h, c);
+    return c;
+}
+
+// 8 consecutive floats p[k .. k+8) of a row, zero beyond `limit`; vector loads when the row allows it
+__device__ __forceinline__ void load8(const float *__restrict__ p, int k, int limit, bool vec, float (&v)[8])
+{
+    if (vec && k + 8 <= limit) {
+        const float4 a = *reinterpret_cast<const float4 *>(p + k), b = *reinterpret_cast<const float4 *>(p + k + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (k + j < limit) ? p[k + j] : 0.0f;
     }
 }
 
-// ------------------------------------------------------------------------------------------------
 // y = act(x W^T + b)
-// ------------------------------------------------------------------------------------------------
 template <int NT>
-__global__ void __launch_bounds__(THREADS)
+__global__ void __launch_bounds__(S_THREADS)
 linear_fwd_kernel(const float *__restrict__ x, int ldx, const float *__restrict__ w,
                   const float *__restrict__ b, int64_t n, int K, int N, int act,
                   float *__restrict__ y, int ldy)
 {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int KP = (K + 1) & ~1, ld = KP + 1;
-    float *Ws = smem;                                   // [NT*32][ld]
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float *Xs = smem + NT * 32 * ld + wave * ROWS_PER_WAVE * ld;  // [32][ld], private to the wave
-
-    stage_weights(w, N, K, NT * 32, KP, ld, Ws);
-
-    const int64_t row0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave * ROWS_PER_WAVE;
-    for (int e = lane; e < ROWS_PER_WAVE * KP; e += 64) {
-        const int r = e / KP, c = e - r * KP;
-        const int64_t gr = row0 + r;
-        Xs[r * ld + c] = (gr < n && c < K) ? x[gr * ldx + c] : 0.0f;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    const int KS = (K + 15) >> 4;
+    const int part = NT * KS * 2 * 32;
+    unsigned short *e16 = reinterpret_cast<unsigned short *>(smem_b);
+    float *bias = reinterpret_cast<float *>(smem_b + (size_t)3 * part * 16);
+    // A[i = n][k natural] : element e = (((nt*KS + ks)*2 + hf)*32 + c)*8 + j
+    for (int e = threadIdx.x; e < part * 8; e += S_THREADS) {
+        const int j = e & 7, c = (e >> 3) & 31, hf = (e >> 8) & 1, ks = (e >> 9) % KS, nt = (e >> 9) / KS;
+        const int nn = 32 * nt + c, k = 16 * ks + 8 * hf + j;
+        store3(e16, (size_t)part * 8, e, (nn < N && k < K) ? w[nn * K + k] : 0.0f);
     }
+    for (int e = threadIdx.x; e < NT * 32; e += S_THREADS) bias[e] = (b && e < N) ? b[e] : 0.0f;
     __syncthreads();
+    const u32x4 *wl = reinterpret_cast<const u32x4 *>(smem_b);
 
-    const int li = lane & 31, lh = lane >> 5;
-    f32x16 acc[NT];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 31, hf = lane >> 5;
+    const bool vx = (ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    const bool vy = (ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+    const int64_t n_tiles = (n + 31) >> 5;
+    for (int64_t tile = (int64_t)blockIdx.x * S_WAVES + wave; tile < n_tiles; tile += (int64_t)gridDim.x * S_WAVES) {
+        const int64_t row = tile * 32 + c;
+        const bool ok = row < n;
+        const float *xr = x + (ok ? row : 0) * (int64_t)ldx;
+        f32x16 acc[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int col = t * 32 + li;
-        const float bv = (b && col < N) ? b[col] : 0.0f;
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = bv;
-    }
-    for (int k0 = 0; k0 < KP; k0 += 2) {
-        const float a = Xs[li * ld + k0 + lh];
+            for (int r = 0; r < 16; ++r) acc[t][r] = bias[32 * t + (r & 3) + 8 * (r >> 2) + 4 * hf];
+        for (int ks = 0; ks < KS; ++ks) {
+            float v[8];
+            load8(xr, 16 * ks + 8 * hf, ok ? K : 0, vx, v);
+            const Frag3 xb = split_frag(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const float bb = Ws[(t * 32 + li) * ld + k0 + lh];
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc[t], 0, 0, 0);
+            for (int t = 0; t < NT; ++t)
+                acc[t] = mma6s(wl + ((t * KS + ks) * 2 + hf) * 32 + c, part, xb, acc[t]);
         }
-    }
+        if (!ok) continue;
+        float *yr = y + row * (int64_t)ldy;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int col = t * 32 + li;
-        if (col < N) {
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t gr = row0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (gr < n) y[gr * ldy + col] = act_fwd(acc[t][r], act);
+            for (int g = 0; g < 4; ++g) {
+                const int col = 32 * t + 8 * g + 4 * hf;   // registers 4g .. 4g+3 = features col .. col+3
+                float o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = act_fwd(acc[t][4 * g + q], act);
+                if (vy && col + 4 <= N) {
+                    *reinterpret_cast<float4 *>(yr + col) = make_float4(o[0], o[1], o[2], o[3]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (col + q < N) yr[col + q] = o[q];
+                }
             }
-        }
     }
 }
 
-// ------------------------------------------------------------------------------------------------
 // dz = dy * act'(y);  dx[:, 0:Kout] = dz @ W[:, k0:k0+Kout]
-// ------------------------------------------------------------------------------------------------
 template <int JT>
-__global__ void __launch_bounds__(THREADS)
+__global__ void __launch_bounds__(S_THREADS)
 linear_bwd_input_kernel(const float *dy, const float *__restrict__ y, int lddy,
                         const float *__restrict__ w, int64_t n, int K, int N, int act, int k0,
                         int Kout, float *dz, float *__restrict__ dx, int lddx)
 {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int KP = (K + 1) & ~1, ldw = KP + 1;
-    const int NP = (N + 1) & ~1, ldz = NP + 1;
-    const int NR = (N + 31) & ~31;
-    float *Ws = smem;  // [NR][ldw]
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float *Zs = smem + NR * ldw + wave * ROWS_PER_WAVE * ldz;  // [32][ldz]
-
-    if (dx) stage_weights(w, N, K, NR, KP, ldw, Ws);
-
-    const int64_t row0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave * ROWS_PER_WAVE;
-    for (int e = lane; e < ROWS_PER_WAVE * NP; e += 64) {
-        const int r = e / NP, c = e - r * NP;
-        const int64_t gr = row0 + r;
-        float v = 0.0f;
-        if (gr < n && c < N) {
-            v = dy[gr * lddy + c];
-            if (act != RSDF_ACT_NONE) v *= act_bwd_from_y(y[gr * lddy + c], act);
-            if (dz) dz[gr * lddy + c] = v;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    const int NS = (N + 15) >> 4;
+    const int part = JT * NS * 2 * 32;
+    if (dx) {
+        // A[i = window column][k = n natural] = W[n][k0 + column]
+        unsigned short *e16 = reinterpret_cast<unsigned short *>(smem_b);
+        for (int e = threadIdx.x; e < part * 8; e += S_THREADS) {
+            const int j = e & 7, c = (e >> 3) & 31, hf = (e >> 8) & 1, ns = (e >> 9) % NS, jt = (e >> 9) / NS;
+            const int col = 32 * jt + c, nn = 16 * ns + 8 * hf + j;
+            store3(e16, (size_t)part * 8, e, (col < Kout && nn < N) ? w[nn * K + k0 + col] : 0.0f);
         }
-        Zs[r * ldz + c] = v;
+        __syncthreads();
     }
-    __syncthreads();
-    if (!dx) return;
-
-    const int li = lane & 31, lh = lane >> 5;
-    f32x16 acc[JT];
+    const u32x4 *wl = reinterpret_cast<const u32x4 *>(smem_b);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 31, hf = lane >> 5;
+    const bool vz = (lddy & 3) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0 &&
+                    (y == nullptr || (reinterpret_cast<uintptr_t>(y) & 15) == 0) &&
+                    (dz == nullptr || (reinterpret_cast<uintptr_t>(dz) & 15) == 0);
+    const bool vx = dx != nullptr && (lddx & 3) == 0 && (reinterpret_cast<uintptr_t>(dx) & 15) == 0;
+    const int64_t n_tiles = (n + 31) >> 5;
+    for (int64_t tile = (int64_t)blockIdx.x * S_WAVES + wave; tile < n_tiles; tile += (int64_t)gridDim.x * S_WAVES) {
+        const int64_t row = tile * 32 + c;
+        const bool ok = row < n;
+        const int64_t rbase = (ok ? row : 0) * (int64_t)lddy;
+        f32x16 acc[JT];
 #pragma unroll
-    for (int t = 0; t < JT; ++t)
+        for (int t = 0; t < JT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-    for (int n0 = 0; n0 < NP; n0 += 2) {
-        const float a = Zs[li * ldz + n0 + lh];
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        for (int ns = 0; ns < NS; ++ns) {
+            const int kk = 16 * ns + 8 * hf;
+            float v[8];
+            load8(dy + rbase, kk, ok ? N : 0, vz, v);
+            if (act != RSDF_ACT_NONE) {
+                float yv[8];
+                load8(y + rbase, kk, ok ? N : 0, vz, yv);
 #pragma unroll
-        for (int t = 0; t < JT; ++t) {
-            const int col = k0 + t * 32 + li;  // < KP guaranteed by the launcher's padding rule
-            const float bb = (col < KP) ? Ws[(n0 + lh) * ldw + col] : 0.0f;
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc[t], 0, 0, 0);
-        }
-    }
+                for (int j = 0; j < 8; ++j) v[j] *= act_bwd_from_y(yv[j], act);
+            }
+            if (dz != nullptr && ok) {
+                if (vz && kk + 8 <= N) {
+                    *reinterpret_cast<float4 *>(dz + rbase + kk) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4 *>(dz + rbase + kk + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                } else {
 #pragma unroll
-    for (int t = 0; t < JT; ++t) {
-        const int col = t * 32 + li;
-        if (col < Kout) {
+                    for (int j = 0; j < 8; ++j)
+                        if (kk + j < N) dz[rbase + kk + j] = v[j];
+                }
+            }
+            if (dx) {
+                const Frag3 zb = split_frag(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t gr = row0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (gr < n) dx[gr * lddx + col] = acc[t][r];
+                for (int t = 0; t < JT; ++t)
+                    acc[t] = mma6s(wl + ((t * NS + ns) * 2 + hf) * 32 + c, part, zb, acc[t]);
             }
         }
+        if (!dx || !ok) continue;
+        float *xr = dx + row * (int64_t)lddx;
+#pragma unroll
+        for (int t = 0; t < JT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = 32 * t + 8 * g + 4 * hf;
+                if (vx && col + 4 <= Kout) {
+                    *reinterpret_cast<float4 *>(xr + col) =
+                        make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (col + q < Kout) xr[col + q] = acc[t][4 * g + q];
+                }
+            }
     }
 }
 
@@ -275,15 +322,18 @@ weight_norm_bwd_kernel(const float *__restrict__ g, const float *__restrict__ v,
 
 size_t fwd_lds_bytes(int K, int NT)
 {
-    const int KP = (K + 1) & ~1, ld = KP + 1;
-    return (size_t)(NT * 32 + ROWS_PER_BLOCK) * ld * sizeof(float);
+    const int KS = (K + 15) >> 4;
+    return (size_t)3 * NT * KS * 2 * 32 * 16 + (size_t)NT * 32 * sizeof(float);
 }
-size_t bwd_lds_bytes(int K, int N)
+size_t bwd_lds_bytes(int N, int JT)
 {
-    const int KP = (K + 1) & ~1, ldw = KP + 1;
-    const int NP = (N + 1) & ~1, ldz = NP + 1;
-    const int NR = (N + 31) & ~31;
-    return ((size_t)NR * ldw + (size_t)ROWS_PER_BLOCK * ldz) * sizeof(float);
+    const int NS = (N + 15) >> 4;
+    return (size_t)3 * JT * NS * 2 * 32 * 16;
+}
+unsigned persistent_blocks(int64_t n)
+{
+    const int64_t want = ((n + 31) / 32 + S_WAVES - 1) / S_WAVES;
+    return (unsigned)(want < 1 ? 1 : (want > 512 ? 512 : want));
 }
 
 template <typename Kern>
@@ -309,13 +359,13 @@ int rsdf_linear_fwd(const float *x, int ldx, const float *w, const float *b, int
     if (n <= 0) return 0;
     const int NT = (N + 31) / 32;
     const size_t lds = fwd_lds_bytes(K, NT);
-    const unsigned grid = rsdf_blocks(n, ROWS_PER_BLOCK);
+    const unsigned grid = persistent_blocks(n);
     hipStream_t st = (hipStream_t)stream;
     int rc = 0;
 #define LAUNCH_FWD(NT_)                                                                        \
     rc = allow_lds(linear_fwd_kernel<NT_>, lds);                                               \
     if (rc) return rc;                                                                         \
-    linear_fwd_kernel<NT_><<<grid, THREADS, lds, st>>>(x, ldx, w, b, n, K, N, act, y, ldy)
+    linear_fwd_kernel<NT_><<<grid, S_THREADS, lds, st>>>(x, ldx, w, b, n, K, N, act, y, ldy)
     switch (NT) {
     case 1: LAUNCH_FWD(1); break;
     case 2: LAUNCH_FWD(2); break;
@@ -339,14 +389,14 @@ int rsdf_linear_bwd_input(const float *dy, const float *y, int lddy, const float
     }
     if (n <= 0) return 0;
     const int JT = dx ? (Kout + 31) / 32 : 1;
-    const size_t lds = bwd_lds_bytes(K, N);
-    const unsigned grid = rsdf_blocks(n, ROWS_PER_BLOCK);
+    const size_t lds = bwd_lds_bytes(N, JT);
+    const unsigned grid = persistent_blocks(n);
     hipStream_t st = (hipStream_t)stream;
     int rc = 0;
 #define LAUNCH_BI(JT_)                                                                         \
     rc = allow_lds(linear_bwd_input_kernel<JT_>, lds);                                         \
     if (rc) return rc;                                                                         \
-    linear_bwd_input_kernel<JT_><<<grid, THREADS, lds, st>>>(dy, y, lddy, w, n, K, N, act, k0, \
+    linear_bwd_input_kernel<JT_><<<grid, S_THREADS, lds, st>>>(dy, y, lddy, w, n, K, N, act, k0, \
                                                              Kout, dz, dx, lddx)
     switch (JT) {
     case 1: LAUNCH_BI(1); break;

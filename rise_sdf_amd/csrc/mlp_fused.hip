@@ -16,10 +16,9 @@
 //     the vector ALU instead of a matrix tile; the full feature row is produced for centre rows only.
 // All results are fp32-equivalent (parity tests: 1e-5 relative); summation order differs from a row-major GEMM.
 #include "common.h"
+#include "split_bf16.h"
 
 namespace {
-
-using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int BWD_WAVES = 4;      // backward: one wave per SIMD (register-resident weight fragments + accumulators)
 constexpr int BWD_THREADS = BWD_WAVES * 64;
@@ -77,61 +76,6 @@ __device__ __forceinline__ void fetch_tile(float (&pre)[18], const TileSrc &src,
 // are staged in LDS already permuted to that k order, one 16-byte A fragment per lane:
 //     Wp[part][n tile][k tile][s][lane >> 5][lane & 31][j]  =  W[32 nt + (lane & 31)][32 kt + 16 s + 8 (j >> 2) + 4 (lane >> 5) + (j & 3)]
 // ------------------------------------------------------------------------------------------------
-using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
-using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
-using f32x2 = __attribute__((ext_vector_type(2))) float;
-using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
-
-struct Frag3 { u32x4 h, m, l; };
-
-__device__ __forceinline__ unsigned pack_bf16(float a, float b)  // v_cvt_pk_bf16_f32 (RNE); a -> low half
-{
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
-}
-__device__ __forceinline__ float bf16_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
-__device__ __forceinline__ float bf16_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
-
-__device__ __forceinline__ void split3_pair(float a, float b, unsigned &h, unsigned &m, unsigned &l)
-{
-    h = pack_bf16(a, b);
-    const float ra = a - bf16_lo(h), rb = b - bf16_hi(h);   // exact
-    m = pack_bf16(ra, rb);
-    l = pack_bf16(ra - bf16_lo(m), rb - bf16_hi(m));
-}
-// 8 consecutive fragment elements -> 3-part fragment
-__device__ __forceinline__ Frag3 split_frag(float v0, float v1, float v2, float v3, float v4, float v5, float v6,
-                                            float v7)
-{
-    unsigned h[4], m[4], l[4];
-    split3_pair(v0, v1, h[0], m[0], l[0]);
-    split3_pair(v2, v3, h[1], m[1], l[1]);
-    split3_pair(v4, v5, h[2], m[2], l[2]);
-    split3_pair(v6, v7, h[3], m[3], l[3]);
-    Frag3 f;
-    f.h = u32x4{h[0], h[1], h[2], h[3]};
-    f.m = u32x4{m[0], m[1], m[2], m[3]};
-    f.l = u32x4{l[0], l[1], l[2], l[3]};
-    return f;
-}
-__device__ __forceinline__ f32x16 mma_bf16(u32x4 a, u32x4 b, f32x16 c)
-{
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c,
-                                                    0, 0, 0);
-}
-// a (weights: LDS, three parts PART_STRIDE bytes apart) x b (activations), six partial products
-template <int PART_STRIDE_U4>
-__device__ __forceinline__ f32x16 mma6(const u32x4 *__restrict__ wa, const Frag3 &b, f32x16 c)
-{
-    const u32x4 ah = wa[0], am = wa[PART_STRIDE_U4], al = wa[2 * PART_STRIDE_U4];
-    c = mma_bf16(al, b.h, c);
-    c = mma_bf16(ah, b.l, c);
-    c = mma_bf16(am, b.m, c);
-    c = mma_bf16(am, b.h, c);
-    c = mma_bf16(ah, b.m, c);
-    c = mma_bf16(ah, b.h, c);
-    return c;
-}
-
 // Softplus(beta = 100, threshold = 20) on the raw exp2 / log2 units:  max(z, 0) + log2(1 + 2^(-|100 z| log2 e)) ln 2 / 100
 __device__ __forceinline__ float softplus100_fast(float z)
 {
@@ -167,14 +111,6 @@ struct SmemS {
     static constexpr int PER_WAVE_F = 32 * 65;   // X tile [32][LDXF] fp32, overlaid by the feature transpose [32][65]
 };
 
-__device__ __forceinline__ void store3(unsigned short *base, size_t part_stride_elems, size_t idx, float w)
-{
-    unsigned h, m, l;
-    split3_pair(w, 0.0f, h, m, l);
-    base[idx] = (unsigned short)(h & 0xffffu);
-    base[idx + part_stride_elems] = (unsigned short)(m & 0xffffu);
-    base[idx + 2 * part_stride_elems] = (unsigned short)(l & 0xffffu);
-}
 // k of element j of lane half hf in k-step s of a 32-feature activation tile
 __device__ __forceinline__ int frag_k(int s, int hf, int j) { return 16 * s + 8 * (j >> 2) + 4 * hf + (j & 3); }
 
@@ -450,17 +386,6 @@ __device__ __forceinline__ void stage_split_weights_bwd(unsigned char *smem, con
     }
 }
 
-// six partial products with the weight fragment in registers
-__device__ __forceinline__ f32x16 mma6r(const Frag3 &a, const Frag3 &b, f32x16 c)
-{
-    c = mma_bf16(a.l, b.h, c);
-    c = mma_bf16(a.h, b.l, c);
-    c = mma_bf16(a.m, b.m, c);
-    c = mma_bf16(a.m, b.h, c);
-    c = mma_bf16(a.h, b.m, c);
-    c = mma_bf16(a.h, b.h, c);
-    return c;
-}
 __device__ __forceinline__ Frag3 frag_of(const f32x16 &v, int s)
 {
     return split_frag(v[8 * s], v[8 * s + 1], v[8 * s + 2], v[8 * s + 3], v[8 * s + 4], v[8 * s + 5], v[8 * s + 6],
