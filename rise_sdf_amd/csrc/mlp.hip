@@ -17,7 +17,6 @@
 namespace {
 
 constexpr int THREADS = 256;
-constexpr int WAVES = THREADS / 64;
 
 __device__ __forceinline__ float act_fwd(float z, int act)
 {
@@ -223,64 +222,65 @@ linear_bwd_input_kernel(const float *dy, const float *__restrict__ y, int lddy,
 }
 
 // ------------------------------------------------------------------------------------------------
-// dw[N,K] += dz^T x ; db[N] += colsum(dz)
-// Each block owns SLAB rows; wave w owns rows [w*SLAB/4, (w+1)*SLAB/4) and walks the n-tiles one at
-// a time, holding the KT k-tiles of that n-tile in accumulators.  Both MFMA operands are read
-// straight from global memory: lane l reads element (row s0 + (l>>5), column tile*32 + (l&31)),
-// i.e. two coalesced 128-byte row segments per instruction.
+// dw[N,K] += dz^T x ; db[N] += colsum(dz)          (split-bf16, sum over rows = the MFMA k dimension)
+// A[i = n][k = row] and B[k = row][j = input column]: a lane's fragment is 8 consecutive ROWS of its own
+// column, so for each of the 8 rows the 32 lanes of a half read 128 contiguous bytes -- operands come straight
+// from global memory, no transpose.  Wave w of a workgroup owns output n-tile w % NT (all KT k-tiles, in
+// registers for the whole kernel) and row slab w / NT; workgroups are persistent and flush once with atomics.
 // ------------------------------------------------------------------------------------------------
-constexpr int SLAB = 4096;
-
 template <int KT>
-__global__ void __launch_bounds__(THREADS)
+__global__ void __launch_bounds__(S_THREADS)
 linear_bwd_weight_kernel(const float *__restrict__ dz, int lddz, const float *__restrict__ x,
                          int ldx, int64_t n, int K, int N, float *__restrict__ dw,
                          float *__restrict__ db)
 {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int li = lane & 31, lh = lane >> 5;
-    const int64_t r_begin = (int64_t)blockIdx.x * SLAB + wave * (SLAB / WAVES);
-    int64_t r_end = r_begin + SLAB / WAVES;
-    if (r_end > n) r_end = n;
-    if (r_begin >= n) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 31, hf = lane >> 5;
     const int NT = (N + 31) >> 5;
-    for (int nt = 0; nt < NT; ++nt) {
-        f32x16 acc[KT];
+    const int slabs = S_WAVES / NT;              // row slabs per workgroup (waves beyond NT * slabs idle)
+    const int nt = wave % NT, slab = wave / NT;
+    if (slab >= slabs) return;
+    f32x16 acc[KT];
 #pragma unroll
-        for (int t = 0; t < KT; ++t)
+    for (int t = 0; t < KT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-        float bsum = 0.0f;
-        const int ncol = nt * 32 + li;
-        const bool nok = ncol < N;
-        for (int64_t s0 = r_begin; s0 < r_end; s0 += 2) {
-            const int64_t s = s0 + lh;
-            const bool rok = s < r_end;
-            const float a = (rok && nok) ? dz[s * lddz + ncol] : 0.0f;
-            bsum += a;
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    float bsum = 0.0f;
+    const int ncol = nt * 32 + c;
+    const bool nok = ncol < N;
+    const int64_t n_steps = (n + 15) >> 4;       // 16 rows per MFMA k-step
+    const int64_t stride = (int64_t)gridDim.x * slabs;
+    for (int64_t step = (int64_t)blockIdx.x * slabs + slab; step < n_steps; step += stride) {
+        const int64_t r0 = step * 16 + 8 * hf;
+        float av[8];
 #pragma unroll
-            for (int t = 0; t < KT; ++t) {
-                const int kcol = t * 32 + li;
-                const float bb = (rok && kcol < K) ? x[s * ldx + kcol] : 0.0f;
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc[t], 0, 0, 0);
-            }
-        }
-        // D[i = n within tile][j = k within tile]
+        for (int j = 0; j < 8; ++j) av[j] = (nok && r0 + j < n) ? dz[(r0 + j) * lddz + ncol] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bsum += av[j];
+        const Frag3 af = split_frag(av[0], av[1], av[2], av[3], av[4], av[5], av[6], av[7]);
 #pragma unroll
         for (int t = 0; t < KT; ++t) {
-            const int kcol = t * 32 + li;
-            if (kcol < K) {
+            const int kcol = t * 32 + c;
+            float bv[8];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int nrow = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (nrow < N) atomicAdd(&dw[nrow * K + kcol], acc[t][r]);
-                }
+            for (int j = 0; j < 8; ++j) bv[j] = (kcol < K && r0 + j < n) ? x[(r0 + j) * ldx + kcol] : 0.0f;
+            acc[t] = mma6r(af, split_frag(bv[0], bv[1], bv[2], bv[3], bv[4], bv[5], bv[6], bv[7]), acc[t]);
+        }
+    }
+    // D[i = n within tile][j = k within tile]
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+        const int kcol = t * 32 + c;
+        if (kcol < K) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nrow = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+                if (nrow < N && acc[t][r] != 0.0f) atomicAdd(&dw[nrow * K + kcol], acc[t][r]);
             }
         }
-        if (db) {
-            bsum += __shfl_xor(bsum, 32, 64);
-            if (lh == 0 && nok) atomicAdd(&db[ncol], bsum);
-        }
+    }
+    if (db) {
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (hf == 0 && nok && bsum != 0.0f) atomicAdd(&db[ncol], bsum);
     }
 }
 
@@ -415,13 +415,15 @@ int rsdf_linear_bwd_weight(const float *dz, int lddz, const float *x, int ldx, i
     RSDF_CHECK_ARG(lddz >= N && ldx >= K, "linear_bwd_weight: row stride smaller than the row");
     if (n <= 0) return 0;
     const int KT = (K + 31) / 32;
-    const unsigned grid = rsdf_blocks(n, SLAB);
+    const int slabs = S_WAVES / ((N + 31) / 32);
+    int64_t want = ((n + 15) / 16 + slabs - 1) / slabs;
+    const unsigned grid = (unsigned)(want < 1 ? 1 : (want > 512 ? 512 : want));
     hipStream_t st = (hipStream_t)stream;
     switch (KT) {
-    case 1: linear_bwd_weight_kernel<1><<<grid, THREADS, 0, st>>>(dz, lddz, x, ldx, n, K, N, dw, db); break;
-    case 2: linear_bwd_weight_kernel<2><<<grid, THREADS, 0, st>>>(dz, lddz, x, ldx, n, K, N, dw, db); break;
-    case 3: linear_bwd_weight_kernel<3><<<grid, THREADS, 0, st>>>(dz, lddz, x, ldx, n, K, N, dw, db); break;
-    default: linear_bwd_weight_kernel<4><<<grid, THREADS, 0, st>>>(dz, lddz, x, ldx, n, K, N, dw, db); break;
+    case 1: linear_bwd_weight_kernel<1><<<grid, S_THREADS, 0, st>>>(dz, lddz, x, ldx, n, K, N, dw, db); break;
+    case 2: linear_bwd_weight_kernel<2><<<grid, S_THREADS, 0, st>>>(dz, lddz, x, ldx, n, K, N, dw, db); break;
+    case 3: linear_bwd_weight_kernel<3><<<grid, S_THREADS, 0, st>>>(dz, lddz, x, ldx, n, K, N, dw, db); break;
+    default: linear_bwd_weight_kernel<4><<<grid, S_THREADS, 0, st>>>(dz, lddz, x, ldx, n, K, N, dw, db); break;
     }
     RSDF_RETURN_LAUNCH();
 }

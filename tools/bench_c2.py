@@ -18,7 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--width", type=int, default=800)
     ap.add_argument("--height", type=int, default=800)
-    ap.add_argument("--chunk", type=int, default=8192)
+    ap.add_argument("--chunk", type=int, default=16384)
     ap.add_argument("--stage", type=int, default=1)
     ap.add_argument("--tex-hidden", type=int, default=128)
     ap.add_argument("--steps", type=int, default=1)
@@ -64,14 +64,22 @@ def main():
     def step():
         for p in model.parameters():
             p.grad = None
+        em = model.emitter
         if model.stage:
-            model.emitter.build_mips()
+            # one prefilter per step; the chunks see detached leaves of the filtered maps and their gradients are
+            # pushed through build_mips once at the end (instead of once per chunk via retain_graph)
+            em.build_mips()
+            built = em.specular + [em.diffuse]
+            leaves = [t.detach().requires_grad_(True) for t in built]
+            em.specular, em.diffuse = leaves[:-1], leaves[-1]
         total = 0
         for s in range(0, n, args.chunk):
             out = model.forward_(rays[s:s + args.chunk], stratified_u=u[s:s + args.chunk])
             total += int(out["num_samples"])
             key = "comp_rgb_phys_full" if model.stage else "comp_rgb_full"
-            (out[key] * cot[s:s + args.chunk]).sum().backward(retain_graph=bool(model.stage))
+            (out[key] * cot[s:s + args.chunk]).sum().backward()
+        if model.stage:
+            torch.autograd.backward(built, [l.grad if l.grad is not None else torch.zeros_like(l) for l in leaves])
         return total
 
     step()
