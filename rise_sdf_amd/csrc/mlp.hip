@@ -16,7 +16,6 @@
 
 namespace {
 
-constexpr int THREADS = 256;
 
 __device__ __forceinline__ float act_fwd(float z, int act)
 {
