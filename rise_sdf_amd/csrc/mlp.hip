@@ -381,6 +381,7 @@ int rsdf_linear_bwd_input(const float *dy, const float *y, int lddy, const float
 {
     RSDF_CHECK_ARG(K >= 1 && K <= 128 && N >= 1 && N <= 128, "linear_bwd_input: K and N must be in [1,128]");
     RSDF_CHECK_ARG(lddy >= N, "linear_bwd_input: lddy < N");
+    if (n <= 0) return 0;
     RSDF_CHECK_ARG(act == RSDF_ACT_NONE || y != nullptr, "linear_bwd_input: activation needs y");
     if (dx) {
         RSDF_CHECK_ARG(k0 >= 0 && Kout >= 1 && k0 + Kout <= K, "linear_bwd_input: bad column window");

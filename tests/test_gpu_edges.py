@@ -1,0 +1,92 @@
+"""GPU edge cases: empty and tiny batches, odd widths, through the same entry points as the parity tests."""
+import math
+
+import pytest
+import torch
+
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n", [0, 1, 31, 33])
+@pytest.mark.parametrize("K,N,act", [(73, 128, "relu"), (84, 6, "sigmoid"), (5, 1, "none")])
+def test_linear_small_batches_and_odd_widths(dev, n, K, N, act):
+    from rise_sdf_amd import ops
+    g = torch.Generator().manual_seed(n * 100 + K)
+    x, w, b = torch.randn(n, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+    gy = torch.randn(n, N, generator=g)
+    f = {"relu": torch.relu, "sigmoid": torch.sigmoid, "none": lambda t: t}[act]
+    xo, wo, bo = [t.double().requires_grad_(True) for t in (x, w, b)]
+    yo = f(torch.nn.functional.linear(xo, wo, bo))
+    (yo * gy.double()).sum().backward()
+    xg, wg, bg = [t.to(dev).requires_grad_(True) for t in (x, w, b)]
+    yg = ops.linear(xg, wg, bg, act=act)
+    assert yg.shape == (n, N)
+    (yg * gy.to(dev)).sum().backward()
+    if n == 0:
+        assert float(wg.grad.abs().max()) == 0.0 and float(bg.grad.abs().max()) == 0.0
+        return
+    assert rel_err(yg, yo) < 1e-5
+    assert rel_err(xg.grad, xo.grad) < 1e-5
+    assert rel_err(wg.grad, wo.grad) < 2e-5
+    assert rel_err(bg.grad, bo.grad) < 2e-5
+
+
+def test_empty_batches_of_the_frontend_and_loss(dev):
+    from rise_sdf_amd import ops
+    from rise_sdf_amd.loss import loss_tail
+    e64 = torch.zeros(0, dtype=torch.int64, device=dev)
+    rays, rgb, fg = ops.gen_rays(torch.zeros(1, dtype=torch.int64, device=dev), e64, e64,
+                                 torch.zeros(4, 4, 3, device=dev), torch.zeros(1, 3, 4, device=dev),
+                                 torch.zeros(1, 4, 4, 3, device=dev), torch.zeros(1, 4, 4, device=dev),
+                                 torch.ones(3, device=dev), apply_mask=True)
+    assert rays.shape == (0, 6) and rgb.shape == (0, 3) and fg.shape == (0,)
+    # occupancy update with no touched cells only re-thresholds
+    occs = torch.tensor([0.0, 0.2, 0.4, 0.6], device=dev)
+    binary = torch.zeros(4, dtype=torch.uint8, device=dev)
+    ops.occ_update(occs, binary, e64, torch.zeros(0, device=dev), 0.95, 0.25)
+    assert binary.cpu().tolist() == [0, 0, 1, 1]
+    # a batch whose rays are all invalid and that has no samples: means over nothing are NaN and, as in the
+    # reference (NaN * lambda), so is the weighted sum
+    N = 8
+    out = {"comp_rgb_full": torch.rand(N, 3, device=dev, requires_grad=True),
+           "opacity": torch.rand(N, 1, device=dev).clamp(0.1, 0.9).requires_grad_(True),
+           "rays_valid_full": torch.zeros(N, 1, dtype=torch.bool, device=dev),
+           "sdf_samples": torch.zeros(0, device=dev, requires_grad=True),
+           "sdf_grad_samples": torch.zeros(0, 3, device=dev, requires_grad=True)}
+    batch = {"rgb": torch.rand(N, 3, device=dev), "fg_mask": torch.ones(N, device=dev)}
+    loss, terms = loss_tail(out, batch, {"lambda_mask": 1.0, "lambda_opaque": 0.1})
+    assert math.isnan(float(terms["loss_rgb_mse"])) and math.isnan(float(terms["loss_eikonal"]))
+    assert math.isfinite(float(terms["loss_mask"])) and math.isfinite(float(terms["loss_opaque"]))
+    assert math.isnan(float(loss))
+    loss.backward()   # must not fault
+
+
+@pytest.mark.parametrize("S", [1, 7, 33])
+def test_fused_field_tiny_sample_counts(dev, S):
+    """The fused stencil kernels on fewer samples than one 32-row tile."""
+    import oracle
+    from rise_sdf_amd import ops
+    from test_gpu_model import model_config, oracle_params
+    import rise_sdf_amd as R
+    torch.manual_seed(0)
+    model = R.make("neus", model_config(n_levels=4, hidden=32)).to(dev)
+    model.train()
+    model.geometry.update_step(0, 0)
+    g = torch.Generator().manual_seed(S)
+    n_rays = 3
+    rays_o = torch.randn(n_rays, 3, generator=g) * 0.2
+    rays_d = torch.nn.functional.normalize(torch.randn(n_rays, 3, generator=g), dim=-1)
+    ri = torch.sort(torch.randint(0, n_rays, (S,), generator=g)).values
+    ts = torch.rand(S, generator=g)
+    te = ts + 0.01
+    geo = model.geometry
+    sdf7t, feat = geo.sdf7_from_rays(rays_o.to(dev), rays_d.to(dev), ri.to(dev), ts.to(dev), te.to(dev), want_feature=True)
+    assert sdf7t.shape == (7, S) and feat.shape == (S, 13)
+    out7 = geo.field7_from_rays(rays_o.to(dev), rays_d.to(dev), ri.to(dev), ts.to(dev), te.to(dev))
+    ref = out7.view(S, 7, -1)
+    assert torch.allclose(sdf7t.t(), ref[:, :, 0], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(feat, ref[:, 0], rtol=1e-5, atol=1e-6)
+    (sdf7t.sum() + feat.sum()).backward()
+    assert bool(torch.isfinite(geo.encoding.encoding.encoding.params.grad).all())
