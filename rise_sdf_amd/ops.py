@@ -281,10 +281,26 @@ class _HashGrid(torch.autograd.Function):
         n = xf.shape[0]
         LF = meta.n_levels * meta.n_features
         col = 3 if include_xyz else 0
-        out = torch.empty(n, col + LF, dtype=torch.float32, device=xf.device)
-        check(lib().rsdf_hashgrid_fwd(ptr(xf), ptr(tb), ctypes.byref(meta), n, n_active, ptr(out),
-                                      col + LF, col, int(include_xyz), float(xyz_scale),
-                                      float(xyz_offset), stream_ptr()), "hashgrid_fwd")
+        if fd7_eps_unit is not None and meta.n_features == 2 and n % 7 == 0 and n > 0:
+            # x is the [S,7,3] stencil: gather with the stencil-aware kernel (8..32 merged corners per level
+            # instead of 56, bit-identical values) and lay the level planes out as the reference-shaped rows
+            S = n // 7
+            Lv = meta.n_levels
+            x7t = xf.view(S, 7, 3).permute(1, 0, 2).contiguous()
+            planes = torch.empty(Lv, 7, S, 2, dtype=torch.float32, device=xf.device)
+            if n_active < Lv:
+                planes[n_active:].zero_()
+            check(lib().rsdf_hashgrid_fwd_fd7(ptr(x7t), ptr(tb), ctypes.byref(meta), S, n_active, ptr(planes),
+                                              stream_ptr()), "hashgrid_fwd_fd7")
+            out = torch.empty(n, col + LF, dtype=torch.float32, device=xf.device)
+            out[:, col:].view(S, 7, Lv, 2).copy_(planes.permute(2, 1, 0, 3))
+            if include_xyz:
+                out[:, :3] = xf * xyz_scale + xyz_offset
+        else:
+            out = torch.empty(n, col + LF, dtype=torch.float32, device=xf.device)
+            check(lib().rsdf_hashgrid_fwd(ptr(xf), ptr(tb), ctypes.byref(meta), n, n_active, ptr(out),
+                                          col + LF, col, int(include_xyz), float(xyz_scale),
+                                          float(xyz_offset), stream_ptr()), "hashgrid_fwd")
         ctx.save_for_backward(x if x.requires_grad else xf)
         ctx.meta, ctx.n_active, ctx.col, ctx.n_params = meta, n_active, col, tb.numel()
         ctx.fd7, ctx.xyz_scale = fd7_eps_unit, float(xyz_scale)
