@@ -188,14 +188,14 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
-    from helpers import camera_rays
     from rise_sdf_amd import _lib
+    from rise_sdf_amd.ray_utils import orbit_view_rays
     model = build_model(dev, args)
-    rays_cpu = camera_rays(args.width, args.height, seed=rdist.rank_seed(0, rank))
-    n_rays = rays_cpu.shape[0]
+    rays = orbit_view_rays(args.width, args.height, seed=rdist.rank_seed(0, rank), device=dev)   # HIP ray generator
+    n_rays = rays.shape[0]
     g = torch.Generator().manual_seed(2 + rank)
     jitter_cpu = torch.rand(n_rays, generator=g)
-    rays, jitter = rays_cpu.to(dev), jitter_cpu.to(dev)
+    rays_cpu, jitter = rays.cpu(), jitter_cpu.to(dev)
     cot = [torch.randn(n_rays, 1, generator=g).to(dev), torch.randn(n_rays, 1, generator=g).to(dev),
            torch.randn(n_rays, 3, generator=g).to(dev)]
     buckets = rdist.GradBuckets(model.parameters())

@@ -98,3 +98,19 @@ def test_gen_rays_reference_fixture(dev, golden_dir):
     assert torch.equal(rays.cpu()[:, :3], z["rays_o"])
     ref_d = torch.nn.functional.normalize(z["rays_d"], p=2, dim=-1)
     assert torch.allclose(rays.cpu()[:, 3:], ref_d, rtol=0, atol=2e-7)
+
+
+def test_orbit_view_rays_match_the_test_helper(dev):
+    """The package's synthetic view generator (used by bench.py) vs tests/helpers.camera_rays (oracle get_rays)."""
+    from helpers import camera_rays
+    from rise_sdf_amd.ray_utils import get_ray_directions, get_rays, orbit_view_rays
+    ref = camera_rays(40, 30, seed=5)
+    got = orbit_view_rays(40, 30, seed=5, device=dev).cpu()
+    assert torch.equal(got[:, :3], ref[:, :3])
+    assert torch.allclose(got[:, 3:], ref[:, 3:], rtol=0, atol=3e-7)
+    dirs = oracle.get_ray_directions(40, 30, 50.0, 51.0, 20.0, 15.0)
+    assert torch.equal(get_ray_directions(40, 30, 50.0, 51.0, 20.0, 15.0), dirs)
+    c2w = torch.tensor([[0.0, 1, 0, 0.5], [0, 0, 1, -0.2], [1, 0, 0, 2.0]])
+    ro, rd = get_rays(dirs.to(dev), c2w.to(dev))
+    ro_ref, rd_ref = oracle.get_rays(dirs, c2w)
+    assert torch.equal(ro.cpu(), ro_ref) and torch.allclose(rd.cpu(), rd_ref, rtol=1e-6, atol=1e-6)

@@ -25,7 +25,7 @@ def main():
     args = ap.parse_args()
     import rise_sdf_amd as R
     from rise_sdf_amd import _lib
-    from helpers import camera_rays
+    from rise_sdf_amd.ray_utils import orbit_view_rays
     import bench
     dev = torch.device("cuda", 0)
     cfg = bench.c1_config(hidden=64)
@@ -55,7 +55,7 @@ def main():
         l0.weight_v[:, 3:] = torch.randn_like(l0.weight_v[:, 3:]) * 0.05
     model.update_step(0, 0)
     model.background_color = torch.ones(3, device=dev)
-    rays = camera_rays(args.width, args.height, seed=0).to(dev)
+    rays = orbit_view_rays(args.width, args.height, seed=0, device=dev)
     n = rays.shape[0]
     g = torch.Generator().manual_seed(2)
     u = torch.rand(n, generator=g).to(dev)
