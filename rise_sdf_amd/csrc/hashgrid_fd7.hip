@@ -35,7 +35,10 @@ constexpr int F_THREADS = 256;   // forward: samples per workgroup
 // producer: samples per workgroup.  Large on purpose: a workgroup appends one run per bin per round,
 // and HBM write efficiency follows the run length (256 threads: ~0.4 KB runs, 1.6 TB/s; 1024 threads:
 // ~1.5 KB runs) -- measured with the RSDF ablation in profiles/README.md.
-constexpr int P_THREADS = 1024;
+#ifndef P_THREADS_CFG
+#define P_THREADS_CFG 1024
+#endif
+constexpr int P_THREADS = P_THREADS_CFG;
 constexpr int ROUND_RECS = 8;
 constexpr int STAGE_CAP = P_THREADS * ROUND_RECS;
 #ifndef MERGE_MAX_RUNS
