@@ -317,10 +317,12 @@ int rsdf_split_shade1_bwd(const float *albedo6, const float *metallic2, const fl
 int rsdf_diffuse_cubemap_fwd(const float *cubemap, int R, float *out, void *stream);
 int rsdf_diffuse_cubemap_bwd(const float *grad_out, int R, float *grad_cubemap, void *stream);
 int rsdf_specular_bounds(int R, float cos_cutoff, float *bounds, void *stream);
-int rsdf_specular_cubemap_fwd(const float *cubemap, const float *bounds, int R, float roughness,
-                              float cos_cutoff, float *out4, void *stream);
-int rsdf_specular_cubemap_bwd(const float *grad_out, int grad_channels, const float *bounds, int R,
-                              float roughness, float cos_cutoff, float *grad_cubemap, void *stream);
+int rsdf_cubemap_texel_table(int R, float *table /* [6,R,R,4]: unit direction, solid angle / 4 */, void *stream);
+int rsdf_specular_cubemap_fwd(const float *cubemap, const float *bounds, const float *texel_table /*nullable*/,
+                              int R, float roughness, float cos_cutoff, float *out4, void *stream);
+int rsdf_specular_cubemap_bwd(const float *grad_out, int grad_channels, const float *bounds,
+                              const float *texel_table /*nullable*/, int R, float roughness, float cos_cutoff,
+                              float *grad_cubemap, void *stream);
 int rsdf_cubemap_avgpool(const float *cubemap, int R, int C, float *out, void *stream);
 int rsdf_cube_sample_fwd(const float *const *mips /*host array*/, int n_mips, int R0, int C,
                          const float *dirs, const float *level, int64_t n, float *out, void *stream);

@@ -134,6 +134,8 @@ bounds_kernel(int R, float cos_cutoff, float *__restrict__ bounds)
 // GGX NDF at cos = V.H with H = normalize(A + B), A and B unit (bsdf.h ndf_ggx: a2 / (pi d^2), d = (c a2 - c) c + 1).
 // d = 1 - c^2 (1 - a2) cancels catastrophically in fp32 for narrow lobes (a2 ~ 4e-5 at roughness 0.08), so it is
 // evaluated as d = sin^2 (1 - a2) + a2 with sin^2 = |A x B|^2 / |A + B|^2 -- the same function, full precision.
+constexpr int COOP_MAX_R = 128;   // maps up to this resolution run one wavefront per texel
+
 __device__ __forceinline__ float ndf_ggx_pair(float a2, V3 A, V3 B)
 {
     const V3 c = v3(A.y * B.z - A.z * B.y, A.z * B.x - A.x * B.z, A.x * B.y - A.y * B.x);
@@ -144,15 +146,22 @@ __device__ __forceinline__ float ndf_ggx_pair(float a2, V3 A, V3 B)
 }
 
 // forward: out4 = [sum w c, sum w];  backward (gather): dcube[L] = area(L)/4 * sum_V g[V] (L.V) D(V.H)
-template <bool BWD>
+// COOP = false: one thread per texel walks its window (large maps: millions of threads).
+// COOP = true:  one wavefront per texel, the lanes stride over the window and reduce -- the coarse levels have few
+//               texels (6144 at 32^2) but windows of thousands, which a thread per texel leaves latency bound.
+template <bool BWD, bool COOP>
 __global__ void __launch_bounds__(THREADS)
-specular_kernel(const float *__restrict__ src, int src_ch, const float *__restrict__ bounds, int R,
-                float roughness, float cos_cutoff, float *__restrict__ dst)
+specular_kernel(const float *__restrict__ src, int src_ch, const float *__restrict__ bounds,
+                const float4 *__restrict__ table, int R, float roughness, float cos_cutoff,
+                float *__restrict__ dst)
 {
+    // table (nullable) = per texel (unit direction, solid angle / 4) from texel_table_kernel: one 16-byte load
+    // replaces the direction normalisation and the two area factors of every window iteration
     extern __shared__ float s_side[];
     for (int i = threadIdx.x; i < R; i += THREADS) s_side[i] = area_side(i, R);
     __syncthreads();
-    const int idx = blockIdx.x * THREADS + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int idx = COOP ? blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6) : blockIdx.x * THREADS + threadIdx.x;
     if (idx >= 6 * R * R) return;
     const int s0 = idx / (R * R), y0 = (idx / R) % R, x0 = idx % R;
     const V3 A = cube_to_dir(x0, y0, s0, R);
@@ -162,17 +171,31 @@ specular_kernel(const float *__restrict__ src, int src_ch, const float *__restri
         const float *b = bounds + (size_t)idx * 24 + s * 4;
         const int xmin = (int)b[0], xmax = (int)b[1], ymin = (int)b[2], ymax = (int)b[3];
         if (xmin > xmax) continue;
-        for (int y = ymin; y <= ymax; ++y)
-            for (int x = xmin; x <= xmax; ++x) {
-                const V3 B = cube_to_dir(x, y, s, R);
-                const float d = dot3(B, A);
-                if (d < cos_cutoff) continue;
-                const float geom = fmaxf(d, 0.0f) * ndf_ggx_pair(a2, A, B);
-                const float w = BWD ? geom : geom * s_side[x] * s_side[y] / 4.0f;
-                const float *p = src + (size_t)((s * R + y) * R + x) * src_ch;
-                c0 += p[0] * w; c1 += p[1] * w; c2 += p[2] * w;
-                wsum += w;
+        const int bw = xmax - xmin + 1, cnt = bw * (ymax - ymin + 1);
+        for (int i = COOP ? lane : 0; i < cnt; i += COOP ? 64 : 1) {
+            const int y = ymin + i / bw, x = xmin + i % bw;
+            V3 B;
+            float area4;
+            if (table != nullptr) {
+                const float4 t = table[(s * R + y) * R + x];
+                B = v3(t.x, t.y, t.z);
+                area4 = t.w;
+            } else {
+                B = cube_to_dir(x, y, s, R);
+                area4 = s_side[x] * s_side[y] / 4.0f;
             }
+            const float d = dot3(B, A);
+            if (d < cos_cutoff) continue;
+            const float geom = fmaxf(d, 0.0f) * ndf_ggx_pair(a2, A, B);
+            const float w = BWD ? geom : geom * area4;
+            const float *p = src + (size_t)((s * R + y) * R + x) * src_ch;
+            c0 += p[0] * w; c1 += p[1] * w; c2 += p[2] * w;
+            wsum += w;
+        }
+    }
+    if (COOP) {
+        c0 = wave_sum(c0); c1 = wave_sum(c1); c2 = wave_sum(c2); wsum = wave_sum(wsum);
+        if (lane != 0) return;
     }
     if (BWD) {
         const float a = s_side[x0] * s_side[y0] / 4.0f;
@@ -182,6 +205,16 @@ specular_kernel(const float *__restrict__ src, int src_ch, const float *__restri
         float *o = dst + (size_t)idx * 4;
         o[0] = c0; o[1] = c1; o[2] = c2; o[3] = wsum;
     }
+}
+
+__global__ void __launch_bounds__(THREADS)
+texel_table_kernel(int R, float4 *__restrict__ table)
+{
+    const int idx = blockIdx.x * THREADS + threadIdx.x;
+    if (idx >= 6 * R * R) return;
+    const int s = idx / (R * R), y = (idx / R) % R, x = idx % R;
+    const V3 d = cube_to_dir(x, y, s, R);
+    table[idx] = make_float4(d.x, d.y, d.z, area_side(x, R) * area_side(y, R) / 4.0f);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -413,21 +446,42 @@ int rsdf_specular_bounds(int R, float cos_cutoff, float *bounds, void *stream)
     RSDF_RETURN_LAUNCH();
 }
 
-int rsdf_specular_cubemap_fwd(const float *cubemap, const float *bounds, int R, float roughness,
-                              float cos_cutoff, float *out4, void *stream)
+int rsdf_cubemap_texel_table(int R, float *table, void *stream)
 {
-    RSDF_CHECK_ARG(R >= 1 && R <= 4096, "specular_cubemap_fwd: bad resolution");
-    specular_kernel<false><<<rsdf_blocks(6 * R * R, THREADS), THREADS, R * sizeof(float), (hipStream_t)stream>>>(
-        cubemap, 3, bounds, R, roughness, cos_cutoff, out4);
+    RSDF_CHECK_ARG(R >= 1 && table != nullptr, "cubemap_texel_table: bad arguments");
+    texel_table_kernel<<<rsdf_blocks(6 * R * R, THREADS), THREADS, 0, (hipStream_t)stream>>>(
+        R, reinterpret_cast<float4 *>(table));
     RSDF_RETURN_LAUNCH();
 }
 
-int rsdf_specular_cubemap_bwd(const float *grad_out, int grad_channels, const float *bounds, int R,
-                              float roughness, float cos_cutoff, float *grad_cubemap, void *stream)
+int rsdf_specular_cubemap_fwd(const float *cubemap, const float *bounds, const float *texel_table, int R,
+                              float roughness, float cos_cutoff, float *out4, void *stream)
 {
+    const float4 *table = reinterpret_cast<const float4 *>(texel_table);
+    RSDF_CHECK_ARG(R >= 1 && R <= 4096, "specular_cubemap_fwd: bad resolution");
+    if (R <= COOP_MAX_R)
+        specular_kernel<false, true><<<rsdf_blocks(6 * R * R, THREADS / 64), THREADS, R * sizeof(float),
+                                       (hipStream_t)stream>>>(cubemap, 3, bounds, table, R, roughness, cos_cutoff, out4);
+    else
+        specular_kernel<false, false><<<rsdf_blocks(6 * R * R, THREADS), THREADS, R * sizeof(float),
+                                        (hipStream_t)stream>>>(cubemap, 3, bounds, table, R, roughness, cos_cutoff, out4);
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_specular_cubemap_bwd(const float *grad_out, int grad_channels, const float *bounds,
+                              const float *texel_table, int R, float roughness, float cos_cutoff,
+                              float *grad_cubemap, void *stream)
+{
+    const float4 *table = reinterpret_cast<const float4 *>(texel_table);
     RSDF_CHECK_ARG(R >= 1 && R <= 4096 && grad_channels >= 3, "specular_cubemap_bwd: bad arguments");
-    specular_kernel<true><<<rsdf_blocks(6 * R * R, THREADS), THREADS, R * sizeof(float), (hipStream_t)stream>>>(
-        grad_out, grad_channels, bounds, R, roughness, cos_cutoff, grad_cubemap);
+    if (R <= COOP_MAX_R)
+        specular_kernel<true, true><<<rsdf_blocks(6 * R * R, THREADS / 64), THREADS, R * sizeof(float),
+                                      (hipStream_t)stream>>>(grad_out, grad_channels, bounds, table, R, roughness,
+                                                             cos_cutoff, grad_cubemap);
+    else
+        specular_kernel<true, false><<<rsdf_blocks(6 * R * R, THREADS), THREADS, R * sizeof(float),
+                                       (hipStream_t)stream>>>(grad_out, grad_channels, bounds, table, R, roughness,
+                                                              cos_cutoff, grad_cubemap);
     RSDF_RETURN_LAUNCH();
 }
 

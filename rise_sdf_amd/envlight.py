@@ -62,6 +62,7 @@ def ndf_cutoff(roughness, cutoff, n_samples=1000000):
 
 
 _bounds_cache = {}
+_table_cache = {}
 
 
 def specular_bounds(res, roughness, cutoff, device):
@@ -74,27 +75,38 @@ def specular_bounds(res, roughness, cutoff, device):
     return _bounds_cache[key]
 
 
+def texel_table(res, device):
+    """[6,R,R,4] = (unit texel direction, solid angle / 4), cached per resolution like the bounds."""
+    key = (res, str(device))
+    if key not in _table_cache:
+        t = torch.empty(6, res, res, 4, dtype=torch.float32, device=device)
+        check(lib().rsdf_cubemap_texel_table(res, ptr(t), stream_ptr()), "cubemap_texel_table")
+        _table_cache[key] = t
+    return _table_cache[key]
+
+
 class _SpecularCubemap(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cubemap, roughness, cosc, bounds):
         c = _f(cubemap)
         require_device(c, bounds)
         R = c.shape[1]
+        table = texel_table(R, c.device)
         out = torch.empty(6, R, R, 4, dtype=torch.float32, device=c.device)
-        check(lib().rsdf_specular_cubemap_fwd(ptr(c), ptr(bounds), R, float(roughness), float(cosc), ptr(out),
-                                              stream_ptr()), "specular_cubemap_fwd")
-        ctx.save_for_backward(bounds)
+        check(lib().rsdf_specular_cubemap_fwd(ptr(c), ptr(bounds), ptr(table), R, float(roughness), float(cosc),
+                                              ptr(out), stream_ptr()), "specular_cubemap_fwd")
+        ctx.save_for_backward(bounds, table)
         ctx.args = (R, float(roughness), float(cosc))
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        (bounds,) = ctx.saved_tensors
+        bounds, table = ctx.saved_tensors
         R, roughness, cosc = ctx.args
         g = _f(dout)
         gc = torch.empty(6, R, R, 3, dtype=torch.float32, device=g.device)
-        check(lib().rsdf_specular_cubemap_bwd(ptr(g), 4, ptr(bounds), R, roughness, cosc, ptr(gc), stream_ptr()),
-              "specular_cubemap_bwd")
+        check(lib().rsdf_specular_cubemap_bwd(ptr(g), 4, ptr(bounds), ptr(table), R, roughness, cosc, ptr(gc),
+                                              stream_ptr()), "specular_cubemap_bwd")
         return gc, None, None, None
 
 
