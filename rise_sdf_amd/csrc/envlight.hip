@@ -68,22 +68,26 @@ diffuse_kernel(const float *__restrict__ src, int R, float *__restrict__ dst)
     extern __shared__ float s_side[];  // [R]
     for (int i = threadIdx.x; i < R; i += THREADS) s_side[i] = area_side(i, R);
     __syncthreads();
-    const int idx = blockIdx.x * THREADS + threadIdx.x;
+    // one wavefront per output texel; the lanes stride over the 6 R^2 input texels and reduce (R is 16: a thread
+    // per texel would be 1536 threads of 1536 serial iterations)
+    const int lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6);
     if (idx >= 6 * R * R) return;
     const int s0 = idx / (R * R), y0 = (idx / R) % R, x0 = idx % R;
     const V3 A = cube_to_dir(x0, y0, s0, R);
     float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-    for (int s = 0; s < 6; ++s)
-        for (int y = 0; y < R; ++y)
-            for (int x = 0; x < R; ++x) {
-                const V3 B = cube_to_dir(x, y, s, R);
-                const float ct = fminf(fmaxf(dot3(A, B), 0.0f), 0.999f);
-                // forward: weight uses the INPUT texel's area; backward (gather at the input texel A): the
-                // area factor is A's own and is applied after the loop
-                const float w = BWD ? ct : ct * s_side[x] * s_side[y] / 3.141592f;
-                const float *p = src + ((s * R + y) * R + x) * 3;
-                c0 += p[0] * w; c1 += p[1] * w; c2 += p[2] * w;
-            }
+    for (int i = lane; i < 6 * R * R; i += 64) {
+        const int s = i / (R * R), y = (i / R) % R, x = i % R;
+        const V3 B = cube_to_dir(x, y, s, R);
+        const float ct = fminf(fmaxf(dot3(A, B), 0.0f), 0.999f);
+        // forward: weight uses the INPUT texel's area; backward (gather at the input texel A): the
+        // area factor is A's own and is applied after the loop
+        const float w = BWD ? ct : ct * s_side[x] * s_side[y] / 3.141592f;
+        const float *p = src + i * 3;
+        c0 += p[0] * w; c1 += p[1] * w; c2 += p[2] * w;
+    }
+    c0 = wave_sum(c0); c1 = wave_sum(c1); c2 = wave_sum(c2);
+    if (lane != 0) return;
     if (BWD) {
         const float a = s_side[x0] * s_side[y0] / 3.141592f;
         c0 *= a; c1 *= a; c2 *= a;
@@ -428,14 +432,14 @@ extern "C" {
 int rsdf_diffuse_cubemap_fwd(const float *cubemap, int R, float *out, void *stream)
 {
     RSDF_CHECK_ARG(R >= 1 && R <= 64, "diffuse_cubemap: R must be in [1,64] (all-pairs filter)");
-    diffuse_kernel<false><<<rsdf_blocks(6 * R * R, THREADS), THREADS, R * sizeof(float), (hipStream_t)stream>>>(cubemap, R, out);
+    diffuse_kernel<false><<<rsdf_blocks(6 * R * R, THREADS / 64), THREADS, R * sizeof(float), (hipStream_t)stream>>>(cubemap, R, out);
     RSDF_RETURN_LAUNCH();
 }
 
 int rsdf_diffuse_cubemap_bwd(const float *grad_out, int R, float *grad_cubemap, void *stream)
 {
     RSDF_CHECK_ARG(R >= 1 && R <= 64, "diffuse_cubemap: R must be in [1,64] (all-pairs filter)");
-    diffuse_kernel<true><<<rsdf_blocks(6 * R * R, THREADS), THREADS, R * sizeof(float), (hipStream_t)stream>>>(grad_out, R, grad_cubemap);
+    diffuse_kernel<true><<<rsdf_blocks(6 * R * R, THREADS / 64), THREADS, R * sizeof(float), (hipStream_t)stream>>>(grad_out, R, grad_cubemap);
     RSDF_RETURN_LAUNCH();
 }
 
