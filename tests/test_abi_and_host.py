@@ -157,3 +157,14 @@ def test_state_dict_layout_matches_reference(golden_dir):
     for prefix, mod in (("geometry", geometry), ("texture", texture), ("variance", variance), ("emitter", emitter)):
         mine = {k: list(v.shape) for k, v in mod.state_dict().items()}
         assert mine == ref[prefix], (prefix, sorted(set(mine) ^ set(ref[prefix])))
+
+
+def test_ray_directions_match_reference_golden(golden_dir):
+    """I0: rise_sdf_amd.ray_utils.get_ray_directions (host side) vs the reference's output (tests/golden/rays.npz)."""
+    import os
+    import numpy as np
+    from rise_sdf_amd.ray_utils import get_ray_directions
+    z = np.load(os.path.join(golden_dir, "rays.npz"))
+    W, H, f = int(z["W"]), int(z["H"]), float(z["focal"])
+    d = get_ray_directions(W, H, f, f, W / 2, H / 2)
+    assert torch.equal(d, torch.tensor(z["directions"]))
