@@ -138,7 +138,10 @@ bounds_kernel(int R, float cos_cutoff, float *__restrict__ bounds)
 // GGX NDF at cos = V.H with H = normalize(A + B), A and B unit (bsdf.h ndf_ggx: a2 / (pi d^2), d = (c a2 - c) c + 1).
 // d = 1 - c^2 (1 - a2) cancels catastrophically in fp32 for narrow lobes (a2 ~ 4e-5 at roughness 0.08), so it is
 // evaluated as d = sin^2 (1 - a2) + a2 with sin^2 = |A x B|^2 / |A + B|^2 -- the same function, full precision.
-constexpr int COOP_MAX_R = 128;   // maps up to this resolution run one wavefront per texel
+#ifndef COOP_MAX_R_CFG
+#define COOP_MAX_R_CFG 256
+#endif
+constexpr int COOP_MAX_R = COOP_MAX_R_CFG;   // maps up to this resolution run one wavefront per texel
 
 __device__ __forceinline__ float ndf_ggx_pair(float a2, V3 A, V3 B)
 {
