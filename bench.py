@@ -158,6 +158,17 @@ def roofline_from(summary, steps):
     out = {"bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
            "frac": round(ach / peak, 4), "traffic": None, "kernel": name,
            "avg_launch_ms": round(d["ms"] / d["calls"], 4), "launches": d["calls"]}
+    # the same pricing for the other heavy entry points (the north star quotes the hash gather separately)
+    others = {}
+    for k, v in summary.items():
+        b, _ = cost(k, v["args"][0])
+        if b is None or k == name or v["ms"] < 0.02 * d["ms"]:
+            continue
+        wk = sum(cost(k, a)[1] for a in v["args"])
+        a_, p_, u_ = (wk / (v["ms"] / 1e3) / 1e9, HBM_PEAK_GBS, "GB/s") if b == "hbm" else \
+            (wk / (v["ms"] / 1e3) / 1e12, MFMA_F32_PEAK_TF, "TFLOP/s")
+        others[k] = {"bound": b, "achieved": round(a_, 2), "peak": p_, "unit": u_, "frac": round(a_ / p_, 4)}
+    out["other_kernels"] = others
     if name.startswith("rsdf_sdfmlp_fd7"):
         # algorithmic fp32 flops against the fp32 MFMA peak; the kernel evaluates each fp32 product as six
         # bf16 x bf16 partial products on v_mfma_f32_32x32x16_bf16, whose own ceiling for
