@@ -3,7 +3,7 @@
 Layout (only what the path needs):
   csrc/            hand-written HIP kernels for gfx950 + the C ABI (include/risesdf_hip.h)
   _lib.py, ops.py  ctypes binding and torch.autograd wrappers (PyTorch = memory/stream plumbing)
-  nerfacc.py, tinycudann.py            drop-ins for the third-party surfaces the reference calls
+  nerfacc/, tinycudann.py, nvdiffrast/, renderutils.py, dropin.py   drop-ins for the third-party / JIT surfaces the reference calls
   network_utils.py, geometry.py, neus.py, volrend.py   host-side mirror of the reference's models/
   dist.py          ray-parallel multi-GPU helpers (RCCL gradient all-reduce)
 

@@ -24,10 +24,49 @@ from typing import Callable, List, Optional, Union
 import torch
 import torch.nn as nn
 
-from . import ops
-from .ops import (accumulate_along_rays, pack_info, ray_aabb_intersect,  # noqa: F401
-                  render_transmittance_from_alpha, render_visibility, render_weight_from_alpha,
-                  unpack_info)
+from .. import ops
+from ..ops import (accumulate_along_rays, pack_info,  # noqa: F401
+                   render_transmittance_from_alpha, render_visibility, render_weight_from_alpha,
+                   unpack_info)
+from ..ops import ray_aabb_intersect as _ray_aabb_intersect_1box
+
+
+def ray_aabb_intersect(rays_o, rays_d, aabbs, near_plane: float = -float("inf"),
+                       far_plane: float = float("inf"), miss_value: float = float("inf")):
+    """nerfacc 0.5.3 form, as called at models/neus.py:164:
+    ``ray_aabb_intersect(rays_o, rays_d, aabbs [M,6]) -> (t_mins [N,M], t_maxs [N,M], hits bool [N,M])``.
+    One slab-test kernel launch per box (M = 1 at the call site).  The slab test itself is the vendored
+    0.3.5 kernel's (lib/nerfacc/cuda/csrc/intersection.cu:16-66: t_min clamped to >= 0, miss = 1e10), so
+    ``hits`` = "t_min is not the miss marker" and misses are rewritten to ``miss_value``."""
+    aabbs = torch.as_tensor(aabbs, dtype=torch.float32, device=rays_o.device).reshape(-1, 6)
+    t_mins, t_maxs = [], []
+    for m in range(aabbs.shape[0]):
+        tn, tf = _ray_aabb_intersect_1box(rays_o, rays_d, aabbs[m].contiguous())
+        t_mins.append(tn)
+        t_maxs.append(tf)
+    t_mins, t_maxs = torch.stack(t_mins, -1), torch.stack(t_maxs, -1)
+    hits = t_mins < 1e10
+    t_mins = torch.clamp(t_mins, min=near_plane, max=far_plane)
+    t_maxs = torch.clamp(t_maxs, min=near_plane, max=far_plane)
+    hits = hits & (t_maxs > t_mins)
+    t_mins = torch.where(hits, t_mins, torch.full_like(t_mins, miss_value))
+    t_maxs = torch.where(hits, t_maxs, torch.full_like(t_maxs, miss_value))
+    return t_mins, t_maxs, hits
+
+
+def render_weight_from_density(t_starts, t_ends, sigmas, packed_info=None, ray_indices=None, n_rays=None,
+                               prefix_trans=None):
+    """nerfacc 0.5.3 (models/neus.py:195-197, models/volrend.py:227-233): flat ``[S]`` inputs ->
+    ``(weights, trans, alphas)`` with ``alpha = 1 - exp(-sigma (t_end - t_start))`` and the same per-ray scan
+    as :func:`render_weight_from_alpha` (lib/nerfacc/vol_rendering.py:201-262 has the 0.3.5 wording).
+    Only the learned-background branch of the reference uses densities (disabled in both shipped configs), so
+    the density -> alpha step is three torch elementwise ops in front of the HIP scan."""
+    if prefix_trans is not None:
+        raise NotImplementedError("prefix_trans is not used by RISE-SDF")
+    alphas = 1.0 - torch.exp(-sigmas * (t_ends - t_starts))
+    weights, trans = render_weight_from_alpha(alphas, packed_info=packed_info, ray_indices=ray_indices,
+                                              n_rays=n_rays)
+    return weights, trans, alphas
 
 
 class ContractionType(Enum):
@@ -140,7 +179,7 @@ def ray_marching(rays_o, rays_d, t_min=None, t_max=None, scene_aabb=None, grid=N
         raise ValueError("Only one of `alpha_fn` and `sigma_fn` should be provided.")
     if t_min is None or t_max is None:
         if scene_aabb is not None:
-            t_min, t_max = ray_aabb_intersect(rays_o, rays_d, scene_aabb)
+            t_min, t_max = _ray_aabb_intersect_1box(rays_o, rays_d, scene_aabb)
         else:
             t_min = torch.zeros_like(rays_o[..., 0])
             t_max = torch.ones_like(rays_o[..., 0]) * 1e10
@@ -220,7 +259,7 @@ class OccGridEstimator(nn.Module):
         near = None if near_plane is None else float(near_plane)
         far = None if far_plane is None else float(far_plane)
         if t_min is None or t_max is None:
-            t_min, t_max = ray_aabb_intersect(rays_o, rays_d, self.aabbs[0])
+            t_min, t_max = _ray_aabb_intersect_1box(rays_o, rays_d, self.aabbs[0])
         if near is not None:
             t_min = torch.clamp(t_min, min=near)
         if far is not None:
@@ -273,3 +312,6 @@ class OccGridEstimator(nn.Module):
             raise RuntimeError("update_every_n_steps() is a training-time call")
         if step % n == 0:
             self._update(step, occ_eval_fn, occ_thre, ema_decay, warmup_steps)
+
+
+from . import volrend  # noqa: E402,F401  (``from nerfacc.volrend import ...``, models/volrend.py:10-14)

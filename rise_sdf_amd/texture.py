@@ -43,18 +43,10 @@ class VanillaFrequency(nn.Module):
                                                     - torch.arange(0, self.N_freqs)).clamp(0, 1))) / 2.0
 
 
-class SphericalHarmonics(nn.Module):
+def SphericalHarmonics(in_channels, config):
     """tcnn.Encoding(n, {otype: SphericalHarmonics, degree: d}) (models/network_utils.py:98-99)."""
-
-    def __init__(self, in_channels, config):
-        super().__init__()
-        assert in_channels == 3
-        self.n_input_dims, self.degree = 3, int(config["degree"])
-        assert 1 <= self.degree <= 5, "SH degree <= 5 (the RISE-SDF config uses 5; NeuS uses 4)"
-        self.n_output_dims = self.degree ** 2
-
-    def forward(self, d01):
-        return T.sh_encode(d01, self.degree)
+    from . import tinycudann as tcnn
+    return tcnn.Encoding(in_channels, dict(config, otype="SphericalHarmonics"))
 
 
 def get_dir_or_pos_encoding(n_input_dims, config):

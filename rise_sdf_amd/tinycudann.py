@@ -17,19 +17,32 @@ from . import _lib, ops
 
 
 class Encoding(nn.Module):
+    """``tcnn.Encoding(n_input_dims, encoding_config, seed=1337, dtype=None)``: constructing it returns the
+    implementation selected by ``encoding_config['otype']`` (a subclass, so ``isinstance(e, tcnn.Encoding)``
+    holds and ``params`` sits directly on the module as in tcnn's state_dict).  Common surface:
+    ``n_input_dims``, ``n_output_dims``, ``params``, ``dtype``, ``forward(x [S, n_input_dims]) -> [S, n_output_dims]``
+    (fp32)."""
+
+    def __new__(cls, n_input_dims=3, encoding_config=None, *args, **kwargs):
+        if cls is Encoding:
+            otype = str(dict(encoding_config or {}).get("otype", "HashGrid")).lower()
+            if otype not in _OTYPES:
+                raise NotImplementedError(f"tcnn.Encoding otype={dict(encoding_config or {}).get('otype')!r} is not "
+                                          "on the RISE-SDF hot path (implemented: HashGrid, SphericalHarmonics)")
+            cls = _OTYPES[otype]
+        return super().__new__(cls)
+
+
+class HashGridEncoding(Encoding):
     """``otype: HashGrid`` (aliases Grid/hashgrid).  One flat fp32 ``params`` Parameter laid out
     [level][entry][feature], initialised U(-1e-4, 1e-4) like tcnn's grid encodings."""
 
-    def __init__(self, n_input_dims: int, encoding_config: dict, seed: int = 1337,
-                 dtype=torch.float32, device=None):
+    def __init__(self, n_input_dims: int, encoding_config: dict, seed: int = 1337, dtype=None, device=None):
         super().__init__()
         cfg = dict(encoding_config)
-        otype = str(cfg.get("otype", "HashGrid")).lower()
-        if otype not in ("hashgrid", "grid"):
-            raise NotImplementedError(f"tcnn.Encoding otype={cfg.get('otype')!r} is not on the "
-                                      "RISE-SDF geometry path (HashGrid only)")
         if n_input_dims != 3:
             raise NotImplementedError("HashGrid is implemented for 3-D inputs")
+        self.otype = "HashGrid"
         self.n_input_dims = 3
         self.n_levels = int(cfg.get("n_levels", 16))
         self.n_features_per_level = int(cfg.get("n_features_per_level", 2))
@@ -55,6 +68,38 @@ class Encoding(nn.Module):
         return (f"HashGrid L={self.n_levels} F={self.n_features_per_level} "
                 f"T=2^{self.log2_hashmap_size} base={self.base_resolution} "
                 f"scale={self.per_level_scale} params={self.params.numel()}")
+
+
+class SphericalHarmonicsEncoding(Encoding):
+    """``otype: SphericalHarmonics`` (models/network_utils.py:98-99 with yaml ``degree: 5``): directions given
+    in [0,1]^3 (tcnn maps them to [-1,1] internally; callers pre-map with ``(d+1)/2``, models/texture.py:312,348)
+    -> ``degree^2`` real SH coefficients.  Parameter-free (``params`` is an empty tensor attribute).
+    Differentiable in the direction."""
+
+    def __init__(self, n_input_dims: int, encoding_config: dict, seed: int = 1337, dtype=None, device=None):
+        super().__init__()
+        cfg = dict(encoding_config)
+        if n_input_dims != 3:
+            raise NotImplementedError("SphericalHarmonics takes 3-D directions")
+        self.otype = "SphericalHarmonics"
+        self.degree = int(cfg.get("degree", 4))
+        if not 1 <= self.degree <= 5:
+            raise NotImplementedError("SphericalHarmonics degree must be in [1,5] (csrc/texture.hip)")
+        self.n_input_dims = 3
+        self.n_output_dims = self.degree * self.degree
+        self.params = torch.zeros(0, dtype=torch.float32)   # attribute only: nothing to learn or to checkpoint
+        self.dtype = torch.float32
+
+    def forward(self, d01: torch.Tensor) -> torch.Tensor:
+        from . import texture_ops
+        return texture_ops.sh_encode(d01.reshape(-1, 3), self.degree)
+
+    def extra_repr(self):
+        return f"SphericalHarmonics degree={self.degree}"
+
+
+_OTYPES = {"hashgrid": HashGridEncoding, "grid": HashGridEncoding,
+           "sphericalharmonics": SphericalHarmonicsEncoding}
 
 
 def free_temporary_memory():
