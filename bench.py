@@ -88,31 +88,53 @@ def run_step(model, rays, jitter, cot, chunk):
     return total
 
 
-def cpu_baseline(model, rays_cpu, jitter_cpu, n_rays_sample):
-    """The oracle (a port of the reference path) timed on this host's cores, fwd+bwd, on a bounded
-    slice of the same view: the middle rows of the image."""
+def cpu_baseline(model, rays_cpu, jitter_cpu, max_rays, budget_s=8.0, reps=3):
+    """The oracle (a port of the reference path: C + OpenMP for the hash grid and the per-ray loops, torch CPU ops
+    for the MLP / elementwise layers) timed on this host's cores, BASELINE.md section 4's protocol: a contiguous
+    slice of the same view starting at the middle row, fwd+bwd of field query + NeuS alpha + composite, 1 warm-up +
+    ``reps`` timed repetitions, median; the marcher is timed separately.  The slice is ``max_rays`` (4096) rays
+    unless a 128-ray calibration pass says that would exceed ``budget_s`` per repetition."""
+    import statistics
     import oracle
     from test_gpu_model import oracle_params
-    torch.set_num_threads(os.cpu_count() or 1)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
     n = rays_cpu.shape[0]
     s0 = (n // 2 // 800) * 800
-    rays = rays_cpu[s0:s0 + n_rays_sample].contiguous()
-    u = jitter_cpu[s0:s0 + n_rays_sample].contiguous()
     meta, table, mlp, var = oracle_params(model)
     roi = torch.tensor([-1.5, -1.5, -1.5, 1.5, 1.5, 1.5])
-    t0 = time.perf_counter()
-    ri, ts, te = oracle.ray_marching(rays[:, :3].contiguous(), rays[:, 3:].contiguous(), scene_aabb=roi,
-                                     near_plane=0.0, far_plane=1e10,
-                                     render_step_size=model.render_step_size, stratified_u=u)
-    ref = oracle.neus_geometry_render(rays, ri, ts, te, table, meta, mlp, var, radius=1.5,
-                                      fd_eps=model.geometry._finite_difference_eps)
-    (ref["opacity"].sum() + ref["depth"].sum() + ref["comp_normal"].sum()).backward()
-    dt = time.perf_counter() - t0
-    S = int(ri.numel())
-    return {"value": S / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n_rays_sample} rays of the same 800x800 view (pixels {s0}..{s0 + n_rays_sample - 1}), "
-                      f"{S} samples, fwd+bwd {dt:.1f} s; hash grid in scalar C (1 thread), MLP in torch "
-                      f"({torch.get_num_threads()} threads)"}
+
+    def one(n_rays):
+        rays = rays_cpu[s0:s0 + n_rays].contiguous()
+        u = jitter_cpu[s0:s0 + n_rays].contiguous()
+        t0 = time.perf_counter()
+        ri, ts, te = oracle.ray_marching(rays[:, :3].contiguous(), rays[:, 3:].contiguous(), scene_aabb=roi,
+                                         near_plane=0.0, far_plane=1e10,
+                                         render_step_size=model.render_step_size, stratified_u=u)
+        t1 = time.perf_counter()
+        for q in table, *[t for layer in mlp for t in layer.values()], var:
+            if isinstance(q, torch.Tensor) and q.grad is not None:
+                q.grad = None
+        ref = oracle.neus_geometry_render(rays, ri, ts, te, table, meta, mlp, var, radius=1.5,
+                                          fd_eps=model.geometry._finite_difference_eps)
+        (ref["opacity"].sum() + ref["depth"].sum() + ref["comp_normal"].sum()).backward()
+        t2 = time.perf_counter()
+        return int(ri.numel()), t1 - t0, t2 - t1
+
+    S0, _, dt0 = one(128)                     # calibration (also pages everything in)
+    S0, _, dt0 = one(128)
+    n_rays = int(max(128, min(max_rays, (budget_s / max(dt0, 1e-6)) * 128) // 128 * 128))
+    one(n_rays)                               # warm-up at the timed size
+    runs = [one(n_rays) for _ in range(reps)]
+    S = runs[0][0]
+    dt = statistics.median(r[2] for r in runs)
+    dm = statistics.median(r[1] for r in runs)
+    return {"value": S / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{n_rays} rays of the same 800x800 view (pixels {s0}..{s0 + n_rays - 1}), {S} samples; "
+                      f"fwd+bwd of field query + alpha + composite: median of {reps} after 1 warm-up = {dt:.2f} s "
+                      f"(min {min(r[2] for r in runs):.2f}, max {max(r[2] for r in runs):.2f}); marcher timed "
+                      f"separately: {dm * 1e3:.1f} ms ({S / max(dm, 1e-9):.3g} samples/s, 1 thread); hash grid in C "
+                      f"with OpenMP ({cores} threads), MLP in torch ({torch.get_num_threads()} threads)"}
 
 
 def roofline_from(summary, steps):
@@ -141,6 +163,9 @@ def roofline_from(summary, steps):
             return "mfma", 2.0 * a[2] * a[3] * a[4]
         return None, 0.0
 
+    def samples_of(name, a):
+        return a[6] if name.startswith("rsdf_sdfmlp_fd7") else a[0]
+
     best = max(summary.items(), key=lambda kv: kv[1]["ms"])
     name, d = best
     bound, _ = cost(name, d["args"][0])
@@ -157,7 +182,8 @@ def roofline_from(summary, steps):
         ach, peak, unit = work / secs / 1e12, MFMA_F32_PEAK_TF, "TFLOP/s"
     out = {"bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
            "frac": round(ach / peak, 4), "traffic": None, "kernel": name,
-           "avg_launch_ms": round(d["ms"] / d["calls"], 4), "launches": d["calls"]}
+           "avg_launch_ms": round(d["ms"] / d["calls"], 4), "launches": d["calls"],
+           "samples_per_launch": round(sum(samples_of(name, a) for a in d["args"]) / d["calls"])}
     # the same pricing for the other heavy entry points (the north star quotes the hash gather separately)
     others = {}
     for k, v in summary.items():
@@ -177,6 +203,26 @@ def roofline_from(summary, steps):
     return out, breakdown
 
 
+def attach_traffic(roof, path):
+    """roofline.traffic: HBM bytes per launch of the dominant kernel from the committed PMC summary (separate
+    rocprofv3 --pmc passes, FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note; tools/pmc_summary.py).  The
+    counters cannot be collected inside this run, so the figure is per launch of the same kernel at the workload
+    the summary names, rescaled by sample count."""
+    if roof is None or not os.path.exists(path):
+        return
+    try:
+        pmc = json.load(open(path))
+    except Exception:
+        return
+    entry = pmc.get("kernels", {}).get(roof.get("kernel"))
+    if not entry:
+        return
+    per_sample = entry["hbm_bytes_per_sample"]
+    roof["traffic"] = per_sample * roof.get("samples_per_launch", 0) or None
+    roof["traffic_source"] = (f"{os.path.relpath(path, ROOT)} ({pmc.get('source', 'separate --pmc passes')}): "
+                              f"{per_sample:.0f} B/sample fetched+written x samples per launch")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -187,14 +233,23 @@ def main():
     ap.add_argument("--width", type=int, default=800)
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--hidden", type=int, default=64)
-    ap.add_argument("--cpu-rays", type=int, default=384, help="rays in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-rays", type=int, default=4096,
+                    help="upper bound on the rays in the CPU-baseline sample (0 = skip); shrunk to fit ~8 s/repetition")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--pmc-summary", default=os.path.join(ROOT, "profiles", "pmc_summary.json"),
+                    help="committed per-kernel HBM traffic from separate rocprofv3 --pmc passes (tools/pmc_passes.sh)")
     args = ap.parse_args()
 
     from rise_sdf_amd import dist as rdist
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: launch the N ranks ourselves.  Nothing in this process has touched the
+        # GPU yet (torch.cuda.device_count() does not initialise it), and the children are plain subprocesses.
+        n_dev = torch.cuda.device_count()
+        if n_dev < args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) are visible")
+        sys.exit(rdist.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
     rank, local, world = rdist.init_from_env()
-    assert world == args.gpus or world == 1 and args.gpus == 1, \
-        f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the product path)"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
@@ -250,6 +305,7 @@ def main():
         roof, breakdown = (None, None)
         if timer is not None:
             roof, breakdown = roofline_from(timer.summary(), args.steps)
+            attach_traffic(roof, args.pmc_summary)
         cpu = None
         if args.cpu_rays > 0 and world == 1:   # reported at N = 1 only
             cpu = cpu_baseline(model, rays_cpu, jitter_cpu, args.cpu_rays)
@@ -260,6 +316,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "c1: toaster-sized 800x800 view per GPU, dense marching, L=16 T=2^19 "
                                    f"hash grid + 2x{args.hidden} SDF MLP (7 FD taps), NeuS alpha + composite, fwd+bwd",
+                       "hidden": args.hidden, "fused_stencil_kernels": bool(model._fused_ok()),
+                       "rccl_ranks": torch.distributed.get_world_size() if world > 1 else 1,
                        "rays_per_gpu": n_rays, "chunk_rays": args.chunk,
                        "samples_per_step": samples / args.steps,
                        "field_evals_per_sec": 7 * samples / dt, "parallelism": f"ray-parallel x{world}"},

@@ -321,6 +321,8 @@ void orc_hashgrid_fwd(int64_t n, const float *x, const float *table,
                       const orc_grid_meta *m, float *out)
 {
     const uint32_t L = m->n_levels, F = m->n_features;
+    /* samples are independent: OpenMP over them (bench.py's cpu_baseline uses every host core) */
+#pragma omp parallel for schedule(static)
     for (int64_t s = 0; s < n; ++s) {
         for (uint32_t l = 0; l < L; ++l) {
             float w[3];
@@ -350,11 +352,13 @@ void orc_hashgrid_fwd(int64_t n, const float *x, const float *table,
 }
 
 /* d(table) += w_c * d(out); accumulated in double so that the oracle is an   */
-/* order-independent reference for the GPU's fp32 atomics.                    */
+/* order-independent reference for the GPU's fp32 atomics (with OpenMP the    */
+/* fp64 adds commute up to 1e-16 relative: far below any fp32 tolerance).     */
 void orc_hashgrid_bwd(int64_t n, const float *x, const float *dout,
                       const orc_grid_meta *m, double *dtable)
 {
     const uint32_t L = m->n_levels, F = m->n_features;
+#pragma omp parallel for schedule(static)
     for (int64_t s = 0; s < n; ++s) {
         for (uint32_t l = 0; l < L; ++l) {
             float w[3];
@@ -374,9 +378,11 @@ void orc_hashgrid_bwd(int64_t n, const float *x, const float *dout,
                     else { wc *= 1.0f - w[dI]; p[dI] = c[dI]; }
                 }
                 uint32_t idx = hg_index(p[0], p[1], p[2], m->res[l], m->size[l]);
-                for (uint32_t f = 0; f < F; ++f)
-                    tl[(size_t)idx * F + f] +=
-                        (double)wc * (double)dout[(size_t)s * L * F + l * F + f];
+                for (uint32_t f = 0; f < F; ++f) {
+                    const double add = (double)wc * (double)dout[(size_t)s * L * F + l * F + f];
+#pragma omp atomic
+                    tl[(size_t)idx * F + f] += add;
+                }
             }
         }
     }

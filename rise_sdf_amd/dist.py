@@ -103,3 +103,44 @@ class GradBuckets:
             else:
                 p.grad.copy_(g)
             off += k
+
+
+def spawn_ranks(argv: List[str], n: int, timeout: float | None = None) -> int:
+    """Self-launch: start ``n`` copies of ``argv`` (one process per GPU, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set the
+    way torchrun sets them; the reference gets its ranks from Lightning's DDP launcher, launch.py:84-97).  The caller
+    must not have touched the GPU: children are plain subprocesses, nothing is exec'ed over this process.  Rank 0's
+    stdout is passed through; the return value is 0 only if every rank exited 0 (first failing code otherwise, and
+    the remaining ranks are terminated)."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen(argv, env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    import time
+    t0 = time.time()
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:          # a dead rank would leave the others waiting in a collective
+                    q.terminate()
+        if timeout is not None and time.time() - t0 > timeout:
+            for q in live:
+                q.kill()
+            return rc or 124
+        time.sleep(0.05)
+    sys.stdout.flush()
+    return rc

@@ -168,8 +168,12 @@ class VolumeSDF(BaseModel):
         dot = torch.sum(normal * F.normalize(grad_d, dim=-1, eps=1e-6), dim=-1)
         return torch.acos(torch.clamp(dot, -1.0 + 1e-6, 1.0 - 1e-6)) / math.pi
 
-    def forward(self, points, with_grad=True, with_feature=True, with_laplace=False, rand_directions=None):
-        """models/geometry.py:206-292.  points [..., 3] in world space."""
+    def forward(self, points, with_grad=True, with_feature=True, with_laplace=False, rand_directions=None,
+                input_grad=False):
+        """models/geometry.py:206-292.  points [..., 3] in world space.  ``input_grad``: the caller differentiates the
+        output w.r.t. ``points`` (the secondary-ray feature query), so the first layer must return d/d(xyz) for the
+        pass-through columns as well; by default those columns are skipped (positions carry no graph under
+        finite-difference normals)."""
         if with_laplace:
             assert self.grad_type == "finite_difference", \
                 "Laplace computation is only supported with grad_type='finite_difference'"
@@ -190,7 +194,14 @@ class VolumeSDF(BaseModel):
                     laplace = self.curvature(pts, grad, rand_directions)
             else:
                 x = contract_to_unisphere(pts, self.radius, self.contraction_type)
-                feature = self.network(self.encoding(x))
+                cols = getattr(self.network, "input_grad_cols", None)
+                if input_grad and cols is not None and pts.requires_grad:
+                    self.network.input_grad_cols = None
+                try:
+                    feature = self.network(self.encoding(x))
+                finally:
+                    if cols is not None:
+                        self.network.input_grad_cols = cols
                 sdf, grad = feature[..., 0], None
         rv = [sdf.view(*shape)]
         if with_grad:

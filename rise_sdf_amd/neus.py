@@ -5,10 +5,12 @@
                     ``alpha_fn`` of models/split_mixed_occ.py:228-240 and the per-ray
                     compositing of models/volrend.py:851-886.
 
-This is BASELINE.json config[1]: hash-grid SDF + NeuS alpha + transmittance compositing of
-opacity / depth / normals, forward and backward.  The radiance branch (``volume-radiance``
-texture, split-sum PBR) is the next row of SURVEY.md 8a and is attached through ``self.texture``
-when configured; the learned-background branch is disabled in both shipped configs and not built.
+Without a ``texture`` node and with finite-difference normals this is BASELINE.json config[1]: hash-grid SDF +
+NeuS alpha + transmittance compositing of opacity / depth / normals, forward and backward, on the fused
+stencil kernels.  With a ``texture`` (``volume-radiance``) and / or ``grad_type: analytic`` (neus-blender.yaml) it
+takes the general path of models/neus.py:240-317 -- geometry(positions) -> get_alpha -> texture -> composite -- and
+returns ``comp_rgb`` plus the ``_bg`` / ``_full`` dictionaries.  The learned-background branch is disabled in both
+shipped configs and not built.
 """
 from __future__ import annotations
 
@@ -79,6 +81,9 @@ class NeuSModel(BaseModel):
         if self.config.get("learned_background", False):
             raise NotImplementedError("learned_background is disabled in both shipped configs")
         self.variance = VarianceNetwork(self.config.variance)
+        # fused stencil kernels: SDF-only rendering with finite-difference normals.  A radiance network or analytic
+        # normals (neus-blender.yaml) take the general path: geometry(...) -> get_alpha -> texture -> composite.
+        self._general = self.texture is not None or self.geometry.grad_type != "finite_difference"
         r = float(self.config.radius)
         self.register_buffer("scene_aabb", torch.tensor([-r, -r, -r, r, r, r], dtype=torch.float32))
         self.grid_prune = bool(self.config.get("grid_prune", True))
@@ -126,16 +131,24 @@ class NeuSModel(BaseModel):
         """-> (stencil, tap_major): the SDF at each sample's centre and six FD taps, either the
         tap-major [7, S] array of the fused stencil kernels or rows 7i+t (column 0) of the per-layer
         path's [7S, feature_dim] output (``fused: false`` in the model config forces the latter)."""
-        if self.config.get("fused", True) and self.texture is None \
-                and self.geometry.fused_field_available():
+        if self._fused_ok():
             return self.geometry.sdf7_from_rays(rays_o, rays_d, ray_indices, t_starts, t_ends)[0], True
         return self.geometry.field7_from_rays(rays_o, rays_d, ray_indices, t_starts, t_ends), False
+
+    def _fused_ok(self):
+        return (not self._general and self.config.get("fused", True) and self.geometry.fused_field_available())
 
     def _alpha_fn(self, rays_o, rays_d):
         def alpha_fn(t_starts, t_ends, ray_indices):
             if ray_indices.numel() == 0:
                 return torch.zeros((0,), device=rays_o.device)
             with torch.no_grad():
+                if self.geometry.grad_type != "finite_difference":
+                    t_dirs = rays_d[ray_indices]
+                    positions = rays_o[ray_indices] + t_dirs * (t_starts + t_ends)[..., None] / 2.0
+                    sdf, sdf_grad = self.geometry(positions, with_grad=True, with_feature=False)
+                    return self.get_alpha(sdf, F.normalize(sdf_grad, p=2, dim=-1), t_dirs,
+                                          (t_ends - t_starts)[..., None])
                 out7, tm = self._field7(rays_o, rays_d, ray_indices, t_starts, t_ends)
                 return ops.neus_alpha_fd(out7, self.variance.variance, rays_d, ray_indices,
                                          t_starts, t_ends, self.cos_anneal_ratio,
@@ -160,10 +173,21 @@ class NeuSModel(BaseModel):
         dev = rays_o.device
         S = ray_indices.numel()
         packed = ops.pack_info(ray_indices, n_rays)
+        rgb = None
         if S == 0:
             alpha = torch.zeros((0,), device=dev)
             sdf, sdf_grad = torch.zeros((0,), device=dev), torch.zeros((0, 3), device=dev)
             normal = torch.zeros((0, 3), device=dev)
+            rgb = torch.zeros((0, 3), device=dev) if self.texture is not None else None
+        elif self._general:
+            # models/neus.py:250-262, one call each: field (FD or analytic gradient), alpha, radiance
+            t_dirs = rays_d[ray_indices]
+            positions = rays_o[ray_indices] + t_dirs * (t_starts + t_ends)[..., None] / 2.0
+            sdf, sdf_grad, feature = self.geometry(positions, with_grad=True, with_feature=True)
+            normal = F.normalize(sdf_grad, p=2, dim=-1)
+            alpha = self.get_alpha(sdf, normal, t_dirs, (t_ends - t_starts)[..., None])
+            if self.texture is not None:
+                rgb = self.texture(feature, t_dirs, normal)
         else:
             out7, tm = self._field7(rays_o, rays_d, ray_indices, t_starts, t_ends)
             sdf, sdf_grad, normal, alpha = ops.neus_alpha_fd(
@@ -187,7 +211,18 @@ class NeuSModel(BaseModel):
                         "weights": weights.view(-1), "points": midpoints.view(-1),
                         "intervals": (t_ends - t_starts).view(-1),
                         "ray_indices": ray_indices.view(-1)})
-        return out
+        if rgb is None:
+            return out          # geometry-only model (BASELINE config[1]): no radiance keys
+        # models/neus.py:264-317: composited colour + the background / full dictionaries
+        out["comp_rgb"] = ops.accumulate_along_rays(weights, rgb, packed_info=packed)
+        bg = self.background_color if self.background_color is not None else torch.ones(3, device=dev)
+        out_bg = {"comp_rgb": bg[None, :].expand(*out["comp_rgb"].shape),
+                  "num_samples": torch.zeros_like(out["num_samples"]),
+                  "rays_valid": torch.zeros_like(out["rays_valid"])}
+        out_full = {"comp_rgb": out["comp_rgb"] + out_bg["comp_rgb"] * (1.0 - out["opacity"]),
+                    "num_samples": out["num_samples"] + out_bg["num_samples"],
+                    "rays_valid": out["rays_valid"] | out_bg["rays_valid"]}
+        return {**out, **{k + "_bg": v for k, v in out_bg.items()}, **{k + "_full": v for k, v in out_full.items()}}
 
     def forward(self, rays, **kw):
         if self.training:

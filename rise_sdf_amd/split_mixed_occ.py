@@ -77,6 +77,14 @@ class SplitMixedOCCModel(BaseModel):
         """-> (sdf, sdf_grad, normal, alpha, feature or None) for a sample set."""
         geo = self.geometry
         eps = geo._finite_difference_eps
+        if geo.grad_type != "finite_difference":
+            # analytic normals (models/geometry.py:224-228): the general field call + the stand-alone alpha kernel
+            t_dirs = rays_d[ray_indices]
+            positions = rays_o[ray_indices] + t_dirs * (t_starts + t_ends)[..., None] / 2.0
+            sdf, sdf_grad, feature = geo(positions, with_grad=True, with_feature=True)
+            normal = F.normalize(sdf_grad, p=2, dim=-1, eps=1e-6)
+            alphas = self.get_alpha(sdf, normal, t_dirs, (t_ends - t_starts)[..., None])
+            return sdf, sdf_grad, normal, alphas, (feature if want_feature else None)
         if self.config.get("fused", True) and geo.fused_field_available():
             sdf7t, feature = geo.sdf7_from_rays(rays_o, rays_d, ray_indices, t_starts, t_ends,
                                                 want_feature=want_feature)
@@ -157,7 +165,9 @@ class SplitMixedOCCModel(BaseModel):
             sec_d = 2 * torch.sum(wo * nv, dim=-1, keepdim=True) * nv - wo
             tr, sec_depth = self.compute_indirect_radiance(sec_o.detach().contiguous(), sec_d.detach().contiguous())
             tr, sec_depth = tr.clamp(0, 1).detach(), sec_depth.detach()
-            sec_feature = self.geometry(sec_o, with_grad=False, with_feature=True)[1]
+            # sec_o carries a graph (depth_map -> weights): the feature query must propagate d/d(xyz) through the
+            # encoding's xyz pass-through too (models/split_mixed_occ.py:315 goes through tcnn + nn.Linear input grads)
+            sec_feature = self.geometry(sec_o, with_grad=False, with_feature=True, input_grad=True)[1]
             sec_rgb = self.texture.secondary_shading(sec_feature, sec_d, nv)
             spec_rgb_map = spec_rgb_map.clone()
             spec_rgb_map[valid_indices] = tr * spec_rgb_map[valid_indices] + (1 - tr) * sec_rgb

@@ -72,3 +72,34 @@ def test_single_process_is_a_noop():
     p.grad = torch.ones(3)
     rd.GradBuckets([p]).all_reduce_mean(1)
     assert torch.equal(p.grad, torch.ones(3))
+
+
+LAUNCHED = textwrap.dedent("""
+    import json, os, sys, torch
+    sys.path.insert(0, os.environ["RSDF_ROOT"])
+    from rise_sdf_amd import dist as rd
+    rank, local, world = rd.init_from_env(backend="gloo")
+    t = torch.tensor([float(rank + 1)])
+    torch.distributed.all_reduce(t)
+    if len(sys.argv) > 1 and sys.argv[1] == "fail" and rank == 1:
+        sys.exit(3)
+    if rank == 0:
+        print(json.dumps({"rccl_ranks": torch.distributed.get_world_size(), "sum": float(t)}))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+""")
+
+
+def test_spawn_ranks_self_launch(tmp_path, capfd):
+    """bench.py --gpus N without torchrun: N children, rank 0's line passes through, failures propagate."""
+    from rise_sdf_amd import dist as rd
+    script = tmp_path / "launched.py"
+    script.write_text(LAUNCHED)
+    os.environ["RSDF_ROOT"] = ROOT
+    try:
+        assert rd.spawn_ranks([sys.executable, str(script)], 2, timeout=240) == 0
+        out = capfd.readouterr().out
+        assert '"rccl_ranks": 2' in out and '"sum": 3.0' in out
+        assert rd.spawn_ranks([sys.executable, str(script), "fail"], 2, timeout=240) == 3
+    finally:
+        os.environ.pop("RSDF_ROOT", None)

@@ -285,12 +285,19 @@ def test_split_mixed_occ_stage0_matches_oracle(dev, fused):
                                      grid_binary=model.occupancy_grid.binaries[0].cpu(), near_plane=0.0,
                                      far_plane=1e10, render_step_size=model.render_step_size, stratified_u=u,
                                      alpha_fn=alpha_fn)
-    # the surviving sample set depends on fp32 alphas through T >= 1e-4: allow a few borderline samples
-    S_g, S_o = int(out["num_samples"]), ri.numel()
-    assert abs(S_g - S_o) <= max(3, S_o // 2000), (S_g, S_o)
-    if S_g != S_o:
-        pytest.skip("borderline visibility sample differs between fp32 implementations; compared elsewhere")
-    assert torch.equal(out["ray_indices"].cpu(), ri)
+    # the surviving sample set depends on fp32 alphas through T >= 1e-4: a few borderline samples may fall on either
+    # side.  The two sets must agree except for those, and the render is then compared on the GPU's own set (the
+    # oracle evaluates exactly the samples the HIP path composited).
+    with torch.no_grad():
+        rod, rdd = ro.to(dev), rd.to(dev)
+        ri_g, ts_g, te_g = model.occupancy_grid.sampling(
+            rod, rdd, alpha_fn=model._alpha_fn(rod, rdd), render_step_size=model.render_step_size,
+            stratified_u=u.to(dev), cone_angle=0.0, alpha_thre=0.0)
+    assert torch.equal(out["ray_indices"], ri_g)
+    key = lambda r, t: set(zip(r.tolist(), t.view(torch.int32).tolist()))
+    diff = key(ri_g.cpu(), ts_g.cpu()) ^ key(ri, ts)
+    assert len(diff) <= max(3, ri.numel() // 2000), (len(diff), ri.numel())
+    ri, ts, te = ri_g.cpu(), ts_g.cpu(), te_g.cpu()
     ref = oracle.neus_geometry_render(rays, ri, ts, te, table, meta, mlp, var, radius=1.5, fd_eps=eps)
     tex = model.texture
     nets = {}

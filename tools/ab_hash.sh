@@ -1,8 +1,10 @@
 #!/bin/bash
 # A/B builds of hashgrid_fd7.hip with different -D flags on one box: bash tools/ab_hash.sh "-DX=1" "-DX=2" ...
+set -euo pipefail
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (sets GRAFT_REPO_ROOT)}"
 cd "$GRAFT_REPO_ROOT/rise_sdf_amd/csrc"
 for v in "$@"; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -I../../include $v -c hashgrid_fd7.hip -o _build/hashgrid_fd7.o 2>/dev/null
+  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -I../../include $v -c hashgrid_fd7.hip -o _build/hashgrid_fd7.o
   /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 _build/*.o -o ../librisesdf_hip.so
   (cd ../.. && python bench.py --steps 2 --warmup 1 --cpu-rays 0 --width 400 --height 400 2>&1 | tail -1 | grep -o "rsdf_hashgrid_fwd_fd7\": {[^}]*}\|rsdf_hashgrid_bwd_fd7\": {[^}]*}" | tr '\n' ' '; echo " <= [$v]")
 done
