@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RSDF_ABI_VERSION 1
+#define RSDF_ABI_VERSION 2
 #define RSDF_EINVAL 10001
 #define RSDF_MAX_LEVELS 32
 #define RSDF_TAP_MAJOR (-1)
@@ -193,11 +193,13 @@ int rsdf_linear_bwd_weight(const float *dz, int lddz, const float *x, int ldx, i
  * Linear(K0,H) -> Softplus(100) -> Linear(H,H) -> Softplus(100) -> Linear(H,N2), K0 = 3 + 2*n_levels
  * (CompositeEncoding include_xyz + VanillaMLP n_hidden_layers=2, models/network_utils.py:71-157) on
  * the tap-major buffers above.  Activations stay on the CU; levels >= n_active_levels read as zero.
- * Supported: n_levels <= 16, H in {32, 64}, N2 <= 64 (rsdf_sdfmlp_fd7_supported(K0, H, N2)).
+ * Supported: n_levels <= 16, H in {32, 64, 128}, N2 <= 64 (rsdf_sdfmlp_fd7_supported(K0, H, N2)); H = 128 is
+ * the width of configs/split-mixed-occ-tensoir.yaml:73-84.
  * fwd: sdf7t [7][n] = output column 0 of every tap; feature [n, N2] (nullable) = full output of
  *      the centre taps; h2c [n, H] (nullable, needs feature) = their second hidden layer, kept for
  *      the weight gradient of the feature rows.
- * bwd: from d_sdf7t [7][n] and d_feature [n, N2] (nullable): d_planes (nullable) receives
+ * bwd: from d_sdf7t [7][n] and d_feature [n, N2] (nullable; then dh2c_scratch [n, H] must be given: it receives
+ *      d_feature @ W2, the centre taps' d(h2) through the feature rows): d_planes (nullable) receives
  *      d/d(hash features); dw0 [H,K0], db0 [H], dw1 [H,H], db1 [H] are complete; dw2 [N2,H] / db2 [N2]
  *      receive the SDF-column part (row 0 / element 0) -- the caller adds the feature part with
  *      rsdf_linear_bwd_weight(d_feature, h2c).  All accumulated atomically: zero first. */
@@ -211,8 +213,8 @@ int rsdf_sdfmlp_fd7_bwd(const float *x7t, const float *planes, int n_levels, int
                         float xyz_scale, float xyz_offset, int H, int N2, const float *w0,
                         const float *b0, const float *w1, const float *b1, const float *w2,
                         const float *b2, int64_t n_samples, const float *d_sdf7t,
-                        const float *d_feature, float *d_planes, float *dw0, float *db0, float *dw1,
-                        float *db1, float *dw2, float *db2, void *stream);
+                        const float *d_feature, float *dh2c_scratch /*nullable*/, float *d_planes, float *dw0,
+                        float *db0, float *dw1, float *db1, float *dw2, float *db2, void *stream);
 /* weight_norm (torch.nn.utils.weight_norm dim=0): w = g * v / ||v||_row */
 int rsdf_weight_norm_fwd(const float *g, const float *v, int N, int K, float *w, void *stream);
 int rsdf_weight_norm_bwd(const float *g, const float *v, const float *dw, int N, int K, float *dg,

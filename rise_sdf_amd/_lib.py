@@ -76,7 +76,7 @@ _SIGNATURES = {
     "rsdf_linear_bwd_weight": [_P, _I, _P, _I, _L, _I, _I, _P, _P, _P],
     "rsdf_sdfmlp_fd7_supported": [_I, _I, _I],
     "rsdf_sdfmlp_fd7_fwd": [_P, _P, _I, _I, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P],
-    "rsdf_sdfmlp_fd7_bwd": [_P, _P, _I, _I, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P,
+    "rsdf_sdfmlp_fd7_bwd": [_P, _P, _I, _I, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P,
                             _P, _P, _P, _P, _P, _P, _P],
     "rsdf_weight_norm_fwd": [_P, _P, _I, _I, _P, _P],
     "rsdf_weight_norm_bwd": [_P, _P, _P, _I, _I, _P, _P, _P],
@@ -140,7 +140,7 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = argtypes
             fn.restype = _RESTYPES.get(name, ctypes.c_int)
-        if l.rsdf_abi_version() != 1:
+        if l.rsdf_abi_version() != 2:
             raise RiseSdfHipError("librisesdf_hip.so ABI version mismatch")
         _lib = l
     if _timer is not None:

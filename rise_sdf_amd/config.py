@@ -19,6 +19,11 @@ class Config(dict):
     def __setattr__(self, k, v):
         self[k] = v
 
+    def get(self, k, default=None):
+        """OmegaConf's ``node.get`` returns sub-nodes, not plain dicts."""
+        v = dict.get(self, k, default)
+        return Config(v) if isinstance(v, dict) and not isinstance(v, Config) else v
+
     def copy(self):
         return Config(dict.copy(self))
 

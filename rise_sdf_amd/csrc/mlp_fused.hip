@@ -15,6 +15,9 @@
 //   * the taps only need output column 0 (the SDF), so their last layer is a 64-term dot product on
 //     the vector ALU instead of a matrix tile; the full feature row is produced for centre rows only.
 // All results are fp32-equivalent (parity tests: 1e-5 relative); summation order differs from a row-major GEMM.
+#include <stdlib.h>
+#include <string.h>
+
 #include "common.h"
 #include "split_bf16.h"
 
@@ -43,17 +46,18 @@ struct TileSrc {
 __device__ __forceinline__ void fetch_tile(float (&pre)[18], const TileSrc &src, int64_t s0, int tap,
                                            int lane)
 {
-    const int r = lane >> 1;
-    const bool ok = s0 + r < src.S;
+    // RAW loads on clamped (always valid) addresses; the masking happens in store_tile_f.  A load inside a divergent
+    // branch, or a select right behind it, is waited for on the spot (vmcnt), which serialises these 18 loads.
+    const int64_t last = src.S - 1;
+    const int64_t r = s0 + (lane >> 1);
+    const int64_t rc = r <= last ? r : last;
 #pragma unroll
-    for (int l = 0; l < 16; ++l) {
-        float v = 0.0f;
-        if (l < src.n_active && ok) v = src.planes[(((int64_t)l * 7 + tap) * src.S + s0) * 2 + lane];
-        pre[l] = v;
-    }
-    const float *xb = src.x7t + ((int64_t)tap * src.S + s0) * 3;
-    pre[16] = (s0 + lane / 3 < src.S) ? xb[lane] : 0.5f;
-    pre[17] = (lane < 32 && s0 + (lane + 64) / 3 < src.S) ? xb[lane + 64] : 0.5f;
+    for (int l = 0; l < 16; ++l)
+        pre[l] = src.planes[(((int64_t)(l < src.n_active ? l : 0) * 7 + tap) * src.S + rc) * 2 + (lane & 1)];
+    const float *xb = src.x7t + (int64_t)tap * src.S * 3;
+    const int64_t e0 = s0 * 3 + lane, e1 = s0 * 3 + 64 + (lane & 31), emax = src.S * 3 - 1;
+    pre[16] = xb[e0 <= emax ? e0 : emax];
+    pre[17] = xb[e1 <= emax ? e1 : emax];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -152,13 +156,15 @@ __device__ __forceinline__ void stage_split_weights(unsigned char *smem, const f
     for (int e = threadIdx.x; e < 64; e += NTHR) tail[S::B2 + e] = e < N2 ? b2[e] : 0.0f;
 }
 
-__device__ __forceinline__ void store_tile_f(float *Xs, const float (&pre)[18], const TileSrc &src, int lane)
+__device__ __forceinline__ void store_tile_f(float *Xs, const float (&pre)[18], const TileSrc &src, int64_t s0, int lane)
 {
     const int r = lane >> 1, f = lane & 1;
+    const bool ok = s0 + r < src.S;
 #pragma unroll
-    for (int l = 0; l < 16; ++l) Xs[r * LDXF + 3 + 2 * l + f] = pre[l];
-    Xs[(lane / 3) * LDXF + lane % 3] = pre[16] * src.xyz_scale + src.xyz_offset;
-    if (lane < 32) Xs[((lane + 64) / 3) * LDXF + (lane + 64) % 3] = pre[17] * src.xyz_scale + src.xyz_offset;
+    for (int l = 0; l < 16; ++l) Xs[r * LDXF + 3 + 2 * l + f] = (ok && l < src.n_active) ? pre[l] : 0.0f;
+    const float x0 = s0 + lane / 3 < src.S ? pre[16] : 0.5f, x1 = s0 + (lane + 64) / 3 < src.S ? pre[17] : 0.5f;
+    Xs[(lane / 3) * LDXF + lane % 3] = x0 * src.xyz_scale + src.xyz_offset;
+    if (lane < 32) Xs[((lane + 64) / 3) * LDXF + (lane + 64) % 3] = x1 * src.xyz_scale + src.xyz_offset;
     if (lane < 32) Xs[lane * LDXF + 35] = 1.0f;   // bias column
 }
 
@@ -251,7 +257,7 @@ sdfmlp_fwd_kernel(const TileSrc src, const float *__restrict__ w0,
     for (int64_t g = g_first; g < n_groups; g += g_step) {
         const int64_t s0 = g * 32;
         for (int tap = 0; tap < 7; ++tap) {
-            store_tile_f(Xs, pre, src, lane);
+            store_tile_f(Xs, pre, src, s0, lane);
             {   // prefetch the next tile of this wave
                 const int ntap = tap == 6 ? 0 : tap + 1;
                 const int64_t ng = tap == 6 ? g + g_step : g;
@@ -464,7 +470,7 @@ sdfmlp_bwd_kernel(const TileSrc src, const float *__restrict__ w0,
     for (int64_t g = g_first; g < n_groups; g += g_step) {
         const int64_t s0 = g * 32;
         for (int tap = 0; tap < 7; ++tap) {
-            store_tile_f(Xs, pre, src, lane);
+            store_tile_f(Xs, pre, src, s0, lane);
             {
                 const int ntap = tap == 6 ? 0 : tap + 1;
                 const int64_t ng = tap == 6 ? g + g_step : g;
@@ -472,7 +478,7 @@ sdfmlp_bwd_kernel(const TileSrc src, const float *__restrict__ w0,
             }
             f32x16 h1[NT], dz2[NT];
             const int64_t s = s0 + c;
-            const float dsdf = s < n_samples ? d_sdf7[(int64_t)tap * n_samples + s] : 0.0f;
+            const float dsdf_raw = d_sdf7[(int64_t)tap * n_samples + (s < n_samples ? s : n_samples - 1)];
             {
                 f32x16 h2[NT];
                 float b1r[NT][16];
@@ -484,6 +490,7 @@ sdfmlp_bwd_kernel(const TileSrc src, const float *__restrict__ w0,
                     static_assert(S::W0 == F::W0 && S::W1 == F::W1, "recompute shares the forward's weight image");
                     hidden_forward_s<H>(smem_b, Xs, c, hf, b1r, h1, h2);
                 }
+                const float dsdf = s < n_samples ? dsdf_raw : 0.0f;
                 gb2 += (hf == 0) ? dsdf : 0.0f;
                 // ---- layer 3: dh2 = W2^T d_out.  Output channel 0 is the SDF: on the centre tap with feature
                 // gradients d_sdf joins column 0 of d_feature and the whole product runs on the matrix cores;
@@ -672,9 +679,23 @@ size_t bwd_lds(int steps2)
 template <typename K>
 int set_lds(K kern, size_t bytes)
 {
+    // the attribute sticks to the function on a device: set it once per (kernel, device, size) and host thread
+    static thread_local const void *done[8] = {};
+    static thread_local size_t done_key[8] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const size_t key = bytes * 64 + (size_t)dev + 1;
+    for (int i = 0; i < 8; ++i)
+        if (done[i] == reinterpret_cast<const void *>(kern) && done_key[i] == key) return 0;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) { rsdf_set_error(hipGetErrorString(e)); return (int)e; }
+    for (int i = 0; i < 8; ++i)
+        if (done[i] == nullptr || done[i] == reinterpret_cast<const void *>(kern)) {
+            done[i] = reinterpret_cast<const void *>(kern);
+            done_key[i] = key;
+            break;
+        }
     return 0;
 }
 
@@ -685,15 +706,34 @@ unsigned persistent_grid(int64_t n_samples, int waves)
     return (unsigned)(want < 512 ? (want > 0 ? want : 1) : 512);
 }
 
+bool env_is(const char *name, const char *value)
+{
+    const char *v = getenv(name);
+    return v != nullptr && strcmp(v, value) == 0;
+}
+
 }  // namespace
+
+// cooperative kernels (mlp_coop.hip): a workgroup of H/32 waves, wave w owns features 32w..32w+31
+int rsdf_coop_fwd(int NT, const float *x7t, const float *planes, int n_levels, int n_active, float xyz_scale,
+                  float xyz_offset, int N2, const float *w0, const float *b0, const float *w1, const float *b1,
+                  const float *w2, const float *b2, int64_t n_samples, float *sdf7t, float *feature, float *h2c,
+                  hipStream_t st);
+int rsdf_coop_bwd(int NT, const float *x7t, const float *planes, int n_levels, int n_active, float xyz_scale,
+                  float xyz_offset, const float *w0, const float *b0, const float *w1, const float *b1, const float *w2,
+                  int64_t n_samples, const float *d_sdf7t, const float *dh2c, float *d_planes, float *dw0, float *db0,
+                  float *dw1, float *db1, float *dw2, float *db2, hipStream_t st);
 
 extern "C" {
 
 int rsdf_sdfmlp_fd7_supported(int K0, int H, int N2)
 {
-    return (K0 >= 1 && K0 <= 35 && (H == 32 || H == 64) && N2 >= 1 && N2 <= 64) ? 1 : 0;
+    return (K0 >= 1 && K0 <= 35 && (H == 32 || H == 64 || H == 128) && N2 >= 1 && N2 <= 64) ? 1 : 0;
 }
 
+// Kernel selection.  Forward: the per-wave kernel of this file for H <= 64 (every wave holds all weights through LDS),
+// the cooperative kernel for H = 128.  Backward: the cooperative kernel for every width.  RSDF_MLP_FWD=coop /
+// RSDF_MLP_BWD=legacy force the other form where it exists (A/B timing, parity tests of both).
 int rsdf_sdfmlp_fd7_fwd(const float *x7t, const float *planes, int n_levels, int n_active_levels,
                         float xyz_scale, float xyz_offset, int H, int N2, const float *w0,
                         const float *b0, const float *w1, const float *b1, const float *w2,
@@ -707,6 +747,9 @@ int rsdf_sdfmlp_fd7_fwd(const float *x7t, const float *planes, int n_levels, int
     if (n_samples <= 0) return 0;
     if (n_active_levels < 0 || n_active_levels > n_levels) n_active_levels = n_levels;
     hipStream_t st = (hipStream_t)stream;
+    if (H == 128 || env_is("RSDF_MLP_FWD", "coop"))
+        return rsdf_coop_fwd(H / 32, x7t, planes, n_levels, n_active_levels, xyz_scale, xyz_offset, N2, w0, b0, w1, b1,
+                             w2, b2, n_samples, sdf7t, feature, h2c, st);
     const unsigned grid = persistent_grid(n_samples, FWD_WAVES);
     const TileSrc src{x7t, planes, n_samples, n_levels, n_active_levels, xyz_scale, xyz_offset};
     int rc;
@@ -726,8 +769,8 @@ int rsdf_sdfmlp_fd7_bwd(const float *x7t, const float *planes, int n_levels, int
                         float xyz_scale, float xyz_offset, int H, int N2, const float *w0,
                         const float *b0, const float *w1, const float *b1, const float *w2,
                         const float *b2, int64_t n_samples, const float *d_sdf7t, const float *d_feature,
-                        float *d_planes, float *dw0, float *db0, float *dw1, float *db1, float *dw2, float *db2,
-                        void *stream)
+                        float *dh2c_scratch, float *d_planes, float *dw0, float *db0, float *dw1, float *db1,
+                        float *dw2, float *db2, void *stream)
 {
     const int K0 = 3 + 2 * n_levels;
     RSDF_CHECK_ARG(n_levels >= 1 && n_levels <= 16, "sdfmlp_fd7_bwd: n_levels must be in [1,16]");
@@ -735,6 +778,19 @@ int rsdf_sdfmlp_fd7_bwd(const float *x7t, const float *planes, int n_levels, int
     if (n_samples <= 0) return 0;
     if (n_active_levels < 0 || n_active_levels > n_levels) n_active_levels = n_levels;
     hipStream_t st = (hipStream_t)stream;
+    if (!(H <= 64 && env_is("RSDF_MLP_BWD", "legacy"))) {
+        if (d_feature != nullptr) {
+            // d(h2) of the centre taps through the feature rows of the last layer: one per-layer product
+            // [n, N2] x [N2, H]; the cooperative kernel adds the SDF row and continues the chain
+            RSDF_CHECK_ARG(dh2c_scratch != nullptr, "sdfmlp_fd7_bwd: d_feature needs the [n, H] dh2c scratch");
+            const int rc = rsdf_linear_bwd_input(d_feature, nullptr, N2, w2, n_samples, H, N2, RSDF_ACT_NONE, 0, H,
+                                                 nullptr, dh2c_scratch, H, stream);
+            if (rc) return rc;
+        }
+        return rsdf_coop_bwd(H / 32, x7t, planes, n_levels, n_active_levels, xyz_scale, xyz_offset, w0, b0, w1, b1, w2,
+                             n_samples, d_sdf7t, d_feature != nullptr ? dh2c_scratch : nullptr, d_planes, dw0, db0, dw1,
+                             db1, dw2, db2, st);
+    }
     const unsigned grid = persistent_grid(n_samples, BWD_WAVES);
     const TileSrc src{x7t, planes, n_samples, n_levels, n_active_levels, xyz_scale, xyz_offset};
     // k-steps (of 16 output channels) of the feature-gradient product staged in LDS

@@ -7,8 +7,9 @@ cache lines and nothing 35 columns wide ever goes through autograd.
 
 Forward:  x7t -> planes (rsdf_hashgrid_fwd_fd7: one gather of the centre cell + 4 corners per displaced
           tap) -> sdf7t [7][S] (+ feature [S,N2] of the centre taps) (rsdf_sdfmlp_fd7_fwd).
-Backward: d_sdf7t (+ d_feature) -> rsdf_sdfmlp_fd7_bwd (recomputes the hidden layers; weight / bias
-          gradients and d_planes) -> rsdf_hashgrid_bwd_fd7 (merge, bin through LDS, reduce in LDS) ->
+Backward: d_sdf7t (+ d_feature, first pushed through the feature rows of the last layer into a [S,H] scratch)
+          -> rsdf_sdfmlp_fd7_bwd (recomputes the hidden layers; weight / bias gradients and d_planes)
+          -> rsdf_hashgrid_bwd_fd7 (merge, bin through LDS, reduce in LDS) ->
           d_table; the feature rows of dW2 come from rsdf_linear_bwd_weight on the saved centre h2.
 
 This is what VolumeSDF.forward does for finite-difference normals between ``points_d`` and
@@ -78,9 +79,10 @@ class _SdfFieldFD7(torch.autograd.Function):
         dw0, db0 = torch.zeros_like(w0), torch.zeros_like(b0)
         dw1, db1 = torch.zeros_like(w1), torch.zeros_like(b1)
         dw2, db2 = torch.zeros_like(w2), torch.zeros_like(b2)
+        dh2c = torch.empty(S, H, dtype=torch.float32, device=dev) if gf is not None else None
         check(lib().rsdf_sdfmlp_fd7_bwd(ptr(xf), ptr(planes), Lv, ctx.n_active, ctx.xyz[0], ctx.xyz[1],
                                         H, N2, ptr(w0), ptr(b0), ptr(w1), ptr(b1), ptr(w2), ptr(b2), S,
-                                        ptr(g), ptr(gf), ptr(d_planes), ptr(dw0), ptr(db0), ptr(dw1),
+                                        ptr(g), ptr(gf), ptr(dh2c), ptr(d_planes), ptr(dw0), ptr(db0), ptr(dw1),
                                         ptr(db1), ptr(dw2), ptr(db2), st), "sdfmlp_fd7_bwd")
         if gf is not None:
             # feature rows of the last layer: dW2 += d_feature^T h2(centre), db2 += colsum(d_feature)

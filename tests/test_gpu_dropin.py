@@ -58,7 +58,7 @@ def test_vendored_C_marcher_and_grid(dev, mods):
     x = (torch.rand(4096, 3, generator=g) * 2 - 1) * 1.7
     occs = torch.rand(32, 32, 32, generator=g)
     got = C.grid_query(x.to(dev), ROI.to(dev), occs.to(dev), C.ContractionType.AABB).cpu()
-    inside = oracle.query_occ(x, ROI, torch.ones(32, 32, 32, dtype=torch.bool))
+    inside, _ = oracle.query_occ(x, ROI, torch.ones(32, 32, 32, dtype=torch.bool))
     unit = (x - ROI[:3]) / (ROI[3:] - ROI[:3])
     ijk = (unit * 32).to(torch.int32).clamp(0, 31).long()
     want = torch.where(inside, occs[ijk[:, 0], ijk[:, 1], ijk[:, 2]], torch.zeros(()))
@@ -223,7 +223,8 @@ def test_dr_texture_cube(dev, mods):
         assert rel_err(a, b) < 1e-4
     # direction gradients: exclude samples whose bilinear footprint touches a texel border (kink)
     assert float((grads[3].cpu().double() - rgrads[3]).abs().median()) < 1e-5
-    assert rel_err(grads[4], rgrads[4]) < 1e-4
+    # d/d(level): one-sided at exactly integer levels (entries 0..2 were set to 0, 1, 2): compare the others
+    assert rel_err(grads[4][4:], rgrads[4][4:]) < 1e-4
 
 
 def test_renderutils_plugin_names(dev):

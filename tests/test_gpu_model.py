@@ -60,7 +60,8 @@ def oracle_params(model):
 
 
 @pytest.mark.parametrize("prune,fused,hidden,n_levels", [(False, True, 32, 4), (True, True, 64, 6),
-                                                         (False, False, 32, 4), (True, False, 64, 4)])
+                                                         (False, False, 32, 4), (True, False, 64, 4),
+                                                         (True, True, 128, 6), (False, True, 128, 16)])
 def test_neus_render_matches_oracle(dev, prune, fused, hidden, n_levels):
     import rise_sdf_amd as R
     torch.manual_seed(0)
@@ -184,7 +185,7 @@ def test_volume_sdf_reference_fixture(dev, golden_dir):
                 assert rel_err(getattr(geo.network.layers[i], n).grad, ref) < 5e-3, (step, i, n)
 
 
-@pytest.mark.parametrize("hidden,n_levels", [(32, 4), (64, 16)])
+@pytest.mark.parametrize("hidden,n_levels", [(32, 4), (64, 16), (128, 16), (128, 5)])
 def test_fused_field_with_feature_gradients(dev, hidden, n_levels):
     """Fused stencil field (hash gather + MLP in one node) with gradients through BOTH the SDF stencil and
     the centre feature vector, vs the oracle's VolumeSDF restatement (models/geometry.py:206-244)."""
@@ -192,7 +193,7 @@ def test_fused_field_with_feature_gradients(dev, hidden, n_levels):
     from rise_sdf_amd import ops
     torch.manual_seed(1)
     log2_T = 14 if n_levels == 4 else 15
-    cfg = model_config(hidden=hidden, n_levels=n_levels, feat=48 if hidden == 64 else 13, log2_T=log2_T)
+    cfg = model_config(hidden=hidden, n_levels=n_levels, feat=48 if hidden >= 64 else 13, log2_T=log2_T)
     geo = R.make("volume-sdf", cfg.geometry).to(dev)
     geo.train()
     with torch.no_grad():
