@@ -24,6 +24,8 @@
 //      with contiguous (full-rate) global atomics.
 // Hashed levels bin by the high index bits; dense levels bin by idx % n_bins so that a spatially
 // compact batch of rays still loads all bins evenly.
+#include <stdlib.h>
+
 #include "hashgrid_common.h"
 
 namespace {
@@ -491,7 +493,15 @@ int make_plan(const rsdf_grid_meta *meta, int64_t S, int n_active, float eps_uni
         plan->n_bins[l] = nb;
         plan->interleaved[l] = is_dense ? 1 : 0;
         const double per_bin = (double)S * expected_records(meta->scale[l], eps_unit) / nb;
-        plan->cap[l] = (int64_t)(per_bin * 1.15) + 16384;
+        // RSDF_FD7_QUEUE_SCALE (test knob, default 1): shrinks the queues so that the overflow path -- a record that
+        // finds its queue full goes to the table with a direct atomic, and the reducer clamps its count -- is exercised
+        // (tests/test_gpu_regimes.py).  Read here so that scratch_bytes() and the launch agree.
+        double qscale = 1.0;
+        if (const char *e = getenv("RSDF_FD7_QUEUE_SCALE")) {
+            const double v = atof(e);
+            if (v > 0.0 && v <= 1.0) qscale = v;
+        }
+        plan->cap[l] = qscale < 1.0 ? (int64_t)(per_bin * qscale) + 64 : (int64_t)(per_bin * 1.15) + 16384;
         int ns = (int)(per_bin / per_wg + 0.999);
         plan->n_split[l] = ns < 1 ? 1 : (ns > 256 ? 256 : ns);
         plan->queue_off[l] = qoff;
@@ -571,11 +581,13 @@ int rsdf_hashgrid_bwd_fd7(const float *x7t, const float *dplanes, const rsdf_gri
     (void)hipMemsetAsync(counters, 0, cbytes, st);
     dim3 pgrid(rsdf_blocks(n_samples, P_THREADS), na);
     const size_t stage_bytes = (size_t)STAGE_CAP * sizeof(Record);
-    static bool pattr_set = false;
-    if (!pattr_set) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    static thread_local unsigned long long pattr_set = 0;      // one bit per device (the attribute is per device)
+    if (!(pattr_set >> (dev & 63) & 1ull)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fd7_produce_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_bytes);
-        pattr_set = true;
+        pattr_set |= 1ull << (dev & 63);
     }
     fd7_produce_kernel<<<pgrid, P_THREADS, stage_bytes, st>>>(x7t, reinterpret_cast<const float2 *>(dplanes), *meta,
                                                     plan, n_samples, queues, counters, dtable);
@@ -585,11 +597,11 @@ int rsdf_hashgrid_bwd_fd7(const float *x7t, const float *dplanes, const rsdf_gri
         max_wgs = w > max_wgs ? w : max_wgs;
     }
     const size_t lds = (size_t)BIN_ENTRIES * 2 * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static thread_local unsigned long long attr_set = 0;
+    if (!(attr_set >> (dev & 63) & 1ull)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fd7_reduce_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+        attr_set |= 1ull << (dev & 63);
     }
     dim3 rgrid(max_wgs, na);
     fd7_reduce_kernel<<<rgrid, R_THREADS, lds, st>>>(*meta, plan, queues, counters, dtable);

@@ -165,6 +165,9 @@ class SplitMixedOCCModel(BaseModel):
             sec_d = 2 * torch.sum(wo * nv, dim=-1, keepdim=True) * nv - wo
             tr, sec_depth = self.compute_indirect_radiance(sec_o.detach().contiguous(), sec_d.detach().contiguous())
             tr, sec_depth = tr.clamp(0, 1).detach(), sec_depth.detach()
+            # (references only, no copies: what a parity test needs to line the secondary pass up with the oracle)
+            self._last_secondary = {"valid_indices": valid_indices, "sec_o": sec_o.detach(), "sec_d": sec_d.detach(),
+                                    "tr": tr, "sec_depth": sec_depth}
             # sec_o carries a graph (depth_map -> weights): the feature query must propagate d/d(xyz) through the
             # encoding's xyz pass-through too (models/split_mixed_occ.py:315 goes through tcnn + nn.Linear input grads)
             sec_feature = self.geometry(sec_o, with_grad=False, with_feature=True, input_grad=True)[1]
