@@ -23,13 +23,13 @@ ROI = lambda r: torch.tensor([-r, -r, -r, r, r, r], dtype=torch.float32)   # noq
 
 def emitter_fns(base):
     """lib/pbr/light.py:169-206 for a base cube map [6,R,R,3]: build_mips once -> (eval_diffuse, eval_specular)."""
-    spec, diffuse = E.build_mips(base)
+    spec, diffuse = E.build_mips(base.double())            # fp64 prefilters (dense weights), as the envlight tests
 
     def eval_diffuse(n):
-        return E.cube_sample_linear(diffuse, n)
+        return E.cube_sample_linear(diffuse, n.double()).to(n.dtype)
 
     def eval_specular(d, roughness):
-        return E.cube_sample_mip(spec, d, E.get_mip(roughness, len(spec))[..., 0])
+        return E.cube_sample_mip(spec, d.double(), E.get_mip(roughness.double(), len(spec))[..., 0]).to(d.dtype)
     return eval_diffuse, eval_specular
 
 
@@ -99,8 +99,10 @@ def render(rays, P, *, stage, indirect, relighting=False, stratified_u=None, ove
             sdepth = accumulate_along_rays(sw, ((sts + ste) / 2.0)[:, None], ray_indices=sri, n_rays=valid.numel())
             tr = (1.0 - sacc).clamp(0, 1)
         out["tr"], out["sec_depth"] = tr, sdepth
-        # feature at the hit point WITH its graph (sec_o depends on depth -> weights), :315
-        sec_feature = volume_sdf(sec_o, P["table"], P["meta"], P["mlp"], radius=r, fd_eps=P["fd_eps"])[2]
+        # feature at the hit point WITH its graph (sec_o depends on depth -> weights; the reference goes through tcnn's
+        # input gradient and nn.Linear, :315): the torch-op hash grid of oracle/analytic.py differentiates in x
+        from . import analytic as OA
+        sec_feature = OA.field(sec_o, P["table"], P["meta"], P["mlp"], r)
         sec_in = torch.cat([sec_feature, T.sh_encode((sec_d + 1.0) / 2.0, 5), nv], -1)
         sec_rgb = torch.sigmoid(T.relu_mlp(sec_in, P["nets"]["secondary"]))
         spec = spec.clone()
