@@ -218,6 +218,33 @@ def roofline_from(summary, steps):
     return out, breakdown
 
 
+def generic_gather_probe(model, rays, jitter, chunk):
+    """The generic tcnn-shaped encoder (rsdf_hashgrid_fwd: what every reference-shaped caller of tcnn.Encoding uses) on
+    the centre points of one bench chunk (~19 M ray samples), timed with HIP events outside the timed region."""
+    from rise_sdf_amd import ops
+    with torch.no_grad():
+        ro, rd = rays[:chunk, :3].contiguous(), rays[:chunk, 3:].contiguous()
+        ri, ts, te = model.occupancy_grid.sampling(ro, rd, render_step_size=model.render_step_size,
+                                                   stratified_u=jitter[:chunk], cone_angle=0.0, alpha_thre=0.0)
+        x7 = ops.fd_points(ro, rd, ri, ts, te, model.geometry.radius, model.geometry._finite_difference_eps)
+        x = x7.view(-1, 7, 3)[:, 0].contiguous()
+        del x7
+        enc = model.geometry.encoding.encoding.encoding
+        enc(x)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            enc(x)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 3
+    n = x.shape[0]
+    gbs = n * 1164 / (ms / 1e3) / 1e9
+    return {"bound": "hbm", "evals": n, "avg_launch_ms": round(ms, 3), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "evals_per_sec": n / (ms / 1e3),
+            "note": "generic per-point gather, 1164 algorithmic B per evaluation, centre points of one 32768-ray chunk"}
+
+
 def attach_traffic(roof, path):
     """roofline.traffic: HBM bytes per launch of the dominant kernel from the committed PMC summary (separate
     rocprofv3 --pmc passes, FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note; tools/pmc_summary.py).  The
@@ -321,6 +348,17 @@ def main():
         if timer is not None:
             roof, breakdown = roofline_from(timer.summary(), args.steps)
             attach_traffic(roof, args.pmc_summary)
+            if roof is not None and "other_kernels" in roof:
+                fd7 = roof["other_kernels"].get("rsdf_hashgrid_fwd_fd7")
+                if fd7 is not None:
+                    # the stencil gather priced two ways: SURVEY 8d's algorithmic bytes (7 evaluations x 1164 B; a
+                    # fraction >= 1 only says that it fetches far fewer corners than 56 per level), and the bytes it
+                    # cannot avoid moving through HBM (x7t 84 B + planes 896 B per sample; the table is L2 / MALL resident)
+                    fd7["necessary_bytes_per_sample"] = 980
+                    fd7["achieved_necessary"] = round(fd7["achieved"] * 980.0 / (7 * 1164.0), 1)
+                    fd7["frac_necessary"] = round(fd7["achieved_necessary"] / HBM_PEAK_GBS, 4)
+                    fd7["evals_per_sec"] = round(fd7["achieved"] * 1e9 / 1164.0)
+                roof["other_kernels"]["rsdf_hashgrid_fwd (generic)"] = generic_gather_probe(model, rays, jitter, args.chunk)
         cpu = None
         if args.cpu_rays > 0 and world == 1:   # reported at N = 1 only
             cpu = cpu_baseline(model, rays_cpu, jitter_cpu, args.cpu_rays)

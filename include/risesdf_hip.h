@@ -259,6 +259,10 @@ int rsdf_neus_alpha_fd_bwd(const float *sdf7, int ld, const float *rays_d,
 int rsdf_neus_alpha_fwd(const float *sdf, const float *normal, const float *dirs,
                         const float *dists, const float *variance, float cos_anneal_ratio,
                         int64_t n, float *alpha, void *stream);
+/* A2: occ_eval_fn (models/split_mixed_occ.py:108-119): alpha of the occupancy-grid update = the formula above with
+ * cos == -1 and dists == render_step_size, from the SDF at the cell points (no gradient). */
+int rsdf_neus_occ_alpha(const float *sdf, const float *variance, float render_step_size, int64_t n, float *alpha,
+                        void *stream);
 int rsdf_neus_alpha_bwd(const float *sdf, const float *normal, const float *dirs,
                         const float *dists, const float *variance, float cos_anneal_ratio,
                         int64_t n, const float *d_alpha, float *d_sdf, float *d_normal,

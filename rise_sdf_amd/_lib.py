@@ -111,6 +111,7 @@ _SIGNATURES = {
     "rsdf_grid_sample2d_bwd2": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "rsdf_neus_alpha_fwd": [_P, _P, _P, _P, _P, _F, _L, _P, _P],
     "rsdf_neus_alpha_bwd": [_P, _P, _P, _P, _P, _F, _L, _P, _P, _P, _P, _P],
+    "rsdf_neus_occ_alpha": [_P, _P, _F, _L, _P, _P],
 }
 _RESTYPES = {"rsdf_last_error": ctypes.c_char_p, "rsdf_scan_scratch_bytes": ctypes.c_int64,
              "rsdf_grid_meta_init": ctypes.c_int64,

@@ -223,22 +223,28 @@ __device__ __forceinline__ void emit_round(const uint32_t (&ridx)[ROUND_RECS],
         }
     }
     __syncthreads();  // A
-    if (tid < 64) {  // first wavefront: exclusive scan of the bin counts + queue reservations
+    // First wavefront: exclusive scan of the bin counts + queue reservations.  The reservation is a RETURNING global
+    // atomic (~1-2 us under load); its result is only needed by the copy-out, so it is parked in a register here and
+    // published to s_gbase after this wave has staged its own records: the round trip overlaps barrier B and the staging
+    // instead of holding all sixteen waves at B.
+    int gbase = 0;
+    if (tid < 64) {
         const int c = tid < n_bins ? s_cnt[tid] : 0;
         const int incl = wave_incl_sum_i(c);
         if (tid < n_bins) {
             s_off[tid] = incl - c;
-            s_gbase[tid] = c > 0 ? atomicAdd(&qcount[tid], c) : 0;
+            gbase = c > 0 ? atomicAdd(&qcount[tid], c) : 0;
             s_cnt[tid] = 0;
         }
         if (tid == 63) s_off[MAX_BINS] = incl;
     }
     __syncthreads();  // B
     const int total = s_off[MAX_BINS];
-    if (total == 0) return;  // uniform
+    if (total == 0) return;  // uniform (no reservation was made: every count was zero)
 #pragma unroll
     for (int r = 0; r < ROUND_RECS; ++r)
         if (valid_mask & (1u << r)) s_stage[s_off[bin[r]] + slot[r]] = Record{ridx[r], rval[r].x, rval[r].y};
+    if (tid < n_bins) s_gbase[tid] = gbase;
     __syncthreads();  // C
     for (int i = tid; i < total; i += P_THREADS) {
         const Record rec = s_stage[i];
@@ -253,6 +259,9 @@ __device__ __forceinline__ void emit_round(const uint32_t (&ridx)[ROUND_RECS],
     }
 }
 
+// Work item of the second phase: a displaced tap.  bits 0..9 sample within the workgroup, 10..12 tap - 1, 13 side (1: +1 cell)
+constexpr int MAX_ITEMS = P_THREADS * 6;
+
 __global__ void __launch_bounds__(P_THREADS)
 fd7_produce_kernel(const float *__restrict__ x7t, const float2 *__restrict__ dplanes,
                    const rsdf_grid_meta meta, const LevelPlan plan, int64_t S,
@@ -262,8 +271,11 @@ fd7_produce_kernel(const float *__restrict__ x7t, const float2 *__restrict__ dpl
     __shared__ int s_cnt[MAX_BINS];
     __shared__ int s_off[MAX_BINS + 1];
     __shared__ int s_gbase[MAX_BINS];
+    __shared__ int s_nitems;
+    __shared__ unsigned short s_items[MAX_ITEMS];
     extern __shared__ __attribute__((aligned(16))) Record s_stage[];  // [STAGE_CAP]
     if (threadIdx.x < MAX_BINS) s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_nitems = 0;
     __syncthreads();
 
     const int l = blockIdx.y;
@@ -274,20 +286,20 @@ fd7_produce_kernel(const float *__restrict__ x7t, const float2 *__restrict__ dpl
     const int n_bins = plan.n_bins[l], interleaved = plan.interleaved[l];
     const int64_t cap = plan.cap[l];
 
-    const int64_t s = (int64_t)blockIdx.x * P_THREADS + threadIdx.x;
+    const int64_t s_block = (int64_t)blockIdx.x * P_THREADS;
+    const int64_t s = s_block + threadIdx.x;
     const bool active = s < S;
 
+    // ---- phase 1: one thread per sample.  The centre cell's 8 corners collect the centre tap, every tap that stays in
+    // the cell, and the shared face of every tap that moved to a face neighbour.  The 4 NEW corners of such a displaced
+    // tap are not computed here: the tap is queued as a work item, so that their cost follows the number of displaced
+    // taps (~ eps / cell: a few per cent at the coarse levels) instead of being paid by every thread at every level.
     float2 acc[8];
-    float2 ex[3][8];
-    bool plus[3] = {false, false, false}, minus[3] = {false, false, false};
     CellFrac c0;
 #pragma unroll
     for (int c = 0; c < 8; ++c) acc[c] = make_float2(0.f, 0.f);
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int c = 0; c < 8; ++c) ex[a][c] = make_float2(0.f, 0.f);
     c0.c[0] = c0.c[1] = c0.c[2] = 0;
+    unsigned items = 0;   // 6 x 2 bits: bit 2(t-1) = displaced, bit 2(t-1)+1 = side
 
     if (active) {
         {
@@ -315,30 +327,17 @@ fd7_produce_kernel(const float *__restrict__ x7t, const float2 *__restrict__ dpl
                     acc[c].x += w * gr.x;
                     acc[c].y += w * gr.y;
                 }
-            } else if (da == 1) {
-                plus[a] = true;
+            } else if (da == 1 || da == -1) {
+                // the tap's near face (its corners with bit a == (da < 0)) coincides with the centre cell's far face
+                items |= (da == 1 ? 3u : 1u) << (2 * (t - 1));
+                const int near = da == 1 ? 0 : 1;
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    const float w = corner_weight(ct, c);
-                    if (((c >> a) & 1) == 0) {
-                        acc[c | (1 << a)].x += w * gr.x;
-                        acc[c | (1 << a)].y += w * gr.y;
-                    } else {
-                        ex[a][other_bits(c, a)].x += w * gr.x;
-                        ex[a][other_bits(c, a)].y += w * gr.y;
-                    }
-                }
-            } else if (da == -1) {
-                minus[a] = true;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const float w = corner_weight(ct, c);
-                    if (((c >> a) & 1) == 1) {
-                        acc[c & ~(1 << a)].x += w * gr.x;
-                        acc[c & ~(1 << a)].y += w * gr.y;
-                    } else {
-                        ex[a][4 + other_bits(c, a)].x += w * gr.x;
-                        ex[a][4 + other_bits(c, a)].y += w * gr.y;
+                    if (((c >> a) & 1) == near) {
+                        const float w = corner_weight(ct, c);
+                        const int cc = c ^ (1 << a);
+                        acc[cc].x += w * gr.x;
+                        acc[cc].y += w * gr.y;
                     }
                 }
             } else {  // tap more than one cell away (eps larger than a cell): rare slow path
@@ -352,6 +351,14 @@ fd7_produce_kernel(const float *__restrict__ x7t, const float2 *__restrict__ dpl
                 }
             }
         }
+    }
+    {   // append this thread's displaced taps to the workgroup's work list
+        const int cnt = __popc(items & 0x555u);
+        int pos = cnt ? atomicAdd(&s_nitems, cnt) : 0;
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+            if (items >> (2 * t) & 1u)
+                s_items[pos++] = (unsigned short)(threadIdx.x | (t << 10) | ((items >> (2 * t + 1) & 1u) << 13));
     }
 
     // Cross-sample merge at coarse levels: consecutive samples of a ray (= consecutive lanes) share their centre
@@ -392,15 +399,40 @@ fd7_produce_kernel(const float *__restrict__ x7t, const float2 *__restrict__ dpl
 #pragma unroll
     for (int c = 0; c < 8; ++c)
         ridx[c] = entry_index(c0.c[0] + (c & 1), c0.c[1] + ((c >> 1) & 1), c0.c[2] + ((c >> 2) & 1), g);
-    emit_round(ridx, acc, emit0 ? 0xffu : 0u, n_bins, interleaved, cap, queue, qcount, dlevel, s_cnt,
-               s_off, s_gbase, s_stage);
+    emit_round(ridx, acc, emit0 ? 0xffu : 0u, n_bins, interleaved, cap, queue, qcount, dlevel, s_cnt, s_off,
+               s_gbase, s_stage);   // (its barriers also publish the work list)
+
+    // ---- phase 2: dense over the displaced taps, two per thread and round (4 new corners each)
+    const int n_items = s_nitems;
+    for (int base = 0; base < n_items; base += 2 * P_THREADS) {
+        uint32_t mask = 0;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
+        for (int j = 0; j < 2; ++j) {
+            const int i = base + j * P_THREADS + (int)threadIdx.x;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) ridx[k] = extra_index(c0, a, k, g);
-        const uint32_t mask = (active && plus[a] ? 0x0fu : 0u) | (active && minus[a] ? 0xf0u : 0u);
-        emit_round(ridx, ex[a], mask, n_bins, interleaved, cap, queue, qcount, dlevel, s_cnt, s_off,
-                   s_gbase, s_stage);
+            for (int k = 0; k < 4; ++k) {
+                ridx[4 * j + k] = 0;
+                acc[4 * j + k] = make_float2(0.f, 0.f);
+            }
+            if (i < n_items) {
+                const unsigned it = s_items[i];
+                const int64_t s2 = s_block + (it & 1023u);
+                const int t = (int)(it >> 10 & 7u) + 1, a = (t - 1) >> 1, far = (int)(it >> 13 & 1u);
+                const float *p = x7t + ((int64_t)t * S + s2) * 3;
+                const CellFrac ct = cell_frac(p[0], p[1], p[2], g.scale);
+                const float2 gr = dplanes[((int64_t)l * 7 + t) * S + s2];
+                const int o1 = (a == 0) ? 1 : 0, o2 = (a == 2) ? 1 : 2;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int c = (far << a) | ((k & 1) << o1) | ((k >> 1) << o2);   // far face: bit a == (da > 0)
+                    const float w = corner_weight(ct, c);
+                    ridx[4 * j + k] = entry_index(ct.c[0] + (c & 1), ct.c[1] + ((c >> 1) & 1), ct.c[2] + ((c >> 2) & 1), g);
+                    acc[4 * j + k] = make_float2(w * gr.x, w * gr.y);
+                }
+                mask |= 0xfu << (4 * j);
+            }
+        }
+        emit_round(ridx, acc, mask, n_bins, interleaved, cap, queue, qcount, dlevel, s_cnt, s_off, s_gbase, s_stage);
     }
 }
 

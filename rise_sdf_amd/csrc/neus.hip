@@ -273,6 +273,18 @@ alpha_fwd_kernel(const float *__restrict__ sdf, const float *__restrict__ normal
     alpha[i] = alpha_core(sdf[i], cosv, dists[i], inv_s_from(variance), r, t);
 }
 
+// A2: occ_eval_fn (models/split_mixed_occ.py:108-119, models/neus.py:101-111): the same formula with cos == -1 and
+// dist == render_step_size, on the SDF of the occupancy grid's cell points (no gradient: the update runs under no_grad)
+__global__ void __launch_bounds__(THREADS)
+occ_alpha_kernel(const float *__restrict__ sdf, const float *__restrict__ variance, float step, int64_t n,
+                 float *__restrict__ alpha)
+{
+    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= n) return;
+    AlphaTerms t;
+    alpha[i] = alpha_core(sdf[i], -1.0f, step, inv_s_from(variance), 1.0f, t);
+}
+
 __global__ void __launch_bounds__(THREADS)
 alpha_bwd_kernel(const float *__restrict__ sdf, const float *__restrict__ normal,
                  const float *__restrict__ dirs, const float *__restrict__ dists,
@@ -389,6 +401,15 @@ int rsdf_neus_alpha_fwd(const float *sdf, const float *normal, const float *dirs
     if (n <= 0) return 0;
     alpha_fwd_kernel<<<rsdf_blocks(n, THREADS), THREADS, 0, (hipStream_t)stream>>>(
         sdf, normal, dirs, dists, variance, cos_anneal_ratio, n, alpha);
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_neus_occ_alpha(const float *sdf, const float *variance, float render_step_size, int64_t n, float *alpha,
+                        void *stream)
+{
+    if (n <= 0) return 0;
+    occ_alpha_kernel<<<rsdf_blocks(n, THREADS), THREADS, 0, (hipStream_t)stream>>>(sdf, variance, render_step_size, n,
+                                                                                 alpha);
     RSDF_RETURN_LAUNCH();
 }
 

@@ -114,12 +114,9 @@ class NeuSModel(BaseModel):
     def occ_eval_fn(self, x):
         """models/neus.py:101-111 (A2): alpha with cos == -1 and delta == render_step_size."""
         sdf = self.geometry(x, with_grad=False, with_feature=False)
-        inv_s = self.variance(torch.zeros([1, 3]))[:, :1].clip(1e-6, 1e6)
-        inv_s = inv_s.expand(sdf.shape[0], 1)
-        next_sdf = sdf[..., None] - self.render_step_size * 0.5
-        prev_sdf = sdf[..., None] + self.render_step_size * 0.5
-        prev_cdf, next_cdf = torch.sigmoid(prev_sdf * inv_s), torch.sigmoid(next_sdf * inv_s)
-        return ((prev_cdf - next_cdf + 1e-5) / (prev_cdf + 1e-5)).view(-1, 1).clip(0.0, 1.0)
+        if getattr(self.variance, "modulate", False):
+            raise NotImplementedError("occ_eval_fn with a modulated variance (disabled in the shipped configs)")
+        return ops.occ_alpha(sdf, self.variance.variance, self.render_step_size)      # one kernel (A2)
 
     def get_alpha(self, sdf, normal, dirs, dists):
         """models/neus.py:128-150."""

@@ -64,10 +64,9 @@ class SplitMixedOCCModel(BaseModel):
 
     def occ_eval_fn(self, x):
         sdf = self.geometry(x, with_grad=False, with_feature=False)
-        inv_s = self.variance(torch.zeros([1, 3]))[:, :1].clip(1e-6, 1e6).expand(sdf.shape[0], 1)
-        prev_cdf = torch.sigmoid((sdf[..., None] + self.render_step_size * 0.5) * inv_s)
-        next_cdf = torch.sigmoid((sdf[..., None] - self.render_step_size * 0.5) * inv_s)
-        return ((prev_cdf - next_cdf + 1e-5) / (prev_cdf + 1e-5)).view(-1, 1).clip(0.0, 1.0)
+        if getattr(self.variance, "modulate", False):
+            raise NotImplementedError("occ_eval_fn with a modulated variance (disabled in the shipped configs)")
+        return ops.occ_alpha(sdf, self.variance.variance, self.render_step_size)      # one kernel (A2)
 
     def get_alpha(self, sdf, normal, dirs, dists):
         return ops.neus_alpha(sdf, normal, dirs, dists, self.variance.variance, self.cos_anneal_ratio)

@@ -43,6 +43,21 @@ def main():
     import rise_sdf_amd.renderutils as R
     assert ru_ops._get_plugin() is R.plugin
 
+    # B1: the registry swap of INTEGRATION.md -- the reference's own ``models.make`` then builds this repo's classes
+    import models as ref_models
+    import rise_sdf_amd
+    for name in ("volume-sdf", "neus", "split-mixed-occ", "volume-mixed-mip-split-occ", "volume-radiance",
+                 "envlight-mip-cube"):
+        assert name in ref_models.models, name                     # the reference registered it under this name
+        ref_models.models[name] = rise_sdf_amd.models[name]
+    cfg = rise_sdf_amd.Config({"name": "volume-radiance", "input_feature_dim": 16,
+                               "dir_encoding_config": {"otype": "SphericalHarmonics", "degree": 4},
+                               "mlp_network_config": {"otype": "VanillaMLP", "activation": "ReLU",
+                                                      "output_activation": "none", "n_neurons": 16, "n_hidden_layers": 1},
+                               "color_activation": "sigmoid"})
+    built = ref_models.make("volume-radiance", cfg)
+    assert type(built).__module__.startswith("rise_sdf_amd."), type(built)
+
     import nerfacc
     import nvdiffrast.torch as dr
     import tinycudann as tcnn

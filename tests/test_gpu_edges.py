@@ -4,6 +4,7 @@ import math
 import pytest
 import torch
 
+import oracle
 from helpers import rel_err
 
 pytestmark = pytest.mark.gpu
@@ -90,3 +91,66 @@ def test_fused_field_tiny_sample_counts(dev, S):
     assert torch.allclose(feat, ref[:, 0], rtol=1e-5, atol=1e-6)
     (sdf7t.sum() + feat.sum()).backward()
     assert bool(torch.isfinite(geo.encoding.encoding.encoding.params.grad).all())
+
+
+def test_occ_eval_alpha_kernel(dev):
+    """A2 (models/split_mixed_occ.py:108-119): the occupancy-update alpha as one kernel vs the oracle's formula."""
+    from rise_sdf_amd import ops
+    g = torch.Generator().manual_seed(0)
+    sdf = (torch.rand(5000, generator=g) * 2 - 1) * 0.05
+    sdf[:4] = torch.tensor([0.0, 1.0, -1.0, 1e-4])
+    for v in (0.3, 0.05, 0.9):
+        var = torch.tensor(v)
+        got = ops.occ_alpha(sdf.to(dev), var.to(dev), 0.00507421875)
+        want = oracle.occ_alpha(sdf, oracle.inv_s_from_variance(var), 0.00507421875)
+        assert got.shape == (5000, 1)
+        assert torch.allclose(got.cpu().view(-1), want.view(-1), rtol=1e-5, atol=1e-6), v
+
+
+def test_fused_mlp_is_fp32_accurate(dev):
+    """The split-bf16 fused kernels against an fp64 evaluation of the same weights on the same hash features, next to
+    plain fp32 torch: the fused SDF must be at least as close to fp64 as torch's fp32 GEMM chain, and the error of the
+    finite-difference normal must be of the size an fp32 ulp of SDF noise explains (|err| ~ ulp / eps), which is the
+    justification of the gradient tolerances in test_gpu_model.py."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    import rise_sdf_amd as R
+    from rise_sdf_amd import fused, ops
+    for hidden in (64, 128):
+        torch.manual_seed(0)
+        model = R.make("neus", bench.c1_config(hidden=hidden)).to(dev)
+        geo = model.geometry
+        with torch.no_grad():
+            geo.encoding.encoding.encoding.params.uniform_(-1e-1, 1e-1)
+            l0 = geo.network.layers[0]
+            l0.weight_v[:, 3:] = torch.randn_like(l0.weight_v[:, 3:]) * 0.3
+        model.train()
+        geo.update_step(0, 20000)
+        S = 60000
+        g = torch.Generator().manual_seed(1)
+        pts = (torch.rand(S, 3, generator=g) * 2 - 1) * 1.4
+        x7 = ops.fd_taps(pts.to(dev), geo.radius, geo._finite_difference_eps)
+        enc = geo.encoding(x7.view(-1, 3), fd7_eps_unit=geo._eps_unit()).detach()       # bit-exact gather
+        wb = [(w.detach(), b.detach()) for w, b in geo.network.effective_weights()]
+
+        def mlp(x, dtype):
+            h = x.to(dtype)
+            for i, (w, b) in enumerate(wb):
+                h = torch.nn.functional.linear(h, w.to(dtype), b.to(dtype))
+                if i < len(wb) - 1:
+                    h = torch.nn.functional.softplus(h, beta=100)
+            return h[:, 0]
+        ref = mlp(enc, torch.float64)
+        t32 = mlp(enc, torch.float32).double()
+        grid, n_active = geo.encoding._hash()
+        sdf7t, _ = fused.sdf_field_fd7(x7.permute(1, 0, 2).contiguous(), grid.params, geo.network.effective_weights(),
+                                       grid.meta, grid.n_levels if n_active is None else n_active,
+                                       geo.encoding.xyz_scale, geo.encoding.xyz_offset, geo._eps_unit(), False)
+        fs = sdf7t.detach().t().reshape(-1).double()
+        e_fused, e_t32 = float((fs - ref).abs().max()), float((t32 - ref).abs().max())
+        assert e_fused < 4e-7 and e_fused <= 1.5 * e_t32 + 1e-7, (hidden, e_fused, e_t32)
+        eps = geo._finite_difference_eps
+        fd = lambda s: 0.5 * (s.view(-1, 7)[:, 1::2] - s.view(-1, 7)[:, 2::2]) / eps   # noqa: E731
+        e_n = float((fd(fs) - fd(ref)).abs().max())
+        assert e_n < 2.0 * e_fused / eps + 1e-6 and e_n < 2e-3, (hidden, e_n, e_fused / eps)

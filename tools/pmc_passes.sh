@@ -1,6 +1,8 @@
 #!/bin/bash
 # PMC counter passes for bench.py (one counter group per run, kernel-trace only; MI355X_MICROARCH.md "rocprofv3
 # PMC slots").  Run on the GPU box: bash tools/pmc_passes.sh [bench args].  Summaries land in gpurun_out/pmc/.
+set -uo pipefail
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}"
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 ARGS=${@:---steps 1 --warmup 0 --cpu-rays 0 --width 400 --height 400 --no-kernel-timing}
