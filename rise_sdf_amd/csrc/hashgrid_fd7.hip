@@ -22,7 +22,7 @@
 //      thread), accumulates into a 128 KiB fp64 LDS image with ds_add_f64 (measured 18x the rate of
 //      ds_add_f32 on gfx950, tools/lds_atomic_bench.hip) and adds the image to dtable
 //      with contiguous (full-rate) global atomics.
-// Hashed levels bin by the high index bits; dense levels bin by idx % n_bins so that a spatially
+// Hashed levels bin by the high index bits; dense levels bin by idx % n_bins (n_bins a power of two) so that a spatially
 // compact batch of rays still loads all bins evenly.
 #include <stdlib.h>
 
@@ -57,7 +57,7 @@ struct Record {
 struct LevelPlan {
     int count;                       // active levels
     int n_bins[RSDF_MAX_LEVELS];
-    int interleaved[RSDF_MAX_LEVELS];  // 1: bin = idx % n_bins (dense levels), 0: bin = idx >> 14
+    int interleaved[RSDF_MAX_LEVELS];  // 0: bin = idx >> 13 (hashed levels); k > 0: n_bins = 2^(k-1), bin = idx & (n_bins-1)
     int n_split[RSDF_MAX_LEVELS];      // reducer workgroups per bin (balances the per-level load)
     int64_t cap[RSDF_MAX_LEVELS];      // records per bin queue
     int64_t queue_off[RSDF_MAX_LEVELS];
@@ -66,7 +66,7 @@ struct LevelPlan {
 
 struct LevelGeom {
     float scale;
-    uint32_t res, size, mask;
+    uint32_t res, res2, size, mask;
     bool dense;
 };
 
@@ -76,6 +76,7 @@ __device__ __forceinline__ LevelGeom level_geom(const rsdf_grid_meta &m, int l)
     g.scale = m.scale[l];
     g.res = m.res[l];
     g.size = m.size[l];
+    g.res2 = g.res * g.res;
     g.dense = (uint64_t)g.res * g.res * g.res <= (uint64_t)g.size;
     g.mask = g.size - 1u;
     return g;
@@ -86,6 +87,27 @@ __device__ __forceinline__ uint32_t entry_index(uint32_t x, uint32_t y, uint32_t
 {
     if (g.dense) return (x + y * g.res + z * g.res * g.res) % g.size;
     return ((x * 1u) ^ (y * 2654435761u) ^ (z * 805459861u)) & g.mask;
+}
+
+// The 8 corner indices of cell (x, y, z), sharing the multiplications: (y + 1) p == y p + p (mod 2^32), so the hashed
+// form needs 2 integer multiplies per cell instead of 16 (v_mul_lo_u32 is a quarter-rate instruction), and the dense form
+// replaces "% size" by one conditional subtract: all coordinates are in [0, res], hence x + y res + z res^2 < 2 res^3 <=
+// 2 size.  Same values as entry_index() for every corner.
+__device__ __forceinline__ void corner_indices(uint32_t x, uint32_t y, uint32_t z, const LevelGeom &g, uint32_t (&idx)[8])
+{
+    if (g.dense) {
+        const uint32_t b = x + y * g.res + z * g.res2;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const uint32_t v = b + (uint32_t)(c & 1) + ((c >> 1) & 1 ? g.res : 0u) + ((c >> 2) & 1 ? g.res2 : 0u);
+            idx[c] = v >= g.size ? v - g.size : v;
+        }
+    } else {
+        const uint32_t yp0 = y * 2654435761u, zp0 = z * 805459861u;
+        const uint32_t xs[2] = {x, x + 1u}, yp[2] = {yp0, yp0 + 2654435761u}, zp[2] = {zp0, zp0 + 805459861u};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) idx[c] = (xs[c & 1] ^ yp[(c >> 1) & 1] ^ zp[(c >> 2) & 1]) & g.mask;
+    }
 }
 
 // compact index 0..3 of the two axes other than a
@@ -195,7 +217,7 @@ fd7_fwd_kernel(const float *__restrict__ x7t, const float *__restrict__ table,
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int bin_of(uint32_t idx, int n_bins, int interleaved)
 {
-    return interleaved ? (int)(idx % (uint32_t)n_bins) : (int)(idx >> BIN_SHIFT);
+    return interleaved ? (int)(idx & (uint32_t)(n_bins - 1)) : (int)(idx >> BIN_SHIFT);   // no division on this path
 }
 
 __device__ __forceinline__ void emit_round(const uint32_t (&ridx)[ROUND_RECS],
@@ -302,10 +324,12 @@ fd7_produce_kernel(const float *__restrict__ x7t, const float2 *__restrict__ dpl
     unsigned items = 0;   // 6 x 2 bits: bit 2(t-1) = displaced, bit 2(t-1)+1 = side
 
     if (active) {
+        const float *px = x7t + s * 3;                                  // tap t: px + t (3 S)
+        const float2 *pg = dplanes + ((int64_t)l * 7) * S + s;          // tap t: pg + t S
         {
-            const float *p = x7t + s * 3;
+            const float *p = px;
             c0 = cell_frac(p[0], p[1], p[2], g.scale);
-            const float2 gr = dplanes[((int64_t)l * 7) * S + s];
+            const float2 gr = pg[0];
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const float w = corner_weight(c0, c);
@@ -316,9 +340,9 @@ fd7_produce_kernel(const float *__restrict__ x7t, const float2 *__restrict__ dpl
 #pragma unroll
         for (int t = 1; t < 7; ++t) {
             const int a = (t - 1) >> 1;
-            const float *p = x7t + ((int64_t)t * S + s) * 3;
+            const float *p = px + (int64_t)t * S * 3;
             const CellFrac ct = cell_frac(p[0], p[1], p[2], g.scale);
-            const float2 gr = dplanes[((int64_t)l * 7 + t) * S + s];
+            const float2 gr = pg[(int64_t)t * S];
             const int32_t da = (int32_t)(ct.c[a] - c0.c[a]);
             if (da == 0) {
 #pragma unroll
@@ -396,9 +420,7 @@ fd7_produce_kernel(const float *__restrict__ x7t, const float2 *__restrict__ dpl
         }
     }
     uint32_t ridx[ROUND_RECS];
-#pragma unroll
-    for (int c = 0; c < 8; ++c)
-        ridx[c] = entry_index(c0.c[0] + (c & 1), c0.c[1] + ((c >> 1) & 1), c0.c[2] + ((c >> 2) & 1), g);
+    corner_indices(c0.c[0], c0.c[1], c0.c[2], g, ridx);
     emit_round(ridx, acc, emit0 ? 0xffu : 0u, n_bins, interleaved, cap, queue, qcount, dlevel, s_cnt, s_off,
                s_gbase, s_stage);   // (its barriers also publish the work list)
 
@@ -422,11 +444,13 @@ fd7_produce_kernel(const float *__restrict__ x7t, const float2 *__restrict__ dpl
                 const CellFrac ct = cell_frac(p[0], p[1], p[2], g.scale);
                 const float2 gr = dplanes[((int64_t)l * 7 + t) * S + s2];
                 const int o1 = (a == 0) ? 1 : 0, o2 = (a == 2) ? 1 : 2;
+                uint32_t cidx[8];
+                corner_indices(ct.c[0], ct.c[1], ct.c[2], g, cidx);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int c = (far << a) | ((k & 1) << o1) | ((k >> 1) << o2);   // far face: bit a == (da > 0)
                     const float w = corner_weight(ct, c);
-                    ridx[4 * j + k] = entry_index(ct.c[0] + (c & 1), ct.c[1] + ((c >> 1) & 1), ct.c[2] + ((c >> 2) & 1), g);
+                    ridx[4 * j + k] = cidx[c];
                     acc[4 * j + k] = make_float2(w * gr.x, w * gr.y);
                 }
                 mask |= 0xfu << (4 * j);
@@ -460,7 +484,8 @@ fd7_reduce_kernel(const rsdf_grid_meta meta, const LevelPlan plan, const Record 
     if (r0 >= r1) return;
     const uint32_t size = meta.size[l];
     // entries this bin owns
-    const int entries = interleaved ? (int)((size - (uint32_t)b + (uint32_t)n_bins - 1u) / (uint32_t)n_bins)
+    const int lg = interleaved - 1;   // log2(n_bins) of an interleaved level
+    const int entries = interleaved ? (int)((size - (uint32_t)b + (uint32_t)n_bins - 1u) >> lg)
                                     : (int)(size < (uint32_t)BIN_ENTRIES ? size : (uint32_t)BIN_ENTRIES);
 
     for (int i = threadIdx.x; i < entries * 2; i += R_THREADS) s_acc[i] = 0.0;
@@ -476,7 +501,7 @@ fd7_reduce_kernel(const rsdf_grid_meta meta, const LevelPlan plan, const Record 
 #pragma unroll
         for (int u = 0; u < R_UNROLL; ++u) {
             if (i0 + (int64_t)u * R_THREADS < r1) {
-                const uint32_t e = interleaved ? rec[u].idx / (uint32_t)n_bins
+                const uint32_t e = interleaved ? rec[u].idx >> lg
                                                : (rec[u].idx & (uint32_t)(BIN_ENTRIES - 1));
                 atomicAdd(&s_acc[2 * e], (double)rec[u].v0);
                 atomicAdd(&s_acc[2 * e + 1], (double)rec[u].v1);
@@ -520,10 +545,15 @@ int make_plan(const rsdf_grid_meta *meta, int64_t S, int n_active, float eps_uni
         const uint64_t dense = (uint64_t)meta->res[l] * meta->res[l] * meta->res[l];
         const bool is_dense = dense <= size;
         if (!is_dense && (size & (size - 1u))) return -3;  // hashed sizes must be powers of two
-        const int nb = (int)((size + BIN_ENTRIES - 1) >> BIN_SHIFT);
+        int nb = (int)((size + BIN_ENTRIES - 1) >> BIN_SHIFT);
+        int lg = 0;
+        if (is_dense) {            // round up to a power of two: bin = idx & (nb - 1), entry = idx >> lg (shifts, no division)
+            while ((1 << lg) < nb) ++lg;
+            nb = 1 << lg;
+        }
         if (nb > MAX_BINS) return -2;
         plan->n_bins[l] = nb;
-        plan->interleaved[l] = is_dense ? 1 : 0;
+        plan->interleaved[l] = is_dense ? lg + 1 : 0;
         const double per_bin = (double)S * expected_records(meta->scale[l], eps_unit) / nb;
         // RSDF_FD7_QUEUE_SCALE (test knob, default 1): shrinks the queues so that the overflow path -- a record that
         // finds its queue full goes to the table with a direct atomic, and the reducer clamps its count -- is exercised
