@@ -66,6 +66,29 @@ struct G {
     static constexpr int SP = TAB + 2 * H * 4;                    // fp32 [NT][32] partial SDF sums (forward)
     static constexpr int RAW = SP + NT * 32 * 4;                  // fp32 [2][18][64]: LDS-DMA landing zone of the next tile
     static constexpr int END = RAW + 2 * 18 * 256;
+    static constexpr int N_XI = 2;
+};
+
+// Forward-only layout ("lean"): one X image, the H1 image, tables, partial sums, landing zone.  52 KB at H = 128, so two
+// workgroups share a CU (two waves per SIMD: the second hides the first one's barrier and LDS latencies, and a SIMD
+// issues a vector instruction every 2 cycles with two waves against every 4 with one).  W0 fragments are per-wave
+// registers; the last layer's feature rows are NOT in this kernel (the caller runs them as one per-layer product on h2c).
+template <int NT>
+struct GF {
+    static constexpr int H = 32 * NT;
+    static constexpr int THREADS = 64 * NT;
+    static constexpr int HCH = H / 8;
+    static constexpr int H_PART = HCH * CS;
+    static constexpr int W0CS = 0, W0_PART = 0, W0I = 0;
+    static constexpr bool W0_LDS = false;
+    static constexpr int LPW = 16 / NT;
+    static constexpr int XI = 0;
+    static constexpr int H1I = XI + 3 * X_PART;
+    static constexpr int TAB = H1I + 3 * H_PART;
+    static constexpr int SP = TAB + 2 * H * 4;                    // fp32 [2][NT][32] partial SDF sums (tile parity)
+    static constexpr int RAW = SP + 2 * NT * 32 * 4;
+    static constexpr int END = RAW + 2 * 18 * 256;
+    static constexpr int N_XI = 1;
 };
 
 // ---- image addressing -------------------------------------------------------------------------------------------
@@ -202,15 +225,14 @@ struct Src {
 
 // Stage the per-workgroup constants: zeroed images, the "1" column, the W0 image (columns in X order), b1 / w2r0 tables.
 //   X column order: 2 l + f = hash feature f of level l (0..31), 32..34 = xyz, 35 = 1 (carries b0), 36..63 = 0.
-template <int NT>
+template <typename L>
 __device__ __forceinline__ void stage_common(unsigned char *smem, const float *__restrict__ w0, const float *__restrict__ b0,
                                              const float *__restrict__ b1, const float *__restrict__ w2, int n_levels)
 {
-    using L = G<NT>;
     const int K0 = 3 + 2 * n_levels;
     for (int e = threadIdx.x; e < L::END / 4; e += L::THREADS) reinterpret_cast<unsigned *>(smem)[e] = 0u;
     __syncthreads();
-    if (threadIdx.x < 64)                                         // 1.0 (h part) in both X images
+    if (threadIdx.x < 32 * L::N_XI)                               // 1.0 (h part) in every X image
         *reinterpret_cast<unsigned short *>(smem + L::XI + (threadIdx.x >> 5) * 3 * X_PART + img_off(threadIdx.x & 31, 35)) = 0x3F80;
     unsigned short *w0i = reinterpret_cast<unsigned short *>(smem + L::W0I);
     for (int e = threadIdx.x; L::W0_LDS && e < L::H * 48; e += L::THREADS) {
@@ -366,11 +388,10 @@ __device__ __forceinline__ void load_w1t(Frag3 (&f)[NT][2], const float *__restr
 
 // ---- the two hidden layers of the tile in flight ---------------------------------------------------------------------
 // On return h1 / h2 hold this wave's feature tile (activated), the H1 image is complete and visible to every wave.
-template <int NT>
+template <int NT, typename L>
 __device__ __forceinline__ void hidden_layers(unsigned char *smem, const unsigned char *xi, const Frag3 (&w0f)[3],
                                               const Frag3 (&w1f)[NT][2], int w, int c, int hf, f32x16 &h1, f32x16 &h2)
 {
-    using L = G<NT>;
     f32x16 acc;
     {   // layer 1: all 18 fragment reads in flight, then the 18 products
         Frag3 a[3], b[3];
@@ -436,7 +457,7 @@ coop_fwd_kernel(const Src src, const float *__restrict__ w0, const float *__rest
     constexpr int H = L::H;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 31, hf = lane >> 5;
-    stage_common<NT>(smem, w0, b0, b1, w2, src.n_levels);
+    stage_common<G<NT>>(smem, w0, b0, b1, w2, src.n_levels);
     Frag3 w1f[NT][2], w0f[3];
     load_w1f<NT>(w1f, w1, w, c, hf);
     if (!L::W0_LDS) load_w0f(w0f, w0, b0, src.n_levels, 32 * w + c);
@@ -477,7 +498,7 @@ coop_fwd_kernel(const Src src, const float *__restrict__ w0, const float *__rest
             }
             lds_barrier();                                                     // X image complete
             f32x16 h1, h2;
-            hidden_layers<NT>(smem, xi, w0f, w1f, w, c, hf, h1, h2);
+            hidden_layers<NT, G<NT>>(smem, xi, w0f, w1f, w, c, hf, h1, h2);
             // SDF = W2[0,:] . h2 + b2[0]: this wave's 32 features, then across the waves through LDS
             float part = 0.0f;
 #pragma unroll
@@ -529,6 +550,71 @@ coop_fwd_kernel(const Src src, const float *__restrict__ w0, const float *__rest
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// forward, lean form (layout GF): sdf7t [7][S]; centre taps: h2c [S, H] (nullable).  Two workgroups per CU.
+// ------------------------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ void __launch_bounds__(64 * NT, 2)
+coop_fwd_lean_kernel(const Src src, const float *__restrict__ w0, const float *__restrict__ b0, const float *__restrict__ w1,
+                     const float *__restrict__ b1, const float *__restrict__ w2, const float *__restrict__ b2,
+                     float *__restrict__ sdf7, float *__restrict__ h2c)
+{
+    using L = GF<NT>;
+    constexpr int H = L::H;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 31, hf = lane >> 5;
+    stage_common<L>(smem, w0, b0, b1, w2, src.n_levels);
+    Frag3 w1f[NT][2], w0f[3];
+    load_w1f<NT>(w1f, w1, w, c, hf);
+    load_w0f(w0f, w0, b0, src.n_levels, 32 * w + c);
+    const float b2_0 = b2[0];
+    __syncthreads();
+    const float *tab = reinterpret_cast<const float *>(smem + L::TAB);
+    float *sp = reinterpret_cast<float *>(smem + L::SP);
+    unsigned char *xi = smem + L::XI;
+
+    const int64_t n_groups = (src.S + 31) / 32;
+    if ((int64_t)blockIdx.x < n_groups) dma_x<NT>(smem + L::RAW, src, (int64_t)blockIdx.x * 32, 0, w, lane);
+    int parity = 0;
+    for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        const int64_t s0 = g * 32;
+        for (int tap = 0; tap < 7; ++tap) {
+            wait_vm0();                                                          // this tile's inputs have landed
+            // (every wave is past barrier (b) of the previous tile, i.e. past its reads of the X image and of sp)
+            store_x<NT>(xi, smem + L::RAW + parity * 18 * 256, src, s0, w, lane);
+            parity ^= 1;
+            {
+                const int ntap = tap == 6 ? 0 : tap + 1;
+                const int64_t ng = tap == 6 ? g + gridDim.x : g;
+                if (ng < n_groups) dma_x<NT>(smem + L::RAW + parity * 18 * 256, src, ng * 32, ntap, w, lane);
+            }
+            lds_barrier();                                                     // (a) X image complete
+            f32x16 h1, h2;
+            hidden_layers<NT, L>(smem, xi, w0f, w1f, w, c, hf, h1, h2);         // barrier inside: H1 image complete
+            float part = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part = fmaf(tab[H + (2 * w + hf) * 16 + r], h2[r], part);
+            part += __shfl_xor(part, 32, 64);
+            // two partial-sum buffers by tile parity: wave 0 reads sp of this tile after (b) while the others may already
+            // be writing the next tile's sums
+            if (hf == 0) sp[(parity * NT + w) * 32 + c] = part;
+            if (tap == 0 && h2c != nullptr && s0 + c < src.S) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4 *>(h2c + (s0 + c) * H + 32 * w + 8 * q + 4 * hf) =
+                        float4{h2[4 * q], h2[4 * q + 1], h2[4 * q + 2], h2[4 * q + 3]};
+            }
+            lds_barrier();                                                     // (b) partial sums visible
+            if (w == 0 && hf == 0 && s0 + c < src.S) {
+                float acc = b2_0;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc += sp[(parity * NT + t) * 32 + c];
+                sdf7[(int64_t)tap * src.S + s0 + c] = acc;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // backward: d_sdf7t [7][S] (+ dh2c [S, H]: d(loss)/d(h2) of the centre taps through the feature rows of the last layer,
 //           nullable) -> d_planes [L][7][S][2] (nullable), dW0, db0, dW1, db1, dW2 row 0, db2[0] (atomically accumulated)
 // ------------------------------------------------------------------------------------------------------------------
@@ -545,7 +631,7 @@ coop_bwd_kernel(const Src src, const float *__restrict__ w0, const float *__rest
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 31, hf = lane >> 5;
     const int K0 = 3 + 2 * src.n_levels;
-    stage_common<NT>(smem, w0, b0, b1, w2, src.n_levels);
+    stage_common<G<NT>>(smem, w0, b0, b1, w2, src.n_levels);
     Frag3 w1f[NT][2], w1t[NT][2], w0t[2], w0f[3];
     load_w1f<NT>(w1f, w1, w, c, hf);
     if (!L::W0_LDS) load_w0f(w0f, w0, b0, src.n_levels, 32 * w + c);
@@ -604,7 +690,7 @@ coop_bwd_kernel(const Src src, const float *__restrict__ w0, const float *__rest
             }
             lds_barrier();                                                     // (1) X image complete
             f32x16 h1, h2;
-            hidden_layers<NT>(smem, xi, w0f, w1f, w, c, hf, h1, h2);                  // (2) inside: H1 image complete
+            hidden_layers<NT, G<NT>>(smem, xi, w0f, w1f, w, c, hf, h1, h2);                  // (2) inside: H1 image complete
             // ---- layer 3: d(h2) = W2[0,:] d_sdf (+ feature part); dW2[0,:] += d_sdf h2; dz2 = d(h2) sigma'(z2)
             const float dsdf = row_ok ? dsdf_raw : 0.0f;
             if (w == 0 && hf == 0) gb2 += dsdf;
@@ -797,6 +883,24 @@ int rsdf_coop_fwd(int NT, const float *x7t, const float *planes, int n_levels, i
 {
     const Src src{x7t, planes, n_samples, n_levels, n_active, xyz_scale, xyz_offset};
     int rc;
+    if (feature == nullptr || h2c != nullptr) {
+        // lean kernel (two workgroups per CU); the feature rows of the last layer are one per-layer product on h2c
+#define RSDF_COOP_FWD_LEAN(N)                                                                                        \
+    if ((rc = coop_set_lds(coop_fwd_lean_kernel<N>, GF<N>::END))) return rc;                                         \
+    coop_fwd_lean_kernel<N><<<2 * coop_grid<N>(n_samples), 64 * N, GF<N>::END, st>>>(src, w0, b0, w1, b1, w2, b2,      \
+                                                                                      sdf7t, feature ? h2c : nullptr)
+        if (NT == 4) { RSDF_COOP_FWD_LEAN(4); }
+        else if (NT == 2) { RSDF_COOP_FWD_LEAN(2); }
+        else { RSDF_COOP_FWD_LEAN(1); }
+#undef RSDF_COOP_FWD_LEAN
+        {
+            hipError_t e_ = hipGetLastError();
+            if (e_ != hipSuccess) { rsdf_set_error(hipGetErrorString(e_)); return (int)e_; }
+        }
+        if (feature != nullptr)
+            return rsdf_linear_fwd(h2c, 32 * NT, w2, b2, n_samples, 32 * NT, N2, RSDF_ACT_NONE, feature, N2, (void *)st);
+        return 0;
+    }
 #define RSDF_COOP_FWD(N)                                                                                             \
     if ((rc = coop_set_lds(coop_fwd_kernel<N>, G<N>::END))) return rc;                                               \
     coop_fwd_kernel<N><<<coop_grid<N>(n_samples), 64 * N, G<N>::END, st>>>(src, w0, b0, w1, b1, w2, b2, N2, sdf7t,    \
