@@ -287,7 +287,7 @@ def main():
         # bare `python bench.py --gpus N`: launch the N ranks ourselves.  Nothing in this process has touched the
         # GPU yet (torch.cuda.device_count() does not initialise it), and the children are plain subprocesses.
         n_dev = torch.cuda.device_count()
-        if n_dev < args.gpus:
+        if n_dev < args.gpus and os.environ.get("RSDF_DIST_SHARE_GPU") != "1":
             sys.exit(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) are visible")
         sys.exit(rdist.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
     rank, local, world = rdist.init_from_env()
@@ -371,6 +371,7 @@ def main():
                                    f"hash grid + 2x{args.hidden} SDF MLP (7 FD taps), NeuS alpha + composite, fwd+bwd",
                        "hidden": args.hidden, "fused_stencil_kernels": bool(model._fused_ok()),
                        "rccl_ranks": torch.distributed.get_world_size() if world > 1 else 1,
+                       "dist_backend": torch.distributed.get_backend() if world > 1 else None,
                        "rays_per_gpu": n_rays, "chunk_rays": args.chunk,
                        "samples_per_step": samples / args.steps,
                        "field_evals_per_sec": 7 * samples / dt, "parallelism": f"ray-parallel x{world}"},

@@ -26,11 +26,16 @@ def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # RSDF_DIST_SHARE_GPU=1 (test knob): every rank uses device 0 and the collectives go over gloo (RCCL refuses two
+    # ranks on one device).  It lets the N > 1 code path -- barriers, max/sum reductions of the timing, the gradient
+    # buckets on device tensors -- run on a one-GPU box; it is not a performance configuration.
+    if os.environ.get("RSDF_DIST_SHARE_GPU") == "1":
+        local, backend = 0, "gloo"
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("RSDF_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

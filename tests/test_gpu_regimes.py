@@ -164,3 +164,28 @@ def test_hash_backward_queue_overflow_path(dev, qscale, tmp_path):
     err, scale, nz_g, nz_o = float(line[1]), float(line[2]), int(line[3]), int(line[4])
     assert err < 2e-5 * scale + 1e-7, (err, scale)
     assert nz_g == nz_o
+
+
+def test_bench_two_ranks_on_one_gpu(dev):
+    """bench.py's N > 1 path on real hardware.  No multi-GPU node has been available, so two ranks share this GPU
+    (RSDF_DIST_SHARE_GPU=1: gloo collectives, RCCL refuses two ranks per device): the self-launcher, the barriers, the
+    max/sum reductions of time and samples and the gradient all-reduce on device tensors all execute; the line must
+    aggregate both ranks.  Not a performance number."""
+    import json
+    env = dict(os.environ, RSDF_DIST_SHARE_GPU="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    common = ["--steps", "1", "--warmup", "1", "--width", "96", "--height", "96", "--chunk", "4608", "--cpu-rays", "0"]
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common, env=env,
+                        capture_output=True, text=True, timeout=900)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    two = json.loads(r2.stdout.strip().splitlines()[-1])
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, env=env,
+                        capture_output=True, text=True, timeout=900)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    one = json.loads(r1.stdout.strip().splitlines()[-1])
+    assert two["n_gpus"] == 2 and two["config"]["rccl_ranks"] == 2 and two["config"]["dist_backend"] == "gloo"
+    assert two["scaling"] == "weak" and one["n_gpus"] == 1
+    # each rank renders its own view of the same box: the job's samples are about twice one rank's
+    ratio = two["config"]["samples_per_step"] / one["config"]["samples_per_step"]
+    assert 1.6 < ratio < 2.4, ratio
