@@ -58,3 +58,30 @@ def report(cs):
 if __name__ == "__main__":
     for cs in [int(x) for x in sys.argv[1:]] or [512, 528, 544, 576, 640]:
         print(cs, report(cs), "(conflict-free: b128 4, tr 2, w64 4)")
+
+
+def report16(cs):
+    """Access patterns of the 16x16x32 form (mlp_quad.hip): wave owns 16 features; lanes = (k-group g = l >> 4, col l & 15)."""
+    worst = {}
+    for kb in range(2):
+        for rh in range(2):                               # B row read: lane (row 16 rh + (l & 15), features 32 kb + 8 g ..)
+            a = [chunked(16 * rh + (l & 15), 32 * kb + 8 * (l >> 4), cs) for l in range(64)]
+            worst["row b128"] = max(worst.get("row b128", 0), cycles(a, "b128")[0])
+    for ft in range(4):
+        for half in range(2):                             # tr read: rows 8 g + 4 half + q, features 16 ft + 4 p ..
+            a = []
+            for l in range(64):
+                g, q, p = l >> 4, (l & 15) >> 2, l & 3
+                a.append(chunked(8 * g + 4 * half + q, 16 * ft + 4 * p, cs))
+            worst["tr"] = max(worst.get("tr", 0), cycles(a, "tr")[0])
+    for w in range(4):
+        for rh in range(2):                               # activation write: lane (row 16 rh + (l & 15), features 16 w + 4 g ..)
+            a = [chunked(16 * rh + (l & 15), 16 * w + 4 * (l >> 4), cs) for l in range(64)]
+            worst["w64"] = max(worst.get("w64", 0), cycles(a, "w64")[0])
+    return worst
+
+
+if __name__ == "__main__":
+    print("16x16x32 form:")
+    for cs in [512, 528, 544, 560, 576, 592, 608, 640, 656, 672, 704]:
+        print(cs, report16(cs))
