@@ -18,6 +18,7 @@ ENTRY = {  # kernel name fragment -> C-ABI entry point
     "fd7_produce_kernel": "rsdf_hashgrid_bwd_fd7",
     "fd7_reduce_kernel": "rsdf_hashgrid_bwd_fd7",
     "coop_bwd_kernel": "rsdf_sdfmlp_fd7_bwd",
+    "quad_bwd_kernel": "rsdf_sdfmlp_fd7_bwd",
     "sdfmlp_bwd_kernel": "rsdf_sdfmlp_fd7_bwd",
     "coop_fwd_kernel": "rsdf_sdfmlp_fd7_fwd",
     "sdfmlp_fwd_kernel": "rsdf_sdfmlp_fd7_fwd",
