@@ -189,3 +189,15 @@ def test_bench_two_ranks_on_one_gpu(dev):
     # each rank renders its own view of the same box: the job's samples are about twice one rank's
     ratio = two["config"]["samples_per_step"] / one["config"]["samples_per_step"]
     assert 1.6 < ratio < 2.4, ratio
+
+
+@pytest.mark.parametrize("which", ["coop", "legacy"])
+def test_alternative_mlp_backward_kernels_stay_correct(dev, which):
+    """H = 64 ships the quad backward (mlp_quad.hip); the cooperative (mlp_coop.hip, also the H = 32 / 128 kernel) and the
+    round-1 per-wave kernels remain selectable with RSDF_MLP_BWD for A/B timing.  They must keep passing the same
+    parity tests (the variable is read at launch, so the run is a subprocess)."""
+    env = dict(os.environ, RSDF_MLP_BWD=which)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_model.py"), "-q", "-m", "gpu",
+                        "-k", "fused_field_with_feature_gradients or neus_render_matches_oracle", "-x"],
+                       env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:]
