@@ -65,8 +65,9 @@ struct Q {
     static constexpr int LPW = 16 / NW;
     static constexpr int XI = 0;                                  // two X images (tile parity)
     static constexpr int H1I = XI + 2 * 3 * QX_PART;
-    static constexpr int DZI = H1I + 3 * H_PART;
-    static constexpr int RAW = DZI + 3 * H_PART;                  // fp32 [2][18][64] LDS-DMA landing zone
+    static constexpr int DZI = H1I + 3 * H_PART;                  // dz2
+    static constexpr int DZ1 = DZI + 3 * H_PART;                  // dz1 in an image of its own: no barrier between the last
+    static constexpr int RAW = DZ1 + 3 * H_PART;                  //   read of dz2 and the write of dz1.  fp32 [2][18][64] landing zone
     static constexpr int END = RAW + 2 * 18 * 256;
 };
 
@@ -80,10 +81,30 @@ struct SrcQ {
 
 __device__ __forceinline__ u32x4 ldq128(const unsigned char *p) { return *reinterpret_cast<const u32x4 *>(p); }
 
-// B fragment of a layer product: lane (k-group g, sample row 16 rh + c16) reads features 32 kb + 8 g .. +7
-__device__ __forceinline__ Frag3 rowq(const unsigned char *img, int part, int kb, int rh, int g, int c16)
+// Per-lane address constants.  With the swizzle keyed on the chunk parity, every fragment address is
+//   (lane constant) + (compile-time constant): the loop body carries no address arithmetic, only ds_* immediates.
+struct LaneQ {
+    int row;     // B fragment of a layer product (rowq): chunk 4 kb + g, row 16 rh + c16
+    int tr0;     // transposed fragment (trfq): rows 8 g + q, columns 16 ft + 4 p ..
+    int tr1;     //   rows + 4
+    int st;      // store_q: row 16 rh + c16, columns 16 w + 4 g ..
+};
+__device__ __forceinline__ LaneQ lane_consts(int w, int lane)
 {
-    const unsigned char *p = img + qoff(16 * rh + c16, 32 * kb + 8 * g);
+    const int g = lane >> 4, c16 = lane & 15, q = c16 >> 2, p = lane & 3;
+    LaneQ c;
+    c.row = g * QCS + ((c16 ^ (12 * (g & 1))) << 4);
+    c.tr0 = (p >> 1) * QCS + (((8 * g + q) ^ (12 * (p >> 1))) << 4) + (p & 1) * 8;
+    c.tr1 = (p >> 1) * QCS + (((8 * g + 4 + q) ^ (12 * (p >> 1))) << 4) + (p & 1) * 8;
+    c.st = (2 * w + (g >> 1)) * QCS + ((c16 ^ (12 * (g >> 1))) << 4) + (g & 1) * 8;
+    return c;
+}
+
+// B fragment of a layer product: lane (k-group g, sample row 16 rh + c16) reads features 32 kb + 8 g .. +7
+//   = qoff(16 rh + c16, 32 kb + 8 g): the row offset 16 rh does not touch the swizzled bits
+__device__ __forceinline__ Frag3 rowq(const unsigned char *img, int part, int kb, int rh, const LaneQ &c)
+{
+    const unsigned char *p = img + c.row + kb * (4 * QCS) + rh * 256;
     Frag3 f;
     f.h = ldq128(p);
     f.m = ldq128(p + part);
@@ -100,11 +121,10 @@ __device__ __forceinline__ void trq(const unsigned char *p, unsigned &a, unsigne
 }
 // Fragment whose k dimension is the tile's 32 ROWS: lane (k-group g: rows 8 g .. 8 g + 7, column 16 ft + c16).  Serves as the
 // A operand (A[i = column][k = row]) and as the B operand (B[k = row][j = column]) of the weight-gradient products.
-__device__ __forceinline__ Frag3 trfq(const unsigned char *img, int part, int ft, int lane)
+__device__ __forceinline__ Frag3 trfq(const unsigned char *img, int part, int ft, const LaneQ &c)
 {
-    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
-    const unsigned char *a0 = img + qoff(8 * g + q, 16 * ft + 4 * p);
-    const unsigned char *a1 = img + qoff(8 * g + 4 + q, 16 * ft + 4 * p);
+    const unsigned char *a0 = img + c.tr0 + ft * (2 * QCS);      // = qoff(8 g + q, 16 ft + 4 p)
+    const unsigned char *a1 = img + c.tr1 + ft * (2 * QCS);      // = qoff(8 g + 4 + q, 16 ft + 4 p)
     Frag3 f;
     unsigned x0, x1, y0, y1;
     trq(a0, x0, x1);
@@ -120,12 +140,12 @@ __device__ __forceinline__ Frag3 trfq(const unsigned char *img, int part, int ft
 }
 
 // this wave's 16 x 16 result (features 16 w + 4 g + r, sample row 16 rh + c16) -> split once -> image
-__device__ __forceinline__ void store_q(unsigned char *img, int part, int w, int rh, int g, int c16, const f32x4 &v)
+__device__ __forceinline__ void store_q(unsigned char *img, int part, int rh, const LaneQ &c, const f32x4 &v)
 {
     unsigned h0, m0, l0, h1, m1, l1;
     split3_pair(v[0], v[1], h0, m0, l0);
     split3_pair(v[2], v[3], h1, m1, l1);
-    unsigned char *p = img + qoff(16 * rh + c16, 16 * w + 4 * g);
+    unsigned char *p = img + c.st + rh * 256;                    // = qoff(16 rh + c16, 16 w + 4 g)
     *reinterpret_cast<uint2 *>(p) = uint2{h0, h1};
     *reinterpret_cast<uint2 *>(p + part) = uint2{m0, m1};
     *reinterpret_cast<uint2 *>(p + 2 * part) = uint2{l0, l1};
@@ -225,6 +245,7 @@ quad_bwd_kernel(const SrcQ src, const float *__restrict__ w0, const float *__res
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
     const int K0 = 3 + 2 * src.n_levels;
     const int fw = 16 * w + c16;                   // the feature this lane addresses in an A fragment of its wave
+    const LaneQ lc = lane_consts(w, lane);
 
     for (int e = threadIdx.x; e < L::END / 4; e += L::THREADS) reinterpret_cast<unsigned *>(smem)[e] = 0u;
     __syncthreads();
@@ -316,11 +337,11 @@ quad_bwd_kernel(const SrcQ src, const float *__restrict__ w0, const float *__res
 #pragma unroll
             for (int rh = 0; rh < 2; ++rh) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                acc = mma6q(w0f[0], rowq(xi, QX_PART, 0, rh, g, c16), acc);
-                acc = mma6q(w0f[1], rowq(xi, QX_PART, 1, rh, g, c16), acc);
+                acc = mma6q(w0f[0], rowq(xi, QX_PART, 0, rh, lc), acc);
+                acc = mma6q(w0f[1], rowq(xi, QX_PART, 1, rh, lc), acc);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) h1[rh][r] = softplus100q(acc[r]);
-                store_q(smem + L::H1I, L::H_PART, w, rh, g, c16, h1[rh]);
+                store_q(smem + L::H1I, L::H_PART, rh, lc, h1[rh]);
             }
             lds_barrier_q();                                                     // (2) H1 image complete
             // ---- recompute layer 2, then layer 3 backward: dz2 = (W2[0,:] d_sdf + feature part) sigma'(z2)
@@ -328,7 +349,7 @@ quad_bwd_kernel(const SrcQ src, const float *__restrict__ w0, const float *__res
             for (int rh = 0; rh < 2; ++rh) {
                 f32x4 acc = b1r;
 #pragma unroll
-                for (int kb = 0; kb < KB; ++kb) acc = mma6q(w1f[kb], rowq(smem + L::H1I, L::H_PART, kb, rh, g, c16), acc);
+                for (int kb = 0; kb < KB; ++kb) acc = mma6q(w1f[kb], rowq(smem + L::H1I, L::H_PART, kb, rh, lc), acc);
                 const float dsdf = row_ok[rh] ? dsdf_raw[rh] : 0.0f;
                 if (w == 0 && g == 0) gb2 += dsdf;
 #pragma unroll
@@ -338,7 +359,7 @@ quad_bwd_kernel(const SrcQ src, const float *__restrict__ w0, const float *__res
                     dz[rh][r] = row_ok[rh] ? fmaf(w2r[r], dsdf, dz[rh][r]) * softplus100q_grad(h2[rh][r]) : 0.0f;
                     gb1p[r] += dz[rh][r];
                 }
-                store_q(smem + L::DZI, L::H_PART, w, rh, g, c16, dz[rh]);
+                store_q(smem + L::DZI, L::H_PART, rh, lc, dz[rh]);
             }
             lds_barrier_q();                                                     // (3) dz2 image complete
             // ---- layer 2 backward: dz1[own k1] = (W1^T dz2) sigma'(z1) ; dW1[own n][all k] += dz2^T h1 (K = the 32 rows)
@@ -346,24 +367,23 @@ quad_bwd_kernel(const SrcQ src, const float *__restrict__ w0, const float *__res
             for (int rh = 0; rh < 2; ++rh) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int kb = 0; kb < KB; ++kb) acc = mma6q(w1t[kb], rowq(smem + L::DZI, L::H_PART, kb, rh, g, c16), acc);
+                for (int kb = 0; kb < KB; ++kb) acc = mma6q(w1t[kb], rowq(smem + L::DZI, L::H_PART, kb, rh, lc), acc);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dz[rh][r] = acc[r] * softplus100q_grad(h1[rh][r]);
             }
             {
-                const Frag3 a = trfq(smem + L::DZI, L::H_PART, w, lane);
+                const Frag3 a = trfq(smem + L::DZI, L::H_PART, w, lc);
 #pragma unroll
-                for (int n = 0; n < H / 16; ++n) gw1[n] = mma6q(a, trfq(smem + L::H1I, L::H_PART, n, lane), gw1[n]);
+                for (int n = 0; n < H / 16; ++n) gw1[n] = mma6q(a, trfq(smem + L::H1I, L::H_PART, n, lc), gw1[n]);
             }
-            lds_barrier_q();                                                     // (4) every wave has read dz2 / h1
-            store_q(smem + L::DZI, L::H_PART, w, 0, g, c16, dz[0]);
-            store_q(smem + L::DZI, L::H_PART, w, 1, g, c16, dz[1]);
-            lds_barrier_q();                                                     // (5) dz1 image complete
+            store_q(smem + L::DZ1, L::H_PART, 0, lc, dz[0]);
+            store_q(smem + L::DZ1, L::H_PART, 1, lc, dz[1]);
+            lds_barrier_q();                                                     // (4) dz1 image complete
             // ---- layer 1 backward: d(hash features) sub-tile (16 columns x 16 rows, all 64 features); dW0 += dz1^T X
             {
                 f32x4 dx = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int kb = 0; kb < KB; ++kb) dx = mma6q(w0t[kb], rowq(smem + L::DZI, L::H_PART, kb, rhx, g, c16), dx);
+                for (int kb = 0; kb < KB; ++kb) dx = mma6q(w0t[kb], rowq(smem + L::DZ1, L::H_PART, kb, rhx, lc), dx);
                 // result rows = hash columns 16 mt + 4 g + r = (level 8 mt + 2 g + (r >> 1), feature r & 1); lane column =
                 // sample row 16 rhx + c16: two float2 stores, 16 lanes cover 128 contiguous bytes of a level plane
                 const int64_t row = s0 + 16 * rhx + c16;
@@ -376,11 +396,11 @@ quad_bwd_kernel(const SrcQ src, const float *__restrict__ w0, const float *__res
                 }
             }
             {
-                const Frag3 a = trfq(smem + L::DZI, L::H_PART, w, lane);
+                const Frag3 a = trfq(smem + L::DZ1, L::H_PART, w, lc);
 #pragma unroll
-                for (int ct = 0; ct < 3; ++ct) gw0[ct] = mma6q(a, trfq(xi, QX_PART, ct, lane), gw0[ct]);
+                for (int ct = 0; ct < 3; ++ct) gw0[ct] = mma6q(a, trfq(xi, QX_PART, ct, lc), gw0[ct]);
             }
-            // no barrier: the next tile stages the other X image; its H1 / dz writes sit behind its barriers (1) .. (4)
+            // no barrier: the next tile stages the other X image; its H1 / dz2 / dz1 writes sit behind its barriers (1) .. (3)
         }
     }
 
