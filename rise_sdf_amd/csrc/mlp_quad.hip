@@ -204,7 +204,12 @@ __device__ __forceinline__ void stage_q(unsigned char *xi, const unsigned char *
     for (int i = 0; i < LPW; i += 2) {
         const float p0 = (ok && w * LPW + i < src.n_active) ? pre[i] : 0.0f;
         const float p1 = (ok && w * LPW + i + 1 < src.n_active) ? pre[i + 1] : 0.0f;
+#ifdef RSDF_NO_DPP
         const float got = __shfl_xor(f ? p0 : p1, 1, 64);
+#else
+        // lane ^ 1 through DPP quad_perm [1,0,3,2]: a vector-ALU move, no LDS round trip (ds_bpermute)
+        const float got = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f ? p0 : p1), 0xB1, 0xF, 0xF, true));
+#endif
         const float v0 = f ? got : p0, v1 = f ? p1 : got;                   // features 0, 1 of level w LPW + i + f
         unsigned h, m, l;
         split3_pair(v0, v1, h, m, l);

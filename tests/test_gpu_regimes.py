@@ -201,3 +201,57 @@ def test_alternative_mlp_backward_kernels_stay_correct(dev, which):
                         "-k", "fused_field_with_feature_gradients or neus_render_matches_oracle", "-x"],
                        env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:]
+
+
+@pytest.mark.parametrize("hidden", [32, 64, 128])
+@pytest.mark.parametrize("n_samples,active,frozen", [(5, 6, False), (33, 3, False), (1000, 6, True)])
+def test_fused_kernels_edge_shapes(dev, hidden, n_samples, active, frozen):
+    """Tile remainders (5 and 33 samples: fewer rows than a tile / one row over), masked levels (3 of 6 active) and a
+    frozen table (no d_planes requested): the fused stencil kernels against the per-layer path on the same weights
+    (itself checked against the oracle in test_gpu_model.py)."""
+    import rise_sdf_amd as R
+    from test_gpu_model import model_config
+    torch.manual_seed(7)
+    cfg = model_config(hidden=hidden, n_levels=6, feat=13)
+    geo = R.make("volume-sdf", cfg.geometry).to(dev)
+    geo.train()
+    with torch.no_grad():
+        geo.encoding.encoding.encoding.params.mul_(300.0)
+        l0 = geo.network.layers[0]
+        l0.weight_v[:, 3:] = torch.randn_like(l0.weight_v[:, 3:]) * 0.3
+    geo.update_step(0, 0)
+    if active < 6:
+        geo.encoding.encoding.current_level = active            # ProgressiveBandHashGrid: levels >= active read as zero
+        geo.encoding.encoding.mask = torch.cat([torch.ones(2 * active), torch.zeros(2 * (6 - active))])
+    enc = geo.encoding.encoding.encoding
+    enc.params.requires_grad_(not frozen)
+    g = torch.Generator().manual_seed(n_samples)
+    ro = (torch.rand(1, 3, generator=g) - 0.5).to(dev)
+    rd = torch.nn.functional.normalize(torch.randn(1, 3, generator=g), dim=-1).to(dev)
+    ts = (torch.sort(torch.rand(n_samples, generator=g))[0] * 1.2).to(dev)
+    te = ts + 0.004
+    ri = torch.zeros(n_samples, dtype=torch.int64, device=dev)
+    gs = torch.randn(7, n_samples, generator=g).to(dev)
+    gf = torch.randn(n_samples, 13, generator=g).to(dev)
+
+    def grads():
+        out = {n: (p.grad.clone() if p.grad is not None else None) for n, p in geo.named_parameters()}
+        for p in geo.parameters():
+            p.grad = None
+        return out
+
+    sdf7t, feat = geo.sdf7_from_rays(ro, rd, ri, ts, te, want_feature=True)
+    ((sdf7t * gs).sum() + (feat * gf).sum()).backward()
+    g_fused = grads()
+    out7 = geo.field7_from_rays(ro, rd, ri, ts, te)                      # [7S, 13], rows 7 i + t
+    ref7 = out7.view(n_samples, 7, 13)
+    ((ref7[:, :, 0].t() * gs).sum() + (ref7[:, 0, :] * gf).sum()).backward()
+    g_ref = grads()
+    assert torch.allclose(sdf7t, ref7[:, :, 0].t(), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(feat, ref7[:, 0, :], rtol=1e-5, atol=1e-6)
+    for name in g_ref:
+        if g_ref[name] is None:
+            assert g_fused[name] is None, name
+            continue
+        scale = float(g_ref[name].abs().max()) + 1e-12
+        assert float((g_fused[name] - g_ref[name]).abs().max()) < 2e-4 * scale + 1e-7, (name, hidden)
