@@ -738,7 +738,6 @@ coop_bwd_kernel(const Src src, const float *__restrict__ w0, const float *__rest
             Frag3 a1[2];
             a1[0] = tr_frag(smem + L::DZI, L::H_PART, w, 0, lane);
             a1[1] = tr_frag(smem + L::DZI, L::H_PART, w, 1, lane);
-#ifndef RSDF_DW1_LAST
 #pragma unroll
             for (int b = 0; b < NT; ++b) {
                 Frag3 bh[2];
@@ -748,22 +747,10 @@ coop_bwd_kernel(const Src src, const float *__restrict__ w0, const float *__rest
                 gw1[b] = mma6f(a1[0], bh[0], gw1[b]);
                 gw1[b] = mma6f(a1[1], bh[1], gw1[b]);
             }
-#endif
 #pragma unroll
             for (int r = 0; r < 16; ++r) dz[r] = acc[r] * softplus100c_grad(h1[r]);
             Frag3 f1[2];
             split_tile(dz, f1);
-#ifdef RSDF_DW1_LAST
-#pragma unroll
-            for (int b = 0; b < NT; ++b) {
-                Frag3 bh[2];
-                bh[0] = tr_frag(smem + L::H1I, L::H_PART, b, 0, lane);
-                bh[1] = tr_frag(smem + L::H1I, L::H_PART, b, 1, lane);
-                RSDF_SCHED_FENCE();
-                gw1[b] = mma6f(a1[0], bh[0], gw1[b]);
-                gw1[b] = mma6f(a1[1], bh[1], gw1[b]);
-            }
-#endif
             lds_barrier();                                                     // (4) every wave has read dz2 / h1
             store_tile(smem + L::DZI, L::H_PART, w, c, hf, f1);
             // d(hash features): this wave's feature slice, straight from the registers
