@@ -42,7 +42,14 @@ constexpr int F_THREADS = 256;   // forward: samples per workgroup
 #endif
 constexpr int P_THREADS = P_THREADS_CFG;
 constexpr int ROUND_RECS = 8;
-constexpr int STAGE_CAP = P_THREADS * ROUND_RECS;
+// LDS staging of one copy-out pass.  A round holds up to P_THREADS * ROUND_RECS records; staging HALF of that (a full
+// round then takes two passes) keeps the producer at 62 KB of LDS, i.e. two 1024-thread workgroups per CU: the kernel is
+// bound by barrier and memory latency, not by any one unit (PMC: vector issue 24 %, LDS 22 %, 2 TB/s), so the second
+// workgroup's work fills the first one's stalls.
+#ifndef RSDF_STAGE_RECS
+#define RSDF_STAGE_RECS 4
+#endif
+constexpr int STAGE_CAP = P_THREADS * RSDF_STAGE_RECS;
 #ifndef MERGE_MAX_RUNS
 #define MERGE_MAX_RUNS 40
 #endif
@@ -131,16 +138,19 @@ __device__ __forceinline__ uint32_t extra_index(const CellFrac &c0, int a, int k
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(F_THREADS)
-fd7_fwd_kernel(const float *__restrict__ x7t, const float *__restrict__ table,
-               const rsdf_grid_meta meta, int64_t S, float2 *__restrict__ planes)
+#ifndef RSDF_FWD_XCD
+#define RSDF_FWD_XCD 1
+#endif
+#ifndef RSDF_FWD_WAVES
+#define RSDF_FWD_WAVES 3
+#endif
+#ifndef RSDF_FWD_TPB
+#define RSDF_FWD_TPB 1
+#endif
+__device__ __forceinline__ void fd7_fwd_sample(const float *__restrict__ x7t, const float2 *__restrict__ tl,
+                                               const LevelGeom &g, int64_t S, int64_t s, int l,
+                                               float2 *__restrict__ planes)
 {
-    const int64_t s = (int64_t)blockIdx.x * F_THREADS + threadIdx.x;
-    if (s >= S) return;
-    const int l = blockIdx.y;
-    const LevelGeom g = level_geom(meta, l);
-    const float2 *tl = reinterpret_cast<const float2 *>(table) + meta.offset[l];
-
     CellFrac cf[7];
 #pragma unroll
     for (int t = 0; t < 7; ++t) {
@@ -212,6 +222,27 @@ fd7_fwd_kernel(const float *__restrict__ x7t, const float *__restrict__ table,
     }
 }
 
+__global__ void __launch_bounds__(F_THREADS, RSDF_FWD_WAVES)
+fd7_fwd_kernel(const float *__restrict__ x7t, const float *__restrict__ table,
+               const rsdf_grid_meta meta, int64_t S, int tiles_per_xcd, float2 *__restrict__ planes)
+{
+    // Workgroups go round-robin over the 8 XCDs by linear id, and every XCD has its own L2.  Samples are ray-major and
+    // neighbouring rays (neighbouring pixels) share their cells on the levels whose cell is wider than a pixel footprint,
+    // so each XCD takes one CONTIGUOUS eighth of the sample tiles: rays next to each other meet in the same L2.
+    // gridDim.x = 8 * ceil(tiles_per_xcd / RSDF_FWD_TPB); a workgroup walks RSDF_FWD_TPB consecutive tiles.
+    const int l = blockIdx.y;
+    const LevelGeom g = level_geom(meta, l);
+    const float2 *tl = reinterpret_cast<const float2 *>(table) + meta.offset[l];
+    const int t0 = (int)(blockIdx.x >> 3) * RSDF_FWD_TPB;
+#pragma unroll 1
+    for (int rep = 0; rep < RSDF_FWD_TPB; ++rep) {
+        if (t0 + rep >= tiles_per_xcd) break;
+        const int64_t tile = (int64_t)(blockIdx.x & 7) * tiles_per_xcd + t0 + rep;
+        const int64_t s = tile * F_THREADS + threadIdx.x;
+        if (s < S) fd7_fwd_sample(x7t, tl, g, S, s, l, planes);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // backward: produce
 // ------------------------------------------------------------------------------------------------
@@ -228,21 +259,17 @@ __device__ __forceinline__ void emit_round(const uint32_t (&ridx)[ROUND_RECS],
                                            int *s_gbase, Record *s_stage)
 {
     // s_cnt is all zero on entry (zeroed by the kernel prologue / the previous round's scan).
-    // Three barriers per non-empty round, two per empty one:
-    //   slots -> A -> scan (+ re-zero counts) -> B -> stage -> C -> copy out.
+    // Three barriers per non-empty round (four when it needs a second staging pass), two per empty one:
+    //   slots -> A -> scan (+ re-zero counts) -> B -> stage -> C -> copy out [-> D -> stage -> C -> copy out].
     // No barrier is needed after the copy-out: the next round's scan (which overwrites s_off /
     // s_gbase) runs after its barrier A, and its stage writes after its barrier B, both of which
     // every thread reaches only after finishing this copy-out.
     const int tid = threadIdx.x;
-    int slot[ROUND_RECS], bin[ROUND_RECS];
+    int slot[ROUND_RECS];   // rank within the bin
 #pragma unroll
     for (int r = 0; r < ROUND_RECS; ++r) {
         slot[r] = 0;
-        bin[r] = 0;
-        if (valid_mask & (1u << r)) {
-            bin[r] = bin_of(ridx[r], n_bins, interleaved);
-            slot[r] = atomicAdd(&s_cnt[bin[r]], 1);
-        }
+        if (valid_mask & (1u << r)) slot[r] = atomicAdd(&s_cnt[bin_of(ridx[r], n_bins, interleaved)], 1);
     }
     __syncthreads();  // A
     // First wavefront: exclusive scan of the bin counts + queue reservations.  The reservation is a RETURNING global
@@ -263,20 +290,27 @@ __device__ __forceinline__ void emit_round(const uint32_t (&ridx)[ROUND_RECS],
     __syncthreads();  // B
     const int total = s_off[MAX_BINS];
     if (total == 0) return;  // uniform (no reservation was made: every count was zero)
-#pragma unroll
-    for (int r = 0; r < ROUND_RECS; ++r)
-        if (valid_mask & (1u << r)) s_stage[s_off[bin[r]] + slot[r]] = Record{ridx[r], rval[r].x, rval[r].y};
     if (tid < n_bins) s_gbase[tid] = gbase;
-    __syncthreads();  // C
-    for (int i = tid; i < total; i += P_THREADS) {
-        const Record rec = s_stage[i];
-        const int b = bin_of(rec.idx, n_bins, interleaved);
-        const int64_t gpos = (int64_t)s_gbase[b] + (i - s_off[b]);
-        if (gpos < cap) {
-            queue[(int64_t)b * cap + gpos] = rec;
-        } else {  // queue full (capacity carries slack; never drop a contribution)
-            atomicAdd(dlevel + 2 * (size_t)rec.idx, rec.v0);
-            atomicAdd(dlevel + 2 * (size_t)rec.idx + 1, rec.v1);
+    for (int lo = 0; lo < total; lo += STAGE_CAP) {   // uniform; bins stay contiguous: a pass boundary splits one run
+        const int n = min(total - lo, STAGE_CAP);
+        if (lo) __syncthreads();  // D: the previous pass has left the staging buffer
+#pragma unroll
+        for (int r = 0; r < ROUND_RECS; ++r)
+            if (valid_mask & (1u << r)) {
+                const unsigned pos = (unsigned)(s_off[bin_of(ridx[r], n_bins, interleaved)] + slot[r] - lo);
+                if (pos < (unsigned)n) s_stage[pos] = Record{ridx[r], rval[r].x, rval[r].y};
+            }
+        __syncthreads();  // C
+        for (int i = tid; i < n; i += P_THREADS) {
+            const Record rec = s_stage[i];
+            const int b = bin_of(rec.idx, n_bins, interleaved);
+            const int64_t gpos = (int64_t)s_gbase[b] + (lo + i - s_off[b]);
+            if (gpos < cap) {
+                queue[(int64_t)b * cap + gpos] = rec;
+            } else {  // queue full (capacity carries slack; never drop a contribution)
+                atomicAdd(dlevel + 2 * (size_t)rec.idx, rec.v0);
+                atomicAdd(dlevel + 2 * (size_t)rec.idx + 1, rec.v1);
+            }
         }
     }
 }
@@ -284,7 +318,7 @@ __device__ __forceinline__ void emit_round(const uint32_t (&ridx)[ROUND_RECS],
 // Work item of the second phase: a displaced tap.  bits 0..9 sample within the workgroup, 10..12 tap - 1, 13 side (1: +1 cell)
 constexpr int MAX_ITEMS = P_THREADS * 6;
 
-__global__ void __launch_bounds__(P_THREADS)
+__global__ void __launch_bounds__(P_THREADS, RSDF_STAGE_RECS <= 4 ? 8 : 4)
 fd7_produce_kernel(const float *__restrict__ x7t, const float2 *__restrict__ dplanes,
                    const rsdf_grid_meta meta, const LevelPlan plan, int64_t S,
                    Record *__restrict__ queues, int *__restrict__ counters,
@@ -600,8 +634,9 @@ int rsdf_hashgrid_fwd_fd7(const float *x7t, const float *table, const rsdf_grid_
         RSDF_CHECK_ARG(dense <= meta->size[l] || (meta->size[l] & (meta->size[l] - 1u)) == 0,
                        "hashgrid_fwd_fd7: hashed level sizes must be powers of two");
     }
-    dim3 grid(rsdf_blocks(n_samples, F_THREADS), na);
-    fd7_fwd_kernel<<<grid, F_THREADS, 0, (hipStream_t)stream>>>(x7t, table, *meta, n_samples,
+    const unsigned tiles_per_xcd = (rsdf_blocks(n_samples, F_THREADS) + 7) / 8;
+    dim3 grid(8 * ((tiles_per_xcd + RSDF_FWD_TPB - 1) / RSDF_FWD_TPB), na);
+    fd7_fwd_kernel<<<grid, F_THREADS, 0, (hipStream_t)stream>>>(x7t, table, *meta, n_samples, (int)tiles_per_xcd,
                                                                  reinterpret_cast<float2 *>(planes));
     RSDF_RETURN_LAUNCH();
 }

@@ -25,7 +25,10 @@ namespace {
 
 constexpr int BWD_WAVES = 4;      // backward: one wave per SIMD (register-resident weight fragments + accumulators)
 constexpr int BWD_THREADS = BWD_WAVES * 64;
-constexpr int FWD_WAVES = 8;      // forward: 8 waves = two per SIMD
+#ifndef RSDF_FWD_WAVES_CFG
+#define RSDF_FWD_WAVES_CFG 12
+#endif
+constexpr int FWD_WAVES = RSDF_FWD_WAVES_CFG;   // forward: waves per workgroup (one workgroup per CU): 8 = two per SIMD, 12 = three
 constexpr int FWD_THREADS = FWD_WAVES * 64;
 constexpr int LDT = 33;       // [feature][row] transposed tiles
 
@@ -93,6 +96,7 @@ __device__ __forceinline__ float softplus100_grad_fast(float h)
 }
 
 constexpr int LDXF = 36;   // fp32 X tile row stride: 16-byte aligned rows, conflict-free ds_read_b128 over 8 rows
+constexpr int LDFS = 33;   // transposed [row][32 features] staging of the forward's row stores
 constexpr int KS0 = 3;     // layer-1 k-steps of 16 (K0 <= 35, column 35 = 1 carries the bias, 36..47 hit zero weights)
 
 // LDS image of the split weights (units: u32x4 = 16 bytes)
@@ -112,7 +116,9 @@ struct SmemS {
     static constexpr int W2R0 = B2 + 64;  // [H]   row 0 of W2 (SDF) for the vector-ALU dot of the taps
     static constexpr int TAIL_F = W2R0 + H;
     static constexpr size_t SHARED_BYTES = (size_t)END_U4 * 16 + (size_t)TAIL_F * 4;
-    static constexpr int PER_WAVE_F = 32 * 65;   // X tile [32][LDXF] fp32, overlaid by the feature transpose [32][65]
+    // X tile [32][LDXF] fp32 (+ the 12 pad columns the last row's third k-step reads), overlaid by one 32-column half of
+    // the feature transpose [32][LDFS]
+    static constexpr int PER_WAVE_F = 32 * LDXF + 16;
 };
 
 // k of element j of lane half hf in k-step s of a 32-feature activation tile
@@ -171,7 +177,7 @@ __device__ __forceinline__ void store_tile_f(float *Xs, const float (&pre)[18], 
 // hidden layers 1 and 2 of one 32-row tile; h[t][r]: feature 32 t + (r & 3) + 8 (r >> 2) + 4 hf of row c
 template <int H>
 __device__ __forceinline__ void hidden_forward_s(const unsigned char *smem, const float *Xs, int c, int hf,
-                                                 const float (&b1r)[H / 32][16], f32x16 (&h1)[H / 32],
+                                                 const float *b1s, f32x16 (&h1)[H / 32],
                                                  f32x16 (&h2)[H / 32])
 {
     using S = SmemS<H>;
@@ -197,7 +203,10 @@ __device__ __forceinline__ void hidden_forward_s(const unsigned char *smem, cons
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) h2[t][r] = b1r[t][r];
+        for (int q = 0; q < 4; ++q) {   // bias of features 32 t + 8 q + 4 hf .. + 3: one 16-byte LDS read
+            const float4 b = *reinterpret_cast<const float4 *>(b1s + 32 * t + 8 * q + 4 * hf);
+            h2[t][4 * q] = b.x, h2[t][4 * q + 1] = b.y, h2[t][4 * q + 2] = b.z, h2[t][4 * q + 3] = b.w;
+        }
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
@@ -218,7 +227,7 @@ __device__ __forceinline__ void hidden_forward_s(const unsigned char *smem, cons
 // forward: tap-major inputs -> sdf7t [7][S], feature [S, N2] (nullable; centre rows only), h2c (nullable)
 // ------------------------------------------------------------------------------------------------
 template <int H>
-__global__ void __launch_bounds__(FWD_THREADS)
+__global__ void __launch_bounds__(FWD_THREADS, FWD_WAVES / 4)
 sdfmlp_fwd_kernel(const TileSrc src, const float *__restrict__ w0,
                   const float *__restrict__ b0, const float *__restrict__ w1,
                   const float *__restrict__ b1, const float *__restrict__ w2,
@@ -233,21 +242,14 @@ sdfmlp_fwd_kernel(const TileSrc src, const float *__restrict__ w0,
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 31, hf = lane >> 5;
     float *tail = reinterpret_cast<float *>(smem_b + (size_t)S::END_U4 * 16);
     float *Xs = reinterpret_cast<float *>(smem_b + S::SHARED_BYTES) + wave * S::PER_WAVE_F;
-    float *Fs = Xs;  // [32][65] over the X tile, which is dead once the first layer has read it
+    float *Fs = Xs;  // [32][LDFS] over the X tile, which is dead once the first layer has read it
     stage_split_weights<H>(smem_b, w0, b0, w1, b1, w2, b2, K0, N2);
     for (int e = lane; e < S::PER_WAVE_F; e += 64) Xs[e] = 0.0f;   // pad columns must be finite
     __syncthreads();
     const u32x4 *wl = reinterpret_cast<const u32x4 *>(smem_b);
 
-    float b1r[NT][16], w2r[NT][16];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int f = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hf;
-            b1r[t][r] = tail[S::B1 + f];
-            w2r[t][r] = tail[S::W2R0 + f];
-        }
+    // b1 and the SDF row of W2 stay in LDS (16-byte reads at their use): 64 registers less per wave, which is what lets
+    // three waves share a SIMD
     const float b2_0 = tail[S::B2];
 
     const int64_t n_groups = (n_samples + 31) / 32;  // 32 samples per wave iteration
@@ -264,25 +266,32 @@ sdfmlp_fwd_kernel(const TileSrc src, const float *__restrict__ w0,
                 if (ng < n_groups) fetch_tile(pre, src, ng * 32, ntap, lane);
             }
             f32x16 h1[NT], h2[NT];
-            hidden_forward_s<H>(smem_b, Xs, c, hf, b1r, h1, h2);
+            hidden_forward_s<H>(smem_b, Xs, c, hf, tail + S::B1, h1, h2);
             const int64_t s = s0 + c;
             // SDF: dot(W2[0,:], h2[:,row]) on the vector ALU, features split over the lane halves
             float acc = 0.0f;
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc = fmaf(w2r[t][r], h2[t][r], acc);
+                for (int q = 0; q < 4; ++q) {
+                    const float4 w = *reinterpret_cast<const float4 *>(tail + S::W2R0 + 32 * t + 8 * q + 4 * hf);
+                    acc = fmaf(w.x, h2[t][4 * q], acc);
+                    acc = fmaf(w.y, h2[t][4 * q + 1], acc);
+                    acc = fmaf(w.z, h2[t][4 * q + 2], acc);
+                    acc = fmaf(w.w, h2[t][4 * q + 3], acc);
+                }
             acc += __shfl_xor(acc, 32, 64);
             if (hf == 0 && s < n_samples) sdf7[(int64_t)tap * n_samples + s] = acc + b2_0;
             if (tap == 0 && feature != nullptr) {
                 if (h2c != nullptr) {  // second hidden layer of the centre rows, for the dW2 of features
 #pragma unroll
-                    for (int t = 0; t < NT; ++t)
+                    for (int t = 0; t < NT; ++t) {   // 32 features at a time through the wave's LDS tile
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) Fs[c * 65 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf] = h2[t][r];
-                    for (int e = lane; e < 32 * H; e += 64) {
-                        const int r = e / H, cc = e - r * H;
-                        if (s0 + r < n_samples) h2c[(s0 + r) * H + cc] = Fs[r * 65 + cc];
+                        for (int r = 0; r < 16; ++r) Fs[c * LDFS + (r & 3) + 8 * (r >> 2) + 4 * hf] = h2[t][r];
+                        for (int e = lane; e < 32 * 32; e += 64) {
+                            const int r = e >> 5, cc = e & 31;
+                            if (s0 + r < n_samples) h2c[(s0 + r) * H + 32 * t + cc] = Fs[r * LDFS + cc];
+                        }
                     }
                 }
                 // full last layer on the matrix cores: out[n2][row]
@@ -304,14 +313,17 @@ sdfmlp_fwd_kernel(const TileSrc src, const float *__restrict__ w0,
                                 o[t] = mma6<S::W2_PART>(wl + S::W2 + (((t * NT + kt) * 2 + ss) * 2 + hf) * 32 + c, hb,
                                                         o[t]);
                     }
-                // transpose through LDS for coalesced row stores
+                // transpose through LDS for coalesced row stores, 32 columns at a time
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < 2; ++t) {
+                    const int nc = N2 - 32 * t < 32 ? N2 - 32 * t : 32;   // columns of this half (wave-uniform)
+                    if (nc <= 0) break;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) Fs[c * 65 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf] = o[t][r];
-                for (int e = lane; e < 32 * N2; e += 64) {
-                    const int r = e / N2, cc = e - r * N2;
-                    if (s0 + r < n_samples) feature[(s0 + r) * N2 + cc] = Fs[r * 65 + cc];
+                    for (int r = 0; r < 16; ++r) Fs[c * LDFS + (r & 3) + 8 * (r >> 2) + 4 * hf] = o[t][r];
+                    for (int e = lane; e < 32 * nc; e += 64) {
+                        const int r = e / nc, cc = e - r * nc;
+                        if (s0 + r < n_samples) feature[(s0 + r) * N2 + 32 * t + cc] = Fs[r * LDFS + cc];
+                    }
                 }
                 // the X tile region now holds feature rows: restore finite pad columns for the next tile
                 // (columns 36.. of a row alias the next row's data, which stays finite; nothing to do)
@@ -481,14 +493,9 @@ sdfmlp_bwd_kernel(const TileSrc src, const float *__restrict__ w0,
             const float dsdf_raw = d_sdf7[(int64_t)tap * n_samples + (s < n_samples ? s : n_samples - 1)];
             {
                 f32x16 h2[NT];
-                float b1r[NT][16];
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) b1r[t][r] = tail[S::B1 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hf];
                 {   // the forward's hidden layers, weights at this kernel's LDS offsets (same image order)
                     static_assert(S::W0 == F::W0 && S::W1 == F::W1, "recompute shares the forward's weight image");
-                    hidden_forward_s<H>(smem_b, Xs, c, hf, b1r, h1, h2);
+                    hidden_forward_s<H>(smem_b, Xs, c, hf, tail + S::B1, h1, h2);
                 }
                 const float dsdf = s < n_samples ? dsdf_raw : 0.0f;
                 gb2 += (hf == 0) ? dsdf : 0.0f;

@@ -10,6 +10,7 @@
 #include <cstdio>
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
 template <int SHAPE>
 __device__ __forceinline__ void mfma_burst(f32x16 &a0, f32x16 &a1, f32x4 &b0, f32x4 &b1, float x, float y, int n)
@@ -18,6 +19,18 @@ __device__ __forceinline__ void mfma_burst(f32x16 &a0, f32x16 &a1, f32x4 &b0, f3
         if (SHAPE == 0) {
             a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
             a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, x, a1, 0, 0, 0);
+        } else if (SHAPE == 2) {   // split-bf16 kernels: v_mfma_f32_32x32x16_bf16 (32 cycles each)
+            bf16x8 p, q;
+            for (int k = 0; k < 8; ++k) p[k] = (__bf16)x, q[k] = (__bf16)y;
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p, q, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q, p, a1, 0, 0, 0);
+        } else if (SHAPE == 3) {   // v_mfma_f32_16x16x32_bf16 (16 cycles each): four = the time of two 32x32x16
+            bf16x8 p, q;
+            for (int k = 0; k < 8; ++k) p[k] = (__bf16)x, q[k] = (__bf16)y;
+            b0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p, q, b0, 0, 0, 0);
+            b1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q, p, b1, 0, 0, 0);
+            b0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p, q, b0, 0, 0, 0);
+            b1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q, p, b1, 0, 0, 0);
         } else {  // two 16x16x4 = the flops of one 32x32x2
             b0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, b0, 0, 0, 0);
             b1 = __builtin_amdgcn_mfma_f32_16x16x4f32(y, x, b1, 0, 0, 0);
@@ -71,15 +84,18 @@ int main()
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     const int N = 64, iters = 2000;
-    for (int shape = 0; shape < 2; ++shape)
+    const char *names[4] = {"32x32x2 f32", "16x16x4 f32", "32x32x16 bf16", "16x16x32 bf16"};
+    for (int shape = 0; shape < 4; ++shape)
         for (int M : {256, 512, 1024}) {
-            printf("shape %s  N=%d MFMA(32x32x2-equivalents) M=%d VALU per iteration:", shape ? "16x16x4" : "32x32x2", N, M);
+            printf("shape %s  N=%d MFMA(32x32-equivalents) M=%d VALU per iteration:", names[shape], N, M);
             for (int mode = 0; mode < 6; ++mode) {
                 float ms = 0;
                 for (int rep = 0; rep < 2; ++rep) {
                     hipEventRecord(e0);
                     if (shape == 0) bench<0><<<256, 512>>>(d, mode, iters, N, M);
-                    else bench<1><<<256, 512>>>(d, mode, iters, N, M);
+                    else if (shape == 1) bench<1><<<256, 512>>>(d, mode, iters, N, M);
+                    else if (shape == 2) bench<2><<<256, 512>>>(d, mode, iters, N, M);
+                    else bench<3><<<256, 512>>>(d, mode, iters, N, M);
                     hipEventRecord(e1);
                     hipEventSynchronize(e1);
                     hipEventElapsedTime(&ms, e0, e1);
