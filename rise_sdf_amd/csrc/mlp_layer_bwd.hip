@@ -1,0 +1,319 @@
+// T3 / H3: backward of one 128-wide VanillaMLP layer in ONE pass over its rows (models/network_utils.py:109-157;
+// the texture networks of models/texture.py:237-327 are stacks of such layers).
+//
+//   dz = dy * act'(y)                       (never leaves the CU)
+//   dx[:, 0:Kout] = dz @ W[:, k0:k0+Kout]   (nullable)
+//   dW += dz^T x,   db += colsum(dz)
+//
+// The two-kernel form (mlp.hip: linear_bwd_input writes dz, linear_bwd_weight reads dz and x again) moves
+// 16 N + 4 K + 4 (K + N) bytes per row and reads its operands as scalar dwords in fragment order, every value split
+// to bf16 parts once per consuming wave.  Here a workgroup of 8 waves takes 64-row tiles:
+//   * all 512 threads stage the tile with 16-byte loads: dz and x are split ONCE into two LDS images
+//     [part h/m/l][8-column chunk][64 rows][8 columns] (chunk stride 1088 B: the layout of mlp_coop.hip with 64 rows);
+//   * dx: wave (jt = w & 3, row half = w >> 2) owns a 32-column x 32-row output tile; its W^T fragments (8 k-steps x 3
+//     parts = 96 registers) stay in registers for the whole kernel, dz fragments come from the image (ds_read_b128);
+//   * dW: wave (nt = w & 3, k pair = w >> 2) owns two 32 x 32 tiles of dW in registers for the whole row loop; both
+//     operands are transposed fragments of the images (ds_read_b64_tr_b16: rows are the MFMA k dimension);
+//   * db: the staging threads keep running column sums (a thread always stages the same 4 columns);
+//   * the next tile's rows are fetched into registers while the current tile computes; the two workgroup barriers per
+//     tile are s_waitcnt lgkmcnt(0) + s_barrier (a __syncthreads() would also wait for that prefetch).
+// Traffic: 8 N + 4 K (+ 4 Kout) bytes per row.  All products are the 6-term split-bf16 products of split_bf16.h.
+#include "common.h"
+#include "split_bf16.h"
+#include "act.h"
+
+namespace {
+
+typedef short v4i16 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4i16 lds_v4i16;
+
+constexpr int LB_WAVES = 8;
+constexpr int LB_THREADS = LB_WAVES * 64;
+constexpr int LB_ROWS = 64;
+constexpr int LB_N = 128;                      // layer width this kernel is built for
+constexpr int CS64 = LB_ROWS * 16 + 64;        // chunk stride: (CS64 / 4) % 64 == 16, as the 32-row layout (tools/lds_bank_sim.py)
+constexpr int IMG_PART = (LB_N / 8) * CS64;    // one bf16 part of a [64][128] image
+constexpr int IMG_BYTES = 3 * IMG_PART;
+constexpr int PASSES = LB_ROWS * LB_N / 4 / LB_THREADS;   // float4 per thread and operand: 4
+
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);      // s_waitcnt lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+__device__ __forceinline__ u32x4 lds_b128(const unsigned char *p) { return *reinterpret_cast<const u32x4 *>(p); }
+
+// B fragment with k = columns: lane (row, half hf) reads columns 16 ns + 8 hf .. +7
+__device__ __forceinline__ Frag3 row_frag64(const unsigned char *img, int ns, int row, int hf)
+{
+    const unsigned char *p = img + (2 * ns + hf) * CS64 + row * 16;
+    Frag3 f;
+    f.h = lds_b128(p);
+    f.m = lds_b128(p + IMG_PART);
+    f.l = lds_b128(p + 2 * IMG_PART);
+    return f;
+}
+
+__device__ __forceinline__ void tr2(const unsigned char *p, unsigned &a, unsigned &b)
+{
+    const v4i16 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16 *)p);
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, r);
+    a = (unsigned)u;
+    b = (unsigned)(u >> 32);
+}
+// Fragment with k = ROWS: lane (column 32 tile + (lane & 31), h = lane >> 5), k-step ks covers rows 16 ks + 8 h .. +7
+// (the lane map of mlp_coop.hip::tr_frag, checked on the box by tools/tr_read_check.hip).
+__device__ __forceinline__ Frag3 tr_frag64(const unsigned char *img, int tile, int ks, int lane)
+{
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const int row = 16 * ks + 8 * (g >> 1) + q;
+    const unsigned char *a = img + (4 * tile + 2 * (g & 1) + (p >> 1)) * CS64 + row * 16 + (p & 1) * 8;
+    Frag3 f;
+    unsigned x0, x1, y0, y1;
+    tr2(a, x0, x1);
+    tr2(a + 64, y0, y1);                                  // rows + 4
+    f.h = u32x4{x0, x1, y0, y1};
+    tr2(a + IMG_PART, x0, x1);
+    tr2(a + IMG_PART + 64, y0, y1);
+    f.m = u32x4{x0, x1, y0, y1};
+    tr2(a + 2 * IMG_PART, x0, x1);
+    tr2(a + 2 * IMG_PART + 64, y0, y1);
+    f.l = u32x4{x0, x1, y0, y1};
+    return f;
+}
+
+// four consecutive columns col .. col+3 (col % 4 == 0) of one row -> the three parts of an image
+__device__ __forceinline__ void put4(unsigned char *img, int row, int col, float v0, float v1, float v2, float v3)
+{
+    unsigned h0, m0, l0, h1, m1, l1;
+    split3_pair(v0, v1, h0, m0, l0);
+    split3_pair(v2, v3, h1, m1, l1);
+    unsigned char *p = img + (col >> 3) * CS64 + row * 16 + (col & 7) * 2;
+    *reinterpret_cast<uint2 *>(p) = uint2{h0, h1};
+    *reinterpret_cast<uint2 *>(p + IMG_PART) = uint2{m0, m1};
+    *reinterpret_cast<uint2 *>(p + 2 * IMG_PART) = uint2{l0, l1};
+}
+
+// RAW load of 4 consecutive floats on an always-valid address (masking happens at use: a load inside a divergent
+// branch is waited for on the spot, which serialises the prefetch)
+__device__ __forceinline__ float4 load4(const float *__restrict__ p, bool vec)
+{
+    if (vec) return *reinterpret_cast<const float4 *>(p);
+    return make_float4(p[0], p[1], p[2], p[3]);
+}
+
+// ACT is a template parameter: with a run-time activation id the derivative's switch is re-evaluated for each of the
+// 16 staged values (the first build spent 620 scalar and 980 vector instructions per tile on it)
+template <bool HAS_DX, int ACT>
+__global__ void __launch_bounds__(LB_THREADS, 2)
+layer_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ y, int lddy, const float *__restrict__ x,
+                 int ldx, const float *__restrict__ w, int64_t n, int K, int k0, int Kout,
+                 float *__restrict__ dx, int lddx, float *__restrict__ dw, float *__restrict__ db)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    unsigned char *dzi = smem_b, *xi = smem_b + IMG_BYTES;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, c = lane & 31, hf = lane >> 5;
+    const int KT = (K + 31) >> 5;
+
+    // ---- per-wave constant state
+    const int jt = wave & 3, rh = wave >> 2;                 // dx: column tile, row half
+    const bool dx_on = HAS_DX && 32 * jt < Kout;
+    Frag3 wt[HAS_DX ? 8 : 1];
+    if (HAS_DX) {
+        const int kc = 32 * jt + c;
+#pragma unroll
+        for (int ns = 0; ns < 8; ++ns) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = kc < Kout ? w[(16 * ns + 8 * hf + j) * K + k0 + kc] : 0.0f;
+            wt[ns] = split_frag(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+        }
+    }
+    const int nt = wave & 3, kt0 = 2 * (wave >> 2), kt1 = kt0 + 1;   // dW: n tile, the two k tiles
+    const bool w0_on = kt0 < KT, w1_on = kt1 < KT;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = 0.0f, acc1[r] = 0.0f;
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+
+    // ---- staging map: float4 (row (t >> 5) + 16 i, columns col4 .. col4 + 3), i < PASSES
+    const int srow = t >> 5, col4 = (t & 31) * 4;
+    const bool vz = (lddy & 3) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0 &&
+                    (y == nullptr || (reinterpret_cast<uintptr_t>(y) & 15) == 0);
+    const bool vxl = (ldx & 3) == 0 && (K & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    const bool vxs = HAS_DX && (lddx & 3) == 0 && (reinterpret_cast<uintptr_t>(dx) & 15) == 0;
+    // x columns: a clamped (valid) column for the raw load, masked at use
+    const int xcol = col4 + 4 <= K ? col4 : (K >= 4 ? K - 4 : 0);
+    const int64_t last = n - 1;
+    float4 pdy[PASSES], py[PASSES], px[PASSES];
+    auto fetch = [&](int64_t tile) {
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i) {
+            const int64_t row = tile * LB_ROWS + srow + 16 * i;
+            const int64_t rc = row <= last ? row : last;
+            pdy[i] = load4(dy + rc * lddy + col4, vz);
+            if (ACT != RSDF_ACT_NONE) py[i] = load4(y + rc * lddy + col4, vz);
+            if (K >= 4) px[i] = load4(x + rc * ldx + xcol, vxl);
+            else px[i] = make_float4(x[rc * ldx], K > 1 ? x[rc * ldx + 1] : 0.f, K > 2 ? x[rc * ldx + 2] : 0.f, 0.f);
+        }
+    };
+
+    const int64_t n_tiles = (n + LB_ROWS - 1) / LB_ROWS;
+    int64_t tile = blockIdx.x;
+    if (tile < n_tiles) fetch(tile);
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const int64_t row0 = tile * LB_ROWS;
+        // ---- stage: dz and x, split once
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i) {
+            const int row = srow + 16 * i;
+            const bool ok = row0 + row < n;
+            float4 g = pdy[i];
+            if (ACT != RSDF_ACT_NONE) {
+                g.x *= act_bwd_from_y(py[i].x, ACT);
+                g.y *= act_bwd_from_y(py[i].y, ACT);
+                g.z *= act_bwd_from_y(py[i].z, ACT);
+                g.w *= act_bwd_from_y(py[i].w, ACT);
+            }
+            if (!ok) g = make_float4(0.f, 0.f, 0.f, 0.f);
+            bs[0] += g.x, bs[1] += g.y, bs[2] += g.z, bs[3] += g.w;
+            put4(dzi, row, col4, g.x, g.y, g.z, g.w);
+            float4 v = px[i];
+            if (K >= 4 && xcol != col4) {   // the clamped load covers columns xcol .. xcol+3: pick the ones of this slot
+                const float s[4] = {v.x, v.y, v.z, v.w};
+                float o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int src = col4 + q - xcol;
+                    o[q] = (col4 + q < K && src >= 0 && src < 4) ? s[src & 3] : 0.0f;
+                }
+                v = make_float4(o[0], o[1], o[2], o[3]);
+            } else if (K < 4) {
+                if (col4 != 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            put4(xi, row, col4, v.x, v.y, v.z, v.w);
+        }
+        lds_barrier();   // images complete
+        if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x);
+
+        // ---- dx tile [32 columns of the window][32 rows]
+        if (dx_on) {
+            f32x16 a;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a[r] = 0.0f;
+#pragma unroll
+            for (int ns = 0; ns < 8; ++ns) a = mma6r(wt[HAS_DX ? ns : 0], row_frag64(dzi, ns, 32 * rh + c, hf), a);
+            const int64_t row = row0 + 32 * rh + c;
+            if (row < n) {
+                float *xr = dx + row * (int64_t)lddx;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int col = 32 * jt + 8 * g + 4 * hf;   // registers 4g .. 4g+3 = window columns col .. col+3
+                    if (vxs && col + 4 <= Kout) {
+                        *reinterpret_cast<float4 *>(xr + col) = make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (col + q < Kout) xr[col + q] = a[4 * g + q];
+                    }
+                }
+            }
+        }
+        // ---- dW tiles: k = the tile's 64 rows
+        if (w0_on) {
+#pragma unroll
+            for (int ks = 0; ks < LB_ROWS / 16; ++ks) {
+                const Frag3 az = tr_frag64(dzi, nt, ks, lane);
+                acc0 = mma6r(az, tr_frag64(xi, kt0, ks, lane), acc0);
+                if (w1_on) acc1 = mma6r(az, tr_frag64(xi, kt1, ks, lane), acc1);
+            }
+        }
+        lds_barrier();   // images free
+    }
+
+    // ---- flush: D[i = n within tile][j = k within tile]
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int kcol = 32 * (tt ? kt1 : kt0) + c;
+        if ((tt ? w1_on : w0_on) && kcol < K) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = tt ? acc1[r] : acc0[r];
+                const int nrow = 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * hf;
+                if (v != 0.0f) atomicAdd(&dw[nrow * K + kcol], v);
+            }
+        }
+    }
+    if (db) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float s = bs[q] + __shfl_xor(bs[q], 32, 64);   // the wave's two staging rows share their columns
+            if (hf == 0 && s != 0.0f) atomicAdd(&db[col4 + q], s);
+        }
+    }
+}
+
+template <bool HAS_DX, int ACT>
+int launch(unsigned grid, size_t lds, hipStream_t st, const float *dy, const float *y, int lddy, const float *x, int ldx,
+           const float *w, int64_t n, int K, int k0, int Kout, float *dx, int lddx, float *dw, float *db)
+{
+    static bool lds_set = false;   // per instantiation; one device per process
+    if (!lds_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(layer_bwd_kernel<HAS_DX, ACT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { rsdf_set_error(hipGetErrorString(e)); return (int)e; }
+        lds_set = true;
+    }
+    layer_bwd_kernel<HAS_DX, ACT><<<grid, LB_THREADS, lds, st>>>(dy, y, lddy, x, ldx, w, n, K, k0, Kout, dx, lddx, dw, db);
+    return 0;
+}
+
+template <bool HAS_DX>
+int launch_act(int act, unsigned grid, size_t lds, hipStream_t st, const float *dy, const float *y, int lddy, const float *x,
+               int ldx, const float *w, int64_t n, int K, int k0, int Kout, float *dx, int lddx, float *dw, float *db)
+{
+    switch (act) {
+    case RSDF_ACT_NONE: return launch<HAS_DX, RSDF_ACT_NONE>(grid, lds, st, dy, y, lddy, x, ldx, w, n, K, k0, Kout, dx, lddx, dw, db);
+    case RSDF_ACT_RELU: return launch<HAS_DX, RSDF_ACT_RELU>(grid, lds, st, dy, y, lddy, x, ldx, w, n, K, k0, Kout, dx, lddx, dw, db);
+    case RSDF_ACT_SOFTPLUS100:
+        return launch<HAS_DX, RSDF_ACT_SOFTPLUS100>(grid, lds, st, dy, y, lddy, x, ldx, w, n, K, k0, Kout, dx, lddx, dw, db);
+    case RSDF_ACT_SIGMOID:
+        return launch<HAS_DX, RSDF_ACT_SIGMOID>(grid, lds, st, dy, y, lddy, x, ldx, w, n, K, k0, Kout, dx, lddx, dw, db);
+    default: rsdf_set_error("linear_bwd_fused: unknown activation"); return 1;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int rsdf_linear_bwd_fused_supported(int K, int N) { return N == LB_N && K >= 1 && K <= 128; }
+
+int rsdf_linear_bwd_fused(const float *dy, const float *y, int lddy, const float *x, int ldx, const float *w,
+                          int64_t n, int K, int N, int act, int k0, int Kout, float *dx, int lddx, float *dw,
+                          float *db, void *stream)
+{
+    RSDF_CHECK_ARG(rsdf_linear_bwd_fused_supported(K, N), "linear_bwd_fused: needs N == 128 and K in [1,128]");
+    RSDF_CHECK_ARG(lddy >= N && ldx >= K, "linear_bwd_fused: row stride smaller than the row");
+    RSDF_CHECK_ARG(act == RSDF_ACT_NONE || y != nullptr, "linear_bwd_fused: activation needs y");
+    RSDF_CHECK_ARG(dw != nullptr, "linear_bwd_fused: dw is NULL");
+    if (dx) {
+        RSDF_CHECK_ARG(k0 >= 0 && Kout >= 1 && k0 + Kout <= K, "linear_bwd_fused: bad column window");
+        RSDF_CHECK_ARG(lddx >= Kout, "linear_bwd_fused: lddx < Kout");
+    }
+    if (n <= 0) return 0;
+    const size_t lds = 2 * (size_t)IMG_BYTES;
+    const int64_t tiles = (n + LB_ROWS - 1) / LB_ROWS;
+    const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);   // one workgroup per CU
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = dx ? launch_act<true>(act, grid, lds, st, dy, y, lddy, x, ldx, w, n, K, k0, Kout, dx, lddx, dw, db)
+                      : launch_act<false>(act, grid, lds, st, dy, y, lddy, x, ldx, w, n, K, 0, 0, nullptr, 0, dw, db);
+    if (rc) return rc;
+    RSDF_RETURN_LAUNCH();
+}
+
+}  // extern "C"

@@ -11,6 +11,7 @@ Reference interfaces mirrored (paths relative to the upstream RISE-SDF tree):
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional
 
 import torch
@@ -421,7 +422,6 @@ class _Linear(torch.autograd.Function):
         st = stream_ptr()
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], \
             ctx.has_bias and ctx.needs_input_grad[2]
-        dz = torch.empty_like(gy)
         dx = None
         k0, kout = (0, K) if ctx.dx_cols is None else ctx.dx_cols
         dx_win = None
@@ -434,12 +434,19 @@ class _Linear(torch.autograd.Function):
             if k0 + kout < K:
                 dx[:, k0 + kout:].zero_()
             dx_win = ctypes.c_void_p(dx.data_ptr() + 4 * k0)
-        check(lib().rsdf_linear_bwd_input(ptr(gy), ptr(y), N, ptr(wf), n, K, N, ctx.act, k0, kout,
-                                          ptr(dz), dx_win, K, st), "linear_bwd_input")
         dw = db = None
         if need_w or need_b:
             dw = torch.zeros(N, K, dtype=torch.float32, device=xf.device)
             db = torch.zeros(N, dtype=torch.float32, device=xf.device) if need_b else None
+        if dw is not None and lib().rsdf_linear_bwd_fused_supported(K, N) and os.environ.get("RSDF_LAYER_BWD") != "split":
+            # 128-wide layers: one pass, dz never leaves the CU (mlp_layer_bwd.hip)
+            check(lib().rsdf_linear_bwd_fused(ptr(gy), ptr(y), N, ptr(xf), K, ptr(wf), n, K, N, ctx.act, k0, kout,
+                                              dx_win, K, ptr(dw), ptr(db), st), "linear_bwd_fused")
+            return dx, dw, db, None, None
+        dz = torch.empty_like(gy)
+        check(lib().rsdf_linear_bwd_input(ptr(gy), ptr(y), N, ptr(wf), n, K, N, ctx.act, k0, kout,
+                                          ptr(dz), dx_win, K, st), "linear_bwd_input")
+        if dw is not None:
             check(lib().rsdf_linear_bwd_weight(ptr(dz), N, ptr(xf), K, n, K, N, ptr(dw), ptr(db), st),
                   "linear_bwd_weight")
         return dx, dw, db, None, None

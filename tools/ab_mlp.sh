@@ -1,0 +1,19 @@
+#!/bin/bash
+# A/B builds of the three fused-MLP translation units with extra compiler flags on one box:
+#   bash tools/ab_mlp.sh "<flags A>" "<flags B>" ...     (prints ms per launch of the MLP kernels at H = 64 and H = 128)
+set -euo pipefail
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (sets GRAFT_REPO_ROOT)}"
+cd "$GRAFT_REPO_ROOT/rise_sdf_amd/csrc"
+for v in "$@"; do
+  for f in mlp_fused mlp_coop mlp_quad; do
+    /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -I../../include $v -c $f.hip -o _build/$f.o
+  done
+  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 _build/*.o -o ../librisesdf_hip.so
+  for h in 64 128; do
+  (cd ../.. && python bench.py --steps 2 --warmup 1 --cpu-rays 0 --width 400 --height 400 --hidden $h 2>/dev/null | tail -1 | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read()); kb=d['kernel_breakdown']
+print('H=$h', {k:round(v['ms_per_step']/v['calls']*d['steps'],2) for k,v in kb.items() if 'sdfmlp' in k}, '%.4g'%d['value'])")
+  done
+  echo " <= [$v]"
+done
