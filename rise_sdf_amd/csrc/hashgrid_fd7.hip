@@ -138,14 +138,14 @@ __device__ __forceinline__ uint32_t extra_index(const CellFrac &c0, int a, int k
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-#ifndef RSDF_FWD_XCD
-#define RSDF_FWD_XCD 1
-#endif
 #ifndef RSDF_FWD_WAVES
 #define RSDF_FWD_WAVES 3
 #endif
-#ifndef RSDF_FWD_TPB
-#define RSDF_FWD_TPB 1
+#ifndef RSDF_FWD_GROUP
+#define RSDF_FWD_GROUP 4096
+#endif
+#ifndef RSDF_BWD_GROUP
+#define RSDF_BWD_GROUP 256
 #endif
 __device__ __forceinline__ void fd7_fwd_sample(const float *__restrict__ x7t, const float2 *__restrict__ tl,
                                                const LevelGeom &g, int64_t S, int64_t s, int l,
@@ -222,25 +222,25 @@ __device__ __forceinline__ void fd7_fwd_sample(const float *__restrict__ x7t, co
     }
 }
 
+// 1-D grid in SAMPLE-GROUP-MAJOR order: all active levels of RSDF_FWD_GROUP consecutive tiles (4096 x 256 = 1 M samples:
+// 88 MB of x7t), then the next group.  With the level as the slow grid dimension every level's pass re-read the whole
+// 1.6 GB of x7t from HBM (43 % of the kernel's fetch traffic, and the kernel runs at the ~4 TB/s the memory system gives
+// it); inside a group the 15 re-reads come from the 256 MB MALL.  18.8 -> 16.0 ms per launch; 1024-tile groups 16.9,
+// 8192-tile groups (176 MB + the 64 MB of tables: past the MALL) 18.8.  Not paying, measured: XCD-contiguous sample
+// ranges (neighbouring rays in one L2: <= 3 %), several tiles per workgroup, forcing more waves per SIMD.
 __global__ void __launch_bounds__(F_THREADS, RSDF_FWD_WAVES)
 fd7_fwd_kernel(const float *__restrict__ x7t, const float *__restrict__ table,
-               const rsdf_grid_meta meta, int64_t S, int tiles_per_xcd, float2 *__restrict__ planes)
+               const rsdf_grid_meta meta, int64_t S, int n_active, float2 *__restrict__ planes)
 {
-    // Workgroups go round-robin over the 8 XCDs by linear id, and every XCD has its own L2.  Samples are ray-major and
-    // neighbouring rays (neighbouring pixels) share their cells on the levels whose cell is wider than a pixel footprint,
-    // so each XCD takes one CONTIGUOUS eighth of the sample tiles: rays next to each other meet in the same L2.
-    // gridDim.x = 8 * ceil(tiles_per_xcd / RSDF_FWD_TPB); a workgroup walks RSDF_FWD_TPB consecutive tiles.
-    const int l = blockIdx.y;
+    const int64_t per_group = (int64_t)RSDF_FWD_GROUP * n_active;
+    const int64_t grp = blockIdx.x / per_group, r = blockIdx.x - grp * per_group;
+    const int l = (int)(r / RSDF_FWD_GROUP);
+    const int64_t tile = grp * RSDF_FWD_GROUP + (r - (int64_t)l * RSDF_FWD_GROUP);
+    const int64_t s = tile * F_THREADS + threadIdx.x;
+    if (s >= S) return;
     const LevelGeom g = level_geom(meta, l);
     const float2 *tl = reinterpret_cast<const float2 *>(table) + meta.offset[l];
-    const int t0 = (int)(blockIdx.x >> 3) * RSDF_FWD_TPB;
-#pragma unroll 1
-    for (int rep = 0; rep < RSDF_FWD_TPB; ++rep) {
-        if (t0 + rep >= tiles_per_xcd) break;
-        const int64_t tile = (int64_t)(blockIdx.x & 7) * tiles_per_xcd + t0 + rep;
-        const int64_t s = tile * F_THREADS + threadIdx.x;
-        if (s < S) fd7_fwd_sample(x7t, tl, g, S, s, l, planes);
-    }
+    fd7_fwd_sample(x7t, tl, g, S, s, l, planes);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -320,7 +320,7 @@ constexpr int MAX_ITEMS = P_THREADS * 6;
 
 __global__ void __launch_bounds__(P_THREADS, RSDF_STAGE_RECS <= 4 ? 8 : 4)
 fd7_produce_kernel(const float *__restrict__ x7t, const float2 *__restrict__ dplanes,
-                   const rsdf_grid_meta meta, const LevelPlan plan, int64_t S,
+                   const rsdf_grid_meta meta, const LevelPlan plan, int64_t S, int n_active,
                    Record *__restrict__ queues, int *__restrict__ counters,
                    float *__restrict__ dtable)
 {
@@ -334,7 +334,12 @@ fd7_produce_kernel(const float *__restrict__ x7t, const float2 *__restrict__ dpl
     if (threadIdx.x == 0) s_nitems = 0;
     __syncthreads();
 
-    const int l = blockIdx.y;
+    // 1-D grid in sample-group-major order (see the forward): all active levels of RSDF_BWD_GROUP consecutive tiles, then
+    // the next group, so that the 16 re-reads of a group's x7t (and nothing else) come from the MALL
+    const int64_t per_group = (int64_t)RSDF_BWD_GROUP * n_active;
+    const int64_t grp = blockIdx.x / per_group, rem = blockIdx.x - grp * per_group;
+    const int l = (int)(rem / RSDF_BWD_GROUP);
+    const int64_t tile_id = grp * RSDF_BWD_GROUP + (rem - (int64_t)l * RSDF_BWD_GROUP);
     const LevelGeom g = level_geom(meta, l);
     float *dlevel = dtable + (size_t)meta.offset[l] * 2;
     Record *queue = queues + plan.queue_off[l];
@@ -342,7 +347,8 @@ fd7_produce_kernel(const float *__restrict__ x7t, const float2 *__restrict__ dpl
     const int n_bins = plan.n_bins[l], interleaved = plan.interleaved[l];
     const int64_t cap = plan.cap[l];
 
-    const int64_t s_block = (int64_t)blockIdx.x * P_THREADS;
+    const int64_t s_block = tile_id * P_THREADS;
+    if (s_block >= S) return;   // padding tile of the last group (uniform)
     const int64_t s = s_block + threadIdx.x;
     const bool active = s < S;
 
@@ -634,10 +640,11 @@ int rsdf_hashgrid_fwd_fd7(const float *x7t, const float *table, const rsdf_grid_
         RSDF_CHECK_ARG(dense <= meta->size[l] || (meta->size[l] & (meta->size[l] - 1u)) == 0,
                        "hashgrid_fwd_fd7: hashed level sizes must be powers of two");
     }
-    const unsigned tiles_per_xcd = (rsdf_blocks(n_samples, F_THREADS) + 7) / 8;
-    dim3 grid(8 * ((tiles_per_xcd + RSDF_FWD_TPB - 1) / RSDF_FWD_TPB), na);
-    fd7_fwd_kernel<<<grid, F_THREADS, 0, (hipStream_t)stream>>>(x7t, table, *meta, n_samples, (int)tiles_per_xcd,
-                                                                 reinterpret_cast<float2 *>(planes));
+    const unsigned n_tiles_f = (rsdf_blocks(n_samples, F_THREADS) + RSDF_FWD_GROUP - 1) / RSDF_FWD_GROUP * RSDF_FWD_GROUP;
+    // HIP launches in threads: grid.x * block.x must stay below 2^32
+    RSDF_CHECK_ARG((uint64_t)n_tiles_f * na * F_THREADS < (1ull << 32), "hashgrid_fwd_fd7: too many samples for one launch");
+    fd7_fwd_kernel<<<n_tiles_f * na, F_THREADS, 0, (hipStream_t)stream>>>(x7t, table, *meta, n_samples, na,
+                                                                           reinterpret_cast<float2 *>(planes));
     RSDF_RETURN_LAUNCH();
 }
 
@@ -676,7 +683,10 @@ int rsdf_hashgrid_bwd_fd7(const float *x7t, const float *dplanes, const rsdf_gri
     const size_t cbytes = (((size_t)n_cnt * sizeof(int)) + 255) / 256 * 256;
     Record *queues = (Record *)((char *)scratch + cbytes);
     (void)hipMemsetAsync(counters, 0, cbytes, st);
-    dim3 pgrid(rsdf_blocks(n_samples, P_THREADS), na);
+    const unsigned p_tiles = (rsdf_blocks(n_samples, P_THREADS) + RSDF_BWD_GROUP - 1) / RSDF_BWD_GROUP * RSDF_BWD_GROUP;
+    // HIP launches in threads: grid.x * block.x must stay below 2^32
+    RSDF_CHECK_ARG((uint64_t)p_tiles * na * P_THREADS < (1ull << 32), "hashgrid_bwd_fd7: too many samples for one launch");
+    dim3 pgrid(p_tiles * na, 1);
     const size_t stage_bytes = (size_t)STAGE_CAP * sizeof(Record);
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -687,7 +697,7 @@ int rsdf_hashgrid_bwd_fd7(const float *x7t, const float *dplanes, const rsdf_gri
         pattr_set |= 1ull << (dev & 63);
     }
     fd7_produce_kernel<<<pgrid, P_THREADS, stage_bytes, st>>>(x7t, reinterpret_cast<const float2 *>(dplanes), *meta,
-                                                    plan, n_samples, queues, counters, dtable);
+                                                    plan, n_samples, na, queues, counters, dtable);
     int max_wgs = 0;
     for (int l = 0; l < na; ++l) {
         const int w = plan.n_bins[l] * plan.n_split[l];

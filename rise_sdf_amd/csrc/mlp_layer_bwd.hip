@@ -299,13 +299,13 @@ int rsdf_linear_bwd_fused(const float *dy, const float *y, int lddy, const float
 {
     RSDF_CHECK_ARG(rsdf_linear_bwd_fused_supported(K, N), "linear_bwd_fused: needs N == 128 and K in [1,128]");
     RSDF_CHECK_ARG(lddy >= N && ldx >= K, "linear_bwd_fused: row stride smaller than the row");
+    if (n <= 0) return 0;   // an empty batch carries no pointers
     RSDF_CHECK_ARG(act == RSDF_ACT_NONE || y != nullptr, "linear_bwd_fused: activation needs y");
     RSDF_CHECK_ARG(dw != nullptr, "linear_bwd_fused: dw is NULL");
     if (dx) {
         RSDF_CHECK_ARG(k0 >= 0 && Kout >= 1 && k0 + Kout <= K, "linear_bwd_fused: bad column window");
         RSDF_CHECK_ARG(lddx >= Kout, "linear_bwd_fused: lddx < Kout");
     }
-    if (n <= 0) return 0;
     const size_t lds = 2 * (size_t)IMG_BYTES;
     const int64_t tiles = (n + LB_ROWS - 1) / LB_ROWS;
     const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);   // one workgroup per CU
