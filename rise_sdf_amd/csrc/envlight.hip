@@ -137,7 +137,11 @@ bounds_kernel(int R, float cos_cutoff, float *__restrict__ bounds)
 
 // GGX NDF at cos = V.H with H = normalize(A + B), A and B unit (bsdf.h ndf_ggx: a2 / (pi d^2), d = (c a2 - c) c + 1).
 // d = 1 - c^2 (1 - a2) cancels catastrophically in fp32 for narrow lobes (a2 ~ 4e-5 at roughness 0.08), so it is
-// evaluated as d = sin^2 (1 - a2) + a2 with sin^2 = |A x B|^2 / |A + B|^2 -- the same function, full precision.
+// evaluated as d = sin^2 (1 - a2) + a2 with sin^2 = sin^2(angle(A, B) / 2) = |A - B|^2 / 4: the same function, no
+// cancellation (A - B is exact for nearby unit vectors).  The window loops are bound by the vector instructions of this
+// function (per-level times are the same whether a source texel comes from L2 per output texel or from an LDS tile
+// shared by 64 outputs: measured), so it is 9 instructions with one reciprocal (v_rcp_f32, 1 ulp); the first form,
+// |A x B|^2 / |A + B|^2 with two IEEE divisions, cost 35 per pair: 4.6 -> 3.6 (one division) -> 2.x ms per prefilter.
 #ifndef COOP_MAX_R_CFG
 #define COOP_MAX_R_CFG 256
 #endif
@@ -145,11 +149,10 @@ constexpr int COOP_MAX_R = COOP_MAX_R_CFG;   // maps up to this resolution run o
 
 __device__ __forceinline__ float ndf_ggx_pair(float a2, V3 A, V3 B)
 {
-    const V3 c = v3(A.y * B.z - A.z * B.y, A.z * B.x - A.x * B.z, A.x * B.y - A.y * B.x);
-    const V3 h = v3(A.x + B.x, A.y + B.y, A.z + B.z);
-    const float s2 = fminf(dot3(c, c) / dot3(h, h), 1.0f);
+    const V3 e = v3(A.x - B.x, A.y - B.y, A.z - B.z);
+    const float s2 = 0.25f * dot3(e, e);
     const float d = fmaf(s2, 1.0f - a2, a2);
-    return a2 / (d * d * 3.14159265358979323846f);
+    return a2 * __builtin_amdgcn_rcpf(d * d * 3.14159265358979323846f);
 }
 
 // forward: out4 = [sum w c, sum w];  backward (gather): dcube[L] = area(L)/4 * sum_V g[V] (L.V) D(V.H)
@@ -165,8 +168,10 @@ specular_kernel(const float *__restrict__ src, int src_ch, const float *__restri
     // table (nullable) = per texel (unit direction, solid angle / 4) from texel_table_kernel: one 16-byte load
     // replaces the direction normalisation and the two area factors of every window iteration
     extern __shared__ float s_side[];
-    for (int i = threadIdx.x; i < R; i += THREADS) s_side[i] = area_side(i, R);
-    __syncthreads();
+    if (table == nullptr) {   // (with the table no workgroup pays for R atanf before it starts)
+        for (int i = threadIdx.x; i < R; i += THREADS) s_side[i] = area_side(i, R);
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63;
     const int idx = COOP ? blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6) : blockIdx.x * THREADS + threadIdx.x;
     if (idx >= 6 * R * R) return;
@@ -179,8 +184,12 @@ specular_kernel(const float *__restrict__ src, int src_ch, const float *__restri
         const int xmin = (int)b[0], xmax = (int)b[1], ymin = (int)b[2], ymax = (int)b[3];
         if (xmin > xmax) continue;
         const int bw = xmax - xmin + 1, cnt = bw * (ymax - ymin + 1);
+        // i / bw without an integer division per pair (it cost more than the NDF): (i + 0.5) / bw is at least 0.5 / bw away
+        // from an integer and i < 2^18, so the float product truncates to the exact quotient
+        const float inv_bw = 1.0f / (float)bw;
         for (int i = COOP ? lane : 0; i < cnt; i += COOP ? 64 : 1) {
-            const int y = ymin + i / bw, x = xmin + i % bw;
+            const int yo = (int)(((float)i + 0.5f) * inv_bw);
+            const int y = ymin + yo, x = xmin + (i - yo * bw);
             V3 B;
             float area4;
             if (table != nullptr) {
@@ -205,7 +214,7 @@ specular_kernel(const float *__restrict__ src, int src_ch, const float *__restri
         if (lane != 0) return;
     }
     if (BWD) {
-        const float a = s_side[x0] * s_side[y0] / 4.0f;
+        const float a = table != nullptr ? table[idx].w : s_side[x0] * s_side[y0] / 4.0f;
         float *o = dst + (size_t)idx * 3;
         o[0] = c0 * a; o[1] = c1 * a; o[2] = c2 * a;
     } else {

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--rays", type=int, default=4096)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--stage", type=int, default=1)
+    ap.add_argument("--profile", action="store_true", help="cProfile of the host side (no kernel timer)")
     args = ap.parse_args()
     import rise_sdf_amd as R
     from rise_sdf_amd import _lib, ops
@@ -58,6 +59,22 @@ def main():
 
     for _ in range(3):
         step()
+    if args.profile:
+        import cProfile
+        import pstats
+        pr = cProfile.Profile()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pr.enable()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        pr.disable()
+        print("ms per step (under cProfile): %.2f" % ((time.perf_counter() - t0) / args.steps * 1e3))
+        st = pstats.Stats(pr)
+        st.sort_stats("tottime").print_stats(28)
+        st.print_callers("item")
+        return
     timer = _lib.KernelTimer()
     _lib.set_timer(timer)
     torch.cuda.synchronize()
