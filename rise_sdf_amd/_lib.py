@@ -176,10 +176,9 @@ class _TimedLib:
 
     def __getattr__(self, name):
         fn = getattr(self._l, name)
-        if not name.startswith("rsdf_") or name in ("rsdf_last_error", "rsdf_abi_version",
-                                                   "rsdf_scan_scratch_bytes", "rsdf_grid_meta_init",
-                                                   "rsdf_hashgrid_bwd_fd7_scratch_bytes", "rsdf_sdfmlp_fd7_supported",
-                                                   "rsdf_occ_update_scratch_bytes"):
+        # host-only queries launch nothing: not timed
+        if not name.startswith("rsdf_") or name.endswith(("_supported", "_scratch_bytes")) or \
+                name in ("rsdf_last_error", "rsdf_abi_version", "rsdf_grid_meta_init"):
             return fn
         timer = self._t
 

@@ -85,7 +85,11 @@ def texel_table(res, device):
     return _table_cache[key]
 
 
-class _SpecularCubemap(torch.autograd.Function):
+class _SpecularCubemapNormalized(torch.autograd.Function):
+    """lib/renderutils/ops.py:455-458: specular_cubemap's `out[..., 0:3] / out[..., 3:]` inside the node.  The weight sum
+    does not depend on the cube map, so the backward is the gather of dy / wsum: two elementwise kernels per level instead
+    of the ten that autograd issues for the slices and the division (the 4096-ray training step is launch-bound)."""
+
     @staticmethod
     def forward(ctx, cubemap, roughness, cosc, bounds):
         c = _f(cubemap)
@@ -95,17 +99,18 @@ class _SpecularCubemap(torch.autograd.Function):
         out = torch.empty(6, R, R, 4, dtype=torch.float32, device=c.device)
         check(lib().rsdf_specular_cubemap_fwd(ptr(c), ptr(bounds), ptr(table), R, float(roughness), float(cosc),
                                               ptr(out), stream_ptr()), "specular_cubemap_fwd")
-        ctx.save_for_backward(bounds, table)
+        wsum = out[..., 3:]
+        ctx.save_for_backward(bounds, table, wsum)
         ctx.args = (R, float(roughness), float(cosc))
-        return out
+        return out[..., 0:3] / wsum
 
     @staticmethod
-    def backward(ctx, dout):
-        bounds, table = ctx.saved_tensors
+    def backward(ctx, dy):
+        bounds, table, wsum = ctx.saved_tensors
         R, roughness, cosc = ctx.args
-        g = _f(dout)
+        g = (dy / wsum).contiguous()
         gc = torch.empty(6, R, R, 3, dtype=torch.float32, device=g.device)
-        check(lib().rsdf_specular_cubemap_bwd(ptr(g), 4, ptr(bounds), ptr(table), R, roughness, cosc, ptr(gc),
+        check(lib().rsdf_specular_cubemap_bwd(ptr(g), 3, ptr(bounds), ptr(table), R, roughness, cosc, ptr(gc),
                                               stream_ptr()), "specular_cubemap_bwd")
         return gc, None, None, None
 
@@ -114,8 +119,7 @@ def specular_cubemap(cubemap, roughness, cutoff=0.99):
     assert cubemap.shape[0] == 6 and cubemap.shape[1] == cubemap.shape[2], \
         "Bad shape for cubemap tensor: %s" % str(cubemap.shape)
     cosc, bounds = specular_bounds(cubemap.shape[1], roughness, cutoff, cubemap.device)
-    out = _SpecularCubemap.apply(cubemap, roughness, cosc, bounds)
-    return out[..., 0:3] / out[..., 3:]
+    return _SpecularCubemapNormalized.apply(cubemap, roughness, cosc, bounds)
 
 
 # ---- cube lookups ---------------------------------------------------------------------------------------
@@ -163,7 +167,18 @@ def texture_cube(tex, dirs, mips=None, mip_level_bias=None):
     return _CubeSample.apply(dirs, mip_level_bias if mips is not None else None, len(stack), *stack)
 
 
+_dirs_cache = {}
+
+
 def _texel_dirs(R, device):
+    """Face vectors of every texel, [6,R,R,3]; cached per resolution (22 elementwise launches otherwise, five times per step)."""
+    key = (R, str(device))
+    if key not in _dirs_cache:
+        _dirs_cache[key] = _texel_dirs_uncached(R, device)
+    return _dirs_cache[key]
+
+
+def _texel_dirs_uncached(R, device):
     c = 2.0 * ((torch.arange(R, dtype=torch.float32, device=device) + 0.5) / R) - 1.0
     fy, fx = torch.meshgrid(c, c, indexing="ij")
     one = torch.ones_like(fx)

@@ -436,8 +436,10 @@ class _Linear(torch.autograd.Function):
             dx_win = ctypes.c_void_p(dx.data_ptr() + 4 * k0)
         dw = db = None
         if need_w or need_b:
-            dw = torch.zeros(N, K, dtype=torch.float32, device=xf.device)
-            db = torch.zeros(N, dtype=torch.float32, device=xf.device) if need_b else None
+            # one zero-fill for both accumulators (the step at 4096 rays is launch-bound)
+            buf = torch.zeros(N * K + (N if need_b else 0), dtype=torch.float32, device=xf.device)
+            dw = buf[:N * K].view(N, K)
+            db = buf[N * K:] if need_b else None
         if dw is not None and lib().rsdf_linear_bwd_fused_supported(K, N) and os.environ.get("RSDF_LAYER_BWD") != "split":
             # 128-wide layers: one pass, dz never leaves the CU (mlp_layer_bwd.hip)
             check(lib().rsdf_linear_bwd_fused(ptr(gy), ptr(y), N, ptr(xf), K, ptr(wf), n, K, N, ctx.act, k0, kout,

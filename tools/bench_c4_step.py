@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--stage", type=int, default=1)
     ap.add_argument("--profile", action="store_true", help="cProfile of the host side (no kernel timer)")
+    ap.add_argument("--aten-sites", action="store_true",
+                    help="which source lines of the package issue the aten kernels of one step (torch profiler stacks)")
     args = ap.parse_args()
     import rise_sdf_amd as R
     from rise_sdf_amd import _lib, ops
@@ -59,6 +61,32 @@ def main():
 
     for _ in range(3):
         step()
+    if args.aten_sites:
+        import collections
+        import traceback
+        from torch.utils._python_dispatch import TorchDispatchMode
+        sites = collections.Counter()
+        skip = ("aten::empty", "aten::view", "aten::_unsafe_view", "aten::reshape", "aten::detach", "aten::as_strided", "aten::slice",
+                "aten::select", "aten::expand", "aten::t", "aten::transpose", "aten::permute", "aten::unsqueeze", "aten::squeeze",
+                "aten::alias", "aten::_local_scalar_dense", "aten::empty_like", "aten::empty_strided", "aten::split",
+                "aten::unbind", "aten::split_with_sizes", "aten::lift_fresh", "aten::_to_copy", "aten::new_empty")
+
+        class Mode(TorchDispatchMode):
+            def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+                name = func._schema.name
+                if not name.startswith(skip):
+                    fr = [f for f in traceback.extract_stack() if "rise_sdf_amd" in f.filename]
+                    f = fr[-1] if fr else None
+                    where = "%s:%d %s" % (os.path.basename(f.filename), f.lineno, f.name) if f else "?"
+                    sites[(where, name)] += 1
+                return func(*args, **(kwargs or {}))
+
+        with Mode():
+            step()
+        print("aten ops by issuing line, forward + Python-side backward of one step: total", sum(sites.values()))
+        for (site, name), c in sites.most_common(90):
+            print("%4d  %-26s %s" % (c, name, site))
+        return
     if args.profile:
         import cProfile
         import pstats
