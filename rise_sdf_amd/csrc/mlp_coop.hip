@@ -265,6 +265,23 @@ __device__ __forceinline__ void dma_x(unsigned char *raw, const Src &src, int64_
 {
     constexpr int LPW = 16 / NT;
     const int64_t last = src.S - 1;
+    if (s0 + 32 <= src.S) {
+        // Full tile: 16-byte DMAs, four levels each (an LDS-DMA instruction costs 60-185 cycles of issue whatever its width;
+        // the in-kernel stamps of the lean forward put input staging at 18 % of a tile): lane (level l0 + lane / 16, chunk
+        // lane % 16) fetches rows 2 chunk, 2 chunk + 1; same [level][row][2] landing image.  dwordx4 needs dword alignment
+        // only.  The last, partial tile of a launch takes the 4-byte path below.
+#pragma unroll
+        for (int i = 0; i < LPW; i += 4) {
+            const int l = w * LPW + i + (lane >> 4);
+            const float *g = src.planes + (((int64_t)(l < src.n_active ? l : 0) * 7 + tap) * src.S + s0 + 2 * (lane & 15)) * 2;
+            __builtin_amdgcn_global_load_lds((glob_void *)g, (lds_void *)(raw + (w * LPW + i) * 256), 16, 0, 0);
+        }
+        if (w == 0 && lane < 24) {
+            const float *xb = src.x7t + (int64_t)tap * src.S * 3 + s0 * 3 + 4 * lane;
+            __builtin_amdgcn_global_load_lds((glob_void *)xb, (lds_void *)(raw + 16 * 256), 16, 0, 0);
+        }
+        return;
+    }
     const int64_t r = s0 + (lane >> 1);
     const int64_t rc = r <= last ? r : last;
 #pragma unroll
@@ -386,11 +403,32 @@ __device__ __forceinline__ void load_w1t(Frag3 (&f)[NT][2], const float *__restr
         }
 }
 
+// ---- in-kernel stamps (build with -DRSDF_STAMPS; tools/stamps_coop.py): wave 0 of workgroup 0 accumulates the s_memtime
+// cycles between consecutive stamp points of the lean forward into g_stamps[point]; g_stamps[15] counts the tiles
+#ifdef RSDF_STAMPS
+__device__ unsigned long long g_stamps[16];
+struct Stamper {
+    unsigned long long last, acc[16];
+    bool on;
+    __device__ __forceinline__ void begin(bool enable) { on = enable; for (int i = 0; i < 16; ++i) acc[i] = 0; last = __builtin_readcyclecounter(); }
+    __device__ __forceinline__ void at(int i) { const unsigned long long t = __builtin_readcyclecounter(); acc[i] += t - last; last = t; }
+    __device__ __forceinline__ void flush() { if (on) for (int i = 0; i < 16; ++i) g_stamps[i] = acc[i]; }
+};
+#define RSDF_STAMP(st, i) (st).at(i)
+#else
+struct Stamper {
+    __device__ __forceinline__ void begin(bool) {}
+    __device__ __forceinline__ void flush() {}
+};
+#define RSDF_STAMP(st, i)
+#endif
+
 // ---- the two hidden layers of the tile in flight ---------------------------------------------------------------------
 // On return h1 / h2 hold this wave's feature tile (activated), the H1 image is complete and visible to every wave.
 template <int NT, typename L>
 __device__ __forceinline__ void hidden_layers(unsigned char *smem, const unsigned char *xi, const Frag3 (&w0f)[3],
-                                              const Frag3 (&w1f)[NT][2], int w, int c, int hf, f32x16 &h1, f32x16 &h2)
+                                              const Frag3 (&w1f)[NT][2], int w, int c, int hf, f32x16 &h1, f32x16 &h2,
+                                              Stamper &stp)
 {
     f32x16 acc;
     {   // layer 1: all 18 fragment reads in flight, then the 18 products
@@ -412,6 +450,7 @@ __device__ __forceinline__ void hidden_layers(unsigned char *smem, const unsigne
         acc = mma6f(a[1], b[1], acc);
         acc = mma6f(a[2], b[2], acc);
     }
+    RSDF_STAMP(stp, 3);    // layer-1 products issued
 #pragma unroll
     for (int r = 0; r < 16; ++r) h1[r] = softplus100c(acc[r]);
     {
@@ -419,7 +458,9 @@ __device__ __forceinline__ void hidden_layers(unsigned char *smem, const unsigne
         split_tile(h1, f);
         store_tile(smem + L::H1I, L::H_PART, w, c, hf, f);
     }
+    RSDF_STAMP(stp, 4);    // Softplus + split + image store
     lds_barrier();
+    RSDF_STAMP(stp, 5);    // H1 barrier
     const float *tab = reinterpret_cast<const float *>(smem + L::TAB) + (2 * w + hf) * 16;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -440,8 +481,10 @@ __device__ __forceinline__ void hidden_layers(unsigned char *smem, const unsigne
 #pragma unroll
             for (int s = 0; s < 2; ++s) acc = mma6f(w1f[k0 + kk][s], b[kk][s], acc);
     }
+    RSDF_STAMP(stp, 6);    // layer-2 products issued
 #pragma unroll
     for (int r = 0; r < 16; ++r) h2[r] = softplus100c(acc[r]);
+    RSDF_STAMP(stp, 7);    // Softplus
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -482,6 +525,8 @@ coop_fwd_kernel(const Src src, const float *__restrict__ w0, const float *__rest
     float *sp = reinterpret_cast<float *>(smem + L::SP);
 
     const int64_t n_groups = (src.S + 31) / 32;
+    Stamper stp;
+    stp.begin(false);
     if ((int64_t)blockIdx.x < n_groups) dma_x<NT>(smem + L::RAW, src, (int64_t)blockIdx.x * 32, 0, w, lane);
     int parity = 0;
     for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
@@ -498,7 +543,7 @@ coop_fwd_kernel(const Src src, const float *__restrict__ w0, const float *__rest
             }
             lds_barrier();                                                     // X image complete
             f32x16 h1, h2;
-            hidden_layers<NT, G<NT>>(smem, xi, w0f, w1f, w, c, hf, h1, h2);
+            hidden_layers<NT, G<NT>>(smem, xi, w0f, w1f, w, c, hf, h1, h2, stp);
             // SDF = W2[0,:] . h2 + b2[0]: this wave's 32 features, then across the waves through LDS
             float part = 0.0f;
 #pragma unroll
@@ -575,10 +620,14 @@ coop_fwd_lean_kernel(const Src src, const float *__restrict__ w0, const float *_
     const int64_t n_groups = (src.S + 31) / 32;
     if ((int64_t)blockIdx.x < n_groups) dma_x<NT>(smem + L::RAW, src, (int64_t)blockIdx.x * 32, 0, w, lane);
     int parity = 0;
+    Stamper stp;
+    stp.begin(blockIdx.x == 0 && w == 0);
     for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
         const int64_t s0 = g * 32;
         for (int tap = 0; tap < 7; ++tap) {
+            RSDF_STAMP(stp, 9);                                                  // tail of the previous tile (sdf store, loop)
             wait_vm0();                                                          // this tile's inputs have landed
+            RSDF_STAMP(stp, 0);                                                  // wait for the DMA
             // (every wave is past barrier (b) of the previous tile, i.e. past its reads of the X image and of sp)
             store_x<NT>(xi, smem + L::RAW + parity * 18 * 256, src, s0, w, lane);
             parity ^= 1;
@@ -587,9 +636,11 @@ coop_fwd_lean_kernel(const Src src, const float *__restrict__ w0, const float *_
                 const int64_t ng = tap == 6 ? g + gridDim.x : g;
                 if (ng < n_groups) dma_x<NT>(smem + L::RAW + parity * 18 * 256, src, ng * 32, ntap, w, lane);
             }
+            RSDF_STAMP(stp, 1);                                                  // X image store + next DMA issue
             lds_barrier();                                                     // (a) X image complete
+            RSDF_STAMP(stp, 2);                                                  // barrier (a)
             f32x16 h1, h2;
-            hidden_layers<NT, L>(smem, xi, w0f, w1f, w, c, hf, h1, h2);         // barrier inside: H1 image complete
+            hidden_layers<NT, L>(smem, xi, w0f, w1f, w, c, hf, h1, h2, stp);    // barrier inside: H1 image complete
             float part = 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) part = fmaf(tab[H + (2 * w + hf) * 16 + r], h2[r], part);
@@ -603,15 +654,21 @@ coop_fwd_lean_kernel(const Src src, const float *__restrict__ w0, const float *_
                     *reinterpret_cast<float4 *>(h2c + (s0 + c) * H + 32 * w + 8 * q + 4 * hf) =
                         float4{h2[4 * q], h2[4 * q + 1], h2[4 * q + 2], h2[4 * q + 3]};
             }
+            RSDF_STAMP(stp, 8);                                                  // SDF partial + h2c store
             lds_barrier();                                                     // (b) partial sums visible
+            RSDF_STAMP(stp, 10);                                                 // barrier (b)
             if (w == 0 && hf == 0 && s0 + c < src.S) {
                 float acc = b2_0;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc += sp[(parity * NT + t) * 32 + c];
                 sdf7[(int64_t)tap * src.S + s0 + c] = acc;
             }
+#ifdef RSDF_STAMPS
+            stp.acc[15] += 1;
+#endif
         }
     }
+    stp.flush();
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -661,6 +718,8 @@ coop_bwd_kernel(const Src src, const float *__restrict__ w0, const float *__rest
     float gb2 = 0.0f;
 
     const int64_t n_groups = (src.S + 31) / 32;
+    Stamper stp;
+    stp.begin(false);
     if ((int64_t)blockIdx.x < n_groups) dma_x<NT>(smem + L::RAW, src, (int64_t)blockIdx.x * 32, 0, w, lane);
     int parity = 0;
     for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
@@ -690,7 +749,7 @@ coop_bwd_kernel(const Src src, const float *__restrict__ w0, const float *__rest
             }
             lds_barrier();                                                     // (1) X image complete
             f32x16 h1, h2;
-            hidden_layers<NT, G<NT>>(smem, xi, w0f, w1f, w, c, hf, h1, h2);                  // (2) inside: H1 image complete
+            hidden_layers<NT, G<NT>>(smem, xi, w0f, w1f, w, c, hf, h1, h2, stp);             // (2) inside: H1 image complete
             // ---- layer 3: d(h2) = W2[0,:] d_sdf (+ feature part); dW2[0,:] += d_sdf h2; dz2 = d(h2) sigma'(z2)
             const float dsdf = row_ok ? dsdf_raw : 0.0f;
             if (w == 0 && hf == 0) gb2 += dsdf;
@@ -861,6 +920,13 @@ unsigned coop_grid(int64_t n_samples)
 }
 
 }  // namespace
+
+#ifdef RSDF_STAMPS
+extern "C" int rsdf_debug_read_stamps(unsigned long long *out16)
+{
+    return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps), 16 * sizeof(unsigned long long));
+}
+#endif
 
 // entry points used by mlp_fused.hip's dispatchers
 int rsdf_coop_fwd(int NT, const float *x7t, const float *planes, int n_levels, int n_active, float xyz_scale,

@@ -166,6 +166,21 @@ __device__ __forceinline__ void dma_q(unsigned char *raw, const SrcQ &src, int64
 {
     constexpr int LPW = 16 / NW;
     const int64_t last = src.S - 1;
+    if (LPW == 4 && s0 + 32 <= src.S) {
+        // Full tile: one 16-byte DMA per wave instead of four 4-byte ones (an LDS-DMA instruction costs 60-185 cycles of
+        // issue whatever its width): lane (level w*4 + lane / 16, chunk lane % 16) fetches rows 2 chunk, 2 chunk + 1 of
+        // its level; the landing zone is the same [level][row][2] image.  (Global addresses are 8-byte aligned only
+        // when S is odd: dwordx4 needs dword alignment.)  The last, partial tile of a launch takes the narrow path below.
+        const int l = w * 4 + (lane >> 4);
+        const int64_t r = s0 + 2 * (lane & 15);
+        const float *gp = src.planes + (((int64_t)(l < src.n_active ? l : 0) * 7 + tap) * src.S + r) * 2;
+        __builtin_amdgcn_global_load_lds((glob_void *)gp, (lds_void *)(raw + w * 4 * 256), 16, 0, 0);
+        if (w == 0 && lane < 24) {
+            const float *xb = src.x7t + (int64_t)tap * src.S * 3 + s0 * 3 + 4 * lane;
+            __builtin_amdgcn_global_load_lds((glob_void *)xb, (lds_void *)(raw + 16 * 256), 16, 0, 0);
+        }
+        return;
+    }
     const int64_t r = s0 + (lane >> 1);
     const int64_t rc = r <= last ? r : last;
 #pragma unroll
