@@ -26,9 +26,11 @@ namespace {
 constexpr int BWD_WAVES = 4;      // backward: one wave per SIMD (register-resident weight fragments + accumulators)
 constexpr int BWD_THREADS = BWD_WAVES * 64;
 #ifndef RSDF_FWD_WAVES_CFG
-#define RSDF_FWD_WAVES_CFG 12
+#define RSDF_FWD_WAVES_CFG 8
 #endif
 constexpr int FWD_WAVES = RSDF_FWD_WAVES_CFG;   // forward: waves per workgroup (one workgroup per CU): 8 = two per SIMD, 12 = three
+// (12 waves fit since b1 / the SDF row are read from LDS and the wave tile is 4.7 KB, and gained 3 % with the dword prefetch;
+//  with the dwordx4 prefetch the 168-register budget spills and 8 waves are as fast: 68.8 vs 72.0 ms per quarter step)
 constexpr int FWD_THREADS = FWD_WAVES * 64;
 constexpr int LDT = 33;       // [feature][row] transposed tiles
 
@@ -174,6 +176,61 @@ __device__ __forceinline__ void store_tile_f(float *Xs, const float (&pre)[18], 
     if (lane < 32) Xs[lane * LDXF + 35] = 1.0f;   // bias column
 }
 
+// Wide variant for FULL tiles (the forward is bound by its vector instructions: 18 dword loads with their address
+// arithmetic per tile become 5 dwordx4 loads).  v[4k .. 4k+3] = level 4k + lane / 16, rows 2 (lane % 16) and + 1, both
+// features; v[16 .. 19] = floats 4 lane .. + 3 of the tile's 96 point coordinates (lanes >= 24 re-read a valid address).
+// A partial tile (the last one of a launch) keeps the dword path; v is shared storage.
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ void fetch_tile4(float (&v)[20], const TileSrc &src, int64_t s0, int tap, int lane)
+{
+    if (s0 + 32 > src.S) {
+        float pre[18];
+        fetch_tile(pre, src, s0, tap, lane);
+#pragma unroll
+        for (int i = 0; i < 18; ++i) v[i] = pre[i];
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int l = 4 * k + (lane >> 4);
+        const f32x4u t = *reinterpret_cast<const f32x4u *>(
+            src.planes + (((int64_t)(l < src.n_active ? l : 0) * 7 + tap) * src.S + s0 + 2 * (lane & 15)) * 2);
+        v[4 * k] = t[0]; v[4 * k + 1] = t[1]; v[4 * k + 2] = t[2]; v[4 * k + 3] = t[3];
+    }
+    const int xl = lane < 24 ? lane : lane - 24;
+    const f32x4u t = *reinterpret_cast<const f32x4u *>(src.x7t + ((int64_t)tap * src.S + s0) * 3 + 4 * xl);
+    v[16] = t[0]; v[17] = t[1]; v[18] = t[2]; v[19] = t[3];
+}
+__device__ __forceinline__ void store_tile4(float *Xs, const float (&v)[20], const TileSrc &src, int64_t s0, int lane)
+{
+    if (s0 + 32 > src.S) {
+        float pre[18];
+#pragma unroll
+        for (int i = 0; i < 18; ++i) pre[i] = v[i];
+        store_tile_f(Xs, pre, src, s0, lane);
+        return;
+    }
+    const int r0 = 2 * (lane & 15);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int l = 4 * k + (lane >> 4);
+        const bool on = l < src.n_active;
+        float *p = Xs + r0 * LDXF + 3 + 2 * l;
+        p[0] = on ? v[4 * k] : 0.0f;
+        p[1] = on ? v[4 * k + 1] : 0.0f;
+        p[LDXF] = on ? v[4 * k + 2] : 0.0f;
+        p[LDXF + 1] = on ? v[4 * k + 3] : 0.0f;
+    }
+    if (lane < 24) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = 4 * lane + i;
+            Xs[(e / 3) * LDXF + e % 3] = v[16 + i] * src.xyz_scale + src.xyz_offset;
+        }
+    }
+    if (lane < 32) Xs[lane * LDXF + 35] = 1.0f;   // bias column
+}
+
 // hidden layers 1 and 2 of one 32-row tile; h[t][r]: feature 32 t + (r & 3) + 8 (r >> 2) + 4 hf of row c
 template <int H>
 __device__ __forceinline__ void hidden_forward_s(const unsigned char *smem, const float *Xs, int c, int hf,
@@ -254,16 +311,16 @@ sdfmlp_fwd_kernel(const TileSrc src, const float *__restrict__ w0,
 
     const int64_t n_groups = (n_samples + 31) / 32;  // 32 samples per wave iteration
     const int64_t g_first = (int64_t)blockIdx.x * FWD_WAVES + wave, g_step = (int64_t)gridDim.x * FWD_WAVES;
-    float pre[18];
-    if (g_first < n_groups) fetch_tile(pre, src, g_first * 32, 0, lane);
+    float pre[20];
+    if (g_first < n_groups) fetch_tile4(pre, src, g_first * 32, 0, lane);
     for (int64_t g = g_first; g < n_groups; g += g_step) {
         const int64_t s0 = g * 32;
         for (int tap = 0; tap < 7; ++tap) {
-            store_tile_f(Xs, pre, src, s0, lane);
+            store_tile4(Xs, pre, src, s0, lane);
             {   // prefetch the next tile of this wave
                 const int ntap = tap == 6 ? 0 : tap + 1;
                 const int64_t ng = tap == 6 ? g + g_step : g;
-                if (ng < n_groups) fetch_tile(pre, src, ng * 32, ntap, lane);
+                if (ng < n_groups) fetch_tile4(pre, src, ng * 32, ntap, lane);
             }
             f32x16 h1[NT], h2[NT];
             hidden_forward_s<H>(smem_b, Xs, c, hf, tail + S::B1, h1, h2);
