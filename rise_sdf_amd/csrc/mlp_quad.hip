@@ -160,6 +160,26 @@ __device__ __forceinline__ void lds_barrier_q()                                 
     asm volatile("" ::: "memory");
 }
 
+// in-kernel stamps (build with -DRSDF_STAMPS; tools/stamps_quad.sh): wave 0 of workgroup 0 accumulates the s_memtime
+// cycles between consecutive stamp points into g_qstamps[point]; g_qstamps[15] counts the tiles
+#ifdef RSDF_STAMPS
+__device__ unsigned long long g_qstamps[16];
+struct StamperQ {
+    unsigned long long last, acc[16];
+    bool on;
+    __device__ __forceinline__ void begin(bool enable) { on = enable; for (int i = 0; i < 16; ++i) acc[i] = 0; last = __builtin_readcyclecounter(); }
+    __device__ __forceinline__ void at(int i) { const unsigned long long t = __builtin_readcyclecounter(); acc[i] += t - last; last = t; }
+    __device__ __forceinline__ void flush() { if (on) for (int i = 0; i < 16; ++i) g_qstamps[i] = acc[i]; }
+};
+#define RSDF_QSTAMP(i) stq.at(i)
+#else
+struct StamperQ {
+    __device__ __forceinline__ void begin(bool) {}
+    __device__ __forceinline__ void flush() {}
+};
+#define RSDF_QSTAMP(i)
+#endif
+
 // LDS-DMA prefetch of the next tile's inputs (mlp_coop.hip dma_x): wave w lands its LPW levels (and wave 0 the points)
 template <int NW>
 __device__ __forceinline__ void dma_q(unsigned char *raw, const SrcQ &src, int64_t s0, int tap, int w, int lane)
@@ -323,11 +343,15 @@ quad_bwd_kernel(const SrcQ src, const float *__restrict__ w0, const float *__res
     const int64_t n_groups = (src.S + 31) / 32;
     if ((int64_t)blockIdx.x < n_groups) dma_q<NW>(smem + L::RAW, src, (int64_t)blockIdx.x * 32, 0, w, lane);
     int parity = 0;
+    StamperQ stq;
+    stq.begin(blockIdx.x == 0 && w == 0);
     for (int64_t gi = blockIdx.x; gi < n_groups; gi += gridDim.x) {
         const int64_t s0 = gi * 32;
         for (int tap = 0; tap < 7; ++tap) {
             unsigned char *xi = smem + L::XI + parity * 3 * QX_PART;
+            RSDF_QSTAMP(0);                        // loop overhead
             wait_vm0q();                           // this tile's inputs have landed (and the previous tile's stores retired)
+            RSDF_QSTAMP(1);                        // vmcnt wait
             stage_q<NW>(xi, smem + L::RAW + parity * 18 * 256, src, s0, w, lane);
             parity ^= 1;
             bool row_ok[2];
@@ -351,7 +375,9 @@ quad_bwd_kernel(const SrcQ src, const float *__restrict__ w0, const float *__res
                 const int64_t ng = tap == 6 ? gi + gridDim.x : gi;
                 if (ng < n_groups) dma_q<NW>(smem + L::RAW + parity * 18 * 256, src, ng * 32, ntap, w, lane);
             }
+            RSDF_QSTAMP(2);                        // X image staging, d_sdf loads, next DMA issue
             lds_barrier_q();                                                     // (1) X image complete
+            RSDF_QSTAMP(3);                        // barrier 1
             // ---- recompute layer 1
             f32x4 h1[2], h2[2];
 #pragma unroll
@@ -363,7 +389,9 @@ quad_bwd_kernel(const SrcQ src, const float *__restrict__ w0, const float *__res
                 for (int r = 0; r < 4; ++r) h1[rh][r] = softplus100q(acc[r]);
                 store_q(smem + L::H1I, L::H_PART, rh, lc, h1[rh]);
             }
+            RSDF_QSTAMP(4);                        // layer-1 recompute + Softplus + H1 store
             lds_barrier_q();                                                     // (2) H1 image complete
+            RSDF_QSTAMP(5);                        // barrier 2
             // ---- recompute layer 2, then layer 3 backward: dz2 = (W2[0,:] d_sdf + feature part) sigma'(z2)
 #pragma unroll
             for (int rh = 0; rh < 2; ++rh) {
@@ -381,7 +409,9 @@ quad_bwd_kernel(const SrcQ src, const float *__restrict__ w0, const float *__res
                 }
                 store_q(smem + L::DZI, L::H_PART, rh, lc, dz[rh]);
             }
+            RSDF_QSTAMP(6);                        // layer-2 recompute + dz2 + store
             lds_barrier_q();                                                     // (3) dz2 image complete
+            RSDF_QSTAMP(7);                        // barrier 3
             // ---- layer 2 backward: dz1[own k1] = (W1^T dz2) sigma'(z1) ; dW1[own n][all k] += dz2^T h1 (K = the 32 rows)
 #pragma unroll
             for (int rh = 0; rh < 2; ++rh) {
@@ -398,7 +428,9 @@ quad_bwd_kernel(const SrcQ src, const float *__restrict__ w0, const float *__res
             }
             store_q(smem + L::DZ1, L::H_PART, 0, lc, dz[0]);
             store_q(smem + L::DZ1, L::H_PART, 1, lc, dz[1]);
+            RSDF_QSTAMP(8);                        // dz1 + dW1 products + dz1 store
             lds_barrier_q();                                                     // (4) dz1 image complete
+            RSDF_QSTAMP(9);                        // barrier 4
             // ---- layer 1 backward: d(hash features) sub-tile (16 columns x 16 rows, all 64 features); dW0 += dz1^T X
             {
                 f32x4 dx = {0.f, 0.f, 0.f, 0.f};
@@ -420,9 +452,14 @@ quad_bwd_kernel(const SrcQ src, const float *__restrict__ w0, const float *__res
 #pragma unroll
                 for (int ct = 0; ct < 3; ++ct) gw0[ct] = mma6q(a, trfq(xi, QX_PART, ct, lc), gw0[ct]);
             }
+            RSDF_QSTAMP(10);                       // dx + store + dW0 products
+#ifdef RSDF_STAMPS
+            stq.acc[15] += 1;
+#endif
             // no barrier: the next tile stages the other X image; its H1 / dz2 / dz1 writes sit behind its barriers (1) .. (3)
         }
     }
+    stq.flush();
 
     // ---- flush: gw1[n][r] = dW1[16 w + 4 g + r][16 n + c16]; gw0[ct][r] = dW0 image [feature][X column 16 ct + c16]
 #pragma unroll
@@ -453,6 +490,13 @@ quad_bwd_kernel(const SrcQ src, const float *__restrict__ w0, const float *__res
 }
 
 }  // namespace
+
+#ifdef RSDF_STAMPS
+extern "C" int rsdf_debug_read_qstamps(unsigned long long *out16)
+{
+    return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_qstamps), 16 * sizeof(unsigned long long));
+}
+#endif
 
 int rsdf_quad_bwd(int H, const float *x7t, const float *planes, int n_levels, int n_active, float xyz_scale, float xyz_offset,
                   const float *w0, const float *b0, const float *w1, const float *b1, const float *w2, int64_t n_samples,
