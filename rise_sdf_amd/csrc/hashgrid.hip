@@ -30,15 +30,26 @@ struct Feat<2> { using T = float2; };
 template <>
 struct Feat<4> { using T = float4; };
 
+#ifndef RSDF_GEN_FWD_GROUP
+#define RSDF_GEN_FWD_GROUP 1024
+#endif
+constexpr int FWD_GROUP = RSDF_GEN_FWD_GROUP;   // tiles per sample group
+
 template <int F>
 __global__ void __launch_bounds__(THREADS)
 hashgrid_fwd_kernel(const float *__restrict__ x, const float *__restrict__ table,
-                    const rsdf_grid_meta meta, int64_t n, int n_active, float *__restrict__ out,
+                    const rsdf_grid_meta meta, int64_t n, int n_levels, int n_active, float *__restrict__ out,
                     int ld_out, int col_off, int write_xyz, float xyz_scale, float xyz_offset)
 {
-    const int64_t s = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    // 1-D grid in sample-group-major order (hashgrid_fd7.hip, fd7_fwd_kernel): all levels of FWD_GROUP consecutive tiles,
+    // then the next group.  A level writes F floats into each sample's [ld_out] row; with the level as the slow grid
+    // dimension the 16 partial writes of an output line were whole passes over the batch apart (read-modify-write in
+    // HBM each time), inside a group they meet in the L2 / MALL.
+    const int64_t per_group = (int64_t)FWD_GROUP * n_levels;
+    const int64_t grp = blockIdx.x / per_group, r = blockIdx.x - grp * per_group;
+    const int l = (int)(r / FWD_GROUP);
+    const int64_t s = (grp * FWD_GROUP + (r - (int64_t)l * FWD_GROUP)) * THREADS + threadIdx.x;
     if (s >= n) return;
-    const int l = blockIdx.y;
     float *o = out + s * ld_out + col_off + l * F;
     const float px = x[3 * s], py = x[3 * s + 1], pz = x[3 * s + 2];
     if (write_xyz && l == 0) {
@@ -202,12 +213,15 @@ int rsdf_hashgrid_fwd(const float *x, const float *table, const rsdf_grid_meta *
     RSDF_CHECK_ARG(!write_xyz || col_off >= 3, "hashgrid_fwd: write_xyz needs col_off >= 3");
     if (n <= 0) return 0;
     if (n_active_levels < 0 || n_active_levels > L) n_active_levels = L;
-    dim3 grid(rsdf_blocks(n, THREADS), L);
+    const unsigned tiles = (rsdf_blocks(n, THREADS) + FWD_GROUP - 1) / FWD_GROUP * FWD_GROUP;
+    // HIP launches in threads: grid.x * block.x must stay below 2^32
+    RSDF_CHECK_ARG((uint64_t)tiles * L * THREADS < (1ull << 32), "hashgrid_fwd: too many points for one launch");
+    const unsigned grid = tiles * L;
     hipStream_t st = (hipStream_t)stream;
     switch (F) {
-    case 1: hashgrid_fwd_kernel<1><<<grid, THREADS, 0, st>>>(x, table, *meta, n, n_active_levels, out, ld_out, col_off, write_xyz, xyz_scale, xyz_offset); break;
-    case 2: hashgrid_fwd_kernel<2><<<grid, THREADS, 0, st>>>(x, table, *meta, n, n_active_levels, out, ld_out, col_off, write_xyz, xyz_scale, xyz_offset); break;
-    default: hashgrid_fwd_kernel<4><<<grid, THREADS, 0, st>>>(x, table, *meta, n, n_active_levels, out, ld_out, col_off, write_xyz, xyz_scale, xyz_offset); break;
+    case 1: hashgrid_fwd_kernel<1><<<grid, THREADS, 0, st>>>(x, table, *meta, n, L, n_active_levels, out, ld_out, col_off, write_xyz, xyz_scale, xyz_offset); break;
+    case 2: hashgrid_fwd_kernel<2><<<grid, THREADS, 0, st>>>(x, table, *meta, n, L, n_active_levels, out, ld_out, col_off, write_xyz, xyz_scale, xyz_offset); break;
+    default: hashgrid_fwd_kernel<4><<<grid, THREADS, 0, st>>>(x, table, *meta, n, L, n_active_levels, out, ld_out, col_off, write_xyz, xyz_scale, xyz_offset); break;
     }
     RSDF_RETURN_LAUNCH();
 }

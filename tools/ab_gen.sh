@@ -1,0 +1,13 @@
+#!/bin/bash
+# A/B builds of hashgrid.hip (generic encoder) with different -D flags: bash tools/ab_gen.sh "-DX=1" "-DX=2" ...
+set -euo pipefail
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (sets GRAFT_REPO_ROOT)}"
+cd "$GRAFT_REPO_ROOT/rise_sdf_amd/csrc"
+for v in "$@"; do
+  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -I../../include $v -c hashgrid.hip -o _build/hashgrid.o
+  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 _build/*.o -o ../librisesdf_hip.so
+  (cd ../.. && python bench.py --steps 1 --warmup 0 --cpu-rays 0 2>/dev/null | tail -1 | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read()); g=d['roofline']['other_kernels']['rsdf_hashgrid_fwd (generic)']
+print(g['avg_launch_ms'], 'ms', '%.3g evals/s' % g['evals_per_sec'], g['frac'])"; echo " <= [$v]")
+done
