@@ -243,6 +243,32 @@ fd7_fwd_kernel(const float *__restrict__ x7t, const float *__restrict__ table,
     fd7_fwd_sample(x7t, tl, g, S, s, l, planes);
 }
 
+// in-kernel stamps (build with -DRSDF_STAMPS; tools/stamps_produce.sh): thread 0 of the workgroups of level RSDF_STAMP_LEVEL
+// add the s_memtime cycles between consecutive stamp points to g_pstamps[point] (atomically: many workgroups)
+#ifdef RSDF_STAMPS
+#ifndef RSDF_STAMP_LEVEL
+#define RSDF_STAMP_LEVEL 12
+#endif
+__device__ unsigned long long g_pstamps[16];
+struct StamperP {
+    unsigned long long last;
+    bool on;
+    __device__ __forceinline__ void begin(bool enable) { on = enable; last = __builtin_readcyclecounter(); }
+    __device__ __forceinline__ void at(int i)
+    {
+        const unsigned long long t = __builtin_readcyclecounter();
+        if (on) atomicAdd(&g_pstamps[i], t - last);
+        last = __builtin_readcyclecounter();
+    }
+};
+#define RSDF_PSTAMP(st, i) (st).at(i)
+#else
+struct StamperP {
+    __device__ __forceinline__ void begin(bool) {}
+};
+#define RSDF_PSTAMP(st, i)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // backward: produce
 // ------------------------------------------------------------------------------------------------
@@ -256,7 +282,7 @@ __device__ __forceinline__ void emit_round(const uint32_t (&ridx)[ROUND_RECS],
                                            int n_bins, int interleaved, int64_t cap,
                                            Record *__restrict__ queue, int *__restrict__ qcount,
                                            float *__restrict__ dlevel, int *s_cnt, int *s_off,
-                                           int *s_gbase, Record *s_stage)
+                                           int *s_gbase, Record *s_stage, StamperP &stp)
 {
     // s_cnt is all zero on entry (zeroed by the kernel prologue / the previous round's scan).
     // Three barriers per non-empty round (four when it needs a second staging pass), two per empty one:
@@ -271,7 +297,9 @@ __device__ __forceinline__ void emit_round(const uint32_t (&ridx)[ROUND_RECS],
         slot[r] = 0;
         if (valid_mask & (1u << r)) slot[r] = atomicAdd(&s_cnt[bin_of(ridx[r], n_bins, interleaved)], 1);
     }
+    RSDF_PSTAMP(stp, 4);   // slot atomics
     __syncthreads();  // A
+    RSDF_PSTAMP(stp, 5);   // barrier A
     // First wavefront: exclusive scan of the bin counts + queue reservations.  The reservation is a RETURNING global
     // atomic (~1-2 us under load); its result is only needed by the copy-out, so it is parked in a register here and
     // published to s_gbase after this wave has staged its own records: the round trip overlaps barrier B and the staging
@@ -287,7 +315,9 @@ __device__ __forceinline__ void emit_round(const uint32_t (&ridx)[ROUND_RECS],
         }
         if (tid == 63) s_off[MAX_BINS] = incl;
     }
+    RSDF_PSTAMP(stp, 6);   // scan + queue reservation (first wave)
     __syncthreads();  // B
+    RSDF_PSTAMP(stp, 7);   // barrier B
     const int total = s_off[MAX_BINS];
     if (total == 0) return;  // uniform (no reservation was made: every count was zero)
     if (tid < n_bins) s_gbase[tid] = gbase;
@@ -300,7 +330,9 @@ __device__ __forceinline__ void emit_round(const uint32_t (&ridx)[ROUND_RECS],
                 const unsigned pos = (unsigned)(s_off[bin_of(ridx[r], n_bins, interleaved)] + slot[r] - lo);
                 if (pos < (unsigned)n) s_stage[pos] = Record{ridx[r], rval[r].x, rval[r].y};
             }
+        RSDF_PSTAMP(stp, 8);   // staging writes
         __syncthreads();  // C
+        RSDF_PSTAMP(stp, 9);   // barrier C (+ D)
         for (int i = tid; i < n; i += P_THREADS) {
             const Record rec = s_stage[i];
             const int b = bin_of(rec.idx, n_bins, interleaved);
@@ -312,6 +344,7 @@ __device__ __forceinline__ void emit_round(const uint32_t (&ridx)[ROUND_RECS],
                 atomicAdd(dlevel + 2 * (size_t)rec.idx + 1, rec.v1);
             }
         }
+        RSDF_PSTAMP(stp, 10);  // copy-out
     }
 }
 
@@ -351,6 +384,11 @@ fd7_produce_kernel(const float *__restrict__ x7t, const float2 *__restrict__ dpl
     if (s_block >= S) return;   // padding tile of the last group (uniform)
     const int64_t s = s_block + threadIdx.x;
     const bool active = s < S;
+    StamperP stp;
+#ifdef RSDF_STAMPS
+    stp.begin(threadIdx.x == 0 && l == RSDF_STAMP_LEVEL);
+    if (threadIdx.x == 0 && l == RSDF_STAMP_LEVEL) atomicAdd(&g_pstamps[15], 1ull);
+#endif
 
     // ---- phase 1: one thread per sample.  The centre cell's 8 corners collect the centre tap, every tap that stays in
     // the cell, and the shared face of every tap that moved to a face neighbour.  The 4 NEW corners of such a displaced
@@ -416,6 +454,7 @@ fd7_produce_kernel(const float *__restrict__ x7t, const float2 *__restrict__ dpl
             }
         }
     }
+    RSDF_PSTAMP(stp, 0);   // loads + phase-1 weights
     {   // append this thread's displaced taps to the workgroup's work list
         const int cnt = __popc(items & 0x555u);
         int pos = cnt ? atomicAdd(&s_nitems, cnt) : 0;
@@ -425,6 +464,7 @@ fd7_produce_kernel(const float *__restrict__ x7t, const float2 *__restrict__ dpl
                 s_items[pos++] = (unsigned short)(threadIdx.x | (t << 10) | ((items >> (2 * t + 1) & 1u) << 13));
     }
 
+    RSDF_PSTAMP(stp, 1);   // work-list append
     // Cross-sample merge at coarse levels: consecutive samples of a ray (= consecutive lanes) share their centre
     // cell for ~cell/step samples (18 at level 0 of the 32..2048 grid, < 2 from level 6 up).  When a wavefront holds
     // few distinct cells, sum each run of equal cells with a segmented wave scan and let only the run's last lane
@@ -459,10 +499,12 @@ fd7_produce_kernel(const float *__restrict__ x7t, const float2 *__restrict__ dpl
             emit0 = active && (lane == 63 || nx != kx || ny != ky || nz != kz);
         }
     }
+    RSDF_PSTAMP(stp, 2);   // run merge
     uint32_t ridx[ROUND_RECS];
     corner_indices(c0.c[0], c0.c[1], c0.c[2], g, ridx);
+    RSDF_PSTAMP(stp, 3);   // corner indices
     emit_round(ridx, acc, emit0 ? 0xffu : 0u, n_bins, interleaved, cap, queue, qcount, dlevel, s_cnt, s_off,
-               s_gbase, s_stage);   // (its barriers also publish the work list)
+               s_gbase, s_stage, stp);   // (its barriers also publish the work list)
 
     // ---- phase 2: dense over the displaced taps, two per thread and round (4 new corners each)
     const int n_items = s_nitems;
@@ -496,7 +538,8 @@ fd7_produce_kernel(const float *__restrict__ x7t, const float2 *__restrict__ dpl
                 mask |= 0xfu << (4 * j);
             }
         }
-        emit_round(ridx, acc, mask, n_bins, interleaved, cap, queue, qcount, dlevel, s_cnt, s_off, s_gbase, s_stage);
+        RSDF_PSTAMP(stp, 11);  // phase-2 item evaluation
+        emit_round(ridx, acc, mask, n_bins, interleaved, cap, queue, qcount, dlevel, s_cnt, s_off, s_gbase, s_stage, stp);
     }
 }
 
@@ -623,6 +666,18 @@ int64_t scratch_need(int64_t n_rec, int n_cnt)
 }
 
 }  // namespace
+
+#ifdef RSDF_STAMPS
+extern "C" int rsdf_debug_read_pstamps(unsigned long long *out16, int reset)
+{
+    const int rc = (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_pstamps), 16 * sizeof(unsigned long long));
+    if (reset) {
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pstamps), z, sizeof(z));
+    }
+    return rc;
+}
+#endif
 
 extern "C" {
 
