@@ -161,6 +161,67 @@ accumulate_bwd_kernel(const int32_t *__restrict__ packed, const float *__restric
     }
 }
 
+// ---- channel-parallel forms for 4 <= D <= 64 (the 24-channel maps of the split-sum stage) ------------------------------
+// In the kernels above a lane is a sample and walks its D channels: at D = 24 every load / store instruction touches 64
+// rows 96 bytes apart (one 4-byte piece of 64 different lines), 24 times per sample tile.  Here a lane is a (sample slot,
+// channel) pair -- SPW = 64 / D samples per wavefront iteration, channel = lane % D fixed for the lane -- so the values
+// and their gradients move as contiguous runs; the per-sample sum over channels of the backward is a segmented shuffle
+// reduction.  One wavefront per ray as before.
+__global__ void __launch_bounds__(THREADS)
+accumulate_fwd_ch_kernel(const int32_t *__restrict__ packed, const float *__restrict__ weights,
+                         const float *__restrict__ values, int64_t n_rays, int D, float *__restrict__ out)
+{
+    const int64_t r = ray_of_wave();
+    if (r >= n_rays) return;
+    const int base = packed[2 * r], steps = packed[2 * r + 1];
+    const int lane = lane_id();
+    const int spw = 64 / D, q = lane / D, d = lane - q * D;
+    const bool on = q < spw;
+    float acc = 0.0f;
+    for (int j = q; j < steps && on; j += spw) {
+        const int64_t s = base + j;
+        acc = fmaf(weights[s], values[s * D + d], acc);
+    }
+    // sum over the sample slots: lanes d, d + D, d + 2 D, ...
+    for (int o = 1; o < spw; ++o) {
+        const float t = __shfl(acc, d + o * D, 64);
+        if (q == 0) acc += t;
+    }
+    if (lane < D) out[r * D + d] = acc;
+}
+
+// gw_i = sum_d go[r,d] v[i,d];  gv[i,d] = w_i go[r,d]
+__global__ void __launch_bounds__(THREADS)
+accumulate_bwd_ch_kernel(const int32_t *__restrict__ packed, const float *__restrict__ weights,
+                         const float *__restrict__ values, const float *__restrict__ go, int64_t n_rays, int D,
+                         float *__restrict__ gw, float *__restrict__ gv)
+{
+    const int64_t r = ray_of_wave();
+    if (r >= n_rays) return;
+    const int base = packed[2 * r], steps = packed[2 * r + 1];
+    const int lane = lane_id();
+    const int spw = 64 / D, q = lane / D, d = lane - q * D;
+    const bool on = q < spw;
+    const float gd = on ? go[r * D + d] : 0.0f;
+    for (int j0 = 0; j0 < steps; j0 += spw) {      // uniform trip count: the shuffles below need every lane
+        const int j = j0 + q;
+        const bool live = on && j < steps;
+        const int64_t s = base + (live ? j : 0);
+        float p = 0.0f;
+        if (live) {
+            p = gd * values[s * D + d];
+            if (gv) gv[s * D + d] = weights[s] * gd;
+        }
+        if (gw) {
+            for (int o = 1; o < D; o <<= 1) {
+                const float t = __shfl_down(p, o, 64);
+                if (d + o < D) p += t;
+            }
+            if (live && d == 0) gw[s] = p;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -212,7 +273,9 @@ int rsdf_accumulate_fwd(const int32_t *packed_info, const float *weights, const 
     if (n_rays <= 0) return 0;
     const unsigned grid = rsdf_blocks(n_rays * 64, THREADS);
     hipStream_t st = (hipStream_t)stream;
-    if (D <= 1) accumulate_fwd_kernel<1><<<grid, THREADS, 0, st>>>(packed_info, weights, values, n_rays, D, out);
+    if (values != nullptr && D >= 4 && D <= 64)
+        accumulate_fwd_ch_kernel<<<grid, THREADS, 0, st>>>(packed_info, weights, values, n_rays, D, out);
+    else if (D <= 1) accumulate_fwd_kernel<1><<<grid, THREADS, 0, st>>>(packed_info, weights, values, n_rays, D, out);
     else if (D <= 4) accumulate_fwd_kernel<4><<<grid, THREADS, 0, st>>>(packed_info, weights, values, n_rays, D, out);
     else accumulate_fwd_kernel<8><<<grid, THREADS, 0, st>>>(packed_info, weights, values, n_rays, D, out);
     RSDF_RETURN_LAUNCH();
@@ -224,8 +287,12 @@ int rsdf_accumulate_bwd(const int32_t *packed_info, const float *weights, const 
 {
     RSDF_CHECK_ARG(D >= 1, "accumulate_bwd: D must be >= 1");
     if (n_rays <= 0) return 0;
-    accumulate_bwd_kernel<<<rsdf_blocks(n_rays * 64, THREADS), THREADS, 0, (hipStream_t)stream>>>(
-        packed_info, weights, values, grad_out, n_rays, D, grad_weights, grad_values);
+    if (values != nullptr && D >= 4 && D <= 64)
+        accumulate_bwd_ch_kernel<<<rsdf_blocks(n_rays * 64, THREADS), THREADS, 0, (hipStream_t)stream>>>(
+            packed_info, weights, values, grad_out, n_rays, D, grad_weights, grad_values);
+    else
+        accumulate_bwd_kernel<<<rsdf_blocks(n_rays * 64, THREADS), THREADS, 0, (hipStream_t)stream>>>(
+            packed_info, weights, values, grad_out, n_rays, D, grad_weights, grad_values);
     RSDF_RETURN_LAUNCH();
 }
 
