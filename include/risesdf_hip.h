@@ -192,11 +192,14 @@ int rsdf_linear_bwd_weight(const float *dz, int lddz, const float *x, int ldx, i
 /* Both of the above in one pass over the rows, for the 128-wide layers (N == 128, K <= 128:
  * rsdf_linear_bwd_fused_supported): dz = dy * act'(y) stays on the CU, dx (nullable) and dw / db as above.
  * Replaces the dz round trip through HBM of the two-kernel form (models/network_utils.py:109-157 backward;
- * the texture networks of models/texture.py:237-327).  dw (required) and db (nullable) accumulate: zero first. */
+ * the texture networks of models/texture.py:237-327).  dw (required) and db (nullable) accumulate: zero first.
+ * prev_act = RSDF_ACT_RELU (needs dx, k0 == 0): x is the ReLU output of the previous layer of a chain and dx is written as
+ * THAT layer's dz = dx * (x > 0); its backward is then called with act = RSDF_ACT_NONE, y = NULL (nn.Sequential of
+ * Linear + ReLU(inplace), models/network_utils.py:121-126).  Otherwise RSDF_ACT_NONE. */
 int rsdf_linear_bwd_fused_supported(int K, int N);
 int rsdf_linear_bwd_fused(const float *dy, const float *y, int lddy, const float *x, int ldx,
                           const float *w, int64_t n, int K, int N, int act, int k0, int Kout, float *dx,
-                          int lddx, float *dw, float *db, void *stream);
+                          int lddx, int prev_act, float *dw, float *db, void *stream);
 /* Fused SDF network for the finite-difference stencil: [x*xyz_scale+xyz_offset | planes] ->
  * Linear(K0,H) -> Softplus(100) -> Linear(H,H) -> Softplus(100) -> Linear(H,N2), K0 = 3 + 2*n_levels
  * (CompositeEncoding include_xyz + VanillaMLP n_hidden_layers=2, models/network_utils.py:71-157) on

@@ -107,7 +107,10 @@ __device__ __forceinline__ float4 load4(const float *__restrict__ p, bool vec)
 
 // ACT is a template parameter: with a run-time activation id the derivative's switch is re-evaluated for each of the
 // 16 staged values (the first build spent 620 scalar and 980 vector instructions per tile on it)
-template <bool HAS_DX, int ACT>
+// PREV_RELU: the layer's input x is the ReLU output of the previous layer of the chain; dx is then written as that layer's
+// dz = dx * (x > 0), the mask read from the high bf16 part of the X image (same sign and zero as x): the previous layer's
+// backward needs no activation pass and does not read its y at all.
+template <bool HAS_DX, int ACT, bool PREV_RELU>
 __global__ void __launch_bounds__(LB_THREADS, 2)
 layer_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ y, int lddy, const float *__restrict__ x,
                  int ldx, const float *__restrict__ w, int64_t n, int K, int k0, int Kout,
@@ -208,6 +211,17 @@ layer_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ y, int 
 #pragma unroll
             for (int ns = 0; ns < 8; ++ns) a = mma6r(wt[HAS_DX ? ns : 0], row_frag64(dzi, ns, 32 * rh + c, hf), a);
             const int64_t row = row0 + 32 * rh + c;
+            if (PREV_RELU) {   // (k0 == 0: window column = input column)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int col = 32 * jt + 8 * g + 4 * hf;
+                    const uint2 hx = *reinterpret_cast<const uint2 *>(xi + (col >> 3) * CS64 + (32 * rh + c) * 16 + (col & 7) * 2);
+                    if ((short)(hx.x & 0xffffu) <= 0) a[4 * g] = 0.0f;
+                    if ((short)(hx.x >> 16) <= 0) a[4 * g + 1] = 0.0f;
+                    if ((short)(hx.y & 0xffffu) <= 0) a[4 * g + 2] = 0.0f;
+                    if ((short)(hx.y >> 16) <= 0) a[4 * g + 3] = 0.0f;
+                }
+            }
             if (row < n) {
                 float *xr = dx + row * (int64_t)lddx;
 #pragma unroll
@@ -257,32 +271,35 @@ layer_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ y, int 
     }
 }
 
-template <bool HAS_DX, int ACT>
+template <bool HAS_DX, int ACT, bool PREV_RELU>
 int launch(unsigned grid, size_t lds, hipStream_t st, const float *dy, const float *y, int lddy, const float *x, int ldx,
            const float *w, int64_t n, int K, int k0, int Kout, float *dx, int lddx, float *dw, float *db)
 {
     static bool lds_set = false;   // per instantiation; one device per process
     if (!lds_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(layer_bwd_kernel<HAS_DX, ACT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(layer_bwd_kernel<HAS_DX, ACT, PREV_RELU>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { rsdf_set_error(hipGetErrorString(e)); return (int)e; }
         lds_set = true;
     }
-    layer_bwd_kernel<HAS_DX, ACT><<<grid, LB_THREADS, lds, st>>>(dy, y, lddy, x, ldx, w, n, K, k0, Kout, dx, lddx, dw, db);
+    layer_bwd_kernel<HAS_DX, ACT, PREV_RELU><<<grid, LB_THREADS, lds, st>>>(dy, y, lddy, x, ldx, w, n, K, k0, Kout, dx, lddx,
+                                                                           dw, db);
     return 0;
 }
 
-template <bool HAS_DX>
+template <bool HAS_DX, bool PREV_RELU>
 int launch_act(int act, unsigned grid, size_t lds, hipStream_t st, const float *dy, const float *y, int lddy, const float *x,
                int ldx, const float *w, int64_t n, int K, int k0, int Kout, float *dx, int lddx, float *dw, float *db)
 {
     switch (act) {
-    case RSDF_ACT_NONE: return launch<HAS_DX, RSDF_ACT_NONE>(grid, lds, st, dy, y, lddy, x, ldx, w, n, K, k0, Kout, dx, lddx, dw, db);
-    case RSDF_ACT_RELU: return launch<HAS_DX, RSDF_ACT_RELU>(grid, lds, st, dy, y, lddy, x, ldx, w, n, K, k0, Kout, dx, lddx, dw, db);
+    case RSDF_ACT_NONE:
+        return launch<HAS_DX, RSDF_ACT_NONE, PREV_RELU>(grid, lds, st, dy, y, lddy, x, ldx, w, n, K, k0, Kout, dx, lddx, dw, db);
+    case RSDF_ACT_RELU:
+        return launch<HAS_DX, RSDF_ACT_RELU, PREV_RELU>(grid, lds, st, dy, y, lddy, x, ldx, w, n, K, k0, Kout, dx, lddx, dw, db);
     case RSDF_ACT_SOFTPLUS100:
-        return launch<HAS_DX, RSDF_ACT_SOFTPLUS100>(grid, lds, st, dy, y, lddy, x, ldx, w, n, K, k0, Kout, dx, lddx, dw, db);
+        return launch<HAS_DX, RSDF_ACT_SOFTPLUS100, PREV_RELU>(grid, lds, st, dy, y, lddy, x, ldx, w, n, K, k0, Kout, dx, lddx, dw, db);
     case RSDF_ACT_SIGMOID:
-        return launch<HAS_DX, RSDF_ACT_SIGMOID>(grid, lds, st, dy, y, lddy, x, ldx, w, n, K, k0, Kout, dx, lddx, dw, db);
+        return launch<HAS_DX, RSDF_ACT_SIGMOID, PREV_RELU>(grid, lds, st, dy, y, lddy, x, ldx, w, n, K, k0, Kout, dx, lddx, dw, db);
     default: rsdf_set_error("linear_bwd_fused: unknown activation"); return 1;
     }
 }
@@ -294,9 +311,11 @@ extern "C" {
 int rsdf_linear_bwd_fused_supported(int K, int N) { return N == LB_N && K >= 1 && K <= 128; }
 
 int rsdf_linear_bwd_fused(const float *dy, const float *y, int lddy, const float *x, int ldx, const float *w,
-                          int64_t n, int K, int N, int act, int k0, int Kout, float *dx, int lddx, float *dw,
-                          float *db, void *stream)
+                          int64_t n, int K, int N, int act, int k0, int Kout, float *dx, int lddx, int prev_act,
+                          float *dw, float *db, void *stream)
 {
+    RSDF_CHECK_ARG(prev_act == RSDF_ACT_NONE || (prev_act == RSDF_ACT_RELU && dx != nullptr && k0 == 0),
+                   "linear_bwd_fused: prev_act must be NONE, or RELU with dx and k0 == 0");
     RSDF_CHECK_ARG(rsdf_linear_bwd_fused_supported(K, N), "linear_bwd_fused: needs N == 128 and K in [1,128]");
     RSDF_CHECK_ARG(lddy >= N && ldx >= K, "linear_bwd_fused: row stride smaller than the row");
     if (n <= 0) return 0;   // an empty batch carries no pointers
@@ -310,8 +329,10 @@ int rsdf_linear_bwd_fused(const float *dy, const float *y, int lddy, const float
     const int64_t tiles = (n + LB_ROWS - 1) / LB_ROWS;
     const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);   // one workgroup per CU
     hipStream_t st = (hipStream_t)stream;
-    const int rc = dx ? launch_act<true>(act, grid, lds, st, dy, y, lddy, x, ldx, w, n, K, k0, Kout, dx, lddx, dw, db)
-                      : launch_act<false>(act, grid, lds, st, dy, y, lddy, x, ldx, w, n, K, 0, 0, nullptr, 0, dw, db);
+    const int rc = !dx ? launch_act<false, false>(act, grid, lds, st, dy, y, lddy, x, ldx, w, n, K, 0, 0, nullptr, 0, dw, db)
+                   : prev_act == RSDF_ACT_RELU
+                       ? launch_act<true, true>(act, grid, lds, st, dy, y, lddy, x, ldx, w, n, K, k0, Kout, dx, lddx, dw, db)
+                       : launch_act<true, false>(act, grid, lds, st, dy, y, lddy, x, ldx, w, n, K, k0, Kout, dx, lddx, dw, db);
     if (rc) return rc;
     RSDF_RETURN_LAUNCH();
 }

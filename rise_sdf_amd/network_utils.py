@@ -169,13 +169,9 @@ class VanillaMLP(nn.Module):
     def forward(self, x, out_act=None):
         """``out_act`` overrides the configured output activation (lets a caller fuse e.g. the texture
         networks' color_activation into the last layer's kernel)."""
-        h = x.float()
         wb = self.effective_weights()
-        for i, (w, b) in enumerate(wb):
-            last = i == len(wb) - 1
-            h = ops.linear(h, w, b, act=(out_act or self.output_act) if last else self.hidden_act,
-                           dx_cols=self.input_grad_cols if i == 0 else None)
-        return h
+        acts = [self.hidden_act] * (len(wb) - 1) + [out_act or self.output_act]
+        return ops.mlp_chain(x.float(), wb, acts, dx_cols=self.input_grad_cols)
 
 
 def get_mlp(n_input_dims, n_output_dims, config):

@@ -443,7 +443,7 @@ class _Linear(torch.autograd.Function):
         if dw is not None and lib().rsdf_linear_bwd_fused_supported(K, N) and os.environ.get("RSDF_LAYER_BWD") != "split":
             # 128-wide layers: one pass, dz never leaves the CU (mlp_layer_bwd.hip)
             check(lib().rsdf_linear_bwd_fused(ptr(gy), ptr(y), N, ptr(xf), K, ptr(wf), n, K, N, ctx.act, k0, kout,
-                                              dx_win, K, ptr(dw), ptr(db), st), "linear_bwd_fused")
+                                              dx_win, K, L.ACT_IDS["none"], ptr(dw), ptr(db), st), "linear_bwd_fused")
             return dx, dw, db, None, None
         dz = torch.empty_like(gy)
         check(lib().rsdf_linear_bwd_input(ptr(gy), ptr(y), N, ptr(wf), n, K, N, ctx.act, k0, kout,
@@ -456,6 +456,92 @@ class _Linear(torch.autograd.Function):
 
 def linear(x, w, b=None, act="none", dx_cols=None):
     return _Linear.apply(x, w, b, L.ACT_IDS[act] if not isinstance(act, int) else act, dx_cols)
+
+
+class _MLPChain(torch.autograd.Function):
+    """A whole VanillaMLP (models/network_utils.py:109-157: Linear -> act -> ... -> Linear [-> output act]) as ONE autograd
+    node.  Forward: one rsdf_linear_fwd per layer.  Backward: the 128-wide layers run the one-pass kernel
+    (rsdf_linear_bwd_fused), and when the layer below is Linear + ReLU the kernel writes THAT layer's dz = dx * (x > 0)
+    straight away (x, the ReLU output, is on the CU already): the layer below then needs neither its activation pass nor
+    its own output -- 1.5 instead of 2 KB per row and layer -- and autograd sees one node instead of one per layer."""
+
+    @staticmethod
+    def forward(ctx, x, dx_cols, acts, *wb):
+        xf = _f32c(x)
+        ws = [_f32c(t) for t in wb[0::2]]
+        bs = [None if t is None else _f32c(t) for t in wb[1::2]]
+        require_device(xf, *ws)
+        n = xf.shape[0]
+        st = stream_ptr()
+        h, ys = xf, []
+        for w, b, act in zip(ws, bs, acts):
+            N, K = w.shape
+            assert h.shape[1] == K, "layer input width"
+            y = torch.empty(n, N, dtype=torch.float32, device=xf.device)
+            check(lib().rsdf_linear_fwd(ptr(h), K, ptr(w), ptr(b), n, K, N, act, ptr(y), N, st), "linear_fwd")
+            ys.append(y)
+            h = y
+        ctx.save_for_backward(xf, *ws, *ys)
+        ctx.acts, ctx.dx_cols, ctx.n_layers = tuple(acts), dx_cols, len(ws)
+        ctx.has_bias = [b is not None for b in bs]
+        return ys[-1]
+
+    @staticmethod
+    def backward(ctx, gy):
+        nl = ctx.n_layers
+        saved = ctx.saved_tensors
+        xf, ws, ys = saved[0], saved[1:1 + nl], saved[1 + nl:]
+        n = xf.shape[0]
+        st = stream_ptr()
+        relu, none = L.ACT_IDS["relu"], L.ACT_IDS["none"]
+        split = os.environ.get("RSDF_LAYER_BWD") == "split"
+        g, g_is_dz = _f32c(gy), False
+        grads = [None] * (2 * nl)
+        dx_in = None
+        for i in range(nl - 1, -1, -1):
+            w, y = ws[i], ys[i]
+            xin = ys[i - 1] if i > 0 else xf
+            N, K = w.shape
+            act = none if g_is_dz else ctx.acts[i]
+            yarg = None if g_is_dz else y
+            need_dx = i > 0 or ctx.needs_input_grad[0]
+            k0, kout = (0, K) if (i > 0 or ctx.dx_cols is None) else ctx.dx_cols
+            dx = dx_win = None
+            if need_dx:
+                dx = torch.empty(n, K, dtype=torch.float32, device=xf.device)
+                if k0 > 0:
+                    dx[:, :k0].zero_()
+                if k0 + kout < K:
+                    dx[:, k0 + kout:].zero_()
+                dx_win = ctypes.c_void_p(dx.data_ptr() + 4 * k0)
+            buf = torch.zeros(N * K + (N if ctx.has_bias[i] else 0), dtype=torch.float32, device=xf.device)
+            dw = buf[:N * K].view(N, K)
+            db = buf[N * K:] if ctx.has_bias[i] else None
+            fused = not split and bool(lib().rsdf_linear_bwd_fused_supported(K, N))
+            prev_relu = fused and i > 0 and ctx.acts[i - 1] == relu
+            if fused:
+                check(lib().rsdf_linear_bwd_fused(ptr(g), ptr(yarg), N, ptr(xin), K, ptr(w), n, K, N, act, k0, kout,
+                                                  dx_win, K, relu if prev_relu else none, ptr(dw), ptr(db), st),
+                      "linear_bwd_fused")
+            else:
+                dz = torch.empty_like(g)
+                check(lib().rsdf_linear_bwd_input(ptr(g), ptr(yarg), N, ptr(w), n, K, N, act, k0, kout, ptr(dz), dx_win,
+                                                  K, st), "linear_bwd_input")
+                check(lib().rsdf_linear_bwd_weight(ptr(dz), N, ptr(xin), K, n, K, N, ptr(dw), ptr(db), st),
+                      "linear_bwd_weight")
+            grads[2 * i], grads[2 * i + 1] = dw, db
+            g, g_is_dz = dx, prev_relu
+            if i == 0:
+                dx_in = dx
+        return (dx_in, None, None, *grads)
+
+
+def mlp_chain(x, layers, acts, dx_cols=None):
+    """``layers`` = [(W [out,in], b [out] or None)], ``acts`` = activation name per layer; see _MLPChain."""
+    flat = []
+    for w, b in layers:
+        flat += [w, b]
+    return _MLPChain.apply(x, dx_cols, tuple(L.ACT_IDS[a] if not isinstance(a, int) else a for a in acts), *flat)
 
 
 class _WeightNorm(torch.autograd.Function):

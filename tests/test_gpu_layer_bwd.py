@@ -96,4 +96,65 @@ def test_layer_bwd_fused_rejects_other_widths():
     assert lib.rsdf_linear_bwd_fused_supported(84, 128) == 1
     assert lib.rsdf_linear_bwd_fused_supported(128, 64) == 0
     p = ctypes.c_void_p(16)
-    assert lib.rsdf_linear_bwd_fused(p, p, 64, p, 64, p, 10, 64, 64, 0, 0, 0, None, 0, p, None, None) != 0
+    assert lib.rsdf_linear_bwd_fused(p, p, 64, p, 64, p, 10, 64, 64, 0, 0, 0, None, 0, 0, p, None, None) != 0
+
+
+def _chain_ref(x, layers, acts, gy):
+    x64 = x.double().detach().requires_grad_(True)
+    ps = [(w.double().detach().requires_grad_(True), b.double().detach().requires_grad_(True)) for w, b in layers]
+    h = x64
+    for (w, b), a in zip(ps, acts):
+        z = h @ w.t() + b
+        h = {"relu": torch.relu, "sigmoid": torch.sigmoid, "none": lambda t: t,
+             "softplus100": lambda t: torch.nn.functional.softplus(t, beta=100, threshold=20)}[a](z)
+    h.backward(gy.double())
+    return h.detach(), x64.grad, [(w.grad, b.grad) for w, b in ps]
+
+
+@pytest.mark.parametrize("hidden_act,out_act", [("relu", "sigmoid"), ("relu", "none"), ("softplus100", "none")])
+@pytest.mark.parametrize("dims", [(84, 128, 128, 128, 128, 3), (73, 128, 128, 1), (128, 128, 6), (35, 64, 64, 13)])
+@pytest.mark.parametrize("n", [257, 5000])
+def test_mlp_chain_matches_fp64(hidden_act, out_act, dims, n, monkeypatch):
+    """The whole VanillaMLP as one autograd node (ops.mlp_chain): 128-wide ReLU layers hand dz to the layer below from
+    inside the kernel; other widths / activations take the two-kernel layers.  All gradients vs fp64 autograd."""
+    from rise_sdf_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(n + len(dims))
+    x = torch.randn(n, dims[0], generator=g).to(dev)
+    layers = [((torch.randn(o, i, generator=g) * (2.0 / i) ** 0.5).to(dev), (0.1 * torch.randn(o, generator=g)).to(dev))
+              for i, o in zip(dims[:-1], dims[1:])]
+    acts = [hidden_act] * (len(layers) - 1) + [out_act]
+    gy = torch.randn(n, dims[-1], generator=g).to(dev)
+    y_ref, dx_ref, gref = _chain_ref(x, layers, acts, gy)
+    for mode in ("fused", "split"):
+        monkeypatch.setenv("RSDF_LAYER_BWD", mode)
+        xr = x.clone().requires_grad_(True)
+        ps = [(w.clone().requires_grad_(True), b.clone().requires_grad_(True)) for w, b in layers]
+        y = ops.mlp_chain(xr, ps, acts)
+        assert _rel(y, y_ref) < 5e-6
+        y.backward(gy)
+        assert _rel(xr.grad, dx_ref) < 1e-5, (mode, "dx", _rel(xr.grad, dx_ref))
+        for (w, b), (gw, gb) in zip(ps, gref):
+            assert _rel(w.grad, gw) < 1e-5, (mode, "dw", tuple(w.shape), _rel(w.grad, gw))
+            assert _rel(b.grad, gb) < 1e-5, (mode, "db", tuple(w.shape), _rel(b.grad, gb))
+
+
+def test_mlp_chain_input_window_and_frozen_input():
+    from rise_sdf_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(3)
+    n, dims = 1500, (35, 128, 128, 13)
+    x = torch.randn(n, dims[0], generator=g).to(dev)
+    layers = [((torch.randn(o, i, generator=g) * (2.0 / i) ** 0.5).to(dev), torch.zeros(o).to(dev))
+              for i, o in zip(dims[:-1], dims[1:])]
+    acts = ["relu", "relu", "none"]
+    gy = torch.randn(n, dims[-1], generator=g).to(dev)
+    _, dx_ref, gref = _chain_ref(x, layers, acts, gy)
+    xr = x.clone().requires_grad_(True)
+    ps = [(w.clone().requires_grad_(True), b.clone().requires_grad_(True)) for w, b in layers]
+    ops.mlp_chain(xr, ps, acts, dx_cols=(3, 32)).backward(gy)
+    assert torch.all(xr.grad[:, :3] == 0) and _rel(xr.grad[:, 3:], dx_ref[:, 3:]) < 1e-5
+    ps2 = [(w.clone().requires_grad_(True), b.clone().requires_grad_(True)) for w, b in layers]
+    ops.mlp_chain(x, ps2, acts).backward(gy)       # the input needs no gradient: the first layer runs the dx-free kernel
+    for (w, b), (gw, gb) in zip(ps2, gref):
+        assert _rel(w.grad, gw) < 1e-5 and _rel(b.grad, gb) < 1e-5
