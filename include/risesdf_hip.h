@@ -200,6 +200,13 @@ int rsdf_linear_bwd_fused_supported(int K, int N);
 int rsdf_linear_bwd_fused(const float *dy, const float *y, int lddy, const float *x, int ldx,
                           const float *w, int64_t n, int K, int N, int act, int k0, int Kout, float *dx,
                           int lddx, int prev_act, float *dw, float *db, void *stream);
+/* The same for the hidden layer right below a network's narrow output layer (N2 <= 4 columns, weights w2 [N2][128], act =
+ * ReLU): its input gradient dy = dz_out @ w2 is formed on the fly from the output layer's dz_out [n][N2] (computed by the
+ * caller, e.g. rsdf_linear_bwd_input with dx = NULL), so that layer needs no input-gradient kernel at all. */
+int rsdf_linear_bwd_fused_tail(const float *dz_out, int N2, const float *w2, const float *y, int lddy,
+                               const float *x, int ldx, const float *w, int64_t n, int K, int N, int act,
+                               int k0, int Kout, float *dx, int lddx, int prev_act, float *dw, float *db,
+                               void *stream);
 /* Fused SDF network for the finite-difference stencil: [x*xyz_scale+xyz_offset | planes] ->
  * Linear(K0,H) -> Softplus(100) -> Linear(H,H) -> Softplus(100) -> Linear(H,N2), K0 = 3 + 2*n_levels
  * (CompositeEncoding include_xyz + VanillaMLP n_hidden_layers=2, models/network_utils.py:71-157) on

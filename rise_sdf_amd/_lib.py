@@ -76,6 +76,7 @@ _SIGNATURES = {
     "rsdf_linear_bwd_weight": [_P, _I, _P, _I, _L, _I, _I, _P, _P, _P],
     "rsdf_linear_bwd_fused_supported": [_I, _I],
     "rsdf_linear_bwd_fused": [_P, _P, _I, _P, _I, _P, _L, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P],
+    "rsdf_linear_bwd_fused_tail": [_P, _I, _P, _P, _I, _P, _I, _P, _L, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P],
     "rsdf_sdfmlp_fd7_supported": [_I, _I, _I],
     "rsdf_sdfmlp_fd7_fwd": [_P, _P, _I, _I, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P],
     "rsdf_sdfmlp_fd7_bwd": [_P, _P, _I, _I, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P,

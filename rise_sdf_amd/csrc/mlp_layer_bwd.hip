@@ -110,14 +110,26 @@ __device__ __forceinline__ float4 load4(const float *__restrict__ p, bool vec)
 // PREV_RELU: the layer's input x is the ReLU output of the previous layer of the chain; dx is then written as that layer's
 // dz = dx * (x > 0), the mask read from the high bf16 part of the X image (same sign and zero as x): the previous layer's
 // backward needs no activation pass and does not read its y at all.
-template <bool HAS_DX, int ACT, bool PREV_RELU>
+// TAIL: the layer above is the network's narrow output layer (N2 <= 4 columns, weights w2 [N2][128]); instead of reading its
+// input gradient dy [n][128] this kernel forms it while staging, dy[row][col] = sum_q dzo[row][q] w2[q][col], from that
+// layer's dz (dzo [n][N2], 4-16 bytes per row): the output layer's input-gradient kernel and 512 bytes per row go away.
+struct TailArgs {
+    const float *dzo, *w2;
+    int N2;
+};
+template <bool HAS_DX, int ACT, bool PREV_RELU, bool TAIL>
 __global__ void __launch_bounds__(LB_THREADS, 2)
 layer_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ y, int lddy, const float *__restrict__ x,
-                 int ldx, const float *__restrict__ w, int64_t n, int K, int k0, int Kout,
+                 int ldx, const float *__restrict__ w, int64_t n, int K, int k0, int Kout, const TailArgs tail,
                  float *__restrict__ dx, int lddx, float *__restrict__ dw, float *__restrict__ db)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     unsigned char *dzi = smem_b, *xi = smem_b + IMG_BYTES;
+    float *w2s = reinterpret_cast<float *>(smem_b + 2 * IMG_BYTES);   // TAIL: [4][128]
+    if (TAIL) {
+        for (int e = threadIdx.x; e < 4 * LB_N; e += LB_THREADS) w2s[e] = e < tail.N2 * LB_N ? tail.w2[e] : 0.0f;
+        __syncthreads();   // once, before any prefetch is in flight
+    }
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63, c = lane & 31, hf = lane >> 5;
     const int KT = (K + 31) >> 5;
 
@@ -157,7 +169,12 @@ layer_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ y, int 
         for (int i = 0; i < PASSES; ++i) {
             const int64_t row = tile * LB_ROWS + srow + 16 * i;
             const int64_t rc = row <= last ? row : last;
-            pdy[i] = load4(dy + rc * lddy + col4, vz);
+            if (TAIL) {
+                const float *p = tail.dzo + rc * tail.N2;
+                pdy[i] = make_float4(p[0], tail.N2 > 1 ? p[1] : 0.f, tail.N2 > 2 ? p[2] : 0.f, tail.N2 > 3 ? p[3] : 0.f);
+            } else {
+                pdy[i] = load4(dy + rc * lddy + col4, vz);
+            }
             if (ACT != RSDF_ACT_NONE) py[i] = load4(y + rc * lddy + col4, vz);
             if (K >= 4) px[i] = load4(x + rc * ldx + xcol, vxl);
             else px[i] = make_float4(x[rc * ldx], K > 1 ? x[rc * ldx + 1] : 0.f, K > 2 ? x[rc * ldx + 2] : 0.f, 0.f);
@@ -175,6 +192,16 @@ layer_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ y, int 
             const int row = srow + 16 * i;
             const bool ok = row0 + row < n;
             float4 g = pdy[i];
+            if (TAIL) {
+                const float4 d = pdy[i];
+                const float4 a0 = *reinterpret_cast<const float4 *>(w2s + col4), a1 = *reinterpret_cast<const float4 *>(w2s + LB_N + col4);
+                const float4 a2 = *reinterpret_cast<const float4 *>(w2s + 2 * LB_N + col4),
+                             a3 = *reinterpret_cast<const float4 *>(w2s + 3 * LB_N + col4);
+                g.x = fmaf(d.w, a3.x, fmaf(d.z, a2.x, fmaf(d.y, a1.x, d.x * a0.x)));
+                g.y = fmaf(d.w, a3.y, fmaf(d.z, a2.y, fmaf(d.y, a1.y, d.x * a0.y)));
+                g.z = fmaf(d.w, a3.z, fmaf(d.z, a2.z, fmaf(d.y, a1.z, d.x * a0.z)));
+                g.w = fmaf(d.w, a3.w, fmaf(d.z, a2.w, fmaf(d.y, a1.w, d.x * a0.w)));
+            }
             if (ACT != RSDF_ACT_NONE) {
                 g.x *= act_bwd_from_y(py[i].x, ACT);
                 g.y *= act_bwd_from_y(py[i].y, ACT);
@@ -271,37 +298,63 @@ layer_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ y, int 
     }
 }
 
-template <bool HAS_DX, int ACT, bool PREV_RELU>
-int launch(unsigned grid, size_t lds, hipStream_t st, const float *dy, const float *y, int lddy, const float *x, int ldx,
-           const float *w, int64_t n, int K, int k0, int Kout, float *dx, int lddx, float *dw, float *db)
+struct LaunchArgs {
+    unsigned grid;
+    size_t lds;
+    hipStream_t st;
+    const float *dy, *y;
+    int lddy;
+    const float *x;
+    int ldx;
+    const float *w;
+    int64_t n;
+    int K, k0, Kout;
+    TailArgs tail;
+    float *dx;
+    int lddx;
+    float *dw, *db;
+};
+
+template <bool HAS_DX, int ACT, bool PREV_RELU, bool TAIL>
+int launch(const LaunchArgs &a)
 {
     static bool lds_set = false;   // per instantiation; one device per process
     if (!lds_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(layer_bwd_kernel<HAS_DX, ACT, PREV_RELU>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(layer_bwd_kernel<HAS_DX, ACT, PREV_RELU, TAIL>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)a.lds);
         if (e != hipSuccess) { rsdf_set_error(hipGetErrorString(e)); return (int)e; }
         lds_set = true;
     }
-    layer_bwd_kernel<HAS_DX, ACT, PREV_RELU><<<grid, LB_THREADS, lds, st>>>(dy, y, lddy, x, ldx, w, n, K, k0, Kout, dx, lddx,
-                                                                           dw, db);
+    layer_bwd_kernel<HAS_DX, ACT, PREV_RELU, TAIL><<<a.grid, LB_THREADS, a.lds, a.st>>>(
+        a.dy, a.y, a.lddy, a.x, a.ldx, a.w, a.n, a.K, a.k0, a.Kout, a.tail, a.dx, a.lddx, a.dw, a.db);
     return 0;
 }
 
 template <bool HAS_DX, bool PREV_RELU>
-int launch_act(int act, unsigned grid, size_t lds, hipStream_t st, const float *dy, const float *y, int lddy, const float *x,
-               int ldx, const float *w, int64_t n, int K, int k0, int Kout, float *dx, int lddx, float *dw, float *db)
+int launch_act(int act, const LaunchArgs &a)
 {
     switch (act) {
-    case RSDF_ACT_NONE:
-        return launch<HAS_DX, RSDF_ACT_NONE, PREV_RELU>(grid, lds, st, dy, y, lddy, x, ldx, w, n, K, k0, Kout, dx, lddx, dw, db);
-    case RSDF_ACT_RELU:
-        return launch<HAS_DX, RSDF_ACT_RELU, PREV_RELU>(grid, lds, st, dy, y, lddy, x, ldx, w, n, K, k0, Kout, dx, lddx, dw, db);
-    case RSDF_ACT_SOFTPLUS100:
-        return launch<HAS_DX, RSDF_ACT_SOFTPLUS100, PREV_RELU>(grid, lds, st, dy, y, lddy, x, ldx, w, n, K, k0, Kout, dx, lddx, dw, db);
-    case RSDF_ACT_SIGMOID:
-        return launch<HAS_DX, RSDF_ACT_SIGMOID, PREV_RELU>(grid, lds, st, dy, y, lddy, x, ldx, w, n, K, k0, Kout, dx, lddx, dw, db);
+    case RSDF_ACT_NONE: return launch<HAS_DX, RSDF_ACT_NONE, PREV_RELU, false>(a);
+    case RSDF_ACT_RELU: return launch<HAS_DX, RSDF_ACT_RELU, PREV_RELU, false>(a);
+    case RSDF_ACT_SOFTPLUS100: return launch<HAS_DX, RSDF_ACT_SOFTPLUS100, PREV_RELU, false>(a);
+    case RSDF_ACT_SIGMOID: return launch<HAS_DX, RSDF_ACT_SIGMOID, PREV_RELU, false>(a);
     default: rsdf_set_error("linear_bwd_fused: unknown activation"); return 1;
     }
+}
+
+int check_common(const float *y, int lddy, const float *x, int ldx, int K, int N, int act, int k0, int Kout, const float *dx,
+                 int lddx, int prev_act, const float *dw)
+{
+    RSDF_CHECK_ARG(N == LB_N && K >= 1 && K <= 128, "linear_bwd_fused: needs N == 128 and K in [1,128]");
+    RSDF_CHECK_ARG(lddy >= N && ldx >= K, "linear_bwd_fused: row stride smaller than the row");
+    RSDF_CHECK_ARG(prev_act == RSDF_ACT_NONE || (prev_act == RSDF_ACT_RELU && dx != nullptr && k0 == 0),
+                   "linear_bwd_fused: prev_act must be NONE, or RELU with dx and k0 == 0");
+    RSDF_CHECK_ARG(dw != nullptr, "linear_bwd_fused: dw is NULL");
+    if (dx) {
+        RSDF_CHECK_ARG(k0 >= 0 && Kout >= 1 && k0 + Kout <= K, "linear_bwd_fused: bad column window");
+        RSDF_CHECK_ARG(lddx >= Kout, "linear_bwd_fused: lddx < Kout");
+    }
+    return 0;
 }
 
 }  // namespace
@@ -314,25 +367,31 @@ int rsdf_linear_bwd_fused(const float *dy, const float *y, int lddy, const float
                           int64_t n, int K, int N, int act, int k0, int Kout, float *dx, int lddx, int prev_act,
                           float *dw, float *db, void *stream)
 {
-    RSDF_CHECK_ARG(prev_act == RSDF_ACT_NONE || (prev_act == RSDF_ACT_RELU && dx != nullptr && k0 == 0),
-                   "linear_bwd_fused: prev_act must be NONE, or RELU with dx and k0 == 0");
-    RSDF_CHECK_ARG(rsdf_linear_bwd_fused_supported(K, N), "linear_bwd_fused: needs N == 128 and K in [1,128]");
-    RSDF_CHECK_ARG(lddy >= N && ldx >= K, "linear_bwd_fused: row stride smaller than the row");
+    if (int rc = check_common(y, lddy, x, ldx, K, N, act, k0, Kout, dx, lddx, prev_act, dw)) return rc;
     if (n <= 0) return 0;   // an empty batch carries no pointers
     RSDF_CHECK_ARG(act == RSDF_ACT_NONE || y != nullptr, "linear_bwd_fused: activation needs y");
-    RSDF_CHECK_ARG(dw != nullptr, "linear_bwd_fused: dw is NULL");
-    if (dx) {
-        RSDF_CHECK_ARG(k0 >= 0 && Kout >= 1 && k0 + Kout <= K, "linear_bwd_fused: bad column window");
-        RSDF_CHECK_ARG(lddx >= Kout, "linear_bwd_fused: lddx < Kout");
-    }
-    const size_t lds = 2 * (size_t)IMG_BYTES;
     const int64_t tiles = (n + LB_ROWS - 1) / LB_ROWS;
-    const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);   // one workgroup per CU
-    hipStream_t st = (hipStream_t)stream;
-    const int rc = !dx ? launch_act<false, false>(act, grid, lds, st, dy, y, lddy, x, ldx, w, n, K, 0, 0, nullptr, 0, dw, db)
-                   : prev_act == RSDF_ACT_RELU
-                       ? launch_act<true, true>(act, grid, lds, st, dy, y, lddy, x, ldx, w, n, K, k0, Kout, dx, lddx, dw, db)
-                       : launch_act<true, false>(act, grid, lds, st, dy, y, lddy, x, ldx, w, n, K, k0, Kout, dx, lddx, dw, db);
+    LaunchArgs a{(unsigned)(tiles < 256 ? tiles : 256), 2 * (size_t)IMG_BYTES, (hipStream_t)stream, dy, y, lddy, x, ldx, w, n, K,
+                 dx ? k0 : 0, dx ? Kout : 0, TailArgs{nullptr, nullptr, 0}, dx, dx ? lddx : 0, dw, db};
+    const int rc = !dx ? launch_act<false, false>(act, a)
+                   : prev_act == RSDF_ACT_RELU ? launch_act<true, true>(act, a) : launch_act<true, false>(act, a);
+    if (rc) return rc;
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_linear_bwd_fused_tail(const float *dz_out, int N2, const float *w2, const float *y, int lddy, const float *x,
+                               int ldx, const float *w, int64_t n, int K, int N, int act, int k0, int Kout, float *dx,
+                               int lddx, int prev_act, float *dw, float *db, void *stream)
+{
+    if (int rc = check_common(y, lddy, x, ldx, K, N, act, k0, Kout, dx, lddx, prev_act, dw)) return rc;
+    RSDF_CHECK_ARG(N2 >= 1 && N2 <= 4, "linear_bwd_fused_tail: the output layer must have 1..4 columns");
+    RSDF_CHECK_ARG(act == RSDF_ACT_RELU && dx != nullptr, "linear_bwd_fused_tail: built for ReLU layers with an input gradient");
+    if (n <= 0) return 0;
+    RSDF_CHECK_ARG(dz_out != nullptr && w2 != nullptr && y != nullptr, "linear_bwd_fused_tail: NULL argument");
+    const int64_t tiles = (n + LB_ROWS - 1) / LB_ROWS;
+    LaunchArgs a{(unsigned)(tiles < 256 ? tiles : 256), 2 * (size_t)IMG_BYTES + 4 * LB_N * sizeof(float), (hipStream_t)stream,
+                 nullptr, y, lddy, x, ldx, w, n, K, k0, Kout, TailArgs{dz_out, w2, N2}, dx, lddx, dw, db};
+    const int rc = prev_act == RSDF_ACT_RELU ? launch<true, RSDF_ACT_RELU, true, true>(a) : launch<true, RSDF_ACT_RELU, false, true>(a);
     if (rc) return rc;
     RSDF_RETURN_LAUNCH();
 }

@@ -498,7 +498,22 @@ class _MLPChain(torch.autograd.Function):
         g, g_is_dz = _f32c(gy), False
         grads = [None] * (2 * nl)
         dx_in = None
-        for i in range(nl - 1, -1, -1):
+        top, tail = nl - 1, None
+        # narrow output layer (<= 4 columns) on top of a 128-wide ReLU layer: only its dz and its weight gradient are
+        # computed here; the layer below forms its own input gradient from that dz (rsdf_linear_bwd_fused_tail)
+        if (not split and nl >= 2 and ws[-1].shape[0] <= 4 and ws[-1].shape[1] == 128 and ctx.acts[nl - 2] == relu
+                and bool(lib().rsdf_linear_bwd_fused_supported(ws[-2].shape[1], ws[-2].shape[0]))):
+            w, y, xin = ws[-1], ys[-1], ys[-2]
+            N, K = w.shape
+            dzo = torch.empty_like(g)
+            check(lib().rsdf_linear_bwd_input(ptr(g), ptr(y), N, ptr(w), n, K, N, ctx.acts[-1], 0, K, ptr(dzo), None, K, st),
+                  "linear_bwd_input")
+            buf = torch.zeros(N * K + (N if ctx.has_bias[-1] else 0), dtype=torch.float32, device=xf.device)
+            dw, db = buf[:N * K].view(N, K), (buf[N * K:] if ctx.has_bias[-1] else None)
+            check(lib().rsdf_linear_bwd_weight(ptr(dzo), N, ptr(xin), K, n, K, N, ptr(dw), ptr(db), st), "linear_bwd_weight")
+            grads[2 * top], grads[2 * top + 1] = dw, db
+            tail, top = (dzo, N, w), nl - 2
+        for i in range(top, -1, -1):
             w, y = ws[i], ys[i]
             xin = ys[i - 1] if i > 0 else xf
             N, K = w.shape
@@ -519,7 +534,18 @@ class _MLPChain(torch.autograd.Function):
             db = buf[N * K:] if ctx.has_bias[i] else None
             fused = not split and bool(lib().rsdf_linear_bwd_fused_supported(K, N))
             prev_relu = fused and i > 0 and ctx.acts[i - 1] == relu
-            if fused:
+            if tail is not None:
+                dzo, n2, w2 = tail
+                tail = None
+                if dx is None:   # (a one-hidden-layer network whose input needs no gradient: still wants a dx buffer)
+                    dx = torch.empty(n, K, dtype=torch.float32, device=xf.device)
+                    dx_win, k0, kout = ptr(dx), 0, K
+                check(lib().rsdf_linear_bwd_fused_tail(ptr(dzo), n2, ptr(w2), ptr(y), N, ptr(xin), K, ptr(w), n, K, N,
+                                                       ctx.acts[i], k0, kout, dx_win, K, relu if prev_relu else none,
+                                                       ptr(dw), ptr(db), st), "linear_bwd_fused_tail")
+                if not need_dx:
+                    dx = None
+            elif fused:
                 check(lib().rsdf_linear_bwd_fused(ptr(g), ptr(yarg), N, ptr(xin), K, ptr(w), n, K, N, act, k0, kout,
                                                   dx_win, K, relu if prev_relu else none, ptr(dw), ptr(db), st),
                       "linear_bwd_fused")
