@@ -108,8 +108,9 @@ __device__ __forceinline__ float4 load4(const float *__restrict__ p, bool vec)
 // ACT is a template parameter: with a run-time activation id the derivative's switch is re-evaluated for each of the
 // 16 staged values (the first build spent 620 scalar and 980 vector instructions per tile on it)
 // PREV_RELU: the layer's input x is the ReLU output of the previous layer of the chain; dx is then written as that layer's
-// dz = dx * (x > 0), the mask read from the high bf16 part of the X image (same sign and zero as x): the previous layer's
-// backward needs no activation pass and does not read its y at all.
+// dz = dx * (x > 0), the mask read from the high bf16 part of the X image (same sign as x, and zero exactly when x is zero
+// or a positive value below half the smallest bf16 subnormal, 4.6e-41 -- not a value an activation takes): the previous
+// layer's backward needs no activation pass and does not read its y at all.
 // TAIL: the layer above is the network's narrow output layer (N2 <= 4 columns, weights w2 [N2][128]); instead of reading its
 // input gradient dy [n][128] this kernel forms it while staging, dy[row][col] = sum_q dzo[row][q] w2[q][col], from that
 // layer's dz (dzo [n][N2], 4-16 bytes per row): the output layer's input-gradient kernel and 512 bytes per row go away.
