@@ -164,6 +164,8 @@ def roofline_from(summary, steps):
             return "hbm", n * (L * 8 * 2 * 4 + 12 + L * 2 * 4)
         if name in ("rsdf_hashgrid_fwd_fd7", "rsdf_hashgrid_bwd_fd7"):   # n_samples, n_active, ...
             return "hbm", 7 * a[0] * (16 * 8 * 2 * 4 + 12 + 16 * 2 * 4)   # 7 evaluations x 1164 B
+        if name in ("rsdf_hashgrid_fwd_fd7_pts", "rsdf_hashgrid_bwd_fd7_pts"):   # radius, eps, n_samples, n_active, ...
+            return "hbm", 7 * a[2] * (16 * 8 * 2 * 4 + 12 + 16 * 2 * 4)
         if name == "rsdf_sdfmlp_fd7_fwd":    # L, n_active, xyz_scale, xyz_offset, H, N2, n_samples
             K0, H, S = 3 + 2 * a[0], a[4], a[6]
             return "mfma", 2.0 * 7 * S * (K0 * H + H * H + H)            # last layer: SDF column only
@@ -179,6 +181,8 @@ def roofline_from(summary, steps):
         return None, 0.0
 
     def samples_of(name, a):
+        if name.endswith("_fd7_pts"):
+            return a[2]
         return a[6] if name.startswith("rsdf_sdfmlp_fd7") else a[0]
 
     best = max(summary.items(), key=lambda kv: kv[1]["ms"])
@@ -349,13 +353,14 @@ def main():
             roof, breakdown = roofline_from(timer.summary(), args.steps)
             attach_traffic(roof, args.pmc_summary)
             if roof is not None and "other_kernels" in roof:
-                fd7 = roof["other_kernels"].get("rsdf_hashgrid_fwd_fd7")
+                fd7 = roof["other_kernels"].get("rsdf_hashgrid_fwd_fd7_pts") or \
+                    roof["other_kernels"].get("rsdf_hashgrid_fwd_fd7")
                 if fd7 is not None:
                     # the stencil gather priced two ways: SURVEY 8d's algorithmic bytes (7 evaluations x 1164 B; a
                     # fraction >= 1 only says that it fetches far fewer corners than 56 per level), and the bytes it
-                    # cannot avoid moving through HBM (x7t 84 B + planes 896 B per sample; the table is L2 / MALL resident)
-                    fd7["necessary_bytes_per_sample"] = 980
-                    fd7["achieved_necessary"] = round(fd7["achieved"] * 980.0 / (7 * 1164.0), 1)
+                    # cannot avoid moving through HBM (centre 12 B + planes 896 B per sample; the table is L2 / MALL resident)
+                    fd7["necessary_bytes_per_sample"] = 908
+                    fd7["achieved_necessary"] = round(fd7["achieved"] * 908.0 / (7 * 1164.0), 1)
                     fd7["frac_necessary"] = round(fd7["achieved_necessary"] / HBM_PEAK_GBS, 4)
                     fd7["evals_per_sec"] = round(fd7["achieved"] * 1e9 / 1164.0)
                 roof["other_kernels"]["rsdf_hashgrid_fwd (generic)"] = generic_gather_probe(model, rays, jitter, args.chunk)

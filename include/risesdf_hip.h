@@ -161,6 +161,17 @@ int64_t rsdf_hashgrid_bwd_fd7_scratch_bytes(const rsdf_grid_meta *meta /*host*/,
 int rsdf_hashgrid_bwd_fd7(const float *x7t, const float *dplanes, const rsdf_grid_meta *meta /*host*/,
                           int64_t n_samples, int n_active_levels, float eps_unit, float *dtable,
                           void *scratch, int64_t scratch_bytes, void *stream);
+/* The same two kernels with the stencil DERIVED in-kernel from each sample's world-space centre points [n][3]
+ * (what rsdf_fd_points returns as `positions`): x +- eps e_k, clamp(-radius, radius), AABB contraction, in exactly
+ * rsdf_fd_points' arithmetic (models/geometry.py:229-244), so cells and weights are bit-identical to the x7t form.
+ * Both kernels walk the samples once per level; 16 x 84 B of tap positions per sample become 16 x 12 B.
+ * bwd: eps_unit (= eps / (2*radius)) only sizes the queues, as above; pass the value the scratch size was asked for. */
+int rsdf_hashgrid_fwd_fd7_pts(const float *points, float radius, float eps, const float *table,
+                              const rsdf_grid_meta *meta /*host*/, int64_t n_samples, int n_active_levels,
+                              float *planes, void *stream);
+int rsdf_hashgrid_bwd_fd7_pts(const float *points, float radius, float eps, const float *dplanes,
+                              const rsdf_grid_meta *meta /*host*/, int64_t n_samples, int n_active_levels,
+                              float eps_unit, float *dtable, void *scratch, int64_t scratch_bytes, void *stream);
 
 /* H1 input gradient (what tcnn's autograd supplies to analytic normals, models/geometry.py:224-228, and to the
  * curvature term, geometry.py:262-270) and its backward (tcnn double backward).  x in [0,1]; dx in the same

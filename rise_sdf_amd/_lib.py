@@ -11,7 +11,9 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "librisesdf_hip.so")
+# RSDF_LIB selects another build of the same ABI (tools/ab_*.sh, tools/stamps_*.sh put their experiment builds there instead
+# of overwriting the shipped library)
+SO_PATH = os.environ.get("RSDF_LIB") or os.path.join(_HERE, "librisesdf_hip.so")
 MAX_LEVELS = 32
 
 ACT_NONE, ACT_RELU, ACT_SOFTPLUS100, ACT_SIGMOID = 0, 1, 2, 3
@@ -61,6 +63,8 @@ _SIGNATURES = {
     "rsdf_hashgrid_bwd_fd7_scratch_bytes": [ctypes.POINTER(GridMeta), _L, _I, _F],
     "rsdf_hashgrid_fwd_fd7": [_P, _P, ctypes.POINTER(GridMeta), _L, _I, _P, _P],
     "rsdf_hashgrid_bwd_fd7": [_P, _P, ctypes.POINTER(GridMeta), _L, _I, _F, _P, _P, _L, _P],
+    "rsdf_hashgrid_fwd_fd7_pts": [_P, _F, _F, _P, ctypes.POINTER(GridMeta), _L, _I, _P, _P],
+    "rsdf_hashgrid_bwd_fd7_pts": [_P, _F, _F, _P, ctypes.POINTER(GridMeta), _L, _I, _F, _P, _P, _L, _P],
     "rsdf_loss_rays_fwd": [_P, _P, _P, _P, _P, _P, _L, _P, _P],
     "rsdf_loss_rays_bwd": [_P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P],
     "rsdf_loss_samples_fwd": [_P, _P, _P, _F, _L, _P, _P],

@@ -8,7 +8,8 @@
 
 #define RSDF_WAVE 64
 
-extern "C" void rsdf_set_error(const char *msg);
+// library-internal (hidden: not part of the C ABI in include/risesdf_hip.h)
+extern "C" __attribute__((visibility("hidden"))) void rsdf_set_error(const char *msg);
 
 #define RSDF_CHECK_ARG(cond, msg)        \
     do {                                 \
@@ -30,6 +31,13 @@ extern "C" void rsdf_set_error(const char *msg);
     } while (0)
 
 static inline unsigned rsdf_blocks(int64_t n, int threads) { return (unsigned)((n + threads - 1) / threads); }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize for kernels that want more than 64 KB of LDS.  The attribute is per DEVICE
+// (and autograd runs backward on another host thread), so the "already set" cache is keyed on (kernel, device, bytes) and
+// thread-local; returns 0 or the hipError_t (rsdf_last_error() set).  Library-internal: not exported.
+__attribute__((visibility("hidden"))) int rsdf_func_lds(const void *kernel, size_t bytes);
+// getenv() once per process for the A/B knobs (DESIGN.md "Knobs"): the value cannot change under a running library
+__attribute__((visibility("hidden"))) bool rsdf_env_is(const char *name, const char *value);
 
 // ---- wave64 primitives -------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }

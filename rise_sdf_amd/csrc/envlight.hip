@@ -538,14 +538,8 @@ int rsdf_cube_sample_bwd(const float *const *mips, float *const *grad_mips, int 
         plan.total += cnt;
     }
     const size_t lds = (size_t)plan.total * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(cube_sample_bwd_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)(LDS_BUDGET_FLOATS * sizeof(float)));
-        if (e != hipSuccess) { rsdf_set_error(hipGetErrorString(e)); return (int)e; }
-        attr_set = true;
-    }
+    if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(cube_sample_bwd_kernel), LDS_BUDGET_FLOATS * sizeof(float)))
+        return rc;
     unsigned grid = rsdf_blocks(n, BWD_THREADS);
     if (plan.total > 0 && grid > 512) grid = 512;   // persistent: one LDS copy (and one flush) per workgroup
     cube_sample_bwd_kernel<<<grid, BWD_THREADS, lds, (hipStream_t)stream>>>(st, plan, dirs, level, n, grad_out,

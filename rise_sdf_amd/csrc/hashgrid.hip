@@ -226,23 +226,6 @@ int rsdf_hashgrid_fwd(const float *x, const float *table, const rsdf_grid_meta *
     RSDF_RETURN_LAUNCH();
 }
 
-// internal (not in the public header): atomic scatter for a contiguous range of levels; used by
-// hashgrid_fd7.hip for the dense coarse levels
-int rsdf_internal_hashgrid_bwd_levels(const float *x, const float *dout, const rsdf_grid_meta *meta,
-                                      int64_t n, int ld_dout, int col_off, float *dtable,
-                                      int level_begin, int level_count, void *stream)
-{
-    if (n <= 0 || level_count <= 0) return 0;
-    dim3 grid(rsdf_blocks(n, THREADS), level_count);
-    hipStream_t st = (hipStream_t)stream;
-    switch ((int)meta->n_features) {
-    case 1: hashgrid_bwd_kernel<1, true><<<grid, THREADS, 0, st>>>(x, dout, *meta, n, ld_dout, col_off, dtable, level_begin); break;
-    case 2: hashgrid_bwd_kernel<2, true><<<grid, THREADS, 0, st>>>(x, dout, *meta, n, ld_dout, col_off, dtable, level_begin); break;
-    default: hashgrid_bwd_kernel<4, true><<<grid, THREADS, 0, st>>>(x, dout, *meta, n, ld_dout, col_off, dtable, level_begin); break;
-    }
-    RSDF_RETURN_LAUNCH();
-}
-
 int rsdf_hashgrid_bwd(const float *x, const float *dout, const rsdf_grid_meta *meta, int64_t n,
                       int n_active_levels, int ld_dout, int col_off, float *dtable, void *stream)
 {

@@ -135,6 +135,105 @@ __device__ __forceinline__ uint32_t extra_index(const CellFrac &c0, int a, int k
     return entry_index(cc[0], cc[1], cc[2], g);
 }
 
+// Where a sample's seven stencil points come from.
+//   x7t != nullptr : read them, x7t [7][S][3] (unit cube), as rsdf_fd_points / rsdf_fd_taps wrote them;
+//   x7t == nullptr : DERIVE them from the sample's world-space centre pw [S][3] with exactly rsdf_fd_points' arithmetic
+//                    (models/geometry.py:229-244: x +- eps e_k, clamp(-r, r), AABB contraction (q - (-r)) / (r - (-r));
+//                    this file is built with -ffp-contract=off and IEEE division like neus.hip), so that the cells and
+//                    weights are bit-identical to the x7t form.  Both stencil kernels walk the samples once per level:
+//                    16 x 84 B of tap positions per sample become 16 x 12 B (1.3 of the forward's 4.2 KB).
+struct TapSrc {
+    const float *x7t;
+    const float *pw;
+    float radius, eps;
+};
+
+__device__ __forceinline__ void cell_frac1(float u, float scale, uint32_t &c, float &w)
+{
+    const float p = fmaf(scale, u, 0.5f);
+    const float f = floorf(p);
+    c = (uint32_t)(int32_t)f;
+    w = p - f;
+}
+
+// The centre's unit-cube coordinates u0 (unclamped, as fd_points writes tap 0) and the clamped form uc that every
+// displaced tap carries in its two OTHER components (fd_points clamps all three components of a tap; uc differs from u0
+// only for a centre that rounding has put outside [-r, r]).  uc needs no second division: (clamp(p, -r, r) + r) / 2r ==
+// clamp((p + r) / 2r, 0, 1) bit for bit -- inside the box both are u0; for p > r the left side is 2r / 2r = 1 and
+// u0 >= 1 (rounding is monotonic); for p < -r the left side is 0 / 2r = +0 and u0 < 0.
+struct CentreUnit {
+    float p[3];
+    CellFrac c0, cc;
+};
+
+__device__ __forceinline__ CentreUnit centre_unit(const TapSrc &src, int64_t s, float scale)
+{
+    CentreUnit cu;
+    const float *pp = src.pw + s * 3;
+    const float r = src.radius, two_r = r - (-r);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        cu.p[k] = pp[k];
+        const float u0 = (cu.p[k] - (-r)) / two_r;
+        cell_frac1(u0, scale, cu.c0.c[k], cu.c0.w[k]);
+        cu.cc.c[k] = cu.c0.c[k];
+        cu.cc.w[k] = cu.c0.w[k];
+        const float uc = fminf(fmaxf(u0, 0.0f), 1.0f);
+        if (uc != u0) cell_frac1(uc, scale, cu.cc.c[k], cu.cc.w[k]);   // rare: centre outside the box
+    }
+    return cu;
+}
+
+// tap t = 1..6 (+x,-x,+y,-y,+z,-z) of a derived stencil
+__device__ __forceinline__ CellFrac derived_tap(const TapSrc &src, const CentreUnit &cu, int t, float scale)
+{
+    const int a = (t - 1) >> 1;
+    const float off = ((t - 1) & 1) ? -src.eps : src.eps;
+    const float r = src.radius, two_r = r - (-r);
+    CellFrac ct = cu.cc;
+    const float q = fminf(fmaxf(cu.p[a] + off, -r), r);
+    cell_frac1((q - (-r)) / two_r, scale, ct.c[a], ct.w[a]);
+    return ct;
+}
+
+// the same for a tap index known only at run time (the producer's work items): selects instead of indexed registers
+__device__ __forceinline__ CellFrac derived_tap_rt(const TapSrc &src, const CentreUnit &cu, int t, float scale)
+{
+    const int a = (t - 1) >> 1;
+    const float off = ((t - 1) & 1) ? -src.eps : src.eps;
+    const float r = src.radius, two_r = r - (-r);
+    const float pa = a == 0 ? cu.p[0] : (a == 1 ? cu.p[1] : cu.p[2]);
+    const float q = fminf(fmaxf(pa + off, -r), r);
+    uint32_t c;
+    float w;
+    cell_frac1((q - (-r)) / two_r, scale, c, w);
+    CellFrac ct = cu.cc;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        if (k == a) {
+            ct.c[k] = c;
+            ct.w[k] = w;
+        }
+    return ct;
+}
+
+template <bool DERIVE>
+__device__ __forceinline__ void load_stencil(const TapSrc &src, int64_t S, int64_t s, float scale, CellFrac (&cf)[7])
+{
+    if (DERIVE) {
+        const CentreUnit cu = centre_unit(src, s, scale);
+        cf[0] = cu.c0;
+#pragma unroll
+        for (int t = 1; t < 7; ++t) cf[t] = derived_tap(src, cu, t, scale);
+    } else {
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {
+            const float *p = src.x7t + ((int64_t)t * S + s) * 3;
+            cf[t] = cell_frac(p[0], p[1], p[2], scale);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
@@ -147,16 +246,13 @@ __device__ __forceinline__ uint32_t extra_index(const CellFrac &c0, int a, int k
 #ifndef RSDF_BWD_GROUP
 #define RSDF_BWD_GROUP 256
 #endif
-__device__ __forceinline__ void fd7_fwd_sample(const float *__restrict__ x7t, const float2 *__restrict__ tl,
+template <bool DERIVE>
+__device__ __forceinline__ void fd7_fwd_sample(const TapSrc &src, const float2 *__restrict__ tl,
                                                const LevelGeom &g, int64_t S, int64_t s, int l,
                                                float2 *__restrict__ planes)
 {
     CellFrac cf[7];
-#pragma unroll
-    for (int t = 0; t < 7; ++t) {
-        const float *p = x7t + ((int64_t)t * S + s) * 3;
-        cf[t] = cell_frac(p[0], p[1], p[2], g.scale);
-    }
+    load_stencil<DERIVE>(src, S, s, g.scale, cf);
     const CellFrac &c0 = cf[0];
     int da[7];
     bool plus[3] = {false, false, false}, minus[3] = {false, false, false};
@@ -228,8 +324,9 @@ __device__ __forceinline__ void fd7_fwd_sample(const float *__restrict__ x7t, co
 // it); inside a group the 15 re-reads come from the 256 MB MALL.  18.8 -> 16.0 ms per launch; 1024-tile groups 16.9,
 // 8192-tile groups (176 MB + the 64 MB of tables: past the MALL) 18.8.  Not paying, measured: XCD-contiguous sample
 // ranges (neighbouring rays in one L2: <= 3 %), several tiles per workgroup, forcing more waves per SIMD.
+template <bool DERIVE>
 __global__ void __launch_bounds__(F_THREADS, RSDF_FWD_WAVES)
-fd7_fwd_kernel(const float *__restrict__ x7t, const float *__restrict__ table,
+fd7_fwd_kernel(const TapSrc src, const float *__restrict__ table,
                const rsdf_grid_meta meta, int64_t S, int n_active, float2 *__restrict__ planes)
 {
     const int64_t per_group = (int64_t)RSDF_FWD_GROUP * n_active;
@@ -240,7 +337,7 @@ fd7_fwd_kernel(const float *__restrict__ x7t, const float *__restrict__ table,
     if (s >= S) return;
     const LevelGeom g = level_geom(meta, l);
     const float2 *tl = reinterpret_cast<const float2 *>(table) + meta.offset[l];
-    fd7_fwd_sample(x7t, tl, g, S, s, l, planes);
+    fd7_fwd_sample<DERIVE>(src, tl, g, S, s, l, planes);
 }
 
 // in-kernel stamps (build with -DRSDF_STAMPS; tools/stamps_produce.sh): thread 0 of the workgroups of level RSDF_STAMP_LEVEL
@@ -351,8 +448,9 @@ __device__ __forceinline__ void emit_round(const uint32_t (&ridx)[ROUND_RECS],
 // Work item of the second phase: a displaced tap.  bits 0..9 sample within the workgroup, 10..12 tap - 1, 13 side (1: +1 cell)
 constexpr int MAX_ITEMS = P_THREADS * 6;
 
+template <bool DERIVE>
 __global__ void __launch_bounds__(P_THREADS, RSDF_STAGE_RECS <= 4 ? 8 : 4)
-fd7_produce_kernel(const float *__restrict__ x7t, const float2 *__restrict__ dplanes,
+fd7_produce_kernel(const TapSrc src, const float2 *__restrict__ dplanes,
                    const rsdf_grid_meta meta, const LevelPlan plan, int64_t S, int n_active,
                    Record *__restrict__ queues, int *__restrict__ counters,
                    float *__restrict__ dtable)
@@ -402,11 +500,11 @@ fd7_produce_kernel(const float *__restrict__ x7t, const float2 *__restrict__ dpl
     unsigned items = 0;   // 6 x 2 bits: bit 2(t-1) = displaced, bit 2(t-1)+1 = side
 
     if (active) {
-        const float *px = x7t + s * 3;                                  // tap t: px + t (3 S)
         const float2 *pg = dplanes + ((int64_t)l * 7) * S + s;          // tap t: pg + t S
+        CellFrac cf[7];
+        load_stencil<DERIVE>(src, S, s, g.scale, cf);
         {
-            const float *p = px;
-            c0 = cell_frac(p[0], p[1], p[2], g.scale);
+            c0 = cf[0];
             const float2 gr = pg[0];
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
@@ -418,8 +516,7 @@ fd7_produce_kernel(const float *__restrict__ x7t, const float2 *__restrict__ dpl
 #pragma unroll
         for (int t = 1; t < 7; ++t) {
             const int a = (t - 1) >> 1;
-            const float *p = px + (int64_t)t * S * 3;
-            const CellFrac ct = cell_frac(p[0], p[1], p[2], g.scale);
+            const CellFrac ct = cf[t];
             const float2 gr = pg[(int64_t)t * S];
             const int32_t da = (int32_t)(ct.c[a] - c0.c[a]);
             if (da == 0) {
@@ -522,8 +619,13 @@ fd7_produce_kernel(const float *__restrict__ x7t, const float2 *__restrict__ dpl
                 const unsigned it = s_items[i];
                 const int64_t s2 = s_block + (it & 1023u);
                 const int t = (int)(it >> 10 & 7u) + 1, a = (t - 1) >> 1, far = (int)(it >> 13 & 1u);
-                const float *p = x7t + ((int64_t)t * S + s2) * 3;
-                const CellFrac ct = cell_frac(p[0], p[1], p[2], g.scale);
+                CellFrac ct;
+                if (DERIVE) {
+                    ct = derived_tap_rt(src, centre_unit(src, s2, g.scale), t, g.scale);
+                } else {
+                    const float *p = src.x7t + ((int64_t)t * S + s2) * 3;
+                    ct = cell_frac(p[0], p[1], p[2], g.scale);
+                }
                 const float2 gr = dplanes[((int64_t)l * 7 + t) * S + s2];
                 const int o1 = (a == 0) ? 1 : 0, o2 = (a == 2) ? 1 : 2;
                 uint32_t cidx[8];
@@ -641,11 +743,14 @@ int make_plan(const rsdf_grid_meta *meta, int64_t S, int n_active, float eps_uni
         // RSDF_FD7_QUEUE_SCALE (test knob, default 1): shrinks the queues so that the overflow path -- a record that
         // finds its queue full goes to the table with a direct atomic, and the reducer clamps its count -- is exercised
         // (tests/test_gpu_regimes.py).  Read here so that scratch_bytes() and the launch agree.
-        double qscale = 1.0;
-        if (const char *e = getenv("RSDF_FD7_QUEUE_SCALE")) {
-            const double v = atof(e);
-            if (v > 0.0 && v <= 1.0) qscale = v;
-        }
+        static const double qscale_env = [] {
+            if (const char *e = getenv("RSDF_FD7_QUEUE_SCALE")) {
+                const double v = atof(e);
+                if (v > 0.0 && v <= 1.0) return v;
+            }
+            return 1.0;
+        }();
+        const double qscale = qscale_env;
         plan->cap[l] = qscale < 1.0 ? (int64_t)(per_bin * qscale) + 64 : (int64_t)(per_bin * 1.15) + 16384;
         int ns = (int)(per_bin / per_wg + 0.999);
         plan->n_split[l] = ns < 1 ? 1 : (ns > 256 ? 256 : ns);
@@ -679,10 +784,10 @@ extern "C" int rsdf_debug_read_pstamps(unsigned long long *out16, int reset)
 }
 #endif
 
-extern "C" {
+namespace {
 
-int rsdf_hashgrid_fwd_fd7(const float *x7t, const float *table, const rsdf_grid_meta *meta,
-                          int64_t n_samples, int n_active_levels, float *planes, void *stream)
+int launch_fwd(const TapSrc &src, const float *table, const rsdf_grid_meta *meta, int64_t n_samples,
+               int n_active_levels, float *planes, void *stream)
 {
     RSDF_CHECK_ARG(meta != nullptr, "hashgrid_fwd_fd7: meta is NULL");
     RSDF_CHECK_ARG(meta->n_features == 2, "hashgrid_fwd_fd7: n_features must be 2");
@@ -698,27 +803,31 @@ int rsdf_hashgrid_fwd_fd7(const float *x7t, const float *table, const rsdf_grid_
     const unsigned n_tiles_f = (rsdf_blocks(n_samples, F_THREADS) + RSDF_FWD_GROUP - 1) / RSDF_FWD_GROUP * RSDF_FWD_GROUP;
     // HIP launches in threads: grid.x * block.x must stay below 2^32
     RSDF_CHECK_ARG((uint64_t)n_tiles_f * na * F_THREADS < (1ull << 32), "hashgrid_fwd_fd7: too many samples for one launch");
-    fd7_fwd_kernel<<<n_tiles_f * na, F_THREADS, 0, (hipStream_t)stream>>>(x7t, table, *meta, n_samples, na,
-                                                                           reinterpret_cast<float2 *>(planes));
+    float2 *pl = reinterpret_cast<float2 *>(planes);
+    if (src.x7t)
+        fd7_fwd_kernel<false><<<n_tiles_f * na, F_THREADS, 0, (hipStream_t)stream>>>(src, table, *meta, n_samples, na, pl);
+    else
+        fd7_fwd_kernel<true><<<n_tiles_f * na, F_THREADS, 0, (hipStream_t)stream>>>(src, table, *meta, n_samples, na, pl);
     RSDF_RETURN_LAUNCH();
 }
 
-int64_t rsdf_hashgrid_bwd_fd7_scratch_bytes(const rsdf_grid_meta *meta, int64_t n_samples,
-                                            int n_active_levels, float eps_unit)
+template <bool DERIVE>
+void launch_produce(dim3 grid, size_t stage_bytes, hipStream_t st, const TapSrc &src, const float2 *dplanes,
+                    const rsdf_grid_meta &meta, const LevelPlan &plan, int64_t n_samples, int na, Record *queues,
+                    int *counters, float *dtable, int dev)
 {
-    if (!meta) return -1;
-    LevelPlan plan;
-    int n_cnt;
-    int64_t n_rec;
-    int na = n_active_levels;
-    if (na < 0 || na > (int)meta->n_levels) na = (int)meta->n_levels;
-    if (make_plan(meta, n_samples, na, eps_unit, &plan, &n_rec, &n_cnt) != 0) return -1;
-    return scratch_need(n_rec, n_cnt);
+    static thread_local unsigned long long attr_set = 0;      // one bit per device (the attribute is per device)
+    if (!(attr_set >> (dev & 63) & 1ull)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fd7_produce_kernel<DERIVE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_bytes);
+        attr_set |= 1ull << (dev & 63);
+    }
+    fd7_produce_kernel<DERIVE><<<grid, P_THREADS, stage_bytes, st>>>(src, dplanes, meta, plan, n_samples, na, queues,
+                                                                     counters, dtable);
 }
 
-int rsdf_hashgrid_bwd_fd7(const float *x7t, const float *dplanes, const rsdf_grid_meta *meta,
-                          int64_t n_samples, int n_active_levels, float eps_unit, float *dtable,
-                          void *scratch, int64_t scratch_bytes, void *stream)
+int launch_bwd(const TapSrc &src, const float *dplanes, const rsdf_grid_meta *meta, int64_t n_samples,
+               int n_active_levels, float eps_unit, float *dtable, void *scratch, int64_t scratch_bytes, void *stream)
 {
     RSDF_CHECK_ARG(meta != nullptr, "hashgrid_bwd_fd7: meta is NULL");
     RSDF_CHECK_ARG(meta->n_features == 2, "hashgrid_bwd_fd7: n_features must be 2");
@@ -745,14 +854,11 @@ int rsdf_hashgrid_bwd_fd7(const float *x7t, const float *dplanes, const rsdf_gri
     const size_t stage_bytes = (size_t)STAGE_CAP * sizeof(Record);
     int dev = 0;
     (void)hipGetDevice(&dev);
-    static thread_local unsigned long long pattr_set = 0;      // one bit per device (the attribute is per device)
-    if (!(pattr_set >> (dev & 63) & 1ull)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fd7_produce_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_bytes);
-        pattr_set |= 1ull << (dev & 63);
-    }
-    fd7_produce_kernel<<<pgrid, P_THREADS, stage_bytes, st>>>(x7t, reinterpret_cast<const float2 *>(dplanes), *meta,
-                                                    plan, n_samples, na, queues, counters, dtable);
+    const float2 *dpl = reinterpret_cast<const float2 *>(dplanes);
+    if (src.x7t)
+        launch_produce<false>(pgrid, stage_bytes, st, src, dpl, *meta, plan, n_samples, na, queues, counters, dtable, dev);
+    else
+        launch_produce<true>(pgrid, stage_bytes, st, src, dpl, *meta, plan, n_samples, na, queues, counters, dtable, dev);
     int max_wgs = 0;
     for (int l = 0; l < na; ++l) {
         const int w = plan.n_bins[l] * plan.n_split[l];
@@ -768,6 +874,58 @@ int rsdf_hashgrid_bwd_fd7(const float *x7t, const float *dplanes, const rsdf_gri
     dim3 rgrid(max_wgs, na);
     fd7_reduce_kernel<<<rgrid, R_THREADS, lds, st>>>(*meta, plan, queues, counters, dtable);
     RSDF_RETURN_LAUNCH();
+}
+
+}  // namespace
+
+extern "C" {
+
+int rsdf_hashgrid_fwd_fd7(const float *x7t, const float *table, const rsdf_grid_meta *meta,
+                          int64_t n_samples, int n_active_levels, float *planes, void *stream)
+{
+    RSDF_CHECK_ARG(x7t != nullptr || n_samples <= 0, "hashgrid_fwd_fd7: x7t is NULL");
+    return launch_fwd(TapSrc{x7t, nullptr, 0.f, 0.f}, table, meta, n_samples, n_active_levels, planes, stream);
+}
+
+int rsdf_hashgrid_fwd_fd7_pts(const float *points, float radius, float eps, const float *table,
+                              const rsdf_grid_meta *meta, int64_t n_samples, int n_active_levels, float *planes,
+                              void *stream)
+{
+    RSDF_CHECK_ARG(points != nullptr || n_samples <= 0, "hashgrid_fwd_fd7_pts: points is NULL");
+    RSDF_CHECK_ARG(radius > 0.f, "hashgrid_fwd_fd7_pts: radius must be > 0");
+    return launch_fwd(TapSrc{nullptr, points, radius, eps}, table, meta, n_samples, n_active_levels, planes, stream);
+}
+
+int64_t rsdf_hashgrid_bwd_fd7_scratch_bytes(const rsdf_grid_meta *meta, int64_t n_samples,
+                                            int n_active_levels, float eps_unit)
+{
+    if (!meta) return -1;
+    LevelPlan plan;
+    int n_cnt;
+    int64_t n_rec;
+    int na = n_active_levels;
+    if (na < 0 || na > (int)meta->n_levels) na = (int)meta->n_levels;
+    if (make_plan(meta, n_samples, na, eps_unit, &plan, &n_rec, &n_cnt) != 0) return -1;
+    return scratch_need(n_rec, n_cnt);
+}
+
+int rsdf_hashgrid_bwd_fd7(const float *x7t, const float *dplanes, const rsdf_grid_meta *meta,
+                          int64_t n_samples, int n_active_levels, float eps_unit, float *dtable,
+                          void *scratch, int64_t scratch_bytes, void *stream)
+{
+    RSDF_CHECK_ARG(x7t != nullptr || n_samples <= 0, "hashgrid_bwd_fd7: x7t is NULL");
+    return launch_bwd(TapSrc{x7t, nullptr, 0.f, 0.f}, dplanes, meta, n_samples, n_active_levels, eps_unit, dtable,
+                      scratch, scratch_bytes, stream);
+}
+
+int rsdf_hashgrid_bwd_fd7_pts(const float *points, float radius, float eps, const float *dplanes,
+                              const rsdf_grid_meta *meta, int64_t n_samples, int n_active_levels, float eps_unit,
+                              float *dtable, void *scratch, int64_t scratch_bytes, void *stream)
+{
+    RSDF_CHECK_ARG(points != nullptr || n_samples <= 0, "hashgrid_bwd_fd7_pts: points is NULL");
+    RSDF_CHECK_ARG(radius > 0.f, "hashgrid_bwd_fd7_pts: radius must be > 0");
+    return launch_bwd(TapSrc{nullptr, points, radius, eps}, dplanes, meta, n_samples, n_active_levels, eps_unit, dtable,
+                      scratch, scratch_bytes, stream);
 }
 
 }  // extern "C"

@@ -323,8 +323,21 @@ int rsdf_compact_samples(const uint8_t *keep, const int64_t *ray_indices, const 
 
 // ---- marcher entry points (roi read from device memory) ---------------------------------------
 namespace {
+// One thread per ray, as the reference (ray_marching.cu:81-192), and the reference's arithmetic statement by statement:
+// the sample set is an integer function of a serial fp32 accumulation (t1 = t0 + dt, the do { _t += dt } while skip), so
+// the recurrence cannot be re-associated.  What CAN change is how long a thread waits: the loop's only memory access is
+// the occupancy byte of the current step, a dependent load (~1 us) per step, and a 32768-ray chunk is 512 wavefronts on
+// 1024 SIMDs -- the kernel was pure load latency (0.45 ms per pass whatever the ray count: 143 ms of a step at 4096-ray
+// chunks).  Each trip now SPECULATES that the next SPEC steps are occupied: it runs the recurrence SPEC steps ahead,
+// issues their SPEC occupancy loads back to back, then replays the reference's decisions in order on the loaded bytes
+// and discards everything after the first empty cell (the skip restarts from that step's exact (t0, t1, t_mid)).  Same
+// emitted (t0, t1) bit for bit; 1/SPEC of the waits inside occupied runs.  Inside empty space a trip uses one cell only,
+// so after a trip that broke at its first step the next one looks at a single cell.
+constexpr int SPEC = 8;
+constexpr int MARCH_THREADS = 64;
+
 template <bool WRITE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(MARCH_THREADS)
 march_entry(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
             const float *__restrict__ t_min, const float *__restrict__ t_max, GridDev gd,
             float step_size, float cone_angle, int64_t n_rays,
@@ -348,31 +361,64 @@ march_entry(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
     float dt = calc_dt(t0, cone_angle, dt_min, dt_max);
     float t1 = t0 + dt;
     float t_mid = (t0 + t1) * 0.5f;
+    int n_spec = SPEC;
     while (t_mid < far_) {
-        const float x = ox + t_mid * dx, y = oy + t_mid * dy, z = oz + t_mid * dz;
-        if (occupied_at(x, y, z, g)) {
-            if (WRITE) {
-                t_starts[base + j] = t0;
-                t_ends[base + j] = t1;
-                ray_indices[base + j] = i;
-            }
-            ++j;
-            t0 = t1;
-            t1 = t0 + calc_dt(t0, cone_angle, dt_min, dt_max);
-            t_mid = (t0 + t1) * 0.5f;
-        } else {
-            const float tx = axis_dist(x, dx, ix, g.roi[0], g.roi[3], g.res[0]);
-            const float ty = axis_dist(y, dy, iy, g.roi[1], g.roi[4], g.res[1]);
-            const float tz = axis_dist(z, dz, iz, g.roi[2], g.roi[5], g.res[2]);
-            float t_target = t_mid + fmaxf(fminf(fminf(tx, ty), tz), 0.0f);
-            t_target = fminf(t_target, far_);
-            float _t = t_mid;
-            do { _t += dt_min; } while (_t < t_target);
-            t_mid = _t;
-            dt = calc_dt(t_mid, cone_angle, dt_min, dt_max);
-            t0 = t_mid - dt * 0.5f;
-            t1 = t_mid + dt * 0.5f;
+        // the recurrence of the "occupied" branch, SPEC steps ahead: state m = (a0, a1, am)[m] after m occupied steps
+        float a0[SPEC + 1], a1[SPEC + 1], am[SPEC + 1];
+        a0[0] = t0, a1[0] = t1, am[0] = t_mid;
+#pragma unroll
+        for (int m = 1; m <= SPEC; ++m) {
+            a0[m] = a1[m - 1];
+            a1[m] = a0[m] + calc_dt(a0[m], cone_angle, dt_min, dt_max);
+            am[m] = (a0[m] + a1[m]) * 0.5f;
         }
+        int occ[SPEC];
+#pragma unroll
+        for (int m = 0; m < SPEC; ++m) {
+            occ[m] = 0;
+            if (m < n_spec && am[m] < far_) {
+                const int c = cell_index(ox + am[m] * dx, oy + am[m] * dy, oz + am[m] * dz, g);
+                if (c >= 0) occ[m] = g.binary[c];
+            }
+        }
+        // replay in order
+        int m = 0;
+#pragma unroll
+        for (int q = 0; q < SPEC; ++q) {
+            if (m == q && q < n_spec && am[q] < far_ && occ[q] != 0) {
+                if (WRITE) {
+                    t_starts[base + j] = a0[q];
+                    t_ends[base + j] = a1[q];
+                    ray_indices[base + j] = i;
+                }
+                ++j;
+                m = q + 1;
+            }
+        }
+        // state after the m accepted steps (m is 0..SPEC: select, no indexed registers)
+        t0 = a0[0], t1 = a1[0], t_mid = am[0];
+#pragma unroll
+        for (int q = 1; q <= SPEC; ++q)
+            if (m == q) t0 = a0[q], t1 = a1[q], t_mid = am[q];
+        if (m == n_spec) {       // every speculated step was occupied: keep going at full depth
+            n_spec = SPEC;
+            continue;
+        }
+        if (!(t_mid < far_)) break;
+        // step m is inside the range and its cell is empty (or outside the box): the reference's skip
+        const float x = ox + t_mid * dx, y = oy + t_mid * dy, z = oz + t_mid * dz;
+        const float tx = axis_dist(x, dx, ix, g.roi[0], g.roi[3], g.res[0]);
+        const float ty = axis_dist(y, dy, iy, g.roi[1], g.roi[4], g.res[1]);
+        const float tz = axis_dist(z, dz, iz, g.roi[2], g.roi[5], g.res[2]);
+        float t_target = t_mid + fmaxf(fminf(fminf(tx, ty), tz), 0.0f);
+        t_target = fminf(t_target, far_);
+        float _t = t_mid;
+        do { _t += dt_min; } while (_t < t_target);
+        t_mid = _t;
+        dt = calc_dt(t_mid, cone_angle, dt_min, dt_max);
+        t0 = t_mid - dt * 0.5f;
+        t1 = t_mid + dt * 0.5f;
+        n_spec = (m == 0) ? 1 : SPEC;    // still in empty space: look at one cell next time
     }
     if (!WRITE) num_steps[i] = j;
 }
@@ -400,7 +446,7 @@ int rsdf_march_count(const float *rays_o, const float *rays_d, const float *t_mi
     RSDF_CHECK_ARG(step_size > 0.f, "march_count: step_size must be > 0");
     if (n_rays <= 0) return 0;
     GridDev gd{roi, {res_x, res_y, res_z}, binary};
-    march_entry<false><<<rsdf_blocks(n_rays, 256), 256, 0, (hipStream_t)stream>>>(
+    march_entry<false><<<rsdf_blocks(n_rays, MARCH_THREADS), MARCH_THREADS, 0, (hipStream_t)stream>>>(
         rays_o, rays_d, t_min, t_max, gd, step_size, cone_angle, n_rays, nullptr, num_steps, nullptr,
         nullptr, nullptr);
     RSDF_RETURN_LAUNCH();
@@ -416,7 +462,7 @@ int rsdf_march_write(const float *rays_o, const float *rays_d, const float *t_mi
     RSDF_CHECK_ARG(step_size > 0.f, "march_write: step_size must be > 0");
     if (n_rays <= 0) return 0;
     GridDev gd{roi, {res_x, res_y, res_z}, binary};
-    march_entry<true><<<rsdf_blocks(n_rays, 256), 256, 0, (hipStream_t)stream>>>(
+    march_entry<true><<<rsdf_blocks(n_rays, MARCH_THREADS), MARCH_THREADS, 0, (hipStream_t)stream>>>(
         rays_o, rays_d, t_min, t_max, gd, step_size, cone_angle, n_rays, packed_info, nullptr,
         ray_indices, t_starts, t_ends);
     RSDF_RETURN_LAUNCH();

@@ -929,7 +929,7 @@ extern "C" int rsdf_debug_read_stamps(unsigned long long *out16)
 #endif
 
 // entry points used by mlp_fused.hip's dispatchers
-int rsdf_coop_fwd(int NT, const float *x7t, const float *planes, int n_levels, int n_active, float xyz_scale,
+__attribute__((visibility("hidden"))) int rsdf_coop_fwd(int NT, const float *x7t, const float *planes, int n_levels, int n_active, float xyz_scale,
                   float xyz_offset, int N2, const float *w0, const float *b0, const float *w1, const float *b1,
                   const float *w2, const float *b2, int64_t n_samples, float *sdf7t, float *feature, float *h2c,
                   hipStream_t st)
@@ -965,7 +965,7 @@ int rsdf_coop_fwd(int NT, const float *x7t, const float *planes, int n_levels, i
     RSDF_RETURN_LAUNCH();
 }
 
-int rsdf_coop_bwd(int NT, const float *x7t, const float *planes, int n_levels, int n_active, float xyz_scale,
+__attribute__((visibility("hidden"))) int rsdf_coop_bwd(int NT, const float *x7t, const float *planes, int n_levels, int n_active, float xyz_scale,
                   float xyz_offset, const float *w0, const float *b0, const float *w1, const float *b1, const float *w2,
                   int64_t n_samples, const float *d_sdf7t, const float *dh2c, float *d_planes, float *dw0, float *db0,
                   float *dw1, float *db1, float *dw2, float *db2, hipStream_t st)

@@ -283,8 +283,15 @@ __device__ __forceinline__ void hidden_forward_s(const unsigned char *smem, cons
 // ------------------------------------------------------------------------------------------------
 // forward: tap-major inputs -> sdf7t [7][S], feature [S, N2] (nullable; centre rows only), h2c (nullable)
 // ------------------------------------------------------------------------------------------------
+// RSDF_FWD_VGPR_CAP: 192 registers x 2 waves leave 128 of a SIMD's 512 free, i.e. room for one wave of the stencil
+// gather (fd7_fwd_kernel, 128 registers) beside this kernel: NeuSModel's pipelined forward runs the next chunk's gather on
+// a second stream while this (vector-issue-bound) kernel computes.
+// (on gfx90a+ the attribute counts architectural VGPRs of the unified file: LLVM doubles it, so 96 = 192 unified.)
+#ifndef RSDF_FWD_VGPR_CAP
+#define RSDF_FWD_VGPR_CAP 96
+#endif
 template <int H>
-__global__ void __launch_bounds__(FWD_THREADS, FWD_WAVES / 4)
+__global__ void __launch_bounds__(FWD_THREADS, FWD_WAVES / 4) __attribute__((amdgpu_num_vgpr(RSDF_FWD_VGPR_CAP)))
 sdfmlp_fwd_kernel(const TileSrc src, const float *__restrict__ w0,
                   const float *__restrict__ b0, const float *__restrict__ w1,
                   const float *__restrict__ b1, const float *__restrict__ w2,
@@ -770,26 +777,22 @@ unsigned persistent_grid(int64_t n_samples, int waves)
     return (unsigned)(want < 512 ? (want > 0 ? want : 1) : 512);
 }
 
-bool env_is(const char *name, const char *value)
-{
-    const char *v = getenv(name);
-    return v != nullptr && strcmp(v, value) == 0;
-}
+bool env_is(const char *name, const char *value) { return rsdf_env_is(name, value); }   // cached getenv (core.hip)
 
 }  // namespace
 
 // cooperative kernels (mlp_coop.hip): a workgroup of H/32 waves, wave w owns features 32w..32w+31
-int rsdf_coop_fwd(int NT, const float *x7t, const float *planes, int n_levels, int n_active, float xyz_scale,
+__attribute__((visibility("hidden"))) int rsdf_coop_fwd(int NT, const float *x7t, const float *planes, int n_levels, int n_active, float xyz_scale,
                   float xyz_offset, int N2, const float *w0, const float *b0, const float *w1, const float *b1,
                   const float *w2, const float *b2, int64_t n_samples, float *sdf7t, float *feature, float *h2c,
                   hipStream_t st);
-int rsdf_coop_bwd(int NT, const float *x7t, const float *planes, int n_levels, int n_active, float xyz_scale,
+__attribute__((visibility("hidden"))) int rsdf_coop_bwd(int NT, const float *x7t, const float *planes, int n_levels, int n_active, float xyz_scale,
                   float xyz_offset, const float *w0, const float *b0, const float *w1, const float *b1, const float *w2,
                   int64_t n_samples, const float *d_sdf7t, const float *dh2c, float *d_planes, float *dw0, float *db0,
                   float *dw1, float *db1, float *dw2, float *db2, hipStream_t st);
 
 // quad kernel (mlp_quad.hip): H = 64 backward on 16-feature wave tiles, two waves per SIMD
-int rsdf_quad_bwd(int H, const float *x7t, const float *planes, int n_levels, int n_active, float xyz_scale, float xyz_offset,
+__attribute__((visibility("hidden"))) int rsdf_quad_bwd(int H, const float *x7t, const float *planes, int n_levels, int n_active, float xyz_scale, float xyz_offset,
                   const float *w0, const float *b0, const float *w1, const float *b1, const float *w2, int64_t n_samples,
                   const float *d_sdf7t, const float *dh2c, float *d_planes, float *dw0, float *db0, float *dw1, float *db1,
                   float *dw2, float *db2, hipStream_t st);

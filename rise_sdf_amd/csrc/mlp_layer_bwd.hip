@@ -319,13 +319,8 @@ struct LaunchArgs {
 template <bool HAS_DX, int ACT, bool PREV_RELU, bool TAIL>
 int launch(const LaunchArgs &a)
 {
-    static bool lds_set = false;   // per instantiation; one device per process
-    if (!lds_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(layer_bwd_kernel<HAS_DX, ACT, PREV_RELU, TAIL>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)a.lds);
-        if (e != hipSuccess) { rsdf_set_error(hipGetErrorString(e)); return (int)e; }
-        lds_set = true;
-    }
+    if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(layer_bwd_kernel<HAS_DX, ACT, PREV_RELU, TAIL>), a.lds))
+        return rc;   // per (kernel, device, host thread): autograd calls this from its own thread
     layer_bwd_kernel<HAS_DX, ACT, PREV_RELU, TAIL><<<a.grid, LB_THREADS, a.lds, a.st>>>(
         a.dy, a.y, a.lddy, a.x, a.ldx, a.w, a.n, a.K, a.k0, a.Kout, a.tail, a.dx, a.lddx, a.dw, a.db);
     return 0;

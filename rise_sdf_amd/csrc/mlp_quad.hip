@@ -498,7 +498,7 @@ extern "C" int rsdf_debug_read_qstamps(unsigned long long *out16)
 }
 #endif
 
-int rsdf_quad_bwd(int H, const float *x7t, const float *planes, int n_levels, int n_active, float xyz_scale, float xyz_offset,
+__attribute__((visibility("hidden"))) int rsdf_quad_bwd(int H, const float *x7t, const float *planes, int n_levels, int n_active, float xyz_scale, float xyz_offset,
                   const float *w0, const float *b0, const float *w1, const float *b1, const float *w2, int64_t n_samples,
                   const float *d_sdf7t, const float *dh2c, float *d_planes, float *dw0, float *db0, float *dw1, float *db1,
                   float *dw2, float *db2, hipStream_t st)

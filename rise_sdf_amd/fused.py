@@ -35,7 +35,7 @@ def supported(K0: int, H: int, N2: int, n_hidden_layers: int, hidden_act: str, o
 class _SdfFieldFD7(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x7t, table, w0, b0, w1, b1, w2, b2, meta, n_active, xyz_scale, xyz_offset,
-                eps_unit, want_feature):
+                eps_unit, want_feature, points=None, radius=None, eps=None):
         xf = x7t.detach().to(torch.float32).contiguous()
         assert xf.dim() == 3 and xf.shape[0] == 7 and xf.shape[2] == 3, "x7t must be [7,S,3]"
         tb = table.detach()
@@ -47,8 +47,18 @@ class _SdfFieldFD7(torch.autograd.Function):
         dev = xf.device
         st = stream_ptr()
         planes = torch.empty(Lv, 7, S, 2, dtype=torch.float32, device=dev)
-        check(lib().rsdf_hashgrid_fwd_fd7(ptr(xf), ptr(tb), ctypes.byref(meta), S, n_active, ptr(planes),
-                                          st), "hashgrid_fwd_fd7")
+        pts = None
+        if points is not None:
+            # the hash kernels derive the stencil from the world-space centres (12 instead of 84 bytes per sample and
+            # level); x7t still feeds the xyz columns of the MLP kernels, which read it once
+            pts = points.detach().to(torch.float32).contiguous()
+            require_device(pts)
+            assert pts.shape == (S, 3), "points must be [S,3]"
+            check(lib().rsdf_hashgrid_fwd_fd7_pts(ptr(pts), float(radius), float(eps), ptr(tb), ctypes.byref(meta), S,
+                                                  n_active, ptr(planes), st), "hashgrid_fwd_fd7_pts")
+        else:
+            check(lib().rsdf_hashgrid_fwd_fd7(ptr(xf), ptr(tb), ctypes.byref(meta), S, n_active, ptr(planes),
+                                              st), "hashgrid_fwd_fd7")
         sdf7t = torch.empty(7, S, dtype=torch.float32, device=dev)
         feature = torch.empty(S, N2, dtype=torch.float32, device=dev) if want_feature else None
         h2c = torch.empty(S, H, dtype=torch.float32, device=dev) if want_feature else None
@@ -57,6 +67,7 @@ class _SdfFieldFD7(torch.autograd.Function):
                                         ptr(feature), ptr(h2c), st), "sdfmlp_fd7_fwd")
         ctx.save_for_backward(xf, planes, *ws)
         ctx.h2c = h2c
+        ctx.pts, ctx.radius, ctx.eps = pts, radius, eps
         ctx.meta, ctx.n_active, ctx.eps_unit, ctx.n_params = meta, n_active, float(eps_unit), tb.numel()
         ctx.xyz = (float(xyz_scale), float(xyz_offset))
         ctx.dims = (S, Lv, H, N2)
@@ -66,7 +77,7 @@ class _SdfFieldFD7(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_sdf7t, g_feature):
         if g_sdf7t is None and g_feature is None:
-            return (None,) * 14
+            return (None,) * 17
         xf, planes, w0, b0, w1, b1, w2, b2 = ctx.saved_tensors
         S, Lv, H, N2 = ctx.dims
         dev = xf.device
@@ -96,16 +107,25 @@ class _SdfFieldFD7(torch.autograd.Function):
             if nbytes < 0:
                 raise L.RiseSdfHipError("hashgrid_bwd_fd7: unsupported level layout")
             scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            check(lib().rsdf_hashgrid_bwd_fd7(ptr(xf), ptr(d_planes), ctypes.byref(ctx.meta), S,
-                                              ctx.n_active, ctx.eps_unit, ptr(dt), ptr(scratch), nbytes,
-                                              st), "hashgrid_bwd_fd7")
-        return (None, dt, dw0, db0, dw1, db1, dw2, db2, None, None, None, None, None, None)
+            if ctx.pts is not None:
+                check(lib().rsdf_hashgrid_bwd_fd7_pts(ptr(ctx.pts), float(ctx.radius), float(ctx.eps), ptr(d_planes),
+                                                      ctypes.byref(ctx.meta), S, ctx.n_active, ctx.eps_unit, ptr(dt),
+                                                      ptr(scratch), nbytes, st), "hashgrid_bwd_fd7_pts")
+            else:
+                check(lib().rsdf_hashgrid_bwd_fd7(ptr(xf), ptr(d_planes), ctypes.byref(ctx.meta), S,
+                                                  ctx.n_active, ctx.eps_unit, ptr(dt), ptr(scratch), nbytes,
+                                                  st), "hashgrid_bwd_fd7")
+        return (None, dt, dw0, db0, dw1, db1, dw2, db2, None, None, None, None, None, None, None, None, None)
 
 
 def sdf_field_fd7(x7t, table, weights, meta, n_active, xyz_scale, xyz_offset, eps_unit,
-                  want_feature=False):
+                  want_feature=False, points=None, radius=None, eps=None):
     """weights = [(w0,b0),(w1,b1),(w2,b2)] effective (already weight-normalised) layer parameters.
+    ``points`` [S,3] (world-space sample centres, with ``radius`` and the FD ``eps``): the hash kernels derive the
+    stencil from them instead of re-reading x7t once per level.
     Returns (sdf7t [7,S], feature [S,N2] or None)."""
     (w0, b0), (w1, b1), (w2, b2) = weights
+    if points is not None:
+        assert radius is not None and eps is not None
     return _SdfFieldFD7.apply(x7t, table, w0, b0, w1, b1, w2, b2, meta, int(n_active), xyz_scale,
-                              xyz_offset, eps_unit, bool(want_feature))
+                              xyz_offset, eps_unit, bool(want_feature), points, radius, eps)

@@ -110,13 +110,14 @@ class VolumeSDF(BaseModel):
         """Fused fast path: -> (sdf7t [7, S] tap-major SDF stencil, feature [S, feature_dim] or
         None).  Gradients flow through the SDF values only."""
         from . import fused
-        x7t = ops.fd_points(rays_o, rays_d, ray_indices, t_starts, t_ends, self.radius,
-                            self._finite_difference_eps, tap_major=True)
+        x7t, pts = ops.fd_points(rays_o, rays_d, ray_indices, t_starts, t_ends, self.radius,
+                                 self._finite_difference_eps, want_positions=True, tap_major=True)
         grid, n_active = self.encoding._hash()
         return fused.sdf_field_fd7(
             x7t, grid.params, self.network.effective_weights(), grid.meta,
             grid.n_levels if n_active is None else n_active, self.encoding.xyz_scale,
-            self.encoding.xyz_offset, self._eps_unit(), want_feature)
+            self.encoding.xyz_offset, self._eps_unit(), want_feature,
+            points=pts, radius=self.radius, eps=self._finite_difference_eps)
 
     def _eps_unit(self):
         return self._finite_difference_eps / (2.0 * self.radius)

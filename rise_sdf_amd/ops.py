@@ -754,7 +754,6 @@ def neus_alpha(sdf, normal, dirs, dists, variance, cos_anneal_ratio=1.0):
 # M2 / N2
 # ------------------------------------------------------------------------------------------------
 @torch.no_grad()
-@torch.no_grad()
 def occ_alpha(sdf, variance, render_step_size):
     """occ_eval_fn (models/split_mixed_occ.py:108-119, models/neus.py:101-111): [n] SDF -> [n,1] alpha with
     cos == -1 and dists == render_step_size; inv_s = clip(exp(10 variance), 1e-6, 1e6) on the device."""
@@ -767,6 +766,7 @@ def occ_alpha(sdf, variance, render_step_size):
     return out.view(-1, 1)
 
 
+@torch.no_grad()
 def occ_cell_points(indices, jitter, roi, resolution):
     """lib/nerfacc/grid.py:213-222: world-space sample point of each listed cell (all cells when ``indices`` is
     None): (coords + jitter) / res * (roi_max - roi_min) + roi_min."""

@@ -407,3 +407,93 @@ def test_hashgrid_forward_fd7_bit_exact(dev, ops):
                                               _lib.ptr(planes), _lib.stream_ptr())
         assert rc == 0
         assert torch.equal(planes.cpu().permute(1, 2, 0, 3), ref), eps_unit
+
+
+# ---- H1 / H1b stencil kernels with the taps DERIVED in-kernel from world-space centres ---------------------------
+def _stencil_points(dev, ops, S, eps, radius=1.5, seed=41):
+    """World-space centres incl. box faces, points an ulp outside the box (the marcher's rounding) and far outside,
+    pushed through rsdf_fd_points as degenerate rays (o = p, d = 0) -> (x7t [7,S,3], pts [S,3]) on the device."""
+    g = torch.Generator().manual_seed(seed)
+    p = (torch.rand(S, 3, generator=g) * 2 - 1) * radius
+    up = float(np.nextafter(np.float32(radius), np.float32(2 * radius)))
+    p[:8] = torch.tensor([[radius, radius, radius], [-radius, -radius, -radius], [up, 0.0, -up], [-up, up, 0.3],
+                          [radius - eps, -radius + eps, 0.0], [radius - eps / 2, 0.0, -radius + eps / 2],
+                          [1.7, 1.9, 0.2], [0.0, 0.0, 0.0]])
+    o = p.to(dev)
+    d = torch.zeros_like(o)
+    ri = torch.arange(S, device=dev)
+    t = torch.zeros(S, device=dev)
+    return ops.fd_points(o, d, ri, t, t, radius, eps, want_positions=True, tap_major=True)
+
+
+@pytest.mark.parametrize("eps_cells", [1.0, 6.35, 3.0])
+def test_hashgrid_fd7_pts_forward_bit_exact(dev, ops, eps_cells):
+    """rsdf_hashgrid_fwd_fd7_pts (stencil derived from the centre) == rsdf_hashgrid_fwd_fd7 on
+    the x7t that rsdf_fd_points wrote for the same samples, bit for bit -- and therefore == the generic encoder."""
+    import ctypes
+    from rise_sdf_amd import _lib
+    cfg = GRIDS[1]
+    meta_o, n_params = oracle.grid_meta(**cfg)
+    meta_g, _ = _lib.make_grid_meta(**cfg)
+    radius, S = 1.5, 5000
+    eps = 2 * radius / 8192 * eps_cells        # one finest cell, a mid level's cell, 3 finest cells (slow path)
+    tg = ((torch.rand(n_params, generator=torch.Generator().manual_seed(5)) * 2 - 1) * 1e-4).to(dev)
+    x7t, pts = _stencil_points(dev, ops, S, eps, radius)
+    assert torch.equal(pts, pts) and x7t.shape == (7, S, 3)
+    a = torch.empty(16, 7, S, 2, device=dev)
+    b = torch.full_like(a, float("nan"))
+    assert _lib.lib().rsdf_hashgrid_fwd_fd7(_lib.ptr(x7t), _lib.ptr(tg), ctypes.byref(meta_g), S, 16, _lib.ptr(a),
+                                            _lib.stream_ptr()) == 0
+    assert _lib.lib().rsdf_hashgrid_fwd_fd7_pts(_lib.ptr(pts), radius, eps, _lib.ptr(tg), ctypes.byref(meta_g), S, 16,
+                                                _lib.ptr(b), _lib.stream_ptr()) == 0
+    assert torch.equal(a, b)
+    # and both equal the oracle wherever the whole stencil lies in the unit cube (the oracle's encoder is only defined there;
+    # the out-of-box centres above exist to pin the two kernels' clamping against each other)
+    xc = x7t.cpu()
+    inside = ((xc >= 0) & (xc <= 1)).all(-1).all(0)
+    assert int(inside.sum()) > S - 16
+    ref = oracle.hashgrid_encode(xc[:, inside].reshape(-1, 3), tg.cpu(), meta_o).view(7, -1, 16, 2)
+    assert torch.equal(b.cpu().permute(1, 2, 0, 3)[:, inside], ref)
+
+
+@pytest.mark.parametrize("eps_cells", [1.0, 6.35, 3.0])
+def test_hashgrid_fd7_pts_backward(dev, ops, eps_cells):
+    """The derived-stencil backward against the oracle's fp64-accumulated scatter and against the x7t form."""
+    import ctypes
+    from rise_sdf_amd import _lib
+    cfg = GRIDS[1]
+    meta_o, n_params = oracle.grid_meta(**cfg)
+    meta_g, _ = _lib.make_grid_meta(**cfg)
+    radius, S = 1.5, 6000
+    eps = 2 * radius / 8192 * eps_cells
+    eps_unit = eps / (2 * radius)
+    x7t, pts = _stencil_points(dev, ops, S, eps, radius, seed=43)
+    dpl = torch.randn(16, 7, S, 2, generator=torch.Generator().manual_seed(7)).to(dev)
+    nbytes = int(_lib.lib().rsdf_hashgrid_bwd_fd7_scratch_bytes(ctypes.byref(meta_g), S, 16, eps_unit))
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    d_x = torch.zeros(n_params, device=dev)
+    d_p = torch.zeros(n_params, device=dev)
+    assert _lib.lib().rsdf_hashgrid_bwd_fd7(_lib.ptr(x7t), _lib.ptr(dpl), ctypes.byref(meta_g), S, 16, eps_unit,
+                                            _lib.ptr(d_x), _lib.ptr(scratch), nbytes, _lib.stream_ptr()) == 0
+    assert _lib.lib().rsdf_hashgrid_bwd_fd7_pts(_lib.ptr(pts), radius, eps, _lib.ptr(dpl), ctypes.byref(meta_g), S, 16,
+                                                eps_unit, _lib.ptr(d_p), _lib.ptr(scratch), nbytes,
+                                                _lib.stream_ptr()) == 0
+    scale = float(d_x.abs().max())
+    assert float((d_p - d_x).abs().max()) < 2e-6 * scale      # same records, different summation order only
+    assert int((d_p != 0).sum()) == int((d_x != 0).sum())
+    # against the oracle's fp64-accumulated scatter, on the samples whose whole stencil lies in the unit cube
+    xc = x7t.cpu()
+    inside = ((xc >= 0) & (xc <= 1)).all(-1).all(0)
+    idx = inside.nonzero().view(-1).to(dev)
+    Si = int(idx.numel())
+    d_i = torch.zeros(n_params, device=dev)
+    pts_i, dpl_i = pts[idx].contiguous(), dpl[:, :, idx].contiguous()
+    assert _lib.lib().rsdf_hashgrid_bwd_fd7_pts(_lib.ptr(pts_i), radius, eps, _lib.ptr(dpl_i), ctypes.byref(meta_g), Si,
+                                                16, eps_unit, _lib.ptr(d_i), _lib.ptr(scratch), nbytes,
+                                                _lib.stream_ptr()) == 0
+    t_o = torch.zeros(n_params, requires_grad=True)
+    gout = dpl_i.cpu().permute(1, 2, 0, 3).reshape(7, Si, 32)        # [tap, sample, level * 2 + feature]
+    (oracle.hashgrid_encode(xc[:, inside].reshape(-1, 3), t_o, meta_o).view(7, Si, 32) * gout).sum().backward()
+    scale = float(t_o.grad.abs().max())
+    assert float((d_i.cpu() - t_o.grad).abs().max()) < 1e-5 * scale + 1e-7
+    assert int((d_i.cpu() != 0).sum()) == int((t_o.grad != 0).sum())
