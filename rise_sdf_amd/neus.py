@@ -48,6 +48,16 @@ class VarianceNetwork(nn.Module):
     def forward(self, x):
         return torch.ones([len(x), 1], device=self.variance.device) * self.inv_s
 
+    def effective_variance(self):
+        """The scalar the alpha kernels exponentiate (inv_s = clip(exp(10 v), 1e-6, 1e6) on the device).  With
+        ``modulate`` active (models/neus.py:36-37: ``inv_s.clamp_max(mod_val)``) the clamp is applied to v instead:
+        exp(10 min(v, ln(mod_val) / 10)) == min(exp(10 v), mod_val) up to rounding, and ``torch.minimum`` gives the
+        clamp's gradient (none while the clamp is active)."""
+        if self.modulate and self.do_mod:
+            import math
+            return torch.minimum(self.variance, self.variance.new_tensor(math.log(self.mod_val) / 10.0))
+        return self.variance
+
     def update_step(self, epoch, global_step):
         if self.modulate:
             self.do_mod = global_step > self.mod_start_steps
@@ -114,13 +124,11 @@ class NeuSModel(BaseModel):
     def occ_eval_fn(self, x):
         """models/neus.py:101-111 (A2): alpha with cos == -1 and delta == render_step_size."""
         sdf = self.geometry(x, with_grad=False, with_feature=False)
-        if getattr(self.variance, "modulate", False):
-            raise NotImplementedError("occ_eval_fn with a modulated variance (disabled in the shipped configs)")
-        return ops.occ_alpha(sdf, self.variance.variance, self.render_step_size)      # one kernel (A2)
+        return ops.occ_alpha(sdf, self.variance.effective_variance(), self.render_step_size)      # one kernel (A2)
 
     def get_alpha(self, sdf, normal, dirs, dists):
         """models/neus.py:128-150."""
-        return ops.neus_alpha(sdf, normal, dirs, dists, self.variance.variance,
+        return ops.neus_alpha(sdf, normal, dirs, dists, self.variance.effective_variance(),
                               self.cos_anneal_ratio)
 
     # ---- one ray batch ------------------------------------------------------------------------------
@@ -147,7 +155,7 @@ class NeuSModel(BaseModel):
                     return self.get_alpha(sdf, F.normalize(sdf_grad, p=2, dim=-1), t_dirs,
                                           (t_ends - t_starts)[..., None])
                 out7, tm = self._field7(rays_o, rays_d, ray_indices, t_starts, t_ends)
-                return ops.neus_alpha_fd(out7, self.variance.variance, rays_d, ray_indices,
+                return ops.neus_alpha_fd(out7, self.variance.effective_variance(), rays_d, ray_indices,
                                          t_starts, t_ends, self.cos_anneal_ratio,
                                          self.geometry._finite_difference_eps, tap_major=tm)[3]
         return alpha_fn
@@ -188,7 +196,7 @@ class NeuSModel(BaseModel):
         else:
             out7, tm = self._field7(rays_o, rays_d, ray_indices, t_starts, t_ends)
             sdf, sdf_grad, normal, alpha = ops.neus_alpha_fd(
-                out7, self.variance.variance, rays_d, ray_indices, t_starts, t_ends,
+                out7, self.variance.effective_variance(), rays_d, ray_indices, t_starts, t_ends,
                 self.cos_anneal_ratio, self.geometry._finite_difference_eps, tap_major=tm)
         midpoints = (t_starts + t_ends)[..., None] / 2.0
         weights, _ = ops.render_weight_from_alpha(alpha, packed_info=packed)

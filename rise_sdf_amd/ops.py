@@ -396,6 +396,14 @@ def hashgrid_encode(x, table, meta, n_active_levels=None, include_xyz=False, xyz
 # ------------------------------------------------------------------------------------------------
 # H3
 # ------------------------------------------------------------------------------------------------
+def _dw_db(N, K, has_bias, device):
+    """One zero-fill for both accumulators of a layer (the training step at 4096 rays is launch-bound); db starts at a
+    16-byte aligned offset so that a bias .grad is aligned like any other tensor."""
+    off = (N * K + 3) // 4 * 4
+    buf = torch.zeros(off + (N if has_bias else 0), dtype=torch.float32, device=device)
+    return buf[:N * K].view(N, K), (buf[off:] if has_bias else None)
+
+
 class _Linear(torch.autograd.Function):
     """y = act(x @ w^T + b) on the fp32 matrix cores; backward fused with the activation."""
 
@@ -436,10 +444,7 @@ class _Linear(torch.autograd.Function):
             dx_win = ctypes.c_void_p(dx.data_ptr() + 4 * k0)
         dw = db = None
         if need_w or need_b:
-            # one zero-fill for both accumulators (the step at 4096 rays is launch-bound)
-            buf = torch.zeros(N * K + (N if need_b else 0), dtype=torch.float32, device=xf.device)
-            dw = buf[:N * K].view(N, K)
-            db = buf[N * K:] if need_b else None
+            dw, db = _dw_db(N, K, need_b, xf.device)
         if dw is not None and lib().rsdf_linear_bwd_fused_supported(K, N) and os.environ.get("RSDF_LAYER_BWD") != "split":
             # 128-wide layers: one pass, dz never leaves the CU (mlp_layer_bwd.hip)
             check(lib().rsdf_linear_bwd_fused(ptr(gy), ptr(y), N, ptr(xf), K, ptr(wf), n, K, N, ctx.act, k0, kout,
@@ -499,17 +504,21 @@ class _MLPChain(torch.autograd.Function):
         grads = [None] * (2 * nl)
         dx_in = None
         top, tail = nl - 1, None
+        # frozen / evaluation weights (needs_input_grad says nobody wants dW or db of layer i): that layer runs the plain
+        # input-gradient kernel and allocates, zero-fills and accumulates nothing
+        need_w = [bool(ctx.needs_input_grad[3 + 2 * i] or (ctx.has_bias[i] and ctx.needs_input_grad[4 + 2 * i]))
+                  for i in range(nl)]
         # narrow output layer (<= 4 columns) on top of a 128-wide ReLU layer: only its dz and its weight gradient are
         # computed here; the layer below forms its own input gradient from that dz (rsdf_linear_bwd_fused_tail)
-        if (not split and nl >= 2 and ws[-1].shape[0] <= 4 and ws[-1].shape[1] == 128 and ctx.acts[nl - 2] == relu
+        if (not split and nl >= 2 and need_w[-1] and need_w[-2]
+                and ws[-1].shape[0] <= 4 and ws[-1].shape[1] == 128 and ctx.acts[nl - 2] == relu
                 and bool(lib().rsdf_linear_bwd_fused_supported(ws[-2].shape[1], ws[-2].shape[0]))):
             w, y, xin = ws[-1], ys[-1], ys[-2]
             N, K = w.shape
             dzo = torch.empty_like(g)
             check(lib().rsdf_linear_bwd_input(ptr(g), ptr(y), N, ptr(w), n, K, N, ctx.acts[-1], 0, K, ptr(dzo), None, K, st),
                   "linear_bwd_input")
-            buf = torch.zeros(N * K + (N if ctx.has_bias[-1] else 0), dtype=torch.float32, device=xf.device)
-            dw, db = buf[:N * K].view(N, K), (buf[N * K:] if ctx.has_bias[-1] else None)
+            dw, db = _dw_db(N, K, ctx.has_bias[-1], xf.device)
             check(lib().rsdf_linear_bwd_weight(ptr(dzo), N, ptr(xin), K, n, K, N, ptr(dw), ptr(db), st), "linear_bwd_weight")
             grads[2 * top], grads[2 * top + 1] = dw, db
             tail, top = (dzo, N, w), nl - 2
@@ -529,9 +538,16 @@ class _MLPChain(torch.autograd.Function):
                 if k0 + kout < K:
                     dx[:, k0 + kout:].zero_()
                 dx_win = ctypes.c_void_p(dx.data_ptr() + 4 * k0)
-            buf = torch.zeros(N * K + (N if ctx.has_bias[i] else 0), dtype=torch.float32, device=xf.device)
-            dw = buf[:N * K].view(N, K)
-            db = buf[N * K:] if ctx.has_bias[i] else None
+            if not need_w[i]:
+                if need_dx:
+                    dz = torch.empty_like(g)
+                    check(lib().rsdf_linear_bwd_input(ptr(g), ptr(yarg), N, ptr(w), n, K, N, act, k0, kout, ptr(dz),
+                                                      dx_win, K, st), "linear_bwd_input")
+                g, g_is_dz = dx, False
+                if i == 0:
+                    dx_in = dx
+                continue
+            dw, db = _dw_db(N, K, ctx.has_bias[i], xf.device)
             fused = not split and bool(lib().rsdf_linear_bwd_fused_supported(K, N))
             prev_relu = fused and i > 0 and ctx.acts[i - 1] == relu
             if tail is not None:

@@ -64,12 +64,10 @@ class SplitMixedOCCModel(BaseModel):
 
     def occ_eval_fn(self, x):
         sdf = self.geometry(x, with_grad=False, with_feature=False)
-        if getattr(self.variance, "modulate", False):
-            raise NotImplementedError("occ_eval_fn with a modulated variance (disabled in the shipped configs)")
-        return ops.occ_alpha(sdf, self.variance.variance, self.render_step_size)      # one kernel (A2)
+        return ops.occ_alpha(sdf, self.variance.effective_variance(), self.render_step_size)      # one kernel (A2)
 
     def get_alpha(self, sdf, normal, dirs, dists):
-        return ops.neus_alpha(sdf, normal, dirs, dists, self.variance.variance, self.cos_anneal_ratio)
+        return ops.neus_alpha(sdf, normal, dirs, dists, self.variance.effective_variance(), self.cos_anneal_ratio)
 
     # ---- field access -----------------------------------------------------------------------------------
     def _stencil(self, rays_o, rays_d, ray_indices, t_starts, t_ends, want_feature):
@@ -87,11 +85,11 @@ class SplitMixedOCCModel(BaseModel):
         if self.config.get("fused", True) and geo.fused_field_available():
             sdf7t, feature = geo.sdf7_from_rays(rays_o, rays_d, ray_indices, t_starts, t_ends,
                                                 want_feature=want_feature)
-            out = ops.neus_alpha_fd(sdf7t, self.variance.variance, rays_d, ray_indices, t_starts, t_ends,
+            out = ops.neus_alpha_fd(sdf7t, self.variance.effective_variance(), rays_d, ray_indices, t_starts, t_ends,
                                     self.cos_anneal_ratio, eps, tap_major=True)
             return (*out, feature)
         out7 = geo.field7_from_rays(rays_o, rays_d, ray_indices, t_starts, t_ends)
-        out = ops.neus_alpha_fd(out7, self.variance.variance, rays_d, ray_indices, t_starts, t_ends,
+        out = ops.neus_alpha_fd(out7, self.variance.effective_variance(), rays_d, ray_indices, t_starts, t_ends,
                                 self.cos_anneal_ratio, eps)
         feature = out7.view(-1, 7, out7.shape[-1])[:, 0] if want_feature else None
         return (*out, feature)

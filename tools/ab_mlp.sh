@@ -4,11 +4,16 @@
 set -euo pipefail
 : "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (sets GRAFT_REPO_ROOT)}"
 cd "$GRAFT_REPO_ROOT/rise_sdf_amd/csrc"
+# experiment objects and the variant library live in /tmp/ab and are selected with RSDF_LIB (rise_sdf_amd/_lib.py): the
+# shipped rise_sdf_amd/librisesdf_hip.so and _build/ are never overwritten
+mkdir -p /tmp/ab; rm -f /tmp/ab/*.o
+export RSDF_LIB=/tmp/ab/librisesdf_hip.variant.so
+variant_objs() { for o in _build/*.o; do b=$(basename $o); if [ -f /tmp/ab/$b ]; then echo /tmp/ab/$b; else echo $o; fi; done; }
 for v in "$@"; do
   for f in mlp_fused mlp_coop mlp_quad; do
-    /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -I../../include $v -c $f.hip -o _build/$f.o
+    /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -I../../include $v -c $f.hip -o /tmp/ab/$f.o
   done
-  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 _build/*.o -o ../librisesdf_hip.so
+  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $(variant_objs) -o $RSDF_LIB
   for h in 64 128; do
   (cd ../.. && python bench.py --steps 2 --warmup 1 --cpu-rays 0 --width 400 --height 400 --hidden $h 2>/dev/null | tail -1 | python3 -c "
 import json,sys

@@ -4,8 +4,13 @@
 set -euo pipefail
 : "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (sets GRAFT_REPO_ROOT)}"
 cd "$GRAFT_REPO_ROOT/rise_sdf_amd/csrc"
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -I../../include -DRSDF_STAMPS ${STAMP_FLAGS:-} -c mlp_quad.hip -o _build/mlp_quad.o
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 _build/*.o -o ../librisesdf_hip.so
+# experiment objects and the variant library live in /tmp/ab and are selected with RSDF_LIB (rise_sdf_amd/_lib.py): the
+# shipped rise_sdf_amd/librisesdf_hip.so and _build/ are never overwritten
+mkdir -p /tmp/ab; rm -f /tmp/ab/*.o
+export RSDF_LIB=/tmp/ab/librisesdf_hip.variant.so
+variant_objs() { for o in _build/*.o; do b=$(basename $o); if [ -f /tmp/ab/$b ]; then echo /tmp/ab/$b; else echo $o; fi; done; }
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -I../../include -DRSDF_STAMPS ${STAMP_FLAGS:-} -c mlp_quad.hip -o /tmp/ab/mlp_quad.o
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $(variant_objs) -o $RSDF_LIB
 cd ../..
 python3 - <<'PY'
 import ctypes, sys, io, contextlib, runpy
