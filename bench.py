@@ -269,11 +269,173 @@ def attach_traffic(roof, path):
                               f"{per_sample:.0f} B/sample fetched+written x samples per launch")
 
 
+def measure_c1(model, rays, jitter, cot, chunk, steps, warmup, world=1, buckets=None, timing=True):
+    """``warmup`` untimed + ``steps`` timed passes over all rays (fwd+bwd per chunk, gradients accumulated, then the
+    gradient all-reduce for world > 1) -> dict(dt, samples, summary)."""
+    from rise_sdf_amd import _lib
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        S = run_step(model, rays, jitter, cot, chunk)
+        if buckets is not None:
+            buckets.all_reduce_mean(world)
+        return S
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    timer = None
+    if timing:
+        timer = _lib.KernelTimer()
+        _lib.set_timer(timer)
+    barrier()
+    t0 = time.perf_counter()
+    samples = 0
+    for _ in range(steps):
+        samples += step()
+    barrier()
+    dt = time.perf_counter() - t0
+    _lib.set_timer(None)
+    return {"dt": dt, "samples": samples, "summary": timer.summary() if timer is not None else None}
+
+
+def brief(res, steps):
+    """samples/s + the dominant kernel's roofline fraction of a secondary measurement."""
+    out = {"samples_per_s": res["samples"] / res["dt"], "ms_per_step": res["dt"] / steps * 1e3,
+           "samples_per_step": res["samples"] / steps}
+    if res.get("summary"):
+        roof, _ = roofline_from(res["summary"], steps)
+        if roof is not None:
+            out["dominant_kernel"] = {k: roof.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac",
+                                                               "avg_launch_ms")}
+    return out
+
+
+def secondary_measurements(dev, args, rays, jitter, cot):
+    """the numbers outside the headline configuration, measured by the same command so that the
+    driver's run records them: c1 at 4096-ray chunks (the reference's ray_chunk), c1 at the yaml's MLP width, the
+    per-layer drop-in route INTEGRATION.md leads with, config[2] on the full 800x800 view, and the config[3] training
+    step at the reference's 262,144-samples operating point.  Untimed for ``value``; each entry is guarded so that a
+    failure is recorded instead of losing the headline line."""
+    import gc
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    extras = {}
+
+    def guarded(name, fn):
+        gc.collect()
+        torch.cuda.empty_cache()
+        try:
+            extras[name] = fn()
+        except Exception as e:   # noqa: BLE001  (recorded, not swallowed: the key carries the error)
+            extras[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+
+    def c1_variant(hidden, chunk, n_rays=None, fused=True, steps=1, warmup=1):
+        a = argparse.Namespace(hidden=hidden)
+        m = build_model(dev, a)
+        if not fused:
+            m.config["fused"] = False
+        r = rays if n_rays is None else rays[:n_rays]
+        res = measure_c1(m, r, jitter[:r.shape[0]], [c[:r.shape[0]] for c in cot], chunk, steps, warmup)
+        out = brief(res, steps)
+        out["config"] = {"hidden": hidden, "chunk_rays": chunk, "rays": int(r.shape[0]),
+                         "fused_stencil_kernels": bool(m._fused_ok())}
+        return out
+
+    guarded("chunk4096", lambda: c1_variant(args.hidden, 4096))
+    guarded("h128", lambda: c1_variant(128, args.chunk))
+    # the per-layer API route (tcnn.Encoding / VanillaMLP shaped calls, one or a few kernels each; INTEGRATION.md's
+    # two-line dropin.install()): [7 S, 35] rows through HBM, so a quarter of the view at the reference's chunk size
+    guarded("dropin_path", lambda: c1_variant(args.hidden, 4096, n_rays=rays.shape[0] // 4 // 800 * 800, fused=False))
+
+    def c2():
+        from bench_c2 import measure_c2
+        r = measure_c2(dev, args.width, args.height, 16384, stage=1, tex_hidden=128, steps=1)
+        out = brief({"dt": r["ms_per_step"] / 1e3, "samples": r["samples_per_step"], "summary": r["summary"]}, 1)
+        out["workload"] = r["workload"]
+        return out
+    guarded("c2_800", c2)
+
+    def c3():
+        from bench_step import measure
+        r = measure(dev, stage=1, steps=30, settle=80)
+        return {k: r[k] for k in ("ms_per_step", "rays_per_step", "samples_per_step", "samples_per_s",
+                                  "rsdf_kernel_ms_per_step", "top", "hidden", "stage")}
+    guarded("c3_step", c3)
+    return extras
+
+
+def run_c3(args, rank, local, world, dev):
+    """BASELINE.json config[3]: the split-mixed-occ training step with occupancy-grid marching, <= 4096 rays per rank
+    steered to 262,144 samples per step (systems/split_occ.py:51,159-161), one process per GPU, gradient mean over the
+    ranks after every backward (launch.py:84-97).  A step = update_step (occupancy update every 16th) + ray batch +
+    build_mips + forward + loss + backward + all-reduce + Adam; value = surviving samples of all ranks per second."""
+    from rise_sdf_amd import _lib
+    from rise_sdf_amd.step import build_synthetic_training
+    model, ts = build_synthetic_training(dev, stage=1, hidden=args.hidden if args.hidden != 64 else 128, rank=rank,
+                                         world=world)
+    gs = 20000
+    warm = max(args.warmup, 80)                      # dynamic_ray_sampling needs ~60 steps to reach the operating point
+    for k in range(warm):
+        ts.step(gs + k)
+    gs += warm
+    timer = None
+    if rank == 0 and not args.no_kernel_timing:
+        timer = _lib.KernelTimer()
+        _lib.set_timer(timer)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    samples = rays = 0
+    for k in range(args.steps):
+        r = ts.step(gs + k)
+        samples += r["num_samples"]
+        rays += r["num_rays"]
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    _lib.set_timer(None)
+    tt = torch.tensor([dt, float(samples), float(rays)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = tt[0:1].clone()
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        ssum = tt[1:3].clone()
+        torch.distributed.all_reduce(ssum, op=torch.distributed.ReduceOp.SUM)
+        dt, samples, rays = float(tmax), float(ssum[0]), float(ssum[1])
+    if rank == 0:
+        roof = breakdown = None
+        if timer is not None:
+            roof, breakdown = roofline_from(timer.summary(), args.steps)
+        print(json.dumps({
+            "metric": "ray-marched SDF samples/sec (fwd+bwd), occupancy-pruned training step", "value": samples / dt,
+            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": warm,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "c3: split-mixed-occ (yaml sizes) training step, occupancy-grid marching, <= 4096 rays "
+                                   "per rank steered to 262,144 samples, stage 1, grad all-reduce",
+                       "hidden": int(model.geometry.network.n_neurons), "rccl_ranks": world,
+                       "dist_backend": torch.distributed.get_backend() if world > 1 else None,
+                       "rays_per_step": rays / args.steps, "samples_per_step": samples / args.steps,
+                       "parallelism": f"ray-parallel x{world}"},
+            "roofline": roof, "cpu_baseline": None, "kernel_breakdown": breakdown}))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c1", choices=["c1", "c3"],
+                    help="c1 = BASELINE.json config[1] (the metric); c3 = the occupancy-pruned N-rank training step")
     ap.add_argument("--chunk", type=int, default=32768,
                     help="rays per forward/backward chunk (~5 KB of HBM scratch per sample: 32768 rays = ~100 GB)")
     ap.add_argument("--width", type=int, default=800)
@@ -282,6 +444,8 @@ def main():
     ap.add_argument("--cpu-rays", type=int, default=4096,
                     help="upper bound on the rays in the CPU-baseline sample (0 = skip); shrunk to fit ~8 s/repetition")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the secondary measurements appended to the line at N = 1 (see secondary_measurements)")
     ap.add_argument("--pmc-summary", default=os.path.join(ROOT, "profiles", "pmc_summary.json"),
                     help="committed per-kernel HBM traffic from separate rocprofv3 --pmc passes (tools/pmc_passes.sh)")
     args = ap.parse_args()
@@ -299,8 +463,9 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the product path)"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    if args.workload == "c3":
+        return run_c3(args, rank, local, world, dev)
 
-    from rise_sdf_amd import _lib
     from rise_sdf_amd.ray_utils import orbit_view_rays
     model = build_model(dev, args)
     rays = orbit_view_rays(args.width, args.height, seed=rdist.rank_seed(0, rank), device=dev)   # HIP ray generator
@@ -312,32 +477,9 @@ def main():
            torch.randn(n_rays, 3, generator=g).to(dev)]
     buckets = rdist.GradBuckets(model.parameters())
 
-    def step():
-        for p in model.parameters():
-            p.grad = None
-        S = run_step(model, rays, jitter, cot, args.chunk)
-        buckets.all_reduce_mean(world)
-        return S
-
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    timer = None
-    if rank == 0 and not args.no_kernel_timing:
-        timer = _lib.KernelTimer()
-        _lib.set_timer(timer)
-    barrier()
-    t0 = time.perf_counter()
-    samples = 0
-    for _ in range(args.steps):
-        samples += step()
-    barrier()
-    dt = time.perf_counter() - t0
-    _lib.set_timer(None)
+    res = measure_c1(model, rays, jitter, cot, args.chunk, args.steps, args.warmup, world, buckets,
+                     timing=(rank == 0 and not args.no_kernel_timing))
+    dt, samples = res["dt"], res["samples"]
 
     tt = torch.tensor([dt, float(samples)], dtype=torch.float64, device=dev)
     if world > 1:
@@ -349,8 +491,8 @@ def main():
 
     if rank == 0:
         roof, breakdown = (None, None)
-        if timer is not None:
-            roof, breakdown = roofline_from(timer.summary(), args.steps)
+        if res["summary"] is not None:
+            roof, breakdown = roofline_from(res["summary"], args.steps)
             attach_traffic(roof, args.pmc_summary)
             if roof is not None and "other_kernels" in roof:
                 fd7 = roof["other_kernels"].get("rsdf_hashgrid_fwd_fd7_pts") or \
@@ -382,6 +524,9 @@ def main():
                        "field_evals_per_sec": 7 * samples / dt, "parallelism": f"ray-parallel x{world}"},
             "roofline": roof, "cpu_baseline": cpu, "kernel_breakdown": breakdown,
         }
+        if world == 1 and not args.no_extras:
+            del model, buckets
+            line["secondary"] = secondary_measurements(dev, args, rays, jitter, cot)
         print(json.dumps(line))
     if world > 1:
         torch.distributed.barrier()

@@ -19,6 +19,21 @@ def _f(t):
     return None if t is None else t.detach().to(torch.float32).contiguous()
 
 
+_LAMBDA_CACHE = {}
+
+
+def _lambda_tensor(lam, dev):
+    """The nine coefficients on the device.  They change rarely (a scheduled lambda at most once per step), so the
+    host-to-device copy -- a synchronising call in the middle of the step -- is made once per distinct tuple."""
+    key = (tuple(lam), str(dev))
+    t = _LAMBDA_CACHE.get(key)
+    if t is None:
+        if len(_LAMBDA_CACHE) > 64:
+            _LAMBDA_CACHE.clear()
+        t = _LAMBDA_CACHE[key] = torch.tensor(lam, dtype=torch.float32, device=dev)
+    return t
+
+
 class _LossTail(torch.autograd.Function):
     @staticmethod
     def forward(ctx, comp_rgb, comp_rgb_phys, opacity, sdf, sdf_grad, laplace, target, rays_valid, fg_mask,
@@ -47,7 +62,7 @@ class _LossTail(torch.autograd.Function):
             terms[4] = 0.0
         if lp is None:
             terms[8] = 0.0
-        lam_t = torch.tensor(lam, dtype=torch.float32, device=dev)
+        lam_t = _lambda_tensor(lam, dev)
         # per-term normalisers for the backward: 1 / (3 valid) x4, 1 / N x2, 1 / S x3
         inv = torch.cat([(1.0 / n3).to(torch.float32).expand(4), torch.full((2,), 1.0 / N, device=dev),
                          torch.full((3,), 1.0 / max(S, 1), device=dev)])

@@ -244,6 +244,9 @@ class OccGridEstimator(nn.Module):
         self.register_buffer("grid_coords", _meshgrid3d(resolution).reshape(self.cells_per_lvl, 3),
                              persistent=False)
         self.register_buffer("grid_indices", torch.arange(self.cells_per_lvl), persistent=False)
+        # optional torch.Generator for the update's random cells / jitter (rise_sdf_amd.step.TrainStep seeds one alike on
+        # every rank so that the replicated grids stay identical); None = the global generator, as the reference
+        self.rng = None
 
     @property
     def device(self):
@@ -285,10 +288,10 @@ class OccGridEstimator(nn.Module):
 
     @torch.no_grad()
     def _sample_uniform_and_occupied_cells(self, n: int):
-        uniform = torch.randint(self.cells_per_lvl, (n,), device=self.device)
+        uniform = torch.randint(self.cells_per_lvl, (n,), device=self.device, generator=self.rng)
         occupied = torch.nonzero(self.binaries[0].flatten())[:, 0]
         if n < len(occupied):
-            occupied = occupied[torch.randint(len(occupied), (n,), device=self.device)]
+            occupied = occupied[torch.randint(len(occupied), (n,), device=self.device, generator=self.rng)]
         return torch.cat([uniform, occupied], dim=0)
 
     @torch.no_grad()
@@ -299,7 +302,8 @@ class OccGridEstimator(nn.Module):
                 self._sample_uniform_and_occupied_cells(self.cells_per_lvl // 4)
         all_cells = indices is self.grid_indices
         if cell_jitter is None:
-            cell_jitter = torch.rand((indices.numel(), 3), dtype=torch.float32, device=self.occs.device)
+            cell_jitter = torch.rand((indices.numel(), 3), dtype=torch.float32, device=self.occs.device,
+                                     generator=self.rng)
         x = ops.occ_cell_points(None if all_cells else indices, cell_jitter, self.aabbs[0], self.resolution.tolist())
         occ = occ_eval_fn(x).squeeze(-1)
         ops.occ_update(self.occs, self.binaries.view(torch.uint8).view(-1), None if all_cells else indices, occ,

@@ -209,9 +209,10 @@ class NeuSModel(BaseModel):
             "opacity": opacity,
             "depth": depth,
             "rays_valid": opacity > 0,
-            "num_samples": torch.as_tensor([S], dtype=torch.int32, device=dev),
+            "num_samples": torch.full((1,), S, dtype=torch.int32, device=dev),
         }
         if self.training:
+            out["num_samples_host"] = int(S)      # see split_mixed_occ.py: no second host read for dynamic_ray_sampling
             out.update({"sdf_samples": sdf, "sdf_grad_samples": sdf_grad,
                         "weights": weights.view(-1), "points": midpoints.view(-1),
                         "intervals": (t_ends - t_starts).view(-1),

@@ -193,13 +193,16 @@ class SplitMixedOCCModel(BaseModel):
         out = {"comp_rgb": rgb, "comp_diffuse_rgb": diff_rgb_map, "comp_spec_rgb": spec_rgb_map,
                "comp_blend": blend_map, "comp_normal": normal_map, "opacity": acc_map, "depth": depth_map,
                "rays_valid": acc_map > 0,
-               "num_samples": torch.as_tensor([len(t_starts)], dtype=torch.int32, device=dev)}
+               "num_samples": torch.full((1,), len(t_starts), dtype=torch.int32, device=dev)}   # (a fill kernel: no host-to-device copy)
         if self.stage != 0:
             out.update({"comp_rgb_phys": diff_rgb_pbr_map + spec_rgb_pbr_map,
                         "comp_diffuse_rgb_phys": diff_rgb_pbr_map, "comp_spec_rgb_phys": spec_rgb_pbr_map,
                         "comp_albedo": albedo_map, "comp_metallic": metallic_map, "comp_roughness": roughness_map})
         if self.training:
             weights = extras["weights"]
+            # the host already holds the sample count (the sampler sized its outputs with it): hand it on, so that
+            # dynamic_ray_sampling (systems/split_occ.py:160 ``.item()``) needs no second read
+            out["num_samples_host"] = int(t_starts.shape[0])
             out.update({"sdf_samples": extras["sdf"], "sdf_grad_samples": extras["sdf_grad"],
                         "weights": weights.view(-1), "ray_indices": ray_indices.view(-1)})
             if has_laplace:

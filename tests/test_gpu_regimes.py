@@ -175,7 +175,7 @@ def test_bench_two_ranks_on_one_gpu(dev):
     env = dict(os.environ, RSDF_DIST_SHARE_GPU="1")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
-    common = ["--steps", "1", "--warmup", "1", "--width", "96", "--height", "96", "--chunk", "4608", "--cpu-rays", "0"]
+    common = ["--steps", "1", "--warmup", "1", "--width", "96", "--height", "96", "--chunk", "4608", "--cpu-rays", "0", "--no-extras"]
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common, env=env,
                         capture_output=True, text=True, timeout=900)
     assert r2.returncode == 0, r2.stderr[-2000:]

@@ -14,21 +14,16 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--width", type=int, default=800)
-    ap.add_argument("--height", type=int, default=800)
-    ap.add_argument("--chunk", type=int, default=16384)
-    ap.add_argument("--stage", type=int, default=1)
-    ap.add_argument("--tex-hidden", type=int, default=128)
-    ap.add_argument("--steps", type=int, default=1)
-    args = ap.parse_args()
+def measure_c2(dev, width=800, height=800, chunk=16384, stage=1, tex_hidden=128, steps=1, hidden=64):
+    """-> dict(samples_per_s, ms_per_step, samples_per_step, kernel_ms_total, top, summary): one view of config[2]
+    (c1 + radiance branch + split-sum shading against a 512^2 environment), fwd+bwd, one build_mips per step."""
+    import types
+    args = types.SimpleNamespace(width=width, height=height, chunk=chunk, stage=stage, tex_hidden=tex_hidden, steps=steps)
     import rise_sdf_amd as R
     from rise_sdf_amd import _lib
     from rise_sdf_amd.ray_utils import orbit_view_rays
     import bench
-    dev = torch.device("cuda", 0)
-    cfg = bench.c1_config(hidden=64)
+    cfg = bench.c1_config(hidden=hidden)
     mlp = lambda n: {"otype": "VanillaMLP", "activation": "ReLU", "output_activation": "none",
                      "n_neurons": args.tex_hidden, "n_hidden_layers": n}
     feat = cfg["geometry"]["feature_dim"]
@@ -93,10 +88,24 @@ def main():
     _lib.set_timer(None)
     summ = timer.summary()
     top = {k: round(v["ms"] / args.steps, 1) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:14]}
-    print(json.dumps({"workload": f"c2 stage {model.stage}: split-mixed-occ, {args.width}x{args.height}, texture width "
-                                  f"{args.tex_hidden}, env 512^2", "samples_per_s": samples / dt,
-                      "ms_per_step": dt / args.steps * 1e3, "samples_per_step": samples / args.steps,
-                      "kernel_ms_total": round(sum(v["ms"] for v in summ.values()) / args.steps, 1), "top": top}))
+    return {"workload": f"c2 stage {model.stage}: split-mixed-occ, {args.width}x{args.height}, texture width "
+                        f"{args.tex_hidden}, env 512^2", "samples_per_s": samples / dt,
+            "ms_per_step": dt / args.steps * 1e3, "samples_per_step": samples / args.steps,
+            "kernel_ms_total": round(sum(v["ms"] for v in summ.values()) / args.steps, 1), "top": top, "summary": summ}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--width", type=int, default=800)
+    ap.add_argument("--height", type=int, default=800)
+    ap.add_argument("--chunk", type=int, default=16384)
+    ap.add_argument("--stage", type=int, default=1)
+    ap.add_argument("--tex-hidden", type=int, default=128)
+    ap.add_argument("--steps", type=int, default=1)
+    args = ap.parse_args()
+    r = measure_c2(torch.device("cuda", 0), args.width, args.height, args.chunk, args.stage, args.tex_hidden, args.steps)
+    r.pop("summary")
+    print(json.dumps(r))
 
 
 if __name__ == "__main__":

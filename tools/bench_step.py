@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""The config[3] / config[4]-shaped training step at the reference's operating point: the full split-mixed-occ model at
+the yaml's sizes, occupancy-grid update + pruned sampling, <= 4096 rays steered by dynamic_ray_sampling to 256 * 1024 =
+262,144 samples per step (systems/split_occ.py:51,159-161), loss tail, Adam.
+
+    python tools/bench_step.py [--stage 1] [--steps 30] [--settle 80] [--syncs]
+
+Prints one JSON line: ms per step, rays and samples per step at the operating point, the device time of the rsdf_*
+entry points per step, and (--syncs) the number of host-synchronising calls in one step."""
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def build(dev, stage=1, hidden=128, **kw):
+    from rise_sdf_amd.step import build_synthetic_training
+    return build_synthetic_training(dev, stage=stage, hidden=hidden, **kw)
+
+
+def count_syncs(fn):
+    """Host-synchronising torch calls inside fn(), by torch.cuda's sync debug mode (one warning per call)."""
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("warn")
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            fn()
+        n = sum(1 for x in w if "synchroniz" in str(x.message).lower())
+        sites = {}
+        for x in w:
+            if "synchroniz" in str(x.message).lower():
+                k = "%s:%d" % (os.path.basename(x.filename), x.lineno)
+                sites[k] = sites.get(k, 0) + 1
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    return n, sites
+
+
+def measure(dev, stage=1, steps=30, settle=80, first_step=20000, syncs=False, hidden=128, quiet=True):
+    from rise_sdf_amd import _lib
+    model, ts = build(dev, stage=stage, hidden=hidden)
+    gs = first_step                      # past the progressive-level ramp: all 16 levels, eps = one finest cell
+    traj = []
+    for k in range(settle):              # occupancy grid + dynamic ray count settle at the operating point
+        r = ts.step(gs + k)
+        traj.append((r["num_rays"], r["num_samples"]))
+    gs += settle
+    timer = _lib.KernelTimer()
+    _lib.set_timer(timer)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rays = samples = 0
+    for k in range(steps):
+        r = ts.step(gs + k)
+        rays += r["num_rays"]
+        samples += r["num_samples"]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    _lib.set_timer(None)
+    summ = timer.summary()
+    out = {"stage": int(model.stage), "hidden": hidden, "ms_per_step": dt / steps * 1e3, "steps_per_s": steps / dt,
+           "rays_per_step": rays / steps, "samples_per_step": samples / steps, "samples_per_s": samples / dt,
+           "rsdf_kernel_ms_per_step": round(sum(v["ms"] for v in summ.values()) / steps, 2),
+           "top": {k: round(v["ms"] / steps, 2) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:10]},
+           "settle_first": traj[:3], "settle_last": traj[-3:]}
+    if syncs:
+        n, sites = count_syncs(lambda: ts.step(gs + steps))
+        out["host_syncs_per_step"], out["sync_sites"] = n, sites
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--stage", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--settle", type=int, default=80)
+    ap.add_argument("--hidden", type=int, default=128)
+    ap.add_argument("--syncs", action="store_true")
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    print(json.dumps(measure(dev, args.stage, args.steps, args.settle, syncs=args.syncs, hidden=args.hidden)))
+
+
+if __name__ == "__main__":
+    main()
