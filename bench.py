@@ -33,9 +33,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: fp32 matrix peak
+MFMA_BF16_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 matrix peak (the sparsity-doubled headline is never used)
 
 
-def c1_config(hidden=64, n_levels=16, log2_T=19, base=32, feat=48):
+def c1_config(hidden=64, n_levels=16, log2_T=19, base=32, feat=48, precision="fp32"):
     from rise_sdf_amd import Config
     return Config({
         "name": "neus", "radius": 1.5, "num_samples_per_ray": 1024, "randomized": True,
@@ -52,7 +53,7 @@ def c1_config(hidden=64, n_levels=16, log2_T=19, base=32, feat=48):
             "mlp_network_config": {
                 "otype": "VanillaMLP", "activation": "ReLU", "output_activation": "none",
                 "n_neurons": hidden, "n_hidden_layers": 2, "sphere_init": True,
-                "sphere_init_radius": 0.5, "weight_norm": True},
+                "sphere_init_radius": 0.5, "weight_norm": True, "precision": precision},
         },
     })
 
@@ -60,7 +61,7 @@ def c1_config(hidden=64, n_levels=16, log2_T=19, base=32, feat=48):
 def build_model(dev, args):
     import rise_sdf_amd as R
     torch.manual_seed(0)
-    model = R.make("neus", c1_config(hidden=args.hidden)).to(dev)
+    model = R.make("neus", c1_config(hidden=args.hidden, precision=getattr(args, "precision", "fp32"))).to(dev)
     enc = model.geometry.encoding.encoding.encoding
     gen = torch.Generator().manual_seed(0)
     with torch.no_grad():
@@ -155,6 +156,9 @@ def cpu_baseline(model, rays_cpu, jitter_cpu, max_rays, budget_s=8.0, reps=3):
 def roofline_from(summary, steps):
     """Pick the entry point with the most device time and price it against its roofline."""
     def cost(name, a):
+        if name.endswith("_bf16"):           # config[4]'s bf16 MLP mode: same algorithmic flops, bf16 matrix peak
+            b, w = cost(name[:-5], a)
+            return ("mfma_bf16" if b == "mfma" else b), w
         # scalar args in ABI order (see include/risesdf_hip.h)
         if name == "rsdf_hashgrid_fwd":      # n, n_active, ld_out, col_off, write_xyz, scale, offset
             n, L = a[0], 16
@@ -183,7 +187,7 @@ def roofline_from(summary, steps):
     def samples_of(name, a):
         if name.endswith("_fd7_pts"):
             return a[2]
-        return a[6] if name.startswith("rsdf_sdfmlp_fd7") else a[0]
+        return a[6] if name.startswith("rsdf_sdfmlp_fd7") else a[0]   # (also the _bf16 names)
 
     best = max(summary.items(), key=lambda kv: kv[1]["ms"])
     name, d = best
@@ -198,7 +202,9 @@ def roofline_from(summary, steps):
     if bound == "hbm":
         ach, peak, unit = work / secs / 1e9, HBM_PEAK_GBS, "GB/s"
     else:
-        ach, peak, unit = work / secs / 1e12, MFMA_F32_PEAK_TF, "TFLOP/s"
+        ach, peak, unit = work / secs / 1e12, (MFMA_BF16_PEAK_TF if bound == "mfma_bf16" else MFMA_F32_PEAK_TF), "TFLOP/s"
+    bf16 = bound == "mfma_bf16"
+    bound = "mfma" if bf16 else bound
     out = {"bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
            "frac": round(ach / peak, 4), "traffic": None, "kernel": name,
            "avg_launch_ms": round(d["ms"] / d["calls"], 4), "launches": d["calls"],
@@ -211,10 +217,13 @@ def roofline_from(summary, steps):
             continue
         wk = sum(cost(k, a)[1] for a in v["args"])
         a_, p_, u_ = (wk / (v["ms"] / 1e3) / 1e9, HBM_PEAK_GBS, "GB/s") if b == "hbm" else \
-            (wk / (v["ms"] / 1e3) / 1e12, MFMA_F32_PEAK_TF, "TFLOP/s")
-        others[k] = {"bound": b, "achieved": round(a_, 2), "peak": p_, "unit": u_, "frac": round(a_ / p_, 4)}
+            (wk / (v["ms"] / 1e3) / 1e12, MFMA_BF16_PEAK_TF if b == "mfma_bf16" else MFMA_F32_PEAK_TF, "TFLOP/s")
+        others[k] = {"bound": "mfma" if b == "mfma_bf16" else b, "achieved": round(a_, 2), "peak": p_, "unit": u_,
+                     "frac": round(a_ / p_, 4)}
     out["other_kernels"] = others
-    if name.startswith("rsdf_sdfmlp_fd7"):
+    if bf16:
+        out["note"] = "one bf16 x bf16 MFMA product per k-step, fp32 accumulate; peak = dense bf16 MFMA"
+    elif name.startswith("rsdf_sdfmlp_fd7"):
         # algorithmic fp32 flops against the fp32 MFMA peak; the kernel evaluates each fp32 product as six
         # bf16 x bf16 partial products on v_mfma_f32_32x32x16_bf16, whose own ceiling for
         # fp32-equivalent work is 2500 / 6 = 417 TFLOP/s
@@ -334,20 +343,22 @@ def secondary_measurements(dev, args, rays, jitter, cot):
         except Exception as e:   # noqa: BLE001  (recorded, not swallowed: the key carries the error)
             extras[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
 
-    def c1_variant(hidden, chunk, n_rays=None, fused=True, steps=1, warmup=1):
-        a = argparse.Namespace(hidden=hidden)
+    def c1_variant(hidden, chunk, n_rays=None, fused=True, steps=1, warmup=1, precision="fp32"):
+        a = argparse.Namespace(hidden=hidden, precision=precision)
         m = build_model(dev, a)
         if not fused:
             m.config["fused"] = False
         r = rays if n_rays is None else rays[:n_rays]
         res = measure_c1(m, r, jitter[:r.shape[0]], [c[:r.shape[0]] for c in cot], chunk, steps, warmup)
         out = brief(res, steps)
-        out["config"] = {"hidden": hidden, "chunk_rays": chunk, "rays": int(r.shape[0]),
+        out["config"] = {"hidden": hidden, "chunk_rays": chunk, "rays": int(r.shape[0]), "mlp_precision": precision,
                          "fused_stencil_kernels": bool(m._fused_ok())}
         return out
 
     guarded("chunk4096", lambda: c1_variant(args.hidden, 4096))
     guarded("h128", lambda: c1_variant(128, args.chunk))
+    # config[4]'s opt-in bf16 MLP mode at the yaml's width (dtype bf16; never part of the f32 headline)
+    guarded("h128_bf16", lambda: c1_variant(128, args.chunk, precision="bf16"))
     # the per-layer API route (tcnn.Encoding / VanillaMLP shaped calls, one or a few kernels each; INTEGRATION.md's
     # two-line dropin.install()): [7 S, 35] rows through HBM, so a quarter of the view at the reference's chunk size
     guarded("dropin_path", lambda: c1_variant(args.hidden, 4096, n_rays=rays.shape[0] // 4 // 800 * 800, fused=False))
@@ -441,6 +452,9 @@ def main():
     ap.add_argument("--width", type=int, default=800)
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--hidden", type=int, default=64)
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                    help="MLP matrix precision: fp32 = fp32-equivalent split products (the metric's dtype f32); bf16 = "
+                         "BASELINE.json configs[4]'s opt-in bf16 MLP mode (reported with dtype bf16)")
     ap.add_argument("--cpu-rays", type=int, default=4096,
                     help="upper bound on the rays in the CPU-baseline sample (0 = skip); shrunk to fit ~8 s/repetition")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -513,10 +527,12 @@ def main():
             "metric": "ray-marched SDF samples/sec (fwd+bwd), 800x800 rays, L=16 hashgrid",
             "value": samples / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32",
+            "data": "synthetic",
             "config": {"workload": "c1: toaster-sized 800x800 view per GPU, dense marching, L=16 T=2^19 "
                                    f"hash grid + 2x{args.hidden} SDF MLP (7 FD taps), NeuS alpha + composite, fwd+bwd",
-                       "hidden": args.hidden, "fused_stencil_kernels": bool(model._fused_ok()),
+                       "hidden": args.hidden, "mlp_precision": args.precision,
+                       "fused_stencil_kernels": bool(model._fused_ok()),
                        "rccl_ranks": torch.distributed.get_world_size() if world > 1 else 1,
                        "dist_backend": torch.distributed.get_backend() if world > 1 else None,
                        "rays_per_gpu": n_rays, "chunk_rays": args.chunk,

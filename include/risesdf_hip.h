@@ -244,6 +244,39 @@ int rsdf_sdfmlp_fd7_bwd(const float *x7t, const float *planes, int n_levels, int
                         const float *b2, int64_t n_samples, const float *d_sdf7t,
                         const float *d_feature, float *dh2c_scratch /*nullable*/, float *d_planes, float *dw0,
                         float *db0, float *dw1, float *db1, float *dw2, float *db2, void *stream);
+/* ---- config[4]'s "bf16 MLP on MFMA" (BASELINE.json configs[4]; models/network_utils.py:109-157 at reduced matrix
+ * precision): the same entry points with the suffix _bf16.  Same arguments, layouts and fp32 tensors; every matrix
+ * operand (weights, activations, gradients) is rounded ONCE to bf16 (round to nearest even) and each k-step is ONE
+ * v_mfma_f32_*_bf16 product with fp32 accumulation; master weights, biases, activations in memory and weight-gradient
+ * accumulators stay fp32.  Opt-in per network (``precision: bf16`` in a network's config node on the Python side); the
+ * default entry points above compute fp32-equivalent products. */
+int rsdf_linear_fwd_bf16(const float *x, int ldx, const float *w, const float *b, int64_t n, int K,
+                         int N, int act, float *y, int ldy, void *stream);
+int rsdf_linear_bwd_input_bf16(const float *dy, const float *y, int lddy, const float *w, int64_t n,
+                               int K, int N, int act, int k0, int Kout, float *dz, float *dx, int lddx,
+                               void *stream);
+int rsdf_linear_bwd_weight_bf16(const float *dz, int lddz, const float *x, int ldx, int64_t n, int K,
+                                int N, float *dw, float *db, void *stream);
+int rsdf_linear_bwd_fused_supported_bf16(int K, int N);
+int rsdf_linear_bwd_fused_bf16(const float *dy, const float *y, int lddy, const float *x, int ldx,
+                               const float *w, int64_t n, int K, int N, int act, int k0, int Kout, float *dx,
+                               int lddx, int prev_act, float *dw, float *db, void *stream);
+int rsdf_linear_bwd_fused_tail_bf16(const float *dz_out, int N2, const float *w2, const float *y, int lddy,
+                                    const float *x, int ldx, const float *w, int64_t n, int K, int N, int act,
+                                    int k0, int Kout, float *dx, int lddx, int prev_act, float *dw, float *db,
+                                    void *stream);
+int rsdf_sdfmlp_fd7_supported_bf16(int K0, int H, int N2);
+int rsdf_sdfmlp_fd7_fwd_bf16(const float *x7t, const float *planes, int n_levels, int n_active_levels,
+                             float xyz_scale, float xyz_offset, int H, int N2, const float *w0,
+                             const float *b0, const float *w1, const float *b1, const float *w2,
+                             const float *b2, int64_t n_samples, float *sdf7t, float *feature, float *h2c,
+                             void *stream);
+int rsdf_sdfmlp_fd7_bwd_bf16(const float *x7t, const float *planes, int n_levels, int n_active_levels,
+                             float xyz_scale, float xyz_offset, int H, int N2, const float *w0,
+                             const float *b0, const float *w1, const float *b1, const float *w2,
+                             const float *b2, int64_t n_samples, const float *d_sdf7t,
+                             const float *d_feature, float *dh2c_scratch /*nullable*/, float *d_planes, float *dw0,
+                             float *db0, float *dw1, float *db1, float *dw2, float *db2, void *stream);
 /* weight_norm (torch.nn.utils.weight_norm dim=0): w = g * v / ||v||_row */
 int rsdf_weight_norm_fwd(const float *g, const float *v, int N, int K, float *w, void *stream);
 int rsdf_weight_norm_bwd(const float *g, const float *v, const float *dw, int N, int K, float *dg,

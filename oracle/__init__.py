@@ -392,13 +392,58 @@ def weight_norm_effective(g, v):
     return v * (g / v.norm(dim=1, keepdim=True))
 
 
+# ---- config[4]'s bf16 MLP mode (BASELINE.json configs[4]): the same networks with every matrix operand rounded once to
+# bf16 (round to nearest even) and fp32 accumulation, forward and backward -- what one v_mfma_f32_*_bf16 product per
+# k-step computes.  ``with oracle.mlp_precision("bf16"):`` switches every nn.Linear restated here (vanilla_mlp,
+# texture.relu_mlp) to it; parameters, biases, activations and accumulators stay fp32.
+_MLP_PRECISION = ["fp32"]
+
+
+class mlp_precision:
+    def __init__(self, precision):
+        assert precision in ("fp32", "bf16")
+        self.p = precision
+
+    def __enter__(self):
+        self.old = _MLP_PRECISION[0]
+        _MLP_PRECISION[0] = self.p
+
+    def __exit__(self, *a):
+        _MLP_PRECISION[0] = self.old
+
+
+def _rb(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+class _LinearBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        xr, wr = _rb(x), _rb(w)
+        ctx.save_for_backward(xr, wr)
+        return xr @ wr.t() + b
+
+    @staticmethod
+    def backward(ctx, dy):
+        xr, wr = ctx.saved_tensors
+        dr = _rb(dy)                                  # dz = dy * act'(y) is formed in fp32, then rounded as an operand
+        return dr @ wr, dr.t() @ xr, dy.sum(0)
+
+
+def linear(x, w, b):
+    """nn.Linear at the oracle's current MLP precision."""
+    if _MLP_PRECISION[0] == "bf16":
+        return _LinearBF16.apply(x.float(), w.float(), b.float())
+    return F.linear(x, w, b)
+
+
 def vanilla_mlp(x, params, activation="softplus100"):
     """Linear -> act -> ... -> Linear.  ``params`` is a list of {g,v,b} (weight-normed) or
     {w,b}.  Softplus(beta=100, threshold=20) for sphere-init nets, ReLU otherwise (:152-157)."""
     h = x.float()
     for i, p in enumerate(params):
         w = weight_norm_effective(p["g"], p["v"]) if "g" in p else p["w"]
-        h = F.linear(h, w, p["b"])
+        h = linear(h, w, p["b"])
         if i < len(params) - 1:
             h = F.softplus(h, beta=100) if activation == "softplus100" else F.relu(h)
     return h

@@ -63,11 +63,16 @@ def reflect_dirs(dirs, normals):
     return wo, nov
 
 
+def _oracle_linear(x, w, b):
+    from . import linear
+    return linear(x, w, b)
+
+
 def relu_mlp(x, params):
     """VanillaMLP without sphere init / weight norm: ReLU hidden layers (network_utils.py:145-157)."""
     h = x
     for i, p in enumerate(params):
-        h = F.linear(h, p["w"], p["b"])
+        h = _oracle_linear(h, p["w"], p["b"])      # fp32, or bf16 operands inside oracle.mlp_precision("bf16")
         if i < len(params) - 1:
             h = F.relu(h)
     return h

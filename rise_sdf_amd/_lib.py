@@ -120,6 +120,26 @@ _SIGNATURES = {
     "rsdf_neus_alpha_bwd": [_P, _P, _P, _P, _P, _F, _L, _P, _P, _P, _P, _P],
     "rsdf_neus_occ_alpha": [_P, _P, _F, _L, _P, _P],
 }
+# config[4]'s bf16 MLP mode: the MLP entry points a second time with the suffix _bf16 (same signatures; split_bf16.h)
+BF16_ENTRY_POINTS = ("rsdf_linear_fwd", "rsdf_linear_bwd_input", "rsdf_linear_bwd_weight",
+                     "rsdf_linear_bwd_fused_supported", "rsdf_linear_bwd_fused", "rsdf_linear_bwd_fused_tail",
+                     "rsdf_sdfmlp_fd7_supported", "rsdf_sdfmlp_fd7_fwd", "rsdf_sdfmlp_fd7_bwd")
+for _n in BF16_ENTRY_POINTS:
+    _SIGNATURES[_n + "_bf16"] = _SIGNATURES[_n]
+PRECISIONS = ("fp32", "bf16")
+
+
+def mlp_fn(name, precision="fp32"):
+    """The MLP entry point ``name`` at ``precision``: 'fp32' (fp32-equivalent split products, the default) or 'bf16'
+    (one bf16 product per k-step, fp32 accumulate; opt-in, BASELINE.json configs[4])."""
+    if precision in (None, "fp32", "f32", "float32"):
+        return getattr(lib(), name)
+    if precision in ("bf16", "bfloat16"):
+        assert name in BF16_ENTRY_POINTS, name
+        return getattr(lib(), name + "_bf16")
+    raise ValueError(f"unknown MLP precision {precision!r} (fp32 or bf16)")
+
+
 _RESTYPES = {"rsdf_last_error": ctypes.c_char_p, "rsdf_scan_scratch_bytes": ctypes.c_int64,
              "rsdf_grid_meta_init": ctypes.c_int64,
              "rsdf_hashgrid_bwd_fd7_scratch_bytes": ctypes.c_int64,
@@ -182,7 +202,7 @@ class _TimedLib:
     def __getattr__(self, name):
         fn = getattr(self._l, name)
         # host-only queries launch nothing: not timed
-        if not name.startswith("rsdf_") or name.endswith(("_supported", "_scratch_bytes")) or \
+        if not name.startswith("rsdf_") or "_supported" in name or name.endswith("_scratch_bytes") or \
                 name in ("rsdf_last_error", "rsdf_abi_version", "rsdf_grid_meta_init"):
             return fn
         timer = self._t

@@ -27,6 +27,7 @@ constexpr int S_THREADS = S_WAVES * 64;
 // LDS weight image (16-byte units): [part 3][out tile OT][k-step KS][hf 2][c 32], then OT*32 floats of bias
 __device__ __forceinline__ f32x16 mma6s(const u32x4 *__restrict__ wa, int part_stride, const Frag3 &b, f32x16 c)
 {
+    if (!RSDF_SPLIT3) return mma_bf16(wa[0], b.h, c);
     const u32x4 ah = wa[0], am = wa[part_stride], al = wa[2 * part_stride];
     c = mma_bf16(al, b.h, c);
     c = mma_bf16(ah, b.l, c);
@@ -325,7 +326,7 @@ int allow_lds(Kern kern, size_t bytes)
 
 extern "C" {
 
-int rsdf_linear_fwd(const float *x, int ldx, const float *w, const float *b, int64_t n, int K, int N,
+int RSDF_P(rsdf_linear_fwd)(const float *x, int ldx, const float *w, const float *b, int64_t n, int K, int N,
                     int act, float *y, int ldy, void *stream)
 {
     RSDF_CHECK_ARG(K >= 1 && K <= 128 && N >= 1 && N <= 128, "linear_fwd: K and N must be in [1,128]");
@@ -350,7 +351,7 @@ int rsdf_linear_fwd(const float *x, int ldx, const float *w, const float *b, int
     RSDF_RETURN_LAUNCH();
 }
 
-int rsdf_linear_bwd_input(const float *dy, const float *y, int lddy, const float *w, int64_t n, int K,
+int RSDF_P(rsdf_linear_bwd_input)(const float *dy, const float *y, int lddy, const float *w, int64_t n, int K,
                           int N, int act, int k0, int Kout, float *dz, float *dx, int lddx,
                           void *stream)
 {
@@ -383,7 +384,7 @@ int rsdf_linear_bwd_input(const float *dy, const float *y, int lddy, const float
     RSDF_RETURN_LAUNCH();
 }
 
-int rsdf_linear_bwd_weight(const float *dz, int lddz, const float *x, int ldx, int64_t n, int K, int N,
+int RSDF_P(rsdf_linear_bwd_weight)(const float *dz, int lddz, const float *x, int ldx, int64_t n, int K, int N,
                            float *dw, float *db, void *stream)
 {
     RSDF_CHECK_ARG(K >= 1 && K <= 128 && N >= 1 && N <= 128, "linear_bwd_weight: K and N must be in [1,128]");
@@ -403,6 +404,7 @@ int rsdf_linear_bwd_weight(const float *dz, int lddz, const float *x, int ldx, i
     RSDF_RETURN_LAUNCH();
 }
 
+#ifndef RSDF_BF16   // precision-independent: only in the default build
 int rsdf_weight_norm_fwd(const float *g, const float *v, int N, int K, float *w, void *stream)
 {
     if (N <= 0) return 0;
@@ -417,5 +419,6 @@ int rsdf_weight_norm_bwd(const float *g, const float *v, const float *dw, int N,
     weight_norm_bwd_kernel<<<N, 64, 0, (hipStream_t)stream>>>(g, v, dw, K, dg, dv);
     RSDF_RETURN_LAUNCH();
 }
+#endif
 
 }  // extern "C"

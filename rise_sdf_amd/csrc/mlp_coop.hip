@@ -176,6 +176,7 @@ __device__ __forceinline__ void store_tile(unsigned char *img, int part_stride, 
         unsigned char *p = img + (4 * w + 2 * s) * CS + c * 16 + 8 * hf;
         *reinterpret_cast<uint2 *>(p) = uint2{f[s].h[0], f[s].h[1]};
         *reinterpret_cast<uint2 *>(p + CS) = uint2{f[s].h[2], f[s].h[3]};
+        if (!RSDF_SPLIT3) continue;      // bf16 build: the middle / low images are never read
         *reinterpret_cast<uint2 *>(p + part_stride) = uint2{f[s].m[0], f[s].m[1]};
         *reinterpret_cast<uint2 *>(p + part_stride + CS) = uint2{f[s].m[2], f[s].m[3]};
         *reinterpret_cast<uint2 *>(p + 2 * part_stride) = uint2{f[s].l[0], f[s].l[1]};
@@ -188,6 +189,7 @@ __device__ __forceinline__ f32x16 mma6f(const Frag3 &a, const Frag3 &b, f32x16 c
 __device__ __forceinline__ f32x16 mma6z(const Frag3 &a, const Frag3 &b)
 {
     const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (!RSDF_SPLIT3) return mma_bf16(a.h, b.h, z);
     f32x16 c = mma_bf16(a.l, b.h, z);
     c = mma_bf16(a.h, b.l, c);
     c = mma_bf16(a.m, b.m, c);
@@ -315,6 +317,7 @@ __device__ __forceinline__ void put3(unsigned char *xi, int off, float v)
     unsigned h, m, l;
     split3_pair(v, 0.0f, h, m, l);
     *reinterpret_cast<unsigned short *>(xi + off) = (unsigned short)h;
+    if (!RSDF_SPLIT3) return;
     *reinterpret_cast<unsigned short *>(xi + off + X_PART) = (unsigned short)m;
     *reinterpret_cast<unsigned short *>(xi + off + 2 * X_PART) = (unsigned short)l;
 }
@@ -929,7 +932,7 @@ extern "C" int rsdf_debug_read_stamps(unsigned long long *out16)
 #endif
 
 // entry points used by mlp_fused.hip's dispatchers
-__attribute__((visibility("hidden"))) int rsdf_coop_fwd(int NT, const float *x7t, const float *planes, int n_levels, int n_active, float xyz_scale,
+__attribute__((visibility("hidden"))) int RSDF_P(rsdf_coop_fwd)(int NT, const float *x7t, const float *planes, int n_levels, int n_active, float xyz_scale,
                   float xyz_offset, int N2, const float *w0, const float *b0, const float *w1, const float *b1,
                   const float *w2, const float *b2, int64_t n_samples, float *sdf7t, float *feature, float *h2c,
                   hipStream_t st)
@@ -965,7 +968,7 @@ __attribute__((visibility("hidden"))) int rsdf_coop_fwd(int NT, const float *x7t
     RSDF_RETURN_LAUNCH();
 }
 
-__attribute__((visibility("hidden"))) int rsdf_coop_bwd(int NT, const float *x7t, const float *planes, int n_levels, int n_active, float xyz_scale,
+__attribute__((visibility("hidden"))) int RSDF_P(rsdf_coop_bwd)(int NT, const float *x7t, const float *planes, int n_levels, int n_active, float xyz_scale,
                   float xyz_offset, const float *w0, const float *b0, const float *w1, const float *b1, const float *w2,
                   int64_t n_samples, const float *d_sdf7t, const float *dh2c, float *d_planes, float *dw0, float *db0,
                   float *dw1, float *db1, float *dw2, float *db2, hipStream_t st)

@@ -782,24 +782,24 @@ bool env_is(const char *name, const char *value) { return rsdf_env_is(name, valu
 }  // namespace
 
 // cooperative kernels (mlp_coop.hip): a workgroup of H/32 waves, wave w owns features 32w..32w+31
-__attribute__((visibility("hidden"))) int rsdf_coop_fwd(int NT, const float *x7t, const float *planes, int n_levels, int n_active, float xyz_scale,
+__attribute__((visibility("hidden"))) int RSDF_P(rsdf_coop_fwd)(int NT, const float *x7t, const float *planes, int n_levels, int n_active, float xyz_scale,
                   float xyz_offset, int N2, const float *w0, const float *b0, const float *w1, const float *b1,
                   const float *w2, const float *b2, int64_t n_samples, float *sdf7t, float *feature, float *h2c,
                   hipStream_t st);
-__attribute__((visibility("hidden"))) int rsdf_coop_bwd(int NT, const float *x7t, const float *planes, int n_levels, int n_active, float xyz_scale,
+__attribute__((visibility("hidden"))) int RSDF_P(rsdf_coop_bwd)(int NT, const float *x7t, const float *planes, int n_levels, int n_active, float xyz_scale,
                   float xyz_offset, const float *w0, const float *b0, const float *w1, const float *b1, const float *w2,
                   int64_t n_samples, const float *d_sdf7t, const float *dh2c, float *d_planes, float *dw0, float *db0,
                   float *dw1, float *db1, float *dw2, float *db2, hipStream_t st);
 
 // quad kernel (mlp_quad.hip): H = 64 backward on 16-feature wave tiles, two waves per SIMD
-__attribute__((visibility("hidden"))) int rsdf_quad_bwd(int H, const float *x7t, const float *planes, int n_levels, int n_active, float xyz_scale, float xyz_offset,
+__attribute__((visibility("hidden"))) int RSDF_P(rsdf_quad_bwd)(int H, const float *x7t, const float *planes, int n_levels, int n_active, float xyz_scale, float xyz_offset,
                   const float *w0, const float *b0, const float *w1, const float *b1, const float *w2, int64_t n_samples,
                   const float *d_sdf7t, const float *dh2c, float *d_planes, float *dw0, float *db0, float *dw1, float *db1,
                   float *dw2, float *db2, hipStream_t st);
 
 extern "C" {
 
-int rsdf_sdfmlp_fd7_supported(int K0, int H, int N2)
+int RSDF_P(rsdf_sdfmlp_fd7_supported)(int K0, int H, int N2)
 {
     return (K0 >= 1 && K0 <= 35 && (H == 32 || H == 64 || H == 128) && N2 >= 1 && N2 <= 64) ? 1 : 0;
 }
@@ -807,7 +807,7 @@ int rsdf_sdfmlp_fd7_supported(int K0, int H, int N2)
 // Kernel selection.  Forward: the per-wave kernel of this file for H <= 64 (every wave holds all weights through LDS),
 // the cooperative kernel for H = 128.  Backward: the cooperative kernel for every width.  RSDF_MLP_FWD=coop /
 // RSDF_MLP_BWD=legacy force the other form where it exists (A/B timing, parity tests of both).
-int rsdf_sdfmlp_fd7_fwd(const float *x7t, const float *planes, int n_levels, int n_active_levels,
+int RSDF_P(rsdf_sdfmlp_fd7_fwd)(const float *x7t, const float *planes, int n_levels, int n_active_levels,
                         float xyz_scale, float xyz_offset, int H, int N2, const float *w0,
                         const float *b0, const float *w1, const float *b1, const float *w2,
                         const float *b2, int64_t n_samples, float *sdf7t, float *feature, float *h2c,
@@ -821,7 +821,7 @@ int rsdf_sdfmlp_fd7_fwd(const float *x7t, const float *planes, int n_levels, int
     if (n_active_levels < 0 || n_active_levels > n_levels) n_active_levels = n_levels;
     hipStream_t st = (hipStream_t)stream;
     if (H == 128 || env_is("RSDF_MLP_FWD", "coop"))
-        return rsdf_coop_fwd(H / 32, x7t, planes, n_levels, n_active_levels, xyz_scale, xyz_offset, N2, w0, b0, w1, b1,
+        return RSDF_P(rsdf_coop_fwd)(H / 32, x7t, planes, n_levels, n_active_levels, xyz_scale, xyz_offset, N2, w0, b0, w1, b1,
                              w2, b2, n_samples, sdf7t, feature, h2c, st);
     const unsigned grid = persistent_grid(n_samples, FWD_WAVES);
     const TileSrc src{x7t, planes, n_samples, n_levels, n_active_levels, xyz_scale, xyz_offset};
@@ -838,7 +838,7 @@ int rsdf_sdfmlp_fd7_fwd(const float *x7t, const float *planes, int n_levels, int
     RSDF_RETURN_LAUNCH();
 }
 
-int rsdf_sdfmlp_fd7_bwd(const float *x7t, const float *planes, int n_levels, int n_active_levels,
+int RSDF_P(rsdf_sdfmlp_fd7_bwd)(const float *x7t, const float *planes, int n_levels, int n_active_levels,
                         float xyz_scale, float xyz_offset, int H, int N2, const float *w0,
                         const float *b0, const float *w1, const float *b1, const float *w2,
                         const float *b2, int64_t n_samples, const float *d_sdf7t, const float *d_feature,
@@ -861,10 +861,10 @@ int rsdf_sdfmlp_fd7_bwd(const float *x7t, const float *planes, int n_levels, int
             if (rc) return rc;
         }
         if (H == 64 && !env_is("RSDF_MLP_BWD", "coop"))
-            return rsdf_quad_bwd(H, x7t, planes, n_levels, n_active_levels, xyz_scale, xyz_offset, w0, b0, w1, b1, w2,
+            return RSDF_P(rsdf_quad_bwd)(H, x7t, planes, n_levels, n_active_levels, xyz_scale, xyz_offset, w0, b0, w1, b1, w2,
                                  n_samples, d_sdf7t, d_feature != nullptr ? dh2c_scratch : nullptr, d_planes, dw0, db0,
                                  dw1, db1, dw2, db2, st);
-        return rsdf_coop_bwd(H / 32, x7t, planes, n_levels, n_active_levels, xyz_scale, xyz_offset, w0, b0, w1, b1, w2,
+        return RSDF_P(rsdf_coop_bwd)(H / 32, x7t, planes, n_levels, n_active_levels, xyz_scale, xyz_offset, w0, b0, w1, b1, w2,
                              n_samples, d_sdf7t, d_feature != nullptr ? dh2c_scratch : nullptr, d_planes, dw0, db0, dw1,
                              db1, dw2, db2, st);
     }

@@ -357,9 +357,9 @@ int check_common(const float *y, int lddy, const float *x, int ldx, int K, int N
 
 extern "C" {
 
-int rsdf_linear_bwd_fused_supported(int K, int N) { return N == LB_N && K >= 1 && K <= 128; }
+int RSDF_P(rsdf_linear_bwd_fused_supported)(int K, int N) { return N == LB_N && K >= 1 && K <= 128; }
 
-int rsdf_linear_bwd_fused(const float *dy, const float *y, int lddy, const float *x, int ldx, const float *w,
+int RSDF_P(rsdf_linear_bwd_fused)(const float *dy, const float *y, int lddy, const float *x, int ldx, const float *w,
                           int64_t n, int K, int N, int act, int k0, int Kout, float *dx, int lddx, int prev_act,
                           float *dw, float *db, void *stream)
 {
@@ -375,7 +375,7 @@ int rsdf_linear_bwd_fused(const float *dy, const float *y, int lddy, const float
     RSDF_RETURN_LAUNCH();
 }
 
-int rsdf_linear_bwd_fused_tail(const float *dz_out, int N2, const float *w2, const float *y, int lddy, const float *x,
+int RSDF_P(rsdf_linear_bwd_fused_tail)(const float *dz_out, int N2, const float *w2, const float *y, int lddy, const float *x,
                                int ldx, const float *w, int64_t n, int K, int N, int act, int k0, int Kout, float *dx,
                                int lddx, int prev_act, float *dw, float *db, void *stream)
 {

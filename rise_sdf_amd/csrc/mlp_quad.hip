@@ -48,6 +48,7 @@ __device__ __forceinline__ f32x4 mma16(u32x4 a, u32x4 b, f32x4 c)
 }
 __device__ __forceinline__ f32x4 mma6q(const Frag3 &a, const Frag3 &b, f32x4 c)
 {
+    if (!RSDF_SPLIT3) return mma16(a.h, b.h, c);
     c = mma16(a.l, b.h, c);
     c = mma16(a.h, b.l, c);
     c = mma16(a.m, b.m, c);
@@ -221,6 +222,7 @@ __device__ __forceinline__ void put3q(unsigned char *xi, int off, float v)
     unsigned h, m, l;
     split3_pair(v, 0.0f, h, m, l);
     *reinterpret_cast<unsigned short *>(xi + off) = (unsigned short)h;
+    if (!RSDF_SPLIT3) return;
     *reinterpret_cast<unsigned short *>(xi + off + QX_PART) = (unsigned short)m;
     *reinterpret_cast<unsigned short *>(xi + off + 2 * QX_PART) = (unsigned short)l;
 }
@@ -498,7 +500,7 @@ extern "C" int rsdf_debug_read_qstamps(unsigned long long *out16)
 }
 #endif
 
-__attribute__((visibility("hidden"))) int rsdf_quad_bwd(int H, const float *x7t, const float *planes, int n_levels, int n_active, float xyz_scale, float xyz_offset,
+__attribute__((visibility("hidden"))) int RSDF_P(rsdf_quad_bwd)(int H, const float *x7t, const float *planes, int n_levels, int n_active, float xyz_scale, float xyz_offset,
                   const float *w0, const float *b0, const float *w1, const float *b1, const float *w2, int64_t n_samples,
                   const float *d_sdf7t, const float *dh2c, float *d_planes, float *dw0, float *db0, float *dw1, float *db1,
                   float *dw2, float *db2, hipStream_t st)

@@ -3,7 +3,27 @@
 #pragma once
 #include "common.h"
 
+// Two builds of the MLP translation units share this header (Makefile):
+//   default      fp32-equivalent: every operand is the exact sum of three bf16 parts, six partial products;
+//   -DRSDF_BF16  config[4]'s "bf16 MLP on MFMA" (BASELINE.json configs[4]; SURVEY H3 "c4 optional bf16"): operands
+//                rounded ONCE to bf16 (v_cvt_pk_bf16_f32, round to nearest even), ONE v_mfma_f32_*_bf16 product per
+//                k-step, fp32 accumulation, fp32 master weights and fp32 weight-gradient accumulators.  The middle and
+//                low parts are compile-time zeros there: their conversions, LDS traffic and five of the six matrix
+//                instructions disappear.  Entry points of that build carry the suffix _bf16 (RSDF_P), so both
+//                precisions live in one library and the choice is per call (opt-in; the f32 headline never uses it).
+#ifdef RSDF_BF16
+#define RSDF_P(name) name##_bf16
+#else
+#define RSDF_P(name) name
+#endif
+
 namespace {
+
+#ifdef RSDF_BF16
+constexpr bool RSDF_SPLIT3 = false;
+#else
+constexpr bool RSDF_SPLIT3 = true;
+#endif
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
@@ -23,6 +43,10 @@ __device__ __forceinline__ float bf16_hi(unsigned p) { return __builtin_bit_cast
 __device__ __forceinline__ void split3_pair(float a, float b, unsigned &h, unsigned &m, unsigned &l)
 {
     h = pack_bf16(a, b);
+    if (!RSDF_SPLIT3) {
+        m = l = 0u;
+        return;
+    }
     const float ra = a - bf16_lo(h), rb = b - bf16_hi(h);   // exact
     m = pack_bf16(ra, rb);
     l = pack_bf16(ra - bf16_lo(m), rb - bf16_hi(m));
@@ -51,6 +75,7 @@ __device__ __forceinline__ f32x16 mma_bf16(u32x4 a, u32x4 b, f32x16 c)
 template <int PART_STRIDE_U4>
 __device__ __forceinline__ f32x16 mma6(const u32x4 *__restrict__ wa, const Frag3 &b, f32x16 c)
 {
+    if (!RSDF_SPLIT3) return mma_bf16(wa[0], b.h, c);
     const u32x4 ah = wa[0], am = wa[PART_STRIDE_U4], al = wa[2 * PART_STRIDE_U4];
     c = mma_bf16(al, b.h, c);
     c = mma_bf16(ah, b.l, c);
@@ -66,12 +91,14 @@ __device__ __forceinline__ void store3(unsigned short *base, size_t part_stride_
     unsigned h, m, l;
     split3_pair(w, 0.0f, h, m, l);
     base[idx] = (unsigned short)(h & 0xffffu);
+    if (!RSDF_SPLIT3) return;
     base[idx + part_stride_elems] = (unsigned short)(m & 0xffffu);
     base[idx + 2 * part_stride_elems] = (unsigned short)(l & 0xffffu);
 }
 // six partial products with the weight fragment in registers
 __device__ __forceinline__ f32x16 mma6r(const Frag3 &a, const Frag3 &b, f32x16 c)
 {
+    if (!RSDF_SPLIT3) return mma_bf16(a.h, b.h, c);
     c = mma_bf16(a.l, b.h, c);
     c = mma_bf16(a.h, b.l, c);
     c = mma_bf16(a.m, b.m, c);

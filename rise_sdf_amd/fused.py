@@ -35,7 +35,7 @@ def supported(K0: int, H: int, N2: int, n_hidden_layers: int, hidden_act: str, o
 class _SdfFieldFD7(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x7t, table, w0, b0, w1, b1, w2, b2, meta, n_active, xyz_scale, xyz_offset,
-                eps_unit, want_feature, points=None, radius=None, eps=None):
+                eps_unit, want_feature, points=None, radius=None, eps=None, precision="fp32"):
         xf = x7t.detach().to(torch.float32).contiguous()
         assert xf.dim() == 3 and xf.shape[0] == 7 and xf.shape[2] == 3, "x7t must be [7,S,3]"
         tb = table.detach()
@@ -62,12 +62,12 @@ class _SdfFieldFD7(torch.autograd.Function):
         sdf7t = torch.empty(7, S, dtype=torch.float32, device=dev)
         feature = torch.empty(S, N2, dtype=torch.float32, device=dev) if want_feature else None
         h2c = torch.empty(S, H, dtype=torch.float32, device=dev) if want_feature else None
-        check(lib().rsdf_sdfmlp_fd7_fwd(ptr(xf), ptr(planes), Lv, n_active, float(xyz_scale),
+        check(L.mlp_fn("rsdf_sdfmlp_fd7_fwd", precision)(ptr(xf), ptr(planes), Lv, n_active, float(xyz_scale),
                                         float(xyz_offset), H, N2, *[ptr(t) for t in ws], S, ptr(sdf7t),
                                         ptr(feature), ptr(h2c), st), "sdfmlp_fd7_fwd")
         ctx.save_for_backward(xf, planes, *ws)
         ctx.h2c = h2c
-        ctx.pts, ctx.radius, ctx.eps = pts, radius, eps
+        ctx.pts, ctx.radius, ctx.eps, ctx.precision = pts, radius, eps, precision
         ctx.meta, ctx.n_active, ctx.eps_unit, ctx.n_params = meta, n_active, float(eps_unit), tb.numel()
         ctx.xyz = (float(xyz_scale), float(xyz_offset))
         ctx.dims = (S, Lv, H, N2)
@@ -77,7 +77,7 @@ class _SdfFieldFD7(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_sdf7t, g_feature):
         if g_sdf7t is None and g_feature is None:
-            return (None,) * 17
+            return (None,) * 18
         xf, planes, w0, b0, w1, b1, w2, b2 = ctx.saved_tensors
         S, Lv, H, N2 = ctx.dims
         dev = xf.device
@@ -91,13 +91,14 @@ class _SdfFieldFD7(torch.autograd.Function):
         dw1, db1 = torch.zeros_like(w1), torch.zeros_like(b1)
         dw2, db2 = torch.zeros_like(w2), torch.zeros_like(b2)
         dh2c = torch.empty(S, H, dtype=torch.float32, device=dev) if gf is not None else None
-        check(lib().rsdf_sdfmlp_fd7_bwd(ptr(xf), ptr(planes), Lv, ctx.n_active, ctx.xyz[0], ctx.xyz[1],
+        check(L.mlp_fn("rsdf_sdfmlp_fd7_bwd", ctx.precision)(ptr(xf), ptr(planes), Lv, ctx.n_active, ctx.xyz[0], ctx.xyz[1],
                                         H, N2, ptr(w0), ptr(b0), ptr(w1), ptr(b1), ptr(w2), ptr(b2), S,
                                         ptr(g), ptr(gf), ptr(dh2c), ptr(d_planes), ptr(dw0), ptr(db0), ptr(dw1),
                                         ptr(db1), ptr(dw2), ptr(db2), st), "sdfmlp_fd7_bwd")
         if gf is not None:
             # feature rows of the last layer: dW2 += d_feature^T h2(centre), db2 += colsum(d_feature)
-            check(lib().rsdf_linear_bwd_weight(ptr(gf), N2, ptr(ctx.h2c), H, S, H, N2, ptr(dw2), ptr(db2), st),
+            check(L.mlp_fn("rsdf_linear_bwd_weight", ctx.precision)(ptr(gf), N2, ptr(ctx.h2c), H, S, H, N2, ptr(dw2),
+                                                                    ptr(db2), st),
                   "linear_bwd_weight (feature rows)")
         dt = None
         if need_table:
@@ -115,11 +116,11 @@ class _SdfFieldFD7(torch.autograd.Function):
                 check(lib().rsdf_hashgrid_bwd_fd7(ptr(xf), ptr(d_planes), ctypes.byref(ctx.meta), S,
                                                   ctx.n_active, ctx.eps_unit, ptr(dt), ptr(scratch), nbytes,
                                                   st), "hashgrid_bwd_fd7")
-        return (None, dt, dw0, db0, dw1, db1, dw2, db2, None, None, None, None, None, None, None, None, None)
+        return (None, dt, dw0, db0, dw1, db1, dw2, db2, None, None, None, None, None, None, None, None, None, None)
 
 
 def sdf_field_fd7(x7t, table, weights, meta, n_active, xyz_scale, xyz_offset, eps_unit,
-                  want_feature=False, points=None, radius=None, eps=None):
+                  want_feature=False, points=None, radius=None, eps=None, precision="fp32"):
     """weights = [(w0,b0),(w1,b1),(w2,b2)] effective (already weight-normalised) layer parameters.
     ``points`` [S,3] (world-space sample centres, with ``radius`` and the FD ``eps``): the hash kernels derive the
     stencil from them instead of re-reading x7t once per level.
@@ -128,4 +129,4 @@ def sdf_field_fd7(x7t, table, weights, meta, n_active, xyz_scale, xyz_offset, ep
     if points is not None:
         assert radius is not None and eps is not None
     return _SdfFieldFD7.apply(x7t, table, w0, b0, w1, b1, w2, b2, meta, int(n_active), xyz_scale,
-                              xyz_offset, eps_unit, bool(want_feature), points, radius, eps)
+                              xyz_offset, eps_unit, bool(want_feature), points, radius, eps, precision)

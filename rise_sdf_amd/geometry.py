@@ -117,7 +117,8 @@ class VolumeSDF(BaseModel):
             x7t, grid.params, self.network.effective_weights(), grid.meta,
             grid.n_levels if n_active is None else n_active, self.encoding.xyz_scale,
             self.encoding.xyz_offset, self._eps_unit(), want_feature,
-            points=pts, radius=self.radius, eps=self._finite_difference_eps)
+            points=pts, radius=self.radius, eps=self._finite_difference_eps,
+            precision=getattr(self.network, "precision", "fp32"))
 
     def _eps_unit(self):
         return self._finite_difference_eps / (2.0 * self.radius)
@@ -139,18 +140,18 @@ class VolumeSDF(BaseModel):
         wb = net.effective_weights()
         slopes = []
         for w, b in wb[:-1]:
-            z = ops.linear(h, w, b, act="none")
+            z = ops.linear(h, w, b, act="none", precision=net.precision)
             if net.hidden_act == "softplus100":
                 h, sl = F.softplus(z, beta=100), torch.sigmoid(100.0 * z)
             else:
                 h, sl = F.relu(z), (z > 0).to(z.dtype)
             slopes.append(sl)
         w_last, b_last = wb[-1]
-        out = ops.linear(h, w_last, b_last, act="none")
+        out = ops.linear(h, w_last, b_last, act="none", precision=net.precision)
         # reverse sweep for output channel 0: u <- (u * act'(z_i)) @ W_i
         u = w_last[0:1].expand(out.shape[0], -1)
         for (w, _), sl in zip(reversed(wb[:-1]), reversed(slopes)):
-            u = ops.linear((u * sl).contiguous(), w.t().contiguous(), None, act="none")
+            u = ops.linear((u * sl).contiguous(), w.t().contiguous(), None, act="none", precision=net.precision)
         g_unit = ops.hashgrid_dx(x, grid.params, u, grid.meta, n_active, col)
         if col:
             g_unit = g_unit + u[:, :3] * enc.xyz_scale

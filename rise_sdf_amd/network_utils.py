@@ -117,6 +117,12 @@ class VanillaMLP(nn.Module):
         self.weight_norm = config.get("weight_norm", False)
         self.sphere_init_radius = config.get("sphere_init_radius", 0.5)
         self.inside_outside = config.get("inside_outside", False)
+        # 'fp32' (default: fp32-equivalent split products, the reference's nn.Linear precision) or 'bf16' (BASELINE.json
+        # configs[4] "bf16 MLP on MFMA": operands rounded once to bf16, fp32 accumulation, fp32 master weights); a
+        # per-network opt-in key of the network's config node that the reference's yaml simply does not carry
+        self.precision = str(config.get("precision", "fp32")).lower()
+        if self.precision not in ("fp32", "bf16"):
+            raise ValueError(f"VanillaMLP precision {self.precision!r}: fp32 or bf16")
         layers = [self.make_linear(dim_in, self.n_neurons, True, False), self.make_activation()]
         for _ in range(self.n_hidden_layers - 1):
             layers += [self.make_linear(self.n_neurons, self.n_neurons, False, False),
@@ -171,7 +177,7 @@ class VanillaMLP(nn.Module):
         networks' color_activation into the last layer's kernel)."""
         wb = self.effective_weights()
         acts = [self.hidden_act] * (len(wb) - 1) + [out_act or self.output_act]
-        return ops.mlp_chain(x.float(), wb, acts, dx_cols=self.input_grad_cols)
+        return ops.mlp_chain(x.float(), wb, acts, dx_cols=self.input_grad_cols, precision=self.precision)
 
 
 def get_mlp(n_input_dims, n_output_dims, config):

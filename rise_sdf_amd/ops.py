@@ -408,17 +408,17 @@ class _Linear(torch.autograd.Function):
     """y = act(x @ w^T + b) on the fp32 matrix cores; backward fused with the activation."""
 
     @staticmethod
-    def forward(ctx, x, w, b, act, dx_cols):
+    def forward(ctx, x, w, b, act, dx_cols, precision="fp32"):
         xf, wf = _f32c(x), _f32c(w)
         bf = None if b is None else _f32c(b)
         require_device(xf, wf, bf)
         n, K = xf.shape
         N = wf.shape[0]
         y = torch.empty(n, N, dtype=torch.float32, device=xf.device)
-        check(lib().rsdf_linear_fwd(ptr(xf), K, ptr(wf), ptr(bf), n, K, N, act, ptr(y), N,
-                                    stream_ptr()), "linear_fwd")
+        check(L.mlp_fn("rsdf_linear_fwd", precision)(ptr(xf), K, ptr(wf), ptr(bf), n, K, N, act, ptr(y), N,
+                                                     stream_ptr()), "linear_fwd")
         ctx.save_for_backward(xf, wf, y)
-        ctx.act, ctx.has_bias, ctx.dx_cols = act, b is not None, dx_cols
+        ctx.act, ctx.has_bias, ctx.dx_cols, ctx.precision = act, b is not None, dx_cols, precision
         return y
 
     @staticmethod
@@ -445,22 +445,23 @@ class _Linear(torch.autograd.Function):
         dw = db = None
         if need_w or need_b:
             dw, db = _dw_db(N, K, need_b, xf.device)
-        if dw is not None and lib().rsdf_linear_bwd_fused_supported(K, N) and os.environ.get("RSDF_LAYER_BWD") != "split":
+        fn = lambda name: L.mlp_fn(name, ctx.precision)   # noqa: E731
+        if dw is not None and fn("rsdf_linear_bwd_fused_supported")(K, N) and os.environ.get("RSDF_LAYER_BWD") != "split":
             # 128-wide layers: one pass, dz never leaves the CU (mlp_layer_bwd.hip)
-            check(lib().rsdf_linear_bwd_fused(ptr(gy), ptr(y), N, ptr(xf), K, ptr(wf), n, K, N, ctx.act, k0, kout,
+            check(fn("rsdf_linear_bwd_fused")(ptr(gy), ptr(y), N, ptr(xf), K, ptr(wf), n, K, N, ctx.act, k0, kout,
                                               dx_win, K, L.ACT_IDS["none"], ptr(dw), ptr(db), st), "linear_bwd_fused")
-            return dx, dw, db, None, None
+            return dx, dw, db, None, None, None
         dz = torch.empty_like(gy)
-        check(lib().rsdf_linear_bwd_input(ptr(gy), ptr(y), N, ptr(wf), n, K, N, ctx.act, k0, kout,
+        check(fn("rsdf_linear_bwd_input")(ptr(gy), ptr(y), N, ptr(wf), n, K, N, ctx.act, k0, kout,
                                           ptr(dz), dx_win, K, st), "linear_bwd_input")
         if dw is not None:
-            check(lib().rsdf_linear_bwd_weight(ptr(dz), N, ptr(xf), K, n, K, N, ptr(dw), ptr(db), st),
+            check(fn("rsdf_linear_bwd_weight")(ptr(dz), N, ptr(xf), K, n, K, N, ptr(dw), ptr(db), st),
                   "linear_bwd_weight")
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
-def linear(x, w, b=None, act="none", dx_cols=None):
-    return _Linear.apply(x, w, b, L.ACT_IDS[act] if not isinstance(act, int) else act, dx_cols)
+def linear(x, w, b=None, act="none", dx_cols=None, precision="fp32"):
+    return _Linear.apply(x, w, b, L.ACT_IDS[act] if not isinstance(act, int) else act, dx_cols, precision)
 
 
 class _MLPChain(torch.autograd.Function):
@@ -471,7 +472,7 @@ class _MLPChain(torch.autograd.Function):
     its own output -- 1.5 instead of 2 KB per row and layer -- and autograd sees one node instead of one per layer."""
 
     @staticmethod
-    def forward(ctx, x, dx_cols, acts, *wb):
+    def forward(ctx, x, dx_cols, acts, precision, *wb):
         xf = _f32c(x)
         ws = [_f32c(t) for t in wb[0::2]]
         bs = [None if t is None else _f32c(t) for t in wb[1::2]]
@@ -483,17 +484,19 @@ class _MLPChain(torch.autograd.Function):
             N, K = w.shape
             assert h.shape[1] == K, "layer input width"
             y = torch.empty(n, N, dtype=torch.float32, device=xf.device)
-            check(lib().rsdf_linear_fwd(ptr(h), K, ptr(w), ptr(b), n, K, N, act, ptr(y), N, st), "linear_fwd")
+            check(L.mlp_fn("rsdf_linear_fwd", precision)(ptr(h), K, ptr(w), ptr(b), n, K, N, act, ptr(y), N, st),
+                  "linear_fwd")
             ys.append(y)
             h = y
         ctx.save_for_backward(xf, *ws, *ys)
-        ctx.acts, ctx.dx_cols, ctx.n_layers = tuple(acts), dx_cols, len(ws)
+        ctx.acts, ctx.dx_cols, ctx.n_layers, ctx.precision = tuple(acts), dx_cols, len(ws), precision
         ctx.has_bias = [b is not None for b in bs]
         return ys[-1]
 
     @staticmethod
     def backward(ctx, gy):
         nl = ctx.n_layers
+        fn = lambda name: L.mlp_fn(name, ctx.precision)   # noqa: E731
         saved = ctx.saved_tensors
         xf, ws, ys = saved[0], saved[1:1 + nl], saved[1 + nl:]
         n = xf.shape[0]
@@ -506,20 +509,20 @@ class _MLPChain(torch.autograd.Function):
         top, tail = nl - 1, None
         # frozen / evaluation weights (needs_input_grad says nobody wants dW or db of layer i): that layer runs the plain
         # input-gradient kernel and allocates, zero-fills and accumulates nothing
-        need_w = [bool(ctx.needs_input_grad[3 + 2 * i] or (ctx.has_bias[i] and ctx.needs_input_grad[4 + 2 * i]))
+        need_w = [bool(ctx.needs_input_grad[4 + 2 * i] or (ctx.has_bias[i] and ctx.needs_input_grad[5 + 2 * i]))
                   for i in range(nl)]
         # narrow output layer (<= 4 columns) on top of a 128-wide ReLU layer: only its dz and its weight gradient are
         # computed here; the layer below forms its own input gradient from that dz (rsdf_linear_bwd_fused_tail)
         if (not split and nl >= 2 and need_w[-1] and need_w[-2]
                 and ws[-1].shape[0] <= 4 and ws[-1].shape[1] == 128 and ctx.acts[nl - 2] == relu
-                and bool(lib().rsdf_linear_bwd_fused_supported(ws[-2].shape[1], ws[-2].shape[0]))):
+                and bool(fn("rsdf_linear_bwd_fused_supported")(ws[-2].shape[1], ws[-2].shape[0]))):
             w, y, xin = ws[-1], ys[-1], ys[-2]
             N, K = w.shape
             dzo = torch.empty_like(g)
-            check(lib().rsdf_linear_bwd_input(ptr(g), ptr(y), N, ptr(w), n, K, N, ctx.acts[-1], 0, K, ptr(dzo), None, K, st),
+            check(fn("rsdf_linear_bwd_input")(ptr(g), ptr(y), N, ptr(w), n, K, N, ctx.acts[-1], 0, K, ptr(dzo), None, K, st),
                   "linear_bwd_input")
             dw, db = _dw_db(N, K, ctx.has_bias[-1], xf.device)
-            check(lib().rsdf_linear_bwd_weight(ptr(dzo), N, ptr(xin), K, n, K, N, ptr(dw), ptr(db), st), "linear_bwd_weight")
+            check(fn("rsdf_linear_bwd_weight")(ptr(dzo), N, ptr(xin), K, n, K, N, ptr(dw), ptr(db), st), "linear_bwd_weight")
             grads[2 * top], grads[2 * top + 1] = dw, db
             tail, top = (dzo, N, w), nl - 2
         for i in range(top, -1, -1):
@@ -541,14 +544,14 @@ class _MLPChain(torch.autograd.Function):
             if not need_w[i]:
                 if need_dx:
                     dz = torch.empty_like(g)
-                    check(lib().rsdf_linear_bwd_input(ptr(g), ptr(yarg), N, ptr(w), n, K, N, act, k0, kout, ptr(dz),
+                    check(fn("rsdf_linear_bwd_input")(ptr(g), ptr(yarg), N, ptr(w), n, K, N, act, k0, kout, ptr(dz),
                                                       dx_win, K, st), "linear_bwd_input")
                 g, g_is_dz = dx, False
                 if i == 0:
                     dx_in = dx
                 continue
             dw, db = _dw_db(N, K, ctx.has_bias[i], xf.device)
-            fused = not split and bool(lib().rsdf_linear_bwd_fused_supported(K, N))
+            fused = not split and bool(fn("rsdf_linear_bwd_fused_supported")(K, N))
             prev_relu = fused and i > 0 and ctx.acts[i - 1] == relu
             if tail is not None:
                 dzo, n2, w2 = tail
@@ -556,34 +559,36 @@ class _MLPChain(torch.autograd.Function):
                 if dx is None:   # (a one-hidden-layer network whose input needs no gradient: still wants a dx buffer)
                     dx = torch.empty(n, K, dtype=torch.float32, device=xf.device)
                     dx_win, k0, kout = ptr(dx), 0, K
-                check(lib().rsdf_linear_bwd_fused_tail(ptr(dzo), n2, ptr(w2), ptr(y), N, ptr(xin), K, ptr(w), n, K, N,
+                check(fn("rsdf_linear_bwd_fused_tail")(ptr(dzo), n2, ptr(w2), ptr(y), N, ptr(xin), K, ptr(w), n, K, N,
                                                        ctx.acts[i], k0, kout, dx_win, K, relu if prev_relu else none,
                                                        ptr(dw), ptr(db), st), "linear_bwd_fused_tail")
                 if not need_dx:
                     dx = None
             elif fused:
-                check(lib().rsdf_linear_bwd_fused(ptr(g), ptr(yarg), N, ptr(xin), K, ptr(w), n, K, N, act, k0, kout,
+                check(fn("rsdf_linear_bwd_fused")(ptr(g), ptr(yarg), N, ptr(xin), K, ptr(w), n, K, N, act, k0, kout,
                                                   dx_win, K, relu if prev_relu else none, ptr(dw), ptr(db), st),
                       "linear_bwd_fused")
             else:
                 dz = torch.empty_like(g)
-                check(lib().rsdf_linear_bwd_input(ptr(g), ptr(yarg), N, ptr(w), n, K, N, act, k0, kout, ptr(dz), dx_win,
+                check(fn("rsdf_linear_bwd_input")(ptr(g), ptr(yarg), N, ptr(w), n, K, N, act, k0, kout, ptr(dz), dx_win,
                                                   K, st), "linear_bwd_input")
-                check(lib().rsdf_linear_bwd_weight(ptr(dz), N, ptr(xin), K, n, K, N, ptr(dw), ptr(db), st),
+                check(fn("rsdf_linear_bwd_weight")(ptr(dz), N, ptr(xin), K, n, K, N, ptr(dw), ptr(db), st),
                       "linear_bwd_weight")
             grads[2 * i], grads[2 * i + 1] = dw, db
             g, g_is_dz = dx, prev_relu
             if i == 0:
                 dx_in = dx
-        return (dx_in, None, None, *grads)
+        return (dx_in, None, None, None, *grads)
 
 
-def mlp_chain(x, layers, acts, dx_cols=None):
-    """``layers`` = [(W [out,in], b [out] or None)], ``acts`` = activation name per layer; see _MLPChain."""
+def mlp_chain(x, layers, acts, dx_cols=None, precision="fp32"):
+    """``layers`` = [(W [out,in], b [out] or None)], ``acts`` = activation name per layer; see _MLPChain.
+    ``precision``: 'fp32' (fp32-equivalent split products) or 'bf16' (one bf16 product, fp32 accumulate; opt-in)."""
     flat = []
     for w, b in layers:
         flat += [w, b]
-    return _MLPChain.apply(x, dx_cols, tuple(L.ACT_IDS[a] if not isinstance(a, int) else a for a in acts), *flat)
+    return _MLPChain.apply(x, dx_cols, tuple(L.ACT_IDS[a] if not isinstance(a, int) else a for a in acts), precision,
+                           *flat)
 
 
 class _WeightNorm(torch.autograd.Function):

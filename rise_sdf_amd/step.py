@@ -44,7 +44,7 @@ class TrainStep:
         # parameters with the same random cells and jitter, from a generator of its own that every rank seeds alike and
         # that nothing else draws from (SURVEY 8e option (a): no traffic).
         grid = getattr(model, "occupancy_grid", None)
-        if grid is not None and hasattr(grid, "rng"):
+        if grid is not None and getattr(grid, "rng", 0) is None:     # (a generator already in place is kept)
             grid.rng = torch.Generator(device=dev)
             grid.rng.manual_seed(int(seed) + 7919)
 

@@ -95,6 +95,16 @@ def main():
     dist.all_gather(other, flat)
     if rank == 0:
         res["replicas_bit_identical"] = bool(torch.equal(other[0], other[1]))
+        if not res["replicas_bit_identical"]:              # name the tensors that differ
+            names = [n for n, _ in model.named_parameters()] + ["occupancy_grid.binaries", "occupancy_grid.occs"]
+            off, bad = 0, []
+            for n, t in zip(names, state):
+                k = t.numel()
+                d = int((other[0][off:off + k] != other[1][off:off + k]).sum())
+                if d:
+                    bad.append((n, d, k))
+                off += k
+            res["differing"] = bad[:12]
         res["n_state_words"] = int(flat.numel())
         res["occupied_cells"] = int(model.occupancy_grid.binaries.sum())
         res["samples_rank0"] = samples

@@ -1,0 +1,118 @@
+"""config[4]'s "bf16 MLP on MFMA" mode (BASELINE.json configs[4]): the ``_bf16`` entry points -- one
+bf16 x bf16 product per k-step, fp32 accumulation, fp32 master weights and weight gradients -- against the oracle's networks
+evaluated with bf16-rounded operands (``oracle.mlp_precision("bf16")``).
+
+Tolerances.  Two evaluations that round the same operands agree to fp32 accumulation order EXCEPT where that order moves
+an intermediate activation across a bf16 rounding boundary (one part in 2^9 of that activation); such flips are rare and
+bounded, so values are held to 4e-3 of the output scale and gradients to a cosine of 0.999 / 3e-2 of their scale.  Each test
+also checks that the mode is really in force (it differs from the fp32 result by about a bf16 epsilon, far more than the
+1e-5 the fp32 entry points hold) and that it is CLOSER to the bf16 oracle than to the fp32 one."""
+import pytest
+import torch
+
+import oracle
+from helpers import camera_rays, rel_err
+from test_gpu_model import model_config, oracle_params
+
+pytestmark = pytest.mark.gpu
+
+
+def _cos(a, b):
+    a, b = a.double().flatten().cpu(), b.double().flatten().cpu()
+    return float((a * b).sum() / (a.norm() * b.norm() + 1e-300))
+
+
+@pytest.mark.parametrize("widths", [(84, 128, 128, 128, 128, 3), (73, 128, 128, 1), (35, 64, 64, 48)])
+def test_mlp_chain_bf16_matches_bf16_oracle(dev, widths):
+    from rise_sdf_amd import ops
+    g = torch.Generator().manual_seed(len(widths))
+    n = 3000
+    x = torch.randn(n, widths[0], generator=g)
+    params = [{"w": torch.randn(o, i, generator=g) * (1.6 / i ** 0.5), "b": torch.randn(o, generator=g) * 0.1}
+              for i, o in zip(widths[:-1], widths[1:])]
+    gy = torch.randn(n, widths[-1], generator=g)
+
+    def run_oracle(prec):
+        xs = x.clone().requires_grad_(True)
+        ps = [{k: v.clone().requires_grad_(True) for k, v in p.items()} for p in params]
+        with oracle.mlp_precision(prec):
+            y = oracle.texture.relu_mlp(xs, ps)
+            (y * gy).sum().backward()
+        return y.detach(), xs.grad, ps
+
+    def run_hip(prec):
+        xs = x.to(dev).requires_grad_(True)
+        ps = [(p["w"].to(dev).requires_grad_(True), p["b"].to(dev).requires_grad_(True)) for p in params]
+        y = ops.mlp_chain(xs, ps, ["relu"] * (len(ps) - 1) + ["none"], precision=prec)
+        (y * gy.to(dev)).sum().backward()
+        return y.detach(), xs.grad, ps
+
+    y_b, dx_b, p_b = run_oracle("bf16")
+    y_f, _, _ = run_oracle("fp32")
+    y_g, dx_g, p_g = run_hip("bf16")
+    y_g32, _, _ = run_hip("fp32")
+    scale = float(y_f.abs().max())
+    assert rel_err(y_g32, y_f) < 1e-5                                  # the default entry points are untouched
+    d_mode = float((y_g.cpu() - y_f).abs().max()) / scale
+    assert 2e-4 < d_mode < 5e-2, d_mode                                # bf16 is in force (and sane)
+    err_b = float((y_g.cpu() - y_b).abs().max()) / scale
+    assert err_b < 4e-3 and err_b < 0.5 * d_mode, (err_b, d_mode)      # ... and it is the bf16-operand network
+    assert _cos(dx_g, dx_b) > 0.999 and rel_err(dx_g, dx_b) < 3e-2
+    for (w, b), p in zip(p_g, p_b):
+        assert _cos(w.grad, p["w"].grad) > 0.999 and rel_err(w.grad, p["w"].grad) < 3e-2
+        assert rel_err(b.grad, p["b"].grad) < 3e-2
+
+
+@pytest.mark.parametrize("hidden,n_levels", [(64, 4), (128, 4), (32, 4)])
+def test_fused_field_bf16_matches_bf16_oracle(dev, hidden, n_levels):
+    """The fused stencil kernels (hash gather -> 2-hidden-layer SDF MLP, forward and backward) at ``precision: bf16``."""
+    import rise_sdf_amd as R
+    torch.manual_seed(1)
+    cfg = model_config(hidden=hidden, n_levels=n_levels, feat=48 if hidden >= 64 else 13)
+    cfg["geometry"]["mlp_network_config"]["precision"] = "bf16"
+    geo = R.make("volume-sdf", cfg.geometry).to(dev)
+    geo.train()
+    assert geo.network.precision == "bf16"
+    with torch.no_grad():
+        geo.encoding.encoding.encoding.params.mul_(300.0)
+        l0 = geo.network.layers[0]
+        l0.weight_v[:, 3:] = torch.randn_like(l0.weight_v[:, 3:]) * 0.3
+    geo.update_step(0, 0)
+    assert geo.fused_field_available()
+    rays = camera_rays(12, 12, seed=4)
+    ro, rd = rays[:, :3].contiguous(), rays[:, 3:].contiguous()
+    roi = torch.tensor([-1.5, -1.5, -1.5, 1.5, 1.5, 1.5])
+    ri, ts, te = oracle.ray_marching(ro, rd, scene_aabb=roi, render_step_size=0.02)
+    eps = geo._finite_difference_eps
+    sdf7t, feat = geo.sdf7_from_rays(ro.to(dev), rd.to(dev), ri.to(dev), ts.to(dev), te.to(dev), want_feature=True)
+
+    class M:
+        geometry = geo
+        variance = type("V", (), {"variance": torch.tensor(0.3)})()
+    pos = ro[ri] + rd[ri] * ((ts + te) / 2.0)[:, None]
+    g = torch.Generator().manual_seed(5)
+    gs, gf = torch.randn(ri.numel(), generator=g), torch.randn(ri.numel(), feat.shape[1], generator=g)
+
+    def run_oracle(prec):
+        meta, table, mlp, _ = oracle_params(M)
+        with oracle.mlp_precision(prec):
+            sdf_o, grad_o, feat_o = oracle.volume_sdf(pos, table, meta, mlp, radius=1.5, fd_eps=eps)
+            ((sdf_o * gs).sum() + (feat_o * gf).sum()).backward()
+        return sdf_o.detach(), feat_o.detach(), table, mlp
+
+    sdf_b, feat_b, table_b, mlp_b = run_oracle("bf16")
+    sdf_f, feat_f, _, _ = run_oracle("fp32")
+    ((sdf7t[0] * gs.to(dev)).sum() + (feat * gf.to(dev)).sum()).backward()
+    s_scale, f_scale = float(sdf_f.abs().max()), float(feat_f.abs().max())
+    d_mode = float((feat.detach().cpu() - feat_f).abs().max()) / f_scale
+    assert 2e-4 < d_mode < 5e-2, d_mode
+    assert float((feat.detach().cpu() - feat_b).abs().max()) / f_scale < 4e-3
+    # the taps' SDF column is the fused kernels' fp32 dot product of the bf16-rounded layer-2 activations with the
+    # un-rounded SDF row of W2 (mlp_fused.hip "last layer of taps on VALU"): bf16-close to both evaluations
+    assert float((sdf7t[0].detach().cpu() - sdf_b).abs().max()) / s_scale < 6e-3
+    gt = geo.encoding.encoding.encoding.params.grad.cpu()
+    assert _cos(gt, table_b.grad) > 0.995
+    lin = [m for m in geo.network.layers if isinstance(m, torch.nn.Linear)]
+    for m, p in zip(lin, mlp_b):
+        assert _cos(m.weight_v.grad, p["v"].grad) > 0.995, hidden
+        assert rel_err(m.bias.grad, p["b"].grad) < 5e-2, hidden
