@@ -954,7 +954,7 @@ __attribute__((visibility("hidden"))) int RSDF_P(rsdf_coop_fwd)(int NT, const fl
             if (e_ != hipSuccess) { rsdf_set_error(hipGetErrorString(e_)); return (int)e_; }
         }
         if (feature != nullptr)
-            return rsdf_linear_fwd(h2c, 32 * NT, w2, b2, n_samples, 32 * NT, N2, RSDF_ACT_NONE, feature, N2, (void *)st);
+            return RSDF_P(rsdf_linear_fwd)(h2c, 32 * NT, w2, b2, n_samples, 32 * NT, N2, RSDF_ACT_NONE, feature, N2, (void *)st);
         return 0;
     }
 #define RSDF_COOP_FWD(N)                                                                                             \

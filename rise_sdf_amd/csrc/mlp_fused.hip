@@ -816,7 +816,7 @@ int RSDF_P(rsdf_sdfmlp_fd7_fwd)(const float *x7t, const float *planes, int n_lev
     const int K0 = 3 + 2 * n_levels;
     RSDF_CHECK_ARG(n_levels >= 1 && n_levels <= 16, "sdfmlp_fd7_fwd: n_levels must be in [1,16]");
     RSDF_CHECK_ARG(h2c == nullptr || feature != nullptr, "sdfmlp_fd7_fwd: h2c needs feature");
-    RSDF_CHECK_ARG(rsdf_sdfmlp_fd7_supported(K0, H, N2), "sdfmlp_fd7_fwd: unsupported layer sizes");
+    RSDF_CHECK_ARG(RSDF_P(rsdf_sdfmlp_fd7_supported)(K0, H, N2), "sdfmlp_fd7_fwd: unsupported layer sizes");
     if (n_samples <= 0) return 0;
     if (n_active_levels < 0 || n_active_levels > n_levels) n_active_levels = n_levels;
     hipStream_t st = (hipStream_t)stream;
@@ -847,7 +847,7 @@ int RSDF_P(rsdf_sdfmlp_fd7_bwd)(const float *x7t, const float *planes, int n_lev
 {
     const int K0 = 3 + 2 * n_levels;
     RSDF_CHECK_ARG(n_levels >= 1 && n_levels <= 16, "sdfmlp_fd7_bwd: n_levels must be in [1,16]");
-    RSDF_CHECK_ARG(rsdf_sdfmlp_fd7_supported(K0, H, N2), "sdfmlp_fd7_bwd: unsupported layer sizes");
+    RSDF_CHECK_ARG(RSDF_P(rsdf_sdfmlp_fd7_supported)(K0, H, N2), "sdfmlp_fd7_bwd: unsupported layer sizes");
     if (n_samples <= 0) return 0;
     if (n_active_levels < 0 || n_active_levels > n_levels) n_active_levels = n_levels;
     hipStream_t st = (hipStream_t)stream;
@@ -856,7 +856,7 @@ int RSDF_P(rsdf_sdfmlp_fd7_bwd)(const float *x7t, const float *planes, int n_lev
             // d(h2) of the centre taps through the feature rows of the last layer: one per-layer product
             // [n, N2] x [N2, H]; the cooperative kernel adds the SDF row and continues the chain
             RSDF_CHECK_ARG(dh2c_scratch != nullptr, "sdfmlp_fd7_bwd: d_feature needs the [n, H] dh2c scratch");
-            const int rc = rsdf_linear_bwd_input(d_feature, nullptr, N2, w2, n_samples, H, N2, RSDF_ACT_NONE, 0, H,
+            const int rc = RSDF_P(rsdf_linear_bwd_input)(d_feature, nullptr, N2, w2, n_samples, H, N2, RSDF_ACT_NONE, 0, H,
                                                  nullptr, dh2c_scratch, H, stream);
             if (rc) return rc;
         }

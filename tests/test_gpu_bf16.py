@@ -11,6 +11,7 @@ import pytest
 import torch
 
 import oracle
+from oracle import texture as otex
 from helpers import camera_rays, rel_err
 from test_gpu_model import model_config, oracle_params
 
@@ -36,7 +37,7 @@ def test_mlp_chain_bf16_matches_bf16_oracle(dev, widths):
         xs = x.clone().requires_grad_(True)
         ps = [{k: v.clone().requires_grad_(True) for k, v in p.items()} for p in params]
         with oracle.mlp_precision(prec):
-            y = oracle.texture.relu_mlp(xs, ps)
+            y = otex.relu_mlp(xs, ps)
             (y * gy).sum().backward()
         return y.detach(), xs.grad, ps
 
