@@ -1,8 +1,9 @@
 """config[4]-shaped end-to-end check: the full split-mixed-occ model at the yaml's sizes (128-wide SDF and texture
 MLPs, 48 features, 16-level grid, 512^2 environment map, occupancy pruning, secondary rays, curvature, stage switch)
 driven like systems/split_occ.py's training_step -- ray generation, update_step, build_mips, forward, loss tail,
-backward, Adam -- for a few steps on synthetic images.  Checks that every piece composes and trains (finite losses,
-parameters move, stage switches), not numerical parity (the pieces have their own parity tests)."""
+backward, Adam -- for a few steps on synthetic images.  Checks that every piece composes at the real sizes (finite losses,
+parameters move, stage switches).  Numerical parity of the training step itself -- HIP vs the oracle step by step, and the
+convergence proxy for the PSNR gate -- is tests/test_gpu_convergence.py; the N-rank step is tests/test_gpu_dist_step.py."""
 import math
 
 import pytest
@@ -12,36 +13,9 @@ pytestmark = pytest.mark.gpu
 
 
 def c4_config(n_levels=16, log2_T=19):
-    from rise_sdf_amd import Config
-    mlp = lambda n: {"otype": "VanillaMLP", "activation": "ReLU", "output_activation": "none", "n_neurons": 128,
-                     "n_hidden_layers": n}
-    return Config({
-        "name": "split-mixed-occ", "indirect_pred": True, "relighting_threshold": 0.3, "radius": 1.5,
-        "num_samples_per_ray": 1024, "num_samples_per_secondary_ray": 96, "train_num_rays": 256,
-        "grid_prune": True, "grid_prune_occ_thre": 0.001, "randomized": True, "ray_chunk": 4096,
-        "cos_anneal_end": 10000, "learned_background": False, "split_sum_kick_in_step": 2,
-        "variance": {"init_val": 0.3, "modulate": False},
-        "geometry": {
-            "name": "volume-sdf", "radius": 1.5, "feature_dim": 48, "grad_type": "finite_difference",
-            "finite_difference_eps": "progressive",
-            "xyz_encoding_config": {"otype": "ProgressiveBandHashGrid", "n_levels": n_levels, "start_level": 6,
-                                    "start_step": 6000, "update_steps": 500, "n_features_per_level": 2,
-                                    "log2_hashmap_size": log2_T, "base_resolution": 32,
-                                    "per_level_scale": 1.447269237440378, "include_xyz": True},
-            "mlp_network_config": {"otype": "VanillaMLP", "activation": "ReLU", "output_activation": "none",
-                                   "n_neurons": 128, "n_hidden_layers": 2, "sphere_init": True,
-                                   "sphere_init_radius": 0.5, "weight_norm": True}},
-        "texture": {"name": "volume-mixed-mip-split-occ", "input_feature_dim": 48, "other_dim": 3, "sample_size": 8,
-                    "dir_encoding_config": {"otype": "SphericalHarmonics", "degree": 5, "reflected": True},
-                    "metallic_mlp_network_config": mlp(2), "albedo_mlp_network_config": mlp(4),
-                    "spec_mlp_network_config": mlp(4), "roughness_mlp_network_config": mlp(2),
-                    "secondary_mlp_network_config": mlp(4),
-                    "xyz_encoding_config": {"otype": "VanillaFrequency", "n_frequencies": 6},
-                    "color_activation": "sigmoid"},
-        "light": {"name": "envlight-mip-cube",
-                  "envlight_config": {"hdr_filepath": None, "clamp": True, "nmf_format": False, "scale": 0.5,
-                                      "bias": 0.25, "base_res": 512}},
-    })
+    """The yaml's model node (rise_sdf_amd.config.tensoir_model_config) with the stage switch pulled to step 2."""
+    from rise_sdf_amd.config import tensoir_model_config
+    return tensoir_model_config(n_levels=n_levels, log2_T=log2_T, split_sum_kick_in_step=2)
 
 
 def test_full_model_trains_a_few_steps(dev):
