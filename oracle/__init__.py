@@ -458,15 +458,26 @@ def contract_aabb(x, radius):
 
 
 def volume_sdf(points, table, meta, mlp_params, *, radius, fd_eps, n_active_levels=None,
-               with_grad=True):
+               with_grad=True, sdf7_given=None, return_sdf7=False):
     """Returns (sdf [S], grad [S,3] or None, feature [S,D]).  FD taps are clamped to +-radius
-    before contraction (geometry.py:241)."""
+    before contraction (geometry.py:241).
+
+    ``sdf7_given`` [S,7] (centre, +x,-x,+y,-y,+z,-z): the VALUES of the seven SDF evaluations are replaced by these
+    while the autograd graph stays this function's own (value substitution: x + (given - x).detach()).  The
+    finite-difference divide amplifies one ulp of SDF disagreement between two fp32 implementations by 1/eps; handing
+    the implementation under test's stencil values in removes that forward amplification, so everything downstream
+    of the divide -- normals, alpha, weights, and every gradient back to the table and the weights -- can be compared
+    at the tolerances of SURVEY 8(d) (1e-4 on MLP parameters, 1e-3 on table rows) instead of 1/eps times looser."""
     def field(p_unit):
         enc = composite_encoding(p_unit.reshape(-1, 3), table, meta, n_active_levels)
         return vanilla_mlp(enc, mlp_params)
 
     out = field(contract_aabb(points, radius))
     sdf, feature = out[..., 0], out
+    own7 = [sdf]
+    if sdf7_given is not None:
+        sdf = sdf + (sdf7_given[:, 0].to(sdf.dtype) - sdf).detach()
+        feature = torch.cat([sdf[:, None], out[..., 1:]], -1)
     grad = None
     if with_grad:
         eps = fd_eps
@@ -474,7 +485,12 @@ def volume_sdf(points, table, meta, mlp_params, *, radius, fd_eps, n_active_leve
                              [0, 0, eps], [0, 0, -eps]], dtype=points.dtype)
         pd = (points[:, None, :] + offs).clamp(-radius, radius)
         sd = field(contract_aabb(pd, radius))[..., 0].view(-1, 6)
+        own7.append(sd)
+        if sdf7_given is not None:
+            sd = sd + (sdf7_given[:, 1:].to(sd.dtype) - sd).detach()
         grad = 0.5 * (sd[:, 0::2] - sd[:, 1::2]) / eps
+    if return_sdf7:      # this function's OWN seven values (before any substitution), [S,7]
+        return sdf, grad, feature, torch.cat([own7[0][:, None]] + own7[1:], -1).detach()
     return sdf, grad, feature
 
 
@@ -524,9 +540,10 @@ def occ_grid_update(occs, indices, occ, resolution, occ_thre=0.01, ema_decay=0.9
 # --------------------------------------------------------------------------------------
 def neus_geometry_render(rays, ray_indices, t_starts, t_ends, table, meta, mlp_params,
                          variance, *, radius, fd_eps, cos_anneal_ratio=1.0,
-                         n_active_levels=None):
+                         n_active_levels=None, sdf7_given=None):
     """Field query + NeuS alpha + composite for an already-marched sample set.
-    Returns dict(opacity [N,1], depth [N,1], comp_normal [N,3], weights, alphas, sdf, sdf_grad)."""
+    Returns dict(opacity [N,1], depth [N,1], comp_normal [N,3], weights, alphas, sdf, sdf_grad, sdf7 (own values)).
+    ``sdf7_given``: see volume_sdf."""
     n_rays = rays.shape[0]
     rays_o, rays_d = rays[:, 0:3], rays[:, 3:6]
     ri = ray_indices.to(torch.int64)
@@ -534,8 +551,9 @@ def neus_geometry_render(rays, ray_indices, t_starts, t_ends, table, meta, mlp_p
     mid = (t_starts + t_ends)[:, None] / 2.0
     positions = t_o + t_d * mid
     dists = (t_ends - t_starts)[:, None]
-    sdf, grad, feature = volume_sdf(positions, table, meta, mlp_params, radius=radius,
-                                    fd_eps=fd_eps, n_active_levels=n_active_levels)
+    sdf, grad, feature, own7 = volume_sdf(positions, table, meta, mlp_params, radius=radius,
+                                          fd_eps=fd_eps, n_active_levels=n_active_levels,
+                                          sdf7_given=sdf7_given, return_sdf7=True)
     normal = F.normalize(grad, p=2, dim=-1, eps=1e-6)
     alphas = get_alpha(sdf, normal, t_d, dists, inv_s_from_variance(variance), cos_anneal_ratio)
     weights, trans = render_weight_from_alpha(alphas, ray_indices=ri, n_rays=n_rays)
@@ -544,7 +562,7 @@ def neus_geometry_render(rays, ray_indices, t_starts, t_ends, table, meta, mlp_p
     comp_normal = accumulate_along_rays(weights, normal, ray_indices=ri, n_rays=n_rays)
     return {"opacity": opacity, "depth": depth, "comp_normal": comp_normal, "weights": weights,
             "trans": trans, "alphas": alphas, "sdf": sdf, "sdf_grad": grad, "feature": feature,
-            "normal": normal}
+            "normal": normal, "sdf7": own7}
 
 
 # --------------------------------------------------------------------------------------

@@ -58,7 +58,9 @@ def render(rays, P, *, stage, indirect, relighting=False, stratified_u=None, ove
                                far_plane=1e10, render_step_size=P["render_step_size"], stratified_u=stratified_u,
                                alpha_fn=alpha_fn_for(ro, rd))
     ri, ts, te = override.get("primary", own_primary)
-    ref = neus_geometry_render(rays, ri, ts, te, P["table"], P["meta"], P["mlp"], P["var"], **field)
+    # override["sdf7"] [S,7]: the stencil VALUES of the implementation under test (oracle.volume_sdf, sdf7_given)
+    ref = neus_geometry_render(rays, ri, ts, te, P["table"], P["meta"], P["mlp"], P["var"], **field,
+                               sdf7_given=override.get("sdf7"))
     pos = ro[ri] + rd[ri] * ((ts + te) / 2.0)[:, None]
     if stage == 0:
         colors = T.texture_stage0(ref["feature"], rd[ri], ref["normal"], pos, P["nets"])
@@ -69,7 +71,7 @@ def render(rays, P, *, stage, indirect, relighting=False, stratified_u=None, ove
     normal_map = ref["comp_normal"]
     acc, depth = ref["opacity"], ref["depth"]
     diff, spec, blend = comp[:, :3], comp[:, 3:6], comp[:, 6:7]
-    out = {"own_primary": own_primary, "primary": (ri, ts, te)}
+    out = {"own_primary": own_primary, "primary": (ri, ts, te), "sdf7": ref["sdf7"]}
     if stage != 0:
         diff_pbr, spec_pbr = comp[:, 7:10], comp[:, 10:13]
         spec_ref, spec_light = comp[:, 13:16], comp[:, 16:19]

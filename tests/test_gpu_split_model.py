@@ -8,7 +8,7 @@ import oracle
 from oracle import split_mixed_occ as OS
 from oracle import texture as OT
 from helpers import camera_rays, rel_err, sphere_binary
-from test_gpu_model import oracle_params, split_config
+from test_gpu_model import assert_grads_tight, hip_sdf7, oracle_params, split_config
 
 pytestmark = pytest.mark.gpu
 LIGHT = {"name": "envlight-mip-cube", "envlight_config": {"scale": 0.5, "bias": 0.25, "base_res": 64, "hdr_filepath": None}}
@@ -67,6 +67,30 @@ def _same_up_to_borderline(a, b, slack):
     return len(key(a[0], a[1]) ^ key(b[0], b[1])) <= slack
 
 
+def _n_different(a, b):
+    key = lambda r, t: set(zip(r.tolist(), t.contiguous().view(torch.int32).tolist()))   # noqa: E731
+    return len(key(a[0], a[1]) ^ key(b[0], b[1]))
+
+
+def _all_param_grads(model, P):
+    """name -> (HIP grad, oracle grad) for every network of the model."""
+    hip, ref = {}, {}
+    lin = [m for m in model.geometry.network.layers if isinstance(m, torch.nn.Linear)]
+    for i, (m, p) in enumerate(zip(lin, P["mlp"])):
+        for name, key in (("weight_v", "v"), ("weight_g", "g"), ("bias", "b")):
+            if p[key].grad is not None:
+                hip[f"sdf{i}.{name}"], ref[f"sdf{i}.{name}"] = getattr(m, name).grad, p[key].grad
+    for net in ("albedo", "metallic", "roughness", "env", "secondary"):
+        layers = [m for m in getattr(model.texture, net + "_network").layers if isinstance(m, torch.nn.Linear)]
+        for i, (m, p) in enumerate(zip(layers, P["nets"][net])):
+            if p["w"].grad is not None:
+                hip[f"{net}{i}.w"], ref[f"{net}{i}.w"] = m.weight.grad, p["w"].grad
+                hip[f"{net}{i}.b"], ref[f"{net}{i}.b"] = m.bias.grad, p["b"].grad
+    if P["var"].grad is not None:
+        hip["variance"], ref["variance"] = model.variance.variance.grad.reshape(1), P["var"].grad.reshape(1)
+    return hip, ref
+
+
 def _run(dev, model, rays, u, P, stage, relighting):
     """HIP forward, then the oracle on the HIP path's own sample sets / secondary rays (after checking that the
     oracle's own ones agree with them up to borderline-visibility samples)."""
@@ -86,8 +110,17 @@ def _run(dev, model, rays, u, P, stage, relighting):
                                             render_step_size=step, stratified=False)
     cpu = lambda t3: tuple(t.cpu() for t in t3)   # noqa: E731
     ov = {"primary": cpu(prim), "sec_rays": (so.cpu(), sd.cpu()), "secondary": cpu(sec)}
+    # the primary stencil VALUES of the HIP path (oracle.volume_sdf, sdf7_given): removes the 1/eps amplification of forward
+    # ulps, so that the gradients below are held to SURVEY 8(d)'s 1e-4 / 1e-3 instead of a cosine
+    ov["sdf7"] = hip_sdf7(model, rays, *ov["primary"])
     ref = OS.render(rays, P, stage=stage, indirect=True, relighting=relighting, stratified_u=u, override=ov)
-    # the oracle's OWN sampling / secondary rays agree with the HIP path's up to borderline samples and fp32 depth
+    assert rel_err(ov["sdf7"], ref["sdf7"]) < 3e-6                     # ... and the stencil itself agrees to fp32 rounding
+    # the oracle's OWN sampling / secondary rays agree with the HIP path's up to borderline samples and fp32 depth;
+    # the number of borderline samples that actually differed is reported (no silent slack)
+    d_prim = _n_different(ref["own_primary"], ov["primary"])
+    d_sec = _n_different(ref["own_secondary"], ov["secondary"])
+    print("borderline-visibility samples that differ: primary %d of %d, secondary %d of %d" %
+          (d_prim, ov["primary"][0].numel(), d_sec, ov["secondary"][0].numel()))
     assert _same_up_to_borderline(ref["own_primary"], ov["primary"], max(3, ov["primary"][0].numel() // 2000))
     assert torch.equal(ref["valid_indices"], last["valid_indices"].cpu())
     assert torch.allclose(ref["own_sec_rays"][0], so.cpu(), rtol=1e-4, atol=2e-5)
@@ -110,10 +143,12 @@ def test_secondary_rays_stage0_vs_oracle(dev):
     g = torch.randn(ref["comp_rgb_full"].shape, generator=torch.Generator().manual_seed(4))
     (ref["comp_rgb_full"] * g).sum().backward()
     (out["comp_rgb_full"] * g.to(dev)).sum().backward()
-    s0 = [m for m in model.texture.secondary_network.layers if isinstance(m, torch.nn.Linear)][0]
-    assert rel_err(s0.weight.grad, P["nets"]["secondary"][0]["w"].grad) < 2e-3
     gt = model.geometry.encoding.encoding.encoding.params.grad.cpu()
-    assert torch.nn.functional.cosine_similarity(gt[None], P["table"].grad[None]).item() > 0.999
+    assert torch.nn.functional.cosine_similarity(gt[None], P["table"].grad[None]).item() > 0.99999
+    # every parameter gradient at SURVEY 8(d)'s tolerances (the oracle ran on the HIP path's stencil values, _run)
+    hip, ref_g = _all_param_grads(model, P)
+    assert len(ref_g) >= 3 * 3 + 2 * 5 and "secondary0.w" in ref_g
+    assert_grads_tight(hip, ref_g, gt, P["table"].grad)
 
 
 def test_stage1_model_vs_oracle(dev):
@@ -131,8 +166,12 @@ def test_stage1_model_vs_oracle(dev):
     (ref["comp_rgb_phys_full"] * g).sum().backward()
     (out["comp_rgb_phys_full"] * g.to(dev)).sum().backward()
     assert rel_err(model.emitter.base.grad, P["emitter_base"].grad) < 1e-3
-    a0 = [m for m in model.texture.albedo_network.layers if isinstance(m, torch.nn.Linear)][0]
-    assert rel_err(a0.weight.grad, P["nets"]["albedo"][0]["w"].grad) < 2e-3
+    hip, ref_g = _all_param_grads(model, P)
+    gt = model.geometry.encoding.encoding.encoding.params.grad.cpu()
+    # stage 1 runs through the prefiltered environment (the oracle's prefilters and cube lookups are fp64 dense-weight
+    # restatements, oracle/envlight.py) and the FG-LUT: every parameter gradient within 2e-3 of its tensor's largest entry
+    # (measured: up to 1.1e-3 on the radiance networks; the old gate looked at ONE layer at 2e-3 and the table by cosine)
+    assert_grads_tight(hip, ref_g, gt, P["table"].grad, mlp_tol=2e-3, table_tol=2e-3)
 
 
 def test_relight_third_bounce_vs_oracle(dev):
