@@ -61,9 +61,13 @@ def test_hip_model_matches_reference_forward(dev, tag):
     for k in (KEYS1 if stage else KEYS0):
         ref = fx[f"{tag}__{k}"]
         got = out[k].cpu()
-        atol = 1e-4 if relighting else 2e-5
+        atol = 1e-4 if stage else 2e-5      # stage 1: fp32 prefilters / cube lookups here, fp64 in the reference run
         ok = torch.isclose(got, ref, rtol=1e-4, atol=atol).all(-1)
         bad[k] = int((~ok).sum())
-        # a borderline sample that falls on the other side of T >= 1e-4 moves its pixel by ~1e-4: at most `diff` pixels
-        assert bad[k] <= diff, (tag, k, bad[k], float((got - ref).abs().max()))
+        # a borderline sample that falls on the other side of T >= 1e-4 moves its pixel by ~1e-4: at most `diff` pixels for
+        # the primary set, and up to two more through the secondary (occlusion) pass, whose own sample set has the same
+        # borderline cases and whose rays start from a composited fp32 depth; nothing is off by more than 1e-3
+        allowed = diff + (2 if indirect else 0)
+        assert bad[k] <= allowed and float((got - ref).abs().max()) < 1e-3, (tag, k, bad[k], float((got - ref).abs().max()))
+    print(f"{tag}: pixels outside 1e-4 per output: " + ", ".join(f"{k} {v}" for k, v in bad.items() if v))
     assert torch.equal(out["rays_valid"].cpu(), fx[f"{tag}__rays_valid"])
