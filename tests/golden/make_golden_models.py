@@ -199,6 +199,42 @@ def main():
     saved["render_step_size"] = np.array(model.render_step_size)
     mg.save("models_split_mixed_occ.npz", **saved)
 
+    # ---- NeuSModel (models/neus.py:52-92,128-150,227-317): geometry + volume-radiance texture, occupancy sampling
+    # WITHOUT visibility pruning, composited colour and the _bg / _full dictionaries ---------------------------------
+    from models.neus import NeuSModel
+    ncfg = model_cfg(False, False)
+    ncfg.update({"name": "neus", "variance": {"init_val": 0.45, "modulate": False}, "num_samples_per_ray": 512,
+                 "texture": {"name": "volume-radiance", "input_feature_dim": 13 + 3,
+                             "dir_encoding_config": {"otype": "SphericalHarmonics", "degree": 4},
+                             "mlp_network_config": {"otype": "VanillaMLP", "activation": "ReLU",
+                                                    "output_activation": "none", "n_neurons": 64, "n_hidden_layers": 2},
+                             "color_activation": "sigmoid"}})
+    ncfg.pop("light")
+    torch.manual_seed(6)
+    neus = NeuSModel(mg.Cfg(ncfg))
+    with torch.no_grad():
+        neus.geometry.encoding.encoding.encoding.params.mul_(10.0)
+        l0 = neus.geometry.network.layers[0]
+        l0.weight_v[:, 3:] = torch.randn_like(l0.weight_v[:, 3:]) * 0.3
+    from models import geometry as rgeo
+    neus.geometry.contraction_type = rgeo.ContractionType.AABB      # (neus.py:57 leaves it to the caller)
+    neus.eval()
+    neus.update_step(0, 0)
+    neus.background_color = torch.ones(3)
+    with torch.no_grad():
+        nout = neus.forward_(rays)
+    call = neus.occupancy_grid.calls[0]
+    print("neus samples", call[0].numel(), "valid rays", int((nout["opacity"][:, 0] > 0.5).sum()))
+    nsaved = {"rays": rays, "shell": np.array(SHELL), "fd_eps": np.array(neus.geometry._finite_difference_eps),
+              "render_step_size": np.array(neus.render_step_size),
+              "primary_ri": call[0], "primary_ts": call[1], "primary_te": call[2]}
+    for k, v in nout.items():
+        if isinstance(v, torch.Tensor):
+            nsaved["out__" + k] = v
+    for k, v in neus.state_dict().items():
+        nsaved["p__" + k] = v
+    mg.save("models_neus.npz", **nsaved)
+
 
 if __name__ == "__main__":
     main()

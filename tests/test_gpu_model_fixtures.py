@@ -71,3 +71,35 @@ def test_hip_model_matches_reference_forward(dev, tag):
         assert bad[k] <= allowed and float((got - ref).abs().max()) < 1e-3, (tag, k, bad[k], float((got - ref).abs().max()))
     print(f"{tag}: pixels outside 1e-4 per output: " + ", ".join(f"{k} {v}" for k, v in bad.items() if v))
     assert torch.equal(out["rays_valid"].cpu(), fx[f"{tag}__rays_valid"])
+
+
+def test_hip_neus_matches_reference_forward(dev):
+    """NeuSModel (general path: FD normals + volume-radiance texture) loaded from the reference's state_dict."""
+    import rise_sdf_amd as R
+    from test_gpu_model import model_config
+    from test_oracle_models import load_neus_fixture
+    fx = load_neus_fixture()
+    cfg = model_config(hidden=32, n_levels=4, feat=13, grid_prune=True)
+    cfg["variance"]["init_val"] = 0.45
+    cfg["num_samples_per_ray"] = 512
+    cfg["texture"] = {"name": "volume-radiance", "input_feature_dim": 13 + 3,
+                      "dir_encoding_config": {"otype": "SphericalHarmonics", "degree": 4},
+                      "mlp_network_config": {"otype": "VanillaMLP", "activation": "ReLU", "output_activation": "none",
+                                             "n_neurons": 64, "n_hidden_layers": 2},
+                      "color_activation": "sigmoid"}
+    model = R.make("neus", R.Config(dict(cfg))).to(dev)
+    state = {k[3:]: v for k, v in fx.items() if k.startswith("p__")}
+    missing, unexpected = model.load_state_dict(state, strict=False)
+    assert not unexpected, unexpected
+    assert all("occupancy_grid" in m for m in missing), missing
+    model.occupancy_grid.binaries = sphere_binary(128, *[float(v) for v in fx["shell"]]).to(dev)[None]
+    model.eval()
+    model.update_step(0, 0)
+    model.background_color = torch.ones(3, device=dev)
+    with torch.no_grad():
+        out = model.forward_(fx["rays"].to(dev))
+    assert int(out["num_samples"]) == int(fx["out__num_samples"])            # no visibility pruning: the marcher is bit-exact
+    for k in ("comp_rgb", "opacity", "depth", "comp_normal", "comp_rgb_full"):
+        ref = fx["out__" + k]
+        assert torch.allclose(out[k].cpu(), ref, rtol=1e-4, atol=2e-5), (k, float((out[k].cpu() - ref).abs().max()))
+    assert torch.equal(out["rays_valid_full"].cpu(), fx["out__rays_valid_full"])

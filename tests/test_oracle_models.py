@@ -72,3 +72,45 @@ def test_oracle_model_matches_reference_forward(tag):
     assert int((fx[f"{tag}__opacity"][:, 0] > 0.5).sum()) == out["valid_indices"].numel() > 30
     if relighting:
         assert int(out["rmask"].sum()) > 0, "the relighting fixture must exercise the third bounce"
+
+
+# ---- NeuSModel (models/neus.py:227-317) --------------------------------------------------------------------------------
+NEUS_GOLDEN = os.path.join(os.path.dirname(GOLDEN), "models_neus.npz")
+
+
+def load_neus_fixture():
+    z = np.load(NEUS_GOLDEN)
+    return {k: torch.from_numpy(z[k]) for k in z.files}
+
+
+def test_oracle_neus_matches_reference_forward():
+    """oracle.neus_geometry_render + the radiance network against the reference's own NeuSModel.forward_ (eval mode,
+    occupancy sampling without visibility pruning, volume-radiance texture, white background)."""
+    import torch.nn.functional as F
+    fx = load_neus_fixture()
+    t = lambda k: fx["p__" + k]   # noqa: E731
+    meta, n_params = oracle.grid_meta(4, 2, 14, 16, 1.5)
+    table = t("geometry.encoding.encoding.encoding.params")
+    mlp = [{"g": t(f"geometry.network.layers.{i}.weight_g"), "v": t(f"geometry.network.layers.{i}.weight_v"),
+            "b": t(f"geometry.network.layers.{i}.bias")} for i in (0, 2, 4)]
+    tex = [{"w": t(f"texture.network.layers.{i}.weight"), "b": t(f"texture.network.layers.{i}.bias")} for i in (0, 2, 4)]
+    rays = fx["rays"]
+    roi = OS.ROI(1.5)
+    shell = [float(v) for v in fx["shell"]]
+    with torch.no_grad():
+        ri, ts, te = oracle.ray_marching(rays[:, :3].contiguous(), rays[:, 3:].contiguous(), scene_aabb=roi, grid_roi=roi,
+                                         grid_binary=sphere_binary(128, *shell), near_plane=0.0, far_plane=1e10,
+                                         render_step_size=float(fx["render_step_size"]))
+        assert torch.equal(ri, fx["primary_ri"]) and torch.equal(ts, fx["primary_ts"]) and torch.equal(te, fx["primary_te"])
+        ref = oracle.neus_geometry_render(rays, ri, ts, te, table, meta, mlp, t("variance.variance"), radius=1.5,
+                                          fd_eps=float(fx["fd_eps"]))
+        t_dirs = rays[:, 3:][ri]
+        normal = F.normalize(ref["sdf_grad"], p=2, dim=-1)                  # models/neus.py:258
+        rgb = torch.sigmoid(OT.relu_mlp(torch.cat([ref["feature"], OT.sh_encode((t_dirs + 1) / 2, 4), normal], -1), tex))
+        comp = oracle.accumulate_along_rays(ref["weights"], rgb, ray_indices=ri, n_rays=rays.shape[0])
+    got = {"comp_rgb": comp, "opacity": ref["opacity"], "depth": ref["depth"],
+           "comp_normal": F.normalize(ref["comp_normal"], p=2, dim=-1),
+           "comp_rgb_full": comp + 1.0 * (1.0 - ref["opacity"])}
+    for k, v in got.items():
+        assert torch.allclose(v, fx["out__" + k], rtol=1e-5, atol=2e-6), (k, float((v - fx["out__" + k]).abs().max()))
+    assert int(fx["out__num_samples_full"]) == ri.numel() and int((fx["out__opacity"][:, 0] > 0.5).sum()) > 50
