@@ -354,7 +354,13 @@ march_entry(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
     const float near_ = t_min[i], far_ = t_max[i];
     const float dt_min = step_size, dt_max = 1e10f;
     int64_t base = 0;
-    if (WRITE) base = packed_info[2 * i];
+    int limit = 0;
+    if (WRITE) {
+        base = packed_info[2 * i];
+        // never write more than packed_info says (normally exactly the recount below).  A caller that sized its buffers
+        // from an earlier step and clamped packed_info to that capacity (OccGridEstimator capacity mode) stays in bounds.
+        limit = packed_info[2 * i + 1];
+    }
 
     int j = 0;
     float t0 = near_;
@@ -386,7 +392,7 @@ march_entry(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
 #pragma unroll
         for (int q = 0; q < SPEC; ++q) {
             if (m == q && q < n_spec && am[q] < far_ && occ[q] != 0) {
-                if (WRITE) {
+                if (WRITE && j < limit) {
                     t_starts[base + j] = a0[q];
                     t_ends[base + j] = a1[q];
                     ray_indices[base + j] = i;

@@ -247,6 +247,9 @@ class OccGridEstimator(nn.Module):
         # optional torch.Generator for the update's random cells / jitter (rise_sdf_amd.step.TrainStep seeds one alike on
         # every rank so that the replicated grids stay identical); None = the global generator, as the reference
         self.rng = None
+        self.capacity_mode = False
+        self._capacity = {}
+        self.stats = {"capped_calls": 0, "overflows": 0}
 
     @property
     def device(self):
@@ -270,9 +273,16 @@ class OccGridEstimator(nn.Module):
         if stratified or stratified_u is not None:
             u = torch.rand_like(t_min) if stratified_u is None else stratified_u.to(t_min)
             t_min = t_min + u * render_step_size
+        if self.capacity_mode and alpha_fn is not None and sigma_fn is None:
+            out = self._sampling_capped(rays_o, rays_d, t_min, t_max, alpha_fn, render_step_size, cone_angle,
+                                        early_stop_eps, alpha_thre, key=(near, far, round(float(render_step_size), 9)))
+            if out is not None:
+                return out
         packed_info, ray_indices, t_starts, t_ends = ops.march(
             rays_o, rays_d, t_min, t_max, self.aabbs[0], self.binaries[0], render_step_size,
             cone_angle)
+        if self.capacity_mode:
+            self._remember(key=(near, far, round(float(render_step_size), 9)), n_candidates=ray_indices.numel())
         if (sigma_fn is not None or alpha_fn is not None) and ray_indices.numel() > 0:
             if sigma_fn is not None:
                 sigmas = sigma_fn(t_starts, t_ends, ray_indices)
@@ -285,6 +295,36 @@ class OccGridEstimator(nn.Module):
                                      early_stop_eps=early_stop_eps, alpha_thre=alpha_thre)
             ray_indices, t_starts, t_ends = ops.compact_samples(keep, ray_indices, t_starts, t_ends)
         return ray_indices, t_starts, t_ends
+
+    # ---- capacity mode (opt-in: ``estimator.capacity_mode = True``; rise_sdf_amd.step.TrainStep switches it on) ----------
+    # Visibility-pruned sampling reads two counts back per call in the reference (the marcher's candidate total,
+    # ray_marching.cu:257-261, and the survivors after the boolean-mask compaction).  With buffers sized from the previous
+    # call of the same kind (+15 %) the marcher, alpha_fn, the visibility test and the compaction are all enqueued without
+    # knowing either count, and both are read together afterwards: ONE host read per sampling call.  The samples, their
+    # order and every value are identical to the exact path (tests/test_gpu_edges.py); if the candidates outgrew the
+    # buffers the call is redone the exact way and the capacity grows.
+    def _remember(self, key, n_candidates):
+        self._capacity[key] = int(n_candidates * 1.15) + 4096
+
+    def _sampling_capped(self, rays_o, rays_d, t_min, t_max, alpha_fn, render_step_size, cone_angle, early_stop_eps,
+                         alpha_thre, key):
+        cap = self._capacity.get(key)
+        if cap is None:
+            return None
+        packed, ri, ts, te, total = ops.march_capped(rays_o, rays_d, t_min, t_max, self.aabbs[0], self.binaries[0],
+                                                     render_step_size, cap, cone_angle)
+        alphas = alpha_fn(ts, te, ri)
+        keep = render_visibility(alphas, packed_info=packed, early_stop_eps=early_stop_eps, alpha_thre=alpha_thre,
+                                 zero_init=True)
+        cnt = []
+        ri_o, ts_o, te_o = ops.compact_samples(keep, ri, ts, te, count_out=cnt)
+        n_cand, n_kept = torch.cat([total, cnt[0]]).tolist()          # the one host read of this call
+        self._remember(key, n_cand)
+        self.stats["capped_calls"] += 1
+        if n_cand > cap:                                               # truncated: redo exactly (rare)
+            self.stats["overflows"] += 1
+            return None
+        return ri_o[:n_kept], ts_o[:n_kept], te_o[:n_kept]
 
     @torch.no_grad()
     def _sample_uniform_and_occupied_cells(self, n: int):

@@ -87,6 +87,37 @@ def march(rays_o, rays_d, t_min, t_max, roi, binary, step_size, cone_angle=0.0):
 
 
 @torch.no_grad()
+def march_capped(rays_o, rays_d, t_min, t_max, roi, binary, step_size, capacity, cone_angle=0.0):
+    """The marcher WITHOUT its host read: count -> device scan -> write into buffers of ``capacity`` samples that the
+    caller sized from an earlier call.  packed_info is clamped to the capacity on the device (a ray whose samples would
+    not fit keeps the ones that do), the tail of the buffers is a harmless dummy sample (ray 0, t = 0) that no ray's
+    packed_info covers.  -> (packed_info, ray_indices [cap], t_starts [cap], t_ends [cap], total int32 [1] on the
+    device: the TRUE sample count; total > capacity means the set was truncated and must be redone)."""
+    o, d, tn, tf, r = _f32c(rays_o), _f32c(rays_d), _f32c(t_min), _f32c(t_max), _f32c(roi)
+    b = _u8(binary)
+    require_device(o, d, tn, tf, r, b)
+    n, dev = o.shape[0], o.device
+    rx, ry, rz = b.shape
+    counts = torch.empty(n, dtype=torch.int32, device=dev)
+    packed = torch.empty(n, 2, dtype=torch.int32, device=dev)
+    total = torch.zeros(1, dtype=torch.int32, device=dev)
+    st = stream_ptr()
+    check(lib().rsdf_march_count(ptr(o), ptr(d), ptr(tn), ptr(tf), ptr(r), ptr(b), rx, ry, rz, float(step_size),
+                                 float(cone_angle), n, ptr(counts), st), "march_count")
+    check(lib().rsdf_pack_from_counts(ptr(counts), n, ptr(packed), ptr(total), ptr(_scan_scratch(n, dev)), st),
+          "pack_from_counts")
+    cap = int(capacity)
+    packed[:, 1] = torch.minimum(packed[:, 1], (cap - packed[:, 0]).clamp_(min=0))
+    ri = torch.zeros(cap, dtype=torch.int64, device=dev)
+    ts = torch.zeros(cap, dtype=torch.float32, device=dev)
+    te = torch.zeros(cap, dtype=torch.float32, device=dev)
+    if cap > 0:
+        check(lib().rsdf_march_write(ptr(o), ptr(d), ptr(tn), ptr(tf), ptr(r), ptr(b), rx, ry, rz, float(step_size),
+                                     float(cone_angle), n, ptr(packed), ptr(ri), ptr(ts), ptr(te), st), "march_write")
+    return packed, ri, ts, te, total
+
+
+@torch.no_grad()
 def query_occ(samples, roi, binary, return_cell=False):
     """lib/nerfacc/grid.py query_grid / ray_marching.cu:295-358 (AABB)."""
     x, r = _f32c(samples), _f32c(roi)
@@ -132,8 +163,9 @@ def unpack_info(packed_info, n_samples):
 
 
 @torch.no_grad()
-def compact_samples(keep, ray_indices, t_starts, t_ends):
-    """Boolean-mask compaction of lib/nerfacc/ray_marching.py:213-218 (one host read of the count)."""
+def compact_samples(keep, ray_indices, t_starts, t_ends, count_out=None):
+    """Boolean-mask compaction of lib/nerfacc/ray_marching.py:213-218 (one host read of the count; with ``count_out`` (a
+    list) the device count is appended to it instead and the un-sliced outputs are returned)."""
     k = keep.contiguous().view(torch.uint8) if keep.dtype == torch.bool else keep.contiguous()
     ri, ts, te = ray_indices.contiguous(), _f32c(t_starts), _f32c(t_ends)
     require_device(k, ri, ts, te)
@@ -144,6 +176,9 @@ def compact_samples(keep, ray_indices, t_starts, t_ends):
     check(lib().rsdf_compact_samples(ptr(k), ptr(ri), ptr(ts), ptr(te), n, ptr(off), ptr(cnt),
                                      ptr(_scan_scratch(n, dev)), ptr(ri_o), ptr(ts_o), ptr(te_o),
                                      stream_ptr()), "compact_samples")
+    if count_out is not None:          # capacity mode: the caller reads this count together with the marcher's total
+        count_out.append(cnt)
+        return ri_o, ts_o, te_o
     m = int(cnt.item())
     return ri_o[:m], ts_o[:m], te_o[:m]
 
@@ -219,12 +254,13 @@ def render_transmittance_from_alpha(alphas, *, ray_indices=None, packed_info=Non
 
 @torch.no_grad()
 def render_visibility(alphas, *, ray_indices=None, packed_info=None, n_rays=None,
-                      early_stop_eps=1e-4, alpha_thre=0.0):
-    """lib/nerfacc/vol_rendering.py:452-520 -> bool [S]."""
+                      early_stop_eps=1e-4, alpha_thre=0.0, zero_init=False):
+    """lib/nerfacc/vol_rendering.py:452-520 -> bool [S].  ``zero_init``: entries that no ray's packed_info covers (the
+    dummy tail of a capacity-sized buffer) read as False instead of being left unwritten."""
     pk = _packed(ray_indices, packed_info, n_rays)
     a = _f32c(alphas.reshape(-1))
     require_device(pk, a)
-    keep = torch.empty(a.numel(), dtype=torch.uint8, device=a.device)
+    keep = (torch.zeros if zero_init else torch.empty)(a.numel(), dtype=torch.uint8, device=a.device)
     check(lib().rsdf_visibility_from_alpha(ptr(pk), ptr(a), pk.shape[0], float(early_stop_eps),
                                            float(alpha_thre), ptr(keep), stream_ptr()),
           "visibility_from_alpha")

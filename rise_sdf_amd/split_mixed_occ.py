@@ -48,6 +48,9 @@ class SplitMixedOCCModel(BaseModel):
         self.secondary_shader_chunk = self.config.get("secondary_shader_chunk", 160000)
         self.cos_anneal_ratio = 1.0
         self.stage = 0
+        # opt-in (rise_sdf_amd.step.TrainStep): the secondary-ray blend as a select over all rays instead of a
+        # gather / scatter over torch.nonzero(opacity > 0.5), which costs a host read per step
+        self.masked_secondary = False
 
     # ---- per-step schedule (:98-136) ------------------------------------------------------------------
     def update_step(self, epoch, global_step):
@@ -103,14 +106,21 @@ class SplitMixedOCCModel(BaseModel):
         return alpha_fn
 
     # ---- secondary-ray occlusion (R1, :179-222) -------------------------------------------------------------
-    def compute_indirect_radiance(self, rays_o, rays_d):
+    def compute_indirect_radiance(self, rays_o, rays_d, valid=None):
+        """``valid`` (bool [n_rays], masked-secondary mode): rays outside it are given an empty [t_min, t_max] interval, so
+        they march to nothing; the others see exactly the interval the slab test gives them."""
         n_rays = rays_o.shape[0]
         alpha_fn = self._alpha_fn(rays_o, rays_d)
         with torch.no_grad():
             step = (self.secondary_far_plane - self.secondary_near_plane) / (self.num_samples_per_secondary_ray - 1)
+            t_min = t_max = None
+            if valid is not None:
+                t_min, t_max = ops.ray_aabb_intersect(rays_o, rays_d, self.occupancy_grid.aabbs[0])
+                miss = torch.full_like(t_min, 1e10)
+                t_min, t_max = torch.where(valid, t_min, miss), torch.where(valid, t_max, miss)
             ray_indices, t_starts, t_ends = self.occupancy_grid.sampling(
                 rays_o, rays_d, alpha_fn=alpha_fn, near_plane=self.secondary_near_plane,
-                far_plane=self.secondary_far_plane, render_step_size=step, stratified=False)
+                far_plane=self.secondary_far_plane, render_step_size=step, stratified=False, t_min=t_min, t_max=t_max)
             acc_map, depth_map, _ = secondary_rendering(t_starts, t_ends, ray_indices=ray_indices, n_rays=n_rays,
                                                         alpha_fn=alpha_fn, chunk_size=self.secondary_shader_chunk)
         return 1.0 - acc_map, depth_map
@@ -154,8 +164,28 @@ class SplitMixedOCCModel(BaseModel):
             diff_rgb_pbr_map, spec_rgb_pbr_map = rgb_map[..., 7:10], rgb_map[..., 10:13]
             spec_ref_map, spec_light_map = rgb_map[..., 13:16], rgb_map[..., 16:19]
             albedo_map, metallic_map, roughness_map = rgb_map[..., 19:22], rgb_map[..., 22:23], rgb_map[..., 23:]
-        valid_indices = torch.nonzero(acc_map > 0.5)[..., 0]
-        if valid_indices.numel() > 0 and self.config.get("indirect_pred", False):
+        if (self.masked_secondary and self.training and not relighting and self.config.get("indirect_pred", False)):
+            # The same blend without the host read of ``torch.nonzero`` (models/split_mixed_occ.py:291): every ray goes
+            # through the secondary pass, rays with opacity <= 0.5 with an empty marching interval, and the blend is a
+            # select.  Per ray the arithmetic is the reference's; unselected rays contribute nothing, forward or backward.
+            valid = acc_map > 0.5                                            # [N,1]
+            sec_o = rays_o + depth_map * rays_d
+            wo = -rays_d
+            sec_d = 2 * torch.sum(wo * normal_map, dim=-1, keepdim=True) * normal_map - wo
+            tr, sec_depth = self.compute_indirect_radiance(sec_o.detach().contiguous(), sec_d.detach().contiguous(),
+                                                           valid=valid[:, 0])
+            tr, sec_depth = tr.clamp(0, 1).detach(), sec_depth.detach()
+            self._last_secondary = {"valid": valid, "sec_o": sec_o.detach(), "sec_d": sec_d.detach(), "tr": tr,
+                                    "sec_depth": sec_depth}
+            sec_feature = self.geometry(sec_o, with_grad=False, with_feature=True, input_grad=True)[1]
+            sec_rgb = self.texture.secondary_shading(sec_feature, sec_d, normal_map)
+            spec_rgb_map = torch.where(valid, tr * spec_rgb_map + (1 - tr) * sec_rgb, spec_rgb_map)
+            if self.stage != 0:
+                spec_rgb_pbr_map = torch.where(valid, tr * spec_rgb_pbr_map + (1 - tr) * sec_rgb, spec_rgb_pbr_map)
+            valid_indices = None
+        else:
+            valid_indices = torch.nonzero(acc_map > 0.5)[..., 0]
+        if valid_indices is not None and valid_indices.numel() > 0 and self.config.get("indirect_pred", False):
             sec_o = rays_o[valid_indices] + depth_map[valid_indices] * rays_d[valid_indices]
             wo = -rays_d[valid_indices]
             nv = normal_map[valid_indices]

@@ -23,7 +23,7 @@ from .loss import loss_tail
 class TrainStep:
     def __init__(self, model, dataset, optimizer, lambdas, *, train_num_rays=256, max_train_num_rays=4096,
                  num_samples_per_ray=1024, dynamic_ray_sampling=True, background_color="random", apply_mask=True,
-                 sparsity_scale=1.0, seed=0, rank=0, world=1, grad_buckets=None, reg_lambdas=None):
+                 sparsity_scale=1.0, seed=0, rank=0, world=1, grad_buckets=None, reg_lambdas=None, sync_free=True):
         self.model, self.ds, self.opt, self.lambdas = model, dataset, optimizer, dict(lambdas)
         self.train_num_rays = int(train_num_rays)
         self.max_train_num_rays = int(max_train_num_rays)
@@ -44,6 +44,15 @@ class TrainStep:
         # parameters with the same random cells and jitter, from a generator of its own that every rank seeds alike and
         # that nothing else draws from (SURVEY 8e option (a): no traffic).
         grid = getattr(model, "occupancy_grid", None)
+        if sync_free:
+            # Host reads of the reference's step: marcher total + compaction count per sampling call (x2 with
+            # secondary rays), torch.nonzero for the secondary rays, num_samples.item() for dynamic_ray_sampling = 6, plus
+            # two host-to-device copies this mirror had added.  Here: ONE read per sampling call (capacity mode,
+            # nerfacc/__init__.py) = 2 per step with secondary rays, 1 without; identical samples and values.
+            if grid is not None and hasattr(grid, "capacity_mode"):
+                grid.capacity_mode = True
+            if hasattr(model, "masked_secondary"):
+                model.masked_secondary = True
         if grid is not None and getattr(grid, "rng", 0) is None:     # (a generator already in place is kept)
             grid.rng = torch.Generator(device=dev)
             grid.rng.manual_seed(int(seed) + 7919)

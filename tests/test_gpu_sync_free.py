@@ -1,0 +1,89 @@
+"""The training step's host reads.  Capacity-mode sampling (one read per sampling call instead of
+two) and the masked secondary-ray blend (no ``torch.nonzero``) must produce exactly what the exact paths produce."""
+import pytest
+import torch
+
+from helpers import camera_rays, sphere_binary
+from test_gpu_model import split_config
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(dev, indirect=True, stage1=False):
+    import rise_sdf_amd as R
+    torch.manual_seed(0)
+    cfg = split_config(indirect=indirect)
+    cfg["curvature"] = False
+    if stage1:
+        cfg["split_sum_kick_in_step"] = 0
+        cfg["light"] = {"name": "envlight-mip-cube", "envlight_config": {"scale": 0.5, "bias": 0.25, "base_res": 64,
+                                                                           "hdr_filepath": None}}
+    model = R.make("split-mixed-occ", cfg).to(dev)
+    model.train()
+    with torch.no_grad():
+        model.geometry.encoding.encoding.encoding.params.mul_(1000.0)
+        l0 = model.geometry.network.layers[0]
+        l0.weight_v[:, 3:] = torch.randn_like(l0.weight_v[:, 3:]) * 0.3
+        model.variance.variance.fill_(0.6)
+    model.occupancy_grid.binaries = sphere_binary(128, 0.2, 0.9).to(dev)[None]
+    model.background_color = torch.ones(3, device=dev)
+    model.update_step(0, 0)
+    return model
+
+
+def test_capacity_mode_sampling_is_identical(dev):
+    model = _model(dev)
+    grid = model.occupancy_grid
+    rays = camera_rays(24, 24, seed=2).to(dev)
+    ro, rd = rays[:, :3].contiguous(), rays[:, 3:].contiguous()
+    u = torch.rand(rays.shape[0], generator=torch.Generator().manual_seed(3)).to(dev)
+    kw = dict(alpha_fn=model._alpha_fn(ro, rd), render_step_size=model.render_step_size, stratified_u=u, cone_angle=0.0,
+              alpha_thre=0.0)
+    with torch.no_grad():
+        exact = grid.sampling(ro, rd, **kw)
+        grid.capacity_mode = True
+        first = grid.sampling(ro, rd, **kw)                  # no capacity yet: exact path, remembers the size
+        assert grid.stats["capped_calls"] == 0
+        capped = grid.sampling(ro, rd, **kw)                 # sized from the previous call: one host read
+        assert grid.stats["capped_calls"] == 1 and grid.stats["overflows"] == 0
+        for k in list(grid._capacity):                       # a capacity that is too small: detected, redone exactly
+            grid._capacity[k] = 1000
+        over = grid.sampling(ro, rd, **kw)
+        assert grid.stats["overflows"] == 1
+        again = grid.sampling(ro, rd, **kw)                  # ... and the capacity has grown back
+        assert grid.stats["overflows"] == 1 and grid.stats["capped_calls"] == 3
+    assert exact[0].numel() > 3000
+    for other in (first, capped, over, again):
+        for a, b in zip(exact, other):
+            assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("stage1", [False, True])
+def test_masked_secondary_blend_matches_the_gather_path(dev, stage1):
+    rays = camera_rays(20, 20, seed=2).to(dev)
+    u = torch.rand(rays.shape[0], generator=torch.Generator().manual_seed(3)).to(dev)
+    g = torch.randn(rays.shape[0], 3, generator=torch.Generator().manual_seed(4)).to(dev)
+    key = "comp_rgb_phys_full" if stage1 else "comp_rgb_full"
+    res = []
+    for masked in (False, True):
+        model = _model(dev, stage1=stage1)
+        model.masked_secondary = masked
+        model.occupancy_grid.capacity_mode = masked
+        if stage1:
+            model.emitter.build_mips()
+        for _ in range(2 if masked else 1):                  # second pass: the capped sampler is in use
+            for p in model.parameters():
+                p.grad = None
+            out = model.forward_(rays, stratified_u=u)
+            (out[key] * g).sum().backward()
+        if masked:
+            assert model.occupancy_grid.stats["capped_calls"] >= 2       # primary and secondary sampling
+            assert int(model._last_secondary["valid"].sum()) > 40
+        res.append((out, {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
+    (o0, g0), (o1, g1) = res
+    for k in ("comp_rgb", "comp_spec_rgb", "comp_rgb_full", "opacity", "depth") + (("comp_rgb_phys", key) if stage1 else ()):
+        assert torch.allclose(o0[k], o1[k], rtol=0, atol=1e-6), k
+    assert set(g0) == set(g1)
+    for n in g0:
+        scale = float(g0[n].abs().max()) + 1e-20
+        assert float((g0[n] - g1[n]).abs().max()) < 2e-5 * scale, n     # float atomics: last bits only
