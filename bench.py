@@ -363,20 +363,24 @@ def secondary_measurements(dev, args, rays, jitter, cot):
     # two-line dropin.install()): [7 S, 35] rows through HBM, so a quarter of the view at the reference's chunk size
     guarded("dropin_path", lambda: c1_variant(args.hidden, 4096, n_rays=rays.shape[0] // 4 // 800 * 800, fused=False))
 
-    def c2():
+    def c2(tex_precision="fp32"):
         from bench_c2 import measure_c2
-        r = measure_c2(dev, args.width, args.height, 16384, stage=1, tex_hidden=128, steps=1)
+        r = measure_c2(dev, args.width, args.height, 16384, stage=1, tex_hidden=128, steps=1, tex_precision=tex_precision)
         out = brief({"dt": r["ms_per_step"] / 1e3, "samples": r["samples_per_step"], "summary": r["summary"]}, 1)
         out["workload"] = r["workload"]
         return out
     guarded("c2_800", c2)
+    # configs[4]'s bf16 mode on the radiance networks only (SDF network fp32: the combination the convergence proxy,
+    # tests/test_gpu_convergence.py, finds indistinguishable from fp32)
+    guarded("c2_800_bf16_radiance", lambda: c2("bf16"))
 
-    def c3():
+    def c3(**kw):
         from bench_step import measure
-        r = measure(dev, stage=1, steps=30, settle=80)
+        r = measure(dev, stage=1, steps=30, settle=80, syncs=True, **kw)
         return {k: r[k] for k in ("ms_per_step", "rays_per_step", "samples_per_step", "samples_per_s",
-                                  "rsdf_kernel_ms_per_step", "top", "hidden", "stage")}
+                                  "rsdf_kernel_ms_per_step", "host_syncs_per_step", "top", "hidden", "stage")}
     guarded("c3_step", c3)
+    guarded("c3_step_bf16_radiance", lambda: c3(tex_precision="bf16"))
     return extras
 
 

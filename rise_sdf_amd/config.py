@@ -111,12 +111,13 @@ def load_yaml(path, overrides=None):
     return Config(deep(root))
 
 
-def tensoir_model_config(n_levels=16, log2_T=19, hidden=128, **overrides):
+def tensoir_model_config(n_levels=16, log2_T=19, hidden=128, tex_precision="fp32", sdf_precision="fp32", **overrides):
     """The ``model:`` node of configs/split-mixed-occ-tensoir.yaml:31-133 as a Config (sizes, schedules and flags of the
     shipped yaml: 128-wide SDF and radiance MLPs, 48 features, 16-level base-32 T = 2^19 grid, 512^2 environment cube,
-    occupancy pruning, secondary rays, split-sum from step 10000).  ``overrides`` replace top-level keys."""
+    occupancy pruning, secondary rays, split-sum from step 10000).  ``tex_precision`` / ``sdf_precision``: this build's
+    per-network ``precision`` key (fp32 or bf16; BASELINE.json configs[4]).  ``overrides`` replace top-level keys."""
     mlp = lambda n: {"otype": "VanillaMLP", "activation": "ReLU", "output_activation": "none", "n_neurons": hidden,   # noqa: E731
-                     "n_hidden_layers": n}
+                     "n_hidden_layers": n, "precision": tex_precision}
     cfg = {
         "name": "split-mixed-occ", "indirect_pred": True, "relighting_threshold": 0.3, "radius": 1.5,
         "num_samples_per_ray": 1024, "num_samples_per_secondary_ray": 96, "train_num_rays": 256,
@@ -133,7 +134,7 @@ def tensoir_model_config(n_levels=16, log2_T=19, hidden=128, **overrides):
                                     "per_level_scale": 1.447269237440378, "include_xyz": True},
             "mlp_network_config": {"otype": "VanillaMLP", "activation": "ReLU", "output_activation": "none",
                                    "n_neurons": hidden, "n_hidden_layers": 2, "sphere_init": True,
-                                   "sphere_init_radius": 0.5, "weight_norm": True}},
+                                   "sphere_init_radius": 0.5, "weight_norm": True, "precision": sdf_precision}},
         "texture": {"name": "volume-mixed-mip-split-occ", "input_feature_dim": 48, "other_dim": 3, "sample_size": 8,
                     "dir_encoding_config": {"otype": "SphericalHarmonics", "degree": 5, "reflected": True},
                     "metallic_mlp_network_config": mlp(2), "albedo_mlp_network_config": mlp(4),

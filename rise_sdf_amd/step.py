@@ -109,7 +109,8 @@ class TrainStep:
 
 
 def build_synthetic_training(dev, *, stage=1, hidden=128, views=8, res=200, seed=0, rank=0, world=1, indirect=True,
-                             curvature=True, grad_buckets=True, model_overrides=None):
+                             curvature=True, grad_buckets=True, model_overrides=None, tex_precision="fp32",
+                             sdf_precision="fp32"):
     """The full split-mixed-occ model at the yaml's sizes (rise_sdf_amd.config.tensoir_model_config) with the yaml's
     optimizer and loss weights, on the synthetic analytic scene (rise_sdf_amd.synthetic): what bench.py's config[3]
     workload, tools/bench_step.py and the multi-rank tests drive.  -> (model, TrainStep)."""
@@ -119,6 +120,7 @@ def build_synthetic_training(dev, *, stage=1, hidden=128, views=8, res=200, seed
     from .synthetic import make_dataset
     torch.manual_seed(seed)                                   # identical initial replicas on every rank
     cfg = tensoir_model_config(hidden=hidden, indirect_pred=indirect, curvature=curvature,
+                               tex_precision=tex_precision, sdf_precision=sdf_precision,
                                split_sum_kick_in_step=0 if stage else 1 << 60, **(model_overrides or {}))
     model = make("split-mixed-occ", cfg).to(dev)
     model.train()

@@ -69,11 +69,11 @@ def test_masked_secondary_blend_matches_the_gather_path(dev, stage1):
         model = _model(dev, stage1=stage1)
         model.masked_secondary = masked
         model.occupancy_grid.capacity_mode = masked
-        if stage1:
-            model.emitter.build_mips()
         for _ in range(2 if masked else 1):                  # second pass: the capped sampler is in use
             for p in model.parameters():
                 p.grad = None
+            if stage1:
+                model.emitter.build_mips()
             out = model.forward_(rays, stratified_u=u)
             (out[key] * g).sum().backward()
         if masked:

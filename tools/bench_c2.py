@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def measure_c2(dev, width=800, height=800, chunk=16384, stage=1, tex_hidden=128, steps=1, hidden=64):
+def measure_c2(dev, width=800, height=800, chunk=16384, stage=1, tex_hidden=128, steps=1, hidden=64, tex_precision="fp32"):
     """-> dict(samples_per_s, ms_per_step, samples_per_step, kernel_ms_total, top, summary): one view of config[2]
     (c1 + radiance branch + split-sum shading against a 512^2 environment), fwd+bwd, one build_mips per step."""
     import types
@@ -25,7 +25,7 @@ def measure_c2(dev, width=800, height=800, chunk=16384, stage=1, tex_hidden=128,
     import bench
     cfg = bench.c1_config(hidden=hidden)
     mlp = lambda n: {"otype": "VanillaMLP", "activation": "ReLU", "output_activation": "none",
-                     "n_neurons": args.tex_hidden, "n_hidden_layers": n}
+                     "n_neurons": args.tex_hidden, "n_hidden_layers": n, "precision": tex_precision}
     feat = cfg["geometry"]["feature_dim"]
     cfg.update({
         "name": "split-mixed-occ", "indirect_pred": False, "curvature": False,
@@ -89,7 +89,7 @@ def measure_c2(dev, width=800, height=800, chunk=16384, stage=1, tex_hidden=128,
     summ = timer.summary()
     top = {k: round(v["ms"] / args.steps, 1) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:14]}
     return {"workload": f"c2 stage {model.stage}: split-mixed-occ, {args.width}x{args.height}, texture width "
-                        f"{args.tex_hidden}, env 512^2", "samples_per_s": samples / dt,
+                        f"{args.tex_hidden} ({tex_precision}), env 512^2", "samples_per_s": samples / dt,
             "ms_per_step": dt / args.steps * 1e3, "samples_per_step": samples / args.steps,
             "kernel_ms_total": round(sum(v["ms"] for v in summ.values()) / args.steps, 1), "top": top, "summary": summ}
 

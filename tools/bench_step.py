@@ -44,9 +44,9 @@ def count_syncs(fn):
     return n, sites
 
 
-def measure(dev, stage=1, steps=30, settle=80, first_step=20000, syncs=False, hidden=128, quiet=True):
+def measure(dev, stage=1, steps=30, settle=80, first_step=20000, syncs=False, hidden=128, quiet=True, **build_kw):
     from rise_sdf_amd import _lib
-    model, ts = build(dev, stage=stage, hidden=hidden)
+    model, ts = build(dev, stage=stage, hidden=hidden, **build_kw)
     gs = first_step                      # past the progressive-level ramp: all 16 levels, eps = one finest cell
     traj = []
     for k in range(settle):              # occupancy grid + dynamic ray count settle at the operating point
@@ -84,9 +84,12 @@ def main():
     ap.add_argument("--settle", type=int, default=80)
     ap.add_argument("--hidden", type=int, default=128)
     ap.add_argument("--syncs", action="store_true")
+    ap.add_argument("--tex-precision", default="fp32")
+    ap.add_argument("--sdf-precision", default="fp32")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
-    print(json.dumps(measure(dev, args.stage, args.steps, args.settle, syncs=args.syncs, hidden=args.hidden)))
+    print(json.dumps(measure(dev, args.stage, args.steps, args.settle, syncs=args.syncs, hidden=args.hidden,
+                             tex_precision=args.tex_precision, sdf_precision=args.sdf_precision)))
 
 
 if __name__ == "__main__":

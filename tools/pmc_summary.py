@@ -13,10 +13,12 @@ import json
 import os
 import sys
 
-ENTRY = {  # kernel name fragment -> C-ABI entry point
+ENTRY = {  # kernel name fragment -> C-ABI entry point (first match wins; <true> = taps derived in-kernel, the _pts entry points)
+    "fd7_fwd_kernel<true>": "rsdf_hashgrid_fwd_fd7_pts",
+    "fd7_produce_kernel<true>": "rsdf_hashgrid_bwd_fd7_pts",
+    "fd7_reduce_kernel": "rsdf_hashgrid_bwd_fd7_pts",       # (bench.py only runs the _pts form)
     "fd7_fwd_kernel": "rsdf_hashgrid_fwd_fd7",
     "fd7_produce_kernel": "rsdf_hashgrid_bwd_fd7",
-    "fd7_reduce_kernel": "rsdf_hashgrid_bwd_fd7",
     "coop_bwd_kernel": "rsdf_sdfmlp_fd7_bwd",
     "quad_bwd_kernel": "rsdf_sdfmlp_fd7_bwd",
     "sdfmlp_bwd_kernel": "rsdf_sdfmlp_fd7_bwd",
@@ -35,6 +37,7 @@ def read(path, counter):
         for frag, entry in ENTRY.items():
             if frag in row["kernel"]:
                 out[entry] = out.get(entry, 0.0) + float(row[counter])
+                break
     return out
 
 
