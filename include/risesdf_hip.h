@@ -173,6 +173,16 @@ int rsdf_hashgrid_bwd_fd7_pts(const float *points, float radius, float eps, cons
                               const rsdf_grid_meta *meta /*host*/, int64_t n_samples, int n_active_levels,
                               float eps_unit, float *dtable, void *scratch, int64_t scratch_bytes, void *stream);
 
+/* The table scatter of rsdf_hashgrid_bwd (mode 0) or of rsdf_hashgrid_dx_bwd (mode 1; g_dx [n,3] as there; call that
+ * entry with dtable = NULL for its other outputs) for n_features = 2, through the bin-and-reduce queues of the stencil
+ * backward instead of per-corner float atomics: same sums (fp64 accumulation per bin, then one add per entry).  Worth it
+ * from a few 1e4 points (the training step's curvature term sends 2.6e5 per step).  dtable is accumulated into;
+ * scratch >= rsdf_hashgrid_scatter_binned_scratch_bytes(meta, n, n_active_levels). */
+int64_t rsdf_hashgrid_scatter_binned_scratch_bytes(const rsdf_grid_meta *meta /*host*/, int64_t n, int n_active_levels);
+int rsdf_hashgrid_scatter_binned(int mode, const float *x, const float *dy, int ld_dy, int col_off, const float *g_dx,
+                                 const rsdf_grid_meta *meta /*host*/, int64_t n, int n_active_levels, float *dtable,
+                                 void *scratch, int64_t scratch_bytes, void *stream);
+
 /* H1 input gradient (what tcnn's autograd supplies to analytic normals, models/geometry.py:224-228, and to the
  * curvature term, geometry.py:262-270) and its backward (tcnn double backward).  x in [0,1]; dx in the same
  * unit-cube coordinates; levels >= n_active_levels contribute nothing.

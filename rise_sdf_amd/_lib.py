@@ -63,6 +63,8 @@ _SIGNATURES = {
     "rsdf_hashgrid_bwd_fd7_scratch_bytes": [ctypes.POINTER(GridMeta), _L, _I, _F],
     "rsdf_hashgrid_fwd_fd7": [_P, _P, ctypes.POINTER(GridMeta), _L, _I, _P, _P],
     "rsdf_hashgrid_bwd_fd7": [_P, _P, ctypes.POINTER(GridMeta), _L, _I, _F, _P, _P, _L, _P],
+    "rsdf_hashgrid_scatter_binned_scratch_bytes": [ctypes.POINTER(GridMeta), _L, _I],
+    "rsdf_hashgrid_scatter_binned": [_I, _P, _P, _I, _I, _P, ctypes.POINTER(GridMeta), _L, _I, _P, _P, _L, _P],
     "rsdf_hashgrid_fwd_fd7_pts": [_P, _F, _F, _P, ctypes.POINTER(GridMeta), _L, _I, _P, _P],
     "rsdf_hashgrid_bwd_fd7_pts": [_P, _F, _F, _P, ctypes.POINTER(GridMeta), _L, _I, _F, _P, _P, _L, _P],
     "rsdf_loss_rays_fwd": [_P, _P, _P, _P, _P, _P, _L, _P, _P],
@@ -143,6 +145,7 @@ def mlp_fn(name, precision="fp32"):
 _RESTYPES = {"rsdf_last_error": ctypes.c_char_p, "rsdf_scan_scratch_bytes": ctypes.c_int64,
              "rsdf_grid_meta_init": ctypes.c_int64,
              "rsdf_hashgrid_bwd_fd7_scratch_bytes": ctypes.c_int64,
+             "rsdf_hashgrid_scatter_binned_scratch_bytes": ctypes.c_int64,
              "rsdf_occ_update_scratch_bytes": ctypes.c_int64}
 
 EXPORTS = tuple(_SIGNATURES)

@@ -646,6 +646,108 @@ fd7_produce_kernel(const TapSrc src, const float2 *__restrict__ dplanes,
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same queue machinery for PLAIN points (one evaluation per point, row-major gradients): the table scatter of the
+// generic encoder's backward (MODE 0: value = w_c * dy) and of the input-gradient's backward (MODE 1: value = scale * m_c *
+// dy with m_c = sum_d g_d dw_c/dx_d, hashgrid_dx.hip).  The curvature term of the training step (models/geometry.py:246-282)
+// sends 2.6e5 points per step through both; as per-corner float atomics they were 3.3 + 2.2 ms of a 32 ms step (the memory
+// side executes ~2e10 scattered atomics per second), as records through the bins they cost what 8 records per (point,
+// level) cost.  x [n,3] unit cube; dy rows [n, ld_dy], level l at columns col_off + 2 l, + 1.
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ void __launch_bounds__(P_THREADS, RSDF_STAGE_RECS <= 4 ? 8 : 4)
+scatter_produce_kernel(const float *__restrict__ x, const float *__restrict__ dy, int ld_dy, int col_off,
+                       const float *__restrict__ gdx, const rsdf_grid_meta meta, const LevelPlan plan, int64_t S,
+                       int n_active, Record *__restrict__ queues, int *__restrict__ counters, float *__restrict__ dtable)
+{
+    __shared__ int s_cnt[MAX_BINS];
+    __shared__ int s_off[MAX_BINS + 1];
+    __shared__ int s_gbase[MAX_BINS];
+    extern __shared__ __attribute__((aligned(16))) Record s_stage[];  // [STAGE_CAP]
+    if (threadIdx.x < MAX_BINS) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t per_group = (int64_t)RSDF_BWD_GROUP * n_active;
+    const int64_t grp = blockIdx.x / per_group, rem = blockIdx.x - grp * per_group;
+    const int l = (int)(rem / RSDF_BWD_GROUP);
+    const int64_t tile_id = grp * RSDF_BWD_GROUP + (rem - (int64_t)l * RSDF_BWD_GROUP);
+    const LevelGeom g = level_geom(meta, l);
+    float *dlevel = dtable + (size_t)meta.offset[l] * 2;
+    Record *queue = queues + plan.queue_off[l];
+    int *qcount = counters + plan.counter_off[l];
+    const int n_bins = plan.n_bins[l], interleaved = plan.interleaved[l];
+    const int64_t cap = plan.cap[l];
+    const int64_t s_block = tile_id * P_THREADS;
+    if (s_block >= S) return;   // padding tile of the last group (uniform)
+    const int64_t s = s_block + threadIdx.x;
+    const bool active = s < S;
+    StamperP stp;
+    stp.begin(false);
+
+    float2 acc[8];
+    CellFrac c0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = make_float2(0.f, 0.f);
+    c0.c[0] = c0.c[1] = c0.c[2] = 0;
+    if (active) {
+        c0 = cell_frac(x[3 * s], x[3 * s + 1], x[3 * s + 2], g.scale);
+        const float *d = dy + s * ld_dy + col_off + 2 * l;
+        const float d0 = d[0], d1 = d[1];
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+        if (MODE == 1) { g0 = gdx[3 * s]; g1 = gdx[3 * s + 1]; g2 = gdx[3 * s + 2]; }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float w;
+            if (MODE == 0) {
+                w = corner_weight(c0, c);
+                acc[c] = make_float2(w * d0, w * d1);
+            } else {
+                // hashgrid_dx.hip: m_c = sum_d g_d sgn_d(c) prod_{k != d} omega_k(c_k); contribution scale * dy * m_c,
+                // formed in the atomic kernel's order (scale * dy) * m
+                const float o0 = (c & 1) ? c0.w[0] : 1.0f - c0.w[0], o1 = (c & 2) ? c0.w[1] : 1.0f - c0.w[1],
+                            o2 = (c & 4) ? c0.w[2] : 1.0f - c0.w[2];
+                const float s0 = (c & 1) ? 1.0f : -1.0f, s1 = (c & 2) ? 1.0f : -1.0f, s2 = (c & 4) ? 1.0f : -1.0f;
+                w = g0 * s0 * o1 * o2 + g1 * s1 * o0 * o2 + g2 * s2 * o0 * o1;
+                acc[c] = make_float2(g.scale * d0 * w, g.scale * d1 * w);
+            }
+        }
+    }
+    // cross-sample merge of runs of equal cells (consecutive samples of a ray at coarse levels), as fd7_produce_kernel
+    bool emit0 = active;
+    {
+        const int lane = lane_id();
+        const uint32_t kx = active ? c0.c[0] : 0xffffffffu, ky = active ? c0.c[1] : (uint32_t)lane, kz = c0.c[2];
+        const uint32_t px = __shfl_up(kx, 1, 64), py = __shfl_up(ky, 1, 64), pz = __shfl_up(kz, 1, 64);
+        int head = (lane == 0 || px != kx || py != ky || pz != kz) ? 1 : 0;
+        const int n_runs = __popcll(__ballot(head));
+        if (n_runs <= MERGE_MAX_RUNS) {  // wave-uniform
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                float2 u[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    u[c].x = __shfl_up(acc[c].x, o, 64);
+                    u[c].y = __shfl_up(acc[c].y, o, 64);
+                }
+                const int hu = __shfl_up(head, o, 64);
+                if (lane >= o && !head) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        acc[c].x += u[c].x;
+                        acc[c].y += u[c].y;
+                    }
+                    head = hu;
+                }
+            }
+            const uint32_t nx = __shfl_down(kx, 1, 64), ny = __shfl_down(ky, 1, 64), nz = __shfl_down(kz, 1, 64);
+            emit0 = active && (lane == 63 || nx != kx || ny != ky || nz != kz);
+        }
+    }
+    uint32_t ridx[ROUND_RECS];
+    corner_indices(c0.c[0], c0.c[1], c0.c[2], g, ridx);
+    emit_round(ridx, acc, emit0 ? 0xffu : 0u, n_bins, interleaved, cap, queue, qcount, dlevel, s_cnt, s_off, s_gbase,
+               s_stage, stp);
+}
+
+// ------------------------------------------------------------------------------------------------
 // backward: reduce
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(R_THREADS)
@@ -876,9 +978,63 @@ int launch_bwd(const TapSrc &src, const float *dplanes, const rsdf_grid_meta *me
     RSDF_RETURN_LAUNCH();
 }
 
+template <int MODE>
+void launch_scatter_produce(dim3 grid, size_t stage_bytes, hipStream_t st, const float *x, const float *dy, int ld_dy,
+                            int col_off, const float *gdx, const rsdf_grid_meta &meta, const LevelPlan &plan, int64_t n,
+                            int na, Record *queues, int *counters, float *dtable)
+{
+    (void)rsdf_func_lds(reinterpret_cast<const void *>(scatter_produce_kernel<MODE>), stage_bytes);
+    scatter_produce_kernel<MODE><<<grid, P_THREADS, stage_bytes, st>>>(x, dy, ld_dy, col_off, gdx, meta, plan, n, na,
+                                                                      queues, counters, dtable);
+}
+
 }  // namespace
 
 extern "C" {
+
+int64_t rsdf_hashgrid_scatter_binned_scratch_bytes(const rsdf_grid_meta *meta, int64_t n, int n_active_levels)
+{
+    return rsdf_hashgrid_bwd_fd7_scratch_bytes(meta, n, n_active_levels, 0.0f);
+}
+
+int rsdf_hashgrid_scatter_binned(int mode, const float *x, const float *dy, int ld_dy, int col_off, const float *g_dx,
+                                 const rsdf_grid_meta *meta, int64_t n, int n_active_levels, float *dtable, void *scratch,
+                                 int64_t scratch_bytes, void *stream)
+{
+    RSDF_CHECK_ARG(meta != nullptr && meta->n_features == 2, "hashgrid_scatter_binned: n_features must be 2");
+    RSDF_CHECK_ARG(mode == 0 || (mode == 1 && g_dx != nullptr), "hashgrid_scatter_binned: mode 0, or 1 with g_dx");
+    if (n <= 0) return 0;
+    int na = n_active_levels;
+    if (na < 0 || na > (int)meta->n_levels) na = (int)meta->n_levels;
+    if (na == 0) return 0;
+    LevelPlan plan;
+    int n_cnt;
+    int64_t n_rec;
+    RSDF_CHECK_ARG(make_plan(meta, n, na, 0.0f, &plan, &n_rec, &n_cnt) == 0, "hashgrid_scatter_binned: unsupported level layout");
+    RSDF_CHECK_ARG(scratch != nullptr && scratch_bytes >= scratch_need(n_rec, n_cnt), "hashgrid_scatter_binned: scratch too small");
+    hipStream_t st = (hipStream_t)stream;
+    int *counters = (int *)scratch;
+    const size_t cbytes = (((size_t)n_cnt * sizeof(int)) + 255) / 256 * 256;
+    Record *queues = (Record *)((char *)scratch + cbytes);
+    (void)hipMemsetAsync(counters, 0, cbytes, st);
+    const unsigned p_tiles = (rsdf_blocks(n, P_THREADS) + RSDF_BWD_GROUP - 1) / RSDF_BWD_GROUP * RSDF_BWD_GROUP;
+    RSDF_CHECK_ARG((uint64_t)p_tiles * na * P_THREADS < (1ull << 32), "hashgrid_scatter_binned: too many points for one launch");
+    const dim3 pgrid(p_tiles * na, 1);
+    const size_t stage_bytes = (size_t)STAGE_CAP * sizeof(Record);
+    if (mode == 0)
+        launch_scatter_produce<0>(pgrid, stage_bytes, st, x, dy, ld_dy, col_off, g_dx, *meta, plan, n, na, queues, counters, dtable);
+    else
+        launch_scatter_produce<1>(pgrid, stage_bytes, st, x, dy, ld_dy, col_off, g_dx, *meta, plan, n, na, queues, counters, dtable);
+    int max_wgs = 0;
+    for (int l = 0; l < na; ++l) {
+        const int w = plan.n_bins[l] * plan.n_split[l];
+        max_wgs = w > max_wgs ? w : max_wgs;
+    }
+    const size_t lds = (size_t)BIN_ENTRIES * 2 * sizeof(double);
+    if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(fd7_reduce_kernel), lds)) return rc;
+    fd7_reduce_kernel<<<dim3(max_wgs, na), R_THREADS, lds, st>>>(*meta, plan, queues, counters, dtable);
+    RSDF_RETURN_LAUNCH();
+}
 
 int rsdf_hashgrid_fwd_fd7(const float *x7t, const float *table, const rsdf_grid_meta *meta,
                           int64_t n_samples, int n_active_levels, float *planes, void *stream)

@@ -367,6 +367,9 @@ class _HashGrid(torch.autograd.Function):
             check(lib().rsdf_hashgrid_bwd_fd7(ptr(x7t), ptr(dpl), ctypes.byref(ctx.meta), S, ctx.n_active,
                                               float(ctx.fd7), ptr(dt), ptr(scratch), nbytes,
                                               stream_ptr()), "hashgrid_bwd_fd7")
+        elif _use_binned(ctx.meta, n):
+            # many plain points (the curvature term's 2.6e5 per training step): bins instead of per-corner atomics
+            _scatter_binned(0, xf, g, g.shape[1], ctx.col, None, ctx.meta, ctx.n_active, dt)
         else:
             check(lib().rsdf_hashgrid_bwd(ptr(xf), ptr(g), ctypes.byref(ctx.meta), n, ctx.n_active,
                                           g.shape[1], ctx.col, ptr(dt), stream_ptr()), "hashgrid_bwd")
@@ -377,6 +380,25 @@ class _HashGrid(torch.autograd.Function):
             if ctx.col:
                 dx = dx + gout[:, :3] * ctx.xyz_scale
         return dx, dt, None, None, None, None, None, None
+
+
+BINNED_SCATTER_MIN_POINTS = 16384
+
+
+def _scatter_binned(mode, xf, g, ld, col, gd, meta, n_active, dt):
+    """dt += the table scatter of the generic backward (mode 0) / the input-gradient's backward (mode 1) through the
+    bin-and-reduce queues (rsdf_hashgrid_scatter_binned) instead of per-corner float atomics."""
+    n = xf.shape[0]
+    nbytes = int(lib().rsdf_hashgrid_scatter_binned_scratch_bytes(ctypes.byref(meta), n, n_active))
+    if nbytes < 0:
+        raise L.RiseSdfHipError("hashgrid_scatter_binned: unsupported level layout")
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=xf.device)
+    check(lib().rsdf_hashgrid_scatter_binned(mode, ptr(xf), ptr(g), ld, col, ptr(gd), ctypes.byref(meta), n, n_active,
+                                             ptr(dt), ptr(scratch), nbytes, stream_ptr()), "hashgrid_scatter_binned")
+
+
+def _use_binned(meta, n):
+    return meta.n_features == 2 and n >= BINNED_SCATTER_MIN_POINTS and os.environ.get("RSDF_SCATTER") != "atomics"
 
 
 class _HashGridDx(torch.autograd.Function):
@@ -404,9 +426,13 @@ class _HashGridDx(torch.autograd.Function):
         gx = torch.empty(n, 3, dtype=torch.float32, device=xf.device) if need_x else None
         dt = torch.zeros_like(tb) if need_t else None
         ddy = torch.zeros_like(g) if need_dy else None
-        check(lib().rsdf_hashgrid_dx_bwd(ptr(xf), ptr(tb), ctypes.byref(ctx.meta), n, ctx.n_active, ptr(g),
-                                         g.shape[1], ctx.col, ptr(gd), ptr(ddy), g.shape[1], ctx.col, ptr(dt),
-                                         ptr(gx), stream_ptr()), "hashgrid_dx_bwd")
+        binned = need_t and _use_binned(ctx.meta, n)      # the table scatter through the bins, the rest as before
+        if need_x or need_dy or (need_t and not binned):
+            check(lib().rsdf_hashgrid_dx_bwd(ptr(xf), ptr(tb), ctypes.byref(ctx.meta), n, ctx.n_active, ptr(g),
+                                             g.shape[1], ctx.col, ptr(gd), ptr(ddy), g.shape[1], ctx.col,
+                                             None if binned else ptr(dt), ptr(gx), stream_ptr()), "hashgrid_dx_bwd")
+        if binned:
+            _scatter_binned(1, xf, g, g.shape[1], ctx.col, gd, ctx.meta, ctx.n_active, dt)
         return gx, dt, ddy, None, None, None
 
 
