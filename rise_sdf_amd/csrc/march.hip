@@ -323,18 +323,18 @@ int rsdf_compact_samples(const uint8_t *keep, const int64_t *ray_indices, const 
 
 // ---- marcher entry points (roi read from device memory) ---------------------------------------
 namespace {
-// One thread per ray, as the reference (ray_marching.cu:81-192), and the reference's arithmetic statement by statement:
-// the sample set is an integer function of a serial fp32 accumulation (t1 = t0 + dt, the do { _t += dt } while skip), so
-// the recurrence cannot be re-associated.  What CAN change is how long a thread waits: the loop's only memory access is
-// the occupancy byte of the current step, a dependent load (~1 us) per step, and a 32768-ray chunk is 512 wavefronts on
-// 1024 SIMDs -- the kernel was pure load latency (0.45 ms per pass whatever the ray count: 143 ms of a step at 4096-ray
-// chunks).  Each trip now SPECULATES that the next SPEC steps are occupied: it runs the recurrence SPEC steps ahead,
-// issues their SPEC occupancy loads back to back, then replays the reference's decisions in order on the loaded bytes
-// and discards everything after the first empty cell (the skip restarts from that step's exact (t0, t1, t_mid)).  Same
-// emitted (t0, t1) bit for bit; 1/SPEC of the waits inside occupied runs.  Inside empty space a trip uses one cell only,
-// so after a trip that broke at its first step the next one looks at a single cell.
-constexpr int SPEC = 8;
-constexpr int MARCH_THREADS = 64;
+// The reference marches one ray per thread (ray_marching.cu:81-192); its sample set is an integer function of a SERIAL fp32
+// recurrence (t1 = t0 + dt; the do { _t += dt } while skip), so the arithmetic cannot be re-associated -- but the mapping
+// can change.  Here ONE WAVEFRONT marches a ray.  Per trip, lane k runs the "occupied" recurrence k steps ahead of the
+// ray's current state (k dependent adds: the only serial part, two vector instructions per step for the whole wave), all
+// lanes look their cell up at once (one load latency per up-to-64 steps instead of one per step), a ballot finds the
+// first lane whose step the reference would NOT have taken as occupied (outside [near, far) or an empty cell), the
+// lanes before it emit their samples with one coalesced store each, and the ray continues from exactly that lane's
+// state -- into the reference's skip if the cell was empty.  Same (t0, t1) bit for bit, same order.  Inside empty space a
+// trip speculates a single step; after a fully occupied trip the depth grows 8x up to 64.
+// Round 2's thread-per-ray kernel was pure dependent-load latency: 0.45 ms per pass whatever the ray count (143 ms of a
+// step at the reference's 4096-ray chunks); round 3's first cut (8 speculative steps per thread) 0.24.
+constexpr int MARCH_THREADS = 256;     // four rays per workgroup
 
 template <bool WRITE>
 __global__ void __launch_bounds__(MARCH_THREADS)
@@ -346,8 +346,9 @@ march_entry(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
             float *__restrict__ t_ends)
 {
     const Grid g = load_grid(gd);
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_rays) return;
+    const int64_t i = ((int64_t)blockIdx.x * MARCH_THREADS + threadIdx.x) >> 6;     // ray = wavefront
+    if (i >= n_rays) return;                                                        // (wave-uniform)
+    const int lane = lane_id();
     const float ox = rays_o[3 * i], oy = rays_o[3 * i + 1], oz = rays_o[3 * i + 2];
     const float dx = rays_d[3 * i], dy = rays_d[3 * i + 1], dz = rays_d[3 * i + 2];
     const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
@@ -367,51 +368,41 @@ march_entry(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
     float dt = calc_dt(t0, cone_angle, dt_min, dt_max);
     float t1 = t0 + dt;
     float t_mid = (t0 + t1) * 0.5f;
-    int n_spec = SPEC;
+    int n_spec = 64;
     while (t_mid < far_) {
-        // the recurrence of the "occupied" branch, SPEC steps ahead: state m = (a0, a1, am)[m] after m occupied steps
-        float a0[SPEC + 1], a1[SPEC + 1], am[SPEC + 1];
-        a0[0] = t0, a1[0] = t1, am[0] = t_mid;
-#pragma unroll
-        for (int m = 1; m <= SPEC; ++m) {
-            a0[m] = a1[m - 1];
-            a1[m] = a0[m] + calc_dt(a0[m], cone_angle, dt_min, dt_max);
-            am[m] = (a0[m] + a1[m]) * 0.5f;
-        }
-        int occ[SPEC];
-#pragma unroll
-        for (int m = 0; m < SPEC; ++m) {
-            occ[m] = 0;
-            if (m < n_spec && am[m] < far_) {
-                const int c = cell_index(ox + am[m] * dx, oy + am[m] * dy, oz + am[m] * dz, g);
-                if (c >= 0) occ[m] = g.binary[c];
+        // lane k: the state after k occupied steps (the reference's "occupied" branch: t0 = t1; t1 = t0 + dt(t0))
+        float l0 = t0, l1 = t1;
+        for (int k = 0; k + 1 < n_spec; ++k) {
+            if (lane > k) {
+                l0 = l1;
+                l1 = l0 + calc_dt(l0, cone_angle, dt_min, dt_max);
             }
         }
-        // replay in order
-        int m = 0;
-#pragma unroll
-        for (int q = 0; q < SPEC; ++q) {
-            if (m == q && q < n_spec && am[q] < far_ && occ[q] != 0) {
-                if (WRITE && j < limit) {
-                    t_starts[base + j] = a0[q];
-                    t_ends[base + j] = a1[q];
-                    ray_indices[base + j] = i;
-                }
-                ++j;
-                m = q + 1;
-            }
+        // lane 0 tests the ray's own t_mid (after a skip that is the accumulated _t, NOT (t0 + t1) / 2 re-rounded);
+        // the others the midpoint the occupied branch would have formed
+        const float lm = lane == 0 ? t_mid : (l0 + l1) * 0.5f;
+        bool take = false;
+        if (lane < n_spec && lm < far_) take = occupied_at(ox + lm * dx, oy + lm * dy, oz + lm * dz, g);
+        const unsigned long long mask = __ballot(take);
+        const int m = mask == ~0ull ? 64 : __ffsll((long long)~mask) - 1;     // leading accepted steps (<= n_spec)
+        if (WRITE && lane < m && j + lane < limit) {
+            t_starts[base + j + lane] = l0;
+            t_ends[base + j + lane] = l1;
+            ray_indices[base + j + lane] = i;
         }
-        // state after the m accepted steps (m is 0..SPEC: select, no indexed registers)
-        t0 = a0[0], t1 = a1[0], t_mid = am[0];
-#pragma unroll
-        for (int q = 1; q <= SPEC; ++q)
-            if (m == q) t0 = a0[q], t1 = a1[q], t_mid = am[q];
-        if (m == n_spec) {       // every speculated step was occupied: keep going at full depth
-            n_spec = SPEC;
+        j += m;
+        if (m > 0) {   // the ray's state after m occupied steps = the successor of lane m - 1's state
+            const float n0 = l1, n1 = n0 + calc_dt(n0, cone_angle, dt_min, dt_max), nm = (n0 + n1) * 0.5f;
+            t0 = __shfl(n0, m - 1, 64);
+            t1 = __shfl(n1, m - 1, 64);
+            t_mid = __shfl(nm, m - 1, 64);
+        }
+        if (m == n_spec) {                        // every speculated step was taken: go deeper
+            n_spec = n_spec >= 8 ? 64 : n_spec * 8;
             continue;
         }
         if (!(t_mid < far_)) break;
-        // step m is inside the range and its cell is empty (or outside the box): the reference's skip
+        // the next step's cell is empty (or outside the box): the reference's skip, computed by every lane alike
         const float x = ox + t_mid * dx, y = oy + t_mid * dy, z = oz + t_mid * dz;
         const float tx = axis_dist(x, dx, ix, g.roi[0], g.roi[3], g.res[0]);
         const float ty = axis_dist(y, dy, iy, g.roi[1], g.roi[4], g.res[1]);
@@ -424,9 +415,9 @@ march_entry(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
         dt = calc_dt(t_mid, cone_angle, dt_min, dt_max);
         t0 = t_mid - dt * 0.5f;
         t1 = t_mid + dt * 0.5f;
-        n_spec = (m == 0) ? 1 : SPEC;    // still in empty space: look at one cell next time
+        n_spec = (m == 0) ? 1 : 64;               // still in empty space: look at one cell next time
     }
-    if (!WRITE) num_steps[i] = j;
+    if (!WRITE && lane == 0) num_steps[i] = j;
 }
 
 __global__ void query_occ_entry(const float *__restrict__ xyz, GridDev gd, int64_t n,
@@ -452,7 +443,7 @@ int rsdf_march_count(const float *rays_o, const float *rays_d, const float *t_mi
     RSDF_CHECK_ARG(step_size > 0.f, "march_count: step_size must be > 0");
     if (n_rays <= 0) return 0;
     GridDev gd{roi, {res_x, res_y, res_z}, binary};
-    march_entry<false><<<rsdf_blocks(n_rays, MARCH_THREADS), MARCH_THREADS, 0, (hipStream_t)stream>>>(
+    march_entry<false><<<rsdf_blocks(n_rays * 64, MARCH_THREADS), MARCH_THREADS, 0, (hipStream_t)stream>>>(
         rays_o, rays_d, t_min, t_max, gd, step_size, cone_angle, n_rays, nullptr, num_steps, nullptr,
         nullptr, nullptr);
     RSDF_RETURN_LAUNCH();
@@ -468,7 +459,7 @@ int rsdf_march_write(const float *rays_o, const float *rays_d, const float *t_mi
     RSDF_CHECK_ARG(step_size > 0.f, "march_write: step_size must be > 0");
     if (n_rays <= 0) return 0;
     GridDev gd{roi, {res_x, res_y, res_z}, binary};
-    march_entry<true><<<rsdf_blocks(n_rays, MARCH_THREADS), MARCH_THREADS, 0, (hipStream_t)stream>>>(
+    march_entry<true><<<rsdf_blocks(n_rays * 64, MARCH_THREADS), MARCH_THREADS, 0, (hipStream_t)stream>>>(
         rays_o, rays_d, t_min, t_max, gd, step_size, cone_angle, n_rays, packed_info, nullptr,
         ray_indices, t_starts, t_ends);
     RSDF_RETURN_LAUNCH();

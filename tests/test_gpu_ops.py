@@ -558,3 +558,25 @@ def test_curvature_path_uses_binned_scatter_and_matches(dev, ops, monkeypatch):
         res.append(tb.grad.clone())
     scale = float(res[1].abs().max())
     assert float((res[0] - res[1]).abs().max()) < 2e-5 * scale
+
+
+@pytest.mark.parametrize("res,fill,step,cone", [(32, 0.3, 0.00507421875, 0.0), (64, 0.08, 0.0152631578947, 0.0),
+                                                (16, 0.5, 0.02, 0.004), (128, 0.02, 0.00507421875, 0.0)])
+def test_marcher_bit_exact_fragmented_grid(dev, ops, res, fill, step, cone):
+    """The wave-per-ray marcher on grids where occupied and empty cells alternate at random (every few steps a skip, runs
+    of every length, speculation depth changing all the time), with near / far clamps and a cone angle: packed_info,
+    ray_indices and every (t0, t1) equal the oracle's thread-per-ray loop bit for bit."""
+    rays = camera_rays(40, 40, seed=res + 1)
+    o, d = rays[:, :3].contiguous(), rays[:, 3:].contiguous()
+    roi = torch.tensor([-1.5, -1.5, -1.5, 1.5, 1.5, 1.5])
+    g = torch.Generator().manual_seed(res)
+    binary = torch.rand(res, res, res, generator=g) < fill
+    tn, tf = oracle.ray_aabb_intersect(o, d, roi)
+    tn = torch.clamp(tn + torch.rand(o.shape[0], generator=g) * step, min=2.7)       # a near plane inside the box
+    tf = torch.clamp(tf, max=5.2)
+    pk, ri, ts, te = oracle.ray_marching_packed(o, d, tn, tf, roi, binary, step, cone)
+    gpk, gri, gts, gte = ops.march(o.to(dev), d.to(dev), tn.to(dev), tf.to(dev), roi.to(dev), binary.to(dev), step, cone)
+    assert ri.numel() > 2000
+    assert torch.equal(gpk.cpu(), pk), "packed_info differs"
+    assert torch.equal(gri.cpu(), ri), "ray_indices differ"
+    assert torch.equal(gts.cpu(), ts) and torch.equal(gte.cpu(), te), "sample intervals differ"
