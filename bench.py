@@ -76,16 +76,50 @@ def build_model(dev, args):
     return model
 
 
-def run_step(model, rays, jitter, cot, chunk):
-    """One pass over all rays: fwd+bwd per chunk.  Returns the number of samples."""
+_STREAMS = {}
+
+
+def side_streams(dev, n):
+    """n HIP streams per device, created once (the chunks of a step alternate over them)."""
+    key = (str(dev), n)
+    if key not in _STREAMS:
+        _STREAMS[key] = [torch.cuda.Stream(device=dev) for _ in range(n)]
+    return _STREAMS[key]
+
+
+def run_step(model, rays, jitter, cot, chunk, streams=1):
+    """One pass over all rays: fwd+bwd per chunk, gradients accumulated.  Returns the number of samples.
+
+    ``streams`` > 1: consecutive chunks are issued on alternating HIP streams, so that the kernels of two chunks are in
+    flight together.  The four large kernels of a chunk are bound by different units (stencil gather: L2 line requests;
+    fused MLP forward: vector issue, capped at 192 registers so that a gather wave fits beside two of its waves; MLP
+    backward: vector issue + matrix pipe with the whole register file; hash backward: queue traffic and latency), and a
+    kernel's tail leaves CUs idle that the other chunk's kernels fill.  Each chunk's whole forward + backward
+    stays on ONE stream (autograd runs a node's backward on the stream of its forward); the leaves' ``.grad`` accumulation
+    is ordered by autograd's own stream synchronisation, and everything is joined before the gradients are used."""
     n = rays.shape[0]
     total = 0
-    for s in range(0, n, chunk):
+    if streams <= 1:
+        for s in range(0, n, chunk):
+            e = min(s + chunk, n)
+            out = model.forward_(rays[s:e], stratified_u=jitter[s:e])
+            total += int(out["ray_indices"].numel())
+            torch.autograd.backward([out["opacity"], out["depth"], out["comp_normal_raw"]],
+                                    [cot[0][s:e], cot[1][s:e], cot[2][s:e]])
+        return total
+    main = torch.cuda.current_stream()
+    pool = side_streams(rays.device, streams)
+    for st in pool:
+        st.wait_stream(main)                       # inputs / zeroed gradients produced on the caller's stream
+    for k, s in enumerate(range(0, n, chunk)):
         e = min(s + chunk, n)
-        out = model.forward_(rays[s:e], stratified_u=jitter[s:e])
-        total += int(out["ray_indices"].numel())
-        torch.autograd.backward([out["opacity"], out["depth"], out["comp_normal_raw"]],
-                                [cot[0][s:e], cot[1][s:e], cot[2][s:e]])
+        with torch.cuda.stream(pool[k % streams]):
+            out = model.forward_(rays[s:e], stratified_u=jitter[s:e])
+            total += int(out["ray_indices"].numel())
+            torch.autograd.backward([out["opacity"], out["depth"], out["comp_normal_raw"]],
+                                    [cot[0][s:e], cot[1][s:e], cot[2][s:e]])
+    for st in pool:
+        main.wait_stream(st)                       # join: the caller (all-reduce, optimizer) sees complete gradients
     return total
 
 
@@ -278,7 +312,7 @@ def attach_traffic(roof, path):
                               f"{per_sample:.0f} B/sample fetched+written x samples per launch")
 
 
-def measure_c1(model, rays, jitter, cot, chunk, steps, warmup, world=1, buckets=None, timing=True):
+def measure_c1(model, rays, jitter, cot, chunk, steps, warmup, world=1, buckets=None, timing=True, streams=1):
     """``warmup`` untimed + ``steps`` timed passes over all rays (fwd+bwd per chunk, gradients accumulated, then the
     gradient all-reduce for world > 1) -> dict(dt, samples, summary)."""
     from rise_sdf_amd import _lib
@@ -286,7 +320,7 @@ def measure_c1(model, rays, jitter, cot, chunk, steps, warmup, world=1, buckets=
     def step():
         for p in model.parameters():
             p.grad = None
-        S = run_step(model, rays, jitter, cot, chunk)
+        S = run_step(model, rays, jitter, cot, chunk, streams)
         if buckets is not None:
             buckets.all_reduce_mean(world)
         return S
@@ -343,19 +377,22 @@ def secondary_measurements(dev, args, rays, jitter, cot):
         except Exception as e:   # noqa: BLE001  (recorded, not swallowed: the key carries the error)
             extras[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
 
-    def c1_variant(hidden, chunk, n_rays=None, fused=True, steps=1, warmup=1, precision="fp32"):
+    def c1_variant(hidden, chunk, n_rays=None, fused=True, steps=1, warmup=1, precision="fp32", streams=None):
         a = argparse.Namespace(hidden=hidden, precision=precision)
         m = build_model(dev, a)
         if not fused:
             m.config["fused"] = False
         r = rays if n_rays is None else rays[:n_rays]
-        res = measure_c1(m, r, jitter[:r.shape[0]], [c[:r.shape[0]] for c in cot], chunk, steps, warmup)
+        ns = args.streams if streams is None else streams
+        res = measure_c1(m, r, jitter[:r.shape[0]], [c[:r.shape[0]] for c in cot], chunk, steps, warmup, streams=ns)
         out = brief(res, steps)
-        out["config"] = {"hidden": hidden, "chunk_rays": chunk, "rays": int(r.shape[0]), "mlp_precision": precision,
+        out["config"] = {"hidden": hidden, "chunk_rays": chunk, "hip_streams": ns, "rays": int(r.shape[0]),
+                         "mlp_precision": precision,
                          "fused_stencil_kernels": bool(m._fused_ok())}
         return out
 
     guarded("chunk4096", lambda: c1_variant(args.hidden, 4096))
+    guarded("one_stream", lambda: c1_variant(args.hidden, args.chunk, streams=1))     # the round-2 issue order
     guarded("h128", lambda: c1_variant(128, args.chunk))
     # config[4]'s opt-in bf16 MLP mode at the yaml's width (dtype bf16; never part of the f32 headline)
     guarded("h128_bf16", lambda: c1_variant(128, args.chunk, precision="bf16"))
@@ -451,8 +488,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c1", choices=["c1", "c3"],
                     help="c1 = BASELINE.json config[1] (the metric); c3 = the occupancy-pruned N-rank training step")
-    ap.add_argument("--chunk", type=int, default=32768,
-                    help="rays per forward/backward chunk (~5 KB of HBM scratch per sample: 32768 rays = ~100 GB)")
+    ap.add_argument("--chunk", type=int, default=32000,
+                    help="rays per forward/backward chunk (~5 KB of HBM scratch per sample and stream in flight: "
+                         "32000 rays x 2 streams = ~190 GB)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams the chunks of a step alternate over (run_step); 1 = one chunk at a time")
     ap.add_argument("--width", type=int, default=800)
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--hidden", type=int, default=64)
@@ -496,7 +536,7 @@ def main():
     buckets = rdist.GradBuckets(model.parameters())
 
     res = measure_c1(model, rays, jitter, cot, args.chunk, args.steps, args.warmup, world, buckets,
-                     timing=(rank == 0 and not args.no_kernel_timing))
+                     timing=(rank == 0 and not args.no_kernel_timing), streams=args.streams)
     dt, samples = res["dt"], res["samples"]
 
     tt = torch.tensor([dt, float(samples)], dtype=torch.float64, device=dev)
@@ -539,7 +579,7 @@ def main():
                        "fused_stencil_kernels": bool(model._fused_ok()),
                        "rccl_ranks": torch.distributed.get_world_size() if world > 1 else 1,
                        "dist_backend": torch.distributed.get_backend() if world > 1 else None,
-                       "rays_per_gpu": n_rays, "chunk_rays": args.chunk,
+                       "rays_per_gpu": n_rays, "chunk_rays": args.chunk, "hip_streams": args.streams,
                        "samples_per_step": samples / args.steps,
                        "field_evals_per_sec": 7 * samples / dt, "parallelism": f"ray-parallel x{world}"},
             "roofline": roof, "cpu_baseline": cpu, "kernel_breakdown": breakdown,

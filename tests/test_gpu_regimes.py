@@ -273,3 +273,41 @@ def test_fused_kernels_edge_shapes(dev, hidden, n_samples, active, frozen):
             continue
         scale = float(g_ref[name].abs().max()) + 1e-12
         assert float((g_fused[name] - g_ref[name]).abs().max()) < 2e-4 * scale + 1e-7, (name, hidden)
+
+
+def test_two_stream_step_accumulates_the_same_gradients(dev):
+    """bench.py's run_step with the chunks alternating over two HIP streams (the shipped default) against one chunk at a
+    time: same sample total, same accumulated gradients (float-atomic order only), for every parameter."""
+    import rise_sdf_amd as R
+    sys.path.insert(0, ROOT)
+    import bench
+    torch.manual_seed(0)
+    cfg = bench.c1_config(hidden=64)
+    cfg["num_samples_per_ray"] = 256
+    model = R.make("neus", cfg).to(dev)
+    enc = model.geometry.encoding.encoding.encoding
+    gen = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        enc.params.copy_(((torch.rand(enc.params.numel(), generator=gen) * 2 - 1) * 3e-2).to(dev))
+        l0 = model.geometry.network.layers[0]
+        l0.weight_v[:, 3:] = (torch.randn(l0.weight_v[:, 3:].shape, generator=gen) * 0.3).to(dev)
+    model.train()
+    model.geometry.update_step(0, 0)
+    rays = camera_rays(64, 64, seed=5).to(dev)
+    n = rays.shape[0]
+    u = torch.rand(n, generator=gen).to(dev)
+    cot = [torch.randn(n, 1, generator=gen).to(dev), torch.randn(n, 1, generator=gen).to(dev),
+           torch.randn(n, 3, generator=gen).to(dev)]
+    res = []
+    for streams in (1, 2, 3):
+        for p in model.parameters():
+            p.grad = None
+        total = bench.run_step(model, rays, u, cot, 512, streams=streams)
+        torch.cuda.synchronize()
+        res.append((total, {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+    assert res[0][0] == res[1][0] == res[2][0] > 100000
+    for total, grads in res[1:]:
+        assert set(grads) == set(res[0][1])
+        for k, g in grads.items():
+            ref = res[0][1][k]
+            assert float((g - ref).abs().max()) < 2e-5 * float(ref.abs().max()) + 1e-12, k
