@@ -11,5 +11,5 @@ variant_objs() { for o in _build/*.o; do b=$(basename $o); if [ -f /tmp/ab/$b ];
 for v in "$1" "$2" "$1" "$2"; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -I../../include $v -c mlp_fused.hip -o /tmp/ab/mlp_fused.o
   /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $(variant_objs) -o $RSDF_LIB
-  (cd ../.. && python bench.py --steps 2 --warmup 1 --cpu-rays 0 --no-extras --width 400 --height 400 2>&1 | tail -1 | grep -o "rsdf_sdfmlp_fd7_fwd[^}]*}\|rsdf_sdfmlp_fd7_bwd\": {[^}]*}" | tr '\n' ' '; echo " <= [$v]")
+  (cd ../.. && python bench.py --steps 2 --warmup 1 --cpu-rays 0 --no-extras --streams 1 --width 400 --height 400 2>&1 | tail -1 | grep -o "rsdf_sdfmlp_fd7_fwd[^}]*}\|rsdf_sdfmlp_fd7_bwd\": {[^}]*}" | tr '\n' ' '; echo " <= [$v]")
 done

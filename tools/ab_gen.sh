@@ -11,7 +11,7 @@ variant_objs() { for o in _build/*.o; do b=$(basename $o); if [ -f /tmp/ab/$b ];
 for v in "$@"; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -I../../include $v -c hashgrid.hip -o /tmp/ab/hashgrid.o
   /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $(variant_objs) -o $RSDF_LIB
-  (cd ../.. && python bench.py --steps 1 --warmup 0 --cpu-rays 0 --no-extras 2>/dev/null | tail -1 | python3 -c "
+  (cd ../.. && python bench.py --steps 1 --warmup 0 --cpu-rays 0 --no-extras --streams 1 2>/dev/null | tail -1 | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read()); g=d['roofline']['other_kernels']['rsdf_hashgrid_fwd (generic)']
 print(g['avg_launch_ms'], 'ms', '%.3g evals/s' % g['evals_per_sec'], g['frac'])"; echo " <= [$v]")

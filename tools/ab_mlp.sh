@@ -15,7 +15,7 @@ for v in "$@"; do
   done
   /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $(variant_objs) -o $RSDF_LIB
   for h in 64 128; do
-  (cd ../.. && python bench.py --steps 2 --warmup 1 --cpu-rays 0 --no-extras --width 400 --height 400 --hidden $h 2>/dev/null | tail -1 | python3 -c "
+  (cd ../.. && python bench.py --steps 2 --warmup 1 --cpu-rays 0 --no-extras --streams 1 --width 400 --height 400 --hidden $h 2>/dev/null | tail -1 | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read()); kb=d['kernel_breakdown']
 print('H=$h', {k:round(v['ms_per_step']/v['calls']*d['steps'],2) for k,v in kb.items() if 'sdfmlp' in k}, '%.4g'%d['value'])")

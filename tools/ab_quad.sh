@@ -12,7 +12,7 @@ ARGS="$1"; shift
 for v in "$@"; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC $v -c mlp_quad.hip -o /tmp/ab/mlp_quad.o
   /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $(variant_objs) -o $RSDF_LIB
-  (cd ../.. && python bench.py --steps 2 --warmup 1 --cpu-rays 0 --no-extras --width 400 --height 400 $ARGS 2>/dev/null | tail -1 | python3 -c "
+  (cd ../.. && python bench.py --steps 2 --warmup 1 --cpu-rays 0 --no-extras --streams 1 --width 400 --height 400 $ARGS 2>/dev/null | tail -1 | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 kb=d['kernel_breakdown']

@@ -5,7 +5,7 @@ set -uo pipefail
 : "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}"
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-ARGS=${@:---steps 1 --warmup 0 --cpu-rays 0 --no-extras --width 400 --height 400 --no-kernel-timing}
+ARGS=${@:---steps 1 --warmup 0 --cpu-rays 0 --no-extras --streams 1 --width 400 --height 400 --no-kernel-timing}
 mkdir -p gpurun_out/pmc
 for pass in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU" "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
   name=$(echo $pass | cut -d' ' -f1)

@@ -14,7 +14,7 @@ variant_objs() { for o in _build/*.o; do b=$(basename $o); if [ -f /tmp/ab/$b ];
 cd ../..
 python3 - <<'PY'
 import ctypes, sys, io, contextlib, runpy
-sys.argv = ["bench.py", "--hidden", "128", "--steps", "1", "--warmup", "0", "--cpu-rays", "0", "--no-extras", "--width", "400", "--height", "400",
+sys.argv = ["bench.py", "--hidden", "128", "--steps", "1", "--warmup", "0", "--cpu-rays", "0", "--no-extras", "--streams", "1", "--width", "400", "--height", "400",
             "--no-kernel-timing"]
 buf = io.StringIO()
 with contextlib.redirect_stdout(buf):
