@@ -489,9 +489,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c1", choices=["c1", "c3"],
                     help="c1 = BASELINE.json config[1] (the metric); c3 = the occupancy-pruned N-rank training step")
-    ap.add_argument("--chunk", type=int, default=32000,
+    ap.add_argument("--chunk", type=int, default=24576,
                     help="rays per forward/backward chunk (~5 KB of HBM scratch per sample and stream in flight: "
-                         "32000 rays x 2 streams = ~190 GB)")
+                         "24576 rays x 2 streams = ~145 GB of the 288 GB; three such streams do not fit and the caching "
+                         "allocator then thrashes)")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the chunks of a step alternate over (run_step); 1 = one chunk at a time")
     ap.add_argument("--width", type=int, default=800)
@@ -503,6 +504,8 @@ def main():
     ap.add_argument("--cpu-rays", type=int, default=4096,
                     help="upper bound on the rays in the CPU-baseline sample (0 = skip); shrunk to fit ~8 s/repetition")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--time-overlapped", action="store_true",
+                    help="also record per-entry-point HIP events inside a two-stream timed region (overlapping times)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the secondary measurements appended to the line at N = 1 (see secondary_measurements)")
     ap.add_argument("--pmc-summary", default=os.path.join(ROOT, "profiles", "pmc_summary.json"),
@@ -536,8 +539,11 @@ def main():
            torch.randn(n_rays, 3, generator=g).to(dev)]
     buckets = rdist.GradBuckets(model.parameters())
 
+    # per-entry-point HIP events inside the timed region only when the step runs on one stream: with two chunks in flight
+    # those times overlap and are not used (the roofline object then comes from a one-stream pass below)
     res = measure_c1(model, rays, jitter, cot, args.chunk, args.steps, args.warmup, world, buckets,
-                     timing=(rank == 0 and not args.no_kernel_timing), streams=args.streams)
+                     timing=(rank == 0 and not args.no_kernel_timing and (args.streams == 1 or args.time_overlapped)),
+                     streams=args.streams)
     dt, samples = res["dt"], res["samples"]
 
     tt = torch.tensor([dt, float(samples)], dtype=torch.float64, device=dev)
@@ -551,12 +557,13 @@ def main():
     if rank == 0:
         roof, breakdown, overlapped = (None, None, None)
         summary, n_timed = res["summary"], args.steps
-        if summary is not None and args.streams > 1:
+        if args.streams > 1 and not args.no_kernel_timing:
             # With two chunks in flight a kernel's event-to-event time includes its neighbour's share of the GPU (the
             # per-entry-point times of the timed region add up to ~1.8x the step), so they cannot price a kernel against
             # its roofline.  The roofline object therefore comes from ONE more pass of the same step issued on one stream,
             # right here in the same run; the timed region's own (overlapped) per-entry-point times are kept beside it.
-            _, overlapped = roofline_from(summary, args.steps)
+            if summary is not None:
+                _, overlapped = roofline_from(summary, args.steps)
             iso = measure_c1(model, rays, jitter, cot, args.chunk, 1, 0, 1, None, timing=True, streams=1)
             summary, n_timed = iso["summary"], 1
         if summary is not None:
