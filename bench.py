@@ -401,13 +401,17 @@ def secondary_measurements(dev, args, rays, jitter, cot):
     # two-line dropin.install()): [7 S, 35] rows through HBM, so a quarter of the view at the reference's chunk size
     guarded("dropin_path", lambda: c1_variant(args.hidden, 4096, n_rays=rays.shape[0] // 4 // 800 * 800, fused=False))
 
-    def c2(tex_precision="fp32"):
+    def c2(tex_precision="fp32", streams=1):
         from bench_c2 import measure_c2
-        r = measure_c2(dev, args.width, args.height, 16384, stage=1, tex_hidden=128, steps=1, tex_precision=tex_precision)
-        out = brief({"dt": r["ms_per_step"] / 1e3, "samples": r["samples_per_step"], "summary": r["summary"]}, 1)
+        # (~9 KB of scratch per sample with the radiance networks' activations: 16384 rays one at a time, 8192 when two
+        # chunks are in flight -- two 16384-ray chunks exceed the HBM and the caching allocator thrashes, 1.7e7)
+        r = measure_c2(dev, args.width, args.height, 16384 if streams == 1 else 8192, stage=1, tex_hidden=128, steps=1,
+                       tex_precision=tex_precision, streams=streams)
+        out = brief({"dt": r["ms_per_step"] / 1e3, "samples": r["samples_per_step"], "summary": r["summary"] or None}, 1)
         out["workload"] = r["workload"]
         return out
-    guarded("c2_800", c2)
+    guarded("c2_800", c2)                                           # one chunk at a time: carries the dominant kernel
+    guarded("c2_800_two_streams", lambda: c2(streams=args.streams))
     # configs[4]'s bf16 mode on the radiance networks only (SDF network fp32: the combination the convergence proxy,
     # tests/test_gpu_convergence.py, finds indistinguishable from fp32)
     guarded("c2_800_bf16_radiance", lambda: c2("bf16"))

@@ -14,7 +14,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def measure_c2(dev, width=800, height=800, chunk=16384, stage=1, tex_hidden=128, steps=1, hidden=64, tex_precision="fp32"):
+def measure_c2(dev, width=800, height=800, chunk=16384, stage=1, tex_hidden=128, steps=1, hidden=64, tex_precision="fp32",
+               streams=1):
     """-> dict(samples_per_s, ms_per_step, samples_per_step, kernel_ms_total, top, summary): one view of config[2]
     (c1 + radiance branch + split-sum shading against a 512^2 environment), fwd+bwd, one build_mips per step."""
     import types
@@ -68,18 +69,26 @@ def measure_c2(dev, width=800, height=800, chunk=16384, stage=1, tex_hidden=128,
             leaves = [t.detach().requires_grad_(True) for t in built]
             em.specular, em.diffuse = leaves[:-1], leaves[-1]
         total = 0
-        for s in range(0, n, args.chunk):
-            out = model.forward_(rays[s:s + args.chunk], stratified_u=u[s:s + args.chunk])
-            total += int(out["num_samples"])
-            key = "comp_rgb_phys_full" if model.stage else "comp_rgb_full"
-            (out[key] * cot[s:s + args.chunk]).sum().backward()
+        key = "comp_rgb_phys_full" if model.stage else "comp_rgb_full"
+        main = torch.cuda.current_stream()
+        pool = bench.side_streams(dev, streams) if streams > 1 else [main]   # chunks alternate over the streams (bench.run_step)
+        for st in pool:
+            st.wait_stream(main)
+        for k, s in enumerate(range(0, n, args.chunk)):
+            with torch.cuda.stream(pool[k % len(pool)]):
+                out = model.forward_(rays[s:s + args.chunk], stratified_u=u[s:s + args.chunk])
+                total += out["num_samples_host"]
+                (out[key] * cot[s:s + args.chunk]).sum().backward()
+        for st in pool:
+            main.wait_stream(st)
         if model.stage:
             torch.autograd.backward(built, [l.grad if l.grad is not None else torch.zeros_like(l) for l in leaves])
         return total
 
     step()
     timer = _lib.KernelTimer()
-    _lib.set_timer(timer)
+    if streams == 1:                  # (per-entry-point events only when one chunk is in flight: bench.py, roofline)
+        _lib.set_timer(timer)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     samples = sum(step() for _ in range(args.steps))
@@ -89,7 +98,7 @@ def measure_c2(dev, width=800, height=800, chunk=16384, stage=1, tex_hidden=128,
     summ = timer.summary()
     top = {k: round(v["ms"] / args.steps, 1) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:14]}
     return {"workload": f"c2 stage {model.stage}: split-mixed-occ, {args.width}x{args.height}, texture width "
-                        f"{args.tex_hidden} ({tex_precision}), env 512^2", "samples_per_s": samples / dt,
+                        f"{args.tex_hidden} ({tex_precision}), env 512^2, {streams} stream(s)", "samples_per_s": samples / dt,
             "ms_per_step": dt / args.steps * 1e3, "samples_per_step": samples / args.steps,
             "kernel_ms_total": round(sum(v["ms"] for v in summ.values()) / args.steps, 1), "top": top, "summary": summ}
 
@@ -102,8 +111,11 @@ def main():
     ap.add_argument("--stage", type=int, default=1)
     ap.add_argument("--tex-hidden", type=int, default=128)
     ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--streams", type=int, default=1)
+    ap.add_argument("--tex-precision", default="fp32")
     args = ap.parse_args()
-    r = measure_c2(torch.device("cuda", 0), args.width, args.height, args.chunk, args.stage, args.tex_hidden, args.steps)
+    r = measure_c2(torch.device("cuda", 0), args.width, args.height, args.chunk, args.stage, args.tex_hidden, args.steps,
+                   tex_precision=args.tex_precision, streams=args.streams)
     r.pop("summary")
     print(json.dumps(r))
 
