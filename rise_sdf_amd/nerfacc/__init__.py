@@ -249,7 +249,8 @@ class OccGridEstimator(nn.Module):
         self.rng = None
         self.capacity_mode = False
         self._capacity = {}
-        self.stats = {"capped_calls": 0, "overflows": 0}
+        self._pending = []
+        self.stats = {"capped_calls": 0, "overflows": 0, "blind_calls": 0, "blind_overflows": 0}
 
     @property
     def device(self):
@@ -282,7 +283,13 @@ class OccGridEstimator(nn.Module):
             rays_o, rays_d, t_min, t_max, self.aabbs[0], self.binaries[0], render_step_size,
             cone_angle)
         if self.capacity_mode:
+            if self._pending:        # (an exact call -- first step, or after an overflow -- settles them with a read of its own)
+                vals = torch.cat([p[2] for p in self._pending]).tolist()
+                self._settle_pending(list(zip(vals[0::2], vals[1::2])))
             self._remember(key=(near, far, round(float(render_step_size), 9)), n_candidates=ray_indices.numel())
+            bkey = ("blind", near, far, round(float(render_step_size), 9))
+            if bkey not in self._capacity:
+                self._capacity[bkey] = int(ray_indices.numel() * 1.5) + 4096
         if (sigma_fn is not None or alpha_fn is not None) and ray_indices.numel() > 0:
             if sigma_fn is not None:
                 sigmas = sigma_fn(t_starts, t_ends, ray_indices)
@@ -318,13 +325,48 @@ class OccGridEstimator(nn.Module):
                                  zero_init=True)
         cnt = []
         ri_o, ts_o, te_o = ops.compact_samples(keep, ri, ts, te, count_out=cnt)
-        n_cand, n_kept = torch.cat([total, cnt[0]]).tolist()          # the one host read of this call
+        vals = torch.cat([total, cnt[0]] + [p[2] for p in self._pending]).tolist()   # the one host read of this call
+        n_cand, n_kept = vals[:2]
+        self._settle_pending(list(zip(vals[2::2], vals[3::2])))      # (+ the counts of earlier read-free passes)
         self._remember(key, n_cand)
         self.stats["capped_calls"] += 1
         if n_cand > cap:                                               # truncated: redo exactly (rare)
             self.stats["overflows"] += 1
             return None
         return ri_o[:n_kept], ts_o[:n_kept], te_o[:n_kept]
+
+    @torch.no_grad()
+    def sampling_blind(self, rays_o, rays_d, alpha_fn, near_plane, far_plane, t_min, t_max, render_step_size,
+                       early_stop_eps: float = 1e-4, alpha_thre: float = 0.0):
+        """Capacity mode WITHOUT a host read, for passes whose results are per-ray only (the secondary-ray occlusion
+        pass): -> (ray_indices, t_starts, t_ends), all of capacity size; entries past the survivor count are empty samples
+        of the LAST ray (the caller appends a phantom ray that owns them), or None when no capacity is known yet.  The
+        two counts stay on the device and ride along with the next capped call's read; if the candidates outgrew the
+        buffers, that pass ran on a truncated set (``stats['blind_overflows']``) and the capacity grows."""
+        key = ("blind", float(near_plane), float(far_plane), round(float(render_step_size), 9))
+        cap = self._capacity.get(key)
+        t_min = torch.clamp(t_min, min=float(near_plane))
+        t_max = torch.clamp(t_max, max=float(far_plane))
+        if cap is None:
+            return None
+        packed, ri, ts, te, total = ops.march_capped(rays_o, rays_d, t_min, t_max, self.aabbs[0], self.binaries[0],
+                                                     render_step_size, cap, 0.0)
+        alphas = alpha_fn(ts, te, ri)
+        keep = render_visibility(alphas, packed_info=packed, early_stop_eps=early_stop_eps, alpha_thre=alpha_thre,
+                                 zero_init=True)
+        cnt = []
+        out = ops.compact_samples(keep, ri, ts, te, count_out=cnt, fill_ray=rays_o.shape[0] - 1)
+        self._pending.append((key, cap, torch.cat([total, cnt[0]])))
+        self.stats["blind_calls"] += 1
+        return out
+
+    def _settle_pending(self, counts):
+        """counts: the host values of the pending blind calls' [candidates, survivors], in order."""
+        for (key, cap, _), (n_cand, _) in zip(self._pending, counts):
+            self._capacity[key] = int(n_cand * 1.5) + 4096
+            if n_cand > cap:
+                self.stats["blind_overflows"] += 1
+        self._pending = []
 
     @torch.no_grad()
     def _sample_uniform_and_occupied_cells(self, n: int):

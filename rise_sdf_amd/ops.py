@@ -163,7 +163,7 @@ def unpack_info(packed_info, n_samples):
 
 
 @torch.no_grad()
-def compact_samples(keep, ray_indices, t_starts, t_ends, count_out=None):
+def compact_samples(keep, ray_indices, t_starts, t_ends, count_out=None, fill_ray=None):
     """Boolean-mask compaction of lib/nerfacc/ray_marching.py:213-218 (one host read of the count; with ``count_out`` (a
     list) the device count is appended to it instead and the un-sliced outputs are returned)."""
     k = keep.contiguous().view(torch.uint8) if keep.dtype == torch.bool else keep.contiguous()
@@ -172,7 +172,10 @@ def compact_samples(keep, ray_indices, t_starts, t_ends, count_out=None):
     n, dev = ri.numel(), ri.device
     off = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
     cnt = torch.zeros(1, dtype=torch.int32, device=dev)
-    ri_o, ts_o, te_o = torch.empty_like(ri), torch.empty_like(ts), torch.empty_like(te)
+    if fill_ray is None:
+        ri_o, ts_o, te_o = torch.empty_like(ri), torch.empty_like(ts), torch.empty_like(te)
+    else:   # entries past the (device-side) count read as empty samples of ray ``fill_ray`` (a phantom last ray)
+        ri_o, ts_o, te_o = torch.full_like(ri, int(fill_ray)), torch.zeros_like(ts), torch.zeros_like(te)
     check(lib().rsdf_compact_samples(ptr(k), ptr(ri), ptr(ts), ptr(te), n, ptr(off), ptr(cnt),
                                      ptr(_scan_scratch(n, dev)), ptr(ri_o), ptr(ts_o), ptr(te_o),
                                      stream_ptr()), "compact_samples")

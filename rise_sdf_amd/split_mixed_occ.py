@@ -118,6 +118,21 @@ class SplitMixedOCCModel(BaseModel):
                 t_min, t_max = ops.ray_aabb_intersect(rays_o, rays_d, self.occupancy_grid.aabbs[0])
                 miss = torch.full_like(t_min, 1e10)
                 t_min, t_max = torch.where(valid, t_min, miss), torch.where(valid, t_max, miss)
+                if self.occupancy_grid.capacity_mode:
+                    # No host read at all for this pass (its results are per ray): capacity-sized sample arrays whose
+                    # unused tail belongs to one phantom ray appended here; counts are checked with the next step's read.
+                    ro_p = torch.cat([rays_o, torch.zeros_like(rays_o[:1])])            # (fills, no host-to-device copies)
+                    rd_p = torch.cat([rays_d, torch.ones_like(rays_d[:1]) * 0.57735026])
+                    a_fn = self._alpha_fn(ro_p, rd_p)
+                    far1 = torch.full_like(t_min[:1], 1e10)
+                    blind = self.occupancy_grid.sampling_blind(
+                        ro_p, rd_p, a_fn, self.secondary_near_plane, self.secondary_far_plane,
+                        torch.cat([t_min, far1]), torch.cat([t_max, far1]), step)
+                    if blind is not None:
+                        acc_map, depth_map, _ = secondary_rendering(blind[1], blind[2], ray_indices=blind[0],
+                                                                    n_rays=n_rays + 1, alpha_fn=a_fn,
+                                                                    chunk_size=self.secondary_shader_chunk)
+                        return 1.0 - acc_map[:n_rays], depth_map[:n_rays]
             ray_indices, t_starts, t_ends = self.occupancy_grid.sampling(
                 rays_o, rays_d, alpha_fn=alpha_fn, near_plane=self.secondary_near_plane,
                 far_plane=self.secondary_far_plane, render_step_size=step, stratified=False, t_min=t_min, t_max=t_max)
