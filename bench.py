@@ -420,7 +420,8 @@ def secondary_measurements(dev, args, rays, jitter, cot):
         from bench_step import measure
         r = measure(dev, stage=1, steps=30, settle=80, syncs=True, **kw)
         return {k: r[k] for k in ("ms_per_step", "rays_per_step", "samples_per_step", "samples_per_s",
-                                  "rsdf_kernel_ms_per_step", "host_syncs_per_step", "top", "hidden", "stage")}
+                                  "rsdf_kernel_ms_per_step", "host_syncs_per_step", "sampler_stats", "top", "hidden",
+                                  "stage")}
     guarded("c3_step", c3)
     guarded("c3_step_bf16_radiance", lambda: c3(tex_precision="bf16"))
     return extras

@@ -71,6 +71,7 @@ def measure(dev, stage=1, steps=30, settle=80, first_step=20000, syncs=False, hi
            "rsdf_kernel_ms_per_step": round(sum(v["ms"] for v in summ.values()) / steps, 2),
            "top": {k: round(v["ms"] / steps, 2) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:10]},
            "settle_first": traj[:3], "settle_last": traj[-3:]}
+    out["sampler_stats"] = dict(getattr(model.occupancy_grid, "stats", {}))
     if syncs:
         n, sites = count_syncs(lambda: ts.step(gs + steps))
         out["host_syncs_per_step"], out["sync_sites"] = n, sites
