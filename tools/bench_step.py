@@ -78,6 +78,36 @@ def measure(dev, stage=1, steps=30, settle=80, first_step=20000, syncs=False, hi
     return out
 
 
+def aten_sites(dev, stage=1, settle=40, **build_kw):
+    """Which source lines of the package issue the aten kernels of one step (torch dispatch mode)."""
+    import collections
+    import traceback
+    from torch.utils._python_dispatch import TorchDispatchMode
+    model, ts = build(dev, stage=stage, **build_kw)
+    for k in range(settle):
+        ts.step(20000 + k)
+    sites = collections.Counter()
+    skip = ("aten::empty", "aten::view", "aten::_unsafe_view", "aten::reshape", "aten::detach", "aten::as_strided",
+            "aten::slice", "aten::select", "aten::expand", "aten::t", "aten::transpose", "aten::permute", "aten::unsqueeze",
+            "aten::squeeze", "aten::alias", "aten::_local_scalar_dense", "aten::empty_like", "aten::empty_strided",
+            "aten::split", "aten::unbind", "aten::split_with_sizes", "aten::lift_fresh", "aten::_to_copy", "aten::new_empty")
+
+    class Mode(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            name = func._schema.name
+            if not name.startswith(skip):
+                fr = [f for f in traceback.extract_stack() if "rise_sdf_amd" in f.filename]
+                f = fr[-1] if fr else None
+                sites[("%s:%d %s" % (os.path.basename(f.filename), f.lineno, f.name) if f else "?", name)] += 1
+            return func(*args, **(kwargs or {}))
+
+    with Mode():
+        ts.step(20000 + settle)
+    print("aten ops by issuing line, forward + Python-side backward of one step: total", sum(sites.values()))
+    for (site, name), c in sites.most_common(70):
+        print("%4d  %-26s %s" % (c, name, site))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--stage", type=int, default=1)
@@ -87,8 +117,11 @@ def main():
     ap.add_argument("--syncs", action="store_true")
     ap.add_argument("--tex-precision", default="fp32")
     ap.add_argument("--sdf-precision", default="fp32")
+    ap.add_argument("--aten-sites", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
+    if args.aten_sites:
+        return aten_sites(dev, args.stage, hidden=args.hidden)
     print(json.dumps(measure(dev, args.stage, args.steps, args.settle, syncs=args.syncs, hidden=args.hidden,
                              tex_precision=args.tex_precision, sdf_precision=args.sdf_precision)))
 
