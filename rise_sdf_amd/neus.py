@@ -69,16 +69,44 @@ class VarianceNetwork(nn.Module):
                                    self.max_inv_s)
 
 
-def chunk_batch(func, chunk_size, move_to_cpu, *args, **kwargs):
-    """models/utils.py:14-51 for dict-returning functions."""
+_EVAL_STREAMS = {}
+
+
+def chunk_batch(func, chunk_size, move_to_cpu, *args, streams=1, **kwargs):
+    """models/utils.py:14-51 for dict-returning functions.
+
+    ``streams`` > 1 (evaluation only: no autograd graph is kept): consecutive chunks are issued on alternating HIP streams.
+    An evaluation chunk blocks the host several times (sample counts), and while one chunk waits the other stream's kernels
+    keep the GPU busy; results are identical (every chunk's kernels stay in order on their own stream) and everything is
+    joined to the caller's stream before the outputs are concatenated."""
     B = next(a.shape[0] for a in args if isinstance(a, torch.Tensor))
+    dev = next((a.device for a in args if isinstance(a, torch.Tensor)), None)
+    use = (streams > 1 and dev is not None and dev.type == "cuda" and not torch.is_grad_enabled() and B > chunk_size)
+    pool = None
+    if use:
+        key = (str(dev), int(streams))
+        if key not in _EVAL_STREAMS:
+            _EVAL_STREAMS[key] = [torch.cuda.Stream(device=dev) for _ in range(int(streams))]
+        pool, main = _EVAL_STREAMS[key], torch.cuda.current_stream(dev)
+        for st in pool:
+            st.wait_stream(main)
     out = {}
-    for i in range(0, B, chunk_size):
-        chunk = func(*[a[i:i + chunk_size] if isinstance(a, torch.Tensor) else a for a in args],
-                     **kwargs)
-        for k, v in chunk.items():
+    for k, i in enumerate(range(0, B, chunk_size)):
+        sl = [a[i:i + chunk_size] if isinstance(a, torch.Tensor) else a for a in args]
+        if pool is not None:
+            with torch.cuda.stream(pool[k % len(pool)]):
+                chunk = func(*sl, **kwargs)
+                for v in chunk.values():
+                    if isinstance(v, torch.Tensor):
+                        v.record_stream(main)          # consumed (torch.cat) on the caller's stream below
+        else:
+            chunk = func(*sl, **kwargs)
+        for k2, v in chunk.items():
             v = v if torch.is_grad_enabled() else v.detach()
-            out.setdefault(k, []).append(v.cpu() if move_to_cpu else v)
+            out.setdefault(k2, []).append(v.cpu() if move_to_cpu else v)
+    if pool is not None:
+        for st in pool:
+            main.wait_stream(st)
     return {k: torch.cat(v, dim=0) for k, v in out.items()}
 
 
@@ -234,7 +262,8 @@ class NeuSModel(BaseModel):
         if self.training:
             out = self.forward_(rays, **kw)
         else:
-            out = chunk_batch(self.forward_, self.config.get("ray_chunk", 4096), False, rays)
+            out = chunk_batch(self.forward_, self.config.get("ray_chunk", 4096), False, rays,
+                              streams=int(self.config.get("eval_streams", 2)))
         return {**out, "inv_s": self.variance.inv_s}
 
     def train(self, mode=True):

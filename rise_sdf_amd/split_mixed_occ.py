@@ -275,7 +275,8 @@ class SplitMixedOCCModel(BaseModel):
         if self.training:
             out = self.forward_(rays, relighting=relighting, **kw)
         else:
-            out = chunk_batch(self.forward_, self.config.get("ray_chunk", 4096), False, rays, relighting)
+            out = chunk_batch(self.forward_, self.config.get("ray_chunk", 4096), False, rays, relighting,
+                              streams=int(self.config.get("eval_streams", 2)))
         return {**out, "inv_s": self.variance.inv_s}
 
     def train(self, mode=True):
