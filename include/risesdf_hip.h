@@ -138,6 +138,14 @@ int64_t rsdf_grid_meta_init(rsdf_grid_meta *meta /*host*/, int n_levels, int n_f
 int rsdf_hashgrid_fwd(const float *x, const float *table, const rsdf_grid_meta *meta /*host*/,
                       int64_t n, int n_active_levels, float *out, int ld_out, int col_off,
                       int write_xyz, float xyz_scale, float xyz_offset, void *stream);
+/* The same encoding (bit-identical rows) for large batches: a level-major pass writes [n_active][n][F] planes into scratch
+ * (every workgroup in flight reads the same L2-resident level), a second pass lays them out as rows through LDS.
+ * scratch >= rsdf_hashgrid_fwd_staged_scratch_bytes(...) bytes; write_xyz needs col_off == 3. */
+int64_t rsdf_hashgrid_fwd_staged_scratch_bytes(const rsdf_grid_meta *meta /*host*/, int64_t n, int n_active_levels);
+int rsdf_hashgrid_fwd_staged(const float *x, const float *table, const rsdf_grid_meta *meta /*host*/,
+                             int64_t n, int n_active_levels, float *out, int ld_out, int col_off,
+                             int write_xyz, float xyz_scale, float xyz_offset, void *scratch,
+                             int64_t scratch_bytes, void *stream);
 /* dtable += scatter(w * dout); dout row stride ld_dout, features at column col_off.
  * dtable must be zeroed (or hold a running sum) by the caller. */
 int rsdf_hashgrid_bwd(const float *x, const float *dout, const rsdf_grid_meta *meta /*host*/,

@@ -59,6 +59,8 @@ _SIGNATURES = {
     "rsdf_accumulate_bwd": [_P, _P, _P, _P, _L, _I, _P, _P, _P],
     "rsdf_grid_meta_init": [ctypes.POINTER(GridMeta), _I, _I, _I, _I, ctypes.c_double],
     "rsdf_hashgrid_fwd": [_P, _P, ctypes.POINTER(GridMeta), _L, _I, _P, _I, _I, _I, _F, _F, _P],
+    "rsdf_hashgrid_fwd_staged_scratch_bytes": [ctypes.POINTER(GridMeta), _L, _I],
+    "rsdf_hashgrid_fwd_staged": [_P, _P, ctypes.POINTER(GridMeta), _L, _I, _P, _I, _I, _I, _F, _F, _P, _L, _P],
     "rsdf_hashgrid_bwd": [_P, _P, ctypes.POINTER(GridMeta), _L, _I, _I, _I, _P, _P],
     "rsdf_hashgrid_bwd_fd7_scratch_bytes": [ctypes.POINTER(GridMeta), _L, _I, _F],
     "rsdf_hashgrid_fwd_fd7": [_P, _P, ctypes.POINTER(GridMeta), _L, _I, _P, _P],
@@ -146,6 +148,7 @@ _RESTYPES = {"rsdf_last_error": ctypes.c_char_p, "rsdf_scan_scratch_bytes": ctyp
              "rsdf_grid_meta_init": ctypes.c_int64,
              "rsdf_hashgrid_bwd_fd7_scratch_bytes": ctypes.c_int64,
              "rsdf_hashgrid_scatter_binned_scratch_bytes": ctypes.c_int64,
+             "rsdf_hashgrid_fwd_staged_scratch_bytes": ctypes.c_int64,
              "rsdf_occ_update_scratch_bytes": ctypes.c_int64}
 
 EXPORTS = tuple(_SIGNATURES)

@@ -98,6 +98,103 @@ hashgrid_fwd_kernel(const float *__restrict__ x, const float *__restrict__ table
     for (int f = 0; f < F; ++f) o[f] = acc[f];
 }
 
+// Staged form of the same gather for large batches (rsdf_hashgrid_fwd_staged).  The sample-group-major order above buys
+// whole-line output writes with table locality: the 8 XCDs change level every FWD_GROUP tiles and every change refills a
+// 4 MiB level into each 4 MiB L2 (a third of the line requests miss at 1024 tiles).  Here the two concerns are separated:
+//   1. planes kernel, PURE level-major (blockIdx.y = level): every workgroup in flight reads the same L2-resident level
+//      and writes its F floats per sample as one coalesced [n][F] plane -- no partial rows anywhere;
+//   2. rows kernel: 128 samples x all levels of planes -> an LDS tile -> whole [ld_out] rows (xyz columns and the zeros of
+//      the inactive levels included), 2 x 4 F L bytes per evaluation of extra streaming traffic.
+// The arithmetic is the kernel's above, statement for statement: bit-identical outputs.
+template <int F>
+__global__ void __launch_bounds__(THREADS)
+hashgrid_fwd_planes_kernel(const float *__restrict__ x, const float *__restrict__ table, const rsdf_grid_meta meta,
+                           int64_t n, float *__restrict__ planes)
+{
+    const int l = blockIdx.y;
+    const int64_t s = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (s >= n) return;
+    const float px = x[3 * s], py = x[3 * s + 1], pz = x[3 * s + 2];
+    const LevelInfo li = level_info(meta, l);
+    const float posx = fmaf(li.scale, px, 0.5f), posy = fmaf(li.scale, py, 0.5f),
+                posz = fmaf(li.scale, pz, 0.5f);
+    const float fx = floorf(posx), fy = floorf(posy), fz = floorf(posz);
+    const uint32_t cx = (uint32_t)(int32_t)fx, cy = (uint32_t)(int32_t)fy, cz = (uint32_t)(int32_t)fz;
+    const float wx = posx - fx, wy = posy - fy, wz = posz - fz;
+    using V = typename Feat<F>::T;
+    const V *tl = reinterpret_cast<const V *>(table) + li.offset;
+    V v[8];
+    float wc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        float w = 1.0f;
+        w *= (c & 1) ? wx : 1.0f - wx;
+        w *= (c & 2) ? wy : 1.0f - wy;
+        w *= (c & 4) ? wz : 1.0f - wz;
+        wc[c] = w;
+        const uint32_t idx = grid_index(cx + (c & 1), cy + ((c >> 1) & 1), cz + ((c >> 2) & 1), li);
+        v[c] = tl[idx];
+    }
+    V acc;
+    float *af = reinterpret_cast<float *>(&acc);
+#pragma unroll
+    for (int f = 0; f < F; ++f) af[f] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float *vf = reinterpret_cast<const float *>(&v[c]);
+#pragma unroll
+        for (int f = 0; f < F; ++f) af[f] = fmaf(wc[c], vf[f], af[f]);
+    }
+    reinterpret_cast<V *>(planes)[(int64_t)l * n + s] = acc;
+}
+
+constexpr int ROWS_TILE = 128;   // samples per workgroup of the rows kernel
+
+template <int F>
+__global__ void __launch_bounds__(THREADS)
+planes_to_rows_kernel(const float *__restrict__ planes, const float *__restrict__ x, int64_t n, int n_levels,
+                      int n_active, float *__restrict__ out, int ld_out, int col_off, int write_xyz, float xyz_scale,
+                      float xyz_offset)
+{
+    // tile [ROWS_TILE][tw] with an odd row stride (conflict-free column writes); tw = (3 +) n_levels F columns that
+    // start at column c0 of the output row
+    extern __shared__ float s_tile[];
+    const int nx = write_xyz ? 3 : 0;
+    const int tw = nx + n_levels * F, stride = tw | 1, c0 = col_off - nx;
+    const int64_t s0 = (int64_t)blockIdx.x * ROWS_TILE;
+    const int r = threadIdx.x & (ROWS_TILE - 1), half = threadIdx.x / ROWS_TILE;   // two threads per sample
+    const int64_t s = s0 + r;
+    using V = typename Feat<F>::T;
+    if (s < n) {
+        float *row = s_tile + r * stride;
+        if (write_xyz && half == 0) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) row[d] = x[3 * s + d] * xyz_scale + xyz_offset;
+        }
+        for (int l = half; l < n_levels; l += THREADS / ROWS_TILE) {
+            V v;
+            float *vf = reinterpret_cast<float *>(&v);
+            if (l < n_active) {
+                v = reinterpret_cast<const V *>(planes)[(int64_t)l * n + s];
+            } else {
+#pragma unroll
+                for (int f = 0; f < F; ++f) vf[f] = 0.0f;
+            }
+#pragma unroll
+            for (int f = 0; f < F; ++f) row[nx + l * F + f] = vf[f];
+        }
+    }
+    __syncthreads();
+    const int rows = (int)min((int64_t)ROWS_TILE, n - s0);
+    const int total = rows * tw;
+    // i / tw without an integer division: (i + 0.5) / tw is at least 0.5 / tw from an integer and i < 2^15
+    const float inv_tw = 1.0f / (float)tw;
+    for (int i = threadIdx.x; i < total; i += THREADS) {
+        const int rr = (int)(((float)i + 0.5f) * inv_tw), c = i - rr * tw;
+        out[(s0 + rr) * ld_out + c0 + c] = s_tile[rr * stride + c];
+    }
+}
+
 // Backward scatter.  RUNS: lanes whose neighbours target the same table entry (the FD taps of one
 // sample, or consecutive samples of a ray at a coarse level) first combine their contributions with
 // a segmented wave scan; only the last lane of each run issues the atomic.  Atomic traffic is the
@@ -222,6 +319,57 @@ int rsdf_hashgrid_fwd(const float *x, const float *table, const rsdf_grid_meta *
     case 1: hashgrid_fwd_kernel<1><<<grid, THREADS, 0, st>>>(x, table, *meta, n, L, n_active_levels, out, ld_out, col_off, write_xyz, xyz_scale, xyz_offset); break;
     case 2: hashgrid_fwd_kernel<2><<<grid, THREADS, 0, st>>>(x, table, *meta, n, L, n_active_levels, out, ld_out, col_off, write_xyz, xyz_scale, xyz_offset); break;
     default: hashgrid_fwd_kernel<4><<<grid, THREADS, 0, st>>>(x, table, *meta, n, L, n_active_levels, out, ld_out, col_off, write_xyz, xyz_scale, xyz_offset); break;
+    }
+    RSDF_RETURN_LAUNCH();
+}
+
+int64_t rsdf_hashgrid_fwd_staged_scratch_bytes(const rsdf_grid_meta *meta, int64_t n, int n_active_levels)
+{
+    if (!meta || n < 0) return -1;
+    const int L = (int)meta->n_levels, F = (int)meta->n_features;
+    if (n_active_levels < 0 || n_active_levels > L) n_active_levels = L;
+    return (int64_t)n_active_levels * n * F * (int64_t)sizeof(float);
+}
+
+int rsdf_hashgrid_fwd_staged(const float *x, const float *table, const rsdf_grid_meta *meta, int64_t n,
+                             int n_active_levels, float *out, int ld_out, int col_off, int write_xyz,
+                             float xyz_scale, float xyz_offset, void *scratch, int64_t scratch_bytes, void *stream)
+{
+    RSDF_CHECK_ARG(meta != nullptr, "hashgrid_fwd_staged: meta is NULL");
+    const int L = (int)meta->n_levels, F = (int)meta->n_features;
+    RSDF_CHECK_ARG(F == 1 || F == 2 || F == 4, "hashgrid_fwd_staged: n_features must be 1, 2 or 4");
+    RSDF_CHECK_ARG(ld_out >= col_off + L * F, "hashgrid_fwd_staged: ld_out too small");
+    RSDF_CHECK_ARG(!write_xyz || col_off == 3, "hashgrid_fwd_staged: write_xyz needs col_off == 3");
+    if (n <= 0) return 0;
+    if (n_active_levels < 0 || n_active_levels > L) n_active_levels = L;
+    RSDF_CHECK_ARG(scratch_bytes >= rsdf_hashgrid_fwd_staged_scratch_bytes(meta, n, n_active_levels) &&
+                       (scratch != nullptr || n_active_levels == 0),
+                   "hashgrid_fwd_staged: scratch too small");
+    RSDF_CHECK_ARG((uint64_t)rsdf_blocks(n, THREADS) * THREADS < (1ull << 32),
+                   "hashgrid_fwd_staged: too many points for one launch");
+    hipStream_t st = (hipStream_t)stream;
+    float *planes = static_cast<float *>(scratch);
+    if (n_active_levels > 0) {
+        const dim3 grid(rsdf_blocks(n, THREADS), n_active_levels);
+        switch (F) {
+        case 1: hashgrid_fwd_planes_kernel<1><<<grid, THREADS, 0, st>>>(x, table, *meta, n, planes); break;
+        case 2: hashgrid_fwd_planes_kernel<2><<<grid, THREADS, 0, st>>>(x, table, *meta, n, planes); break;
+        default: hashgrid_fwd_planes_kernel<4><<<grid, THREADS, 0, st>>>(x, table, *meta, n, planes); break;
+        }
+    }
+    const int tw = (write_xyz ? 3 : 0) + L * F;
+    const size_t lds = (size_t)ROWS_TILE * (tw | 1) * sizeof(float);
+    const unsigned tiles = rsdf_blocks(n, ROWS_TILE);
+    if (lds > 48 * 1024) {   // 32 levels of 4 features: 67 KB
+        const void *k = F == 1 ? reinterpret_cast<const void *>(planes_to_rows_kernel<1>)
+                      : F == 2 ? reinterpret_cast<const void *>(planes_to_rows_kernel<2>)
+                               : reinterpret_cast<const void *>(planes_to_rows_kernel<4>);
+        if (int rc = rsdf_func_lds(k, lds)) return rc;
+    }
+    switch (F) {
+    case 1: planes_to_rows_kernel<1><<<tiles, THREADS, lds, st>>>(planes, x, n, L, n_active_levels, out, ld_out, col_off, write_xyz, xyz_scale, xyz_offset); break;
+    case 2: planes_to_rows_kernel<2><<<tiles, THREADS, lds, st>>>(planes, x, n, L, n_active_levels, out, ld_out, col_off, write_xyz, xyz_scale, xyz_offset); break;
+    default: planes_to_rows_kernel<4><<<tiles, THREADS, lds, st>>>(planes, x, n, L, n_active_levels, out, ld_out, col_off, write_xyz, xyz_scale, xyz_offset); break;
     }
     RSDF_RETURN_LAUNCH();
 }

@@ -338,9 +338,18 @@ class _HashGrid(torch.autograd.Function):
                 out[:, :3] = xf * xyz_scale + xyz_offset
         else:
             out = torch.empty(n, col + LF, dtype=torch.float32, device=xf.device)
-            check(lib().rsdf_hashgrid_fwd(ptr(xf), ptr(tb), ctypes.byref(meta), n, n_active, ptr(out),
-                                          col + LF, col, int(include_xyz), float(xyz_scale),
-                                          float(xyz_offset), stream_ptr()), "hashgrid_fwd")
+            if _use_staged_gather(n):
+                # large batches: level-major planes, then rows through LDS (bit-identical)
+                nbytes = int(lib().rsdf_hashgrid_fwd_staged_scratch_bytes(ctypes.byref(meta), n, n_active))
+                scratch = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=xf.device)
+                check(lib().rsdf_hashgrid_fwd_staged(ptr(xf), ptr(tb), ctypes.byref(meta), n, n_active, ptr(out),
+                                                     col + LF, col, int(include_xyz), float(xyz_scale),
+                                                     float(xyz_offset), ptr(scratch), nbytes, stream_ptr()),
+                      "hashgrid_fwd_staged")
+            else:
+                check(lib().rsdf_hashgrid_fwd(ptr(xf), ptr(tb), ctypes.byref(meta), n, n_active, ptr(out),
+                                              col + LF, col, int(include_xyz), float(xyz_scale),
+                                              float(xyz_offset), stream_ptr()), "hashgrid_fwd")
         ctx.save_for_backward(x if x.requires_grad else xf)
         ctx.meta, ctx.n_active, ctx.col, ctx.n_params = meta, n_active, col, tb.numel()
         ctx.fd7, ctx.xyz_scale = fd7_eps_unit, float(xyz_scale)
@@ -386,6 +395,16 @@ class _HashGrid(torch.autograd.Function):
 
 
 BINNED_SCATTER_MIN_POINTS = 16384
+STAGED_GATHER_MIN_POINTS = 1 << 18
+
+
+def _use_staged_gather(n):
+    """rsdf_hashgrid_fwd_staged from 2^18 points up (below that a level's table is not re-used enough to matter and the
+    second launch costs more than it saves); RSDF_GATHER=rows / staged forces either form for A/B."""
+    mode = os.environ.get("RSDF_GATHER")
+    if mode == "staged":
+        return n > 0
+    return mode != "rows" and n >= STAGED_GATHER_MIN_POINTS
 
 
 def _scatter_binned(mode, xf, g, ld, col, gd, meta, n_active, dt):

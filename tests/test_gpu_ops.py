@@ -211,6 +211,47 @@ def test_hashgrid_forward_bit_exact(dev, ops, gi):
     assert torch.equal(out2.cpu(), ref2)
 
 
+def _entry_points_of(fn):
+    """(fn(), the set of C-ABI entry points it launched)."""
+    from rise_sdf_amd import _lib
+    timer = _lib.KernelTimer()
+    _lib.set_timer(timer)
+    try:
+        out = fn()
+    finally:
+        _lib.set_timer(None)
+    return out, {r[0] for r in timer.records}
+
+
+@pytest.mark.parametrize("gi", [0, 1])
+@pytest.mark.parametrize("n", [1, 127, 5000, (1 << 18) + 77])
+def test_hashgrid_forward_staged_bit_exact(dev, ops, gi, n, monkeypatch):
+    """rsdf_hashgrid_fwd_staged (level-major planes + rows through LDS; what large batches take) writes the rows of
+    rsdf_hashgrid_fwd bit for bit: plain, with the progressive mask + include_xyz, ragged tile ends; and the oracle's
+    values where the oracle is cheap."""
+    from rise_sdf_amd import _lib
+    cfg = GRIDS[gi]
+    meta_o, n_params = oracle.grid_meta(**cfg)
+    meta_g, _ = _lib.make_grid_meta(**cfg)
+    g = torch.Generator().manual_seed(13)
+    table = ((torch.rand(n_params, generator=g) * 2 - 1) * 1e-4).to(dev)
+    x = torch.rand(n, 3, generator=g)
+    x[:1] = torch.tensor([[1.0, 0.0, 1.0]])
+    xd = x.to(dev)
+    for kw in (dict(), dict(n_active_levels=3, include_xyz=True), dict(n_active_levels=0, include_xyz=True)):
+        monkeypatch.setenv("RSDF_GATHER", "rows")
+        rows = ops.hashgrid_encode(xd, table, meta_g, **kw)
+        monkeypatch.setenv("RSDF_GATHER", "staged")
+        staged, calls = _entry_points_of(lambda: ops.hashgrid_encode(xd, table, meta_g, **kw))
+        assert calls == {"rsdf_hashgrid_fwd_staged"}
+        assert torch.equal(staged, rows), kw
+    monkeypatch.delenv("RSDF_GATHER")
+    out, calls = _entry_points_of(lambda: ops.hashgrid_encode(xd, table, meta_g))
+    assert calls == ({"rsdf_hashgrid_fwd_staged"} if n >= 1 << 18 else {"rsdf_hashgrid_fwd"})   # the default's threshold
+    if n <= 5000:
+        assert torch.equal(out.cpu(), oracle.hashgrid_encode(x, table.cpu(), meta_o))
+
+
 @pytest.mark.parametrize("gi", [0, 1])
 def test_hashgrid_backward(dev, ops, gi):
     from rise_sdf_amd import _lib
