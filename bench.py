@@ -289,7 +289,8 @@ def generic_gather_probe(model, rays, jitter, chunk):
     gbs = n * 1164 / (ms / 1e3) / 1e9
     return {"bound": "hbm", "evals": n, "avg_launch_ms": round(ms, 3), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "evals_per_sec": n / (ms / 1e3),
-            "note": "generic per-point gather, 1164 algorithmic B per evaluation, centre points of one 32768-ray chunk"}
+            "note": f"generic per-point gather (rsdf_hashgrid_fwd_staged at this size), 1164 algorithmic B per evaluation, "
+                    f"centre points of one {chunk}-ray chunk"}
 
 
 def attach_traffic(roof, path):

@@ -145,6 +145,7 @@ hashgrid_fwd_planes_kernel(const float *__restrict__ x, const float *__restrict_
 #pragma unroll
         for (int f = 0; f < F; ++f) af[f] = fmaf(wc[c], vf[f], af[f]);
     }
+    // (plain loads and stores: non-temporal hints on x and on the planes made the pass 5 % slower)
     reinterpret_cast<V *>(planes)[(int64_t)l * n + s] = acc;
 }
 
@@ -323,12 +324,28 @@ int rsdf_hashgrid_fwd(const float *x, const float *table, const rsdf_grid_meta *
     RSDF_RETURN_LAUNCH();
 }
 
+// points per pass of the staged gather: x (12 B per point) is read once per level and the planes once by the rows
+// kernel, so a pass is sized for both to stay in the 256 MB MALL beside the table (tools/bench_gather.py, 15 M points:
+// 1 M per pass 2.73e9 evaluations/s, 2 M 2.77, 4 M 2.87, 8 M 2.89, one pass 2.56)
+#ifndef RSDF_STAGED_BATCH
+#define RSDF_STAGED_BATCH (1 << 22)
+#endif
+static int64_t staged_batch()
+{
+    static const int64_t b = [] {
+        const char *e = getenv("RSDF_STAGED_BATCH");
+        const long long v = e ? atoll(e) : 0;
+        return (int64_t)(v > 0 ? v : RSDF_STAGED_BATCH);
+    }();
+    return b;
+}
+
 int64_t rsdf_hashgrid_fwd_staged_scratch_bytes(const rsdf_grid_meta *meta, int64_t n, int n_active_levels)
 {
     if (!meta || n < 0) return -1;
     const int L = (int)meta->n_levels, F = (int)meta->n_features;
     if (n_active_levels < 0 || n_active_levels > L) n_active_levels = L;
-    return (int64_t)n_active_levels * n * F * (int64_t)sizeof(float);
+    return (int64_t)n_active_levels * std::min(n, staged_batch()) * F * (int64_t)sizeof(float);
 }
 
 int rsdf_hashgrid_fwd_staged(const float *x, const float *table, const rsdf_grid_meta *meta, int64_t n,
@@ -345,31 +362,35 @@ int rsdf_hashgrid_fwd_staged(const float *x, const float *table, const rsdf_grid
     RSDF_CHECK_ARG(scratch_bytes >= rsdf_hashgrid_fwd_staged_scratch_bytes(meta, n, n_active_levels) &&
                        (scratch != nullptr || n_active_levels == 0),
                    "hashgrid_fwd_staged: scratch too small");
-    RSDF_CHECK_ARG((uint64_t)rsdf_blocks(n, THREADS) * THREADS < (1ull << 32),
-                   "hashgrid_fwd_staged: too many points for one launch");
     hipStream_t st = (hipStream_t)stream;
     float *planes = static_cast<float *>(scratch);
-    if (n_active_levels > 0) {
-        const dim3 grid(rsdf_blocks(n, THREADS), n_active_levels);
-        switch (F) {
-        case 1: hashgrid_fwd_planes_kernel<1><<<grid, THREADS, 0, st>>>(x, table, *meta, n, planes); break;
-        case 2: hashgrid_fwd_planes_kernel<2><<<grid, THREADS, 0, st>>>(x, table, *meta, n, planes); break;
-        default: hashgrid_fwd_planes_kernel<4><<<grid, THREADS, 0, st>>>(x, table, *meta, n, planes); break;
-        }
-    }
     const int tw = (write_xyz ? 3 : 0) + L * F;
     const size_t lds = (size_t)ROWS_TILE * (tw | 1) * sizeof(float);
-    const unsigned tiles = rsdf_blocks(n, ROWS_TILE);
     if (lds > 48 * 1024) {   // 32 levels of 4 features: 67 KB
         const void *k = F == 1 ? reinterpret_cast<const void *>(planes_to_rows_kernel<1>)
                       : F == 2 ? reinterpret_cast<const void *>(planes_to_rows_kernel<2>)
                                : reinterpret_cast<const void *>(planes_to_rows_kernel<4>);
         if (int rc = rsdf_func_lds(k, lds)) return rc;
     }
-    switch (F) {
-    case 1: planes_to_rows_kernel<1><<<tiles, THREADS, lds, st>>>(planes, x, n, L, n_active_levels, out, ld_out, col_off, write_xyz, xyz_scale, xyz_offset); break;
-    case 2: planes_to_rows_kernel<2><<<tiles, THREADS, lds, st>>>(planes, x, n, L, n_active_levels, out, ld_out, col_off, write_xyz, xyz_scale, xyz_offset); break;
-    default: planes_to_rows_kernel<4><<<tiles, THREADS, lds, st>>>(planes, x, n, L, n_active_levels, out, ld_out, col_off, write_xyz, xyz_scale, xyz_offset); break;
+    const int64_t batch = staged_batch();
+    for (int64_t b0 = 0; b0 < n; b0 += batch) {
+        const int64_t nb = std::min(batch, n - b0);
+        const float *xb = x + 3 * b0;
+        float *ob = out + b0 * ld_out;
+        if (n_active_levels > 0) {
+            const dim3 grid(rsdf_blocks(nb, THREADS), n_active_levels);
+            switch (F) {
+            case 1: hashgrid_fwd_planes_kernel<1><<<grid, THREADS, 0, st>>>(xb, table, *meta, nb, planes); break;
+            case 2: hashgrid_fwd_planes_kernel<2><<<grid, THREADS, 0, st>>>(xb, table, *meta, nb, planes); break;
+            default: hashgrid_fwd_planes_kernel<4><<<grid, THREADS, 0, st>>>(xb, table, *meta, nb, planes); break;
+            }
+        }
+        const unsigned tiles = rsdf_blocks(nb, ROWS_TILE);
+        switch (F) {
+        case 1: planes_to_rows_kernel<1><<<tiles, THREADS, lds, st>>>(planes, xb, nb, L, n_active_levels, ob, ld_out, col_off, write_xyz, xyz_scale, xyz_offset); break;
+        case 2: planes_to_rows_kernel<2><<<tiles, THREADS, lds, st>>>(planes, xb, nb, L, n_active_levels, ob, ld_out, col_off, write_xyz, xyz_scale, xyz_offset); break;
+        default: planes_to_rows_kernel<4><<<tiles, THREADS, lds, st>>>(planes, xb, nb, L, n_active_levels, ob, ld_out, col_off, write_xyz, xyz_scale, xyz_offset); break;
+        }
     }
     RSDF_RETURN_LAUNCH();
 }

@@ -7,7 +7,7 @@ namespace {
 struct LevelInfo {
     float scale;
     uint32_t res, offset, size;
-    bool dense;
+    bool dense, pow2;
 };
 
 __device__ __forceinline__ LevelInfo level_info(const rsdf_grid_meta &m, int l)
@@ -18,14 +18,26 @@ __device__ __forceinline__ LevelInfo level_info(const rsdf_grid_meta &m, int l)
     li.offset = m.offset[l];
     li.size = m.size[l];
     li.dense = (uint64_t)li.res * li.res * li.res <= (uint64_t)li.size;
+    li.pow2 = (li.size & (li.size - 1u)) == 0u;
     return li;
 }
 
 __device__ __forceinline__ uint32_t grid_index(uint32_t x, uint32_t y, uint32_t z, const LevelInfo &li)
 {
-    uint32_t idx = li.dense ? (x + y * li.res + z * li.res * li.res)
-                            : ((x * 1u) ^ (y * 2654435761u) ^ (z * 805459861u));
-    return idx % li.size;
+    // idx % size without the 32-bit division where it can be avoided (8 of them per point and level were half of the
+    // generic gather's vector instructions): same value in every case
+    if (li.dense) {
+        // corners of points in [0,1] give idx < size (1 + 1/res + 1/res^2): one conditional subtraction; anything else
+        // (out-of-range input) takes the division
+        uint32_t idx = x + y * li.res + z * li.res * li.res;
+        if (idx >= li.size) {
+            idx -= li.size;
+            if (idx >= li.size) idx %= li.size;
+        }
+        return idx;
+    }
+    const uint32_t idx = (x * 1u) ^ (y * 2654435761u) ^ (z * 805459861u);
+    return li.pow2 ? (idx & (li.size - 1u)) : idx % li.size;   // hashed levels hold 2^log2_hashmap_size entries
 }
 
 

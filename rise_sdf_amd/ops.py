@@ -395,12 +395,12 @@ class _HashGrid(torch.autograd.Function):
 
 
 BINNED_SCATTER_MIN_POINTS = 16384
-STAGED_GATHER_MIN_POINTS = 1 << 18
+STAGED_GATHER_MIN_POINTS = 1 << 15
 
 
 def _use_staged_gather(n):
-    """rsdf_hashgrid_fwd_staged from 2^18 points up (below that a level's table is not re-used enough to matter and the
-    second launch costs more than it saves); RSDF_GATHER=rows / staged forces either form for A/B."""
+    """rsdf_hashgrid_fwd_staged from 2^15 points up (tools/bench_gather.py: ahead from 65536 points, the smallest size
+    measured; below that both forms are launch latency); RSDF_GATHER=rows / staged forces either form for A/B."""
     mode = os.environ.get("RSDF_GATHER")
     if mode == "staged":
         return n > 0

@@ -224,7 +224,7 @@ def _entry_points_of(fn):
 
 
 @pytest.mark.parametrize("gi", [0, 1])
-@pytest.mark.parametrize("n", [1, 127, 5000, (1 << 18) + 77])
+@pytest.mark.parametrize("n", [1, 127, 5000, (1 << 15) + 77])
 def test_hashgrid_forward_staged_bit_exact(dev, ops, gi, n, monkeypatch):
     """rsdf_hashgrid_fwd_staged (level-major planes + rows through LDS; what large batches take) writes the rows of
     rsdf_hashgrid_fwd bit for bit: plain, with the progressive mask + include_xyz, ragged tile ends; and the oracle's
@@ -247,9 +247,23 @@ def test_hashgrid_forward_staged_bit_exact(dev, ops, gi, n, monkeypatch):
         assert torch.equal(staged, rows), kw
     monkeypatch.delenv("RSDF_GATHER")
     out, calls = _entry_points_of(lambda: ops.hashgrid_encode(xd, table, meta_g))
-    assert calls == ({"rsdf_hashgrid_fwd_staged"} if n >= 1 << 18 else {"rsdf_hashgrid_fwd"})   # the default's threshold
+    assert calls == ({"rsdf_hashgrid_fwd_staged"} if n >= 1 << 15 else {"rsdf_hashgrid_fwd"})   # the default's threshold
     if n <= 5000:
         assert torch.equal(out.cpu(), oracle.hashgrid_encode(x, table.cpu(), meta_o))
+
+
+def test_hashgrid_forward_staged_several_passes(dev, ops, monkeypatch):
+    """More points than one pass of the staged gather holds (2^22): the passes' rows join up bit for bit."""
+    from rise_sdf_amd import _lib
+    meta_g, n_params = _lib.make_grid_meta(**GRIDS[1])
+    g = torch.Generator().manual_seed(14)
+    table = ((torch.rand(n_params, generator=g) * 2 - 1) * 1e-4).to(dev)
+    x = torch.rand((1 << 22) + 333, 3, generator=g).to(dev)
+    monkeypatch.setenv("RSDF_GATHER", "rows")
+    rows = ops.hashgrid_encode(x, table, meta_g, include_xyz=True)
+    monkeypatch.setenv("RSDF_GATHER", "staged")
+    staged = ops.hashgrid_encode(x, table, meta_g, include_xyz=True)
+    assert torch.equal(staged, rows)
 
 
 @pytest.mark.parametrize("gi", [0, 1])
