@@ -17,7 +17,8 @@
 //   1. PRODUCE: one thread per (sample, level) merges the taps' contributions in registers into
 //      the same 8..32 corners, bins the (entry, value) records by table slice (<= 8192 entries, one
 //      LDS image), counting-sorts them by bin inside the workgroup through LDS and appends each bin's
-//      run to its queue in HBM with coalesced 12-byte stores.
+//      run to its queue in HBM as 20-byte elements of two records (10 bytes per record: inside a bin an
+//      entry needs 13 bits).
 //   2. REDUCE: one workgroup per (level, bin, split) streams its queue (4 records in flight per
 //      thread), accumulates into a 128 KiB fp64 LDS image with ds_add_f64 (measured 18x the rate of
 //      ds_add_f32 on gfx950, tools/lds_atomic_bench.hip) and adds the image to dtable
@@ -56,17 +57,26 @@ constexpr int STAGE_CAP = P_THREADS * RSDF_STAGE_RECS;
 constexpr int R_THREADS = 1024;  // reducer
 constexpr int R_UNROLL = 4;
 
-struct Record {
+struct Record {   // LDS staging form
     uint32_t idx;  // entry index within the level
     float v0, v1;
 };
+// Queue form (round 3): TWO contributions of one bin per 20-byte element.  Inside a bin an entry needs 13 bits, so the
+// two indices share a dword: 10 bytes per contribution instead of 12 (the queues are 2/3 of this backward's HBM traffic).
+// A (bin, round) run with an odd record count ends in a half-empty element (e1 == PAIR_NONE).
+struct PairRec {
+    uint32_t e;    // entry within the bin: first contribution bits 0..15, second 16..31
+    float a0, a1, b0, b1;
+};
+constexpr uint32_t PAIR_NONE = 0xffffu;
+constexpr uint32_t PAD_IDX = 0xffffffffu;   // staging slot that pads a run to an even length
 
 struct LevelPlan {
     int count;                       // active levels
     int n_bins[RSDF_MAX_LEVELS];
     int interleaved[RSDF_MAX_LEVELS];  // 0: bin = idx >> 13 (hashed levels); k > 0: n_bins = 2^(k-1), bin = idx & (n_bins-1)
     int n_split[RSDF_MAX_LEVELS];      // reducer workgroups per bin (balances the per-level load)
-    int64_t cap[RSDF_MAX_LEVELS];      // records per bin queue
+    int64_t cap[RSDF_MAX_LEVELS];      // queue elements (record PAIRS) per bin
     int64_t queue_off[RSDF_MAX_LEVELS];
     int counter_off[RSDF_MAX_LEVELS];
 };
@@ -244,8 +254,8 @@ __device__ __forceinline__ void load_stencil(const TapSrc &src, int64_t S, int64
 #define RSDF_FWD_GROUP 4096
 #endif
 #ifndef RSDF_BWD_GROUP
-#define RSDF_BWD_GROUP 256
-#endif
+#define RSDF_BWD_GROUP 64      // producer: 64 x 1024 samples (0.8 MB of centres) per group: the 15 re-reads of a group's centres hit
+#endif                         // in the XCD's L2 (256: they come back from the MALL, +150 B per sample of fetch traffic; same time)
 template <bool DERIVE>
 __device__ __forceinline__ void fd7_fwd_sample(const TapSrc &src, const float2 *__restrict__ tl,
                                                const LevelGeom &g, int64_t S, int64_t s, int l,
@@ -374,10 +384,22 @@ __device__ __forceinline__ int bin_of(uint32_t idx, int n_bins, int interleaved)
     return interleaved ? (int)(idx & (uint32_t)(n_bins - 1)) : (int)(idx >> BIN_SHIFT);   // no division on this path
 }
 
-__device__ __forceinline__ void emit_round(const uint32_t (&ridx)[ROUND_RECS],
+__device__ __forceinline__ uint32_t entry_of(uint32_t idx, int interleaved)
+{
+    return interleaved ? idx >> (interleaved - 1) : (idx & (uint32_t)(BIN_ENTRIES - 1));
+}
+
+// ridx is clobbered: a record's rank within its bin (< 8192: 13 bits) rides in the upper bits of its entry index (< 2^19:
+// make_plan admits at most MAX_BINS * BIN_ENTRIES entries per level) -- eight registers less across the barriers, in a
+// kernel that is held to 64 registers by its occupancy
+constexpr int IDX_BITS = 19;
+static_assert((1u << IDX_BITS) == (unsigned)MAX_BINS * BIN_ENTRIES, "entry index + rank must fit 32 bits");
+constexpr uint32_t IDX_MASK = (1u << IDX_BITS) - 1u;
+
+__device__ __forceinline__ void emit_round(uint32_t (&ridx)[ROUND_RECS],
                                            const float2 (&rval)[ROUND_RECS], uint32_t valid_mask,
                                            int n_bins, int interleaved, int64_t cap,
-                                           Record *__restrict__ queue, int *__restrict__ qcount,
+                                           PairRec *__restrict__ queue, int *__restrict__ qcount,
                                            float *__restrict__ dlevel, int *s_cnt, int *s_off,
                                            int *s_gbase, Record *s_stage, StamperP &stp)
 {
@@ -388,57 +410,68 @@ __device__ __forceinline__ void emit_round(const uint32_t (&ridx)[ROUND_RECS],
     // s_gbase) runs after its barrier A, and its stage writes after its barrier B, both of which
     // every thread reaches only after finishing this copy-out.
     const int tid = threadIdx.x;
-    int slot[ROUND_RECS];   // rank within the bin
 #pragma unroll
-    for (int r = 0; r < ROUND_RECS; ++r) {
-        slot[r] = 0;
-        if (valid_mask & (1u << r)) slot[r] = atomicAdd(&s_cnt[bin_of(ridx[r], n_bins, interleaved)], 1);
-    }
+    for (int r = 0; r < ROUND_RECS; ++r)
+        if (valid_mask & (1u << r))
+            ridx[r] |= (uint32_t)atomicAdd(&s_cnt[bin_of(ridx[r], n_bins, interleaved)], 1) << IDX_BITS;
     RSDF_PSTAMP(stp, 4);   // slot atomics
     __syncthreads();  // A
     RSDF_PSTAMP(stp, 5);   // barrier A
-    // First wavefront: exclusive scan of the bin counts + queue reservations.  The reservation is a RETURNING global
+    // First wavefront: exclusive scan of the bin counts + queue reservations.  Every bin's run is padded to an EVEN length
+    // in the staging order, so that records 2 p, 2 p + 1 of the staging buffer always belong to one bin (or the second is
+    // the pad) and a staging-pass boundary never splits a pair.  The reservation is a RETURNING global
     // atomic (~1-2 us under load); its result is only needed by the copy-out, so it is parked in a register here and
     // published to s_gbase after this wave has staged its own records: the round trip overlaps barrier B and the staging
     // instead of holding all sixteen waves at B.
-    int gbase = 0;
+    int gbase = 0, padpos = -1;
     if (tid < 64) {
         const int c = tid < n_bins ? s_cnt[tid] : 0;
-        const int incl = wave_incl_sum_i(c);
+        const int cp = (c + 1) & ~1;
+        const int incl = wave_incl_sum_i(cp);
         if (tid < n_bins) {
-            s_off[tid] = incl - c;
-            gbase = c > 0 ? atomicAdd(&qcount[tid], c) : 0;
+            s_off[tid] = incl - cp;
+            gbase = c > 0 ? atomicAdd(&qcount[tid], cp >> 1) : 0;
             s_cnt[tid] = 0;
+            if (c & 1) padpos = incl - 1;
         }
         if (tid == 63) s_off[MAX_BINS] = incl;
     }
     RSDF_PSTAMP(stp, 6);   // scan + queue reservation (first wave)
     __syncthreads();  // B
     RSDF_PSTAMP(stp, 7);   // barrier B
-    const int total = s_off[MAX_BINS];
+    const int total = s_off[MAX_BINS];   // even
     if (total == 0) return;  // uniform (no reservation was made: every count was zero)
     if (tid < n_bins) s_gbase[tid] = gbase;
     for (int lo = 0; lo < total; lo += STAGE_CAP) {   // uniform; bins stay contiguous: a pass boundary splits one run
-        const int n = min(total - lo, STAGE_CAP);
+        const int n = min(total - lo, STAGE_CAP);     // even
         if (lo) __syncthreads();  // D: the previous pass has left the staging buffer
 #pragma unroll
         for (int r = 0; r < ROUND_RECS; ++r)
             if (valid_mask & (1u << r)) {
-                const unsigned pos = (unsigned)(s_off[bin_of(ridx[r], n_bins, interleaved)] + slot[r] - lo);
-                if (pos < (unsigned)n) s_stage[pos] = Record{ridx[r], rval[r].x, rval[r].y};
+                const uint32_t idx = ridx[r] & IDX_MASK;
+                const unsigned pos = (unsigned)(s_off[bin_of(idx, n_bins, interleaved)] + (int)(ridx[r] >> IDX_BITS) - lo);
+                if (pos < (unsigned)n) s_stage[pos] = Record{idx, rval[r].x, rval[r].y};
             }
+        if ((unsigned)(padpos - lo) < (unsigned)n) s_stage[padpos - lo].idx = PAD_IDX;
         RSDF_PSTAMP(stp, 8);   // staging writes
         __syncthreads();  // C
         RSDF_PSTAMP(stp, 9);   // barrier C (+ D)
-        for (int i = tid; i < n; i += P_THREADS) {
-            const Record rec = s_stage[i];
-            const int b = bin_of(rec.idx, n_bins, interleaved);
-            const int64_t gpos = (int64_t)s_gbase[b] + (lo + i - s_off[b]);
+        for (int i = tid; 2 * i < n; i += P_THREADS) {
+            const Record r0 = s_stage[2 * i], r1 = s_stage[2 * i + 1];
+            const int b = bin_of(r0.idx, n_bins, interleaved);
+            const bool two = r1.idx != PAD_IDX;
+            const int64_t gpos = (int64_t)s_gbase[b] + ((lo + 2 * i - s_off[b]) >> 1);
             if (gpos < cap) {
-                queue[(int64_t)b * cap + gpos] = rec;
+                const uint32_t e1 = two ? entry_of(r1.idx, interleaved) : PAIR_NONE;
+                queue[(int64_t)b * cap + gpos] = PairRec{entry_of(r0.idx, interleaved) | (e1 << 16), r0.v0, r0.v1,
+                                                        two ? r1.v0 : 0.f, two ? r1.v1 : 0.f};
             } else {  // queue full (capacity carries slack; never drop a contribution)
-                atomicAdd(dlevel + 2 * (size_t)rec.idx, rec.v0);
-                atomicAdd(dlevel + 2 * (size_t)rec.idx + 1, rec.v1);
+                atomicAdd(dlevel + 2 * (size_t)r0.idx, r0.v0);
+                atomicAdd(dlevel + 2 * (size_t)r0.idx + 1, r0.v1);
+                if (two) {
+                    atomicAdd(dlevel + 2 * (size_t)r1.idx, r1.v0);
+                    atomicAdd(dlevel + 2 * (size_t)r1.idx + 1, r1.v1);
+                }
             }
         }
         RSDF_PSTAMP(stp, 10);  // copy-out
@@ -452,7 +485,7 @@ template <bool DERIVE>
 __global__ void __launch_bounds__(P_THREADS, RSDF_STAGE_RECS <= 4 ? 8 : 4)
 fd7_produce_kernel(const TapSrc src, const float2 *__restrict__ dplanes,
                    const rsdf_grid_meta meta, const LevelPlan plan, int64_t S, int n_active,
-                   Record *__restrict__ queues, int *__restrict__ counters,
+                   PairRec *__restrict__ queues, int *__restrict__ counters,
                    float *__restrict__ dtable)
 {
     __shared__ int s_cnt[MAX_BINS];
@@ -466,14 +499,14 @@ fd7_produce_kernel(const TapSrc src, const float2 *__restrict__ dplanes,
     __syncthreads();
 
     // 1-D grid in sample-group-major order (see the forward): all active levels of RSDF_BWD_GROUP consecutive tiles, then
-    // the next group, so that the 16 re-reads of a group's x7t (and nothing else) come from the MALL
+    // the next group, so that the re-reads of a group's stencil centres come from the L2 (RSDF_BWD_GROUP)
     const int64_t per_group = (int64_t)RSDF_BWD_GROUP * n_active;
     const int64_t grp = blockIdx.x / per_group, rem = blockIdx.x - grp * per_group;
     const int l = (int)(rem / RSDF_BWD_GROUP);
     const int64_t tile_id = grp * RSDF_BWD_GROUP + (rem - (int64_t)l * RSDF_BWD_GROUP);
     const LevelGeom g = level_geom(meta, l);
     float *dlevel = dtable + (size_t)meta.offset[l] * 2;
-    Record *queue = queues + plan.queue_off[l];
+    PairRec *queue = queues + plan.queue_off[l];
     int *qcount = counters + plan.counter_off[l];
     const int n_bins = plan.n_bins[l], interleaved = plan.interleaved[l];
     const int64_t cap = plan.cap[l];
@@ -657,7 +690,7 @@ template <int MODE>
 __global__ void __launch_bounds__(P_THREADS, RSDF_STAGE_RECS <= 4 ? 8 : 4)
 scatter_produce_kernel(const float *__restrict__ x, const float *__restrict__ dy, int ld_dy, int col_off,
                        const float *__restrict__ gdx, const rsdf_grid_meta meta, const LevelPlan plan, int64_t S,
-                       int n_active, Record *__restrict__ queues, int *__restrict__ counters, float *__restrict__ dtable)
+                       int n_active, PairRec *__restrict__ queues, int *__restrict__ counters, float *__restrict__ dtable)
 {
     __shared__ int s_cnt[MAX_BINS];
     __shared__ int s_off[MAX_BINS + 1];
@@ -671,7 +704,7 @@ scatter_produce_kernel(const float *__restrict__ x, const float *__restrict__ dy
     const int64_t tile_id = grp * RSDF_BWD_GROUP + (rem - (int64_t)l * RSDF_BWD_GROUP);
     const LevelGeom g = level_geom(meta, l);
     float *dlevel = dtable + (size_t)meta.offset[l] * 2;
-    Record *queue = queues + plan.queue_off[l];
+    PairRec *queue = queues + plan.queue_off[l];
     int *qcount = counters + plan.counter_off[l];
     const int n_bins = plan.n_bins[l], interleaved = plan.interleaved[l];
     const int64_t cap = plan.cap[l];
@@ -751,7 +784,7 @@ scatter_produce_kernel(const float *__restrict__ x, const float *__restrict__ dy
 // backward: reduce
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(R_THREADS)
-fd7_reduce_kernel(const rsdf_grid_meta meta, const LevelPlan plan, const Record *__restrict__ queues,
+fd7_reduce_kernel(const rsdf_grid_meta meta, const LevelPlan plan, const PairRec *__restrict__ queues,
                   const int *__restrict__ counters, float *__restrict__ dtable)
 {
     extern __shared__ __attribute__((aligned(16))) double s_acc[];  // [BIN_ENTRIES][2], fp64: see below
@@ -777,21 +810,24 @@ fd7_reduce_kernel(const rsdf_grid_meta meta, const LevelPlan plan, const Record 
 
     for (int i = threadIdx.x; i < entries * 2; i += R_THREADS) s_acc[i] = 0.0;
     __syncthreads();
-    const Record *q = queues + plan.queue_off[l] + (int64_t)b * cap;
+    const PairRec *q = queues + plan.queue_off[l] + (int64_t)b * cap;
     for (int64_t i0 = r0 + threadIdx.x; i0 < r1; i0 += (int64_t)R_THREADS * R_UNROLL) {
-        Record rec[R_UNROLL];
+        PairRec rec[R_UNROLL];
 #pragma unroll
         for (int u = 0; u < R_UNROLL; ++u) {
             const int64_t i = i0 + (int64_t)u * R_THREADS;
-            rec[u] = i < r1 ? q[i] : Record{0u, 0.f, 0.f};
+            rec[u] = i < r1 ? q[i] : PairRec{0u, 0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int u = 0; u < R_UNROLL; ++u) {
             if (i0 + (int64_t)u * R_THREADS < r1) {
-                const uint32_t e = interleaved ? rec[u].idx >> lg
-                                               : (rec[u].idx & (uint32_t)(BIN_ENTRIES - 1));
-                atomicAdd(&s_acc[2 * e], (double)rec[u].v0);
-                atomicAdd(&s_acc[2 * e + 1], (double)rec[u].v1);
+                const uint32_t e0 = rec[u].e & 0xffffu, e1 = rec[u].e >> 16;   // entries within the bin (the producer's entry_of)
+                atomicAdd(&s_acc[2 * e0], (double)rec[u].a0);
+                atomicAdd(&s_acc[2 * e0 + 1], (double)rec[u].a1);
+                if (e1 != PAIR_NONE) {
+                    atomicAdd(&s_acc[2 * e1], (double)rec[u].b0);
+                    atomicAdd(&s_acc[2 * e1 + 1], (double)rec[u].b1);
+                }
             }
         }
     }
@@ -853,7 +889,9 @@ int make_plan(const rsdf_grid_meta *meta, int64_t S, int n_active, float eps_uni
             return 1.0;
         }();
         const double qscale = qscale_env;
-        plan->cap[l] = qscale < 1.0 ? (int64_t)(per_bin * qscale) + 64 : (int64_t)(per_bin * 1.15) + 16384;
+        // queue elements hold two records; a (workgroup, round, bin) run of odd length leaves half an element unused
+        // (< 1 % at the fine levels, covered by the slack)
+        plan->cap[l] = (qscale < 1.0 ? (int64_t)(per_bin * qscale) + 64 : (int64_t)(per_bin * 1.15) + 16384) / 2 + 1;
         int ns = (int)(per_bin / per_wg + 0.999);
         plan->n_split[l] = ns < 1 ? 1 : (ns > 256 ? 256 : ns);
         plan->queue_off[l] = qoff;
@@ -869,7 +907,7 @@ int make_plan(const rsdf_grid_meta *meta, int64_t S, int n_active, float eps_uni
 int64_t scratch_need(int64_t n_rec, int n_cnt)
 {
     const int64_t cbytes = (((int64_t)n_cnt * (int64_t)sizeof(int)) + 255) / 256 * 256;
-    return cbytes + n_rec * (int64_t)sizeof(Record) + 256;
+    return cbytes + n_rec * (int64_t)sizeof(PairRec) + 256;
 }
 
 }  // namespace
@@ -915,7 +953,7 @@ int launch_fwd(const TapSrc &src, const float *table, const rsdf_grid_meta *meta
 
 template <bool DERIVE>
 void launch_produce(dim3 grid, size_t stage_bytes, hipStream_t st, const TapSrc &src, const float2 *dplanes,
-                    const rsdf_grid_meta &meta, const LevelPlan &plan, int64_t n_samples, int na, Record *queues,
+                    const rsdf_grid_meta &meta, const LevelPlan &plan, int64_t n_samples, int na, PairRec *queues,
                     int *counters, float *dtable, int dev)
 {
     static thread_local unsigned long long attr_set = 0;      // one bit per device (the attribute is per device)
@@ -947,7 +985,7 @@ int launch_bwd(const TapSrc &src, const float *dplanes, const rsdf_grid_meta *me
     hipStream_t st = (hipStream_t)stream;
     int *counters = (int *)scratch;
     const size_t cbytes = (((size_t)n_cnt * sizeof(int)) + 255) / 256 * 256;
-    Record *queues = (Record *)((char *)scratch + cbytes);
+    PairRec *queues = (PairRec *)((char *)scratch + cbytes);
     (void)hipMemsetAsync(counters, 0, cbytes, st);
     const unsigned p_tiles = (rsdf_blocks(n_samples, P_THREADS) + RSDF_BWD_GROUP - 1) / RSDF_BWD_GROUP * RSDF_BWD_GROUP;
     // HIP launches in threads: grid.x * block.x must stay below 2^32
@@ -981,7 +1019,7 @@ int launch_bwd(const TapSrc &src, const float *dplanes, const rsdf_grid_meta *me
 template <int MODE>
 void launch_scatter_produce(dim3 grid, size_t stage_bytes, hipStream_t st, const float *x, const float *dy, int ld_dy,
                             int col_off, const float *gdx, const rsdf_grid_meta &meta, const LevelPlan &plan, int64_t n,
-                            int na, Record *queues, int *counters, float *dtable)
+                            int na, PairRec *queues, int *counters, float *dtable)
 {
     (void)rsdf_func_lds(reinterpret_cast<const void *>(scatter_produce_kernel<MODE>), stage_bytes);
     scatter_produce_kernel<MODE><<<grid, P_THREADS, stage_bytes, st>>>(x, dy, ld_dy, col_off, gdx, meta, plan, n, na,
@@ -1015,7 +1053,7 @@ int rsdf_hashgrid_scatter_binned(int mode, const float *x, const float *dy, int 
     hipStream_t st = (hipStream_t)stream;
     int *counters = (int *)scratch;
     const size_t cbytes = (((size_t)n_cnt * sizeof(int)) + 255) / 256 * 256;
-    Record *queues = (Record *)((char *)scratch + cbytes);
+    PairRec *queues = (PairRec *)((char *)scratch + cbytes);
     (void)hipMemsetAsync(counters, 0, cbytes, st);
     const unsigned p_tiles = (rsdf_blocks(n, P_THREADS) + RSDF_BWD_GROUP - 1) / RSDF_BWD_GROUP * RSDF_BWD_GROUP;
     RSDF_CHECK_ARG((uint64_t)p_tiles * na * P_THREADS < (1ull << 32), "hashgrid_scatter_binned: too many points for one launch");
