@@ -142,11 +142,6 @@ bounds_kernel(int R, float cos_cutoff, float *__restrict__ bounds)
 // function (per-level times are the same whether a source texel comes from L2 per output texel or from an LDS tile
 // shared by 64 outputs: measured), so it is 9 instructions with one reciprocal (v_rcp_f32, 1 ulp); the first form,
 // |A x B|^2 / |A + B|^2 with two IEEE divisions, cost 35 per pair: 4.6 -> 3.6 (one division) -> 2.x ms per prefilter.
-#ifndef COOP_MAX_R_CFG
-#define COOP_MAX_R_CFG 256
-#endif
-constexpr int COOP_MAX_R = COOP_MAX_R_CFG;   // maps up to this resolution run one wavefront per texel
-
 __device__ __forceinline__ float ndf_ggx_pair(float a2, V3 A, V3 B)
 {
     const V3 e = v3(A.x - B.x, A.y - B.y, A.z - B.z);
@@ -156,10 +151,40 @@ __device__ __forceinline__ float ndf_ggx_pair(float a2, V3 A, V3 B)
 }
 
 // forward: out4 = [sum w c, sum w];  backward (gather): dcube[L] = area(L)/4 * sum_V g[V] (L.V) D(V.H)
-// COOP = false: one thread per texel walks its window (large maps: millions of threads).
-// COOP = true:  one wavefront per texel, the lanes stride over the window and reduce -- the coarse levels have few
-//               texels (6144 at 32^2) but windows of thousands, which a thread per texel leaves latency bound.
-template <bool BWD, bool COOP>
+// G lanes per output texel (launch_specular): 1 = a thread walks its window (large maps: millions of threads); 64 = one
+// wavefront per texel, the lanes stride over the window and reduce -- the coarse levels have few texels (6144 at 32^2) but
+// windows of thousands, which a thread per texel leaves latency bound.
+//
+// The window loops are bound by the vector instructions per (output texel, source texel) pair (measured: the same per-level
+// times with the source texels in an LDS tile).  One pair, with the cached texel table (direction + solid angle / 4 in one
+// 16-byte load): L.V, |V - L|^2 as 3 sub + mul + 2 fma, d = fma(|V - L|^2, (1 - a2) / 4, a2), one v_rcp_f32 of d^2 pi / a2, a
+// select on the cutoff and 4 accumulating fma -- the fused forms are written out because this file is built with
+// -ffp-contract=off -- and 32-bit texel indices instead of 64-bit multiply-adds per load.  The pair is branch-free (a texel
+// outside the cone gets weight 0; cc = max(cos_cutoff, 0): a texel with L.V in [cos_cutoff, 0) has weight max(L.V, 0) = 0
+// anyway), so a loop trip holds the four loads of TWO pairs in flight.  L.V is formed exactly as bounds_kernel forms it
+// (unfused, left to right), so the set of texels with a non-zero weight is the reference's.  Round 3: 512^2 1.08 -> 0.68
+// ms, 256^2 1.16 -> 1.03, 128^2 0.46 -> 0.42 per prefilter.  Measured and dropped: the two texels of a trip on packed fp32
+// instructions from a per-texel-pair table (v_pk_fma_f32 & co: 0.73 / 1.20 / 0.50 ms -- no faster than two plain
+// instructions, plus the even-x alignment of the window); 16 lanes per texel (1.10 / 0.40 at 256^2 / 128^2).
+struct PairAcc { float c0, c1, c2, wsum; };
+
+template <bool BWD>
+__device__ __forceinline__ void spec_pair(PairAcc &acc, const V3 &A, float cc, float k1, float a2, float cpi,
+                                          const float4 t, float p0, float p1, float p2)
+{
+    const float d = t.x * A.x + t.y * A.y + t.z * A.z;
+    const float ex = A.x - t.x, ey = A.y - t.y, ez = A.z - t.z;
+    const float e2 = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+    const float dd = fmaf(e2, k1, a2);                                  // sin^2 (1 - a2) + a2, sin^2 = |A - B|^2 / 4
+    const float geom = d * __builtin_amdgcn_rcpf(dd * dd * cpi);        // (L.V) a2 / (pi d^2)
+    const float w = d < cc ? 0.0f : (BWD ? geom : geom * t.w);
+    acc.c0 = fmaf(p0, w, acc.c0);
+    acc.c1 = fmaf(p1, w, acc.c1);
+    acc.c2 = fmaf(p2, w, acc.c2);
+    acc.wsum += w;
+}
+
+template <bool BWD, int G>     // G lanes per output texel: 1 or 64
 __global__ void __launch_bounds__(THREADS)
 specular_kernel(const float *__restrict__ src, int src_ch, const float *__restrict__ bounds,
                 const float4 *__restrict__ table, int R, float roughness, float cos_cutoff,
@@ -172,46 +197,80 @@ specular_kernel(const float *__restrict__ src, int src_ch, const float *__restri
         for (int i = threadIdx.x; i < R; i += THREADS) s_side[i] = area_side(i, R);
         __syncthreads();
     }
-    const int lane = threadIdx.x & 63;
-    const int idx = COOP ? blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6) : blockIdx.x * THREADS + threadIdx.x;
-    if (idx >= 6 * R * R) return;
+    const int sub = threadIdx.x & (G - 1);
+    const int idx = blockIdx.x * (THREADS / G) + threadIdx.x / G;
+    if (idx >= 6 * R * R) return;      // (uniform over the G lanes of a texel)
     const int s0 = idx / (R * R), y0 = (idx / R) % R, x0 = idx % R;
     const V3 A = cube_to_dir(x0, y0, s0, R);
     const float alpha = roughness * roughness, a2 = alpha * alpha;
-    float c0 = 0.f, c1 = 0.f, c2 = 0.f, wsum = 0.f;
+    const float k1 = 0.25f * (1.0f - a2), cpi = 3.14159265358979323846f / a2, cc = fmaxf(cos_cutoff, 0.0f);
+    PairAcc acc = {0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < 6; ++s) {
-        const float *b = bounds + (size_t)idx * 24 + s * 4;
-        const int xmin = (int)b[0], xmax = (int)b[1], ymin = (int)b[2], ymax = (int)b[3];
+        const float4 bb = *reinterpret_cast<const float4 *>(bounds + (size_t)idx * 24 + s * 4);
+        const int xmin = (int)bb.x, xmax = (int)bb.y, ymin = (int)bb.z, ymax = (int)bb.w;
         if (xmin > xmax) continue;
-        const int bw = xmax - xmin + 1, cnt = bw * (ymax - ymin + 1);
-        // i / bw without an integer division per pair (it cost more than the NDF): (i + 0.5) / bw is at least 0.5 / bw away
-        // from an integer and i < 2^18, so the float product truncates to the exact quotient
-        const float inv_bw = 1.0f / (float)bw;
-        for (int i = COOP ? lane : 0; i < cnt; i += COOP ? 64 : 1) {
-            const int yo = (int)(((float)i + 0.5f) * inv_bw);
-            const int y = ymin + yo, x = xmin + (i - yo * bw);
-            V3 B;
-            float area4;
-            if (table != nullptr) {
-                const float4 t = table[(s * R + y) * R + x];
-                B = v3(t.x, t.y, t.z);
-                area4 = t.w;
+        const int bw = xmax - xmin + 1, bh = ymax - ymin + 1;
+        if (table != nullptr) {
+            if (G == 1) {
+                for (int yo = 0; yo < bh; ++yo) {
+                    const int row = (s * R + ymin + yo) * R + xmin;       // < 6 * 4096^2 < 2^31
+                    const float4 *tr = table + row;
+                    const float *pr = src + (size_t)row * src_ch;
+                    int xo = 0;
+                    for (; xo + 1 < bw; xo += 2) {                        // two pairs per trip: four loads in flight
+                        const float4 t0 = tr[xo], t1 = tr[xo + 1];
+                        const float *q0 = pr + xo * src_ch, *q1 = q0 + src_ch;
+                        const float u0 = q0[0], u1 = q0[1], u2 = q0[2], v0 = q1[0], v1 = q1[1], v2 = q1[2];
+                        spec_pair<BWD>(acc, A, cc, k1, a2, cpi, t0, u0, u1, u2);
+                        spec_pair<BWD>(acc, A, cc, k1, a2, cpi, t1, v0, v1, v2);
+                    }
+                    if (xo < bw) {
+                        const float *q0 = pr + xo * src_ch;
+                        spec_pair<BWD>(acc, A, cc, k1, a2, cpi, tr[xo], q0[0], q0[1], q0[2]);
+                    }
+                }
             } else {
-                B = cube_to_dir(x, y, s, R);
-                area4 = s_side[x] * s_side[y] / 4.0f;
+                // i / bw without an integer division per pair: (i + 0.5) / bw is at least 0.5 / bw away from an integer and
+                // i < 2^18, so the float product truncates to the exact quotient.  (Carrying (yo, xo) from pair to pair
+                // instead was measured: slower on the small maps, whose windows are narrower than the stride of G.)
+                const float inv_bw = 1.0f / (float)bw;
+                const int cnt = bw * bh, base = (s * R + ymin) * R + xmin, wrap = R - bw;
+                auto texel = [&](int i) {
+                    const int yo = (int)(((float)i + 0.5f) * inv_bw);
+                    return base + i + (int)__mul24(yo, wrap);            // base + yo R + (i - yo bw)
+                };
+                int i = sub;
+                for (; i + G < cnt; i += 2 * G) {                         // two pairs per trip: four loads in flight
+                    const int ta = texel(i), tb = texel(i + G);
+                    const float4 t0 = table[ta], t1 = table[tb];
+                    const float *q0 = src + (size_t)ta * src_ch, *q1 = src + (size_t)tb * src_ch;
+                    const float u0 = q0[0], u1 = q0[1], u2 = q0[2], v0 = q1[0], v1 = q1[1], v2 = q1[2];
+                    spec_pair<BWD>(acc, A, cc, k1, a2, cpi, t0, u0, u1, u2);
+                    spec_pair<BWD>(acc, A, cc, k1, a2, cpi, t1, v0, v1, v2);
+                }
+                if (i < cnt) {
+                    const int ta = texel(i);
+                    const float *q0 = src + (size_t)ta * src_ch;
+                    spec_pair<BWD>(acc, A, cc, k1, a2, cpi, table[ta], q0[0], q0[1], q0[2]);
+                }
             }
-            const float d = dot3(B, A);
-            if (d < cos_cutoff) continue;
-            const float geom = fmaxf(d, 0.0f) * ndf_ggx_pair(a2, A, B);
-            const float w = BWD ? geom : geom * area4;
-            const float *p = src + (size_t)((s * R + y) * R + x) * src_ch;
-            c0 += p[0] * w; c1 += p[1] * w; c2 += p[2] * w;
-            wsum += w;
+        } else {   // no cached table: direction and solid angle per pair (API completeness; the mirrors always pass one)
+            const float inv_bw = 1.0f / (float)bw;
+            const int cnt = bw * bh;
+            for (int i = sub; i < cnt; i += G) {
+                const int yo = (int)(((float)i + 0.5f) * inv_bw);   // exact: (i + 0.5) / bw is >= 0.5 / bw from an integer
+                const int y = ymin + yo, x = xmin + (i - yo * bw);
+                const V3 B = cube_to_dir(x, y, s, R);
+                const float4 t = make_float4(B.x, B.y, B.z, s_side[x] * s_side[y] / 4.0f);
+                const float *q0 = src + (size_t)((s * R + y) * R + x) * src_ch;
+                spec_pair<BWD>(acc, A, cc, k1, a2, cpi, t, q0[0], q0[1], q0[2]);
+            }
         }
     }
-    if (COOP) {
+    float c0 = acc.c0, c1 = acc.c1, c2 = acc.c2, wsum = acc.wsum;
+    if (G > 1) {
         c0 = wave_sum(c0); c1 = wave_sum(c1); c2 = wave_sum(c2); wsum = wave_sum(wsum);
-        if (lane != 0) return;
+        if (sub != 0) return;
     }
     if (BWD) {
         const float a = table != nullptr ? table[idx].w : s_side[x0] * s_side[y0] / 4.0f;
@@ -221,6 +280,24 @@ specular_kernel(const float *__restrict__ src, int src_ch, const float *__restri
         float *o = dst + (size_t)idx * 4;
         o[0] = c0; o[1] = c1; o[2] = c2; o[3] = wsum;
     }
+}
+
+// lanes per output texel by map size: a thread per texel for the large maps (millions of threads), a wavefront per texel
+// up to 256^2 (few texels, windows of thousands; measured per level at the yaml's 512^2 light: a thread per texel takes
+// 1.9 instead of 1.0 ms at 256^2)
+#ifndef SPEC_G64_MAX_R
+#define SPEC_G64_MAX_R 256
+#endif
+template <bool BWD>
+void launch_specular(const float *src, int src_ch, const float *bounds, const float4 *table, int R, float roughness,
+                     float cos_cutoff, float *dst, hipStream_t st)
+{
+    const size_t lds = R * sizeof(float);
+    const int64_t n = (int64_t)6 * R * R;
+    if (R <= SPEC_G64_MAX_R)
+        specular_kernel<BWD, 64><<<rsdf_blocks(n, THREADS / 64), THREADS, lds, st>>>(src, src_ch, bounds, table, R, roughness, cos_cutoff, dst);
+    else
+        specular_kernel<BWD, 1><<<rsdf_blocks(n, THREADS), THREADS, lds, st>>>(src, src_ch, bounds, table, R, roughness, cos_cutoff, dst);
 }
 
 __global__ void __launch_bounds__(THREADS)
@@ -473,14 +550,9 @@ int rsdf_cubemap_texel_table(int R, float *table, void *stream)
 int rsdf_specular_cubemap_fwd(const float *cubemap, const float *bounds, const float *texel_table, int R,
                               float roughness, float cos_cutoff, float *out4, void *stream)
 {
-    const float4 *table = reinterpret_cast<const float4 *>(texel_table);
     RSDF_CHECK_ARG(R >= 1 && R <= 4096, "specular_cubemap_fwd: bad resolution");
-    if (R <= COOP_MAX_R)
-        specular_kernel<false, true><<<rsdf_blocks(6 * R * R, THREADS / 64), THREADS, R * sizeof(float),
-                                       (hipStream_t)stream>>>(cubemap, 3, bounds, table, R, roughness, cos_cutoff, out4);
-    else
-        specular_kernel<false, false><<<rsdf_blocks(6 * R * R, THREADS), THREADS, R * sizeof(float),
-                                        (hipStream_t)stream>>>(cubemap, 3, bounds, table, R, roughness, cos_cutoff, out4);
+    launch_specular<false>(cubemap, 3, bounds, reinterpret_cast<const float4 *>(texel_table), R, roughness, cos_cutoff, out4,
+                           (hipStream_t)stream);
     RSDF_RETURN_LAUNCH();
 }
 
@@ -488,16 +560,9 @@ int rsdf_specular_cubemap_bwd(const float *grad_out, int grad_channels, const fl
                               const float *texel_table, int R, float roughness, float cos_cutoff,
                               float *grad_cubemap, void *stream)
 {
-    const float4 *table = reinterpret_cast<const float4 *>(texel_table);
     RSDF_CHECK_ARG(R >= 1 && R <= 4096 && grad_channels >= 3, "specular_cubemap_bwd: bad arguments");
-    if (R <= COOP_MAX_R)
-        specular_kernel<true, true><<<rsdf_blocks(6 * R * R, THREADS / 64), THREADS, R * sizeof(float),
-                                      (hipStream_t)stream>>>(grad_out, grad_channels, bounds, table, R, roughness,
-                                                             cos_cutoff, grad_cubemap);
-    else
-        specular_kernel<true, false><<<rsdf_blocks(6 * R * R, THREADS), THREADS, R * sizeof(float),
-                                       (hipStream_t)stream>>>(grad_out, grad_channels, bounds, table, R, roughness,
-                                                              cos_cutoff, grad_cubemap);
+    launch_specular<true>(grad_out, grad_channels, bounds, reinterpret_cast<const float4 *>(texel_table), R, roughness,
+                          cos_cutoff, grad_cubemap, (hipStream_t)stream);
     RSDF_RETURN_LAUNCH();
 }
 
