@@ -375,6 +375,11 @@ int rsdf_split_color0_bwd(const float *albedo6, const float *metallic2, const fl
                           float *d_spec3, void *stream);
 int rsdf_rgb_to_srgb_fwd(const float *x, int64_t n, float *y, void *stream);
 int rsdf_rgb_to_srgb_bwd(const float *x, const float *dy, int64_t n, float *dx, void *stream);
+/* O1, models/split_mixed_occ.py:405-436: y [n,3] = clamp(rgb_to_srgb(comp [n,3] + bg [3] * (1 - opacity [n])), 0, 1) in one
+ * pass; backward writes d_comp [n,3] and d_opacity [n] (nullable).  Same values as the unfused chain. */
+int rsdf_compose_srgb_fwd(const float *comp, const float *bg, const float *opacity, int64_t n, float *y, void *stream);
+int rsdf_compose_srgb_bwd(const float *comp, const float *bg, const float *opacity, const float *dy, int64_t n,
+                          float *d_comp, float *d_opacity /* nullable */, void *stream);
 
 /* stage-1 split-sum shading (models/texture.py:329-345) on ACTIVATED material values (sigmoid already
  * applied: albedo6 = [diff_rgb | albedo], metallic2 = [blend | metallic]); colors24 in the channel order of

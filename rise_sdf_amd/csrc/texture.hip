@@ -318,6 +318,48 @@ srgb_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy, int64
     dx[i] = dy[i] * (f <= 0.0031308f ? 12.92f : 1.055f / 2.4f * powf(f, 1.0f / 2.4f - 1.0f));
 }
 
+// O1 (models/split_mixed_occ.py:405-436): y = clamp(rgb_to_srgb(comp + bg (1 - opacity)), 0, 1) per ray, one pass each way
+// instead of rsub, mul, add, the sRGB kernel and clamp (and clamp's five-kernel backward).  x is formed as torch forms it
+// (this file is built with -ffp-contract=off): same values as the unfused chain, bit for bit.
+__device__ __forceinline__ float srgb_of(float f)
+{
+    return f <= 0.0031308f ? f * 12.92f : powf(fmaxf(f, 0.0031308f), 1.0f / 2.4f) * 1.055f - 0.055f;
+}
+
+__global__ void __launch_bounds__(THREADS)
+compose_srgb_fwd_kernel(const float *__restrict__ comp, const float *__restrict__ bg, const float *__restrict__ opacity,
+                        int64_t n, float *__restrict__ y)
+{
+    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= 3 * n) return;
+    const int64_t row = i / 3;
+    const int c = (int)(i - 3 * row);
+    const float x = comp[i] + bg[c] * (1.0f - opacity[row]);
+    y[i] = fminf(fmaxf(srgb_of(x), 0.0f), 1.0f);
+}
+
+__global__ void __launch_bounds__(THREADS)
+compose_srgb_bwd_kernel(const float *__restrict__ comp, const float *__restrict__ bg, const float *__restrict__ opacity,
+                        const float *__restrict__ dy, int64_t n, float *__restrict__ d_comp, float *__restrict__ d_opacity)
+{
+    const int64_t row = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (row >= n) return;
+    const float om = 1.0f - opacity[row];
+    float dop = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float x = comp[3 * row + c] + bg[c] * om;
+        const float yp = srgb_of(x);
+        // clamp passes the gradient on [0, 1] (bounds included), then the sRGB derivative (srgb_bwd_kernel)
+        const float g = (yp >= 0.0f && yp <= 1.0f)
+                            ? dy[3 * row + c] * (x <= 0.0031308f ? 12.92f : 1.055f / 2.4f * powf(x, 1.0f / 2.4f - 1.0f))
+                            : 0.0f;
+        d_comp[3 * row + c] = g;
+        dop -= g * bg[c];
+    }
+    if (d_opacity != nullptr) d_opacity[row] = dop;
+}
+
 }  // namespace
 
 #define LAUNCH1D(kern, n, ...) kern<<<rsdf_blocks(n, THREADS), THREADS, 0, (hipStream_t)stream>>>(__VA_ARGS__)
@@ -410,6 +452,21 @@ int rsdf_rgb_to_srgb_fwd(const float *x, int64_t n, float *y, void *stream)
 {
     if (n <= 0) return 0;
     LAUNCH1D(srgb_fwd_kernel, n, x, n, y);
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_compose_srgb_fwd(const float *comp, const float *bg, const float *opacity, int64_t n, float *y, void *stream)
+{
+    if (n <= 0) return 0;
+    LAUNCH1D(compose_srgb_fwd_kernel, 3 * n, comp, bg, opacity, n, y);
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_compose_srgb_bwd(const float *comp, const float *bg, const float *opacity, const float *dy, int64_t n,
+                          float *d_comp, float *d_opacity, void *stream)
+{
+    if (n <= 0) return 0;
+    LAUNCH1D(compose_srgb_bwd_kernel, n, comp, bg, opacity, dy, n, d_comp, d_opacity);
     RSDF_RETURN_LAUNCH();
 }
 

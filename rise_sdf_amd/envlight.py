@@ -147,7 +147,13 @@ class _CubeSample(torch.autograd.Function):
         R0, C = ctx.dims
         g = _f(dout)
         need_tex = [ctx.needs_input_grad[3 + i] for i in range(len(ms))]
-        grads = [torch.zeros_like(m) if need else None for m, need in zip(ms, need_tex)]
+        # one zero-fill for the gradients of all mip levels (a fill per level was 7 launches of a launch-bound step)
+        sizes = [m.numel() if need else 0 for m, need in zip(ms, need_tex)]
+        pool = torch.zeros(sum(sizes), dtype=torch.float32, device=d.device) if sum(sizes) else None
+        grads, off = [], 0
+        for m, need, k in zip(ms, need_tex, sizes):
+            grads.append(pool[off:off + k].view(m.shape) if need else None)
+            off += k
         gd = torch.empty_like(d) if ctx.needs_input_grad[0] else None
         gl = torch.empty(d.shape[0], dtype=torch.float32, device=d.device) \
             if (ctx.has_level and ctx.needs_input_grad[1]) else None

@@ -595,6 +595,21 @@ class _MLPChain(torch.autograd.Function):
         # input-gradient kernel and allocates, zero-fills and accumulates nothing
         need_w = [bool(ctx.needs_input_grad[4 + 2 * i] or (ctx.has_bias[i] and ctx.needs_input_grad[5 + 2 * i]))
                   for i in range(nl)]
+        # ONE zero-fill for the weight / bias gradient accumulators of the whole network (the training step is launch-bound:
+        # a zero-fill per layer was 28 launches per step); every accumulator starts at a 16-byte aligned offset
+        offs, total = [], 0
+        for i in range(nl):
+            offs.append(total)
+            if need_w[i]:
+                N_, K_ = ws[i].shape
+                total += (N_ * K_ + 3) // 4 * 4 + ((N_ + 3) // 4 * 4 if ctx.has_bias[i] else 0)
+        pool = torch.zeros(total, dtype=torch.float32, device=xf.device) if total else None
+
+        def layer_acc(i):
+            N, K = ws[i].shape
+            o, a = offs[i], (N * K + 3) // 4 * 4
+            return pool[o:o + N * K].view(N, K), (pool[o + a:o + a + N] if ctx.has_bias[i] else None)
+
         # narrow output layer (<= 4 columns) on top of a 128-wide ReLU layer: only its dz and its weight gradient are
         # computed here; the layer below forms its own input gradient from that dz (rsdf_linear_bwd_fused_tail)
         if (not split and nl >= 2 and need_w[-1] and need_w[-2]
@@ -605,7 +620,7 @@ class _MLPChain(torch.autograd.Function):
             dzo = torch.empty_like(g)
             check(fn("rsdf_linear_bwd_input")(ptr(g), ptr(y), N, ptr(w), n, K, N, ctx.acts[-1], 0, K, ptr(dzo), None, K, st),
                   "linear_bwd_input")
-            dw, db = _dw_db(N, K, ctx.has_bias[-1], xf.device)
+            dw, db = layer_acc(nl - 1)
             check(fn("rsdf_linear_bwd_weight")(ptr(dzo), N, ptr(xin), K, n, K, N, ptr(dw), ptr(db), st), "linear_bwd_weight")
             grads[2 * top], grads[2 * top + 1] = dw, db
             tail, top = (dzo, N, w), nl - 2
@@ -634,7 +649,7 @@ class _MLPChain(torch.autograd.Function):
                 if i == 0:
                     dx_in = dx
                 continue
-            dw, db = _dw_db(N, K, ctx.has_bias[i], xf.device)
+            dw, db = layer_acc(i)
             fused = not split and bool(fn("rsdf_linear_bwd_fused_supported")(K, N))
             prev_relu = fused and i > 0 and ctx.acts[i - 1] == relu
             if tail is not None:

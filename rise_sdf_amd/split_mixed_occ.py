@@ -51,6 +51,7 @@ class SplitMixedOCCModel(BaseModel):
         # opt-in (rise_sdf_amd.step.TrainStep): the secondary-ray blend as a select over all rays instead of a
         # gather / scatter over torch.nonzero(opacity > 0.5), which costs a host read per step
         self.masked_secondary = False
+        self.after_sampling = None        # one-shot callable run right after the primary sampling of the next forward_
 
     # ---- per-step schedule (:98-136) ------------------------------------------------------------------
     def update_step(self, epoch, global_step):
@@ -170,6 +171,13 @@ class SplitMixedOCCModel(BaseModel):
                 render_step_size=self.render_step_size,
                 stratified=self.randomized and stratified_u is None, stratified_u=stratified_u,
                 cone_angle=0.0, alpha_thre=0.0)
+        if self.after_sampling is not None:
+            # Work that does not depend on the samples and that the caller wants issued HERE (rise_sdf_amd.step.TrainStep:
+            # the environment prefilter, systems/split_occ.py:151-152).  The sampling call above ends in the step's one host
+            # read; whatever is enqueued before it only delays that read, whereas the prefilter's ~2 ms of kernels enqueued
+            # after it give the host that long a head start on issuing the render stage.
+            hook, self.after_sampling = self.after_sampling, None
+            hook()
         rgb_map, normal_map, acc_map, depth_map, extras = rendering_with_normals_sdf(
             t_starts, t_ends, ray_indices=ray_indices, n_rays=n_rays, rgb_alpha_fn=rgb_normal_alpha_fn,
             render_bkgd=None, has_laplace=has_laplace, color_dim=7 if self.stage == 0 else 24)
@@ -261,12 +269,12 @@ class SplitMixedOCCModel(BaseModel):
         bg = self.background_color if self.background_color is not None else torch.ones(3, device=dev)
         out_bg = {"comp_rgb": bg[None, :].expand(*rgb.shape), "num_samples": torch.zeros_like(out["num_samples"]),
                   "rays_valid": torch.zeros_like(out["rays_valid"])}
-        out_full = {"comp_rgb": T.rgb_to_srgb(out["comp_rgb"] + out_bg["comp_rgb"] * (1.0 - out["opacity"])).clamp(0, 1),
+        out_full = {"comp_rgb": T.compose_srgb(out["comp_rgb"], bg, out["opacity"]),
                     "num_samples": out["num_samples"] + out_bg["num_samples"],
                     "rays_valid": out["rays_valid"] | out_bg["rays_valid"]}
         if self.stage != 0:
             out_bg["comp_rgb_phys"] = out_bg["comp_rgb"]
-            comp = lambda k: T.rgb_to_srgb(out[k] + out_bg["comp_rgb"] * (1.0 - out["opacity"])).clamp(0, 1)
+            comp = lambda k: T.compose_srgb(out[k], bg, out["opacity"])       # one kernel each way (O1)
             out_full.update({"comp_rgb_phys": comp("comp_rgb_phys"), "comp_spec_rgb": comp("comp_spec_rgb"),
                              "comp_spec_rgb_phys": comp("comp_spec_rgb_phys")})
         return {**out, **{k + "_bg": v for k, v in out_bg.items()}, **{k + "_full": v for k, v in out_full.items()}}

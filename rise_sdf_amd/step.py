@@ -44,6 +44,7 @@ class TrainStep:
         # parameters with the same random cells and jitter, from a generator of its own that every rank seeds alike and
         # that nothing else draws from (SURVEY 8e option (a): no traffic).
         grid = getattr(model, "occupancy_grid", None)
+        self.sync_free = bool(sync_free)
         if sync_free:
             # Host reads of the reference's step: marcher total + compaction count per sampling call (x2 with
             # secondary rays), torch.nonzero for the secondary rays, num_samples.item() for dynamic_ray_sampling = 6, plus
@@ -79,8 +80,17 @@ class TrainStep:
         model = self.model
         model.background_color = batch["background_color"]
         if getattr(model, "emitter", None) is not None and getattr(model, "stage", 0):
-            model.emitter.build_mips()                            # systems/split_occ.py:151-152
+            # systems/split_occ.py:151-152.  The prefilter does not depend on the samples and nothing before the render
+            # stage reads it, so it is issued right AFTER the model's sampling call (whose host read it would otherwise
+            # only delay; split_mixed_occ.forward_): same values, the host gets the prefilter's kernel time as a head start
+            if self.sync_free and hasattr(model, "after_sampling"):
+                model.after_sampling = model.emitter.build_mips
+            else:
+                model.emitter.build_mips()
         out = model(batch["rays"])
+        if getattr(model, "after_sampling", None) is not None:   # a forward that never reached its sampling call
+            model.after_sampling = None
+            model.emitter.build_mips()
         loss, terms = loss_tail(out, batch, self.lambdas, sparsity_scale=self.sparsity_scale)
         for name, value in model.regularizations(out).items():    # systems/split_occ.py:217-221
             lam = self.reg_lambdas.get("lambda_" + name, 0.0)

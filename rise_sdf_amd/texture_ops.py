@@ -133,6 +133,38 @@ def rgb_to_srgb(x):
     return _Srgb.apply(x)
 
 
+class _ComposeSrgb(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, comp, bg, opacity):
+        c, b, o = _f(comp), _f(bg).reshape(-1), _f(opacity).reshape(-1)
+        require_device(c, b, o)
+        assert c.dim() == 2 and c.shape[1] == 3 and b.numel() == 3 and o.numel() == c.shape[0]
+        y = torch.empty_like(c)
+        check(lib().rsdf_compose_srgb_fwd(ptr(c), ptr(b), ptr(o), c.shape[0], ptr(y), stream_ptr()), "compose_srgb_fwd")
+        ctx.save_for_backward(c, b, o)
+        ctx.oshape = opacity.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        c, b, o = ctx.saved_tensors
+        g = _f(g)
+        dc = torch.empty_like(c)
+        do = torch.empty_like(o) if ctx.needs_input_grad[2] else None
+        check(lib().rsdf_compose_srgb_bwd(ptr(c), ptr(b), ptr(o), ptr(g), c.shape[0], ptr(dc), ptr(do), stream_ptr()),
+              "compose_srgb_bwd")
+        db = None
+        if ctx.needs_input_grad[1]:        # a learned background colour (not in the shipped configs): d x / d bg = 1 - opacity
+            db = (dc * (1.0 - o)[:, None]).sum(0)
+        return dc, db, (None if do is None else do.view(ctx.oshape))
+
+
+def compose_srgb(comp, bg, opacity):
+    """models/split_mixed_occ.py:405-436: ``rgb_to_srgb(comp + bg * (1 - opacity)).clamp(0, 1)`` for a constant background
+    colour ``bg`` [3], as one kernel each way (same values as the unfused chain)."""
+    return _ComposeSrgb.apply(comp, bg, opacity)
+
+
 class _SplitShade1(torch.autograd.Function):
     @staticmethod
     def forward(ctx, albedo6, roughness, metallic2, spec3, Ld, Ls, fg):

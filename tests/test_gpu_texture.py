@@ -76,3 +76,33 @@ def test_texture_stage0_reference_fixture(dev, golden_dir):
         ref = z["g__" + name.replace(".", "_")]
         got = torch.zeros_like(ref) if p.grad is None else p.grad.cpu()
         assert float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-7, name
+
+
+def test_compose_srgb_matches_the_unfused_chain_and_the_oracle(dev):
+    """O1 (models/split_mixed_occ.py:405-436): clamp(rgb_to_srgb(comp + bg (1 - opacity)), 0, 1) as one kernel each way ==
+    the unfused chain of the same kernels bit for bit, and the oracle's chain within fp32 rounding; values around both
+    clamp bounds and the sRGB knee."""
+    from rise_sdf_amd import texture_ops as T
+    g = torch.Generator().manual_seed(5)
+    n = 4097
+    comp = torch.rand(n, 3, generator=g) * 1.6 - 0.2           # below 0 and above 1 after composition
+    comp[:64] = torch.rand(64, 3, generator=g) * 0.006          # around the 0.0031308 knee
+    op = torch.rand(n, 1, generator=g)
+    op[:16] = 1.0
+    bg = torch.rand(3, generator=g)
+    gy = torch.randn(n, 3, generator=g)
+    co, oo = comp.clone().requires_grad_(True), op.clone().requires_grad_(True)
+    yo = otex.rgb_to_srgb(co + bg[None, :] * (1.0 - oo)).clamp(0, 1)
+    (yo * gy).sum().backward()
+    cu, ou = comp.to(dev).requires_grad_(True), op.to(dev).requires_grad_(True)
+    yu = T.rgb_to_srgb(cu + bg.to(dev)[None, :].expand(n, 3) * (1.0 - ou)).clamp(0, 1)
+    (yu * gy.to(dev)).sum().backward()
+    cf, of = comp.to(dev).requires_grad_(True), op.to(dev).requires_grad_(True)
+    yf = T.compose_srgb(cf, bg.to(dev), of)
+    (yf * gy.to(dev)).sum().backward()
+    assert torch.equal(yf, yu), "fused compose differs from the unfused chain"
+    assert torch.allclose(yf.cpu(), yo.detach(), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(cf.grad, cu.grad, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(of.grad, ou.grad, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(cf.grad.cpu(), co.grad, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(of.grad.cpu(), oo.grad, rtol=1e-4, atol=1e-5)
