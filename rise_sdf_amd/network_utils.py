@@ -120,6 +120,7 @@ class VanillaMLP(nn.Module):
         # 'fp32' (default: fp32-equivalent split products, the reference's nn.Linear precision) or 'bf16' (BASELINE.json
         # configs[4] "bf16 MLP on MFMA": operands rounded once to bf16, fp32 accumulation, fp32 master weights); a
         # per-network opt-in key of the network's config node that the reference's yaml simply does not carry
+        self._wn_cache = {}     # id(layer) -> ((versions, pointers), W, has_graph): see _normed_weight
         self.precision = str(config.get("precision", "fp32")).lower()
         if self.precision not in ("fp32", "bf16"):
             raise ValueError(f"VanillaMLP precision {self.precision!r}: fp32 or bf16")
@@ -163,12 +164,36 @@ class VanillaMLP(nn.Module):
     def make_activation(self):
         return nn.Softplus(beta=100) if self.sphere_init else nn.ReLU(inplace=True)
 
+    def _normed_weight(self, m):
+        """weight_norm(g, v) of one layer, computed ONCE per parameter version: a training step evaluates the SDF network
+        five times (sampling, render, secondary rays, their sampling, curvature), which re-normalised every layer each time
+        and ran one weight-norm backward per evaluation.  The cached W carries its autograd node, so the evaluations'
+        weight gradients sum there and ONE backward runs; the cache is dropped when that backward has run (the graph is
+        spent), when g or v change (their version counters), or when gradient tracking is needed but the cached W has none."""
+        g, v = m.weight_g, m.weight_v
+        want_graph = torch.is_grad_enabled() and (g.requires_grad or v.requires_grad)
+        key = (g._version, v._version, g.data_ptr(), v.data_ptr())
+        c = self._wn_cache.get(id(m))
+        if c is not None and c[0] == key and (c[2] or not want_graph):
+            return c[1] if want_graph else c[1].detach()
+        with torch.enable_grad() if (g.requires_grad or v.requires_grad) else torch.no_grad():
+            w = ops.weight_norm(g, v)
+        has_graph = w.requires_grad
+        if has_graph:
+            cache, mid = self._wn_cache, id(m)
+
+            def spent(grad):           # (a tensor hook must return None or a tensor)
+                cache.pop(mid, None)
+            w.register_hook(spent)
+        self._wn_cache[id(m)] = (key, w, has_graph)
+        return w if want_graph else w.detach()
+
     def effective_weights(self):
         """[(W [out,in], b [out])] per Linear; W = weight_norm(g, v) through the HIP kernel."""
         out = []
         for m in self.layers:
             if isinstance(m, nn.Linear):
-                w = ops.weight_norm(m.weight_g, m.weight_v) if self.weight_norm else m.weight
+                w = self._normed_weight(m) if self.weight_norm else m.weight
                 out.append((w, m.bias))
         return out
 

@@ -120,7 +120,7 @@ class TrainStep:
 
 def build_synthetic_training(dev, *, stage=1, hidden=128, views=8, res=200, seed=0, rank=0, world=1, indirect=True,
                              curvature=True, grad_buckets=True, model_overrides=None, tex_precision="fp32",
-                             sdf_precision="fp32"):
+                             sdf_precision="fp32", fused_adam=True):
     """The full split-mixed-occ model at the yaml's sizes (rise_sdf_amd.config.tensoir_model_config) with the yaml's
     optimizer and loss weights, on the synthetic analytic scene (rise_sdf_amd.synthetic): what bench.py's config[3]
     workload, tools/bench_step.py and the multi-rank tests drive.  -> (model, TrainStep)."""
@@ -135,7 +135,7 @@ def build_synthetic_training(dev, *, stage=1, hidden=128, views=8, res=200, seed
     model = make("split-mixed-occ", cfg).to(dev)
     model.train()
     ds = make_dataset(n_views=views, W=res, H=res, seed=seed, device=dev)
-    opt = tensoir_optimizer(model)
+    opt = tensoir_optimizer(model, fused=fused_adam)   # (fused multi-tensor Adam: ~30 launches less per step)
     lam = dict(TENSOIR_LAMBDAS)
     if not curvature:
         lam["lambda_curvature"] = 0.0
