@@ -69,23 +69,41 @@ def ndf_cutoff(roughness, cutoff=0.99, n_samples=1000000):
     return float(ct[np.argmax(D >= D[-1] * cutoff)])
 
 
+_WEIGHTS = {}      # (R, roughness, cutoff, dtype, cos_shift) -> weights: the dense matrix of a 64^2 map is 4.8 GB of fp64 and
+                   # a minute of trigonometry; the fixtures of several tests share the same three levels (read-only)
+
+
 def specular_weights(R, roughness, cutoff=0.99, dtype=torch.float64, chunk=1024, cos_shift=0.0):
     """Dense [6RR, 6RR] prefilter weights (row = output texel V, column = input texel L): texels with
-    L.V >= cos_cutoff get (L.V) * D_ggx(V.H) * area / 4  (:246-298)."""
+    L.V >= cos_cutoff get (L.V) * D_ggx(V.H) * area / 4  (:246-298).  Cached per argument tuple (up to 3 entries)."""
+    key = (int(R), float(roughness), float(cutoff), dtype, float(cos_shift))
+    if key not in _WEIGHTS:
+        while len(_WEIGHTS) >= 3:
+            _WEIGHTS.pop(next(iter(_WEIGHTS)))
+        _WEIGHTS[key] = _specular_weights(R, roughness, cutoff, dtype, chunk, cos_shift)
+    return _WEIGHTS[key]
+
+
+def _specular_weights(R, roughness, cutoff, dtype, chunk, cos_shift):
     D = texel_dirs(R, dtype).reshape(-1, 3)
-    area = pixel_area(R, dtype).reshape(1, -1).repeat(1, 6)
+    area = pixel_area(R, dtype).reshape(1, -1).repeat(1, 6)[0]
     cosc = ndf_cutoff(roughness, cutoff) + cos_shift
     a2 = (roughness * roughness) ** 2
     rows = []
     for i in range(0, D.shape[0], chunk):
         V = D[i:i + chunk]
         dot = V @ D.T
-        Hh = V[:, None, :] + D[None, :, :]
+        # the NDF only where the cone test passes (a sharp lobe keeps a fraction of a per cent of the pairs): the same
+        # elementwise arithmetic on the same operands as the dense form, zeros elsewhere
+        vi, li = torch.nonzero(dot >= cosc, as_tuple=True)
+        Vs, Ls = V[vi], D[li]
+        Hh = Vs + Ls
         Hh = Hh / Hh.norm(dim=-1, keepdim=True).clamp_min(1e-20)
-        vh = (Hh * V[:, None, :]).sum(-1).clamp(0.0, 1.0)
+        vh = (Hh * Vs).sum(-1).clamp(0.0, 1.0)
         dd = (vh * a2 - vh) * vh + 1.0
-        w = dot.clamp_min(0.0) * (a2 / (dd * dd * math.pi)) * area / 4.0
-        rows.append(torch.where(dot >= cosc, w, torch.zeros_like(w)))
+        w = torch.zeros_like(dot)
+        w[vi, li] = dot[vi, li].clamp_min(0.0) * (a2 / (dd * dd * math.pi)) * area[li] / 4.0
+        rows.append(w)
     return torch.cat(rows, 0)
 
 
