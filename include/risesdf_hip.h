@@ -236,6 +236,21 @@ int rsdf_linear_bwd_fused_tail(const float *dz_out, int N2, const float *w2, con
                                const float *x, int ldx, const float *w, int64_t n, int K, int N, int act,
                                int k0, int Kout, float *dx, int lddx, int prev_act, float *dw, float *db,
                                void *stream);
+/* The same two calls with a WORKSPACE for the weight-gradient accumulators (round 3): the workgroups store their dW tiles
+ * as plain per-workgroup partials and a second kernel adds their sum to dw, instead of up to 256 workgroups flushing
+ * N K float atomics each onto the same N K addresses (~0.16 ms per launch whatever the row count: two thirds of the call
+ * at a training step's 250 k rows).  workspace >= rsdf_linear_bwd_fused_workspace_bytes(n, K, N) bytes, private to the
+ * stream until the call has run; NULL (or too small, or fewer than 64 row tiles) = the atomic flush.  Same results up to
+ * the order of the fp32 additions. */
+int64_t rsdf_linear_bwd_fused_workspace_bytes(int64_t n, int K, int N);
+int rsdf_linear_bwd_fused_ws(const float *dy, const float *y, int lddy, const float *x, int ldx,
+                             const float *w, int64_t n, int K, int N, int act, int k0, int Kout, float *dx,
+                             int lddx, int prev_act, float *dw, float *db, void *workspace,
+                             int64_t workspace_bytes, void *stream);
+int rsdf_linear_bwd_fused_tail_ws(const float *dz_out, int N2, const float *w2, const float *y, int lddy,
+                                  const float *x, int ldx, const float *w, int64_t n, int K, int N, int act,
+                                  int k0, int Kout, float *dx, int lddx, int prev_act, float *dw, float *db,
+                                  void *workspace, int64_t workspace_bytes, void *stream);
 /* Fused SDF network for the finite-difference stencil: [x*xyz_scale+xyz_offset | planes] ->
  * Linear(K0,H) -> Softplus(100) -> Linear(H,H) -> Softplus(100) -> Linear(H,N2), K0 = 3 + 2*n_levels
  * (CompositeEncoding include_xyz + VanillaMLP n_hidden_layers=2, models/network_utils.py:71-157) on
@@ -283,6 +298,14 @@ int rsdf_linear_bwd_fused_tail_bf16(const float *dz_out, int N2, const float *w2
                                     const float *x, int ldx, const float *w, int64_t n, int K, int N, int act,
                                     int k0, int Kout, float *dx, int lddx, int prev_act, float *dw, float *db,
                                     void *stream);
+int rsdf_linear_bwd_fused_ws_bf16(const float *dy, const float *y, int lddy, const float *x, int ldx,
+                                  const float *w, int64_t n, int K, int N, int act, int k0, int Kout, float *dx,
+                                  int lddx, int prev_act, float *dw, float *db, void *workspace,
+                                  int64_t workspace_bytes, void *stream);
+int rsdf_linear_bwd_fused_tail_ws_bf16(const float *dz_out, int N2, const float *w2, const float *y, int lddy,
+                                       const float *x, int ldx, const float *w, int64_t n, int K, int N, int act,
+                                       int k0, int Kout, float *dx, int lddx, int prev_act, float *dw, float *db,
+                                       void *workspace, int64_t workspace_bytes, void *stream);
 int rsdf_sdfmlp_fd7_supported_bf16(int K0, int H, int N2);
 int rsdf_sdfmlp_fd7_fwd_bf16(const float *x7t, const float *planes, int n_levels, int n_active_levels,
                              float xyz_scale, float xyz_offset, int H, int N2, const float *w0,

@@ -85,6 +85,9 @@ _SIGNATURES = {
     "rsdf_linear_bwd_fused_supported": [_I, _I],
     "rsdf_linear_bwd_fused": [_P, _P, _I, _P, _I, _P, _L, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P],
     "rsdf_linear_bwd_fused_tail": [_P, _I, _P, _P, _I, _P, _I, _P, _L, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P],
+    "rsdf_linear_bwd_fused_workspace_bytes": [_L, _I, _I],
+    "rsdf_linear_bwd_fused_ws": [_P, _P, _I, _P, _I, _P, _L, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P, _L, _P],
+    "rsdf_linear_bwd_fused_tail_ws": [_P, _I, _P, _P, _I, _P, _I, _P, _L, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P, _L, _P],
     "rsdf_sdfmlp_fd7_supported": [_I, _I, _I],
     "rsdf_sdfmlp_fd7_fwd": [_P, _P, _I, _I, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P],
     "rsdf_sdfmlp_fd7_bwd": [_P, _P, _I, _I, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P,
@@ -129,6 +132,7 @@ _SIGNATURES = {
 # config[4]'s bf16 MLP mode: the MLP entry points a second time with the suffix _bf16 (same signatures; split_bf16.h)
 BF16_ENTRY_POINTS = ("rsdf_linear_fwd", "rsdf_linear_bwd_input", "rsdf_linear_bwd_weight",
                      "rsdf_linear_bwd_fused_supported", "rsdf_linear_bwd_fused", "rsdf_linear_bwd_fused_tail",
+                     "rsdf_linear_bwd_fused_ws", "rsdf_linear_bwd_fused_tail_ws",
                      "rsdf_sdfmlp_fd7_supported", "rsdf_sdfmlp_fd7_fwd", "rsdf_sdfmlp_fd7_bwd")
 for _n in BF16_ENTRY_POINTS:
     _SIGNATURES[_n + "_bf16"] = _SIGNATURES[_n]
@@ -151,6 +155,7 @@ _RESTYPES = {"rsdf_last_error": ctypes.c_char_p, "rsdf_scan_scratch_bytes": ctyp
              "rsdf_hashgrid_bwd_fd7_scratch_bytes": ctypes.c_int64,
              "rsdf_hashgrid_scatter_binned_scratch_bytes": ctypes.c_int64,
              "rsdf_hashgrid_fwd_staged_scratch_bytes": ctypes.c_int64,
+             "rsdf_linear_bwd_fused_workspace_bytes": ctypes.c_int64,
              "rsdf_occ_update_scratch_bytes": ctypes.c_int64}
 
 EXPORTS = tuple(_SIGNATURES)

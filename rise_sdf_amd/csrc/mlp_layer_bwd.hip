@@ -122,7 +122,7 @@ template <bool HAS_DX, int ACT, bool PREV_RELU, bool TAIL>
 __global__ void __launch_bounds__(LB_THREADS, 2)
 layer_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ y, int lddy, const float *__restrict__ x,
                  int ldx, const float *__restrict__ w, int64_t n, int K, int k0, int Kout, const TailArgs tail,
-                 float *__restrict__ dx, int lddx, float *__restrict__ dw, float *__restrict__ db)
+                 float *__restrict__ dx, int lddx, float *__restrict__ dw, float *__restrict__ db, float *__restrict__ part)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     unsigned char *dzi = smem_b, *xi = smem_b + IMG_BYTES;
@@ -286,17 +286,53 @@ layer_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ y, int 
             for (int r = 0; r < 16; ++r) {
                 const float v = tt ? acc1[r] : acc0[r];
                 const int nrow = 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * hf;
-                if (v != 0.0f) atomicAdd(&dw[nrow * K + kcol], v);
+                if (part != nullptr) part[(size_t)blockIdx.x * (LB_N * K + LB_N) + nrow * K + kcol] = v;
+                else if (v != 0.0f) atomicAdd(&dw[nrow * K + kcol], v);
             }
         }
     }
     if (db) {
+        // Bias sums: sixteen staging threads hold partial sums of the same four columns.  They meet in LDS (the images are
+        // free) and the workgroup issues 128 adds instead of 1024: per launch every db address used to receive 8 x 256
+        // same-address float atomics, which the memory side executes one after the other -- 0.19 ms whatever the row
+        // count (tools/layer_bwd_fixed_cost.py), more than the rest of the call at a training step's 250 k rows.
+        float *red = reinterpret_cast<float *>(smem_b);           // [16][128]
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float s = bs[q] + __shfl_xor(bs[q], 32, 64);   // the wave's two staging rows share their columns
-            if (hf == 0 && s != 0.0f) atomicAdd(&db[col4 + q], s);
+        for (int q = 0; q < 4; ++q) red[srow * LB_N + col4 + q] = bs[q];
+        __syncthreads();
+        if (t < LB_N) {
+            float s = 0.0f;
+#pragma unroll
+            for (int r = 0; r < LB_THREADS / 32; ++r) s += red[r * LB_N + t];
+            if (part != nullptr) part[(size_t)blockIdx.x * (LB_N * K + LB_N) + LB_N * K + t] = s;
+            else if (s != 0.0f) atomicAdd(&db[t], s);
         }
+    } else if (part != nullptr && t < LB_N) {
+        part[(size_t)blockIdx.x * (LB_N * K + LB_N) + LB_N * K + t] = 0.0f;
     }
+}
+
+// The flush above is N K float atomics per workgroup onto the SAME N K addresses from up to 256 workgroups (4.2 M
+// memory-side atomic operations per launch), and as many same-address adds per db entry as there are workgroups.  With a
+// workspace the workgroups store their dW tiles and bias sums as plain [workgroup][N K + N] partials and this kernel adds
+// their sums to dw / db (which keep their "accumulates: zero first" contract).
+__global__ void __launch_bounds__(256)
+dw_reduce_kernel(const float *__restrict__ part, int n_parts, int NK, int N, float *__restrict__ dw, float *__restrict__ db)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, stride = NK + N;     // a partial: [N K] of dW, then [N] of db
+    if (i >= stride) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int g = 0;
+    for (; g + 3 < n_parts; g += 4) {
+        s0 += part[(size_t)g * stride + i];
+        s1 += part[(size_t)(g + 1) * stride + i];
+        s2 += part[(size_t)(g + 2) * stride + i];
+        s3 += part[(size_t)(g + 3) * stride + i];
+    }
+    for (; g < n_parts; ++g) s0 += part[(size_t)g * stride + i];
+    const float s = (s0 + s1) + (s2 + s3);
+    if (i < NK) dw[i] += s;
+    else if (db != nullptr) db[i - NK] += s;
 }
 
 struct LaunchArgs {
@@ -314,6 +350,7 @@ struct LaunchArgs {
     float *dx;
     int lddx;
     float *dw, *db;
+    float *part;     // workspace for the per-workgroup dW partials (nullptr: atomic flush)
 };
 
 template <bool HAS_DX, int ACT, bool PREV_RELU, bool TAIL>
@@ -322,7 +359,9 @@ int launch(const LaunchArgs &a)
     if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(layer_bwd_kernel<HAS_DX, ACT, PREV_RELU, TAIL>), a.lds))
         return rc;   // per (kernel, device, host thread): autograd calls this from its own thread
     layer_bwd_kernel<HAS_DX, ACT, PREV_RELU, TAIL><<<a.grid, LB_THREADS, a.lds, a.st>>>(
-        a.dy, a.y, a.lddy, a.x, a.ldx, a.w, a.n, a.K, a.k0, a.Kout, a.tail, a.dx, a.lddx, a.dw, a.db);
+        a.dy, a.y, a.lddy, a.x, a.ldx, a.w, a.n, a.K, a.k0, a.Kout, a.tail, a.dx, a.lddx, a.dw, a.db, a.part);
+    if (a.part != nullptr)
+        dw_reduce_kernel<<<(LB_N * a.K + LB_N + 255) / 256, 256, 0, a.st>>>(a.part, (int)a.grid, LB_N * a.K, LB_N, a.dw, a.db);
     return 0;
 }
 
@@ -359,18 +398,64 @@ extern "C" {
 
 int RSDF_P(rsdf_linear_bwd_fused_supported)(int K, int N) { return N == LB_N && K >= 1 && K <= 128; }
 
-int RSDF_P(rsdf_linear_bwd_fused)(const float *dy, const float *y, int lddy, const float *x, int ldx, const float *w,
-                          int64_t n, int K, int N, int act, int k0, int Kout, float *dx, int lddx, int prev_act,
-                          float *dw, float *db, void *stream)
+// workspace: >= rsdf_linear_bwd_fused_workspace_bytes(n, K, N) bytes, or NULL (atomic flush); used only from 64 tiles up
+static float *pick_part(void *workspace, int64_t workspace_bytes, int64_t tiles, unsigned grid, int K)
+{
+    if (workspace == nullptr || tiles < 64) return nullptr;
+    return workspace_bytes >= (int64_t)grid * (LB_N * K + LB_N) * (int64_t)sizeof(float) ? static_cast<float *>(workspace) : nullptr;
+}
+
+#ifndef RSDF_BF16
+int64_t rsdf_linear_bwd_fused_workspace_bytes(int64_t n, int K, int N)
+{
+    if (N != LB_N || K < 1 || K > 128 || n <= 0) return 0;
+    const int64_t tiles = (n + LB_ROWS - 1) / LB_ROWS;
+    return (tiles < 256 ? tiles : 256) * (int64_t)(LB_N * K + LB_N) * (int64_t)sizeof(float);
+}
+#endif
+
+int RSDF_P(rsdf_linear_bwd_fused_ws)(const float *dy, const float *y, int lddy, const float *x, int ldx, const float *w,
+                             int64_t n, int K, int N, int act, int k0, int Kout, float *dx, int lddx, int prev_act,
+                             float *dw, float *db, void *workspace, int64_t workspace_bytes, void *stream)
 {
     if (int rc = check_common(y, lddy, x, ldx, K, N, act, k0, Kout, dx, lddx, prev_act, dw)) return rc;
     if (n <= 0) return 0;   // an empty batch carries no pointers
     RSDF_CHECK_ARG(act == RSDF_ACT_NONE || y != nullptr, "linear_bwd_fused: activation needs y");
     const int64_t tiles = (n + LB_ROWS - 1) / LB_ROWS;
-    LaunchArgs a{(unsigned)(tiles < 256 ? tiles : 256), 2 * (size_t)IMG_BYTES, (hipStream_t)stream, dy, y, lddy, x, ldx, w, n, K,
-                 dx ? k0 : 0, dx ? Kout : 0, TailArgs{nullptr, nullptr, 0}, dx, dx ? lddx : 0, dw, db};
+    const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
+    LaunchArgs a{grid, 2 * (size_t)IMG_BYTES, (hipStream_t)stream, dy, y, lddy, x, ldx, w, n, K,
+                 dx ? k0 : 0, dx ? Kout : 0, TailArgs{nullptr, nullptr, 0}, dx, dx ? lddx : 0, dw, db,
+                 pick_part(workspace, workspace_bytes, tiles, grid, K)};
     const int rc = !dx ? launch_act<false, false>(act, a)
                    : prev_act == RSDF_ACT_RELU ? launch_act<true, true>(act, a) : launch_act<true, false>(act, a);
+    if (rc) return rc;
+    RSDF_RETURN_LAUNCH();
+}
+
+int RSDF_P(rsdf_linear_bwd_fused)(const float *dy, const float *y, int lddy, const float *x, int ldx, const float *w,
+                          int64_t n, int K, int N, int act, int k0, int Kout, float *dx, int lddx, int prev_act,
+                          float *dw, float *db, void *stream)
+{
+    return RSDF_P(rsdf_linear_bwd_fused_ws)(dy, y, lddy, x, ldx, w, n, K, N, act, k0, Kout, dx, lddx, prev_act, dw, db,
+                                            nullptr, 0, stream);
+}
+
+int RSDF_P(rsdf_linear_bwd_fused_tail_ws)(const float *dz_out, int N2, const float *w2, const float *y, int lddy,
+                                  const float *x, int ldx, const float *w, int64_t n, int K, int N, int act, int k0,
+                                  int Kout, float *dx, int lddx, int prev_act, float *dw, float *db, void *workspace,
+                                  int64_t workspace_bytes, void *stream)
+{
+    if (int rc = check_common(y, lddy, x, ldx, K, N, act, k0, Kout, dx, lddx, prev_act, dw)) return rc;
+    RSDF_CHECK_ARG(N2 >= 1 && N2 <= 4, "linear_bwd_fused_tail: the output layer must have 1..4 columns");
+    RSDF_CHECK_ARG(act == RSDF_ACT_RELU && dx != nullptr, "linear_bwd_fused_tail: built for ReLU layers with an input gradient");
+    if (n <= 0) return 0;
+    RSDF_CHECK_ARG(dz_out != nullptr && w2 != nullptr && y != nullptr, "linear_bwd_fused_tail: NULL argument");
+    const int64_t tiles = (n + LB_ROWS - 1) / LB_ROWS;
+    const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
+    LaunchArgs a{grid, 2 * (size_t)IMG_BYTES + 4 * LB_N * sizeof(float), (hipStream_t)stream,
+                 nullptr, y, lddy, x, ldx, w, n, K, k0, Kout, TailArgs{dz_out, w2, N2}, dx, lddx, dw, db,
+                 pick_part(workspace, workspace_bytes, tiles, grid, K)};
+    const int rc = prev_act == RSDF_ACT_RELU ? launch<true, RSDF_ACT_RELU, true, true>(a) : launch<true, RSDF_ACT_RELU, false, true>(a);
     if (rc) return rc;
     RSDF_RETURN_LAUNCH();
 }
@@ -379,17 +464,8 @@ int RSDF_P(rsdf_linear_bwd_fused_tail)(const float *dz_out, int N2, const float 
                                int ldx, const float *w, int64_t n, int K, int N, int act, int k0, int Kout, float *dx,
                                int lddx, int prev_act, float *dw, float *db, void *stream)
 {
-    if (int rc = check_common(y, lddy, x, ldx, K, N, act, k0, Kout, dx, lddx, prev_act, dw)) return rc;
-    RSDF_CHECK_ARG(N2 >= 1 && N2 <= 4, "linear_bwd_fused_tail: the output layer must have 1..4 columns");
-    RSDF_CHECK_ARG(act == RSDF_ACT_RELU && dx != nullptr, "linear_bwd_fused_tail: built for ReLU layers with an input gradient");
-    if (n <= 0) return 0;
-    RSDF_CHECK_ARG(dz_out != nullptr && w2 != nullptr && y != nullptr, "linear_bwd_fused_tail: NULL argument");
-    const int64_t tiles = (n + LB_ROWS - 1) / LB_ROWS;
-    LaunchArgs a{(unsigned)(tiles < 256 ? tiles : 256), 2 * (size_t)IMG_BYTES + 4 * LB_N * sizeof(float), (hipStream_t)stream,
-                 nullptr, y, lddy, x, ldx, w, n, K, k0, Kout, TailArgs{dz_out, w2, N2}, dx, lddx, dw, db};
-    const int rc = prev_act == RSDF_ACT_RELU ? launch<true, RSDF_ACT_RELU, true, true>(a) : launch<true, RSDF_ACT_RELU, false, true>(a);
-    if (rc) return rc;
-    RSDF_RETURN_LAUNCH();
+    return RSDF_P(rsdf_linear_bwd_fused_tail_ws)(dz_out, N2, w2, y, lddy, x, ldx, w, n, K, N, act, k0, Kout, dx, lddx, prev_act,
+                                                 dw, db, nullptr, 0, stream);
 }
 
 }  // extern "C"

@@ -610,6 +610,16 @@ class _MLPChain(torch.autograd.Function):
             o, a = offs[i], (N * K + 3) // 4 * 4
             return pool[o:o + N * K].view(N, K), (pool[o + a:o + a + N] if ctx.has_bias[i] else None)
 
+        # workspace of the one-pass layer backward (per-workgroup dW partials + a reduction instead of 4 M contended float
+        # atomics per launch, include/risesdf_hip.h): one buffer for the whole chain -- its layers run one after the other on
+        # this stream
+        ws_bytes = 0
+        if not split:
+            for i in range(nl):
+                if need_w[i]:
+                    ws_bytes = max(ws_bytes, int(lib().rsdf_linear_bwd_fused_workspace_bytes(n, ws[i].shape[1], ws[i].shape[0])))
+        wsp = torch.empty(ws_bytes // 4, dtype=torch.float32, device=xf.device) if ws_bytes else None
+
         # narrow output layer (<= 4 columns) on top of a 128-wide ReLU layer: only its dz and its weight gradient are
         # computed here; the layer below forms its own input gradient from that dz (rsdf_linear_bwd_fused_tail)
         if (not split and nl >= 2 and need_w[-1] and need_w[-2]
@@ -658,15 +668,15 @@ class _MLPChain(torch.autograd.Function):
                 if dx is None:   # (a one-hidden-layer network whose input needs no gradient: still wants a dx buffer)
                     dx = torch.empty(n, K, dtype=torch.float32, device=xf.device)
                     dx_win, k0, kout = ptr(dx), 0, K
-                check(fn("rsdf_linear_bwd_fused_tail")(ptr(dzo), n2, ptr(w2), ptr(y), N, ptr(xin), K, ptr(w), n, K, N,
-                                                       ctx.acts[i], k0, kout, dx_win, K, relu if prev_relu else none,
-                                                       ptr(dw), ptr(db), st), "linear_bwd_fused_tail")
+                check(fn("rsdf_linear_bwd_fused_tail_ws")(ptr(dzo), n2, ptr(w2), ptr(y), N, ptr(xin), K, ptr(w), n, K, N,
+                                                          ctx.acts[i], k0, kout, dx_win, K, relu if prev_relu else none,
+                                                          ptr(dw), ptr(db), ptr(wsp), ws_bytes, st), "linear_bwd_fused_tail")
                 if not need_dx:
                     dx = None
             elif fused:
-                check(fn("rsdf_linear_bwd_fused")(ptr(g), ptr(yarg), N, ptr(xin), K, ptr(w), n, K, N, act, k0, kout,
-                                                  dx_win, K, relu if prev_relu else none, ptr(dw), ptr(db), st),
-                      "linear_bwd_fused")
+                check(fn("rsdf_linear_bwd_fused_ws")(ptr(g), ptr(yarg), N, ptr(xin), K, ptr(w), n, K, N, act, k0, kout,
+                                                     dx_win, K, relu if prev_relu else none, ptr(dw), ptr(db), ptr(wsp),
+                                                     ws_bytes, st), "linear_bwd_fused")
             else:
                 dz = torch.empty_like(g)
                 check(fn("rsdf_linear_bwd_input")(ptr(g), ptr(yarg), N, ptr(w), n, K, N, act, k0, kout, ptr(dz), dx_win,
