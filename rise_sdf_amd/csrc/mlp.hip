@@ -241,6 +241,28 @@ linear_bwd_weight_kernel(const float *__restrict__ dz, int lddz, const float *__
             acc[t] = mma6r(af, split_frag(bv[0], bv[1], bv[2], bv[3], bv[4], bv[5], bv[6], bv[7]), acc[t]);
         }
     }
+    // The row slabs of the workgroup meet in LDS, slab by slab, and slab 0 flushes: one add per workgroup and address.  A
+    // narrow output layer (N <= 4: eight slabs, 512 workgroups) used to send 4096 float atomics to each of its few dw / db
+    // addresses per launch; same-address atomics execute one after the other at the memory side, which was most of this
+    // kernel's duration at a training step's 250 k rows (see also mlp_layer_bwd.hip).
+    extern __shared__ float s_red[];                       // [NT][KT][16][64] sums, then [NT][32] bias sums
+    float *mine = s_red + (size_t)nt * KT * 1024 + lane;
+    float *bias = s_red + (size_t)NT * KT * 1024 + nt * 32;
+    bsum += __shfl_xor(bsum, 32, 64);
+    for (int sl = 0; sl < slabs; ++sl) {
+        if (slab == sl) {
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float *p = mine + (t * 16 + r) * 64;
+                    *p = sl == 0 ? acc[t][r] : *p + acc[t][r];
+                }
+            if (hf == 0) bias[c] = sl == 0 ? bsum : bias[c] + bsum;
+        }
+        __syncthreads();
+    }
+    if (slab != 0) return;
     // D[i = n within tile][j = k within tile]
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
@@ -249,14 +271,12 @@ linear_bwd_weight_kernel(const float *__restrict__ dz, int lddz, const float *__
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int nrow = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
-                if (nrow < N && acc[t][r] != 0.0f) atomicAdd(&dw[nrow * K + kcol], acc[t][r]);
+                const float v = mine[(t * 16 + r) * 64];
+                if (nrow < N && v != 0.0f) atomicAdd(&dw[nrow * K + kcol], v);
             }
         }
     }
-    if (db) {
-        bsum += __shfl_xor(bsum, 32, 64);
-        if (hf == 0 && nok && bsum != 0.0f) atomicAdd(&db[ncol], bsum);
-    }
+    if (db && hf == 0 && nok && bias[c] != 0.0f) atomicAdd(&db[ncol], bias[c]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -395,12 +415,21 @@ int RSDF_P(rsdf_linear_bwd_weight)(const float *dz, int lddz, const float *x, in
     int64_t want = ((n + 15) / 16 + slabs - 1) / slabs;
     const unsigned grid = (unsigned)(want < 1 ? 1 : (want > 512 ? 512 : want));
     hipStream_t st = (hipStream_t)stream;
-    switch (KT) {
-    case 1: linear_bwd_weight_kernel<1><<<grid, S_THREADS, 0, st>>>(dz, lddz, x, ldx, n, K, N, dw, db); break;
-    case 2: linear_bwd_weight_kernel<2><<<grid, S_THREADS, 0, st>>>(dz, lddz, x, ldx, n, K, N, dw, db); break;
-    case 3: linear_bwd_weight_kernel<3><<<grid, S_THREADS, 0, st>>>(dz, lddz, x, ldx, n, K, N, dw, db); break;
-    default: linear_bwd_weight_kernel<4><<<grid, S_THREADS, 0, st>>>(dz, lddz, x, ldx, n, K, N, dw, db); break;
+    const int NT = (N + 31) / 32;
+    const size_t lds = ((size_t)NT * KT * 1024 + (size_t)NT * 32) * sizeof(float);    // <= 64.5 KB
+#define RSDF_BWDW(KTV)                                                                                              \
+    {                                                                                                               \
+        if (lds > 48 * 1024)                                                                                        \
+            if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(linear_bwd_weight_kernel<KTV>), lds)) return rc; \
+        linear_bwd_weight_kernel<KTV><<<grid, S_THREADS, lds, st>>>(dz, lddz, x, ldx, n, K, N, dw, db);              \
     }
+    switch (KT) {
+    case 1: RSDF_BWDW(1) break;
+    case 2: RSDF_BWDW(2) break;
+    case 3: RSDF_BWDW(3) break;
+    default: RSDF_BWDW(4) break;
+    }
+#undef RSDF_BWDW
     RSDF_RETURN_LAUNCH();
 }
 
