@@ -228,6 +228,24 @@ class EnvironmentLightMipCube(nn.Module):
         base = torch.rand(6, ec.base_res, ec.base_res, 3, dtype=torch.float32) * ec.scale + ec.bias
         self.register_parameter("base", nn.Parameter(base))
         self.specular, self.diffuse = None, None
+        self._ready = None        # event of a build_mips_on() whose results the current stream has not waited for yet
+
+    def build_mips_on(self, stream, cutoff=0.99):
+        """build_mips() issued on ``stream`` (a side stream), ordered after everything already enqueued on the current one;
+        eval_mip() makes the consuming stream wait for it.  The prefilter is vector-ALU work on an L2-resident cube map,
+        the networks evaluated meanwhile are matrix / memory work: the two overlap on the CUs.  Autograd runs the backward
+        of these nodes on ``stream`` as well (and joins the streams at the end of backward), so the prefilter's backward
+        -- the last nodes of the graph -- overlaps the rest of the backward pass the same way.  Same values."""
+        stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(stream):
+            self.build_mips(cutoff)
+            self._ready = torch.cuda.Event()
+            self._ready.record(stream)
+
+    def _wait_ready(self):
+        if self._ready is not None:
+            torch.cuda.current_stream().wait_event(self._ready)
+            self._ready = None
 
     def build_mips(self, cutoff=0.99):
         self.specular = [self.base]
@@ -249,6 +267,7 @@ class EnvironmentLightMipCube(nn.Module):
             (torch.clamp(roughness, self.MAX_ROUGHNESS, 1.0) - self.MAX_ROUGHNESS) / (1.0 - self.MAX_ROUGHNESS) + n - 2)
 
     def eval_mip(self, directions, specular=False, roughness=None):
+        self._wait_ready()
         if specular:
             assert roughness is not None
             miplevel = self.get_mip(roughness)

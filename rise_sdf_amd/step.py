@@ -23,7 +23,8 @@ from .loss import loss_tail
 class TrainStep:
     def __init__(self, model, dataset, optimizer, lambdas, *, train_num_rays=256, max_train_num_rays=4096,
                  num_samples_per_ray=1024, dynamic_ray_sampling=True, background_color="random", apply_mask=True,
-                 sparsity_scale=1.0, seed=0, rank=0, world=1, grad_buckets=None, reg_lambdas=None, sync_free=True):
+                 sparsity_scale=1.0, seed=0, rank=0, world=1, grad_buckets=None, reg_lambdas=None, sync_free=True,
+                 prefilter_on_side_stream=True):
         self.model, self.ds, self.opt, self.lambdas = model, dataset, optimizer, dict(lambdas)
         self.train_num_rays = int(train_num_rays)
         self.max_train_num_rays = int(max_train_num_rays)
@@ -45,6 +46,8 @@ class TrainStep:
         # that nothing else draws from (SURVEY 8e option (a): no traffic).
         grid = getattr(model, "occupancy_grid", None)
         self.sync_free = bool(sync_free)
+        self.prefilter_stream = (torch.cuda.Stream(device=dev) if (prefilter_on_side_stream and sync_free
+                                                                   and dev.type == "cuda") else None)
         if sync_free:
             # Host reads of the reference's step: marcher total + compaction count per sampling call (x2 with
             # secondary rays), torch.nonzero for the secondary rays, num_samples.item() for dynamic_ray_sampling = 6, plus
@@ -84,7 +87,13 @@ class TrainStep:
             # stage reads it, so it is issued right AFTER the model's sampling call (whose host read it would otherwise
             # only delay; split_mixed_occ.forward_): same values, the host gets the prefilter's kernel time as a head start
             if self.sync_free and hasattr(model, "after_sampling"):
-                model.after_sampling = model.emitter.build_mips
+                if self.prefilter_stream is not None and hasattr(model.emitter, "build_mips_on"):
+                    # ... and on a side stream: vector-ALU work beside the networks' matrix / memory work, forward and
+                    # (autograd runs a node's backward on its forward's stream) backward
+                    side, em = self.prefilter_stream, model.emitter
+                    model.after_sampling = lambda: em.build_mips_on(side)
+                else:
+                    model.after_sampling = model.emitter.build_mips
             else:
                 model.emitter.build_mips()
         out = model(batch["rays"])

@@ -113,3 +113,38 @@ def test_eval_render_on_two_streams_is_identical(dev):
         assert torch.equal(outs[2][k], outs[3][k]), k
         assert torch.equal(outs[0][k], outs[3][k]), k
     print("eval render of 4096 rays in 512-ray chunks: one stream %.1f ms, two streams %.1f ms" % (times[2] * 1e3, times[3] * 1e3))
+
+
+def test_training_step_with_the_prefilter_on_a_side_stream(dev):
+    """TrainStep issues build_mips behind the sampling read, on a side stream (the prefilter's vector-ALU work beside the
+    networks' matrix / memory work; its backward runs on that stream too).  With and without the side stream from the same
+    seeds: the first step's loss (a pure forward) is bitwise the same and so are the sample counts; the second step's loss
+    -- after one backward + Adam update -- agrees to what the order of the float atomics in the gradient kernels leaves
+    open between any two runs (measured: 6e-7 relative; Adam with eps 1e-12 amplifies it from the third step on)."""
+    from rise_sdf_amd.step import build_synthetic_training
+
+    def run(side):
+        model, ts = build_synthetic_training(dev, stage=1, hidden=64, views=2, res=48, seed=3, grad_buckets=False,
+                                             model_overrides={"light": {"name": "envlight-mip-cube", "envlight_config": {
+                                                 "hdr_filepath": None, "clamp": True, "nmf_format": False, "scale": 0.5,
+                                                 "bias": 0.25, "base_res": 64}}})
+        if not side:
+            ts.prefilter_stream = None
+        assert (ts.prefilter_stream is not None) == side
+        out = []
+        for k in range(2):
+            r = ts.step(20000 + k)
+            out.append((float(r["loss"]), r["num_samples"]))
+        g = model.emitter.base.grad.detach().clone()
+        torch.cuda.synchronize()
+        return out, g
+
+    a, ga = run(True)
+    b, gb = run(False)
+    c, gc = run(False)
+    assert a[0] == b[0] == c[0], (a, b, c)
+    assert a[1][1] == b[1][1] == c[1][1]
+    noise = abs(b[1][0] - c[1][0]) / abs(b[1][0])
+    assert abs(a[1][0] - b[1][0]) / abs(b[1][0]) < max(1e-5, 10 * noise), (a, b, c)
+    scale = float(gb.abs().max())
+    assert float((ga - gb).abs().max()) <= max(1e-4 * scale, 10 * float((gb - gc).abs().max())), "d loss / d light"
