@@ -395,9 +395,10 @@ def secondary_measurements(dev, args, rays, jitter, cot):
     guarded("chunk4096", lambda: c1_variant(args.hidden, 4096))
     guarded("one_stream", lambda: c1_variant(args.hidden, args.chunk, streams=1))     # the round-2 issue order
     # (H = 128: the cooperative kernels hold every register of a CU, a second chunk in flight only adds contention)
-    guarded("h128", lambda: c1_variant(128, args.chunk, streams=1))
+    h128_chunk = min(args.chunk, 24576)       # (the H = 128 variants keep the chunk size they were measured at)
+    guarded("h128", lambda: c1_variant(128, h128_chunk, streams=1))
     # config[4]'s opt-in bf16 MLP mode at the yaml's width (dtype bf16; never part of the f32 headline)
-    guarded("h128_bf16", lambda: c1_variant(128, args.chunk, precision="bf16"))
+    guarded("h128_bf16", lambda: c1_variant(128, h128_chunk, precision="bf16"))
     # the per-layer API route (tcnn.Encoding / VanillaMLP shaped calls, one or a few kernels each; INTEGRATION.md's
     # two-line dropin.install()): [7 S, 35] rows through HBM, so a quarter of the view at the reference's chunk size
     guarded("dropin_path", lambda: c1_variant(args.hidden, 4096, n_rays=rays.shape[0] // 4 // 800 * 800, fused=False))
@@ -495,9 +496,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c1", choices=["c1", "c3"],
                     help="c1 = BASELINE.json config[1] (the metric); c3 = the occupancy-pruned N-rank training step")
-    ap.add_argument("--chunk", type=int, default=24576,
+    ap.add_argument("--chunk", type=int, default=28672,
                     help="rays per forward/backward chunk (~5 KB of HBM scratch per sample and stream in flight: "
-                         "24576 rays x 2 streams = ~145 GB of the 288 GB; three such streams do not fit and the caching "
+                         "28672 rays x 2 streams = ~170 GB of the 288 GB; three such streams do not fit and the caching "
                          "allocator then thrashes)")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the chunks of a step alternate over (run_step); 1 = one chunk at a time")
