@@ -158,3 +158,36 @@ def test_mlp_chain_input_window_and_frozen_input():
     ops.mlp_chain(x, ps2, acts).backward(gy)       # the input needs no gradient: the first layer runs the dx-free kernel
     for (w, b), (gw, gb) in zip(ps2, gref):
         assert _rel(w.grad, gw) < 1e-5 and _rel(b.grad, gb) < 1e-5
+
+
+def test_weight_norm_cache_semantics():
+    """VanillaMLP computes weight_norm(g, v) once per parameter version (network_utils._normed_weight): a second forward
+    reuses W and its autograd node; a backward spends the node (the next forward re-normalises); an in-place parameter
+    change is seen; a no_grad evaluation first does not hide the parameters from a later gradient pass."""
+    import rise_sdf_amd as R
+    from rise_sdf_amd.network_utils import get_mlp
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    cfg = R.Config({"otype": "VanillaMLP", "activation": "ReLU", "output_activation": "none", "n_neurons": 64,
+                    "n_hidden_layers": 2, "sphere_init": True, "sphere_init_radius": 0.5, "weight_norm": True})
+    net = get_mlp(35, 13, cfg).to(dev)
+    x = torch.randn(300, 35, device=dev)
+    with torch.no_grad():
+        y0 = net(x)                                   # no_grad first: must not poison the cache for the gradient pass
+    y1 = net(x)
+    assert torch.equal(y0, y1) and y1.requires_grad
+    y2 = net(2 * x)                                   # second evaluation in the same "step": same W node
+    (y1.sum() + y2.sum()).backward()
+    g_joint = [p.grad.clone() for p in net.parameters()]
+    assert all(torch.isfinite(g).all() and g.abs().sum() > 0 for g in g_joint)
+    net.zero_grad(set_to_none=True)
+    y1 = net(x)                                       # after a backward without an optimizer step: the node was spent
+    y1.sum().backward()
+    y2 = net(2 * x)
+    y2.sum().backward()                               # (would raise "backward through the graph a second time" if reused)
+    for a, b in zip(g_joint, [p.grad for p in net.parameters()]):
+        assert _rel(b, a) < 1e-5
+    with torch.no_grad():                             # an in-place parameter change is seen by the next forward
+        net.layers[0].weight_g.mul_(1.5)
+    y3 = net(x)
+    assert not torch.allclose(y3, y0)
