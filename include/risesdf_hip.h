@@ -113,6 +113,17 @@ int rsdf_accumulate_fwd(const int32_t *packed_info, const float *weights, const 
 int rsdf_accumulate_bwd(const int32_t *packed_info, const float *weights, const float *values,
                         const float *grad_out, int64_t n_rays, int D, float *grad_weights,
                         float *grad_values, void *stream);
+/* Opacity [n_rays] and depth [n_rays] of models/volrend.py:878-885 in one pass each way: accumulate_along_rays(weights, None)
+ * and accumulate_along_rays(weights, (t_starts + t_ends)[..., None] / 2.0) with the midpoint formed in the kernel;
+ * bit-identical to the two rsdf_accumulate_* calls.  Backward: grad_weights [S] = grad_opacity[ray] + grad_depth[ray] * mid
+ * (either gradient nullable = zero; samples outside packed_info are not written). */
+int rsdf_opacity_depth_fwd(const int32_t *packed_info, const float *weights, const float *t_starts, const float *t_ends,
+                           int64_t n_rays, float *opacity, float *depth,
+                           float *midpoints /* nullable: [S] = (t_starts + t_ends) / 2 of the samples packed_info owns */,
+                           void *stream);
+int rsdf_opacity_depth_bwd(const int32_t *packed_info, const float *t_starts, const float *t_ends,
+                           const float *grad_opacity /* nullable */, const float *grad_depth /* nullable */,
+                           int64_t n_rays, float *grad_weights, void *stream);
 
 /* ---- H1: multiresolution hash-grid encoding ----------------------------------------------------
  * replaces tcnn.Encoding(3, {otype: HashGrid, ...}) forward/backward (constructed

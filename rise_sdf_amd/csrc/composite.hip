@@ -161,6 +161,53 @@ accumulate_bwd_kernel(const int32_t *__restrict__ packed, const float *__restric
     }
 }
 
+// Opacity and depth of a ray in one pass (models/volrend.py:878-885: accumulate_along_rays(weights, None) and
+// accumulate_along_rays(weights, (t_starts + t_ends)[..., None] / 2.0)): the midpoint is formed here, as torch forms it (an
+// add, then the exact halving), and the two sums run in the kernels' own order above -- bit-identical to the two calls,
+// without the midpoint tensor (two elementwise passes over all samples), one of the two launches each way and autograd's
+// add of the two weight gradients.
+__global__ void __launch_bounds__(THREADS)
+opacity_depth_fwd_kernel(const int32_t *__restrict__ packed, const float *__restrict__ weights,
+                         const float *__restrict__ ts, const float *__restrict__ te, int64_t n_rays,
+                         float *__restrict__ opacity, float *__restrict__ depth, float *__restrict__ mid_out)
+{
+    const int64_t r = ray_of_wave();
+    if (r >= n_rays) return;
+    const int base = packed[2 * r], steps = packed[2 * r + 1];
+    const int lane = lane_id();
+    float a0 = 0.0f, a1 = 0.0f;
+    for (int j = lane; j < steps; j += 64) {
+        const float w = weights[base + j];
+        const float mid = (ts[base + j] + te[base + j]) / 2.0f;
+        if (mid_out) mid_out[base + j] = mid;            // (the training outputs' "points": models/neus.py:303)
+        a0 += w;
+        a1 = fmaf(w, mid, a1);
+    }
+    a0 = wave_sum(a0);
+    a1 = wave_sum(a1);
+    if (lane == 0) {
+        opacity[r] = a0;
+        depth[r] = a1;
+    }
+}
+
+// gw_i = g_opacity[r] + g_depth[r] * mid_i   (either gradient may be NULL = zero)
+__global__ void __launch_bounds__(THREADS)
+opacity_depth_bwd_kernel(const int32_t *__restrict__ packed, const float *__restrict__ ts, const float *__restrict__ te,
+                         const float *__restrict__ g_opacity, const float *__restrict__ g_depth, int64_t n_rays,
+                         float *__restrict__ gw)
+{
+    const int64_t r = ray_of_wave();
+    if (r >= n_rays) return;
+    const int base = packed[2 * r], steps = packed[2 * r + 1];
+    const float go = g_opacity ? g_opacity[r] : 0.0f, gd = g_depth ? g_depth[r] : 0.0f;
+    for (int j = lane_id(); j < steps; j += 64) {
+        const float mid = (ts[base + j] + te[base + j]) / 2.0f;
+        const float d = gd * mid;
+        gw[base + j] = g_opacity ? (g_depth ? go + d : go) : d;
+    }
+}
+
 // ---- channel-parallel forms for 4 <= D <= 64 (the 24-channel maps of the split-sum stage) ------------------------------
 // In the kernels above a lane is a sample and walks its D channels: at D = 24 every load / store instruction touches 64
 // rows 96 bytes apart (one 4-byte piece of 64 different lines), 24 times per sample tile.  Here a lane is a (sample slot,
@@ -278,6 +325,25 @@ int rsdf_accumulate_fwd(const int32_t *packed_info, const float *weights, const 
     else if (D <= 1) accumulate_fwd_kernel<1><<<grid, THREADS, 0, st>>>(packed_info, weights, values, n_rays, D, out);
     else if (D <= 4) accumulate_fwd_kernel<4><<<grid, THREADS, 0, st>>>(packed_info, weights, values, n_rays, D, out);
     else accumulate_fwd_kernel<8><<<grid, THREADS, 0, st>>>(packed_info, weights, values, n_rays, D, out);
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_opacity_depth_fwd(const int32_t *packed_info, const float *weights, const float *t_starts, const float *t_ends,
+                           int64_t n_rays, float *opacity, float *depth, float *midpoints, void *stream)
+{
+    if (n_rays <= 0) return 0;
+    opacity_depth_fwd_kernel<<<rsdf_blocks(n_rays * 64, THREADS), THREADS, 0, (hipStream_t)stream>>>(
+        packed_info, weights, t_starts, t_ends, n_rays, opacity, depth, midpoints);
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_opacity_depth_bwd(const int32_t *packed_info, const float *t_starts, const float *t_ends, const float *grad_opacity,
+                           const float *grad_depth, int64_t n_rays, float *grad_weights, void *stream)
+{
+    RSDF_CHECK_ARG(grad_opacity != nullptr || grad_depth != nullptr, "opacity_depth_bwd: both gradients are NULL");
+    if (n_rays <= 0) return 0;
+    opacity_depth_bwd_kernel<<<rsdf_blocks(n_rays * 64, THREADS), THREADS, 0, (hipStream_t)stream>>>(
+        packed_info, t_starts, t_ends, grad_opacity, grad_depth, n_rays, grad_weights);
     RSDF_RETURN_LAUNCH();
 }
 

@@ -226,10 +226,14 @@ class NeuSModel(BaseModel):
             sdf, sdf_grad, normal, alpha = ops.neus_alpha_fd(
                 out7, self.variance.effective_variance(), rays_d, ray_indices, t_starts, t_ends,
                 self.cos_anneal_ratio, self.geometry._finite_difference_eps, tap_major=tm)
-        midpoints = (t_starts + t_ends)[..., None] / 2.0
         weights, _ = ops.render_weight_from_alpha(alpha, packed_info=packed)
-        opacity = ops.accumulate_along_rays(weights, None, packed_info=packed)
-        depth = ops.accumulate_along_rays(weights, midpoints, packed_info=packed)
+        # opacity and depth (weights . (t_starts + t_ends) / 2) in one pass, bit-identical to the two accumulate calls
+        midpoints = None
+        if self.training:      # (the training outputs carry the sample midpoints, models/neus.py:303)
+            opacity, depth, midpoints = ops.accumulate_opacity_depth(weights, t_starts, t_ends, packed_info=packed,
+                                                                     want_midpoints=True)
+        else:
+            opacity, depth = ops.accumulate_opacity_depth(weights, t_starts, t_ends, packed_info=packed)
         comp_normal = ops.accumulate_along_rays(weights, normal, packed_info=packed)
         out = {
             "comp_normal_raw": comp_normal,

@@ -302,6 +302,47 @@ class _Accumulate(torch.autograd.Function):
         return None, gw, gv
 
 
+class _OpacityDepth(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, packed_info, weights, t_starts, t_ends, want_mid):
+        w, ts, te = _f32c(weights), _f32c(t_starts.reshape(-1)), _f32c(t_ends.reshape(-1))
+        require_device(packed_info, w, ts, te)
+        n_rays = packed_info.shape[0]
+        opacity = torch.empty(n_rays, 1, dtype=torch.float32, device=w.device)
+        depth = torch.empty(n_rays, 1, dtype=torch.float32, device=w.device)
+        mid = torch.empty_like(ts) if want_mid else None
+        check(lib().rsdf_opacity_depth_fwd(ptr(packed_info), ptr(w), ptr(ts), ptr(te), n_rays, ptr(opacity), ptr(depth),
+                                           ptr(mid), stream_ptr()), "opacity_depth_fwd")
+        ctx.save_for_backward(packed_info, ts, te)
+        ctx.n_samples = w.shape[0]
+        if want_mid:
+            ctx.mark_non_differentiable(mid)
+            return opacity, depth, mid
+        return opacity, depth
+
+    @staticmethod
+    def backward(ctx, g_op, g_depth, *_):
+        packed_info, ts, te = ctx.saved_tensors
+        if not ctx.needs_input_grad[1] or (g_op is None and g_depth is None):
+            return None, None, None, None, None
+        g_op = None if g_op is None else _f32c(g_op)
+        g_depth = None if g_depth is None else _f32c(g_depth)
+        gw = torch.empty(ctx.n_samples, dtype=torch.float32, device=ts.device)   # (packed_info owns every sample)
+        check(lib().rsdf_opacity_depth_bwd(ptr(packed_info), ptr(ts), ptr(te), ptr(g_op), ptr(g_depth),
+                                           packed_info.shape[0], ptr(gw), stream_ptr()), "opacity_depth_bwd")
+        return None, gw, None, None, None
+
+
+def accumulate_opacity_depth(weights, t_starts, t_ends, *, ray_indices=None, packed_info=None, n_rays=None,
+                             want_midpoints=False):
+    """models/volrend.py:878-885 in one kernel each way: -> (opacity [n_rays,1], depth [n_rays,1]) =
+    (accumulate_along_rays(weights, None), accumulate_along_rays(weights, (t_starts + t_ends)[..., None] / 2.0)), bit for
+    bit, without the midpoint tensor -- or, with ``want_midpoints``, with it as a third (non-differentiable) output [S].
+    t_starts / t_ends carry no gradient (they come from the marcher)."""
+    pk = _packed(ray_indices, packed_info, n_rays)
+    return _OpacityDepth.apply(pk, weights.reshape(-1), t_starts, t_ends, bool(want_midpoints))
+
+
 def accumulate_along_rays(weights, values=None, *, ray_indices=None, packed_info=None, n_rays=None):
     """nerfacc 0.5.3 signature (models/volrend.py:871-885): weights [S], values [S,D] or None ->
     [n_rays, D or 1]."""

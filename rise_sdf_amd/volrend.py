@@ -53,8 +53,7 @@ def rendering_with_normals_sdf(t_starts: Tensor, t_ends: Tensor, ray_indices: Op
         extras["sdf_laplace"] = sdf_laplace
     colors = ops.accumulate_along_rays(weights, rgbs, packed_info=packed)
     normals_map = ops.accumulate_along_rays(weights, normals, packed_info=packed)
-    opacities = ops.accumulate_along_rays(weights, None, packed_info=packed)
-    depths = ops.accumulate_along_rays(weights, (t_starts + t_ends)[..., None] / 2.0, packed_info=packed)
+    opacities, depths = ops.accumulate_opacity_depth(weights, t_starts, t_ends, packed_info=packed)   # (one pass, same bits)
     if render_bkgd is not None:
         colors = colors + render_bkgd * (1.0 - opacities)
         normals_map = normals_map + render_bkgd * (1 - opacities) * torch.tensor([0.0, 0.0, 1.0], device=dev)
@@ -75,6 +74,5 @@ def secondary_rendering(t_starts: Tensor, t_ends: Tensor, ray_indices: Tensor, n
         alphas = torch.empty((0,), device=dev)
     packed = ops.pack_info(ray_indices, n_rays)
     weights, trans = ops.render_weight_from_alpha(alphas, packed_info=packed)
-    opacities = ops.accumulate_along_rays(weights, None, packed_info=packed)
-    depths = ops.accumulate_along_rays(weights, (t_starts + t_ends)[..., None] / 2.0, packed_info=packed)
+    opacities, depths = ops.accumulate_opacity_depth(weights, t_starts, t_ends, packed_info=packed)
     return opacities, depths, {"weights": weights, "trans": trans, "alphas": alphas}

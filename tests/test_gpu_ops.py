@@ -185,6 +185,42 @@ def test_accumulate_fwd_bwd(dev, ops, D):
                               rtol=1e-5, atol=1e-5)
 
 
+def test_opacity_and_depth_in_one_pass(dev, ops):
+    """models/volrend.py:878-885: ops.accumulate_opacity_depth == the two accumulate_along_rays calls bit for bit (values
+    and the weight gradient), == the oracle within fp32 rounding; rays without samples included; the optional midpoints
+    output equals (t_starts + t_ends) / 2."""
+    counts, ri = _ragged(300, 150, 9)
+    g = torch.Generator().manual_seed(11)
+    w = torch.rand(ri.numel(), generator=g)
+    ts = torch.rand(ri.numel(), generator=g) * 3.0
+    te = ts + torch.rand(ri.numel(), generator=g) * 0.01
+    g_op, g_d = torch.randn(300, 1, generator=g), torch.randn(300, 1, generator=g)
+    rid, tsd, ted = ri.to(dev), ts.to(dev), te.to(dev)
+    w1 = w.to(dev).requires_grad_(True)
+    op1 = ops.accumulate_along_rays(w1, None, ray_indices=rid, n_rays=300)
+    d1 = ops.accumulate_along_rays(w1, (tsd + ted)[..., None] / 2.0, ray_indices=rid, n_rays=300)
+    ((op1 * g_op.to(dev)).sum() + (d1 * g_d.to(dev)).sum()).backward()
+    w2 = w.to(dev).requires_grad_(True)
+    op2, d2, mid = ops.accumulate_opacity_depth(w2, tsd, ted, ray_indices=rid, n_rays=300, want_midpoints=True)
+    ((op2 * g_op.to(dev)).sum() + (d2 * g_d.to(dev)).sum()).backward()
+    assert torch.equal(op2, op1) and torch.equal(d2, d1)
+    assert torch.equal(w2.grad, w1.grad)
+    assert torch.equal(mid, (tsd + ted) / 2.0) and not mid.requires_grad
+    w_o = w.clone().requires_grad_(True)
+    op_o = oracle.accumulate_along_rays(w_o, None, ray_indices=ri, n_rays=300)
+    d_o = oracle.accumulate_along_rays(w_o, (ts + te)[..., None] / 2.0, ray_indices=ri, n_rays=300)
+    ((op_o * g_op).sum() + (d_o * g_d).sum()).backward()
+    assert torch.allclose(op2.cpu(), op_o.detach(), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(d2.cpu(), d_o.detach(), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(w2.grad.cpu(), w_o.grad, rtol=1e-5, atol=1e-5)
+    w3 = w.to(dev).requires_grad_(True)                       # only one of the two outputs is used downstream
+    op3, d3 = ops.accumulate_opacity_depth(w3, tsd, ted, ray_indices=rid, n_rays=300)
+    (d3 * g_d.to(dev)).sum().backward()
+    w4 = w.to(dev).requires_grad_(True)
+    (ops.accumulate_along_rays(w4, (tsd + ted)[..., None] / 2.0, ray_indices=rid, n_rays=300) * g_d.to(dev)).sum().backward()
+    assert torch.equal(w3.grad, w4.grad)
+
+
 # ---- H1 -------------------------------------------------------------------------------------------
 GRIDS = [dict(n_levels=4, n_features=2, log2_hashmap_size=14, base_resolution=16, per_level_scale=1.5),
          dict(n_levels=16, n_features=2, log2_hashmap_size=19, base_resolution=32,
