@@ -53,6 +53,18 @@ def _scan_scratch(n, device):
     return torch.empty(max(int(lib().rsdf_scan_scratch_bytes(n)), 4), dtype=torch.uint8, device=device)
 
 
+# The marcher knows the packed_info of the ray_indices it returns; nerfacc's sampling() API hands on ray_indices only
+# and the renderer packs them again (lib/nerfacc/pack.py:47-78: a run-boundary pass over all samples + a scan).  The last
+# marcher result is remembered by the IDENTITY of its ray_indices tensor (a weak reference: no address or shape
+# comparison that a recycled allocation could satisfy); pack_info() returns it for that very tensor.
+_LAST_PACKED = [None, None, 0]      # weakref to ray_indices, packed_info, n_rays
+
+
+def _remember_packed(ray_indices, packed, n_rays):
+    import weakref
+    _LAST_PACKED[0], _LAST_PACKED[1], _LAST_PACKED[2] = weakref.ref(ray_indices), packed, int(n_rays)
+
+
 @torch.no_grad()
 def march(rays_o, rays_d, t_min, t_max, roi, binary, step_size, cone_angle=0.0):
     """The two-pass marcher of lib/nerfacc/cuda/csrc/ray_marching.cu:194-289.
@@ -83,6 +95,7 @@ def march(rays_o, rays_d, t_min, t_max, roi, binary, step_size, cone_angle=0.0):
         check(lib().rsdf_march_write(ptr(o), ptr(d), ptr(tn), ptr(tf), ptr(r), ptr(b), rx, ry, rz,
                                      float(step_size), float(cone_angle), n, ptr(packed), ptr(ri),
                                      ptr(ts), ptr(te), st), "march_write")
+    _remember_packed(ri, packed, n)
     return packed, ri, ts, te
 
 
@@ -137,6 +150,9 @@ def query_occ(samples, roi, binary, return_cell=False):
 @torch.no_grad()
 def pack_info(ray_indices, n_rays):
     """lib/nerfacc/pack.py:47-78: sorted int64 ray_indices [S] -> packed_info int32 [n_rays, 2]."""
+    ref = _LAST_PACKED[0]
+    if ref is not None and ref() is ray_indices and _LAST_PACKED[2] == int(n_rays) and ray_indices._version == 0:
+        return _LAST_PACKED[1]           # the marcher's own packed_info of this very tensor
     ri = ray_indices.to(torch.int64).contiguous()
     require_device(ri)
     dev = ri.device

@@ -103,6 +103,27 @@ def _ragged(n_rays, max_len, seed, empty_every=5):
     return counts, ri
 
 
+def test_pack_info_of_the_marchers_own_ray_indices(dev, ops):
+    """ops.pack_info returns the marcher's packed_info when it is handed the very ray_indices tensor the marcher returned
+    (remembered by identity), and recomputes for any other tensor -- equal content either way; a copy, a slice, or an
+    in-place change of the tensor all take the recomputation."""
+    from helpers import camera_rays, sphere_binary
+    rays = camera_rays(20, 20, seed=4)
+    roi = torch.tensor([-1.5, -1.5, -1.5, 1.5, 1.5, 1.5])
+    binary = sphere_binary(32, 0.3, 0.9)
+    ro, rd = rays[:, :3].contiguous().to(dev), rays[:, 3:].contiguous().to(dev)
+    tmin, tmax = ops.ray_aabb_intersect(ro, rd, roi.to(dev))
+    pk, ri, ts, te = ops.march(ro, rd, tmin, tmax, roi.to(dev), binary.to(dev), 3.0 / 256)
+    assert ri.numel() > 0
+    assert ops.pack_info(ri, ro.shape[0]) is pk
+    again = ops.pack_info(ri.clone(), ro.shape[0])
+    assert again is not pk and torch.equal(again, pk)
+    assert ops.pack_info(ri, ro.shape[0] + 1) is not pk            # another ray count: recomputed
+    assert torch.equal(pk.cpu(), oracle.pack_info(ri.cpu(), ro.shape[0]))
+    ri.add_(0)                                                       # touched in place: no longer trusted
+    assert ops.pack_info(ri, ro.shape[0]) is not pk
+
+
 def test_pack_unpack_compact(dev, ops):
     counts, ri = _ragged(1000, 300, 1)
     pk = oracle.pack_info(ri, 1000)
