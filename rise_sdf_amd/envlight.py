@@ -230,6 +230,11 @@ class EnvironmentLightMipCube(nn.Module):
         self.specular, self.diffuse = None, None
         self._ready = None        # event of a build_mips_on() whose results the current stream has not waited for yet
 
+    def __getstate__(self):
+        d = self.__dict__.copy()        # (a pending event is not state: copy.deepcopy / pickle of a light that has run)
+        d["_ready"] = None
+        return d
+
     def build_mips_on(self, stream, cutoff=0.99):
         """build_mips() issued on ``stream`` (a side stream), ordered after everything already enqueued on the current one;
         eval_mip() makes the consuming stream wait for it.  The prefilter is vector-ALU work on an L2-resident cube map,

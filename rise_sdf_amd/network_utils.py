@@ -164,6 +164,12 @@ class VanillaMLP(nn.Module):
     def make_activation(self):
         return nn.Softplus(beta=100) if self.sphere_init else nn.ReLU(inplace=True)
 
+    def __getstate__(self):
+        # (copy.deepcopy / pickle of a module that has run: the cached W tensors carry autograd nodes and are not state)
+        d = self.__dict__.copy()
+        d["_wn_cache"] = {}
+        return d
+
     def _normed_weight(self, m):
         """weight_norm(g, v) of one layer, computed ONCE per parameter version: a training step evaluates the SDF network
         five times (sampling, render, secondary rays, their sampling, curvature), which re-normalised every layer each time
