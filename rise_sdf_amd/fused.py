@@ -7,6 +7,10 @@ cache lines and nothing 35 columns wide ever goes through autograd.
 
 Forward:  x7t -> planes (rsdf_hashgrid_fwd_fd7: one gather of the centre cell + 4 corners per displaced
           tap) -> sdf7t [7][S] (+ feature [S,N2] of the centre taps) (rsdf_sdfmlp_fd7_fwd).
+          Round 4, H = 64 in fp32: the gather writes the MLP kernels' input PRE-SPLIT into bf16 parts as column planes
+          (``x3`` [7][3][35][S rounded up to 32], rsdf_hashgrid_fwd_fd7_x3) and both MLP kernels consume that image
+          (rsdf_sdfmlp_fd7_fwd_x3 / _bwd_x3): same values bit for bit, without the per-kernel split of the 35 input
+          columns and without the backward's staging pass.  ``RSDF_X3=0`` keeps the fp32 planes for A/B.
 Backward: d_sdf7t (+ d_feature, first pushed through the feature rows of the last layer into a [S,H] scratch)
           -> rsdf_sdfmlp_fd7_bwd (recomputes the hidden layers; weight / bias gradients and d_planes)
           -> rsdf_hashgrid_bwd_fd7 (merge, bin through LDS, reduce in LDS) ->
@@ -18,6 +22,7 @@ This is what VolumeSDF.forward does for finite-difference normals between ``poin
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 
@@ -30,6 +35,13 @@ def supported(K0: int, H: int, N2: int, n_hidden_layers: int, hidden_act: str, o
     return (n_hidden_layers == 2 and hidden_act == "softplus100" and out_act == "none"
             and n_features == 2 and (K0 - 3) % 2 == 0 and (K0 - 3) // 2 <= 16
             and bool(lib().rsdf_sdfmlp_fd7_supported(int(K0), int(H), int(N2))))
+
+
+def use_x3(K0: int, H: int, N2: int, precision: str) -> bool:
+    """The pre-split input image serves the H = 64 fp32 kernels (forward per-wave kernel + quad backward)."""
+    return (precision == "fp32" and H == 64 and os.environ.get("RSDF_X3", "1") != "0"
+            and os.environ.get("RSDF_MLP_FWD", "") != "coop" and os.environ.get("RSDF_MLP_BWD", "") == ""
+            and bool(lib().rsdf_sdfmlp_fd7_x3_supported(int(K0), int(H), int(N2))))
 
 
 class _SdfFieldFD7(torch.autograd.Function):
@@ -46,14 +58,25 @@ class _SdfFieldFD7(torch.autograd.Function):
         H, N2 = ws[0].shape[0], ws[4].shape[0]
         dev = xf.device
         st = stream_ptr()
-        planes = torch.empty(Lv, 7, S, 2, dtype=torch.float32, device=dev)
+        x3 = None
         pts = None
         if points is not None:
-            # the hash kernels derive the stencil from the world-space centres (12 instead of 84 bytes per sample and
-            # level); x7t still feeds the xyz columns of the MLP kernels, which read it once
             pts = points.detach().to(torch.float32).contiguous()
             require_device(pts)
             assert pts.shape == (S, 3), "points must be [S,3]"
+        if S > 0 and use_x3(3 + 2 * Lv, H, N2, precision):
+            x3 = torch.empty(int(lib().rsdf_x3_bytes(S)), dtype=torch.uint8, device=dev)
+            check(lib().rsdf_hashgrid_fwd_fd7_x3(None if pts is not None else ptr(xf), ptr(pts), float(radius or 0.0),
+                                                 float(eps or 0.0), ptr(tb), ctypes.byref(meta), S, n_active,
+                                                 float(xyz_scale), float(xyz_offset), ptr(x3), st), "hashgrid_fwd_fd7_x3")
+            planes = x3
+        else:
+            planes = torch.empty(Lv, 7, S, 2, dtype=torch.float32, device=dev)
+        if x3 is not None:
+            pass
+        elif points is not None:
+            # the hash kernels derive the stencil from the world-space centres (12 instead of 84 bytes per sample and
+            # level); x7t still feeds the xyz columns of the MLP kernels, which read it once
             check(lib().rsdf_hashgrid_fwd_fd7_pts(ptr(pts), float(radius), float(eps), ptr(tb), ctypes.byref(meta), S,
                                                   n_active, ptr(planes), st), "hashgrid_fwd_fd7_pts")
         else:
@@ -62,9 +85,14 @@ class _SdfFieldFD7(torch.autograd.Function):
         sdf7t = torch.empty(7, S, dtype=torch.float32, device=dev)
         feature = torch.empty(S, N2, dtype=torch.float32, device=dev) if want_feature else None
         h2c = torch.empty(S, H, dtype=torch.float32, device=dev) if want_feature else None
-        check(L.mlp_fn("rsdf_sdfmlp_fd7_fwd", precision)(ptr(xf), ptr(planes), Lv, n_active, float(xyz_scale),
-                                        float(xyz_offset), H, N2, *[ptr(t) for t in ws], S, ptr(sdf7t),
-                                        ptr(feature), ptr(h2c), st), "sdfmlp_fd7_fwd")
+        if x3 is not None:
+            check(lib().rsdf_sdfmlp_fd7_fwd_x3(ptr(x3), Lv, H, N2, *[ptr(t) for t in ws], S, ptr(sdf7t), ptr(feature),
+                                               ptr(h2c), st), "sdfmlp_fd7_fwd_x3")
+        else:
+            check(L.mlp_fn("rsdf_sdfmlp_fd7_fwd", precision)(ptr(xf), ptr(planes), Lv, n_active, float(xyz_scale),
+                                            float(xyz_offset), H, N2, *[ptr(t) for t in ws], S, ptr(sdf7t),
+                                            ptr(feature), ptr(h2c), st), "sdfmlp_fd7_fwd")
+        ctx.x3 = x3 is not None
         ctx.save_for_backward(xf, planes, *ws)
         ctx.h2c = h2c
         ctx.pts, ctx.radius, ctx.eps, ctx.precision = pts, radius, eps, precision
@@ -86,15 +114,20 @@ class _SdfFieldFD7(torch.autograd.Function):
             else g_sdf7t.detach().to(torch.float32).contiguous()
         gf = None if g_feature is None else g_feature.detach().to(torch.float32).contiguous()
         need_table = ctx.needs_input_grad[1]
-        d_planes = torch.empty_like(planes) if need_table else None
+        d_planes = torch.empty(Lv, 7, S, 2, dtype=torch.float32, device=dev) if need_table else None
         dw0, db0 = torch.zeros_like(w0), torch.zeros_like(b0)
         dw1, db1 = torch.zeros_like(w1), torch.zeros_like(b1)
         dw2, db2 = torch.zeros_like(w2), torch.zeros_like(b2)
         dh2c = torch.empty(S, H, dtype=torch.float32, device=dev) if gf is not None else None
-        check(L.mlp_fn("rsdf_sdfmlp_fd7_bwd", ctx.precision)(ptr(xf), ptr(planes), Lv, ctx.n_active, ctx.xyz[0], ctx.xyz[1],
-                                        H, N2, ptr(w0), ptr(b0), ptr(w1), ptr(b1), ptr(w2), ptr(b2), S,
-                                        ptr(g), ptr(gf), ptr(dh2c), ptr(d_planes), ptr(dw0), ptr(db0), ptr(dw1),
-                                        ptr(db1), ptr(dw2), ptr(db2), st), "sdfmlp_fd7_bwd")
+        if ctx.x3:
+            check(lib().rsdf_sdfmlp_fd7_bwd_x3(ptr(planes), Lv, ctx.n_active, H, N2, ptr(w0), ptr(b0), ptr(w1), ptr(b1),
+                                               ptr(w2), ptr(b2), S, ptr(g), ptr(gf), ptr(dh2c), ptr(d_planes), ptr(dw0),
+                                               ptr(db0), ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), st), "sdfmlp_fd7_bwd_x3")
+        else:
+            check(L.mlp_fn("rsdf_sdfmlp_fd7_bwd", ctx.precision)(ptr(xf), ptr(planes), Lv, ctx.n_active, ctx.xyz[0], ctx.xyz[1],
+                                            H, N2, ptr(w0), ptr(b0), ptr(w1), ptr(b1), ptr(w2), ptr(b2), S,
+                                            ptr(g), ptr(gf), ptr(dh2c), ptr(d_planes), ptr(dw0), ptr(db0), ptr(dw1),
+                                            ptr(db1), ptr(dw2), ptr(db2), st), "sdfmlp_fd7_bwd")
         if gf is not None:
             # feature rows of the last layer: dW2 += d_feature^T h2(centre), db2 += colsum(d_feature)
             check(L.mlp_fn("rsdf_linear_bwd_weight", ctx.precision)(ptr(gf), N2, ptr(ctx.h2c), H, S, H, N2, ptr(dw2),
