@@ -288,31 +288,38 @@ int rsdf_sdfmlp_fd7_bwd(const float *x7t, const float *planes, int n_levels, int
                         const float *b2, int64_t n_samples, const float *d_sdf7t,
                         const float *d_feature, float *dh2c_scratch /*nullable*/, float *d_planes, float *dw0,
                         float *db0, float *dw1, float *db1, float *dw2, float *db2, void *stream);
-/* ---- The same fused node on a PRE-SPLIT input image ("x3", round 4).  The fused kernels evaluate every fp32 product as six
- * bf16 products of three-way split operands; instead of each MLP kernel splitting the 35 input columns of every tap
- * again, the stencil gather writes the three bf16 parts (h + m + l == the fp32 value exactly) once, as column planes:
- *     x3 [tap 7][part 3][column 35][rows]  bf16,  rows = rsdf_x3_rows(n) = n rounded up to 32 (rows >= n are zeros)
- *     column 2 l + f = feature f of level l (levels >= n_active_levels: zeros); columns 32..34 = the tap's x, y, z in
- *     the unit cube * xyz_scale + xyz_offset (what CompositeEncoding's include_xyz passes through,
- *     models/network_utils.py:71-88).
- * rsdf_hashgrid_fwd_fd7_x3 takes the stencil either as x7t [7][n][3] (points = NULL) or derived from the world-space
- * centres points [n][3] with radius / eps (x7t = NULL), exactly as rsdf_hashgrid_fwd_fd7 / _pts do; the values are
- * bit-identical to splitting their fp32 planes.  The MLP entry points replace (x7t, planes, xyz_scale, xyz_offset) by x3:
- * H <= 64 forward, H = 64 backward (rsdf_sdfmlp_fd7_x3_supported); same outputs and gradient contract as above. */
-int64_t rsdf_x3_rows(int64_t n_samples);
-int64_t rsdf_x3_bytes(int64_t n_samples);
-int rsdf_hashgrid_fwd_fd7_x3(const float *x7t /*or NULL*/, const float *points /*or NULL*/, float radius, float eps,
+/* ---- The same fused node in the "x2" form (round 4; csrc/mlp_x2.hip): every fp32 matrix operand is carried as TWO fp16
+ * parts (v S = hi + lo with a power-of-two class scale S: v to 2^-24 relative, i.e. half an fp32 ulp) and every product is
+ * three v_mfma_f32_*_f16 instructions with fp32 accumulation (the form above: three bf16 parts, six products).  A layer's
+ * error is that of an fp32 GEMM (~1e-7 of the largest output).  The input arrives PRE-SPLIT: the stencil gather writes, in
+ * place of the fp32 planes and at the same 2 x 16 bits per value,
+ *     x2 [tile = row / 32][tap 7][part 2][column 36][32 rows] fp16,   rsdf_x2_bytes(n) bytes, rows = rsdf_x2_rows(n)
+ *     column 2 l + f = feature f of level l (levels >= n_active_levels: zeros), 32..34 = the tap's x, y, z in the unit
+ *     cube * xyz_scale + xyz_offset (CompositeEncoding's include_xyz pass-through, models/network_utils.py:71-88), 35 = 1
+ *     (the bias column); all times 2^8; rows >= n of the last tile are zeros; the two 16-row halves of columns with bit 3
+ *     of their index set are swapped (an LDS bank swizzle the MLP kernels expect).
+ * rsdf_hashgrid_fwd_fd7_x2 takes the stencil either as x7t [7][n][3] (points = NULL) or derived from the world-space
+ * centres points [n][3] with radius / eps (x7t = NULL), exactly as rsdf_hashgrid_fwd_fd7 / _pts do; hi + lo == the value
+ * those write, times 2^8, to 2^-24.  The MLP entry points replace (x7t, planes, xyz_scale, xyz_offset) by x2: forward
+ * H <= 64, backward H = 64 (rsdf_sdfmlp_fd7_x2_supported); same outputs and gradient contract as rsdf_sdfmlp_fd7_fwd / _bwd.
+ * bwd additionally needs absmax_scratch (8 bytes of device memory): it scans d_sdf7t (and d_feature's d(h2)) for their
+ * largest magnitude first, from which the kernel derives the power-of-two scale of its fp16 gradient images.
+ * Preconditions (fp16 range; a violation overflows to inf / nan, never silently): |input| < 255, |weight| < 1023,
+ * |hidden activation| < 1023. */
+int64_t rsdf_x2_rows(int64_t n_samples);
+int64_t rsdf_x2_bytes(int64_t n_samples);
+int rsdf_hashgrid_fwd_fd7_x2(const float *x7t /*or NULL*/, const float *points /*or NULL*/, float radius, float eps,
                              const float *table, const rsdf_grid_meta *meta /*host*/, int64_t n_samples,
-                             int n_active_levels, float xyz_scale, float xyz_offset, void *x3, void *stream);
-int rsdf_sdfmlp_fd7_x3_supported(int K0, int H, int N2);
-int rsdf_sdfmlp_fd7_fwd_x3(const void *x3, int n_levels, int H, int N2, const float *w0, const float *b0,
+                             int n_active_levels, float xyz_scale, float xyz_offset, void *x2, void *stream);
+int rsdf_sdfmlp_fd7_x2_supported(int K0, int H, int N2);
+int rsdf_sdfmlp_fd7_fwd_x2(const void *x2, int n_levels, int H, int N2, const float *w0, const float *b0,
                            const float *w1, const float *b1, const float *w2, const float *b2, int64_t n_samples,
                            float *sdf7t, float *feature, float *h2c, void *stream);
-int rsdf_sdfmlp_fd7_bwd_x3(const void *x3, int n_levels, int n_active_levels, int H, int N2, const float *w0,
+int rsdf_sdfmlp_fd7_bwd_x2(const void *x2, int n_levels, int n_active_levels, int H, int N2, const float *w0,
                            const float *b0, const float *w1, const float *b1, const float *w2, const float *b2,
                            int64_t n_samples, const float *d_sdf7t, const float *d_feature,
-                           float *dh2c_scratch /*nullable*/, float *d_planes, float *dw0, float *db0, float *dw1,
-                           float *db1, float *dw2, float *db2, void *stream);
+                           float *dh2c_scratch /*nullable*/, void *absmax_scratch /*8 bytes*/, float *d_planes,
+                           float *dw0, float *db0, float *dw1, float *db1, float *dw2, float *db2, void *stream);
 /* ---- config[4]'s "bf16 MLP on MFMA" (BASELINE.json configs[4]; models/network_utils.py:109-157 at reduced matrix
  * precision): the same entry points with the suffix _bf16.  Same arguments, layouts and fp32 tensors; every matrix
  * operand (weights, activations, gradients) is rounded ONCE to bf16 (round to nearest even) and each k-step is ONE

@@ -91,12 +91,12 @@ _SIGNATURES = {
     "rsdf_linear_bwd_fused_ws": [_P, _P, _I, _P, _I, _P, _L, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P, _L, _P],
     "rsdf_linear_bwd_fused_tail_ws": [_P, _I, _P, _P, _I, _P, _I, _P, _L, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P, _L, _P],
     "rsdf_sdfmlp_fd7_supported": [_I, _I, _I],
-    "rsdf_x3_rows": [_L],
-    "rsdf_x3_bytes": [_L],
-    "rsdf_hashgrid_fwd_fd7_x3": [_P, _P, _F, _F, _P, ctypes.POINTER(GridMeta), _L, _I, _F, _F, _P, _P],
-    "rsdf_sdfmlp_fd7_x3_supported": [_I, _I, _I],
-    "rsdf_sdfmlp_fd7_fwd_x3": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P],
-    "rsdf_sdfmlp_fd7_bwd_x3": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+    "rsdf_x2_rows": [_L],
+    "rsdf_x2_bytes": [_L],
+    "rsdf_hashgrid_fwd_fd7_x2": [_P, _P, _F, _F, _P, ctypes.POINTER(GridMeta), _L, _I, _F, _F, _P, _P],
+    "rsdf_sdfmlp_fd7_x2_supported": [_I, _I, _I],
+    "rsdf_sdfmlp_fd7_fwd_x2": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P],
+    "rsdf_sdfmlp_fd7_bwd_x2": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                _P],
     "rsdf_sdfmlp_fd7_fwd": [_P, _P, _I, _I, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P],
     "rsdf_sdfmlp_fd7_bwd": [_P, _P, _I, _I, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P,
@@ -160,7 +160,7 @@ def mlp_fn(name, precision="fp32"):
 
 
 _RESTYPES = {"rsdf_last_error": ctypes.c_char_p, "rsdf_scan_scratch_bytes": ctypes.c_int64,
-             "rsdf_x3_rows": ctypes.c_int64, "rsdf_x3_bytes": ctypes.c_int64,
+             "rsdf_x2_rows": ctypes.c_int64, "rsdf_x2_bytes": ctypes.c_int64,
              "rsdf_grid_meta_init": ctypes.c_int64,
              "rsdf_hashgrid_bwd_fd7_scratch_bytes": ctypes.c_int64,
              "rsdf_hashgrid_scatter_binned_scratch_bytes": ctypes.c_int64,

@@ -28,7 +28,6 @@
 #include <stdlib.h>
 
 #include "hashgrid_common.h"
-#include "split_bf16.h"
 
 namespace {
 
@@ -246,70 +245,83 @@ __device__ __forceinline__ void load_stencil(const TapSrc &src, int64_t S, int64
 }
 
 // ------------------------------------------------------------------------------------------------
-// "x3" output of the forward (round 4): the MLP kernels' input image, PRE-SPLIT.  The fused SDF-MLP kernels evaluate every
-// fp32 product as six bf16 products of three-way split operands (split_bf16.h); until round 3 each of them split the same
-// 35 input columns x 7 taps again (5.5 vector instructions per value in kernels that are bound by vector issue, and the
-// whole "staging" phase of the backward).  The split is a deterministic function of the value, so the gather performs it
-// once and writes the three bf16 parts TILE BY TILE in the very layout the MLP kernels keep in LDS:
-//     x3 [tile = row / 32][tap 7][part 3 (h, m, l)][column 36][32 rows] bf16     (6912 contiguous bytes per tile and tap)
+// "x2" output of the forward (round 4): the fused SDF-MLP kernels' input image, PRE-SPLIT.  Those kernels (mlp_x2.hip)
+// carry every fp32 matrix operand as two fp16 parts, v 2^8 = hi + lo (hi = RNE_f16(v 2^8), lo = RNE_f16(v 2^8 - hi): v to
+// 2^-24 relative, 2^-33 absolute near zero).  The split is a deterministic function of the value, so instead of each MLP
+// kernel splitting the 36 input columns of all 7 taps again (and the backward running a whole staging pass for it), the
+// gather performs it once and writes the parts TILE BY TILE in the layout the MLP kernels keep in LDS -- 2 x 16 bits per
+// value, the same bytes as the fp32 planes:
+//     x2 [tile = row / 32][tap 7][part 2 (hi, lo)][column 36][32 rows] fp16      (4608 contiguous bytes per tile and tap)
 //     column 2 l + f = feature f of level l (levels >= n_active_levels: zeros), columns 32..34 = x, y, z of the tap
-//     (unit cube) * xyz_scale + xyz_offset, column 35 = 1 (the bias column); rows >= n_samples of the last tile are zeros;
-//     inside a column with bit 3 of its index set the two 16-row halves are swapped (byte ^ 32): the LDS bank swizzle.
+//     (unit cube) * xyz_scale + xyz_offset, column 35 = 1 (the bias column), all times 2^8; rows >= n_samples of the last
+//     tile are zeros; inside a column with bit 3 of its index set the two 16-row halves are swapped (byte ^ 32): the LDS
+//     bank swizzle.
 // A column is 64 bytes, a 16-byte unit 8 consecutive rows of one column: the MLP backward lands a tile with linear LDS-DMA
 // (no staging pass), and both MLP kernels read layer-1 fragments with ds_read_b64_tr_b16 (columns are the MFMA k
-// dimension) and weight-gradient fragments with ds_read_b128 (rows are).  h + m + l == the fp32 value exactly, part by
-// part what split3_pair() gave the kernels before.
+// dimension) and weight-gradient fragments with ds_read_b128 (rows are).  Precondition: |value| < 255 (fp16 range).
 // ------------------------------------------------------------------------------------------------
-constexpr int X3_COLS = 36;
-constexpr int X3_PART_B = X3_COLS * 64, X3_TAP_B = 3 * X3_PART_B, X3_TILE_B = 7 * X3_TAP_B;
-struct X3Out {
+constexpr int X2_COLS = 36;
+constexpr int X2_PART_B = X2_COLS * 64, X2_TAP_B = 2 * X2_PART_B, X2_TILE_B = 7 * X2_TAP_B;
+constexpr float X2_SCALE = 256.0f;
+struct X2Out {
     unsigned char *base;
     int64_t Sp;
     float xyz_scale, xyz_offset;
 };
-// byte address of (row s, tap, part, column)
-__device__ __forceinline__ unsigned char *x3_at(const X3Out &o, int64_t s, int tap, int part, int col)
+using x2_f32x2 = __attribute__((ext_vector_type(2))) float;
+using x2_f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+__device__ __forceinline__ unsigned x2_pack(float a, float b)        // v_cvt_pk_f16_f32 (round to nearest even); a -> low half
 {
-    return o.base + (s >> 5) * X3_TILE_B + tap * X3_TAP_B + part * X3_PART_B + col * 64 +
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(x2_f32x2{a, b}, x2_f16x2));
+}
+// (a, b) already scaled -> hi, lo exactly as mlp_x2.hip's split2_pair forms them
+__device__ __forceinline__ void x2_split(float a, float b, unsigned &h, unsigned &l)
+{
+    h = x2_pack(a, b);
+    const x2_f16x2 hh = __builtin_bit_cast(x2_f16x2, h);
+    l = x2_pack(a - (float)hh[0], b - (float)hh[1]);
+}
+// byte address of (row s, tap, part, column)
+__device__ __forceinline__ unsigned char *x2_at(const X2Out &o, int64_t s, int tap, int part, int col)
+{
+    return o.base + (s >> 5) * X2_TILE_B + tap * X2_TAP_B + part * X2_PART_B + col * 64 +
            ((2 * (int)(s & 31)) ^ (32 * ((col >> 3) & 1)));
 }
 // Lane pairs (2 i, 2 i + 1) hold rows (s, s + 1): the even lane ends up with feature 0 of both rows, the odd lane with
 // feature 1 of both -- one dword store per lane; the two columns of a level are adjacent, so a wave instruction writes one
 // full 128-byte line per tile.
-__device__ __forceinline__ unsigned x3_pair_exchange(unsigned own, bool odd)
+__device__ __forceinline__ unsigned x2_pair_exchange(unsigned own, bool odd)
 {
     // lane ^ 1 through DPP quad_perm [1,0,3,2] (a vector-ALU move)
     const unsigned nb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own, 0xB1, 0xF, 0xF, true);
     // even: {own.lo16, nb.lo16}; odd: {nb.hi16, own.hi16}
     return odd ? __builtin_amdgcn_perm(nb, own, 0x03020706u) : __builtin_amdgcn_perm(nb, own, 0x05040100u);
 }
-__device__ __forceinline__ void x3_store_features(unsigned char *p, bool odd, float f0, float f1)
+__device__ __forceinline__ void x2_store_features(unsigned char *p, bool odd, float f0, float f1)
 {
-    unsigned h, m, lo;
-    split3_pair(f0, f1, h, m, lo);
-    *reinterpret_cast<unsigned *>(p) = x3_pair_exchange(h, odd);
-    *reinterpret_cast<unsigned *>(p + X3_PART_B) = x3_pair_exchange(m, odd);
-    *reinterpret_cast<unsigned *>(p + 2 * X3_PART_B) = x3_pair_exchange(lo, odd);
+    unsigned h, lo;
+    x2_split(f0 * X2_SCALE, f1 * X2_SCALE, h, lo);
+    *reinterpret_cast<unsigned *>(p) = x2_pair_exchange(h, odd);
+    *reinterpret_cast<unsigned *>(p + X2_PART_B) = x2_pair_exchange(lo, odd);
 }
-__device__ __forceinline__ void x3_store_col(const X3Out &o, int tap, int col, int64_t s, float v)
+__device__ __forceinline__ void x2_store_col(const X2Out &o, int tap, int col, int64_t s, float v)
 {
-    unsigned h, m, lo;
-    split3_pair(v, 0.0f, h, m, lo);
-    unsigned char *p = x3_at(o, s, tap, 0, col);
+    unsigned h, lo;
+    x2_split(v * X2_SCALE, 0.0f, h, lo);
+    unsigned char *p = x2_at(o, s, tap, 0, col);
     *reinterpret_cast<unsigned short *>(p) = (unsigned short)h;
-    *reinterpret_cast<unsigned short *>(p + X3_PART_B) = (unsigned short)m;
-    *reinterpret_cast<unsigned short *>(p + 2 * X3_PART_B) = (unsigned short)lo;
+    *reinterpret_cast<unsigned short *>(p + X2_PART_B) = (unsigned short)lo;
 }
-__device__ __forceinline__ void x3_store_xyz(const X3Out &o, int tap, int k, int64_t s, float u, bool pad)
+__device__ __forceinline__ void x2_store_xyz(const X2Out &o, int tap, int k, int64_t s, float u, bool pad)
 {
-    x3_store_col(o, tap, 32 + k, s, pad ? 0.0f : u * o.xyz_scale + o.xyz_offset);
+    x2_store_col(o, tap, 32 + k, s, pad ? 0.0f : u * o.xyz_scale + o.xyz_offset);
 }
 // unit-cube coordinates of the 7 stencil points, as rsdf_fd_points writes them (neus.hip fd_points_kernel)
 template <bool DERIVE>
-__device__ __forceinline__ void x3_store_points(const X3Out &o, const TapSrc &src, int64_t S, int64_t s, int64_t sl, bool pad)
+__device__ __forceinline__ void x2_store_points(const X2Out &o, const TapSrc &src, int64_t S, int64_t s, int64_t sl, bool pad)
 {
 #pragma unroll
-    for (int t = 0; t < 7; ++t) x3_store_col(o, t, 35, s, pad ? 0.0f : 1.0f);
+    for (int t = 0; t < 7; ++t) x2_store_col(o, t, 35, s, pad ? 0.0f : 1.0f);
     if (DERIVE) {
         const float r = src.radius, two_r = r - (-r);
         float p[3], u0[3], uc[3];
@@ -318,7 +330,7 @@ __device__ __forceinline__ void x3_store_points(const X3Out &o, const TapSrc &sr
             p[k] = src.pw[sl * 3 + k];
             u0[k] = (p[k] - (-r)) / two_r;
             uc[k] = (fminf(fmaxf(p[k], -r), r) - (-r)) / two_r;
-            x3_store_xyz(o, 0, k, s, u0[k], pad);
+            x2_store_xyz(o, 0, k, s, u0[k], pad);
         }
 #pragma unroll
         for (int t = 1; t < 7; ++t) {
@@ -328,14 +340,14 @@ __device__ __forceinline__ void x3_store_points(const X3Out &o, const TapSrc &sr
             for (int k = 0; k < 3; ++k) {
                 float u = uc[k];
                 if (k == a) u = (fminf(fmaxf(p[k] + off, -r), r) - (-r)) / two_r;
-                x3_store_xyz(o, t, k, s, u, pad);
+                x2_store_xyz(o, t, k, s, u, pad);
             }
         }
     } else {
 #pragma unroll
         for (int t = 0; t < 7; ++t)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) x3_store_xyz(o, t, k, s, src.x7t[((int64_t)t * S + sl) * 3 + k], pad);
+            for (int k = 0; k < 3; ++k) x2_store_xyz(o, t, k, s, src.x7t[((int64_t)t * S + sl) * 3 + k], pad);
     }
 }
 
@@ -354,7 +366,7 @@ __device__ __forceinline__ void x3_store_points(const X3Out &o, const TapSrc &sr
 template <bool DERIVE, bool X3>
 __device__ __forceinline__ void fd7_fwd_sample(const TapSrc &src, const float2 *__restrict__ tl,
                                                const LevelGeom &g, int64_t S, int64_t s, int l,
-                                               float2 *__restrict__ planes, const X3Out &x3)
+                                               float2 *__restrict__ planes, const X2Out &x3)
 {
     // x3 form: rows S .. Sp - 1 are padding -- they gather the last sample's cells (valid loads) and store zeros
     const bool pad = X3 && s >= S;
@@ -422,10 +434,19 @@ __device__ __forceinline__ void fd7_fwd_sample(const TapSrc &src, const float2 *
                 acc.y = fmaf(w, val.y, acc.y);
             }
         }
-        if (X3) x3_store_features(x3_at(x3, s & ~(int64_t)1, t, 0, 2 * l + (int)(s & 1)), (s & 1) != 0, pad ? 0.0f : acc.x, pad ? 0.0f : acc.y);
+        if (X3) {
+            // workgroup-uniform base (the block's first tile; a scalar add per tap) + a 32-bit lane offset: the stores
+            // need no vector address arithmetic (global_store ... saddr, parts as immediates)
+            const unsigned loff = (threadIdx.x >> 5) * (unsigned)X2_TILE_B + (unsigned)(2 * l + (int)(threadIdx.x & 1)) * 64u +
+                                  (unsigned)((2 * (int)(threadIdx.x & 30)) ^ (32 * ((l >> 2) & 1)));
+            unsigned char *bb = x3.base + (s - threadIdx.x) / 32 * X2_TILE_B + t * X2_TAP_B;
+            x2_store_features(bb + loff, (threadIdx.x & 1) != 0, pad ? 0.0f : acc.x, pad ? 0.0f : acc.y);
+        }
         else planes[((int64_t)l * 7 + t) * S + s] = acc;
     }
-    if (X3 && l == 0) x3_store_points<DERIVE>(x3, src, S, s, sl, pad);
+#ifndef RSDF_X2_NOXYZ
+    if (X3 && l == 0) x2_store_points<DERIVE>(x3, src, S, s, sl, pad);
+#endif
 }
 
 // 1-D grid in SAMPLE-GROUP-MAJOR order: all active levels of RSDF_FWD_GROUP consecutive tiles (4096 x 256 = 1 M samples:
@@ -434,13 +455,13 @@ __device__ __forceinline__ void fd7_fwd_sample(const TapSrc &src, const float2 *
 // it); inside a group the 15 re-reads come from the 256 MB MALL.  18.8 -> 16.0 ms per launch; 1024-tile groups 16.9,
 // 8192-tile groups (176 MB + the 64 MB of tables: past the MALL) 18.8.  Not paying, measured: XCD-contiguous sample
 // ranges (neighbouring rays in one L2: <= 3 %), several tiles per workgroup, forcing more waves per SIMD.
-#ifndef RSDF_X3_WAVES
-#define RSDF_X3_WAVES 4     // the x3 form's split + stores would take 146 registers (3 waves per SIMD: +23 % time); held to 128
+#ifndef RSDF_X2_WAVES
+#define RSDF_X2_WAVES 4     // the x3 form's split + stores would take 146 registers (3 waves per SIMD: +23 % time); held to 128
 #endif
 template <bool DERIVE, bool X3>
-__global__ void __launch_bounds__(F_THREADS, X3 ? RSDF_X3_WAVES : RSDF_FWD_WAVES)
+__global__ void __launch_bounds__(F_THREADS, X3 ? RSDF_X2_WAVES : RSDF_FWD_WAVES)
 fd7_fwd_kernel(const TapSrc src, const float *__restrict__ table,
-               const rsdf_grid_meta meta, int64_t S, int n_active, float2 *__restrict__ planes, const X3Out x3)
+               const rsdf_grid_meta meta, int64_t S, int n_active, float2 *__restrict__ planes, const X2Out x3)
 {
     const int64_t per_group = (int64_t)RSDF_FWD_GROUP * n_active;
     const int64_t grp = blockIdx.x / per_group, r = blockIdx.x - grp * per_group;
@@ -456,14 +477,14 @@ fd7_fwd_kernel(const TapSrc src, const float *__restrict__ table,
 // zero the columns of the levels that are not active (or do not exist): the MLP kernels read all 32 feature columns.
 // One thread per 16-byte unit: (tile, tap, part) blocks of (32 - col0) columns x 4 units.
 __global__ void __launch_bounds__(256)
-x3_zero_cols_kernel(const X3Out x3, int col0)
+x3_zero_cols_kernel(const X2Out x3, int col0)
 {
     const int per = (32 - col0) * 4;
-    const int64_t n = x3.Sp / 32 * 21 * per;
+    const int64_t n = x3.Sp / 32 * 14 * per;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int64_t blk = i / per;
         const int u = (int)(i - blk * per);
-        *reinterpret_cast<uint4 *>(x3.base + blk * X3_PART_B + col0 * 64 + u * 16) = uint4{0u, 0u, 0u, 0u};
+        *reinterpret_cast<uint4 *>(x3.base + blk * X2_PART_B + col0 * 64 + u * 16) = uint4{0u, 0u, 0u, 0u};
     }
 }
 
@@ -1044,7 +1065,7 @@ extern "C" int rsdf_debug_read_pstamps(unsigned long long *out16, int reset)
 namespace {
 
 int launch_fwd(const TapSrc &src, const float *table, const rsdf_grid_meta *meta, int64_t n_samples,
-               int n_active_levels, float *planes, void *stream, const X3Out *x3 = nullptr)
+               int n_active_levels, float *planes, void *stream, const X2Out *x3 = nullptr)
 {
     RSDF_CHECK_ARG(meta != nullptr, "hashgrid_fwd_fd7: meta is NULL");
     RSDF_CHECK_ARG(meta->n_features == 2, "hashgrid_fwd_fd7: n_features must be 2");
@@ -1064,7 +1085,7 @@ int launch_fwd(const TapSrc &src, const float *table, const rsdf_grid_meta *meta
     hipStream_t st = (hipStream_t)stream;
     if (x3) {
         if (na < 16) {
-            const int64_t n16 = x3->Sp / 32 * 21 * (int64_t)(32 - 2 * na) * 4;
+            const int64_t n16 = x3->Sp / 32 * 14 * (int64_t)(32 - 2 * na) * 4;
             const unsigned gx = (unsigned)((n16 + 255) / 256 < 4096 ? (n16 + 255) / 256 : 4096);
             x3_zero_cols_kernel<<<gx, 256, 0, st>>>(*x3, 2 * na);
         }
@@ -1074,7 +1095,7 @@ int launch_fwd(const TapSrc &src, const float *table, const rsdf_grid_meta *meta
             fd7_fwd_kernel<true, true><<<n_tiles_f * na, F_THREADS, 0, st>>>(src, table, *meta, n_samples, na, nullptr, *x3);
         RSDF_RETURN_LAUNCH();
     }
-    const X3Out none{nullptr, 0, 0.f, 0.f};
+    const X2Out none{nullptr, 0, 0.f, 0.f};
     if (src.x7t)
         fd7_fwd_kernel<false, false><<<n_tiles_f * na, F_THREADS, 0, st>>>(src, table, *meta, n_samples, na, pl, none);
     else
@@ -1221,17 +1242,17 @@ int rsdf_hashgrid_fwd_fd7_pts(const float *points, float radius, float eps, cons
     return launch_fwd(TapSrc{nullptr, points, radius, eps}, table, meta, n_samples, n_active_levels, planes, stream);
 }
 
-int64_t rsdf_x3_rows(int64_t n_samples) { return (n_samples + 31) / 32 * 32; }
-int64_t rsdf_x3_bytes(int64_t n_samples) { return rsdf_x3_rows(n_samples) / 32 * (int64_t)X3_TILE_B; }
+int64_t rsdf_x2_rows(int64_t n_samples) { return (n_samples + 31) / 32 * 32; }
+int64_t rsdf_x2_bytes(int64_t n_samples) { return rsdf_x2_rows(n_samples) / 32 * (int64_t)X2_TILE_B + 1024; }   // + slack: see mlp_x2.hip fetch_x2
 
-int rsdf_hashgrid_fwd_fd7_x3(const float *x7t, const float *points, float radius, float eps, const float *table,
+int rsdf_hashgrid_fwd_fd7_x2(const float *x7t, const float *points, float radius, float eps, const float *table,
                              const rsdf_grid_meta *meta, int64_t n_samples, int n_active_levels, float xyz_scale,
                              float xyz_offset, void *x3, void *stream)
 {
-    RSDF_CHECK_ARG((x7t != nullptr) != (points != nullptr) || n_samples <= 0, "hashgrid_fwd_fd7_x3: give x7t or points");
-    RSDF_CHECK_ARG(points == nullptr || radius > 0.f, "hashgrid_fwd_fd7_x3: radius must be > 0");
-    RSDF_CHECK_ARG(x3 != nullptr || n_samples <= 0, "hashgrid_fwd_fd7_x3: x3 is NULL");
-    const X3Out o{reinterpret_cast<unsigned char *>(x3), rsdf_x3_rows(n_samples), xyz_scale, xyz_offset};
+    RSDF_CHECK_ARG((x7t != nullptr) != (points != nullptr) || n_samples <= 0, "hashgrid_fwd_fd7_x2: give x7t or points");
+    RSDF_CHECK_ARG(points == nullptr || radius > 0.f, "hashgrid_fwd_fd7_x2: radius must be > 0");
+    RSDF_CHECK_ARG(x3 != nullptr || n_samples <= 0, "hashgrid_fwd_fd7_x2: x3 is NULL");
+    const X2Out o{reinterpret_cast<unsigned char *>(x3), rsdf_x2_rows(n_samples), xyz_scale, xyz_offset};
     return launch_fwd(x7t ? TapSrc{x7t, nullptr, 0.f, 0.f} : TapSrc{nullptr, points, radius, eps}, table, meta, n_samples,
                       n_active_levels, nullptr, stream, &o);
 }

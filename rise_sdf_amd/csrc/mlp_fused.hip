@@ -127,8 +127,7 @@ struct SmemS {
 __device__ __forceinline__ int frag_k(int s, int hf, int j) { return 16 * s + 8 * (j >> 2) + 4 * hf + (j & 3); }
 
 // Stage W0 (+ b0 as column 35), W1, W2 as split, fragment-ordered bf16; b1, b2, W2 row 0 in fp32.
-// X3COLS: the x3 image's column order (hash features 0..31, xyz 32..34, 1 at 35) instead of [xyz | hash | 1]
-template <int H, bool X3COLS = false>
+template <int H>
 __device__ __forceinline__ void stage_split_weights(unsigned char *smem, const float *__restrict__ w0,
                                                     const float *__restrict__ b0, const float *__restrict__ w1,
                                                     const float *__restrict__ b1, const float *__restrict__ w2,
@@ -142,9 +141,7 @@ __device__ __forceinline__ void stage_split_weights(unsigned char *smem, const f
     for (int e = threadIdx.x; e < NT * KS0 * 2 * 32 * 8; e += NTHR) {
         const int j = e & 7, c = (e >> 3) & 31, hf = (e >> 8) & 1, s = (e >> 9) % KS0, nt = (e >> 9) / KS0;
         const int n = 32 * nt + c, k = 16 * s + 8 * hf + j;
-        float w;
-        if (X3COLS) w = k < 32 ? (k < K0 - 3 ? w0[n * K0 + 3 + k] : 0.0f) : (k < 35 ? w0[n * K0 + (k - 32)] : (k == 35 ? b0[n] : 0.0f));
-        else w = k < K0 ? w0[n * K0 + k] : (k == 35 ? b0[n] : 0.0f);
+        const float w = k < K0 ? w0[n * K0 + k] : (k == 35 ? b0[n] : 0.0f);
         store3(e16 + (size_t)S::W0 * 8, (size_t)S::W0_PART * 8, e, w);
     }
     for (int e = threadIdx.x; e < NT * NT * 2 * 2 * 32 * 8; e += NTHR) {
@@ -235,45 +232,10 @@ __device__ __forceinline__ void store_tile4(float *Xs, const float (&v)[20], con
 }
 
 // hidden layers 1 and 2 of one 32-row tile; h[t][r]: feature 32 t + (r & 3) + 8 (r >> 2) + 4 hf of row c
-// ---- x3 input image (hashgrid_fd7.hip "x3": the gather writes the three bf16 parts of every input column tile by tile,
-// [tile][tap][part][36 columns][32 rows], 6912 contiguous bytes per tile and tap).  Per wave: [part 3][column 48][32 rows]
-// bf16, 64 B per column; column 35 = 1 (bias, written by the gather), 36..47 = 0 (constant).  The B fragment of k-step s (lane = row c, k = 16 s + 8 hf + j) is two
-// ds_read_b64_tr_b16 per part: block rows = columns k0 + q (+ 4), block columns = tile rows 16 (g & 1) + 4 p ..; the
-// layout is conflict-free for them as it is (a half's 32 lanes cover columns k0 .. k0 + 3 x 64 B = all 64 banks).
-typedef short v4i16f __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) v4i16f lds_v4i16f;
-constexpr int X3_COL_B = 64, X3_PART_B = 48 * X3_COL_B, X3_IMG_B = 3 * X3_PART_B;
-__device__ __forceinline__ int x3_lane_tr(int lane)
-{
-    // columns 16 s + 8 h + q (+ 4): bit 3 of the column index is h, and such columns hold their row halves swapped
-    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3, h = g >> 1;
-    return (8 * h + q) * X3_COL_B + (((16 * (g & 1) + 4 * p) * 2) ^ (32 * h));
-}
-__device__ __forceinline__ u32x4 x3_frag_part(const unsigned char *a)
-{
-    const unsigned long long u0 = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16f *)a));
-    const unsigned long long u1 =
-        __builtin_bit_cast(unsigned long long, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16f *)(a + 4 * X3_COL_B)));
-    return u32x4{(unsigned)u0, (unsigned)(u0 >> 32), (unsigned)u1, (unsigned)(u1 >> 32)};
-}
-__device__ __forceinline__ Frag3 x3_frag(const unsigned char *img, int lctr, int s)
-{
-    const unsigned char *a = img + s * (16 * X3_COL_B) + lctr;
-    Frag3 f;
-    f.h = x3_frag_part(a);
-    if (RSDF_SPLIT3) {
-        f.m = x3_frag_part(a + X3_PART_B);
-        f.l = x3_frag_part(a + 2 * X3_PART_B);
-    } else {
-        f.m = f.l = u32x4{0u, 0u, 0u, 0u};
-    }
-    return f;
-}
-
-template <int H, bool X3 = false>
+template <int H>
 __device__ __forceinline__ void hidden_forward_s(const unsigned char *smem, const float *Xs, int c, int hf,
                                                  const float *b1s, f32x16 (&h1)[H / 32],
-                                                 f32x16 (&h2)[H / 32], int lctr = 0)
+                                                 f32x16 (&h2)[H / 32])
 {
     using S = SmemS<H>;
     constexpr int NT = S::NT;
@@ -284,14 +246,9 @@ __device__ __forceinline__ void hidden_forward_s(const unsigned char *smem, cons
         for (int r = 0; r < 16; ++r) h1[t][r] = 0.0f;
 #pragma unroll
     for (int s = 0; s < KS0; ++s) {
-        Frag3 xb;
-        if (X3) {
-            xb = x3_frag(reinterpret_cast<const unsigned char *>(Xs), lctr, s);
-        } else {
-            const float4 x0 = *reinterpret_cast<const float4 *>(Xs + c * LDXF + 16 * s + 8 * hf);
-            const float4 x1 = *reinterpret_cast<const float4 *>(Xs + c * LDXF + 16 * s + 8 * hf + 4);
-            xb = split_frag(x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w);
-        }
+        const float4 x0 = *reinterpret_cast<const float4 *>(Xs + c * LDXF + 16 * s + 8 * hf);
+        const float4 x1 = *reinterpret_cast<const float4 *>(Xs + c * LDXF + 16 * s + 8 * hf + 4);
+        const Frag3 xb = split_frag(x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
             h1[t] = mma6<S::W0_PART>(wl + S::W0 + ((t * KS0 + s) * 2 + hf) * 32 + c, xb, h1[t]);
@@ -434,150 +391,6 @@ sdfmlp_fwd_kernel(const TileSrc src, const float *__restrict__ w0,
                 }
                 // the X tile region now holds feature rows: restore finite pad columns for the next tile
                 // (columns 36.. of a row alias the next row's data, which stays finite; nothing to do)
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// forward on the x3 image (round 4): same network, same products; the inputs arrive pre-split (no fp32 X tile, no
-// split of the 35 input columns: 132 of the ~930 vector instructions per tile, and the tile's fetch + store arithmetic)
-// ------------------------------------------------------------------------------------------------
-struct X3Src {
-    const unsigned char *x3;
-    int64_t S, Sp;
-    int n_levels;
-};
-constexpr int X3H_PART_B = 36 * 64, X3H_TAP_B = 3 * X3H_PART_B, X3H_TILE_B = 7 * X3H_TAP_B;     // the HBM image
-// 9 x 16 bytes per lane, every load contiguous: load k = part k / 3, bytes 1024 (k % 3) + 16 lane of its 2304 (the third
-// load of a part covers columns 32..35 with 16 lanes)
-__device__ __forceinline__ void fetch_x3(u32x4 (&pre)[9], const X3Src &src, int64_t tile, int tap, int lane)
-{
-    const unsigned char *tb = src.x3 + tile * X3H_TILE_B + tap * X3H_TAP_B + lane * 16;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        const int part = k / 3, j = k % 3;
-        const int off = part * X3H_PART_B + j * 1024;
-        pre[k] = *reinterpret_cast<const u32x4 *>(tb + ((j < 2 || lane < 16) ? off : off - 1024));   // (idle lanes re-read a valid address)
-    }
-}
-__device__ __forceinline__ void store_x3(unsigned char *img, const u32x4 (&pre)[9], int lane)
-{
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        const int part = k / 3, j = k % 3;
-        if (j < 2 || lane < 16)
-            *reinterpret_cast<u32x4 *>(img + part * X3_PART_B + j * 1024 + lane * 16) = pre[k];
-    }
-}
-// columns 35 (ones, h part) .. 47 (zeros) of the h part after the feature transpose has overwritten them: 13 x 64 B
-// (column 35 is rewritten by the next tile's store anyway; the zeros are not)
-__device__ __forceinline__ void x3_const_cols(unsigned char *img, int lane)
-{
-    if (lane < 52) {
-        const unsigned v = lane < 4 ? 0x3F803F80u : 0u;
-        *reinterpret_cast<u32x4 *>(img + 35 * X3_COL_B + lane * 16) = u32x4{v, v, v, v};
-    }
-}
-
-template <int H>
-__global__ void __launch_bounds__(FWD_THREADS, FWD_WAVES / 4) __attribute__((amdgpu_num_vgpr(RSDF_FWD_VGPR_CAP)))
-sdfmlp_fwd_x3_kernel(const X3Src src, const float *__restrict__ w0, const float *__restrict__ b0,
-                     const float *__restrict__ w1, const float *__restrict__ b1, const float *__restrict__ w2,
-                     const float *__restrict__ b2, int N2, float *__restrict__ sdf7, float *__restrict__ feature,
-                     float *__restrict__ h2c)
-{
-    const int64_t n_samples = src.S;
-    const int K0 = 3 + 2 * src.n_levels;
-    using S = SmemS<H>;
-    constexpr int NT = S::NT;
-    static_assert(X3_IMG_B >= 32 * LDFS * 4, "the feature transpose overlays the image");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 31, hf = lane >> 5;
-    float *tail = reinterpret_cast<float *>(smem_b + (size_t)S::END_U4 * 16);
-    unsigned char *img = smem_b + S::SHARED_BYTES + (size_t)wave * X3_IMG_B;
-    float *Fs = reinterpret_cast<float *>(img);   // [32][LDFS] over the image, which is dead once the first layer has read it
-    stage_split_weights<H, true>(smem_b, w0, b0, w1, b1, w2, b2, K0, N2);
-    for (int e = lane; e < X3_IMG_B / 4; e += 64) reinterpret_cast<unsigned *>(img)[e] = 0u;
-    x3_const_cols(img, lane);
-    __syncthreads();
-    const u32x4 *wl = reinterpret_cast<const u32x4 *>(smem_b);
-    const float b2_0 = tail[S::B2];
-    const int lctr = x3_lane_tr(lane);
-
-    const int64_t n_groups = src.Sp / 32;
-    const int64_t g_first = (int64_t)blockIdx.x * FWD_WAVES + wave, g_step = (int64_t)gridDim.x * FWD_WAVES;
-    u32x4 pre[9];
-    if (g_first < n_groups) fetch_x3(pre, src, g_first, 0, lane);
-    for (int64_t g = g_first; g < n_groups; g += g_step) {
-        const int64_t s0 = g * 32;
-        for (int tap = 0; tap < 7; ++tap) {
-            store_x3(img, pre, lane);
-            {   // prefetch the next tile of this wave
-                const int ntap = tap == 6 ? 0 : tap + 1;
-                const int64_t ng = tap == 6 ? g + g_step : g;
-                if (ng < n_groups) fetch_x3(pre, src, ng, ntap, lane);
-            }
-            f32x16 h1[NT], h2[NT];
-            hidden_forward_s<H, true>(smem_b, reinterpret_cast<const float *>(img), c, hf, tail + S::B1, h1, h2, lctr);
-            const int64_t s = s0 + c;
-            float acc = 0.0f;
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 w = *reinterpret_cast<const float4 *>(tail + S::W2R0 + 32 * t + 8 * q + 4 * hf);
-                    acc = fmaf(w.x, h2[t][4 * q], acc);
-                    acc = fmaf(w.y, h2[t][4 * q + 1], acc);
-                    acc = fmaf(w.z, h2[t][4 * q + 2], acc);
-                    acc = fmaf(w.w, h2[t][4 * q + 3], acc);
-                }
-            acc += __shfl_xor(acc, 32, 64);
-            if (hf == 0 && s < n_samples) sdf7[(int64_t)tap * n_samples + s] = acc + b2_0;
-            if (tap == 0 && feature != nullptr) {
-                if (h2c != nullptr) {
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) Fs[c * LDFS + (r & 3) + 8 * (r >> 2) + 4 * hf] = h2[t][r];
-                        for (int e = lane; e < 32 * 32; e += 64) {
-                            const int r = e >> 5, cc = e & 31;
-                            if (s0 + r < n_samples) h2c[(s0 + r) * H + 32 * t + cc] = Fs[r * LDFS + cc];
-                        }
-                    }
-                }
-                f32x16 o[2];
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[t][r] = tail[S::B2 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf];
-#pragma unroll
-                for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-                    for (int ss = 0; ss < 2; ++ss) {
-                        const Frag3 hb = split_frag(h2[kt][8 * ss], h2[kt][8 * ss + 1], h2[kt][8 * ss + 2],
-                                                    h2[kt][8 * ss + 3], h2[kt][8 * ss + 4], h2[kt][8 * ss + 5],
-                                                    h2[kt][8 * ss + 6], h2[kt][8 * ss + 7]);
-#pragma unroll
-                        for (int t = 0; t < 2; ++t)
-                            if (t * 32 < N2)
-                                o[t] = mma6<S::W2_PART>(wl + S::W2 + (((t * NT + kt) * 2 + ss) * 2 + hf) * 32 + c, hb,
-                                                        o[t]);
-                    }
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int nc = N2 - 32 * t < 32 ? N2 - 32 * t : 32;
-                    if (nc <= 0) break;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) Fs[c * LDFS + (r & 3) + 8 * (r >> 2) + 4 * hf] = o[t][r];
-                    for (int e = lane; e < 32 * nc; e += 64) {
-                        const int r = e / nc, cc = e - r * nc;
-                        if (s0 + r < n_samples) feature[(s0 + r) * N2 + 32 * t + cc] = Fs[r * LDFS + cc];
-                    }
-                }
-                // the transpose has overwritten the h part's constant columns (and the head of the m part, which the
-                // next tile's store rewrites): restore them
-                x3_const_cols(img, lane);
             }
         }
     }
@@ -929,8 +742,6 @@ sdfmlp_bwd_kernel(const TileSrc src, const float *__restrict__ w0,
 template <int H>
 size_t fwd_lds() { return SmemS<H>::SHARED_BYTES + (size_t)FWD_WAVES * SmemS<H>::PER_WAVE_F * sizeof(float); }
 template <int H>
-size_t fwd_x3_lds() { return SmemS<H>::SHARED_BYTES + (size_t)FWD_WAVES * X3_IMG_B; }
-template <int H>
 size_t bwd_lds(int steps2)
 {
     return SmemSB<H>::shared_bytes(steps2) + (size_t)BWD_WAVES * SmemSB<H>::PER_WAVE_F * sizeof(float);
@@ -985,12 +796,6 @@ __attribute__((visibility("hidden"))) int RSDF_P(rsdf_quad_bwd)(int H, const flo
                   const float *w0, const float *b0, const float *w1, const float *b1, const float *w2, int64_t n_samples,
                   const float *d_sdf7t, const float *dh2c, float *d_planes, float *dw0, float *db0, float *dw1, float *db1,
                   float *dw2, float *db2, hipStream_t st);
-
-#ifndef RSDF_BF16
-__attribute__((visibility("hidden"))) int rsdf_quad_bwd_x3(int H, const void *x3, int n_levels, int n_active, const float *w0, const float *b0,
-                  const float *w1, const float *b1, const float *w2, int64_t n_samples, const float *d_sdf7t, const float *dh2c,
-                  float *d_planes, float *dw0, float *db0, float *dw1, float *db1, float *dw2, float *db2, hipStream_t st);
-#endif
 
 extern "C" {
 
@@ -1081,59 +886,5 @@ int RSDF_P(rsdf_sdfmlp_fd7_bwd)(const float *x7t, const float *planes, int n_lev
     }
     RSDF_RETURN_LAUNCH();
 }
-
-#ifndef RSDF_BF16
-// The same forward on the gather's pre-split x3 image (hashgrid_fd7.hip, rsdf_hashgrid_fwd_fd7_x3): H <= 64.
-int rsdf_sdfmlp_fd7_x3_supported(int K0, int H, int N2)
-{
-    return (K0 >= 5 && K0 <= 35 && (K0 - 3) % 2 == 0 && (H == 32 || H == 64) && N2 >= 1 && N2 <= 64) ? 1 : 0;
-}
-
-int rsdf_sdfmlp_fd7_fwd_x3(const void *x3, int n_levels, int H, int N2, const float *w0, const float *b0, const float *w1,
-                           const float *b1, const float *w2, const float *b2, int64_t n_samples, float *sdf7t,
-                           float *feature, float *h2c, void *stream)
-{
-    const int K0 = 3 + 2 * n_levels;
-    RSDF_CHECK_ARG(n_levels >= 1 && n_levels <= 16, "sdfmlp_fd7_fwd_x3: n_levels must be in [1,16]");
-    RSDF_CHECK_ARG(h2c == nullptr || feature != nullptr, "sdfmlp_fd7_fwd_x3: h2c needs feature");
-    RSDF_CHECK_ARG(rsdf_sdfmlp_fd7_x3_supported(K0, H, N2), "sdfmlp_fd7_fwd_x3: unsupported layer sizes");
-    if (n_samples <= 0) return 0;
-    hipStream_t st = (hipStream_t)stream;
-    const unsigned grid = persistent_grid(n_samples, FWD_WAVES);
-    const X3Src src{reinterpret_cast<const unsigned char *>(x3), n_samples, (n_samples + 31) / 32 * 32, n_levels};
-    int rc;
-    if (H == 64) {
-        if ((rc = set_lds(sdfmlp_fwd_x3_kernel<64>, fwd_x3_lds<64>()))) return rc;
-        sdfmlp_fwd_x3_kernel<64><<<grid, FWD_THREADS, fwd_x3_lds<64>(), st>>>(src, w0, b0, w1, b1, w2, b2, N2, sdf7t, feature, h2c);
-    } else {
-        if ((rc = set_lds(sdfmlp_fwd_x3_kernel<32>, fwd_x3_lds<32>()))) return rc;
-        sdfmlp_fwd_x3_kernel<32><<<grid, FWD_THREADS, fwd_x3_lds<32>(), st>>>(src, w0, b0, w1, b1, w2, b2, N2, sdf7t, feature, h2c);
-    }
-    RSDF_RETURN_LAUNCH();
-}
-
-// backward on the x3 image: H = 64 (the quad kernel); same contract as rsdf_sdfmlp_fd7_bwd otherwise
-int rsdf_sdfmlp_fd7_bwd_x3(const void *x3, int n_levels, int n_active_levels, int H, int N2, const float *w0, const float *b0,
-                           const float *w1, const float *b1, const float *w2, const float *b2, int64_t n_samples,
-                           const float *d_sdf7t, const float *d_feature, float *dh2c_scratch, float *d_planes, float *dw0,
-                           float *db0, float *dw1, float *db1, float *dw2, float *db2, void *stream)
-{
-    const int K0 = 3 + 2 * n_levels;
-    (void)b2;
-    RSDF_CHECK_ARG(n_levels >= 1 && n_levels <= 16, "sdfmlp_fd7_bwd_x3: n_levels must be in [1,16]");
-    RSDF_CHECK_ARG(H == 64 && rsdf_sdfmlp_fd7_x3_supported(K0, H, N2), "sdfmlp_fd7_bwd_x3: unsupported layer sizes (H must be 64)");
-    if (n_samples <= 0) return 0;
-    if (n_active_levels < 0 || n_active_levels > n_levels) n_active_levels = n_levels;
-    if (d_feature != nullptr) {
-        RSDF_CHECK_ARG(dh2c_scratch != nullptr, "sdfmlp_fd7_bwd_x3: d_feature needs the [n, H] dh2c scratch");
-        const int rc = rsdf_linear_bwd_input(d_feature, nullptr, N2, w2, n_samples, H, N2, RSDF_ACT_NONE, 0, H, nullptr,
-                                             dh2c_scratch, H, stream);
-        if (rc) return rc;
-    }
-    return rsdf_quad_bwd_x3(H, x3, n_levels, n_active_levels, w0, b0, w1, b1, w2, n_samples, d_sdf7t,
-                            d_feature != nullptr ? dh2c_scratch : nullptr, d_planes, dw0, db0, dw1, db1, dw2, db2,
-                            (hipStream_t)stream);
-}
-#endif
 
 }  // extern "C"

@@ -263,78 +263,6 @@ __device__ __forceinline__ void stage_q(unsigned char *xi, const unsigned char *
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// x3 input (round 4; hashgrid_fd7.hip "x3"): the gather has already split the 36 input columns (32 hash features, x, y, z,
-// 1) into bf16 parts and wrote them tile by tile, [tile][tap][part][column 36][32 rows], 6912 contiguous bytes per tile
-// and tap.  The X image becomes COLUMN-major -- [part][column 64][32 rows], 64 B per column, a 16-byte unit = 8
-// consecutive rows of a column -- so a tile lands by LINEAR LDS-DMA directly in its final place (9 instructions per tile
-// and workgroup: 1024 + 1024 + 256 bytes per part) and the staging phase (1445 of 9800 cycles per tile: landing zone ->
-// registers -> split -> image) disappears.  Reads swap kinds: the layer-1 B fragment (k = columns) is two
-// ds_read_b64_tr_b16 per part, the dW0 operand (k = rows) one ds_read_b128.  Rows of columns with bit 3 set arrive with
-// their halves swapped (byte ^ 32, written that way by the gather): conflict-free for both reads.
-// ------------------------------------------------------------------------------------------------------------------
-struct SrcX3 {
-    const unsigned char *x3;
-    int64_t S, Sp;
-    int n_levels, n_active;
-};
-constexpr int X3Q_PART_B = 36 * 64, X3Q_TAP_B = 3 * X3Q_PART_B, X3Q_TILE_B = 7 * X3Q_TAP_B;     // the HBM image
-struct LaneX3 {
-    int tr[2];   // layer-1 B fragment, tile rows 16 rh ..: column 8 g + q, bytes (32 rh + 8 p) ^ 32 (g & 1)
-    int row;     // dW0 operand: column c16, rows 8 g .. 8 g + 7
-};
-__device__ __forceinline__ LaneX3 lane_consts_x3(int lane)
-{
-    const int g = lane >> 4, c16 = lane & 15, q = c16 >> 2, p = lane & 3;
-    LaneX3 c;
-    c.tr[0] = (8 * g + q) * 64 + ((8 * p) ^ (32 * (g & 1)));
-    c.tr[1] = (8 * g + q) * 64 + ((32 + 8 * p) ^ (32 * (g & 1)));
-    c.row = c16 * 64 + ((16 * g) ^ (32 * ((c16 >> 3) & 1)));
-    return c;
-}
-__device__ __forceinline__ u32x4 trq2(const unsigned char *a)
-{
-    unsigned x0, x1, y0, y1;
-    trq(a, x0, x1);
-    trq(a + 4 * 64, y0, y1);
-    return u32x4{x0, x1, y0, y1};
-}
-__device__ __forceinline__ Frag3 colq_x3(const unsigned char *img, int kb, int rh, const LaneX3 &c)
-{
-    const unsigned char *a = img + c.tr[rh] + kb * (32 * 64);
-    Frag3 f;
-    f.h = trq2(a);
-    f.m = trq2(a + QX_PART);
-    f.l = trq2(a + 2 * QX_PART);
-    return f;
-}
-__device__ __forceinline__ Frag3 rowsq_x3(const unsigned char *img, int ct, const LaneX3 &c)
-{
-    const unsigned char *a = img + c.row + ct * (16 * 64);
-    Frag3 f;
-    f.h = ldq128(a);
-    f.m = ldq128(a + QX_PART);
-    f.l = ldq128(a + 2 * QX_PART);
-    return f;
-}
-// 9 DMA instructions per tile: i = 3 part + block; wave w issues i = w, w + 4, w + 8 (ws: the wave index as a SCALAR, so
-// that the choice is a scalar branch and not an exec-masked region)
-__device__ __forceinline__ void dma_x3_one(unsigned char *img, const unsigned char *tb, int i, int lane)
-{
-    const int part = i / 3, b = i - 3 * part;
-    const unsigned char *gp = tb + part * X3Q_PART_B + b * 1024 + lane * 16;
-    unsigned char *dst = img + part * QX_PART + b * 1024;
-    if (b < 2) __builtin_amdgcn_global_load_lds((glob_void *)gp, (lds_void *)dst, 16, 0, 0);
-    else if (lane < 16) __builtin_amdgcn_global_load_lds((glob_void *)gp, (lds_void *)dst, 16, 0, 0);
-}
-__device__ __forceinline__ void dma_x3(unsigned char *img, const SrcX3 &src, int64_t tile, int tap, int ws, int lane)
-{
-    const unsigned char *tb = src.x3 + tile * X3Q_TILE_B + tap * X3Q_TAP_B;
-    dma_x3_one(img, tb, ws, lane);
-    dma_x3_one(img, tb, ws + 4, lane);
-    if (ws == 0) dma_x3_one(img, tb, 8, lane);
-}
-
 __device__ __forceinline__ Frag3 split8(const float (&v)[8])
 {
     return split_frag(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
@@ -343,9 +271,9 @@ __device__ __forceinline__ Frag3 split8(const float (&v)[8])
 // ------------------------------------------------------------------------------------------------------------------
 // backward (H = 64): same contract as coop_bwd_kernel
 // ------------------------------------------------------------------------------------------------------------------
-template <int NW, bool X3, typename SRC>
+template <int NW>
 __global__ void __launch_bounds__(64 * NW, 2)
-quad_bwd_kernel(const SRC src, const float *__restrict__ w0, const float *__restrict__ b0, const float *__restrict__ w1,
+quad_bwd_kernel(const SrcQ src, const float *__restrict__ w0, const float *__restrict__ b0, const float *__restrict__ w1,
                 const float *__restrict__ b1, const float *__restrict__ w2, const float *__restrict__ d_sdf7,
                 const float *__restrict__ dh2c, float *__restrict__ d_planes, float *__restrict__ dw0,
                 float *__restrict__ db0, float *__restrict__ dw1, float *__restrict__ db1, float *__restrict__ dw2,
@@ -361,13 +289,10 @@ quad_bwd_kernel(const SRC src, const float *__restrict__ w0, const float *__rest
     const int fw = 16 * w + c16;                   // the feature this lane addresses in an A fragment of its wave
     const LaneQ lc = lane_consts(w, lane);
 
-    for (int e = threadIdx.x; e < (X3 ? L::RAW : L::END) / 4; e += L::THREADS) reinterpret_cast<unsigned *>(smem)[e] = 0u;
+    for (int e = threadIdx.x; e < L::END / 4; e += L::THREADS) reinterpret_cast<unsigned *>(smem)[e] = 0u;
     __syncthreads();
-    if (!X3 && threadIdx.x < 64)                   // 1.0 (h part) in column 35 of both X images (x3: arrives with the tile)
+    if (threadIdx.x < 64)                          // 1.0 (h part) in column 35 of both X images
         *reinterpret_cast<unsigned short *>(smem + L::XI + (threadIdx.x >> 5) * 3 * QX_PART + qoff(threadIdx.x & 31, 35)) = 0x3F80;
-    LaneX3 lx = {};
-    if constexpr (X3) lx = lane_consts_x3(lane);
-    const int ws = __builtin_amdgcn_readfirstlane(w);
 
     // ---- weight fragments (A operands: lane = (row c16 of the wave's 16-row block, k-group g), 8 consecutive k)
     Frag3 w1f[KB], w1t[KB], w0f[2], w0t[KB];
@@ -418,12 +343,7 @@ quad_bwd_kernel(const SRC src, const float *__restrict__ w0, const float *__rest
     float gb2 = 0.0f;
 
     const int64_t n_groups = (src.S + 31) / 32;
-    if constexpr (X3) {
-        // the images are zeroed / the ones written by other waves: the first DMA may only land behind that
-        if ((int64_t)blockIdx.x < n_groups) dma_x3(smem + L::XI, src, (int64_t)blockIdx.x, 0, ws, lane);
-    } else {
-        if ((int64_t)blockIdx.x < n_groups) dma_q<NW>(smem + L::RAW, src, (int64_t)blockIdx.x * 32, 0, w, lane);
-    }
+    if ((int64_t)blockIdx.x < n_groups) dma_q<NW>(smem + L::RAW, src, (int64_t)blockIdx.x * 32, 0, w, lane);
     int parity = 0;
     StamperQ stq;
     stq.begin(blockIdx.x == 0 && w == 0);
@@ -434,13 +354,7 @@ quad_bwd_kernel(const SRC src, const float *__restrict__ w0, const float *__rest
             RSDF_QSTAMP(0);                        // loop overhead
             wait_vm0q();                           // this tile's inputs have landed (and the previous tile's stores retired)
             RSDF_QSTAMP(1);                        // vmcnt wait
-            if constexpr (X3) {
-                // every wave's share of this tile has landed once all have passed their vmcnt wait; the OTHER image is
-                // free once all have finished the previous tile's dW0 reads: one barrier serves both
-                lds_barrier_q();
-            } else {
-                stage_q<NW>(xi, smem + L::RAW + parity * 18 * 256, src, s0, w, lane);
-            }
+            stage_q<NW>(xi, smem + L::RAW + parity * 18 * 256, src, s0, w, lane);
             parity ^= 1;
             bool row_ok[2];
             float dsdf_raw[2];
@@ -461,27 +375,18 @@ quad_bwd_kernel(const SRC src, const float *__restrict__ w0, const float *__rest
             {
                 const int ntap = tap == 6 ? 0 : tap + 1;
                 const int64_t ng = tap == 6 ? gi + gridDim.x : gi;
-                if constexpr (X3) {
-                    if (ng < n_groups) dma_x3(smem + L::XI + parity * 3 * QX_PART, src, ng, ntap, ws, lane);
-                } else {
-                    if (ng < n_groups) dma_q<NW>(smem + L::RAW + parity * 18 * 256, src, ng * 32, ntap, w, lane);
-                }
+                if (ng < n_groups) dma_q<NW>(smem + L::RAW + parity * 18 * 256, src, ng * 32, ntap, w, lane);
             }
             RSDF_QSTAMP(2);                        // X image staging, d_sdf loads, next DMA issue
-            if constexpr (!X3) lds_barrier_q();                                  // (1) X image complete
+            lds_barrier_q();                                                     // (1) X image complete
             RSDF_QSTAMP(3);                        // barrier 1
             // ---- recompute layer 1
             f32x4 h1[2], h2[2];
 #pragma unroll
             for (int rh = 0; rh < 2; ++rh) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                if constexpr (X3) {
-                    acc = mma6q(w0f[0], colq_x3(xi, 0, rh, lx), acc);
-                    acc = mma6q(w0f[1], colq_x3(xi, 1, rh, lx), acc);
-                } else {
-                    acc = mma6q(w0f[0], rowq(xi, QX_PART, 0, rh, lc), acc);
-                    acc = mma6q(w0f[1], rowq(xi, QX_PART, 1, rh, lc), acc);
-                }
+                acc = mma6q(w0f[0], rowq(xi, QX_PART, 0, rh, lc), acc);
+                acc = mma6q(w0f[1], rowq(xi, QX_PART, 1, rh, lc), acc);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) h1[rh][r] = softplus100q(acc[r]);
                 store_q(smem + L::H1I, L::H_PART, rh, lc, h1[rh]);
@@ -547,7 +452,7 @@ quad_bwd_kernel(const SRC src, const float *__restrict__ w0, const float *__rest
             {
                 const Frag3 a = trfq(smem + L::DZ1, L::H_PART, w, lc);
 #pragma unroll
-                for (int ct = 0; ct < 3; ++ct) gw0[ct] = mma6q(a, X3 ? rowsq_x3(xi, ct, lx) : trfq(xi, QX_PART, ct, lc), gw0[ct]);
+                for (int ct = 0; ct < 3; ++ct) gw0[ct] = mma6q(a, trfq(xi, QX_PART, ct, lc), gw0[ct]);
             }
             RSDF_QSTAMP(10);                       // dx + store + dW0 products
 #ifdef RSDF_STAMPS
@@ -602,28 +507,18 @@ __attribute__((visibility("hidden"))) int RSDF_P(rsdf_quad_bwd)(int H, const flo
 {
     RSDF_CHECK_ARG(H == 64, "quad backward: H must be 64");
     const SrcQ src{x7t, planes, n_samples, n_levels, n_active, xyz_scale, xyz_offset};
-    if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(quad_bwd_kernel<4, false, SrcQ>), Q<4>::END)) return rc;
+    static thread_local unsigned long long attr_set = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!(attr_set >> (dev & 63) & 1ull)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(quad_bwd_kernel<4>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, Q<4>::END);
+        if (e != hipSuccess) { rsdf_set_error(hipGetErrorString(e)); return (int)e; }
+        attr_set |= 1ull << (dev & 63);
+    }
     const int64_t groups = (n_samples + 31) / 32;
     const unsigned grid = (unsigned)(groups < 512 ? (groups > 0 ? groups : 1) : 512);     // two workgroups per CU
-    quad_bwd_kernel<4, false, SrcQ><<<grid, 256, Q<4>::END, st>>>(src, w0, b0, w1, b1, w2, d_sdf7t, dh2c, d_planes, dw0, db0, dw1, db1,
-                                                                    dw2, db2);
+    quad_bwd_kernel<4><<<grid, 256, Q<4>::END, st>>>(src, w0, b0, w1, b1, w2, d_sdf7t, dh2c, d_planes, dw0, db0, dw1, db1,
+                                                      dw2, db2);
     RSDF_RETURN_LAUNCH();
 }
-
-#ifndef RSDF_BF16
-// the same backward on the gather's pre-split x3 image (no landing zone: 60 KB of LDS per workgroup)
-__attribute__((visibility("hidden"))) int rsdf_quad_bwd_x3(int H, const void *x3, int n_levels, int n_active, const float *w0, const float *b0,
-                  const float *w1, const float *b1, const float *w2, int64_t n_samples, const float *d_sdf7t, const float *dh2c,
-                  float *d_planes, float *dw0, float *db0, float *dw1, float *db1, float *dw2, float *db2, hipStream_t st)
-{
-    RSDF_CHECK_ARG(H == 64, "quad backward (x3): H must be 64");
-    const int64_t Sp = (n_samples + 31) / 32 * 32;
-    const SrcX3 src{reinterpret_cast<const unsigned char *>(x3), n_samples, Sp, n_levels, n_active};
-    if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(quad_bwd_kernel<4, true, SrcX3>), Q<4>::RAW)) return rc;
-    const int64_t groups = Sp / 32;
-    const unsigned grid = (unsigned)(groups < 512 ? (groups > 0 ? groups : 1) : 512);
-    quad_bwd_kernel<4, true, SrcX3><<<grid, 256, Q<4>::RAW, st>>>(src, w0, b0, w1, b1, w2, d_sdf7t, dh2c, d_planes, dw0, db0, dw1,
-                                                                   db1, dw2, db2);
-    RSDF_RETURN_LAUNCH();
-}
-#endif

@@ -1,0 +1,829 @@
+// H3 fused, "x2" form (round 4): the SDF VanillaMLP (models/network_utils.py:109-157, n_hidden_layers = 2, Softplus(100)) of the
+// finite-difference stencil (models/geometry.py:229-244) with every fp32 matrix operand carried as TWO fp16 parts and
+// every product evaluated as THREE v_mfma_f32_*_f16 instructions with fp32 accumulation:
+//
+//     v S = hi + lo,   hi = RNE_f16(v S),   lo = RNE_f16(v S - hi)        (S: a power of two per operand class)
+//     a b  ~  a_lo b_hi + a_hi b_lo + a_hi b_hi                            (dropped: a_lo b_lo <= 2^-24 |a||b|)
+//
+// hi carries 11 significant bits, the residual |v S - hi| <= 2^-12 |v S| is rounded to 11 more: hi + lo = v S to 2^-24
+// relative -- half an fp32 ulp, what one fp32 rounding of the operand would cost -- as long as lo is a normal fp16 number
+// (|v S| >= 0.5), and to 2^-25 ABSOLUTE below that (fp16 subnormals: the matrix cores keep them, measured with
+// tools/mfma_f16_subnormal.hip; the vector ALU's f16 conversions keep them by the default mode).  The class scales put the
+// values that matter well above that floor: inputs (hash features, xyz, 1) x 2^8, weights x 2^6, activations x 2^6, and the
+// backward's gradient images x a power of two derived per LAUNCH from max|d_sdf|, max|d h2| and the weights' norms (the
+// weight-gradient accumulators live across the whole row loop, so the scale must not change inside a launch).  All scales
+// are powers of two: scaling and unscaling are exact.  Preconditions (overflow to inf otherwise): |input| < 255,
+// |weight| < 1023, |activation| < 1023.
+//
+// Against the round 1-3 form (three bf16 parts, six products; split_bf16.h): half the matrix instructions, 2 instead of
+// 5.5 vector instructions per split value, 2/3 of the LDS traffic -- and the pre-split input image costs the SAME bytes as
+// the fp32 planes it replaces (2 x 16 bits), so the stencil gather can write it for free (hashgrid_fd7.hip "x2").
+// Accuracy (tools/accuracy_split.py, tests/test_gpu_x2.py): a layer's algorithmic error is ~1e-7 of the largest output,
+// the level of an fp32 GEMM's own accumulation rounding (the six-product bf16 form: 1e-8, below it).
+//
+// Input image, written by rsdf_hashgrid_fwd_fd7_x2:  x2 [tile = row / 32][tap 7][part 2][column 36][32 rows] fp16, column
+// 2 l + f = feature f of level l, 32..34 = xyz * xyz_scale + xyz_offset, 35 = 1, all times 2^8; the row halves of columns
+// with bit 3 set are swapped (the LDS bank swizzle).  4608 contiguous bytes per tile and tap land in LDS as they are.
+#include "common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+typedef short v4i16 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4i16 lds_v4i16;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void glob_void;
+
+constexpr float SX = 256.0f, SW = 64.0f, SH = 64.0f;       // class scales: inputs, weights, activations
+constexpr float T1 = SW * SX, T2 = SW * SH;                 // accumulator scale of layer 1 / of layers 2 and 3
+constexpr float K100 = 144.26950408889634f;                 // 100 log2(e)
+constexpr float LN2_100 = 0.0069314718055994531f;           // ln(2) / 100
+
+struct Frag2 { u32x4 h, l; };
+
+__device__ __forceinline__ unsigned pack_f16(float a, float b)       // v_cvt_pk_f16_f32 (round to nearest even); a -> low half
+{
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, f16x2));
+}
+// a - (float)hi.lo / b - (float)hi.hi in ONE instruction each (v_fma_mix_f32 reads the f16 half directly); exact: the
+// difference of a value and its 11-bit rounding has at most 13 significant bits
+__device__ __forceinline__ float resid_lo(float a, unsigned hi)
+{
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hi), "v"(a));
+    return r;
+}
+__device__ __forceinline__ float resid_hi(float b, unsigned hi)
+{
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hi), "v"(b));
+    return r;
+}
+__device__ __forceinline__ void split2_pair(float a, float b, unsigned &h, unsigned &l)
+{
+    h = pack_f16(a, b);
+    l = pack_f16(resid_lo(a, h), resid_hi(b, h));
+}
+__device__ __forceinline__ Frag2 split2_frag(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7)
+{
+    unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+    split2_pair(v0, v1, h0, l0);
+    split2_pair(v2, v3, h1, l1);
+    split2_pair(v4, v5, h2, l2);
+    split2_pair(v6, v7, h3, l3);
+    Frag2 f;
+    f.h = u32x4{h0, h1, h2, h3};
+    f.l = u32x4{l0, l1, l2, l3};
+    return f;
+}
+__device__ __forceinline__ void store2(unsigned short *base, size_t part_stride_elems, size_t idx, float w)
+{
+    unsigned h, l;
+    split2_pair(w, 0.0f, h, l);
+    base[idx] = (unsigned short)(h & 0xffffu);
+    base[idx + part_stride_elems] = (unsigned short)(l & 0xffffu);
+}
+
+__device__ __forceinline__ f32x16 mma32(u32x4 a, u32x4 b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mma16(u32x4 a, u32x4 b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// a (weights in LDS, the two parts PART_U4 16-byte units apart) x b, small terms first
+template <int PART_U4>
+__device__ __forceinline__ f32x16 mma3(const u32x4 *__restrict__ wa, const Frag2 &b, f32x16 c)
+{
+    const u32x4 ah = wa[0], al = wa[PART_U4];
+    c = mma32(al, b.h, c);
+    c = mma32(ah, b.l, c);
+    c = mma32(ah, b.h, c);
+    return c;
+}
+__device__ __forceinline__ f32x4 mma3q(const Frag2 &a, const Frag2 &b, f32x4 c)
+{
+    c = mma16(a.l, b.h, c);
+    c = mma16(a.h, b.l, c);
+    c = mma16(a.h, b.h, c);
+    return c;
+}
+
+// SH * Softplus(beta = 100)(C / T) from the accumulator C = T z:  SH max(z, 0) + SH ln2/100 log2(1 + 2^(-100 log2(e) |z|))
+template <int LAYER>
+__device__ __forceinline__ float softplus_scaled(float C)
+{
+    constexpr float T = LAYER == 1 ? T1 : T2;
+    const float e = __builtin_amdgcn_exp2f(fabsf(C) * (-K100 / T));
+    return fmaf(fmaxf(C, 0.0f), SH / T, __builtin_amdgcn_logf(1.0f + e) * (LN2_100 * SH));
+}
+// sigmoid(100 z) = 1 - 2^(-100 log2(e) h) from hs = SH h, h = softplus(z)
+__device__ __forceinline__ float softplus_grad_scaled(float hs) { return 1.0f - __builtin_amdgcn_exp2f(hs * (-K100 / SH)); }
+
+__device__ __forceinline__ u32x4 ld128(const unsigned char *p) { return *reinterpret_cast<const u32x4 *>(p); }
+__device__ __forceinline__ void tr64(const unsigned char *p, unsigned &a, unsigned &b)
+{
+    const v4i16 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16 *)p);
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, r);
+    a = (unsigned)u;
+    b = (unsigned)(u >> 32);
+}
+// two transposed reads 4 image "rows" (= 256 bytes in a column-major 64-byte-per-column image) apart -> 8 k-elements
+__device__ __forceinline__ u32x4 tr128(const unsigned char *a, int second)
+{
+    unsigned x0, x1, y0, y1;
+    tr64(a, x0, x1);
+    tr64(a + second, y0, y1);
+    return u32x4{x0, x1, y0, y1};
+}
+
+// the HBM image
+constexpr int X2_PART_B = 36 * 64, X2_TAP_B = 2 * X2_PART_B, X2_TILE_B = 7 * X2_TAP_B;
+struct SrcX2 {
+    const unsigned char *x2;
+    int64_t S, Sp;
+    int n_levels, n_active;
+};
+
+// ==================================================================================================================
+// forward (H = 32 NT <= 64): one 32-row tile per wave and iteration, whole MLP per tile, activations in registers
+// (transposed chaining: a layer's accumulator tile, split, IS the next layer's B operand -- mlp_fused.hip), weights of
+// all layers in LDS, the tile's input image per wave in LDS ([part 2][column 48][32 rows]: columns 36..47 constant zero).
+// ==================================================================================================================
+constexpr int FWD_WAVES = 8, FWD_THREADS = FWD_WAVES * 64;
+constexpr int KS0 = 3;                 // layer-1 k-steps of 16 columns
+constexpr int LDFS = 33;               // [row][32 features] transpose of the centre rows' outputs
+constexpr int XF_COL_B = 64, XF_PART_B = 48 * XF_COL_B, XF_IMG_B = 2 * XF_PART_B;
+
+template <int H>
+struct SmemF {
+    static constexpr int NT = H / 32;
+    static constexpr int W0_PART = NT * KS0 * 2 * 32;            // [nt][s][hf][c]                (units: 16 bytes)
+    static constexpr int W1_PART = NT * NT * 2 * 2 * 32;         // [nt][kt][s][hf][c]
+    static constexpr int W2_PART = 2 * NT * 2 * 2 * 32;          // [n2 tile (2)][kt][s][hf][c]
+    static constexpr int W0 = 0;
+    static constexpr int W1 = W0 + 2 * W0_PART;
+    static constexpr int W2 = W1 + 2 * W1_PART;
+    static constexpr int END_U4 = W2 + 2 * W2_PART;
+    static constexpr int B1 = 0;          // [H]   b1 * T2
+    static constexpr int B2 = B1 + H;     // [64]  b2 (unscaled)
+    static constexpr int W2R0 = B2 + 64;  // [H]   row 0 of W2 / SH: the taps' SDF dot on the vector ALU
+    static constexpr int TAIL_F = W2R0 + H;
+    static constexpr size_t SHARED_BYTES = (size_t)END_U4 * 16 + (size_t)TAIL_F * 4;
+};
+template <int H>
+size_t fwd_lds() { return SmemF<H>::SHARED_BYTES + (size_t)FWD_WAVES * XF_IMG_B; }
+
+// k of element j of lane half hf in k-step s of a 32-feature activation tile (the accumulator's register order)
+__device__ __forceinline__ int frag_k(int s, int hf, int j) { return 16 * s + 8 * (j >> 2) + 4 * hf + (j & 3); }
+
+template <int H>
+__device__ __forceinline__ void stage_weights_fwd(unsigned char *smem, const float *__restrict__ w0, const float *__restrict__ b0,
+                                                  const float *__restrict__ w1, const float *__restrict__ b1,
+                                                  const float *__restrict__ w2, const float *__restrict__ b2, int K0, int N2)
+{
+    using S = SmemF<H>;
+    constexpr int NT = S::NT;
+    unsigned short *e16 = reinterpret_cast<unsigned short *>(smem);
+    const int NTHR = blockDim.x;
+    // W0: [nt][s][hf][c][j], X column k = 16 s + 8 hf + j: hash features 0..31, xyz 32..34, bias (the 1 column) at 35
+    for (int e = threadIdx.x; e < NT * KS0 * 2 * 32 * 8; e += NTHR) {
+        const int j = e & 7, c = (e >> 3) & 31, hf = (e >> 8) & 1, s = (e >> 9) % KS0, nt = (e >> 9) / KS0;
+        const int n = 32 * nt + c, k = 16 * s + 8 * hf + j;
+        const float w = k < 32 ? (k < K0 - 3 ? w0[n * K0 + 3 + k] : 0.0f) : (k < 35 ? w0[n * K0 + (k - 32)] : (k == 35 ? b0[n] : 0.0f));
+        store2(e16 + (size_t)S::W0 * 8, (size_t)S::W0_PART * 8, e, w * SW);
+    }
+    for (int e = threadIdx.x; e < NT * NT * 2 * 2 * 32 * 8; e += NTHR) {
+        const int j = e & 7, c = (e >> 3) & 31, hf = (e >> 8) & 1, s = (e >> 9) & 1, kt = (e >> 10) % NT, nt = (e >> 10) / NT;
+        const int n = 32 * nt + c, k = 32 * kt + frag_k(s, hf, j);
+        store2(e16 + (size_t)S::W1 * 8, (size_t)S::W1_PART * 8, e, w1[n * H + k] * SW);
+    }
+    for (int e = threadIdx.x; e < 2 * NT * 2 * 2 * 32 * 8; e += NTHR) {
+        const int j = e & 7, c = (e >> 3) & 31, hf = (e >> 8) & 1, s = (e >> 9) & 1, kt = (e >> 10) % NT, nt = (e >> 10) / NT;
+        const int n = 32 * nt + c, k = 32 * kt + frag_k(s, hf, j);
+        store2(e16 + (size_t)S::W2 * 8, (size_t)S::W2_PART * 8, e, n < N2 ? w2[n * H + k] * SW : 0.0f);
+    }
+    float *tail = reinterpret_cast<float *>(smem + (size_t)S::END_U4 * 16);
+    for (int e = threadIdx.x; e < H; e += NTHR) {
+        tail[S::B1 + e] = b1[e] * T2;
+        tail[S::W2R0 + e] = w2[e] * (1.0f / SH);
+    }
+    for (int e = threadIdx.x; e < 64; e += NTHR) tail[S::B2 + e] = e < N2 ? b2[e] : 0.0f;
+}
+
+// 6 x 16 bytes per lane, every load contiguous: part p = bytes 1024 j + 16 lane (j = 0, 1, 2) of the part's 2304; the
+// third load of a part needs 16 lanes only (columns 32..35) -- the other lanes read on into what follows (the image is
+// allocated with 1 KB of slack for the very last one) and do not store
+struct PreX2 { u32x4 a0, a1, a2, b0, b1, b2; };
+__device__ __forceinline__ void fetch_x2(PreX2 &pre, const SrcX2 &src, int64_t tile, int tap, int lane)
+{
+    const unsigned char *tb = src.x2 + tile * X2_TILE_B + tap * X2_TAP_B + lane * 16;
+    pre.a0 = *reinterpret_cast<const u32x4 *>(tb);
+    pre.a1 = *reinterpret_cast<const u32x4 *>(tb + 1024);
+    pre.a2 = *reinterpret_cast<const u32x4 *>(tb + 2048);
+    pre.b0 = *reinterpret_cast<const u32x4 *>(tb + X2_PART_B);
+    pre.b1 = *reinterpret_cast<const u32x4 *>(tb + X2_PART_B + 1024);
+    pre.b2 = *reinterpret_cast<const u32x4 *>(tb + X2_PART_B + 2048);
+}
+__device__ __forceinline__ void store_x2(unsigned char *img, const PreX2 &pre, int lane)
+{
+    unsigned char *p = img + lane * 16;
+    *reinterpret_cast<u32x4 *>(p) = pre.a0;
+    *reinterpret_cast<u32x4 *>(p + 1024) = pre.a1;
+    *reinterpret_cast<u32x4 *>(p + XF_PART_B) = pre.b0;
+    *reinterpret_cast<u32x4 *>(p + XF_PART_B + 1024) = pre.b1;
+    if (lane < 16) {
+        *reinterpret_cast<u32x4 *>(p + 2048) = pre.a2;
+        *reinterpret_cast<u32x4 *>(p + XF_PART_B + 2048) = pre.b2;
+    }
+}
+// B fragment of layer-1 k-step s (lane = row c, k = 16 s + 8 hf + j): block rows = columns 16 s + 8 hf + q (+ 4), block
+// columns = tile rows 16 (g & 1) + 4 p ..; bit 3 of the column index is hf, and such columns hold their row halves swapped
+__device__ __forceinline__ int lane_tr_fwd(int lane)
+{
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3, h = g >> 1;
+    return (8 * h + q) * XF_COL_B + (((16 * (g & 1) + 4 * p) * 2) ^ (32 * h));
+}
+__device__ __forceinline__ Frag2 x_frag_fwd(const unsigned char *img, int lctr, int s)
+{
+    const unsigned char *a = img + s * (16 * XF_COL_B) + lctr;
+    Frag2 f;
+    f.h = tr128(a, 4 * XF_COL_B);
+    f.l = tr128(a + XF_PART_B, 4 * XF_COL_B);
+    return f;
+}
+
+template <int H>
+__global__ void __launch_bounds__(FWD_THREADS, FWD_WAVES / 4)
+fwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__restrict__ b0, const float *__restrict__ w1,
+              const float *__restrict__ b1, const float *__restrict__ w2, const float *__restrict__ b2, int N2,
+              float *__restrict__ sdf7, float *__restrict__ feature, float *__restrict__ h2c)
+{
+    const int64_t n_samples = src.S;
+    const int K0 = 3 + 2 * src.n_levels;
+    using S = SmemF<H>;
+    constexpr int NT = S::NT;
+    static_assert(XF_IMG_B >= 32 * LDFS * 4, "the feature transpose overlays the image");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 31, hf = lane >> 5;
+    float *tail = reinterpret_cast<float *>(smem_b + (size_t)S::END_U4 * 16);
+    unsigned char *img = smem_b + S::SHARED_BYTES + (size_t)wave * XF_IMG_B;
+    float *Fs = reinterpret_cast<float *>(img);   // [32][LDFS] over the image, which is dead once the first layer has read it
+    stage_weights_fwd<H>(smem_b, w0, b0, w1, b1, w2, b2, K0, N2);
+    for (int e = lane; e < XF_IMG_B / 4; e += 64) reinterpret_cast<unsigned *>(img)[e] = 0u;
+    __syncthreads();
+    const u32x4 *wl = reinterpret_cast<const u32x4 *>(smem_b);
+    const float b2_0 = tail[S::B2];
+    const int lctr = lane_tr_fwd(lane);
+
+    const int64_t n_groups = src.Sp / 32;
+    const int64_t g_first = (int64_t)blockIdx.x * FWD_WAVES + wave, g_step = (int64_t)gridDim.x * FWD_WAVES;
+    PreX2 pre;
+    if (g_first < n_groups) fetch_x2(pre, src, g_first, 0, lane);
+    for (int64_t g = g_first; g < n_groups; g += g_step) {
+        const int64_t s0 = g * 32;
+        for (int tap = 0; tap < 7; ++tap) {
+            store_x2(img, pre, lane);
+            {   // prefetch the next tile of this wave
+                const int ntap = tap == 6 ? 0 : tap + 1;
+                const int64_t ng = tap == 6 ? g + g_step : g;
+                if (ng < n_groups) fetch_x2(pre, src, ng, ntap, lane);
+            }
+            // ---- layer 1: C = T1 z1
+            f32x16 h1[NT], h2[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) h1[t][r] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < KS0; ++s) {
+                const Frag2 xb = x_frag_fwd(img, lctr, s);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) h1[t] = mma3<S::W0_PART>(wl + S::W0 + ((t * KS0 + s) * 2 + hf) * 32 + c, xb, h1[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) h1[t][r] = softplus_scaled<1>(h1[t][r]);
+            // ---- layer 2: C = T2 z2 (bias pre-scaled)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 b = *reinterpret_cast<const float4 *>(tail + S::B1 + 32 * t + 8 * q + 4 * hf);
+                    h2[t][4 * q] = b.x, h2[t][4 * q + 1] = b.y, h2[t][4 * q + 2] = b.z, h2[t][4 * q + 3] = b.w;
+                }
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const Frag2 hb = split2_frag(h1[kt][8 * s], h1[kt][8 * s + 1], h1[kt][8 * s + 2], h1[kt][8 * s + 3],
+                                                 h1[kt][8 * s + 4], h1[kt][8 * s + 5], h1[kt][8 * s + 6], h1[kt][8 * s + 7]);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        h2[t] = mma3<S::W1_PART>(wl + S::W1 + (((t * NT + kt) * 2 + s) * 2 + hf) * 32 + c, hb, h2[t]);
+                }
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) h2[t][r] = softplus_scaled<2>(h2[t][r]);
+            const int64_t s = s0 + c;
+            // ---- SDF: dot(W2[0,:], h2[:,row]) on the vector ALU (W2 row pre-divided by SH), features split over the lane halves
+            float acc = 0.0f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 w = *reinterpret_cast<const float4 *>(tail + S::W2R0 + 32 * t + 8 * q + 4 * hf);
+                    acc = fmaf(w.x, h2[t][4 * q], acc);
+                    acc = fmaf(w.y, h2[t][4 * q + 1], acc);
+                    acc = fmaf(w.z, h2[t][4 * q + 2], acc);
+                    acc = fmaf(w.w, h2[t][4 * q + 3], acc);
+                }
+            acc += __shfl_xor(acc, 32, 64);
+            if (hf == 0 && s < n_samples) sdf7[(int64_t)tap * n_samples + s] = acc + b2_0;
+            if (tap == 0 && feature != nullptr) {
+                if (h2c != nullptr) {   // second hidden layer of the centre rows (unscaled), for the dW2 of the feature rows
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) Fs[c * LDFS + (r & 3) + 8 * (r >> 2) + 4 * hf] = h2[t][r] * (1.0f / SH);
+                        for (int e = lane; e < 32 * 32; e += 64) {
+                            const int r = e >> 5, cc = e & 31;
+                            if (s0 + r < n_samples) h2c[(s0 + r) * H + 32 * t + cc] = Fs[r * LDFS + cc];
+                        }
+                    }
+                }
+                // full last layer on the matrix cores: C = T2 (W2 h2 + b2)
+                f32x16 o[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[t][r] = tail[S::B2 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf] * T2;
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                    for (int ss = 0; ss < 2; ++ss) {
+                        const Frag2 hb = split2_frag(h2[kt][8 * ss], h2[kt][8 * ss + 1], h2[kt][8 * ss + 2], h2[kt][8 * ss + 3],
+                                                     h2[kt][8 * ss + 4], h2[kt][8 * ss + 5], h2[kt][8 * ss + 6], h2[kt][8 * ss + 7]);
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+                            if (t * 32 < N2)
+                                o[t] = mma3<S::W2_PART>(wl + S::W2 + (((t * NT + kt) * 2 + ss) * 2 + hf) * 32 + c, hb, o[t]);
+                    }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int nc = N2 - 32 * t < 32 ? N2 - 32 * t : 32;   // columns of this half (wave-uniform)
+                    if (nc <= 0) break;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) Fs[c * LDFS + (r & 3) + 8 * (r >> 2) + 4 * hf] = o[t][r] * (1.0f / T2);
+                    for (int e = lane; e < 32 * nc; e += 64) {
+                        const int r = e / nc, cc = e - r * nc;
+                        if (s0 + r < n_samples) feature[(s0 + r) * N2 + 32 * t + cc] = Fs[r * LDFS + cc];
+                    }
+                }
+                // the transpose has overwritten the hi part (and the head of the lo part, which the next tile's store
+                // rewrites): its zero columns 36..47 must be zero again (12 x 64 B; columns 0..35 are rewritten per tile)
+                if (lane < 48) *reinterpret_cast<u32x4 *>(img + 36 * XF_COL_B + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+    }
+}
+
+// ==================================================================================================================
+// backward (H = 64), the "quad" form of mlp_quad.hip: a workgroup is 4 waves, wave w owns features 16 w .. 16 w + 15 of
+// every layer, every product is a v_mfma_f32_16x16x32_f16; the layers are recomputed, weight gradients accumulate in
+// registers over the workgroup's whole row loop.  Images: X column-major (lands by LDS-DMA as the gather wrote it),
+// H1 / dz2 / dz1 in mlp_quad.hip's chunked [8-column chunk][row ^ swizzle][8 columns] form, two fp16 parts each.
+// ==================================================================================================================
+constexpr int QCS = 512;               // chunk: 32 rows x 16 B
+constexpr int QX_PART = 64 * 64;       // X image part: 64 columns x 64 B (columns 36..63 constant zero)
+constexpr int QH_PART = 8 * QCS;       // 64-feature activation image part
+
+struct QL {
+    static constexpr int XI = 0;                                  // two X images (tile parity)
+    static constexpr int H1I = XI + 2 * 2 * QX_PART;
+    static constexpr int DZI = H1I + 2 * QH_PART;                 // dz2
+    static constexpr int DZ1 = DZI + 2 * QH_PART;                 // dz1 in an image of its own (no barrier between the last
+    static constexpr int RED = DZ1 + 2 * QH_PART;                 //   read of dz2 and the write of dz1); 8 floats of scratch
+    static constexpr int END = RED + 32;
+};
+
+__device__ __forceinline__ int qoff(int row, int col)
+{
+    const int ch = col >> 3;
+    return ch * QCS + ((row ^ ((ch & 1) * 12)) << 4) + (col & 7) * 2;
+}
+struct LaneQ {
+    int row;     // B fragment of a layer product: chunk 4 kb + g, row 16 rh + c16
+    int tr0;     // transposed fragment: rows 8 g + q, columns 16 ft + 4 p ..
+    int tr1;     //   rows + 4
+    int st;      // store: row 16 rh + c16, columns 16 w + 4 g ..
+    int xtr[2];  // X image, layer-1 B fragment, tile rows 16 rh ..: column 8 g + q, bytes (32 rh + 8 p) ^ 32 (g & 1)
+    int xrow;    // X image, dW0 operand: column c16, rows 8 g .. 8 g + 7
+};
+__device__ __forceinline__ LaneQ lane_consts(int w, int lane)
+{
+    const int g = lane >> 4, c16 = lane & 15, q = c16 >> 2, p = lane & 3;
+    LaneQ c;
+    c.row = g * QCS + ((c16 ^ (12 * (g & 1))) << 4);
+    c.tr0 = (p >> 1) * QCS + (((8 * g + q) ^ (12 * (p >> 1))) << 4) + (p & 1) * 8;
+    c.tr1 = (p >> 1) * QCS + (((8 * g + 4 + q) ^ (12 * (p >> 1))) << 4) + (p & 1) * 8;
+    c.st = (2 * w + (g >> 1)) * QCS + ((c16 ^ (12 * (g >> 1))) << 4) + (g & 1) * 8;
+    c.xtr[0] = (8 * g + q) * 64 + ((8 * p) ^ (32 * (g & 1)));
+    c.xtr[1] = (8 * g + q) * 64 + ((32 + 8 * p) ^ (32 * (g & 1)));
+    c.xrow = c16 * 64 + ((16 * g) ^ (32 * ((c16 >> 3) & 1)));
+    return c;
+}
+// B fragment of a layer product: lane (k-group g, sample row 16 rh + c16) reads features 32 kb + 8 g .. + 7
+__device__ __forceinline__ Frag2 rowq(const unsigned char *img, int kb, int rh, const LaneQ &c)
+{
+    const unsigned char *p = img + c.row + kb * (4 * QCS) + rh * 256;
+    Frag2 f;
+    f.h = ld128(p);
+    f.l = ld128(p + QH_PART);
+    return f;
+}
+// fragment whose k dimension is the tile's 32 ROWS: lane (rows 8 g .. 8 g + 7, column 16 ft + c16); A operand (A[i = column]
+// [k = row]) and B operand (B[k = row][j = column]) of the weight-gradient products
+__device__ __forceinline__ Frag2 trfq(const unsigned char *img, int ft, const LaneQ &c)
+{
+    const unsigned char *a0 = img + c.tr0 + ft * (2 * QCS), *a1 = img + c.tr1 + ft * (2 * QCS);
+    Frag2 f;
+    unsigned x0, x1, y0, y1;
+    tr64(a0, x0, x1);
+    tr64(a1, y0, y1);
+    f.h = u32x4{x0, x1, y0, y1};
+    tr64(a0 + QH_PART, x0, x1);
+    tr64(a1 + QH_PART, y0, y1);
+    f.l = u32x4{x0, x1, y0, y1};
+    return f;
+}
+// this wave's 16 x 16 result (features 16 w + 4 g + r, sample row 16 rh + c16), already scaled -> split once -> image
+__device__ __forceinline__ void store_q(unsigned char *img, int rh, const LaneQ &c, const f32x4 &v)
+{
+    unsigned h0, l0, h1, l1;
+    split2_pair(v[0], v[1], h0, l0);
+    split2_pair(v[2], v[3], h1, l1);
+    unsigned char *p = img + c.st + rh * 256;
+    *reinterpret_cast<uint2 *>(p) = uint2{h0, h1};
+    *reinterpret_cast<uint2 *>(p + QH_PART) = uint2{l0, l1};
+}
+__device__ __forceinline__ Frag2 x_col(const unsigned char *xi, int kb, int rh, const LaneQ &c)
+{
+    const unsigned char *a = xi + c.xtr[rh] + kb * (32 * 64);
+    Frag2 f;
+    f.h = tr128(a, 4 * 64);
+    f.l = tr128(a + QX_PART, 4 * 64);
+    return f;
+}
+__device__ __forceinline__ Frag2 x_rows(const unsigned char *xi, int ct, const LaneQ &c)
+{
+    const unsigned char *a = xi + c.xrow + ct * (16 * 64);
+    Frag2 f;
+    f.h = ld128(a);
+    f.l = ld128(a + QX_PART);
+    return f;
+}
+__device__ __forceinline__ void wait_vm0() { __builtin_amdgcn_s_waitcnt(0x0F70); }      // s_waitcnt vmcnt(0)
+__device__ __forceinline__ void lds_barrier()                                            // see mlp_coop.hip lds_barrier()
+{
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);      // s_waitcnt lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+// 6 linear DMA instructions per tile (1024 + 1024 + 256 bytes per part): i = 3 part + block; wave w issues i = w and, for
+// w < 2, i = w + 4 (ws: the wave index as a SCALAR, so that the choice is a scalar branch)
+__device__ __forceinline__ void dma_one(unsigned char *img, const unsigned char *tb, int i, int lane)
+{
+    const int part = i / 3, b = i - 3 * part;
+    const unsigned char *gp = tb + part * X2_PART_B + b * 1024 + lane * 16;
+    unsigned char *dst = img + part * QX_PART + b * 1024;
+    if (b < 2) __builtin_amdgcn_global_load_lds((glob_void *)gp, (lds_void *)dst, 16, 0, 0);
+    else if (lane < 16) __builtin_amdgcn_global_load_lds((glob_void *)gp, (lds_void *)dst, 16, 0, 0);
+}
+__device__ __forceinline__ void dma_tile(unsigned char *img, const SrcX2 &src, int64_t tile, int tap, int ws, int lane)
+{
+    const unsigned char *tb = src.x2 + tile * X2_TILE_B + tap * X2_TAP_B;
+    dma_one(img, tb, ws, lane);
+    if (ws < 2) dma_one(img, tb, ws + 4, lane);
+}
+// 2^e with |v| 2^e < 2^14 for every |v| <= bound (bound = 0, inf or nan: 1)
+__device__ __forceinline__ float grad_scale(float bound)
+{
+    if (!(bound > 0.0f) || !(bound < 3.0e38f)) return 1.0f;
+    int e = 13 - ilogbf(bound);
+    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    return ldexpf(1.0f, e);
+}
+
+__global__ void __launch_bounds__(256, 2)
+bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__restrict__ b0, const float *__restrict__ w1,
+              const float *__restrict__ b1, const float *__restrict__ w2, const float *__restrict__ d_sdf7,
+              const float *__restrict__ dh2c, const unsigned *__restrict__ absmax /* [2]: bits of max|d_sdf7|, max|dh2c| */,
+              float *__restrict__ d_planes, float *__restrict__ dw0, float *__restrict__ db0, float *__restrict__ dw1,
+              float *__restrict__ db1, float *__restrict__ dw2, float *__restrict__ db2)
+{
+    using L = QL;
+    constexpr int H = 64, KB = 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *s_red = reinterpret_cast<float *>(smem + L::RED);
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
+    const int ws = __builtin_amdgcn_readfirstlane(w);
+    const int K0 = 3 + 2 * src.n_levels;
+    const int fw = 16 * w + c16;                   // the feature this lane addresses in an A fragment of its wave
+    const LaneQ lc = lane_consts(w, lane);
+
+    for (int e = threadIdx.x; e < L::RED / 4; e += 256) reinterpret_cast<unsigned *>(smem)[e] = 0u;
+    // ---- gradient-image scales of this launch: |dz2| <= max|W2 row 0| max|d_sdf| + max|dh2c|, |dz1| <= max_k sum_n |W1[n][k]| |dz2|
+    float m2 = 0.0f, cs = 0.0f;
+    if (threadIdx.x < H) {
+        m2 = fabsf(w2[threadIdx.x]);
+        for (int n = 0; n < H; ++n) cs += fabsf(w1[(size_t)n * H + threadIdx.x]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        m2 = fmaxf(m2, __shfl_xor(m2, o, 64));
+        cs = fmaxf(cs, __shfl_xor(cs, o, 64));
+    }
+    if (threadIdx.x == 0) { s_red[0] = m2; s_red[1] = cs; }
+    __syncthreads();
+    const float bound2 = s_red[0] * __uint_as_float(absmax[0]) + __uint_as_float(absmax[1]);
+    const float G2 = grad_scale(bound2), G1 = grad_scale(s_red[1] * bound2);
+
+    // ---- weight fragments (A operands: lane = (row c16 of the wave's 16-row block, k-group g), 8 consecutive k), x SW
+    Frag2 w1f[KB], w1t[KB], w0f[2], w0t[KB];
+    const int mt = w & 1, rhx = w >> 1;            // this wave's d(hash features) sub-tile: columns 16 mt.., rows 16 rhx..
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        float v[8];
+        const float *p = w1 + (size_t)fw * H + 32 * kb + 8 * g;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = p[j] * SW;
+        w1f[kb] = split2_frag(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);                                                   // W1[fw][k]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = w1[(size_t)(32 * kb + 8 * g + j) * H + fw] * SW;
+        w1t[kb] = split2_frag(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);                                                   // W1[n][fw]
+        const int col = 16 * mt + c16;                                              // hash column of the dx sub-tile
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = col < 2 * src.n_levels ? w0[(size_t)(32 * kb + 8 * g + j) * K0 + 3 + col] * SW : 0.0f;
+        w0t[kb] = split2_frag(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);                                                   // W0[n][3 + col]
+    }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 32 * kb + 8 * g + j;                                      // X column
+            float x = 0.0f;
+            if (k < 32) x = k < 2 * src.n_levels ? w0[(size_t)fw * K0 + 3 + k] : 0.0f;
+            else if (k < 35) x = w0[(size_t)fw * K0 + (k - 32)];
+            else if (k == 35) x = b0[fw];
+            v[j] = x * SW;
+        }
+        w0f[kb] = split2_frag(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+    }
+    f32x4 b1r, w2r;                                // bias of layer 2 (x T2) / row 0 of W2 for features 16 w + 4 g + r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        b1r[r] = b1[16 * w + 4 * g + r] * T2;
+        w2r[r] = w2[16 * w + 4 * g + r];
+    }
+    __syncthreads();
+
+    f32x4 gw1[H / 16], gw0[3], gw2p = {0.f, 0.f, 0.f, 0.f}, gb1p = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int n = 0; n < H / 16; ++n) gw1[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int n = 0; n < 3; ++n) gw0[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float gb2 = 0.0f;
+    const float k_dz1 = G1 / (SW * G2), k_dx = 1.0f / (SW * G1);
+
+    const int64_t n_groups = src.Sp / 32;
+    if ((int64_t)blockIdx.x < n_groups) dma_tile(smem + L::XI, src, (int64_t)blockIdx.x, 0, ws, lane);
+    int parity = 0;
+    for (int64_t gi = blockIdx.x; gi < n_groups; gi += gridDim.x) {
+        const int64_t s0 = gi * 32;
+        for (int tap = 0; tap < 7; ++tap) {
+            const unsigned char *xi = smem + L::XI + parity * 2 * QX_PART;
+            wait_vm0();                            // this wave's share of the tile has landed (and the previous tile's stores retired)
+            // every wave's share has landed once all have passed their wait; the OTHER image is free once all have finished
+            // the previous tile's dW0 reads: one barrier serves both
+            lds_barrier();                                                       // (1)
+            parity ^= 1;
+            bool row_ok[2];
+            float dsdf_raw[2];
+            f32x4 dz[2];
+#pragma unroll
+            for (int rh = 0; rh < 2; ++rh) {
+                const int64_t row = s0 + 16 * rh + c16;
+                row_ok[rh] = row < src.S;
+                const int64_t rowc = row_ok[rh] ? row : src.S - 1;
+                dsdf_raw[rh] = d_sdf7[(int64_t)tap * src.S + rowc];
+                if (tap == 0 && dh2c != nullptr) {     // (uniform) centre taps: d(h2) through the feature rows
+                    const float4 v = *reinterpret_cast<const float4 *>(dh2c + rowc * H + 16 * w + 4 * g);
+                    dz[rh] = f32x4{v.x, v.y, v.z, v.w};
+                } else {
+                    dz[rh] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            {
+                const int ntap = tap == 6 ? 0 : tap + 1;
+                const int64_t ng = tap == 6 ? gi + gridDim.x : gi;
+                if (ng < n_groups) dma_tile(smem + L::XI + parity * 2 * QX_PART, src, ng, ntap, ws, lane);
+            }
+            // ---- recompute layer 1 (C = T1 z1) -> SH h1
+            f32x4 h1[2], h2[2];
+#pragma unroll
+            for (int rh = 0; rh < 2; ++rh) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc = mma3q(w0f[0], x_col(xi, 0, rh, lc), acc);
+                acc = mma3q(w0f[1], x_col(xi, 1, rh, lc), acc);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h1[rh][r] = softplus_scaled<1>(acc[r]);
+                store_q(smem + L::H1I, rh, lc, h1[rh]);
+            }
+            lds_barrier();                                                       // (2) H1 image complete
+            // ---- recompute layer 2 (C = T2 z2), then layer 3 backward: dz2 = (W2[0,:] d_sdf + feature part) sigma'(z2)
+#pragma unroll
+            for (int rh = 0; rh < 2; ++rh) {
+                f32x4 acc = b1r;
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) acc = mma3q(w1f[kb], rowq(smem + L::H1I, kb, rh, lc), acc);
+                const float dsdf = row_ok[rh] ? dsdf_raw[rh] : 0.0f;
+                if (w == 0 && g == 0) gb2 += dsdf;
+                f32x4 dzs;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    h2[rh][r] = softplus_scaled<2>(acc[r]);
+                    gw2p[r] = fmaf(dsdf, h2[rh][r], gw2p[r]);                    // (x SH: unscaled at the flush)
+                    dz[rh][r] = row_ok[rh] ? fmaf(w2r[r], dsdf, dz[rh][r]) * softplus_grad_scaled(h2[rh][r]) : 0.0f;
+                    gb1p[r] += dz[rh][r];
+                    dzs[r] = dz[rh][r] * G2;
+                }
+                store_q(smem + L::DZI, rh, lc, dzs);
+            }
+            lds_barrier();                                                       // (3) dz2 image complete
+            // ---- layer 2 backward: G1 dz1[own k1] = (W1^T dz2) sigma'(z1) ; dW1[own n][all k] += dz2^T h1 (K = the 32 rows)
+#pragma unroll
+            for (int rh = 0; rh < 2; ++rh) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) acc = mma3q(w1t[kb], rowq(smem + L::DZI, kb, rh, lc), acc);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dz[rh][r] = acc[r] * k_dz1 * softplus_grad_scaled(h1[rh][r]);
+            }
+            {
+                const Frag2 a = trfq(smem + L::DZI, w, lc);
+#pragma unroll
+                for (int n = 0; n < H / 16; ++n) gw1[n] = mma3q(a, trfq(smem + L::H1I, n, lc), gw1[n]);   // x G2 SH
+            }
+            store_q(smem + L::DZ1, 0, lc, dz[0]);
+            store_q(smem + L::DZ1, 1, lc, dz[1]);
+            lds_barrier();                                                       // (4) dz1 image complete
+            // ---- layer 1 backward: d(hash features) sub-tile (16 columns x 16 rows, all 64 features); dW0 += dz1^T X
+            {
+                f32x4 dx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) dx = mma3q(w0t[kb], rowq(smem + L::DZ1, kb, rhx, lc), dx);
+                // result rows = hash columns 16 mt + 4 g + r = (level 8 mt + 2 g + (r >> 1), feature r & 1); lane column =
+                // sample row 16 rhx + c16: two float2 stores, 16 lanes cover 128 contiguous bytes of a level plane
+                const int64_t row = s0 + 16 * rhx + c16;
+                if (d_planes != nullptr && row < src.S) {
+                    const int lev = 8 * mt + 2 * g;
+                    if (lev < src.n_active)
+                        *reinterpret_cast<float2 *>(d_planes + (((int64_t)lev * 7 + tap) * src.S + row) * 2) = float2{dx[0] * k_dx, dx[1] * k_dx};
+                    if (lev + 1 < src.n_active)
+                        *reinterpret_cast<float2 *>(d_planes + (((int64_t)(lev + 1) * 7 + tap) * src.S + row) * 2) = float2{dx[2] * k_dx, dx[3] * k_dx};
+                }
+            }
+            {
+                const Frag2 a = trfq(smem + L::DZ1, w, lc);
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) gw0[ct] = mma3q(a, x_rows(xi, ct, lc), gw0[ct]);           // x G1 SX
+            }
+            // no barrier: the next tile's barrier (1) separates these reads from the DMA that overwrites this X image, and
+            // its H1 / dz2 / dz1 writes sit behind its barriers (1) .. (3)
+        }
+    }
+
+    // ---- flush: gw1[n][r] = G2 SH dW1[16 w + 4 g + r][16 n + c16]; gw0[ct][r] = G1 SX dW0 image [feature][X column 16 ct + c16]
+    const float u1 = 1.0f / (G2 * SH), u0 = 1.0f / (G1 * SX);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int f = 16 * w + 4 * g + r;
+#pragma unroll
+        for (int n = 0; n < H / 16; ++n) atomicAdd(&dw1[(size_t)f * H + 16 * n + c16], gw1[n][r] * u1);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+            if (16 * ct + c16 < 2 * src.n_levels) atomicAdd(&dw0[(size_t)f * K0 + 3 + 16 * ct + c16], gw0[ct][r] * u0);
+        if (c16 < 3) atomicAdd(&dw0[(size_t)f * K0 + c16], gw0[2][r] * u0);
+        if (c16 == 3) atomicAdd(&db0[f], gw0[2][r] * u0);
+        float a = gw2p[r], b = gb1p[r];            // per-lane partials -> sum over the 16 sample columns
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            a += __shfl_xor(a, o, 64);
+            b += __shfl_xor(b, o, 64);
+        }
+        if (c16 == 0) {
+            atomicAdd(&dw2[f], a * (1.0f / SH));
+            atomicAdd(&db1[f], b);
+        }
+    }
+    if (w == 0) {
+        gb2 = wave_sum(gb2);
+        if (lane == 0) atomicAdd(&db2[0], gb2);
+    }
+}
+
+// max |v| over n floats -> *out (bits of a non-negative float: unsigned order == float order); *out zeroed by the caller
+__global__ void __launch_bounds__(256)
+absmax_kernel(const float *__restrict__ v, int64_t n, unsigned *__restrict__ out)
+{
+    float m = 0.0f;
+    const int64_t n4 = n / 4;
+    const float4 *v4 = reinterpret_cast<const float4 *>(v);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 t = v4[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(t.x), fabsf(t.y))), fmaxf(fabsf(t.z), fabsf(t.w)));
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(v[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(out, __float_as_uint(m));
+}
+
+}  // namespace
+
+extern "C" {
+
+int rsdf_sdfmlp_fd7_x2_supported(int K0, int H, int N2)
+{
+    return (K0 >= 5 && K0 <= 35 && (K0 - 3) % 2 == 0 && (H == 32 || H == 64) && N2 >= 1 && N2 <= 64) ? 1 : 0;
+}
+
+int rsdf_sdfmlp_fd7_fwd_x2(const void *x2, int n_levels, int H, int N2, const float *w0, const float *b0, const float *w1,
+                           const float *b1, const float *w2, const float *b2, int64_t n_samples, float *sdf7t, float *feature,
+                           float *h2c, void *stream)
+{
+    const int K0 = 3 + 2 * n_levels;
+    RSDF_CHECK_ARG(n_levels >= 1 && n_levels <= 16, "sdfmlp_fd7_fwd_x2: n_levels must be in [1,16]");
+    RSDF_CHECK_ARG(h2c == nullptr || feature != nullptr, "sdfmlp_fd7_fwd_x2: h2c needs feature");
+    RSDF_CHECK_ARG(rsdf_sdfmlp_fd7_x2_supported(K0, H, N2), "sdfmlp_fd7_fwd_x2: unsupported layer sizes");
+    if (n_samples <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t Sp = (n_samples + 31) / 32 * 32;
+    const int64_t want = (Sp / 32 + FWD_WAVES - 1) / FWD_WAVES;
+    const unsigned grid = (unsigned)(want < 512 ? want : 512);
+    const SrcX2 src{reinterpret_cast<const unsigned char *>(x2), n_samples, Sp, n_levels, n_levels};
+    if (H == 64) {
+        if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(fwd_x2_kernel<64>), fwd_lds<64>())) return rc;
+        fwd_x2_kernel<64><<<grid, FWD_THREADS, fwd_lds<64>(), st>>>(src, w0, b0, w1, b1, w2, b2, N2, sdf7t, feature, h2c);
+    } else {
+        if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(fwd_x2_kernel<32>), fwd_lds<32>())) return rc;
+        fwd_x2_kernel<32><<<grid, FWD_THREADS, fwd_lds<32>(), st>>>(src, w0, b0, w1, b1, w2, b2, N2, sdf7t, feature, h2c);
+    }
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_sdfmlp_fd7_bwd_x2(const void *x2, int n_levels, int n_active_levels, int H, int N2, const float *w0, const float *b0,
+                           const float *w1, const float *b1, const float *w2, const float *b2, int64_t n_samples,
+                           const float *d_sdf7t, const float *d_feature, float *dh2c_scratch, void *absmax_scratch,
+                           float *d_planes, float *dw0, float *db0, float *dw1, float *db1, float *dw2, float *db2, void *stream)
+{
+    const int K0 = 3 + 2 * n_levels;
+    (void)b2;
+    RSDF_CHECK_ARG(n_levels >= 1 && n_levels <= 16, "sdfmlp_fd7_bwd_x2: n_levels must be in [1,16]");
+    RSDF_CHECK_ARG(H == 64 && rsdf_sdfmlp_fd7_x2_supported(K0, H, N2), "sdfmlp_fd7_bwd_x2: unsupported layer sizes (H must be 64)");
+    RSDF_CHECK_ARG(absmax_scratch != nullptr, "sdfmlp_fd7_bwd_x2: the 8-byte absmax scratch is required");
+    if (n_samples <= 0) return 0;
+    if (n_active_levels < 0 || n_active_levels > n_levels) n_active_levels = n_levels;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned *am = reinterpret_cast<unsigned *>(absmax_scratch);
+    (void)hipMemsetAsync(am, 0, 8, st);
+    absmax_kernel<<<1024, 256, 0, st>>>(d_sdf7t, 7 * n_samples, am);
+    if (d_feature != nullptr) {
+        RSDF_CHECK_ARG(dh2c_scratch != nullptr, "sdfmlp_fd7_bwd_x2: d_feature needs the [n, H] dh2c scratch");
+        const int rc = rsdf_linear_bwd_input(d_feature, nullptr, N2, w2, n_samples, H, N2, RSDF_ACT_NONE, 0, H, nullptr,
+                                             dh2c_scratch, H, stream);
+        if (rc) return rc;
+        absmax_kernel<<<1024, 256, 0, st>>>(dh2c_scratch, (int64_t)H * n_samples, am + 1);
+    }
+    const int64_t Sp = (n_samples + 31) / 32 * 32;
+    const SrcX2 src{reinterpret_cast<const unsigned char *>(x2), n_samples, Sp, n_levels, n_active_levels};
+    if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(bwd_x2_kernel), QL::END)) return rc;
+    const int64_t groups = Sp / 32;
+    const unsigned grid = (unsigned)(groups < 512 ? groups : 512);     // two workgroups per CU
+    bwd_x2_kernel<<<grid, 256, QL::END, st>>>(src, w0, b0, w1, b1, w2, d_sdf7t, d_feature != nullptr ? dh2c_scratch : nullptr, am,
+                                              d_planes, dw0, db0, dw1, db1, dw2, db2);
+    RSDF_RETURN_LAUNCH();
+}
+
+}  // extern "C"

@@ -7,10 +7,10 @@ cache lines and nothing 35 columns wide ever goes through autograd.
 
 Forward:  x7t -> planes (rsdf_hashgrid_fwd_fd7: one gather of the centre cell + 4 corners per displaced
           tap) -> sdf7t [7][S] (+ feature [S,N2] of the centre taps) (rsdf_sdfmlp_fd7_fwd).
-          Round 4, H = 64 in fp32: the gather writes the MLP kernels' input PRE-SPLIT into bf16 parts as column planes
-          (``x3`` [7][3][35][S rounded up to 32], rsdf_hashgrid_fwd_fd7_x3) and both MLP kernels consume that image
-          (rsdf_sdfmlp_fd7_fwd_x3 / _bwd_x3): same values bit for bit, without the per-kernel split of the 35 input
-          columns and without the backward's staging pass.  ``RSDF_X3=0`` keeps the fp32 planes for A/B.
+          Round 4, H = 64 in fp32: the "x2" form (csrc/mlp_x2.hip) -- every fp32 matrix operand as two fp16 parts, three
+          matrix instructions per product instead of six, and the gather writes the MLP kernels' input image PRE-SPLIT
+          (``x2`` [S / 32][7][2][36][32] fp16, the same bytes as the fp32 planes; rsdf_hashgrid_fwd_fd7_x2), which both
+          MLP kernels consume as it is (rsdf_sdfmlp_fd7_fwd_x2 / _bwd_x2).  ``RSDF_X2=0`` keeps the round-3 kernels.
 Backward: d_sdf7t (+ d_feature, first pushed through the feature rows of the last layer into a [S,H] scratch)
           -> rsdf_sdfmlp_fd7_bwd (recomputes the hidden layers; weight / bias gradients and d_planes)
           -> rsdf_hashgrid_bwd_fd7 (merge, bin through LDS, reduce in LDS) ->
@@ -37,11 +37,11 @@ def supported(K0: int, H: int, N2: int, n_hidden_layers: int, hidden_act: str, o
             and bool(lib().rsdf_sdfmlp_fd7_supported(int(K0), int(H), int(N2))))
 
 
-def use_x3(K0: int, H: int, N2: int, precision: str) -> bool:
-    """The pre-split input image serves the H = 64 fp32 kernels (forward per-wave kernel + quad backward)."""
-    return (precision == "fp32" and H == 64 and os.environ.get("RSDF_X3", "1") != "0"
+def use_x2(K0: int, H: int, N2: int, precision: str) -> bool:
+    """The two-part fp16 form with the pre-split input image serves H = 64 in fp32 (forward + quad backward)."""
+    return (precision == "fp32" and H == 64 and os.environ.get("RSDF_X2", "1") != "0"
             and os.environ.get("RSDF_MLP_FWD", "") != "coop" and os.environ.get("RSDF_MLP_BWD", "") == ""
-            and bool(lib().rsdf_sdfmlp_fd7_x3_supported(int(K0), int(H), int(N2))))
+            and bool(lib().rsdf_sdfmlp_fd7_x2_supported(int(K0), int(H), int(N2))))
 
 
 class _SdfFieldFD7(torch.autograd.Function):
@@ -58,21 +58,21 @@ class _SdfFieldFD7(torch.autograd.Function):
         H, N2 = ws[0].shape[0], ws[4].shape[0]
         dev = xf.device
         st = stream_ptr()
-        x3 = None
+        x2 = None
         pts = None
         if points is not None:
             pts = points.detach().to(torch.float32).contiguous()
             require_device(pts)
             assert pts.shape == (S, 3), "points must be [S,3]"
-        if S > 0 and use_x3(3 + 2 * Lv, H, N2, precision):
-            x3 = torch.empty(int(lib().rsdf_x3_bytes(S)), dtype=torch.uint8, device=dev)
-            check(lib().rsdf_hashgrid_fwd_fd7_x3(None if pts is not None else ptr(xf), ptr(pts), float(radius or 0.0),
+        if S > 0 and use_x2(3 + 2 * Lv, H, N2, precision):
+            x2 = torch.empty(int(lib().rsdf_x2_bytes(S)), dtype=torch.uint8, device=dev)
+            check(lib().rsdf_hashgrid_fwd_fd7_x2(None if pts is not None else ptr(xf), ptr(pts), float(radius or 0.0),
                                                  float(eps or 0.0), ptr(tb), ctypes.byref(meta), S, n_active,
-                                                 float(xyz_scale), float(xyz_offset), ptr(x3), st), "hashgrid_fwd_fd7_x3")
-            planes = x3
+                                                 float(xyz_scale), float(xyz_offset), ptr(x2), st), "hashgrid_fwd_fd7_x2")
+            planes = x2
         else:
             planes = torch.empty(Lv, 7, S, 2, dtype=torch.float32, device=dev)
-        if x3 is not None:
+        if x2 is not None:
             pass
         elif points is not None:
             # the hash kernels derive the stencil from the world-space centres (12 instead of 84 bytes per sample and
@@ -85,14 +85,14 @@ class _SdfFieldFD7(torch.autograd.Function):
         sdf7t = torch.empty(7, S, dtype=torch.float32, device=dev)
         feature = torch.empty(S, N2, dtype=torch.float32, device=dev) if want_feature else None
         h2c = torch.empty(S, H, dtype=torch.float32, device=dev) if want_feature else None
-        if x3 is not None:
-            check(lib().rsdf_sdfmlp_fd7_fwd_x3(ptr(x3), Lv, H, N2, *[ptr(t) for t in ws], S, ptr(sdf7t), ptr(feature),
-                                               ptr(h2c), st), "sdfmlp_fd7_fwd_x3")
+        if x2 is not None:
+            check(lib().rsdf_sdfmlp_fd7_fwd_x2(ptr(x2), Lv, H, N2, *[ptr(t) for t in ws], S, ptr(sdf7t), ptr(feature),
+                                               ptr(h2c), st), "sdfmlp_fd7_fwd_x2")
         else:
             check(L.mlp_fn("rsdf_sdfmlp_fd7_fwd", precision)(ptr(xf), ptr(planes), Lv, n_active, float(xyz_scale),
                                             float(xyz_offset), H, N2, *[ptr(t) for t in ws], S, ptr(sdf7t),
                                             ptr(feature), ptr(h2c), st), "sdfmlp_fd7_fwd")
-        ctx.x3 = x3 is not None
+        ctx.x2 = x2 is not None
         ctx.save_for_backward(xf, planes, *ws)
         ctx.h2c = h2c
         ctx.pts, ctx.radius, ctx.eps, ctx.precision = pts, radius, eps, precision
@@ -119,10 +119,12 @@ class _SdfFieldFD7(torch.autograd.Function):
         dw1, db1 = torch.zeros_like(w1), torch.zeros_like(b1)
         dw2, db2 = torch.zeros_like(w2), torch.zeros_like(b2)
         dh2c = torch.empty(S, H, dtype=torch.float32, device=dev) if gf is not None else None
-        if ctx.x3:
-            check(lib().rsdf_sdfmlp_fd7_bwd_x3(ptr(planes), Lv, ctx.n_active, H, N2, ptr(w0), ptr(b0), ptr(w1), ptr(b1),
-                                               ptr(w2), ptr(b2), S, ptr(g), ptr(gf), ptr(dh2c), ptr(d_planes), ptr(dw0),
-                                               ptr(db0), ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), st), "sdfmlp_fd7_bwd_x3")
+        if ctx.x2:
+            absmax = torch.empty(2, dtype=torch.int32, device=dev)
+            check(lib().rsdf_sdfmlp_fd7_bwd_x2(ptr(planes), Lv, ctx.n_active, H, N2, ptr(w0), ptr(b0), ptr(w1), ptr(b1),
+                                               ptr(w2), ptr(b2), S, ptr(g), ptr(gf), ptr(dh2c), ptr(absmax), ptr(d_planes),
+                                               ptr(dw0), ptr(db0), ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), st),
+                  "sdfmlp_fd7_bwd_x2")
         else:
             check(L.mlp_fn("rsdf_sdfmlp_fd7_bwd", ctx.precision)(ptr(xf), ptr(planes), Lv, ctx.n_active, ctx.xyz[0], ctx.xyz[1],
                                             H, N2, ptr(w0), ptr(b0), ptr(w1), ptr(b1), ptr(w2), ptr(b2), S,

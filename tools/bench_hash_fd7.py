@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--rays", type=int, default=32768)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--only", default="")
-    ap.add_argument("--forms", default="x7t,pts")
+    ap.add_argument("--forms", default="x7t,pts,x2")
     args = ap.parse_args()
     import bench
     from rise_sdf_amd import _lib, ops
@@ -52,7 +52,10 @@ def main():
     st = _lib.stream_ptr()
     P = _lib.ptr
     L = _lib.lib()
+    x2 = torch.empty(int(L.rsdf_x2_bytes(S)), dtype=torch.uint8, device=dev)
     calls = {
+        "fwd_x2": lambda: L.rsdf_hashgrid_fwd_fd7_x2(None, P(pts), radius, eps, P(table), ctypes.byref(meta), S, Lv, 2.0, -1.0,
+                                                     P(x2), st),
         "fwd_x7t": lambda: L.rsdf_hashgrid_fwd_fd7(P(x7t), P(table), ctypes.byref(meta), S, Lv, P(planes), st),
         "fwd_pts": lambda: L.rsdf_hashgrid_fwd_fd7_pts(P(pts), radius, eps, P(table), ctypes.byref(meta), S, Lv,
                                                        P(planes), st),
