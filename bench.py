@@ -202,8 +202,14 @@ def roofline_from(summary, steps):
             return "hbm", n * (L * 8 * 2 * 4 + 12 + L * 2 * 4)
         if name in ("rsdf_hashgrid_fwd_fd7", "rsdf_hashgrid_bwd_fd7"):   # n_samples, n_active, ...
             return "hbm", 7 * a[0] * (16 * 8 * 2 * 4 + 12 + 16 * 2 * 4)   # 7 evaluations x 1164 B
-        if name in ("rsdf_hashgrid_fwd_fd7_pts", "rsdf_hashgrid_bwd_fd7_pts"):   # radius, eps, n_samples, n_active, ...
-            return "hbm", 7 * a[2] * (16 * 8 * 2 * 4 + 12 + 16 * 2 * 4)
+        if name in ("rsdf_hashgrid_fwd_fd7_pts", "rsdf_hashgrid_bwd_fd7_pts", "rsdf_hashgrid_fwd_fd7_x2"):
+            return "hbm", 7 * a[2] * (16 * 8 * 2 * 4 + 12 + 16 * 2 * 4)       # radius, eps, n_samples, n_active, ...
+        if name == "rsdf_sdfmlp_fd7_fwd_x2":  # L, H, N2, n_samples
+            K0, H, S = 3 + 2 * a[0], a[1], a[3]
+            return "mfma", 2.0 * 7 * S * (K0 * H + H * H + H)
+        if name == "rsdf_sdfmlp_fd7_bwd_x2":  # L, n_active, H, N2, n_samples
+            K0, H, S = 3 + 2 * a[0], a[2], a[4]
+            return "mfma", 2 * 2.0 * 7 * S * (K0 * H + H * H + H)
         if name == "rsdf_sdfmlp_fd7_fwd":    # L, n_active, xyz_scale, xyz_offset, H, N2, n_samples
             K0, H, S = 3 + 2 * a[0], a[4], a[6]
             return "mfma", 2.0 * 7 * S * (K0 * H + H * H + H)            # last layer: SDF column only
@@ -219,8 +225,12 @@ def roofline_from(summary, steps):
         return None, 0.0
 
     def samples_of(name, a):
-        if name.endswith("_fd7_pts"):
+        if name.endswith("_fd7_pts") or name == "rsdf_hashgrid_fwd_fd7_x2":
             return a[2]
+        if name == "rsdf_sdfmlp_fd7_fwd_x2":
+            return a[3]
+        if name == "rsdf_sdfmlp_fd7_bwd_x2":
+            return a[4]
         return a[6] if name.startswith("rsdf_sdfmlp_fd7") else a[0]   # (also the _bf16 names)
 
     best = max(summary.items(), key=lambda kv: kv[1]["ms"])
@@ -257,6 +267,11 @@ def roofline_from(summary, steps):
     out["other_kernels"] = others
     if bf16:
         out["note"] = "one bf16 x bf16 MFMA product per k-step, fp32 accumulate; peak = dense bf16 MFMA"
+    elif name.endswith("_x2"):
+        # algorithmic fp32 flops against the fp32 MFMA peak; the kernel evaluates each fp32 product as three
+        # f16 x f16 partial products of two-part operands on v_mfma_f32_*_f16, whose own ceiling
+        # for fp32-equivalent work is 2500 / 3 = 833 TFLOP/s
+        out["note"] = "fp32-equivalent flops (two-part fp16 operands, 3 MFMA products); peak = fp32 MFMA dense"
     elif name.startswith("rsdf_sdfmlp_fd7"):
         # algorithmic fp32 flops against the fp32 MFMA peak; the kernel evaluates each fp32 product as six
         # bf16 x bf16 partial products on v_mfma_f32_32x32x16_bf16, whose own ceiling for
@@ -585,14 +600,17 @@ def main():
                                                                   / max(overlapped[k]["calls"], 1), 4)
             attach_traffic(roof, args.pmc_summary)
             if roof is not None and "other_kernels" in roof:
-                fd7 = roof["other_kernels"].get("rsdf_hashgrid_fwd_fd7_pts") or \
+                fd7 = roof["other_kernels"].get("rsdf_hashgrid_fwd_fd7_x2") or \
+                    roof["other_kernels"].get("rsdf_hashgrid_fwd_fd7_pts") or \
                     roof["other_kernels"].get("rsdf_hashgrid_fwd_fd7")
                 if fd7 is not None:
                     # the stencil gather priced two ways: SURVEY 8d's algorithmic bytes (7 evaluations x 1164 B; a
                     # fraction >= 1 only says that it fetches far fewer corners than 56 per level), and the bytes it
-                    # cannot avoid moving through HBM (centre 12 B + planes 896 B per sample; the table is L2 / MALL resident)
-                    fd7["necessary_bytes_per_sample"] = 908
-                    fd7["achieved_necessary"] = round(fd7["achieved"] * 908.0 / (7 * 1164.0), 1)
+                    # cannot avoid moving through HBM (centre 12 B + planes 896 B per sample -- the x2 image: 1008 B with its
+                    # xyz / bias columns; the table is L2 / MALL resident)
+                    nb = 1020 if "rsdf_hashgrid_fwd_fd7_x2" in roof["other_kernels"] else 908
+                    fd7["necessary_bytes_per_sample"] = nb
+                    fd7["achieved_necessary"] = round(fd7["achieved"] * nb / (7 * 1164.0), 1)
                     fd7["frac_necessary"] = round(fd7["achieved_necessary"] / HBM_PEAK_GBS, 4)
                     fd7["evals_per_sec"] = round(fd7["achieved"] * 1e9 / 1164.0)
                 roof["other_kernels"]["rsdf_hashgrid_fwd (generic)"] = generic_gather_probe(model, rays, jitter, args.chunk)

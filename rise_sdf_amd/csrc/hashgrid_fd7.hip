@@ -304,50 +304,48 @@ __device__ __forceinline__ void x2_store_features(unsigned char *p, bool odd, fl
     *reinterpret_cast<unsigned *>(p) = x2_pair_exchange(h, odd);
     *reinterpret_cast<unsigned *>(p + X2_PART_B) = x2_pair_exchange(lo, odd);
 }
-__device__ __forceinline__ void x2_store_col(const X2Out &o, int tap, int col, int64_t s, float v)
-{
-    unsigned h, lo;
-    x2_split(v * X2_SCALE, 0.0f, h, lo);
-    unsigned char *p = x2_at(o, s, tap, 0, col);
-    *reinterpret_cast<unsigned short *>(p) = (unsigned short)h;
-    *reinterpret_cast<unsigned short *>(p + X2_PART_B) = (unsigned short)lo;
-}
-__device__ __forceinline__ void x2_store_xyz(const X2Out &o, int tap, int k, int64_t s, float u, bool pad)
-{
-    x2_store_col(o, tap, 32 + k, s, pad ? 0.0f : u * o.xyz_scale + o.xyz_offset);
-}
-// unit-cube coordinates of the 7 stencil points, as rsdf_fd_points writes them (neus.hip fd_points_kernel)
+// unit-cube coordinates of the 7 stencil points, as rsdf_fd_points writes them (neus.hip fd_points_kernel), * scale + offset,
+// and the bias column: written as two more "levels" -- (x, y) into columns 32 / 33 and (z, 1) into 34 / 35 -- through the
+// same pair exchange as the features (two dword stores per lane, tap and part instead of four 2-byte ones: the level-0
+// workgroups that carry these stores were a millisecond of the launch's tail)
 template <bool DERIVE>
 __device__ __forceinline__ void x2_store_points(const X2Out &o, const TapSrc &src, int64_t S, int64_t s, int64_t sl, bool pad)
 {
-#pragma unroll
-    for (int t = 0; t < 7; ++t) x2_store_col(o, t, 35, s, pad ? 0.0f : 1.0f);
+    const bool odd = (threadIdx.x & 1) != 0;
+    const unsigned loff = (threadIdx.x >> 5) * (unsigned)X2_TILE_B + (unsigned)(32 + (int)(threadIdx.x & 1)) * 64u +
+                          (unsigned)(2 * (int)(threadIdx.x & 30));
+    unsigned char *bb = o.base + (s - threadIdx.x) / 32 * X2_TILE_B;
+    const float one = pad ? 0.0f : 1.0f;
+    float u[7][3];
     if (DERIVE) {
         const float r = src.radius, two_r = r - (-r);
-        float p[3], u0[3], uc[3];
+        float p[3], uc[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             p[k] = src.pw[sl * 3 + k];
-            u0[k] = (p[k] - (-r)) / two_r;
+            u[0][k] = (p[k] - (-r)) / two_r;
             uc[k] = (fminf(fmaxf(p[k], -r), r) - (-r)) / two_r;
-            x2_store_xyz(o, 0, k, s, u0[k], pad);
         }
 #pragma unroll
         for (int t = 1; t < 7; ++t) {
             const int a = (t - 1) >> 1;
             const float off = ((t - 1) & 1) ? -src.eps : src.eps;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                float u = uc[k];
-                if (k == a) u = (fminf(fmaxf(p[k] + off, -r), r) - (-r)) / two_r;
-                x2_store_xyz(o, t, k, s, u, pad);
-            }
+            for (int k = 0; k < 3; ++k) u[t][k] = k == a ? (fminf(fmaxf(p[k] + off, -r), r) - (-r)) / two_r : uc[k];
         }
     } else {
 #pragma unroll
         for (int t = 0; t < 7; ++t)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) x2_store_xyz(o, t, k, s, src.x7t[((int64_t)t * S + sl) * 3 + k], pad);
+            for (int k = 0; k < 3; ++k) u[t][k] = src.x7t[((int64_t)t * S + sl) * 3 + k];
+    }
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {
+        float v[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[k] = pad ? 0.0f : u[t][k] * o.xyz_scale + o.xyz_offset;
+        x2_store_features(bb + t * X2_TAP_B + loff, odd, v[0], v[1]);
+        x2_store_features(bb + t * X2_TAP_B + loff + 128, odd, v[2], one);
     }
 }
 
@@ -456,7 +454,7 @@ __device__ __forceinline__ void fd7_fwd_sample(const TapSrc &src, const float2 *
 // 8192-tile groups (176 MB + the 64 MB of tables: past the MALL) 18.8.  Not paying, measured: XCD-contiguous sample
 // ranges (neighbouring rays in one L2: <= 3 %), several tiles per workgroup, forcing more waves per SIMD.
 #ifndef RSDF_X2_WAVES
-#define RSDF_X2_WAVES 4     // the x3 form's split + stores would take 146 registers (3 waves per SIMD: +23 % time); held to 128
+#define RSDF_X2_WAVES 3     // (4 waves per SIMD = 128 registers spill 10 of them: 13.3 against 12.9 ms per launch)
 #endif
 template <bool DERIVE, bool X3>
 __global__ void __launch_bounds__(F_THREADS, X3 ? RSDF_X2_WAVES : RSDF_FWD_WAVES)

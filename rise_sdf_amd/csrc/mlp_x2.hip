@@ -156,7 +156,13 @@ struct SrcX2 {
 // (transposed chaining: a layer's accumulator tile, split, IS the next layer's B operand -- mlp_fused.hip), weights of
 // all layers in LDS, the tile's input image per wave in LDS ([part 2][column 48][32 rows]: columns 36..47 constant zero).
 // ==================================================================================================================
-constexpr int FWD_WAVES = 8, FWD_THREADS = FWD_WAVES * 64;
+#ifndef RSDF_X2_FWD_WAVES
+#define RSDF_X2_FWD_WAVES 12     // 168 registers: three waves per SIMD (8 waves: 7.49 against 7.23 ms per launch)
+#endif
+#ifndef RSDF_X2_BWD_OCC
+#define RSDF_X2_BWD_OCC 2
+#endif
+constexpr int FWD_WAVES = RSDF_X2_FWD_WAVES, FWD_THREADS = FWD_WAVES * 64;
 constexpr int KS0 = 3;                 // layer-1 k-steps of 16 columns
 constexpr int LDFS = 33;               // [row][32 features] transpose of the centre rows' outputs
 constexpr int XF_COL_B = 64, XF_PART_B = 48 * XF_COL_B, XF_IMG_B = 2 * XF_PART_B;
@@ -524,7 +530,7 @@ __device__ __forceinline__ float grad_scale(float bound)
     return ldexpf(1.0f, e);
 }
 
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, RSDF_X2_BWD_OCC)
 bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__restrict__ b0, const float *__restrict__ w1,
               const float *__restrict__ b1, const float *__restrict__ w2, const float *__restrict__ d_sdf7,
               const float *__restrict__ dh2c, const unsigned *__restrict__ absmax /* [2]: bits of max|d_sdf7|, max|dh2c| */,
@@ -820,7 +826,8 @@ int rsdf_sdfmlp_fd7_bwd_x2(const void *x2, int n_levels, int n_active_levels, in
     const SrcX2 src{reinterpret_cast<const unsigned char *>(x2), n_samples, Sp, n_levels, n_active_levels};
     if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(bwd_x2_kernel), QL::END)) return rc;
     const int64_t groups = Sp / 32;
-    const unsigned grid = (unsigned)(groups < 512 ? groups : 512);     // two workgroups per CU
+    const int64_t max_wgs = 256 * RSDF_X2_BWD_OCC;                       // RSDF_X2_BWD_OCC workgroups per CU
+    const unsigned grid = (unsigned)(groups < max_wgs ? groups : max_wgs);
     bwd_x2_kernel<<<grid, 256, QL::END, st>>>(src, w0, b0, w1, b1, w2, d_sdf7t, d_feature != nullptr ? dh2c_scratch : nullptr, am,
                                               d_planes, dw0, db0, dw1, db1, dw2, db2);
     RSDF_RETURN_LAUNCH();
