@@ -167,12 +167,17 @@ constexpr int KS0 = 3;                 // layer-1 k-steps of 16 columns
 constexpr int LDFS = 33;               // [row][32 features] transpose of the centre rows' outputs
 constexpr int XF_COL_B = 64, XF_PART_B = 48 * XF_COL_B, XF_IMG_B = 2 * XF_PART_B;
 
+// H = 128: W0 + W1 alone are 88 KB of the 160: the last layer's feature rows are not staged -- the kernel writes the centre
+// rows' second hidden layer (h2c) and the entry point runs one per-layer product on it (mlp_coop.hip's lean forward did
+// the same).  With three bf16 parts per weight (135 KB) this width needed the cooperative register partition of
+// mlp_coop.hip; with two parts every wave can again hold the whole network through LDS.
 template <int H>
 struct SmemF {
     static constexpr int NT = H / 32;
+    static constexpr bool W2_IN_LDS = H <= 64;
     static constexpr int W0_PART = NT * KS0 * 2 * 32;            // [nt][s][hf][c]                (units: 16 bytes)
     static constexpr int W1_PART = NT * NT * 2 * 2 * 32;         // [nt][kt][s][hf][c]
-    static constexpr int W2_PART = 2 * NT * 2 * 2 * 32;          // [n2 tile (2)][kt][s][hf][c]
+    static constexpr int W2_PART = W2_IN_LDS ? 2 * NT * 2 * 2 * 32 : 0;   // [n2 tile (2)][kt][s][hf][c]
     static constexpr int W0 = 0;
     static constexpr int W1 = W0 + 2 * W0_PART;
     static constexpr int W2 = W1 + 2 * W1_PART;
@@ -184,7 +189,9 @@ struct SmemF {
     static constexpr size_t SHARED_BYTES = (size_t)END_U4 * 16 + (size_t)TAIL_F * 4;
 };
 template <int H>
-size_t fwd_lds() { return SmemF<H>::SHARED_BYTES + (size_t)FWD_WAVES * XF_IMG_B; }
+constexpr int fwd_waves() { return H <= 64 ? FWD_WAVES : 8; }       // H = 128: 88 KB of weights + 8 x 6 KB of images, ~230 registers
+template <int H>
+size_t fwd_lds() { return SmemF<H>::SHARED_BYTES + (size_t)fwd_waves<H>() * XF_IMG_B; }
 
 // k of element j of lane half hf in k-step s of a 32-feature activation tile (the accumulator's register order)
 __device__ __forceinline__ int frag_k(int s, int hf, int j) { return 16 * s + 8 * (j >> 2) + 4 * hf + (j & 3); }
@@ -210,7 +217,7 @@ __device__ __forceinline__ void stage_weights_fwd(unsigned char *smem, const flo
         const int n = 32 * nt + c, k = 32 * kt + frag_k(s, hf, j);
         store2(e16 + (size_t)S::W1 * 8, (size_t)S::W1_PART * 8, e, w1[n * H + k] * SW);
     }
-    for (int e = threadIdx.x; e < 2 * NT * 2 * 2 * 32 * 8; e += NTHR) {
+    for (int e = threadIdx.x; S::W2_IN_LDS && e < 2 * NT * 2 * 2 * 32 * 8; e += NTHR) {
         const int j = e & 7, c = (e >> 3) & 31, hf = (e >> 8) & 1, s = (e >> 9) & 1, kt = (e >> 10) % NT, nt = (e >> 10) / NT;
         const int n = 32 * nt + c, k = 32 * kt + frag_k(s, hf, j);
         store2(e16 + (size_t)S::W2 * 8, (size_t)S::W2_PART * 8, e, n < N2 ? w2[n * H + k] * SW : 0.0f);
@@ -266,7 +273,7 @@ __device__ __forceinline__ Frag2 x_frag_fwd(const unsigned char *img, int lctr, 
 }
 
 template <int H>
-__global__ void __launch_bounds__(FWD_THREADS, FWD_WAVES / 4)
+__global__ void __launch_bounds__(64 * fwd_waves<H>(), fwd_waves<H>() / 4)
 fwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__restrict__ b0, const float *__restrict__ w1,
               const float *__restrict__ b1, const float *__restrict__ w2, const float *__restrict__ b2, int N2,
               float *__restrict__ sdf7, float *__restrict__ feature, float *__restrict__ h2c)
@@ -289,7 +296,7 @@ fwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
     const int lctr = lane_tr_fwd(lane);
 
     const int64_t n_groups = src.Sp / 32;
-    const int64_t g_first = (int64_t)blockIdx.x * FWD_WAVES + wave, g_step = (int64_t)gridDim.x * FWD_WAVES;
+    const int64_t g_first = (int64_t)blockIdx.x * fwd_waves<H>() + wave, g_step = (int64_t)gridDim.x * fwd_waves<H>();
     PreX2 pre;
     if (g_first < n_groups) fetch_x2(pre, src, g_first, 0, lane);
     for (int64_t g = g_first; g < n_groups; g += g_step) {
@@ -354,7 +361,7 @@ fwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
                 }
             acc += __shfl_xor(acc, 32, 64);
             if (hf == 0 && s < n_samples) sdf7[(int64_t)tap * n_samples + s] = acc + b2_0;
-            if (tap == 0 && feature != nullptr) {
+            if (tap == 0 && (S::W2_IN_LDS ? feature != nullptr : h2c != nullptr)) {
                 if (h2c != nullptr) {   // second hidden layer of the centre rows (unscaled), for the dW2 of the feature rows
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
@@ -366,6 +373,7 @@ fwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
                         }
                     }
                 }
+                if constexpr (S::W2_IN_LDS) {
                 // full last layer on the matrix cores: C = T2 (W2 h2 + b2)
                 f32x16 o[2];
 #pragma unroll
@@ -394,6 +402,7 @@ fwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
                         if (s0 + r < n_samples) feature[(s0 + r) * N2 + 32 * t + cc] = Fs[r * LDFS + cc];
                     }
                 }
+                }
                 // the transpose has overwritten the hi part (and the head of the lo part, which the next tile's store
                 // rewrites): its zero columns 36..47 must be zero again (12 x 64 B; columns 0..35 are rewritten per tile)
                 if (lane < 48) *reinterpret_cast<u32x4 *>(img + 36 * XF_COL_B + lane * 16) = u32x4{0u, 0u, 0u, 0u};
@@ -410,14 +419,16 @@ fwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
 // ==================================================================================================================
 constexpr int QCS = 512;               // chunk: 32 rows x 16 B
 constexpr int QX_PART = 64 * 64;       // X image part: 64 columns x 64 B (columns 36..63 constant zero)
-constexpr int QH_PART = 8 * QCS;       // 64-feature activation image part
 
+template <int NW>
 struct QL {
+    static constexpr int H = 16 * NW;
+    static constexpr int H_PART = (H / 8) * QCS;                  // activation image part
     static constexpr int XI = 0;                                  // two X images (tile parity)
     static constexpr int H1I = XI + 2 * 2 * QX_PART;
-    static constexpr int DZI = H1I + 2 * QH_PART;                 // dz2
-    static constexpr int DZ1 = DZI + 2 * QH_PART;                 // dz1 in an image of its own (no barrier between the last
-    static constexpr int RED = DZ1 + 2 * QH_PART;                 //   read of dz2 and the write of dz1); 8 floats of scratch
+    static constexpr int DZI = H1I + 2 * H_PART;                  // dz2
+    static constexpr int DZ1 = DZI + 2 * H_PART;                  // dz1 in an image of its own (no barrier between the last
+    static constexpr int RED = DZ1 + 2 * H_PART;                  //   read of dz2 and the write of dz1); 8 floats of scratch
     static constexpr int END = RED + 32;
 };
 
@@ -448,16 +459,18 @@ __device__ __forceinline__ LaneQ lane_consts(int w, int lane)
     return c;
 }
 // B fragment of a layer product: lane (k-group g, sample row 16 rh + c16) reads features 32 kb + 8 g .. + 7
+template <int PART>
 __device__ __forceinline__ Frag2 rowq(const unsigned char *img, int kb, int rh, const LaneQ &c)
 {
     const unsigned char *p = img + c.row + kb * (4 * QCS) + rh * 256;
     Frag2 f;
     f.h = ld128(p);
-    f.l = ld128(p + QH_PART);
+    f.l = ld128(p + PART);
     return f;
 }
 // fragment whose k dimension is the tile's 32 ROWS: lane (rows 8 g .. 8 g + 7, column 16 ft + c16); A operand (A[i = column]
 // [k = row]) and B operand (B[k = row][j = column]) of the weight-gradient products
+template <int PART>
 __device__ __forceinline__ Frag2 trfq(const unsigned char *img, int ft, const LaneQ &c)
 {
     const unsigned char *a0 = img + c.tr0 + ft * (2 * QCS), *a1 = img + c.tr1 + ft * (2 * QCS);
@@ -466,12 +479,13 @@ __device__ __forceinline__ Frag2 trfq(const unsigned char *img, int ft, const La
     tr64(a0, x0, x1);
     tr64(a1, y0, y1);
     f.h = u32x4{x0, x1, y0, y1};
-    tr64(a0 + QH_PART, x0, x1);
-    tr64(a1 + QH_PART, y0, y1);
+    tr64(a0 + PART, x0, x1);
+    tr64(a1 + PART, y0, y1);
     f.l = u32x4{x0, x1, y0, y1};
     return f;
 }
 // this wave's 16 x 16 result (features 16 w + 4 g + r, sample row 16 rh + c16), already scaled -> split once -> image
+template <int PART>
 __device__ __forceinline__ void store_q(unsigned char *img, int rh, const LaneQ &c, const f32x4 &v)
 {
     unsigned h0, l0, h1, l1;
@@ -479,7 +493,7 @@ __device__ __forceinline__ void store_q(unsigned char *img, int rh, const LaneQ 
     split2_pair(v[2], v[3], h1, l1);
     unsigned char *p = img + c.st + rh * 256;
     *reinterpret_cast<uint2 *>(p) = uint2{h0, h1};
-    *reinterpret_cast<uint2 *>(p + QH_PART) = uint2{l0, l1};
+    *reinterpret_cast<uint2 *>(p + PART) = uint2{l0, l1};
 }
 __device__ __forceinline__ Frag2 x_col(const unsigned char *xi, int kb, int rh, const LaneQ &c)
 {
@@ -505,8 +519,8 @@ __device__ __forceinline__ void lds_barrier()                                   
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
-// 6 linear DMA instructions per tile (1024 + 1024 + 256 bytes per part): i = 3 part + block; wave w issues i = w and, for
-// w < 2, i = w + 4 (ws: the wave index as a SCALAR, so that the choice is a scalar branch)
+// 6 linear DMA instructions per tile (1024 + 1024 + 256 bytes per part): i = 3 part + block; with four waves wave w issues
+// i = w and, for w < 2, i = w + 4; with eight, waves 0..5 one each (ws: the wave index as a SCALAR: scalar branches)
 __device__ __forceinline__ void dma_one(unsigned char *img, const unsigned char *tb, int i, int lane)
 {
     const int part = i / 3, b = i - 3 * part;
@@ -515,11 +529,16 @@ __device__ __forceinline__ void dma_one(unsigned char *img, const unsigned char 
     if (b < 2) __builtin_amdgcn_global_load_lds((glob_void *)gp, (lds_void *)dst, 16, 0, 0);
     else if (lane < 16) __builtin_amdgcn_global_load_lds((glob_void *)gp, (lds_void *)dst, 16, 0, 0);
 }
+template <int NW>
 __device__ __forceinline__ void dma_tile(unsigned char *img, const SrcX2 &src, int64_t tile, int tap, int ws, int lane)
 {
     const unsigned char *tb = src.x2 + tile * X2_TILE_B + tap * X2_TAP_B;
-    dma_one(img, tb, ws, lane);
-    if (ws < 2) dma_one(img, tb, ws + 4, lane);
+    if (NW == 4) {
+        dma_one(img, tb, ws, lane);
+        if (ws < 2) dma_one(img, tb, ws + 4, lane);
+    } else if (ws < 6) {
+        dma_one(img, tb, ws, lane);
+    }
 }
 // 2^e with |v| 2^e < 2^14 for every |v| <= bound (bound = 0, inf or nan: 1)
 __device__ __forceinline__ float grad_scale(float bound)
@@ -530,15 +549,18 @@ __device__ __forceinline__ float grad_scale(float bound)
     return ldexpf(1.0f, e);
 }
 
-__global__ void __launch_bounds__(256, RSDF_X2_BWD_OCC)
+// NW = 4 (H = 64): two workgroups per CU.  NW = 8 (H = 128): one workgroup of eight waves per CU; the four 16 x 16
+// sub-tiles of d(hash features) go to waves 0..3.
+template <int NW>
+__global__ void __launch_bounds__(64 * NW, NW == 4 ? RSDF_X2_BWD_OCC : 1)
 bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__restrict__ b0, const float *__restrict__ w1,
               const float *__restrict__ b1, const float *__restrict__ w2, const float *__restrict__ d_sdf7,
               const float *__restrict__ dh2c, const unsigned *__restrict__ absmax /* [2]: bits of max|d_sdf7|, max|dh2c| */,
               float *__restrict__ d_planes, float *__restrict__ dw0, float *__restrict__ db0, float *__restrict__ dw1,
               float *__restrict__ db1, float *__restrict__ dw2, float *__restrict__ db2)
 {
-    using L = QL;
-    constexpr int H = 64, KB = 2;
+    using L = QL<NW>;
+    constexpr int H = L::H, KB = H / 32, HP = L::H_PART, NTHR = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *s_red = reinterpret_cast<float *>(smem + L::RED);
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
@@ -547,7 +569,7 @@ bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
     const int fw = 16 * w + c16;                   // the feature this lane addresses in an A fragment of its wave
     const LaneQ lc = lane_consts(w, lane);
 
-    for (int e = threadIdx.x; e < L::RED / 4; e += 256) reinterpret_cast<unsigned *>(smem)[e] = 0u;
+    for (int e = threadIdx.x; e < L::RED / 4; e += NTHR) reinterpret_cast<unsigned *>(smem)[e] = 0u;
     // ---- gradient-image scales of this launch: |dz2| <= max|W2 row 0| max|d_sdf| + max|dh2c|, |dz1| <= max_k sum_n |W1[n][k]| |dz2|
     float m2 = 0.0f, cs = 0.0f;
     if (threadIdx.x < H) {
@@ -559,14 +581,15 @@ bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
         m2 = fmaxf(m2, __shfl_xor(m2, o, 64));
         cs = fmaxf(cs, __shfl_xor(cs, o, 64));
     }
-    if (threadIdx.x == 0) { s_red[0] = m2; s_red[1] = cs; }
+    if (lane == 0 && w < 2) { s_red[2 * w] = m2; s_red[2 * w + 1] = cs; }      // (H <= 128: the first two waves)
     __syncthreads();
-    const float bound2 = s_red[0] * __uint_as_float(absmax[0]) + __uint_as_float(absmax[1]);
-    const float G2 = grad_scale(bound2), G1 = grad_scale(s_red[1] * bound2);
+    const float m2a = H > 64 ? fmaxf(s_red[0], s_red[2]) : s_red[0], csa = H > 64 ? fmaxf(s_red[1], s_red[3]) : s_red[1];
+    const float bound2 = m2a * __uint_as_float(absmax[0]) + __uint_as_float(absmax[1]);
+    const float G2 = grad_scale(bound2), G1 = grad_scale(csa * bound2);
 
     // ---- weight fragments (A operands: lane = (row c16 of the wave's 16-row block, k-group g), 8 consecutive k), x SW
     Frag2 w1f[KB], w1t[KB], w0f[2], w0t[KB];
-    const int mt = w & 1, rhx = w >> 1;            // this wave's d(hash features) sub-tile: columns 16 mt.., rows 16 rhx..
+    const int mt = w & 1, rhx = (w >> 1) & 1;      // this wave's d(hash features) sub-tile: columns 16 mt.., rows 16 rhx.. (waves 0..3)
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
         float v[8];
@@ -613,7 +636,7 @@ bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
     const float k_dz1 = G1 / (SW * G2), k_dx = 1.0f / (SW * G1);
 
     const int64_t n_groups = src.Sp / 32;
-    if ((int64_t)blockIdx.x < n_groups) dma_tile(smem + L::XI, src, (int64_t)blockIdx.x, 0, ws, lane);
+    if ((int64_t)blockIdx.x < n_groups) dma_tile<NW>(smem + L::XI, src, (int64_t)blockIdx.x, 0, ws, lane);
     int parity = 0;
     for (int64_t gi = blockIdx.x; gi < n_groups; gi += gridDim.x) {
         const int64_t s0 = gi * 32;
@@ -643,7 +666,7 @@ bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
             {
                 const int ntap = tap == 6 ? 0 : tap + 1;
                 const int64_t ng = tap == 6 ? gi + gridDim.x : gi;
-                if (ng < n_groups) dma_tile(smem + L::XI + parity * 2 * QX_PART, src, ng, ntap, ws, lane);
+                if (ng < n_groups) dma_tile<NW>(smem + L::XI + parity * 2 * QX_PART, src, ng, ntap, ws, lane);
             }
             // ---- recompute layer 1 (C = T1 z1) -> SH h1
             f32x4 h1[2], h2[2];
@@ -654,7 +677,7 @@ bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
                 acc = mma3q(w0f[1], x_col(xi, 1, rh, lc), acc);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) h1[rh][r] = softplus_scaled<1>(acc[r]);
-                store_q(smem + L::H1I, rh, lc, h1[rh]);
+                store_q<HP>(smem + L::H1I, rh, lc, h1[rh]);
             }
             lds_barrier();                                                       // (2) H1 image complete
             // ---- recompute layer 2 (C = T2 z2), then layer 3 backward: dz2 = (W2[0,:] d_sdf + feature part) sigma'(z2)
@@ -662,7 +685,7 @@ bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
             for (int rh = 0; rh < 2; ++rh) {
                 f32x4 acc = b1r;
 #pragma unroll
-                for (int kb = 0; kb < KB; ++kb) acc = mma3q(w1f[kb], rowq(smem + L::H1I, kb, rh, lc), acc);
+                for (int kb = 0; kb < KB; ++kb) acc = mma3q(w1f[kb], rowq<HP>(smem + L::H1I, kb, rh, lc), acc);
                 const float dsdf = row_ok[rh] ? dsdf_raw[rh] : 0.0f;
                 if (w == 0 && g == 0) gb2 += dsdf;
                 f32x4 dzs;
@@ -674,7 +697,7 @@ bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
                     gb1p[r] += dz[rh][r];
                     dzs[r] = dz[rh][r] * G2;
                 }
-                store_q(smem + L::DZI, rh, lc, dzs);
+                store_q<HP>(smem + L::DZI, rh, lc, dzs);
             }
             lds_barrier();                                                       // (3) dz2 image complete
             // ---- layer 2 backward: G1 dz1[own k1] = (W1^T dz2) sigma'(z1) ; dW1[own n][all k] += dz2^T h1 (K = the 32 rows)
@@ -682,23 +705,23 @@ bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
             for (int rh = 0; rh < 2; ++rh) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int kb = 0; kb < KB; ++kb) acc = mma3q(w1t[kb], rowq(smem + L::DZI, kb, rh, lc), acc);
+                for (int kb = 0; kb < KB; ++kb) acc = mma3q(w1t[kb], rowq<HP>(smem + L::DZI, kb, rh, lc), acc);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dz[rh][r] = acc[r] * k_dz1 * softplus_grad_scaled(h1[rh][r]);
             }
             {
-                const Frag2 a = trfq(smem + L::DZI, w, lc);
+                const Frag2 a = trfq<HP>(smem + L::DZI, w, lc);
 #pragma unroll
-                for (int n = 0; n < H / 16; ++n) gw1[n] = mma3q(a, trfq(smem + L::H1I, n, lc), gw1[n]);   // x G2 SH
+                for (int n = 0; n < H / 16; ++n) gw1[n] = mma3q(a, trfq<HP>(smem + L::H1I, n, lc), gw1[n]);   // x G2 SH
             }
-            store_q(smem + L::DZ1, 0, lc, dz[0]);
-            store_q(smem + L::DZ1, 1, lc, dz[1]);
+            store_q<HP>(smem + L::DZ1, 0, lc, dz[0]);
+            store_q<HP>(smem + L::DZ1, 1, lc, dz[1]);
             lds_barrier();                                                       // (4) dz1 image complete
             // ---- layer 1 backward: d(hash features) sub-tile (16 columns x 16 rows, all 64 features); dW0 += dz1^T X
-            {
+            if (NW == 4 || ws < 4) {
                 f32x4 dx = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int kb = 0; kb < KB; ++kb) dx = mma3q(w0t[kb], rowq(smem + L::DZ1, kb, rhx, lc), dx);
+                for (int kb = 0; kb < KB; ++kb) dx = mma3q(w0t[kb], rowq<HP>(smem + L::DZ1, kb, rhx, lc), dx);
                 // result rows = hash columns 16 mt + 4 g + r = (level 8 mt + 2 g + (r >> 1), feature r & 1); lane column =
                 // sample row 16 rhx + c16: two float2 stores, 16 lanes cover 128 contiguous bytes of a level plane
                 const int64_t row = s0 + 16 * rhx + c16;
@@ -711,7 +734,7 @@ bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
                 }
             }
             {
-                const Frag2 a = trfq(smem + L::DZ1, w, lc);
+                const Frag2 a = trfq<HP>(smem + L::DZ1, w, lc);
 #pragma unroll
                 for (int ct = 0; ct < 3; ++ct) gw0[ct] = mma3q(a, x_rows(xi, ct, lc), gw0[ct]);           // x G1 SX
             }
@@ -772,7 +795,7 @@ extern "C" {
 
 int rsdf_sdfmlp_fd7_x2_supported(int K0, int H, int N2)
 {
-    return (K0 >= 5 && K0 <= 35 && (K0 - 3) % 2 == 0 && (H == 32 || H == 64) && N2 >= 1 && N2 <= 64) ? 1 : 0;
+    return (K0 >= 5 && K0 <= 35 && (K0 - 3) % 2 == 0 && (H == 32 || H == 64 || H == 128) && N2 >= 1 && N2 <= 64) ? 1 : 0;
 }
 
 int rsdf_sdfmlp_fd7_fwd_x2(const void *x2, int n_levels, int H, int N2, const float *w0, const float *b0, const float *w1,
@@ -786,15 +809,27 @@ int rsdf_sdfmlp_fd7_fwd_x2(const void *x2, int n_levels, int H, int N2, const fl
     if (n_samples <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const int64_t Sp = (n_samples + 31) / 32 * 32;
-    const int64_t want = (Sp / 32 + FWD_WAVES - 1) / FWD_WAVES;
-    const unsigned grid = (unsigned)(want < 512 ? want : 512);
     const SrcX2 src{reinterpret_cast<const unsigned char *>(x2), n_samples, Sp, n_levels, n_levels};
+    auto grid_of = [&](int waves) {
+        const int64_t want = (Sp / 32 + waves - 1) / waves;
+        return (unsigned)(want < 512 ? want : 512);
+    };
+    if (H == 128) {
+        // the feature rows of the last layer are one per-layer product on the centre rows' h2 (see SmemF)
+        RSDF_CHECK_ARG(feature == nullptr || h2c != nullptr, "sdfmlp_fd7_fwd_x2: at H = 128 the feature output needs h2c");
+        if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(fwd_x2_kernel<128>), fwd_lds<128>())) return rc;
+        fwd_x2_kernel<128><<<grid_of(fwd_waves<128>()), 64 * fwd_waves<128>(), fwd_lds<128>(), st>>>(src, w0, b0, w1, b1, w2, b2, N2,
+                                                                                                   sdf7t, feature, h2c);
+        if (hipGetLastError() != hipSuccess) { rsdf_set_error("sdfmlp_fd7_fwd_x2: launch failed"); return RSDF_EINVAL; }
+        if (feature != nullptr) return rsdf_linear_fwd(h2c, H, w2, b2, n_samples, H, N2, RSDF_ACT_NONE, feature, N2, stream);
+        return 0;
+    }
     if (H == 64) {
         if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(fwd_x2_kernel<64>), fwd_lds<64>())) return rc;
-        fwd_x2_kernel<64><<<grid, FWD_THREADS, fwd_lds<64>(), st>>>(src, w0, b0, w1, b1, w2, b2, N2, sdf7t, feature, h2c);
+        fwd_x2_kernel<64><<<grid_of(FWD_WAVES), FWD_THREADS, fwd_lds<64>(), st>>>(src, w0, b0, w1, b1, w2, b2, N2, sdf7t, feature, h2c);
     } else {
         if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(fwd_x2_kernel<32>), fwd_lds<32>())) return rc;
-        fwd_x2_kernel<32><<<grid, FWD_THREADS, fwd_lds<32>(), st>>>(src, w0, b0, w1, b1, w2, b2, N2, sdf7t, feature, h2c);
+        fwd_x2_kernel<32><<<grid_of(FWD_WAVES), FWD_THREADS, fwd_lds<32>(), st>>>(src, w0, b0, w1, b1, w2, b2, N2, sdf7t, feature, h2c);
     }
     RSDF_RETURN_LAUNCH();
 }
@@ -807,7 +842,7 @@ int rsdf_sdfmlp_fd7_bwd_x2(const void *x2, int n_levels, int n_active_levels, in
     const int K0 = 3 + 2 * n_levels;
     (void)b2;
     RSDF_CHECK_ARG(n_levels >= 1 && n_levels <= 16, "sdfmlp_fd7_bwd_x2: n_levels must be in [1,16]");
-    RSDF_CHECK_ARG(H == 64 && rsdf_sdfmlp_fd7_x2_supported(K0, H, N2), "sdfmlp_fd7_bwd_x2: unsupported layer sizes (H must be 64)");
+    RSDF_CHECK_ARG((H == 64 || H == 128) && rsdf_sdfmlp_fd7_x2_supported(K0, H, N2), "sdfmlp_fd7_bwd_x2: unsupported layer sizes (H must be 64 or 128)");
     RSDF_CHECK_ARG(absmax_scratch != nullptr, "sdfmlp_fd7_bwd_x2: the 8-byte absmax scratch is required");
     if (n_samples <= 0) return 0;
     if (n_active_levels < 0 || n_active_levels > n_levels) n_active_levels = n_levels;
@@ -824,12 +859,18 @@ int rsdf_sdfmlp_fd7_bwd_x2(const void *x2, int n_levels, int n_active_levels, in
     }
     const int64_t Sp = (n_samples + 31) / 32 * 32;
     const SrcX2 src{reinterpret_cast<const unsigned char *>(x2), n_samples, Sp, n_levels, n_active_levels};
-    if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(bwd_x2_kernel), QL::END)) return rc;
     const int64_t groups = Sp / 32;
-    const int64_t max_wgs = 256 * RSDF_X2_BWD_OCC;                       // RSDF_X2_BWD_OCC workgroups per CU
-    const unsigned grid = (unsigned)(groups < max_wgs ? groups : max_wgs);
-    bwd_x2_kernel<<<grid, 256, QL::END, st>>>(src, w0, b0, w1, b1, w2, d_sdf7t, d_feature != nullptr ? dh2c_scratch : nullptr, am,
-                                              d_planes, dw0, db0, dw1, db1, dw2, db2);
+    const float *dh = d_feature != nullptr ? dh2c_scratch : nullptr;
+    if (H == 64) {
+        if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(bwd_x2_kernel<4>), QL<4>::END)) return rc;
+        const int64_t max_wgs = 256 * RSDF_X2_BWD_OCC;                   // RSDF_X2_BWD_OCC workgroups per CU
+        bwd_x2_kernel<4><<<(unsigned)(groups < max_wgs ? groups : max_wgs), 256, QL<4>::END, st>>>(
+            src, w0, b0, w1, b1, w2, d_sdf7t, dh, am, d_planes, dw0, db0, dw1, db1, dw2, db2);
+    } else {
+        if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(bwd_x2_kernel<8>), QL<8>::END)) return rc;
+        bwd_x2_kernel<8><<<(unsigned)(groups < 256 ? groups : 256), 512, QL<8>::END, st>>>(
+            src, w0, b0, w1, b1, w2, d_sdf7t, dh, am, d_planes, dw0, db0, dw1, db1, dw2, db2);
+    }
     RSDF_RETURN_LAUNCH();
 }
 

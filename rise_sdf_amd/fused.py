@@ -38,8 +38,8 @@ def supported(K0: int, H: int, N2: int, n_hidden_layers: int, hidden_act: str, o
 
 
 def use_x2(K0: int, H: int, N2: int, precision: str) -> bool:
-    """The two-part fp16 form with the pre-split input image serves H = 64 in fp32 (forward + quad backward)."""
-    return (precision == "fp32" and H == 64 and os.environ.get("RSDF_X2", "1") != "0"
+    """The two-part fp16 form with the pre-split input image serves H = 64 and 128 in fp32 (forward + quad backward)."""
+    return (precision == "fp32" and H in (64, 128) and os.environ.get("RSDF_X2", "1") != "0"
             and os.environ.get("RSDF_MLP_FWD", "") != "coop" and os.environ.get("RSDF_MLP_BWD", "") == ""
             and bool(lib().rsdf_sdfmlp_fd7_x2_supported(int(K0), int(H), int(N2))))
 

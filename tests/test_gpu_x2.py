@@ -91,17 +91,18 @@ def _field_inputs(dev, ops, S, H, N2, seed=3, table_scale=3e-2):
     table = ((torch.rand(n_params, generator=g) * 2 - 1) * table_scale).to(dev).requires_grad_(True)
     K0 = 35
     mk = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev).requires_grad_(True)
-    ws = [(mk(H, K0, sc=0.4), mk(H, sc=0.1)), (mk(H, H, sc=0.25), mk(H, sc=0.1)), (mk(N2, H, sc=0.3), mk(N2, sc=0.1))]
+    ws = [(mk(H, K0, sc=0.4), mk(H, sc=0.1)), (mk(H, H, sc=2.0 / H ** 0.5), mk(H, sc=0.1)), (mk(N2, H, sc=2.4 / H ** 0.5), mk(N2, sc=0.1))]
     x7t, pts = _stencil_points(dev, ops, S, eps, radius, seed=seed + 10)
     return meta_g, table, ws, x7t, pts, radius, eps
 
 
+@pytest.mark.parametrize("H", [64, 128])
 @pytest.mark.parametrize("S,n_active,want_feature", [(4133, 16, True), (2048, 16, False), (1000, 7, True)])
-def test_x2_field_matches_the_round3_kernels(dev, ops, S, n_active, want_feature, monkeypatch):
+def test_x2_field_matches_the_round3_kernels(dev, ops, S, n_active, want_feature, H, monkeypatch):
     """rise_sdf_amd.fused.sdf_field_fd7 at H = 64 in the x2 form against the round-3 kernels (three bf16 parts, six
     products, fp32 planes) on the same inputs: values to 2e-6 of the largest, gradients to 3e-5."""
     from rise_sdf_amd import fused
-    H, N2 = 64, 13
+    N2 = 13
     meta, table, ws, x7t, pts, radius, eps = _field_inputs(dev, ops, S, H, N2)
     eps_unit = eps / (2 * radius)
     outs = {}
@@ -132,11 +133,12 @@ def test_x2_field_matches_the_round3_kernels(dev, ops, S, n_active, want_feature
         assert float((ga - gb).abs().max()) < 3e-5 * scale, (n, float((ga - gb).abs().max()) / scale)
 
 
-def test_x2_field_vs_fp64(dev, ops, monkeypatch):
+@pytest.mark.parametrize("H", [64, 128])
+def test_x2_field_vs_fp64(dev, ops, H, monkeypatch):
     """The x2 forward against an fp64 evaluation of the same network on the fp32 hash features, next to the round-3 kernels
     and to torch's fp32 GEMM chain on the same inputs: the x2 form must be as accurate as an fp32 GEMM chain."""
     from rise_sdf_amd import _lib, fused
-    H, N2, S = 64, 13, 20000
+    N2, S = 13, 20000
     meta, table, ws, x7t, pts, radius, eps = _field_inputs(dev, ops, S, H, N2, seed=9)
     res = {}
     with torch.no_grad():
@@ -160,7 +162,7 @@ def test_x2_field_vs_fp64(dev, ops, monkeypatch):
     fd = lambda v: (v[1] - v[2]) / (2 * eps)
     n_x2 = float((fd(res["1"][0].double()) - fd(out[..., 0])).abs().max())
     n_t32 = float((fd(t32[..., 0]) - fd(out[..., 0])).abs().max())
-    print(f"max SDF error / max|sdf|: x2 {e_x2:.2e}, round-3 kernels {e_r3:.2e}, torch fp32 chain {e_t32:.2e}; "
+    print(f"H = {H}: max SDF error / max|sdf|: x2 {e_x2:.2e}, round-3 kernels {e_r3:.2e}, torch fp32 chain {e_t32:.2e}; "
           f"FD normal component error: x2 {n_x2:.2e}, torch fp32 {n_t32:.2e}")
     assert e_x2 < max(1.5 * e_t32, 3e-7), (e_x2, e_t32)
     fs = float(out[0].abs().max())
