@@ -12,6 +12,11 @@ launch.py itself (launch.py:40-42 ``import datasets, systems, models``) needs no
    selects the fused stencil kernels.  The reference's modules are imported exactly as launch.py would import them (its
    directory first on ``sys.path``), then the six entries are replaced; launch.py's later ``import models`` is a cache hit.
 
+Several GPUs (``--gpu 0,1``: launch.py:84-97 builds ``Trainer(strategy='ddp')``): Lightning's subprocess launcher starts
+ranks 1..N-1 as ``python launch.py ...``, not through this module.  ``main`` therefore exports ``RSDF_LAUNCH_SCRIPT`` /
+``RSDF_LAUNCH_FUSED`` and prepends ``rise_sdf_amd/_launch_hook`` to ``PYTHONPATH``; its ``sitecustomize`` runs the same
+``prepare()`` in every interpreter that executes that script (tests/test_launcher.py runs a two-rank case).
+
 The script is executed with ``runpy`` as ``__main__`` in this process: nothing is re-exec'd after a GPU may have been
 touched, ``sys.argv`` is what launch.py would have seen, and its ``CUDA_VISIBLE_DEVICES`` handling (launch.py:36-38) still
 runs before anything initialises the device (importing torch or this package does not).
@@ -62,6 +67,12 @@ def main(argv=None):
         os.environ.setdefault("CUDA_DEVICE_ORDER", "PCI_BUS_ID")      # before the script body runs
         os.environ["CUDA_VISIBLE_DEVICES"] = argv[argv.index("--gpu", 1) + 1]
     prepare(script, fused)
+    # child ranks (Lightning's subprocess launcher re-runs the script itself): see _launch_hook/sitecustomize.py
+    hook = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_launch_hook")
+    os.environ["RSDF_LAUNCH_SCRIPT"] = script
+    os.environ["RSDF_LAUNCH_FUSED"] = "1" if fused else "0"
+    os.environ["PYTHONPATH"] = os.pathsep.join([hook] + [p for p in os.environ.get("PYTHONPATH", "").split(os.pathsep)
+                                                          if p and os.path.abspath(p) != hook])
     sys.argv = [script] + argv[1:]
     runpy.run_path(script, run_name="__main__")
 

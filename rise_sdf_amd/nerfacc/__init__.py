@@ -250,6 +250,8 @@ class OccGridEstimator(nn.Module):
         self.capacity_mode = False
         self._capacity = {}
         self._pending = []
+        self._blind_rays = {}            # ray count each read-free capacity was measured at
+        self._blind_exact_next = False   # take the exact path once (grid updated / the last blind pass overflowed)
         self.stats = {"capped_calls": 0, "overflows": 0, "blind_calls": 0, "blind_overflows": 0}
 
     @property
@@ -290,6 +292,7 @@ class OccGridEstimator(nn.Module):
             bkey = ("blind", near, far, round(float(render_step_size), 9))
             if bkey not in self._capacity:
                 self._capacity[bkey] = int(ray_indices.numel() * 1.5) + 4096
+                self._blind_rays[bkey] = int(rays_o.shape[0])
         if (sigma_fn is not None or alpha_fn is not None) and ray_indices.numel() > 0:
             if sigma_fn is not None:
                 sigmas = sigma_fn(t_starts, t_ends, ray_indices)
@@ -347,8 +350,18 @@ class OccGridEstimator(nn.Module):
         cap = self._capacity.get(key)
         t_min = torch.clamp(t_min, min=float(near_plane))
         t_max = torch.clamp(t_max, max=float(far_plane))
-        if cap is None:
+        if cap is None or self._blind_exact_next:
+            # no capacity yet, the grid has just been updated, or the last blind pass overflowed: the caller takes the
+            # exact (read-ful) path once, which also re-measures the capacity
+            self._blind_exact_next = False
+            self._capacity.pop(key, None)
             return None
+        # the capacity was measured for another ray count (dynamic_ray_sampling ramps train_num_rays by up to ~3x per
+        # step early on): scale it by the host-known ratio
+        n_rays = int(rays_o.shape[0])
+        n_meas = self._blind_rays.get(key, n_rays)
+        if n_rays > n_meas:
+            cap = int(cap * (n_rays / max(n_meas, 1))) + 4096
         packed, ri, ts, te, total = ops.march_capped(rays_o, rays_d, t_min, t_max, self.aabbs[0], self.binaries[0],
                                                      render_step_size, cap, 0.0)
         alphas = alpha_fn(ts, te, ri)
@@ -356,16 +369,26 @@ class OccGridEstimator(nn.Module):
                                  zero_init=True)
         cnt = []
         out = ops.compact_samples(keep, ri, ts, te, count_out=cnt, fill_ray=rays_o.shape[0] - 1)
-        self._pending.append((key, cap, torch.cat([total, cnt[0]])))
+        self._pending.append((key, cap, torch.cat([total, cnt[0]]), n_rays))
         self.stats["blind_calls"] += 1
         return out
 
     def _settle_pending(self, counts):
         """counts: the host values of the pending blind calls' [candidates, survivors], in order."""
-        for (key, cap, _), (n_cand, _) in zip(self._pending, counts):
+        for p, (n_cand, _) in zip(self._pending, counts):
+            key, cap = p[0], p[1]
             self._capacity[key] = int(n_cand * 1.5) + 4096
+            if len(p) > 3:
+                self._blind_rays[key] = p[3]
             if n_cand > cap:
+                # that pass ran on a truncated sample set (its tail rays saw transmittance 1): it cannot be redone after
+                # the fact, so say so and take the exact path next time
                 self.stats["blind_overflows"] += 1
+                self._blind_exact_next = True
+                import warnings
+                warnings.warn(f"rise_sdf_amd.nerfacc: a read-free secondary sampling pass outgrew its buffers "
+                              f"({n_cand} candidates > capacity {cap}); its tail rays were left unoccluded for that one "
+                              f"step.  The next pass takes the exact path.", RuntimeWarning, stacklevel=2)
         self._pending = []
 
     @torch.no_grad()
@@ -390,6 +413,7 @@ class OccGridEstimator(nn.Module):
         occ = occ_eval_fn(x).squeeze(-1)
         ops.occ_update(self.occs, self.binaries.view(torch.uint8).view(-1), None if all_cells else indices, occ,
                        ema_decay, occ_thre)
+        self._blind_exact_next = True      # the occupied set has changed: re-measure the read-free pass's capacity
 
     @torch.no_grad()
     def update_every_n_steps(self, step: int, occ_eval_fn: Callable, occ_thre: float = 1e-2,

@@ -181,6 +181,14 @@ class VanillaMLP(nn.Module):
         key = (g._version, v._version, g.data_ptr(), v.data_ptr())
         c = self._wn_cache.get(id(m))
         if c is not None and c[0] == key and (c[2] or not want_graph):
+            # W was produced on the stream recorded with it: a consumer on ANOTHER stream (chunk_batch(streams=2) under
+            # no_grad, the bench's two chunks in flight) waits for that event and tells the allocator the tensor is in use
+            # there (the cache used to rely on an unrelated host sync between the two chunks)
+            if w_is_cuda(c[1]):
+                cur = torch.cuda.current_stream(c[1].device)
+                if c[3] is not None and cur != c[4]:
+                    cur.wait_event(c[3])
+                    c[1].record_stream(cur)
             return c[1] if want_graph else c[1].detach()
         with torch.enable_grad() if (g.requires_grad or v.requires_grad) else torch.no_grad():
             w = ops.weight_norm(g, v)
@@ -191,8 +199,26 @@ class VanillaMLP(nn.Module):
             def spent(grad):           # (a tensor hook must return None or a tensor)
                 cache.pop(mid, None)
             w.register_hook(spent)
-        self._wn_cache[id(m)] = (key, w, has_graph)
+        ev = st = None
+        if w_is_cuda(w):
+            st = torch.cuda.current_stream(w.device)
+            ev = torch.cuda.Event()
+            ev.record(st)
+        self._wn_cache[id(m)] = (key, w, has_graph, ev, st)
         return w if want_graph else w.detach()
+
+    def invalidate_weight_cache(self):
+        """Writes that bypass the version counters (``p.data.copy_()``, ``p.data.mul_()``) leave a stale W behind: call this
+        after them.  ``load_state_dict`` and ``train()`` / ``eval()`` switches do it themselves."""
+        self._wn_cache.clear()
+
+    def _load_from_state_dict(self, *a, **kw):      # (load_state_dict of this module or of any parent comes through here)
+        self.__dict__.get("_wn_cache", {}).clear()
+        return super()._load_from_state_dict(*a, **kw)
+
+    def train(self, mode=True):
+        self.__dict__.get("_wn_cache", {}).clear()
+        return super().train(mode)
 
     def effective_weights(self):
         """[(W [out,in], b [out])] per Linear; W = weight_norm(g, v) through the HIP kernel."""
@@ -209,6 +235,10 @@ class VanillaMLP(nn.Module):
         wb = self.effective_weights()
         acts = [self.hidden_act] * (len(wb) - 1) + [out_act or self.output_act]
         return ops.mlp_chain(x.float(), wb, acts, dx_cols=self.input_grad_cols, precision=self.precision)
+
+
+def w_is_cuda(t):
+    return t is not None and t.is_cuda
 
 
 def get_mlp(n_input_dims, n_output_dims, config):

@@ -436,7 +436,7 @@ class _HashGrid(torch.autograd.Function):
             check(lib().rsdf_hashgrid_bwd_fd7(ptr(x7t), ptr(dpl), ctypes.byref(ctx.meta), S, ctx.n_active,
                                               float(ctx.fd7), ptr(dt), ptr(scratch), nbytes,
                                               stream_ptr()), "hashgrid_bwd_fd7")
-        elif _use_binned(ctx.meta, n):
+        elif _use_binned(ctx.meta, n, ctx.n_active):
             # many plain points (the curvature term's 2.6e5 per training step): bins instead of per-corner atomics
             _scatter_binned(0, xf, g, g.shape[1], ctx.col, None, ctx.meta, ctx.n_active, dt)
         else:
@@ -476,8 +476,14 @@ def _scatter_binned(mode, xf, g, ld, col, gd, meta, n_active, dt):
                                              ptr(dt), ptr(scratch), nbytes, stream_ptr()), "hashgrid_scatter_binned")
 
 
-def _use_binned(meta, n):
-    return meta.n_features == 2 and n >= BINNED_SCATTER_MIN_POINTS and os.environ.get("RSDF_SCATTER") != "atomics"
+def _use_binned(meta, n, n_active=None):
+    """The bins serve F = 2 levels of at most 64 x 8192 = 2^19 entries (hashgrid_fd7.hip make_plan); a table with larger
+    hashed levels (log2_hashmap_size 20..24 through the tcnn drop-in) keeps the per-corner atomic kernels, as does
+    RSDF_SCATTER=atomics."""
+    if meta.n_features != 2 or n < BINNED_SCATTER_MIN_POINTS or os.environ.get("RSDF_SCATTER") == "atomics":
+        return False
+    na = int(meta.n_levels) if n_active is None else int(n_active)
+    return int(lib().rsdf_hashgrid_scatter_binned_scratch_bytes(ctypes.byref(meta), int(n), na)) >= 0
 
 
 class _HashGridDx(torch.autograd.Function):
@@ -505,7 +511,7 @@ class _HashGridDx(torch.autograd.Function):
         gx = torch.empty(n, 3, dtype=torch.float32, device=xf.device) if need_x else None
         dt = torch.zeros_like(tb) if need_t else None
         ddy = torch.zeros_like(g) if need_dy else None
-        binned = need_t and _use_binned(ctx.meta, n)      # the table scatter through the bins, the rest as before
+        binned = need_t and _use_binned(ctx.meta, n, ctx.n_active)      # the table scatter through the bins, the rest as before
         if need_x or need_dy or (need_t and not binned):
             check(lib().rsdf_hashgrid_dx_bwd(ptr(xf), ptr(tb), ctypes.byref(ctx.meta), n, ctx.n_active, ptr(g),
                                              g.shape[1], ctx.col, ptr(gd), ptr(ddy), g.shape[1], ctx.col,

@@ -647,6 +647,32 @@ def test_hashgrid_scatter_binned_matches_atomics(dev, ops, mode):
     assert int(((got != 0) != (ref != 0)).sum()) <= 4          # (an entry whose contributions cancel to exactly 0 in one order)
 
 
+def test_large_hashmap_backward_falls_back_to_atomics(dev, ops):
+    """a tcnn.Encoding with log2_hashmap_size = 21 (hashed levels beyond the bins' 2^19 entries) must still
+    back-propagate above the binned scatter's point threshold -- through the per-corner atomic kernels -- and agree with
+    the oracle's fp64-accumulated scatter."""
+    from rise_sdf_amd import _lib
+    cfg = dict(n_levels=8, n_features=2, log2_hashmap_size=21, base_resolution=32, per_level_scale=1.6)
+    meta_g, n_params = _lib.make_grid_meta(**cfg)
+    meta_o, n_o = oracle.grid_meta(**cfg)
+    assert n_params == n_o
+    n = 20000
+    assert n >= ops.BINNED_SCATTER_MIN_POINTS and not ops._use_binned(meta_g, n, 8)
+    g = torch.Generator().manual_seed(71)
+    x = torch.rand(n, 3, generator=g)
+    table = ((torch.rand(n_params, generator=g) * 2 - 1) * 1e-2)
+    gout = torch.randn(n, 16, generator=g)
+    tg = table.to(dev).requires_grad_(True)
+    xg = x.to(dev).requires_grad_(True)
+    y = ops.hashgrid_encode(xg, tg, meta_g)
+    (y * gout.to(dev)).sum().backward()
+    to = table.clone().requires_grad_(True)
+    (oracle.hashgrid_encode(x, to, meta_o) * gout).sum().backward()
+    scale = float(to.grad.abs().max())
+    assert float((tg.grad.cpu() - to.grad).abs().max()) < 2e-5 * scale
+    assert xg.grad is not None and bool(torch.isfinite(xg.grad).all())
+
+
 def test_curvature_path_uses_binned_scatter_and_matches(dev, ops, monkeypatch):
     """ops.hashgrid_encode / ops.hashgrid_dx on 20000 points: the autograd backward with the binned scatter equals the one
     with RSDF_SCATTER=atomics."""

@@ -91,6 +91,44 @@ def test_masked_secondary_blend_matches_the_gather_path(dev, stage1):
         assert float((g0[n] - g1[n]).abs().max()) < 2e-5 * scale, n     # float atomics: last bits only
 
 
+def test_blind_overflow_warns_and_recovers_on_the_exact_path(dev):
+    """a read-free secondary pass whose candidates outgrow the remembered capacity is counted, warned about, and
+    the NEXT pass takes the exact path (and re-measures); a larger ray batch scales the capacity instead of overflowing."""
+    import warnings
+    model = _model(dev, stage1=False)
+    model.masked_secondary = True
+    est = model.occupancy_grid
+    est.capacity_mode = True
+    rays = camera_rays(20, 20, seed=2).to(dev)
+    u = torch.rand(rays.shape[0], generator=torch.Generator().manual_seed(3)).to(dev)
+    out0 = model.forward_(rays, stratified_u=u)                      # exact first pass: capacities measured
+    model.forward_(rays, stratified_u=u)                             # blind pass in use
+    assert est.stats["blind_calls"] >= 1 and est.stats["blind_overflows"] == 0
+    ref_tr = model._last_secondary["tr"].clone()
+    bkeys = [k for k in est._capacity if k[0] == "blind"]
+    assert bkeys
+    for k in bkeys:                                                   # force an overflow
+        est._capacity[k] = 64
+    model.forward_(rays, stratified_u=u)                             # truncated pass (cannot be redone: per-ray results used)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        model.forward_(rays, stratified_u=u)                         # its counts arrive with this step's read -> warning; this
+        assert any("outgrew its buffers" in str(x.message) for x in w)  #   pass itself already runs exactly
+    assert est.stats["blind_overflows"] >= 1
+    assert torch.allclose(model._last_secondary["tr"], ref_tr, atol=1e-6)
+    n_blind = est.stats["blind_calls"]
+    model.forward_(rays, stratified_u=u)                             # capacity re-measured: blind again, no overflow
+    assert est.stats["blind_calls"] == n_blind + 1
+    # four times the rays: the capacity is scaled by the ray-count ratio instead of overflowing
+    rays4 = camera_rays(40, 40, seed=2).to(dev)
+    u4 = torch.rand(rays4.shape[0], generator=torch.Generator().manual_seed(3)).to(dev)
+    n_over = est.stats["blind_overflows"]
+    model.forward_(rays4, stratified_u=u4)
+    model.forward_(rays4, stratified_u=u4)
+    assert est.stats["blind_overflows"] == n_over
+    assert out0["comp_rgb"].shape[0] == rays.shape[0]
+
+
 def test_eval_render_on_two_streams_is_identical(dev):
     """model.eval()(rays): chunk_batch alternates the ray chunks over two HIP streams (config ``eval_streams``, default 2);
     the rendered maps equal the one-stream render bit for bit."""

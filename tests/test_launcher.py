@@ -73,6 +73,56 @@ def test_launcher_runs_an_unedited_script(tmp_path):
     assert d["neus"] == "models" and d["nerfacc"] == "rise_sdf_amd.nerfacc"
 
 
+def test_launcher_child_ranks_come_back_through_the_drop_ins(tmp_path):
+    """with several GPUs Lightning's subprocess launcher starts ranks 1.. as ``python launch.py ...``
+    (``[sys.executable, sys.argv[0]] + sys.argv[1:]``).  A launcher that does exactly that must find the drop-ins and the
+    swapped registry in the child too."""
+    (tmp_path / "models").mkdir()
+    (tmp_path / "models" / "__init__.py").write_text(textwrap.dedent('''
+        models = {}
+        def register(name):
+            def decorator(cls):
+                models[name] = cls
+                return cls
+            return decorator
+        @register("neus")
+        class TheirNeuS: pass
+    '''))
+    (tmp_path / "launch.py").write_text(textwrap.dedent('''
+        import argparse, json, os, subprocess, sys
+        def main():
+            ap = argparse.ArgumentParser()
+            ap.add_argument("--gpu", default="0")
+            args, _ = ap.parse_known_args()
+            import models
+            import nerfacc
+            me = {"rank": os.environ.get("LOCAL_RANK", "0"), "nerfacc": nerfacc.__name__,
+                  "neus": models.models["neus"].__module__, "argv0": os.path.basename(sys.argv[0])}
+            if me["rank"] == "0" and len(args.gpu.split(",")) > 1:
+                # what lightning.fabric.strategies.launchers.subprocess_script does for the other ranks
+                env = dict(os.environ, LOCAL_RANK="1")
+                r = subprocess.run([sys.executable, os.path.abspath(sys.argv[0])] + sys.argv[1:], env=env,
+                                   capture_output=True, text=True)
+                assert r.returncode == 0, r.stderr[-2000:]
+                me["child"] = json.loads(r.stdout.strip().splitlines()[-1])
+            print(json.dumps(me))
+        if __name__ == "__main__":
+            main()
+    '''))
+    r = _run([str(tmp_path / "launch.py"), "--gpu", "0,1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["nerfacc"] == "rise_sdf_amd.nerfacc" and d["neus"].startswith("rise_sdf_amd.")
+    c = d["child"]
+    assert c["rank"] == "1" and c["argv0"] == "launch.py"
+    assert c["nerfacc"] == "rise_sdf_amd.nerfacc" and c["neus"].startswith("rise_sdf_amd."), c
+    # --per-layer is inherited as well
+    r = _run(["--per-layer", str(tmp_path / "launch.py"), "--gpu", "0,1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    c = json.loads(r.stdout.strip().splitlines()[-1])["child"]
+    assert c["nerfacc"] == "rise_sdf_amd.nerfacc" and c["neus"] == "models"
+
+
 @pytest.mark.skipif(not os.path.isfile("/root/reference/launch.py"), reason="reference tree not present")
 def test_launcher_prepares_the_reference_tree():
     """Build container: the same preparation against the reference's real ``models`` package (absent off-path
