@@ -123,12 +123,13 @@ def run_step(model, rays, jitter, cot, chunk, streams=1):
     return total
 
 
-def cpu_baseline(model, rays_cpu, jitter_cpu, max_rays, budget_s=8.0, reps=3):
+def cpu_baseline(model, rays_cpu, jitter_cpu, max_rays, budget_s=5.0, reps=5):
     """The oracle (a port of the reference path: C + OpenMP for the hash grid and the per-ray loops, torch CPU ops
     for the MLP / elementwise layers) timed on this host's cores, BASELINE.md section 4's protocol: a contiguous
     slice of the same view starting at the middle row, fwd+bwd of field query + NeuS alpha + composite, 1 warm-up +
-    ``reps`` timed repetitions, median; the marcher is timed separately.  The slice is ``max_rays`` (4096) rays
-    unless a 128-ray calibration pass says that would exceed ``budget_s`` per repetition."""
+    ``reps`` (5) timed repetitions, median; the marcher is timed separately.  The slice is ``max_rays`` (4096)
+    rays unless a 128-ray calibration pass says that would exceed ``budget_s`` per repetition (the default bench.py run
+    must stay within minutes); the line says when it was shrunk."""
     import statistics
     import oracle
     from test_gpu_model import oracle_params
@@ -179,7 +180,9 @@ def cpu_baseline(model, rays_cpu, jitter_cpu, max_rays, budget_s=8.0, reps=3):
     dt = statistics.median(r[2] for r in runs)
     dm = statistics.median(r[1] for r in runs)
     return {"value": S / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"{n_rays} rays of the same 800x800 view (pixels {s0}..{s0 + n_rays - 1}), {S} samples; "
+            "slice_shrunk_below_4096_rays": bool(n_rays < max_rays),
+            "sample": f"{n_rays} rays" + (f" (shrunk from {max_rays}: ~{budget_s:.0f} s per repetition)" if n_rays < max_rays else "") +
+                      f" of the same 800x800 view (pixels {s0}..{s0 + n_rays - 1}), {S} samples; "
                       f"fwd+bwd of field query + alpha + composite: median of {reps} after 1 warm-up = {dt:.2f} s "
                       f"(min {min(r[2] for r in runs):.2f}, max {max(r[2] for r in runs):.2f}); marcher timed "
                       f"separately: {dm * 1e3:.1f} ms ({S / max(dm, 1e-9):.3g} samples/s, 1 thread); hash grid in C "
@@ -324,6 +327,7 @@ def attach_traffic(roof, path):
         return
     per_sample = entry["hbm_bytes_per_sample"]
     roof["traffic"] = per_sample * roof.get("samples_per_launch", 0) or None
+    roof["traffic_build"] = pmc.get("build", "unknown")     # the tree the counters were collected on (tools/pmc_summary.py)
     roof["traffic_source"] = (f"{os.path.relpath(path, ROOT)} ({pmc.get('source', 'separate --pmc passes')}): "
                               f"{per_sample:.0f} B/sample fetched+written x samples per launch")
 
@@ -437,7 +441,8 @@ def secondary_measurements(dev, args, rays, jitter, cot):
         from bench_step import measure
         r = measure(dev, stage=1, steps=30, settle=80, syncs=True, **kw)
         return {k: r[k] for k in ("ms_per_step", "rays_per_step", "samples_per_step", "samples_per_s",
-                                  "rsdf_kernel_ms_per_step", "host_syncs_per_step", "sampler_stats", "top", "hidden",
+                                  "rsdf_kernel_ms_per_step", "rsdf_kernel_ms_note", "host_syncs_per_step", "sampler_stats", "top",
+                                  "hidden",
                                   "stage")}
     guarded("c3_step", c3)
     guarded("c3_step_bf16_radiance", lambda: c3(tex_precision="bf16"))

@@ -124,6 +124,17 @@ int rsdf_opacity_depth_fwd(const int32_t *packed_info, const float *weights, con
 int rsdf_opacity_depth_bwd(const int32_t *packed_info, const float *t_starts, const float *t_ends,
                            const float *grad_opacity /* nullable */, const float *grad_depth /* nullable */,
                            int64_t n_rays, float *grad_weights, void *stream);
+/* The same pass with the ray's normal map folded in (models/volrend.py:875-877: accumulate_along_rays(weights,
+ * normals [n_samples,3])): normal_map [n_rays,3]; bit-identical to the separate accumulate call.  bwd: any of the three
+ * incoming gradients may be NULL (zero); grad_weights [n_samples] and / or grad_normals [n_samples,3] (either nullable;
+ * grad_normals needs grad_normal_map) are written for every sample packed_info covers. */
+int rsdf_opacity_depth_normal_fwd(const int32_t *packed_info, const float *weights, const float *t_starts,
+                                  const float *t_ends, const float *normals, int64_t n_rays, float *opacity, float *depth,
+                                  float *normal_map, float *midpoints /*nullable*/, void *stream);
+int rsdf_opacity_depth_normal_bwd(const int32_t *packed_info, const float *weights, const float *t_starts,
+                                  const float *t_ends, const float *normals, const float *grad_opacity,
+                                  const float *grad_depth, const float *grad_normal_map, int64_t n_rays,
+                                  float *grad_weights, float *grad_normals, void *stream);
 
 /* ---- H1: multiresolution hash-grid encoding ----------------------------------------------------
  * replaces tcnn.Encoding(3, {otype: HashGrid, ...}) forward/backward (constructed

@@ -59,6 +59,8 @@ _SIGNATURES = {
     "rsdf_accumulate_bwd": [_P, _P, _P, _P, _L, _I, _P, _P, _P],
     "rsdf_opacity_depth_fwd": [_P, _P, _P, _P, _L, _P, _P, _P, _P],
     "rsdf_opacity_depth_bwd": [_P, _P, _P, _P, _P, _L, _P, _P],
+    "rsdf_opacity_depth_normal_fwd": [_P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P],
+    "rsdf_opacity_depth_normal_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P],
     "rsdf_grid_meta_init": [ctypes.POINTER(GridMeta), _I, _I, _I, _I, ctypes.c_double],
     "rsdf_hashgrid_fwd": [_P, _P, ctypes.POINTER(GridMeta), _L, _I, _P, _I, _I, _I, _F, _F, _P],
     "rsdf_hashgrid_fwd_staged_scratch_bytes": [ctypes.POINTER(GridMeta), _L, _I],

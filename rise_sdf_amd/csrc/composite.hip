@@ -166,45 +166,91 @@ accumulate_bwd_kernel(const int32_t *__restrict__ packed, const float *__restric
 // add, then the exact halving), and the two sums run in the kernels' own order above -- bit-identical to the two calls,
 // without the midpoint tensor (two elementwise passes over all samples), one of the two launches each way and autograd's
 // add of the two weight gradients.
+// NORMALS (round 4): the ray's normal map, accumulate_along_rays(weights, normals [S,3]) (models/volrend.py:875-877), in
+// the same pass: per channel the same fmaf chain in the same lane order and the same wave reduction as
+// accumulate_fwd_kernel<4> runs for D = 3 -- bit-identical to the separate call, one launch less each way.
+template <bool NORMALS>
 __global__ void __launch_bounds__(THREADS)
 opacity_depth_fwd_kernel(const int32_t *__restrict__ packed, const float *__restrict__ weights,
-                         const float *__restrict__ ts, const float *__restrict__ te, int64_t n_rays,
-                         float *__restrict__ opacity, float *__restrict__ depth, float *__restrict__ mid_out)
+                         const float *__restrict__ ts, const float *__restrict__ te, const float *__restrict__ normals,
+                         int64_t n_rays, float *__restrict__ opacity, float *__restrict__ depth,
+                         float *__restrict__ normal_map, float *__restrict__ mid_out)
 {
     const int64_t r = ray_of_wave();
     if (r >= n_rays) return;
     const int base = packed[2 * r], steps = packed[2 * r + 1];
     const int lane = lane_id();
-    float a0 = 0.0f, a1 = 0.0f;
+    float a0 = 0.0f, a1 = 0.0f, nx = 0.0f, ny = 0.0f, nz = 0.0f;
     for (int j = lane; j < steps; j += 64) {
         const float w = weights[base + j];
         const float mid = (ts[base + j] + te[base + j]) / 2.0f;
         if (mid_out) mid_out[base + j] = mid;            // (the training outputs' "points": models/neus.py:303)
         a0 += w;
         a1 = fmaf(w, mid, a1);
+        if (NORMALS) {
+            const float *n = normals + (int64_t)(base + j) * 3;
+            nx = fmaf(w, n[0], nx);
+            ny = fmaf(w, n[1], ny);
+            nz = fmaf(w, n[2], nz);
+        }
     }
     a0 = wave_sum(a0);
     a1 = wave_sum(a1);
+    if (NORMALS) {
+        nx = wave_sum(nx);
+        ny = wave_sum(ny);
+        nz = wave_sum(nz);
+    }
     if (lane == 0) {
         opacity[r] = a0;
         depth[r] = a1;
+        if (NORMALS) {
+            normal_map[3 * r] = nx;
+            normal_map[3 * r + 1] = ny;
+            normal_map[3 * r + 2] = nz;
+        }
     }
 }
 
 // gw_i = g_opacity[r] + g_depth[r] * mid_i   (either gradient may be NULL = zero)
+// with normals: gw_i += sum_d g_normal[r,d] n[i,d] (the chain accumulate_bwd_kernel runs, added last, as autograd adds the
+// two calls' weight gradients); gn[i,d] = w_i g_normal[r,d]
 __global__ void __launch_bounds__(THREADS)
 opacity_depth_bwd_kernel(const int32_t *__restrict__ packed, const float *__restrict__ ts, const float *__restrict__ te,
                          const float *__restrict__ g_opacity, const float *__restrict__ g_depth, int64_t n_rays,
-                         float *__restrict__ gw)
+                         float *__restrict__ gw, const float *__restrict__ weights, const float *__restrict__ normals,
+                         const float *__restrict__ g_normal, float *__restrict__ gn)
 {
     const int64_t r = ray_of_wave();
     if (r >= n_rays) return;
     const int base = packed[2 * r], steps = packed[2 * r + 1];
     const float go = g_opacity ? g_opacity[r] : 0.0f, gd = g_depth ? g_depth[r] : 0.0f;
+    float g3[3] = {0.0f, 0.0f, 0.0f};
+    if (g_normal) {
+        g3[0] = g_normal[3 * r];
+        g3[1] = g_normal[3 * r + 1];
+        g3[2] = g_normal[3 * r + 2];
+    }
     for (int j = lane_id(); j < steps; j += 64) {
-        const float mid = (ts[base + j] + te[base + j]) / 2.0f;
-        const float d = gd * mid;
-        gw[base + j] = g_opacity ? (g_depth ? go + d : go) : d;
+        const int64_t s = base + j;
+        float v = 0.0f;
+        if (g_opacity || g_depth) {
+            const float mid = (ts[s] + te[s]) / 2.0f;
+            const float d = gd * mid;
+            v = g_opacity ? (g_depth ? go + d : go) : d;
+        }
+        if (g_normal) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) acc = fmaf(g3[d], normals[s * 3 + d], acc);
+            v = (g_opacity || g_depth) ? v + acc : acc;
+            if (gn) {
+                const float w = weights[s];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) gn[s * 3 + d] = w * g3[d];
+            }
+        }
+        if (gw) gw[s] = v;
     }
 }
 
@@ -332,8 +378,8 @@ int rsdf_opacity_depth_fwd(const int32_t *packed_info, const float *weights, con
                            int64_t n_rays, float *opacity, float *depth, float *midpoints, void *stream)
 {
     if (n_rays <= 0) return 0;
-    opacity_depth_fwd_kernel<<<rsdf_blocks(n_rays * 64, THREADS), THREADS, 0, (hipStream_t)stream>>>(
-        packed_info, weights, t_starts, t_ends, n_rays, opacity, depth, midpoints);
+    opacity_depth_fwd_kernel<false><<<rsdf_blocks(n_rays * 64, THREADS), THREADS, 0, (hipStream_t)stream>>>(
+        packed_info, weights, t_starts, t_ends, nullptr, n_rays, opacity, depth, nullptr, midpoints);
     RSDF_RETURN_LAUNCH();
 }
 
@@ -343,7 +389,35 @@ int rsdf_opacity_depth_bwd(const int32_t *packed_info, const float *t_starts, co
     RSDF_CHECK_ARG(grad_opacity != nullptr || grad_depth != nullptr, "opacity_depth_bwd: both gradients are NULL");
     if (n_rays <= 0) return 0;
     opacity_depth_bwd_kernel<<<rsdf_blocks(n_rays * 64, THREADS), THREADS, 0, (hipStream_t)stream>>>(
-        packed_info, t_starts, t_ends, grad_opacity, grad_depth, n_rays, grad_weights);
+        packed_info, t_starts, t_ends, grad_opacity, grad_depth, n_rays, grad_weights, nullptr, nullptr, nullptr, nullptr);
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_opacity_depth_normal_fwd(const int32_t *packed_info, const float *weights, const float *t_starts,
+                                  const float *t_ends, const float *normals, int64_t n_rays, float *opacity, float *depth,
+                                  float *normal_map, float *midpoints, void *stream)
+{
+    RSDF_CHECK_ARG(normals != nullptr && normal_map != nullptr, "opacity_depth_normal_fwd: normals / normal_map are NULL");
+    if (n_rays <= 0) return 0;
+    opacity_depth_fwd_kernel<true><<<rsdf_blocks(n_rays * 64, THREADS), THREADS, 0, (hipStream_t)stream>>>(
+        packed_info, weights, t_starts, t_ends, normals, n_rays, opacity, depth, normal_map, midpoints);
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_opacity_depth_normal_bwd(const int32_t *packed_info, const float *weights, const float *t_starts,
+                                  const float *t_ends, const float *normals, const float *grad_opacity,
+                                  const float *grad_depth, const float *grad_normal_map, int64_t n_rays,
+                                  float *grad_weights, float *grad_normals, void *stream)
+{
+    RSDF_CHECK_ARG(grad_opacity != nullptr || grad_depth != nullptr || grad_normal_map != nullptr,
+                   "opacity_depth_normal_bwd: all three gradients are NULL");
+    RSDF_CHECK_ARG(grad_normal_map == nullptr || (normals != nullptr && weights != nullptr),
+                   "opacity_depth_normal_bwd: the normal gradient needs weights and normals");
+    RSDF_CHECK_ARG(grad_weights != nullptr || grad_normals != nullptr, "opacity_depth_normal_bwd: no output requested");
+    if (n_rays <= 0) return 0;
+    opacity_depth_bwd_kernel<<<rsdf_blocks(n_rays * 64, THREADS), THREADS, 0, (hipStream_t)stream>>>(
+        packed_info, t_starts, t_ends, grad_opacity, grad_depth, n_rays, grad_weights, weights, normals, grad_normal_map,
+        grad_normals);
     RSDF_RETURN_LAUNCH();
 }
 

@@ -57,16 +57,27 @@ def shard_chunks(n_items: int, chunk: int, rank: int, world: int) -> List[Tuple[
 
 
 class GradBuckets:
-    """Two persistent flat gradient buffers: [big] the largest parameter (the hash table) reduced
-    in place, [rest] all remaining gradients packed once per step."""
+    """DDP-style gradient mean (launch.py:84-97: Lightning's DDP strategy).  Parameters of at least ``IN_PLACE_MIN``
+    elements (the 55 MiB hash table, the 18 MiB environment map) are reduced IN PLACE in their ``.grad``; all remaining
+    gradients (a few hundred KiB of MLP weights) are packed into one persistent flat buffer per step.  ``all_reduce_mean``
+    with ``async_op=True`` only issues the collectives (RCCL runs them on its own stream); ``finish`` waits, divides and
+    unpacks -- rise_sdf_amd.step.TrainStep issues right after backward and finishes just before the optimizer step."""
+    IN_PLACE_MIN = 1 << 18
 
     def __init__(self, params: Iterable[torch.nn.Parameter]):
         self.params = [p for p in params if p.requires_grad]
-        self.big = max(self.params, key=lambda p: p.numel()) if self.params else None
-        self.rest = [p for p in self.params if p is not self.big]
+        self.big = [p for p in self.params if p.numel() >= self.IN_PLACE_MIN]
+        if not self.big and self.params:
+            self.big = [max(self.params, key=lambda p: p.numel())]
+        ids = {id(p) for p in self.big}
+        self.rest = [p for p in self.params if id(p) not in ids]
         n = sum(p.numel() for p in self.rest)
-        dev = self.big.device if self.big is not None else "cpu"
+        dev = self.params[0].device if self.params else "cpu"
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+
+    def bytes_per_step(self) -> int:
+        """Payload of one gradient exchange (what a ring all-reduce moves ~2 (p-1)/p times per rank)."""
+        return 4 * (sum(p.numel() for p in self.big) + self.flat.numel())
 
     @torch.no_grad()
     def all_reduce_mean(self, world: int, async_op: bool = False):
@@ -74,10 +85,10 @@ class GradBuckets:
         if world <= 1 or not dist.is_initialized():
             return []
         handles = []
-        if self.big is not None:
-            if self.big.grad is None:
-                self.big.grad = torch.zeros_like(self.big)
-            handles.append(dist.all_reduce(self.big.grad, op=dist.ReduceOp.SUM, async_op=True))
+        for p in self.big:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            handles.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True))
         off = 0
         for p in self.rest:
             k = p.numel()
@@ -97,8 +108,10 @@ class GradBuckets:
     def finish(self, handles, world: int):
         for h in handles:
             h.wait()
-        if self.big is not None:
-            self.big.grad.div_(world)
+        if not handles:
+            return
+        for p in self.big:
+            p.grad.div_(world)
         off = 0
         for p in self.rest:
             k = p.numel()

@@ -249,7 +249,13 @@ class EnvironmentLightMipCube(nn.Module):
 
     def _wait_ready(self):
         if self._ready is not None:
-            torch.cuda.current_stream().wait_event(self._ready)
+            cur = torch.cuda.current_stream()
+            cur.wait_event(self._ready)
+            # the mips were allocated on the side stream: tell the caching allocator that this stream reads them too, or a
+            # later build_mips_on() could be handed their blocks while lookups enqueued here are still pending
+            for t in list(self.specular or []) + ([self.diffuse] if self.diffuse is not None else []):
+                if t.is_cuda:
+                    t.record_stream(cur)
             self._ready = None
 
     def build_mips(self, cutoff=0.99):

@@ -227,14 +227,21 @@ class NeuSModel(BaseModel):
                 out7, self.variance.effective_variance(), rays_d, ray_indices, t_starts, t_ends,
                 self.cos_anneal_ratio, self.geometry._finite_difference_eps, tap_major=tm)
         weights, _ = ops.render_weight_from_alpha(alpha, packed_info=packed)
-        # opacity and depth (weights . (t_starts + t_ends) / 2) in one pass, bit-identical to the two accumulate calls
+        # opacity, depth (weights . (t_starts + t_ends) / 2) and the normal map in one pass, bit-identical to the three
+        # accumulate calls (RSDF_FOLD_NORMALS=0: the normal map through accumulate_along_rays, for A/B and the fold's tests)
         midpoints = None
-        if self.training:      # (the training outputs carry the sample midpoints, models/neus.py:303)
-            opacity, depth, midpoints = ops.accumulate_opacity_depth(weights, t_starts, t_ends, packed_info=packed,
-                                                                     want_midpoints=True)
+        if ops.fold_normals():
+            res = ops.accumulate_opacity_depth_normal(weights, t_starts, t_ends, normal, packed_info=packed,
+                                                      want_midpoints=self.training)
+            opacity, depth, comp_normal = res[:3]
+            midpoints = res[3] if self.training else None      # (the training outputs carry the sample midpoints, models/neus.py:303)
         else:
-            opacity, depth = ops.accumulate_opacity_depth(weights, t_starts, t_ends, packed_info=packed)
-        comp_normal = ops.accumulate_along_rays(weights, normal, packed_info=packed)
+            if self.training:
+                opacity, depth, midpoints = ops.accumulate_opacity_depth(weights, t_starts, t_ends, packed_info=packed,
+                                                                         want_midpoints=True)
+            else:
+                opacity, depth = ops.accumulate_opacity_depth(weights, t_starts, t_ends, packed_info=packed)
+            comp_normal = ops.accumulate_along_rays(weights, normal, packed_info=packed)
         out = {
             "comp_normal_raw": comp_normal,
             "comp_normal": F.normalize(comp_normal, p=2, dim=-1),

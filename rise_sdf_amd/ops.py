@@ -121,6 +121,8 @@ def march_capped(rays_o, rays_d, t_min, t_max, roi, binary, step_size, capacity,
           "pack_from_counts")
     cap = int(capacity)
     packed[:, 1] = torch.minimum(packed[:, 1], (cap - packed[:, 0]).clamp_(min=0))
+    packed[:, 0].clamp_(max=cap)        # (rays past the capacity: empty AND inside the buffers -- no kernel dereferences the offset
+                                        #  of an empty ray, but a packed_info should never point outside its arrays: RSDF_CHECK)
     ri = torch.zeros(cap, dtype=torch.int64, device=dev)
     ts = torch.zeros(cap, dtype=torch.float32, device=dev)
     te = torch.zeros(cap, dtype=torch.float32, device=dev)
@@ -250,24 +252,48 @@ class _TransFromAlpha(torch.autograd.Function):
         return None, ga
 
 
-def _packed(ray_indices, packed_info, n_rays):
+CHECK = os.environ.get("RSDF_CHECK", "0") == "1"
+
+
+def check_packed(packed_info, n_samples, what):
+    """RSDF_CHECK=1 (debug; one host sync per call): every ray's [offset, offset + count) must lie inside the sample arrays
+    it is used with.  The per-ray kernels trust packed_info; an inconsistent one (a stale cached pack, an under-sized
+    capacity buffer) would read or write out of bounds."""
+    if not CHECK or packed_info is None or packed_info.numel() == 0:
+        return
+    off, cnt = packed_info[:, 0].long(), packed_info[:, 1].long()
+    bad = (off < 0) | (cnt < 0) | (off + cnt > int(n_samples))
+    if bool(bad.any()):
+        i = int(bad.nonzero()[0])
+        raise RuntimeError(f"RSDF_CHECK {what}: ray {i} covers samples [{int(off[i])}, {int(off[i] + cnt[i])}) of {int(n_samples)}")
+
+
+def _packed(ray_indices, packed_info, n_rays, n_samples=None, what="packed_info"):
     if packed_info is None:
         assert ray_indices is not None and n_rays is not None, \
             "either packed_info or (ray_indices, n_rays) is required"
+        if CHECK and ray_indices.numel():
+            lo, hi = int(ray_indices.min()), int(ray_indices.max())
+            if lo < 0 or hi >= int(n_rays):
+                raise RuntimeError(f"RSDF_CHECK {what}: ray_indices span [{lo}, {hi}] for {int(n_rays)} rays")
         packed_info = pack_info(ray_indices, n_rays)
-    return packed_info.to(torch.int32).contiguous()
+    pk = packed_info.to(torch.int32).contiguous()
+    if n_samples is not None:
+        check_packed(pk, n_samples, what)
+    return pk
 
 
 def render_weight_from_alpha(alphas, *, ray_indices=None, packed_info=None, n_rays=None):
     """nerfacc 0.5.3 signature (models/volrend.py:851-855): flat alphas [S] -> (weights, trans)."""
     shape = alphas.shape
-    w, t = _WeightFromAlpha.apply(_packed(ray_indices, packed_info, n_rays), alphas.reshape(-1))
+    w, t = _WeightFromAlpha.apply(_packed(ray_indices, packed_info, n_rays, alphas.numel(), "render_weight_from_alpha"),
+                                  alphas.reshape(-1))
     return w.view(shape), t.view(shape)
 
 
 def render_transmittance_from_alpha(alphas, *, ray_indices=None, packed_info=None, n_rays=None):
     shape = alphas.shape
-    return _TransFromAlpha.apply(_packed(ray_indices, packed_info, n_rays),
+    return _TransFromAlpha.apply(_packed(ray_indices, packed_info, n_rays, alphas.numel(), "render_transmittance_from_alpha"),
                                  alphas.reshape(-1)).view(shape)
 
 
@@ -276,7 +302,7 @@ def render_visibility(alphas, *, ray_indices=None, packed_info=None, n_rays=None
                       early_stop_eps=1e-4, alpha_thre=0.0, zero_init=False):
     """lib/nerfacc/vol_rendering.py:452-520 -> bool [S].  ``zero_init``: entries that no ray's packed_info covers (the
     dummy tail of a capacity-sized buffer) read as False instead of being left unwritten."""
-    pk = _packed(ray_indices, packed_info, n_rays)
+    pk = _packed(ray_indices, packed_info, n_rays, alphas.numel(), "render_visibility")
     a = _f32c(alphas.reshape(-1))
     require_device(pk, a)
     keep = (torch.zeros if zero_init else torch.empty)(a.numel(), dtype=torch.uint8, device=a.device)
@@ -355,14 +381,67 @@ def accumulate_opacity_depth(weights, t_starts, t_ends, *, ray_indices=None, pac
     (accumulate_along_rays(weights, None), accumulate_along_rays(weights, (t_starts + t_ends)[..., None] / 2.0)), bit for
     bit, without the midpoint tensor -- or, with ``want_midpoints``, with it as a third (non-differentiable) output [S].
     t_starts / t_ends carry no gradient (they come from the marcher)."""
-    pk = _packed(ray_indices, packed_info, n_rays)
+    pk = _packed(ray_indices, packed_info, n_rays, weights.numel(), "accumulate_opacity_depth")
     return _OpacityDepth.apply(pk, weights.reshape(-1), t_starts, t_ends, bool(want_midpoints))
+
+
+def fold_normals():
+    """The ray's normal map inside the opacity / depth pass (default) or through accumulate_along_rays (RSDF_FOLD_NORMALS=0)."""
+    return os.environ.get("RSDF_FOLD_NORMALS", "1") != "0"
+
+
+class _OpacityDepthNormal(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, packed_info, weights, t_starts, t_ends, normals, want_mid):
+        w, ts, te = _f32c(weights), _f32c(t_starts.reshape(-1)), _f32c(t_ends.reshape(-1))
+        nm = _f32c(normals)
+        require_device(packed_info, w, ts, te, nm)
+        assert nm.shape == (w.shape[0], 3), "normals must be [n_samples, 3]"
+        n_rays = packed_info.shape[0]
+        dev = w.device
+        opacity = torch.empty(n_rays, 1, dtype=torch.float32, device=dev)
+        depth = torch.empty(n_rays, 1, dtype=torch.float32, device=dev)
+        nmap = torch.empty(n_rays, 3, dtype=torch.float32, device=dev)
+        mid = torch.empty_like(ts) if want_mid else None
+        check(lib().rsdf_opacity_depth_normal_fwd(ptr(packed_info), ptr(w), ptr(ts), ptr(te), ptr(nm), n_rays, ptr(opacity),
+                                                  ptr(depth), ptr(nmap), ptr(mid), stream_ptr()), "opacity_depth_normal_fwd")
+        ctx.save_for_backward(packed_info, w, ts, te, nm)
+        if want_mid:
+            ctx.mark_non_differentiable(mid)
+            return opacity, depth, nmap, mid
+        return opacity, depth, nmap
+
+    @staticmethod
+    def backward(ctx, g_op, g_depth, g_n, *_):
+        packed_info, w, ts, te, nm = ctx.saved_tensors
+        need_w, need_n = ctx.needs_input_grad[1], ctx.needs_input_grad[4] and g_n is not None
+        if (g_op is None and g_depth is None and g_n is None) or not (need_w or need_n):
+            return None, None, None, None, None, None
+        g_op = None if g_op is None else _f32c(g_op)
+        g_depth = None if g_depth is None else _f32c(g_depth)
+        g_n = None if g_n is None else _f32c(g_n)
+        # zeros, not empty: capacity-mode callers hand in sample arrays whose tail no ray's packed_info covers
+        gw = torch.zeros_like(w) if need_w else None
+        gn = torch.zeros_like(nm) if need_n else None
+        check(lib().rsdf_opacity_depth_normal_bwd(ptr(packed_info), ptr(w), ptr(ts), ptr(te), ptr(nm), ptr(g_op), ptr(g_depth),
+                                                  ptr(g_n), packed_info.shape[0], ptr(gw), ptr(gn), stream_ptr()),
+              "opacity_depth_normal_bwd")
+        return None, gw, None, None, gn, None
+
+
+def accumulate_opacity_depth_normal(weights, t_starts, t_ends, normals, *, ray_indices=None, packed_info=None, n_rays=None,
+                                    want_midpoints=False):
+    """models/volrend.py:875-885 in one kernel each way: -> (opacity [n_rays,1], depth [n_rays,1], normal map [n_rays,3]) =
+    accumulate_opacity_depth(...) + (accumulate_along_rays(weights, normals),), bit for bit (with ``want_midpoints`` the
+    [S] midpoints as a fourth, non-differentiable output)."""
+    pk = _packed(ray_indices, packed_info, n_rays, weights.numel(), "accumulate_opacity_depth_normal")
+    return _OpacityDepthNormal.apply(pk, weights.reshape(-1), t_starts, t_ends, normals, bool(want_midpoints))
 
 
 def accumulate_along_rays(weights, values=None, *, ray_indices=None, packed_info=None, n_rays=None):
     """nerfacc 0.5.3 signature (models/volrend.py:871-885): weights [S], values [S,D] or None ->
     [n_rays, D or 1]."""
-    pk = _packed(ray_indices, packed_info, n_rays)
+    pk = _packed(ray_indices, packed_info, n_rays, weights.numel(), "accumulate_along_rays")
     return _Accumulate.apply(pk, weights.reshape(-1), values)
 
 

@@ -114,9 +114,9 @@ class TrainStep:
         if batch is None:
             batch = self.sample_batch()
         loss, terms, out = self.forward_backward(batch)
-        if self.world > 1 and self.buckets is not None:
-            self.buckets.all_reduce_mean(self.world)              # DDP: mean of the ranks' gradients (launch.py:84-97)
-        self.opt.step()
+        handles = []
+        if self.world > 1 and self.buckets is not None:           # DDP: mean of the ranks' gradients (launch.py:84-97):
+            handles = self.buckets.all_reduce_mean(self.world, async_op=True)   # issued here, finished just before Adam
         n_rays = batch["rays"].shape[0]
         ns = out.get("num_samples_host", None)
         if ns is None:                                            # a model that did not read its count back
@@ -124,6 +124,9 @@ class TrainStep:
         if self.dynamic_ray_sampling and ns > 0:                  # systems/split_occ.py:159-161
             want = int(self.train_num_rays * (self.train_num_samples / ns))
             self.train_num_rays = min(int(self.train_num_rays * 0.9 + want * 0.1), self.max_train_num_rays)
+        if handles:
+            self.buckets.finish(handles, self.world)
+        self.opt.step()
         return {"loss": loss.detach(), "terms": terms, "num_samples": ns, "num_rays": n_rays, "out": out}
 
 

@@ -52,8 +52,13 @@ def rendering_with_normals_sdf(t_starts: Tensor, t_ends: Tensor, ray_indices: Op
     if has_laplace:
         extras["sdf_laplace"] = sdf_laplace
     colors = ops.accumulate_along_rays(weights, rgbs, packed_info=packed)
-    normals_map = ops.accumulate_along_rays(weights, normals, packed_info=packed)
-    opacities, depths = ops.accumulate_opacity_depth(weights, t_starts, t_ends, packed_info=packed)   # (one pass, same bits)
+    if ops.fold_normals() and normals.shape[-1] == 3:
+        # opacity, depth and the normal map in one pass, same bits as the three accumulate calls (volrend.py:875-885)
+        opacities, depths, normals_map = ops.accumulate_opacity_depth_normal(weights, t_starts, t_ends, normals,
+                                                                             packed_info=packed)
+    else:
+        normals_map = ops.accumulate_along_rays(weights, normals, packed_info=packed)
+        opacities, depths = ops.accumulate_opacity_depth(weights, t_starts, t_ends, packed_info=packed)
     if render_bkgd is not None:
         colors = colors + render_bkgd * (1.0 - opacities)
         normals_map = normals_map + render_bkgd * (1 - opacities) * torch.tensor([0.0, 0.0, 1.0], device=dev)

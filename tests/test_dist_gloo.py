@@ -36,6 +36,22 @@ WORKER = textwrap.dedent("""
     assert torch.allclose(big.grad, torch.full((1000,), 1.5))
     assert torch.allclose(small[0].grad, torch.full((7, 3), 15.0))
     assert torch.allclose(small[1].grad, torch.tensor(2.0))
+    # several large parameters (hash table + environment map) are reduced in place, the rest through the flat buffer;
+    # async issue + finish (what TrainStep does around its host-side bookkeeping)
+    rd.GradBuckets.IN_PLACE_MIN = 500
+    table, envmap, w = (torch.nn.Parameter(torch.zeros(1000)), torch.nn.Parameter(torch.zeros(6, 10, 10, 3)),
+                        torch.nn.Parameter(torch.zeros(4, 4)))
+    table.grad, envmap.grad, w.grad = (torch.full((1000,), 2.0 * rank), torch.full((6, 10, 10, 3), 1.0 + rank),
+                                       torch.full((4, 4), 3.0 - rank))
+    b2 = rd.GradBuckets([table, envmap, w])
+    assert len(b2.big) == 2 and len(b2.rest) == 1 and b2.flat.numel() == 16 and b2.bytes_per_step() == 4 * (1000 + 1800 + 16)
+    ptrs = (table.grad.data_ptr(), envmap.grad.data_ptr())
+    handles = b2.all_reduce_mean(world, async_op=True)
+    assert len(handles) == 3
+    b2.finish(handles, world)
+    assert (table.grad.data_ptr(), envmap.grad.data_ptr()) == ptrs            # in place
+    assert torch.allclose(table.grad, torch.full((1000,), 1.0)) and torch.allclose(envmap.grad, torch.full((6, 10, 10, 3), 1.5))
+    assert torch.allclose(w.grad, torch.full((4, 4), 2.5))
     # chunk sharding: every chunk exactly once, round-robin
     mine = rd.shard_chunks(640000, 4096, rank, world)
     gathered = [None, None]

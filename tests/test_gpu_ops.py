@@ -242,6 +242,46 @@ def test_opacity_and_depth_in_one_pass(dev, ops):
     assert torch.equal(w3.grad, w4.grad)
 
 
+def test_opacity_depth_and_normal_map_in_one_pass(dev, ops):
+    """models/volrend.py:875-885: ops.accumulate_opacity_depth_normal == accumulate_opacity_depth + accumulate_along_rays on
+    the [S,3] normals, bit for bit (values, weight gradient, normal gradient); rays without samples included; partial
+    gradient sets; sample arrays with an unowned tail (capacity mode) get zero gradients there."""
+    counts, ri = _ragged(300, 150, 19)
+    g = torch.Generator().manual_seed(21)
+    S = ri.numel()
+    w, nm = torch.rand(S, generator=g), torch.randn(S, 3, generator=g)
+    ts = torch.rand(S, generator=g) * 3.0
+    te = ts + torch.rand(S, generator=g) * 0.01
+    g_op, g_d, g_n = (torch.randn(300, 1, generator=g).to(dev), torch.randn(300, 1, generator=g).to(dev),
+                      torch.randn(300, 3, generator=g).to(dev))
+    rid, tsd, ted = ri.to(dev), ts.to(dev), te.to(dev)
+    for use in ((0, 0, 1), (1, 0, 0), (0, 1, 1), (1, 1, 1)):
+        w1, n1 = w.to(dev).requires_grad_(True), nm.to(dev).requires_grad_(True)
+        op1, d1, mid1 = ops.accumulate_opacity_depth(w1, tsd, ted, ray_indices=rid, n_rays=300, want_midpoints=True)
+        m1 = ops.accumulate_along_rays(w1, n1, ray_indices=rid, n_rays=300)
+        (use[0] * (op1 * g_op).sum() + use[1] * (d1 * g_d).sum() + use[2] * (m1 * g_n).sum()).backward()
+        w2, n2 = w.to(dev).requires_grad_(True), nm.to(dev).requires_grad_(True)
+        op2, d2, m2, mid2 = ops.accumulate_opacity_depth_normal(w2, tsd, ted, n2, ray_indices=rid, n_rays=300,
+                                                                want_midpoints=True)
+        terms = [t for u, t in zip(use, ((op2 * g_op).sum(), (d2 * g_d).sum(), (m2 * g_n).sum())) if u]
+        sum(terms).backward()
+        assert torch.equal(op2, op1) and torch.equal(d2, d1) and torch.equal(m2, m1) and torch.equal(mid2, mid1)
+        assert torch.equal(w2.grad, w1.grad), use
+        if use[2]:
+            assert torch.equal(n2.grad, n1.grad), use
+        else:
+            assert n2.grad is None or not bool(n2.grad.any())
+    assert bool((m2[counts.to(dev) == 0] == 0).all())
+    # an unowned tail: 40 more samples than the rays' packed_info covers (march_capped's dummy tail)
+    pk = ops.pack_info(rid, 300)
+    pad = lambda t: torch.cat([t, torch.full((40,) + t.shape[1:], 0.5, device=dev)])
+    w3, n3 = pad(w.to(dev)).requires_grad_(True), pad(nm.to(dev)).requires_grad_(True)
+    op3, d3, m3 = ops.accumulate_opacity_depth_normal(w3, pad(tsd), pad(ted), n3, packed_info=pk)
+    ((op3 * g_op).sum() + (d3 * g_d).sum() + (m3 * g_n).sum()).backward()
+    assert torch.equal(op3, op1) and torch.equal(m3, m1)
+    assert bool((w3.grad[S:] == 0).all()) and bool((n3.grad[S:] == 0).all()) and torch.equal(w3.grad[:S], w2.grad)
+
+
 # ---- H1 -------------------------------------------------------------------------------------------
 GRIDS = [dict(n_levels=4, n_features=2, log2_hashmap_size=14, base_resolution=16, per_level_scale=1.5),
          dict(n_levels=16, n_features=2, log2_hashmap_size=19, base_resolution=32,

@@ -209,6 +209,32 @@ def test_bench_two_ranks_on_one_gpu(dev):
     assert 1.6 < ratio < 2.4, ratio
 
 
+def test_bench_c3_two_ranks_on_one_gpu(dev):
+    """``bench.py --workload c3 --gpus 2`` itself (only TrainStep was driven so far): the config[3] training
+    step on two ranks sharing this GPU (gloo, RSDF_DIST_SHARE_GPU=1), gradient all-reduce issued asynchronously after the
+    backward and finished before Adam; the printed line must aggregate both ranks (samples summed, time max-reduced)."""
+    import json
+    env = dict(os.environ, RSDF_DIST_SHARE_GPU="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    lines = {}
+    for n in (2, 1):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c3", "--gpus", str(n), "--steps", "3",
+                            "--warmup", "4", "--hidden", "64", "--no-extras", "--cpu-rays", "0"], env=env, capture_output=True,
+                           text=True, timeout=1500)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines[n] = json.loads(r.stdout.strip().splitlines()[-1])
+    two, one = lines[2], lines[1]
+    assert two["n_gpus"] == 2 and two["config"]["rccl_ranks"] == 2 and two["config"]["dist_backend"] == "gloo"
+    assert two["scaling"] == "weak" and two["steps"] == 3 and two["value"] > 0
+    assert one["n_gpus"] == 1 and one["config"]["rccl_ranks"] == 1
+    # every rank steers its own batch to the same sample target: the job's samples and rays are about twice one rank's
+    for k in ("samples_per_step", "rays_per_step"):
+        ratio = two["config"][k] / one["config"][k]
+        assert 1.5 < ratio < 2.6, (k, ratio)
+    assert abs(two["value"] - two["config"]["samples_per_step"] / (two["ms_per_step"] / 1e3)) < 1e-3 * two["value"]
+
+
 @pytest.mark.parametrize("which", ["coop", "legacy"])
 def test_alternative_mlp_backward_kernels_stay_correct(dev, which):
     """H = 64 ships the quad backward (mlp_quad.hip); the cooperative (mlp_coop.hip, also the H = 32 / 128 kernel) and the

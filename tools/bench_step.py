@@ -69,6 +69,8 @@ def measure(dev, stage=1, steps=30, settle=80, first_step=20000, syncs=False, hi
     out = {"stage": int(model.stage), "hidden": hidden, "ms_per_step": dt / steps * 1e3, "steps_per_s": steps / dt,
            "rays_per_step": rays / steps, "samples_per_step": samples / steps, "samples_per_s": samples / dt,
            "rsdf_kernel_ms_per_step": round(sum(v["ms"] for v in summ.values()) / steps, 2),
+           "rsdf_kernel_ms_note": "sum of event-to-event times per entry point; the environment prefilter runs on a side "
+                                  "stream beside the networks' kernels, so the sum can exceed ms_per_step",
            "top": {k: round(v["ms"] / steps, 2) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:10]},
            "settle_first": traj[:3], "settle_last": traj[-3:]}
     out["sampler_stats"] = dict(getattr(model.occupancy_grid, "stats", {}))

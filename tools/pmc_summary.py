@@ -6,7 +6,7 @@ Corrections, per MI355X_MICROARCH.md "HBM": FETCH_SIZE is reported in KiB-like u
 (counter x 1024 = bytes is what the kernel_stats of round 1 cross-checked) and counts 64 B per 128-B request on
 gfx950 -> doubled; WRITE_SIZE reads exact.
 
-    python tools/pmc_summary.py profiles/r02b_.../pmc <samples in the profiled run> profiles/pmc_summary.json
+    python tools/pmc_summary.py profiles/r02b_.../pmc <samples in the profiled run> profiles/pmc_summary.json [build tag]
 """
 import csv
 import json
@@ -14,6 +14,12 @@ import os
 import sys
 
 ENTRY = {  # kernel name fragment -> C-ABI entry point (first match wins; <true> = taps derived in-kernel, the _pts entry points)
+    "fd7_fwd_kernel<true, true>": "rsdf_hashgrid_fwd_fd7_x2",
+    "fd7_fwd_kernel<false, true>": "rsdf_hashgrid_fwd_fd7_x2",
+    "fd7_fwd_kernel<true, false>": "rsdf_hashgrid_fwd_fd7_pts",
+    "fwd_x2_kernel": "rsdf_sdfmlp_fd7_fwd_x2",
+    "bwd_x2_kernel": "rsdf_sdfmlp_fd7_bwd_x2",
+    "absmax_kernel": "rsdf_sdfmlp_fd7_bwd_x2",
     "fd7_fwd_kernel<true>": "rsdf_hashgrid_fwd_fd7_pts",
     "fd7_produce_kernel<true>": "rsdf_hashgrid_bwd_fd7_pts",
     "fd7_reduce_kernel": "rsdf_hashgrid_bwd_fd7_pts",       # (bench.py only runs the _pts form)
@@ -43,6 +49,7 @@ def read(path, counter):
 
 def main():
     src, samples, dst = sys.argv[1], float(sys.argv[2]), sys.argv[3]
+    build = sys.argv[4] if len(sys.argv) > 4 else "unknown"
     fetch = read(os.path.join(src, "FETCH_SIZE.csv"), "FETCH_SIZE")
     write = read(os.path.join(src, "WRITE_SIZE.csv"), "WRITE_SIZE")
     kernels = {}
@@ -52,7 +59,7 @@ def main():
         kernels[k] = {"fetch_bytes_per_sample": f / samples, "write_bytes_per_sample": w / samples,
                       "hbm_bytes_per_sample": (f + w) / samples}
     json.dump({"source": f"{src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled per "
-                         "MI355X_MICROARCH.md)", "samples_in_profiled_run": samples, "kernels": kernels},
+                         "MI355X_MICROARCH.md)", "build": build, "samples_in_profiled_run": samples, "kernels": kernels},
               open(dst, "w"), indent=1)
     for k, v in kernels.items():
         print(f"{k:28s} fetch {v['fetch_bytes_per_sample']:9.0f}  write {v['write_bytes_per_sample']:9.0f}  B/sample")
