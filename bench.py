@@ -193,6 +193,9 @@ def cpu_baseline(model, rays_cpu, jitter_cpu, max_rays, budget_s=5.0, reps=5):
 def roofline_from(summary, steps):
     """Pick the entry point with the most device time and price it against its roofline."""
     def cost(name, a):
+        if name in ("rsdf_sdfmlp_fd7_fwd_x2", "rsdf_sdfmlp_fd7_bwd_x2") and a and a[0] == 1:   # parts = 1: the 16-bit form
+            b, w = cost(name, (2,) + tuple(a[1:]))
+            return "mfma_bf16", w
         if name.endswith("_bf16"):           # config[4]'s bf16 MLP mode: same algorithmic flops, bf16 matrix peak
             b, w = cost(name[:-5], a)
             return ("mfma_bf16" if b == "mfma" else b), w
@@ -207,11 +210,11 @@ def roofline_from(summary, steps):
             return "hbm", 7 * a[0] * (16 * 8 * 2 * 4 + 12 + 16 * 2 * 4)   # 7 evaluations x 1164 B
         if name in ("rsdf_hashgrid_fwd_fd7_pts", "rsdf_hashgrid_bwd_fd7_pts", "rsdf_hashgrid_fwd_fd7_x2"):
             return "hbm", 7 * a[2] * (16 * 8 * 2 * 4 + 12 + 16 * 2 * 4)       # radius, eps, n_samples, n_active, ...
-        if name == "rsdf_sdfmlp_fd7_fwd_x2":  # L, H, N2, n_samples
-            K0, H, S = 3 + 2 * a[0], a[1], a[3]
+        if name == "rsdf_sdfmlp_fd7_fwd_x2":  # parts, L, H, N2, n_samples
+            K0, H, S = 3 + 2 * a[1], a[2], a[4]
             return "mfma", 2.0 * 7 * S * (K0 * H + H * H + H)
-        if name == "rsdf_sdfmlp_fd7_bwd_x2":  # L, n_active, H, N2, n_samples
-            K0, H, S = 3 + 2 * a[0], a[2], a[4]
+        if name == "rsdf_sdfmlp_fd7_bwd_x2":  # parts, L, n_active, H, N2, n_samples
+            K0, H, S = 3 + 2 * a[1], a[3], a[5]
             return "mfma", 2 * 2.0 * 7 * S * (K0 * H + H * H + H)
         if name == "rsdf_sdfmlp_fd7_fwd":    # L, n_active, xyz_scale, xyz_offset, H, N2, n_samples
             K0, H, S = 3 + 2 * a[0], a[4], a[6]
@@ -231,9 +234,9 @@ def roofline_from(summary, steps):
         if name.endswith("_fd7_pts") or name == "rsdf_hashgrid_fwd_fd7_x2":
             return a[2]
         if name == "rsdf_sdfmlp_fd7_fwd_x2":
-            return a[3]
-        if name == "rsdf_sdfmlp_fd7_bwd_x2":
             return a[4]
+        if name == "rsdf_sdfmlp_fd7_bwd_x2":
+            return a[5]
         return a[6] if name.startswith("rsdf_sdfmlp_fd7") else a[0]   # (also the _bf16 names)
 
     best = max(summary.items(), key=lambda kv: kv[1]["ms"])
@@ -416,8 +419,12 @@ def secondary_measurements(dev, args, rays, jitter, cot):
     # (H = 128: the cooperative kernels hold every register of a CU, a second chunk in flight only adds contention)
     h128_chunk = min(args.chunk, 24576)       # (the H = 128 variants keep the chunk size they were measured at)
     guarded("h128", lambda: c1_variant(128, h128_chunk, streams=1))
-    # config[4]'s opt-in bf16 MLP mode at the yaml's width (dtype bf16; never part of the f32 headline)
+    guarded("h128_two_streams", lambda: c1_variant(128, h128_chunk))
+    # config[4]'s opt-in 16-bit MLP modes at the yaml's width (never part of the f32 headline): 'bf16' = the round-3
+    # kernels with one bf16 product per k-step; 'fp16' = the x2 kernels with ONE fp16 part (11 significant bits)
     guarded("h128_bf16", lambda: c1_variant(128, h128_chunk, precision="bf16"))
+    guarded("h128_fp16", lambda: c1_variant(128, h128_chunk, precision="fp16"))
+    guarded("h64_fp16", lambda: c1_variant(64, args.chunk, precision="fp16"))
     # the per-layer API route (tcnn.Encoding / VanillaMLP shaped calls, one or a few kernels each; INTEGRATION.md's
     # two-line dropin.install()): [7 S, 35] rows through HBM, so a quarter of the view at the reference's chunk size
     guarded("dropin_path", lambda: c1_variant(args.hidden, 4096, n_rays=rays.shape[0] // 4 // 800 * 800, fused=False))
@@ -525,7 +532,7 @@ def main():
     ap.add_argument("--width", type=int, default=800)
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--hidden", type=int, default=64)
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "fp16"],
                     help="MLP matrix precision: fp32 = fp32-equivalent split products (the metric's dtype f32); bf16 = "
                          "BASELINE.json configs[4]'s opt-in bf16 MLP mode (reported with dtype bf16)")
     ap.add_argument("--cpu-rays", type=int, default=4096,
@@ -626,7 +633,7 @@ def main():
             "metric": "ray-marched SDF samples/sec (fwd+bwd), 800x800 rays, L=16 hashgrid",
             "value": samples / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32",
+            "scaling": "weak", "vs_baseline": None, "dtype": {"bf16": "bf16", "fp16": "f16"}.get(args.precision, "f32"),
             "data": "synthetic",
             "config": {"workload": "c1: toaster-sized 800x800 view per GPU, dense marching, L=16 T=2^19 "
                                    f"hash grid + 2x{args.hidden} SDF MLP (7 FD taps), NeuS alpha + composite, fwd+bwd",

@@ -316,17 +316,21 @@ int rsdf_sdfmlp_fd7_bwd(const float *x7t, const float *planes, int n_levels, int
  * bwd additionally needs absmax_scratch (8 bytes of device memory): it scans d_sdf7t (and d_feature's d(h2)) for their
  * largest magnitude first, from which the kernel derives the power-of-two scale of its fp16 gradient images.
  * Preconditions (fp16 range; a violation overflows to inf / nan, never silently): |input| < 255, |weight| < 1023,
- * |hidden activation| < 1023. */
+ * |hidden activation| < 1023.
+ * parts = 2 is the fp32-equivalent form above.  parts = 1 is the 16-bit mode of BASELINE.json configs[4] ("bf16 MLP on
+ * MFMA") for this node: the lo parts are dropped everywhere -- operands rounded ONCE to fp16 (11 significant bits against
+ * bf16's 8: the finite-difference normal divides a difference of these values by eps), one matrix instruction per
+ * product, the image [tile][tap][1][36][32] (504 B per sample); fp32 accumulation, master weights and gradients. */
 int64_t rsdf_x2_rows(int64_t n_samples);
-int64_t rsdf_x2_bytes(int64_t n_samples);
+int64_t rsdf_x2_bytes(int64_t n_samples, int parts);
 int rsdf_hashgrid_fwd_fd7_x2(const float *x7t /*or NULL*/, const float *points /*or NULL*/, float radius, float eps,
                              const float *table, const rsdf_grid_meta *meta /*host*/, int64_t n_samples,
-                             int n_active_levels, float xyz_scale, float xyz_offset, void *x2, void *stream);
+                             int n_active_levels, float xyz_scale, float xyz_offset, int parts, void *x2, void *stream);
 int rsdf_sdfmlp_fd7_x2_supported(int K0, int H, int N2);
-int rsdf_sdfmlp_fd7_fwd_x2(const void *x2, int n_levels, int H, int N2, const float *w0, const float *b0,
+int rsdf_sdfmlp_fd7_fwd_x2(const void *x2, int parts, int n_levels, int H, int N2, const float *w0, const float *b0,
                            const float *w1, const float *b1, const float *w2, const float *b2, int64_t n_samples,
                            float *sdf7t, float *feature, float *h2c, void *stream);
-int rsdf_sdfmlp_fd7_bwd_x2(const void *x2, int n_levels, int n_active_levels, int H, int N2, const float *w0,
+int rsdf_sdfmlp_fd7_bwd_x2(const void *x2, int parts, int n_levels, int n_active_levels, int H, int N2, const float *w0,
                            const float *b0, const float *w1, const float *b1, const float *w2, const float *b2,
                            int64_t n_samples, const float *d_sdf7t, const float *d_feature,
                            float *dh2c_scratch /*nullable*/, void *absmax_scratch /*8 bytes*/, float *d_planes,

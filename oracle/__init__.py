@@ -401,7 +401,7 @@ _MLP_PRECISION = ["fp32"]
 
 class mlp_precision:
     def __init__(self, precision):
-        assert precision in ("fp32", "bf16")
+        assert precision in ("fp32", "bf16", "fp16")
         self.p = precision
 
     def __enter__(self):
@@ -413,6 +413,10 @@ class mlp_precision:
 
 
 def _rb(t):
+    if _MLP_PRECISION[0] == "fp16":
+        # the one-part form of csrc/mlp_x2.hip: operands rounded once to fp16 (the kernels' power-of-two class scales do not
+        # change that rounding inside the fp16 normal range; below it the kernels keep MORE bits than this emulation)
+        return t.to(torch.float16).to(torch.float32)
     return t.to(torch.bfloat16).to(torch.float32)
 
 
@@ -432,7 +436,7 @@ class _LinearBF16(torch.autograd.Function):
 
 def linear(x, w, b):
     """nn.Linear at the oracle's current MLP precision."""
-    if _MLP_PRECISION[0] == "bf16":
+    if _MLP_PRECISION[0] in ("bf16", "fp16"):
         return _LinearBF16.apply(x.float(), w.float(), b.float())
     return F.linear(x, w, b)
 

@@ -94,11 +94,11 @@ _SIGNATURES = {
     "rsdf_linear_bwd_fused_tail_ws": [_P, _I, _P, _P, _I, _P, _I, _P, _L, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P, _L, _P],
     "rsdf_sdfmlp_fd7_supported": [_I, _I, _I],
     "rsdf_x2_rows": [_L],
-    "rsdf_x2_bytes": [_L],
-    "rsdf_hashgrid_fwd_fd7_x2": [_P, _P, _F, _F, _P, ctypes.POINTER(GridMeta), _L, _I, _F, _F, _P, _P],
+    "rsdf_x2_bytes": [_L, _I],
+    "rsdf_hashgrid_fwd_fd7_x2": [_P, _P, _F, _F, _P, ctypes.POINTER(GridMeta), _L, _I, _F, _F, _I, _P, _P],
     "rsdf_sdfmlp_fd7_x2_supported": [_I, _I, _I],
-    "rsdf_sdfmlp_fd7_fwd_x2": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P],
-    "rsdf_sdfmlp_fd7_bwd_x2": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+    "rsdf_sdfmlp_fd7_fwd_x2": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P],
+    "rsdf_sdfmlp_fd7_bwd_x2": [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                _P],
     "rsdf_sdfmlp_fd7_fwd": [_P, _P, _I, _I, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P],
     "rsdf_sdfmlp_fd7_bwd": [_P, _P, _I, _I, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P,
@@ -155,10 +155,11 @@ def mlp_fn(name, precision="fp32"):
     (one bf16 product per k-step, fp32 accumulate; opt-in, BASELINE.json configs[4])."""
     if precision in (None, "fp32", "f32", "float32"):
         return getattr(lib(), name)
-    if precision in ("bf16", "bfloat16"):
+    if precision in ("bf16", "bfloat16", "fp16", "half"):     # ('fp16': the fused SDF node's own 16-bit form, fused.x2_parts;
+        #                                                           everything per-layer of such a network uses the bf16 build)
         assert name in BF16_ENTRY_POINTS, name
         return getattr(lib(), name + "_bf16")
-    raise ValueError(f"unknown MLP precision {precision!r} (fp32 or bf16)")
+    raise ValueError(f"unknown MLP precision {precision!r} (fp32, bf16 or fp16)")
 
 
 _RESTYPES = {"rsdf_last_error": ctypes.c_char_p, "rsdf_scan_scratch_bytes": ctypes.c_int64,

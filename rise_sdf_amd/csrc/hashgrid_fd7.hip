@@ -261,12 +261,14 @@ __device__ __forceinline__ void load_stencil(const TapSrc &src, int64_t S, int64
 // dimension) and weight-gradient fragments with ds_read_b128 (rows are).  Precondition: |value| < 255 (fp16 range).
 // ------------------------------------------------------------------------------------------------
 constexpr int X2_COLS = 36;
-constexpr int X2_PART_B = X2_COLS * 64, X2_TAP_B = 2 * X2_PART_B, X2_TILE_B = 7 * X2_TAP_B;
+constexpr int X2_PART_B = X2_COLS * 64;
 constexpr float X2_SCALE = 256.0f;
 struct X2Out {
     unsigned char *base;
     int64_t Sp;
     float xyz_scale, xyz_offset;
+    int parts;          // 2: hi + lo (fp32-equivalent); 1: hi only (the 16-bit mode of mlp_x2.hip)
+    int tap_b, tile_b;  // parts * X2_PART_B, 7 * tap_b
 };
 using x2_f32x2 = __attribute__((ext_vector_type(2))) float;
 using x2_f16x2 = __attribute__((ext_vector_type(2))) _Float16;
@@ -284,7 +286,7 @@ __device__ __forceinline__ void x2_split(float a, float b, unsigned &h, unsigned
 // byte address of (row s, tap, part, column)
 __device__ __forceinline__ unsigned char *x2_at(const X2Out &o, int64_t s, int tap, int part, int col)
 {
-    return o.base + (s >> 5) * X2_TILE_B + tap * X2_TAP_B + part * X2_PART_B + col * 64 +
+    return o.base + (s >> 5) * o.tile_b + tap * o.tap_b + part * X2_PART_B + col * 64 +
            ((2 * (int)(s & 31)) ^ (32 * ((col >> 3) & 1)));
 }
 // Lane pairs (2 i, 2 i + 1) hold rows (s, s + 1): the even lane ends up with feature 0 of both rows, the odd lane with
@@ -297,12 +299,12 @@ __device__ __forceinline__ unsigned x2_pair_exchange(unsigned own, bool odd)
     // even: {own.lo16, nb.lo16}; odd: {nb.hi16, own.hi16}
     return odd ? __builtin_amdgcn_perm(nb, own, 0x03020706u) : __builtin_amdgcn_perm(nb, own, 0x05040100u);
 }
-__device__ __forceinline__ void x2_store_features(unsigned char *p, bool odd, float f0, float f1)
+__device__ __forceinline__ void x2_store_features(unsigned char *p, bool odd, float f0, float f1, int parts)
 {
     unsigned h, lo;
     x2_split(f0 * X2_SCALE, f1 * X2_SCALE, h, lo);
     *reinterpret_cast<unsigned *>(p) = x2_pair_exchange(h, odd);
-    *reinterpret_cast<unsigned *>(p + X2_PART_B) = x2_pair_exchange(lo, odd);
+    if (parts == 2) *reinterpret_cast<unsigned *>(p + X2_PART_B) = x2_pair_exchange(lo, odd);    // (uniform)
 }
 // unit-cube coordinates of the 7 stencil points, as rsdf_fd_points writes them (neus.hip fd_points_kernel), * scale + offset,
 // and the bias column: written as two more "levels" -- (x, y) into columns 32 / 33 and (z, 1) into 34 / 35 -- through the
@@ -312,9 +314,9 @@ template <bool DERIVE>
 __device__ __forceinline__ void x2_store_points(const X2Out &o, const TapSrc &src, int64_t S, int64_t s, int64_t sl, bool pad)
 {
     const bool odd = (threadIdx.x & 1) != 0;
-    const unsigned loff = (threadIdx.x >> 5) * (unsigned)X2_TILE_B + (unsigned)(32 + (int)(threadIdx.x & 1)) * 64u +
+    const unsigned loff = (threadIdx.x >> 5) * (unsigned)o.tile_b + (unsigned)(32 + (int)(threadIdx.x & 1)) * 64u +
                           (unsigned)(2 * (int)(threadIdx.x & 30));
-    unsigned char *bb = o.base + (s - threadIdx.x) / 32 * X2_TILE_B;
+    unsigned char *bb = o.base + (s - threadIdx.x) / 32 * o.tile_b;
     const float one = pad ? 0.0f : 1.0f;
     float u[7][3];
     if (DERIVE) {
@@ -344,8 +346,8 @@ __device__ __forceinline__ void x2_store_points(const X2Out &o, const TapSrc &sr
         float v[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) v[k] = pad ? 0.0f : u[t][k] * o.xyz_scale + o.xyz_offset;
-        x2_store_features(bb + t * X2_TAP_B + loff, odd, v[0], v[1]);
-        x2_store_features(bb + t * X2_TAP_B + loff + 128, odd, v[2], one);
+        x2_store_features(bb + t * o.tap_b + loff, odd, v[0], v[1], o.parts);
+        x2_store_features(bb + t * o.tap_b + loff + 128, odd, v[2], one, o.parts);
     }
 }
 
@@ -435,10 +437,10 @@ __device__ __forceinline__ void fd7_fwd_sample(const TapSrc &src, const float2 *
         if (X3) {
             // workgroup-uniform base (the block's first tile; a scalar add per tap) + a 32-bit lane offset: the stores
             // need no vector address arithmetic (global_store ... saddr, parts as immediates)
-            const unsigned loff = (threadIdx.x >> 5) * (unsigned)X2_TILE_B + (unsigned)(2 * l + (int)(threadIdx.x & 1)) * 64u +
+            const unsigned loff = (threadIdx.x >> 5) * (unsigned)x3.tile_b + (unsigned)(2 * l + (int)(threadIdx.x & 1)) * 64u +
                                   (unsigned)((2 * (int)(threadIdx.x & 30)) ^ (32 * ((l >> 2) & 1)));
-            unsigned char *bb = x3.base + (s - threadIdx.x) / 32 * X2_TILE_B + t * X2_TAP_B;
-            x2_store_features(bb + loff, (threadIdx.x & 1) != 0, pad ? 0.0f : acc.x, pad ? 0.0f : acc.y);
+            unsigned char *bb = x3.base + (s - threadIdx.x) / 32 * x3.tile_b + t * x3.tap_b;
+            x2_store_features(bb + loff, (threadIdx.x & 1) != 0, pad ? 0.0f : acc.x, pad ? 0.0f : acc.y, x3.parts);
         }
         else planes[((int64_t)l * 7 + t) * S + s] = acc;
     }
@@ -478,7 +480,7 @@ __global__ void __launch_bounds__(256)
 x3_zero_cols_kernel(const X2Out x3, int col0)
 {
     const int per = (32 - col0) * 4;
-    const int64_t n = x3.Sp / 32 * 14 * per;
+    const int64_t n = x3.Sp / 32 * 7 * x3.parts * per;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int64_t blk = i / per;
         const int u = (int)(i - blk * per);
@@ -1083,7 +1085,7 @@ int launch_fwd(const TapSrc &src, const float *table, const rsdf_grid_meta *meta
     hipStream_t st = (hipStream_t)stream;
     if (x3) {
         if (na < 16) {
-            const int64_t n16 = x3->Sp / 32 * 14 * (int64_t)(32 - 2 * na) * 4;
+            const int64_t n16 = x3->Sp / 32 * 7 * x3->parts * (int64_t)(32 - 2 * na) * 4;
             const unsigned gx = (unsigned)((n16 + 255) / 256 < 4096 ? (n16 + 255) / 256 : 4096);
             x3_zero_cols_kernel<<<gx, 256, 0, st>>>(*x3, 2 * na);
         }
@@ -1093,7 +1095,7 @@ int launch_fwd(const TapSrc &src, const float *table, const rsdf_grid_meta *meta
             fd7_fwd_kernel<true, true><<<n_tiles_f * na, F_THREADS, 0, st>>>(src, table, *meta, n_samples, na, nullptr, *x3);
         RSDF_RETURN_LAUNCH();
     }
-    const X2Out none{nullptr, 0, 0.f, 0.f};
+    const X2Out none{nullptr, 0, 0.f, 0.f, 2, 0, 0};
     if (src.x7t)
         fd7_fwd_kernel<false, false><<<n_tiles_f * na, F_THREADS, 0, st>>>(src, table, *meta, n_samples, na, pl, none);
     else
@@ -1241,16 +1243,21 @@ int rsdf_hashgrid_fwd_fd7_pts(const float *points, float radius, float eps, cons
 }
 
 int64_t rsdf_x2_rows(int64_t n_samples) { return (n_samples + 31) / 32 * 32; }
-int64_t rsdf_x2_bytes(int64_t n_samples) { return rsdf_x2_rows(n_samples) / 32 * (int64_t)X2_TILE_B + 1024; }   // + slack: see mlp_x2.hip fetch_x2
+int64_t rsdf_x2_bytes(int64_t n_samples, int parts)        // + slack: see mlp_x2.hip fetch_x2
+{
+    return rsdf_x2_rows(n_samples) / 32 * (int64_t)(7 * (parts == 1 ? 1 : 2) * X2_PART_B) + 4096;
+}
 
 int rsdf_hashgrid_fwd_fd7_x2(const float *x7t, const float *points, float radius, float eps, const float *table,
                              const rsdf_grid_meta *meta, int64_t n_samples, int n_active_levels, float xyz_scale,
-                             float xyz_offset, void *x3, void *stream)
+                             float xyz_offset, int parts, void *x3, void *stream)
 {
     RSDF_CHECK_ARG((x7t != nullptr) != (points != nullptr) || n_samples <= 0, "hashgrid_fwd_fd7_x2: give x7t or points");
     RSDF_CHECK_ARG(points == nullptr || radius > 0.f, "hashgrid_fwd_fd7_x2: radius must be > 0");
     RSDF_CHECK_ARG(x3 != nullptr || n_samples <= 0, "hashgrid_fwd_fd7_x2: x3 is NULL");
-    const X2Out o{reinterpret_cast<unsigned char *>(x3), rsdf_x2_rows(n_samples), xyz_scale, xyz_offset};
+    RSDF_CHECK_ARG(parts == 1 || parts == 2, "hashgrid_fwd_fd7_x2: parts must be 1 or 2");
+    const X2Out o{reinterpret_cast<unsigned char *>(x3), rsdf_x2_rows(n_samples), xyz_scale, xyz_offset, parts, parts * X2_PART_B,
+                  7 * parts * X2_PART_B};
     return launch_fwd(x7t ? TapSrc{x7t, nullptr, 0.f, 0.f} : TapSrc{nullptr, points, radius, eps}, table, meta, n_samples,
                       n_active_levels, nullptr, stream, &o);
 }

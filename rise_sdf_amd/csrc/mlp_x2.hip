@@ -64,29 +64,35 @@ __device__ __forceinline__ float resid_hi(float b, unsigned hi)
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hi), "v"(b));
     return r;
 }
+// NP = 2: the fp32-equivalent form.  NP = 1: ONE part -- operands rounded once to fp16 (11 significant bits), one matrix
+// instruction per product: the "16-bit MLP on MFMA" mode of BASELINE.json configs[4] for the fused SDF field (precision
+// 'fp16' on the Python side); same kernels, the lo parts compile away.
+template <int NP = 2>
 __device__ __forceinline__ void split2_pair(float a, float b, unsigned &h, unsigned &l)
 {
     h = pack_f16(a, b);
-    l = pack_f16(resid_lo(a, h), resid_hi(b, h));
+    l = NP == 2 ? pack_f16(resid_lo(a, h), resid_hi(b, h)) : 0u;
 }
+template <int NP = 2>
 __device__ __forceinline__ Frag2 split2_frag(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7)
 {
     unsigned h0, h1, h2, h3, l0, l1, l2, l3;
-    split2_pair(v0, v1, h0, l0);
-    split2_pair(v2, v3, h1, l1);
-    split2_pair(v4, v5, h2, l2);
-    split2_pair(v6, v7, h3, l3);
+    split2_pair<NP>(v0, v1, h0, l0);
+    split2_pair<NP>(v2, v3, h1, l1);
+    split2_pair<NP>(v4, v5, h2, l2);
+    split2_pair<NP>(v6, v7, h3, l3);
     Frag2 f;
     f.h = u32x4{h0, h1, h2, h3};
     f.l = u32x4{l0, l1, l2, l3};
     return f;
 }
+template <int NP = 2>
 __device__ __forceinline__ void store2(unsigned short *base, size_t part_stride_elems, size_t idx, float w)
 {
     unsigned h, l;
-    split2_pair(w, 0.0f, h, l);
+    split2_pair<NP>(w, 0.0f, h, l);
     base[idx] = (unsigned short)(h & 0xffffu);
-    base[idx + part_stride_elems] = (unsigned short)(l & 0xffffu);
+    if (NP == 2) base[idx + part_stride_elems] = (unsigned short)(l & 0xffffu);
 }
 
 __device__ __forceinline__ f32x16 mma32(u32x4 a, u32x4 b, f32x16 c)
@@ -98,19 +104,25 @@ __device__ __forceinline__ f32x4 mma16(u32x4 a, u32x4 b, f32x4 c)
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 // a (weights in LDS, the two parts PART_U4 16-byte units apart) x b, small terms first
-template <int PART_U4>
+template <int PART_U4, int NP = 2>
 __device__ __forceinline__ f32x16 mma3(const u32x4 *__restrict__ wa, const Frag2 &b, f32x16 c)
 {
-    const u32x4 ah = wa[0], al = wa[PART_U4];
-    c = mma32(al, b.h, c);
-    c = mma32(ah, b.l, c);
+    const u32x4 ah = wa[0];
+    if (NP == 2) {
+        const u32x4 al = wa[PART_U4];
+        c = mma32(al, b.h, c);
+        c = mma32(ah, b.l, c);
+    }
     c = mma32(ah, b.h, c);
     return c;
 }
+template <int NP = 2>
 __device__ __forceinline__ f32x4 mma3q(const Frag2 &a, const Frag2 &b, f32x4 c)
 {
-    c = mma16(a.l, b.h, c);
-    c = mma16(a.h, b.l, c);
+    if (NP == 2) {
+        c = mma16(a.l, b.h, c);
+        c = mma16(a.h, b.l, c);
+    }
     c = mma16(a.h, b.h, c);
     return c;
 }
@@ -143,8 +155,10 @@ __device__ __forceinline__ u32x4 tr128(const unsigned char *a, int second)
     return u32x4{x0, x1, y0, y1};
 }
 
-// the HBM image
-constexpr int X2_PART_B = 36 * 64, X2_TAP_B = 2 * X2_PART_B, X2_TILE_B = 7 * X2_TAP_B;
+// the HBM image (NP parts per tap)
+constexpr int X2_PART_B = 36 * 64;
+template <int NP> constexpr int x2_tap_b() { return NP * X2_PART_B; }
+template <int NP> constexpr int x2_tile_b() { return 7 * NP * X2_PART_B; }
 struct SrcX2 {
     const unsigned char *x2;
     int64_t S, Sp;
@@ -162,16 +176,17 @@ struct SrcX2 {
 #ifndef RSDF_X2_BWD_OCC
 #define RSDF_X2_BWD_OCC 2
 #endif
-constexpr int FWD_WAVES = RSDF_X2_FWD_WAVES, FWD_THREADS = FWD_WAVES * 64;
+constexpr int FWD_WAVES = RSDF_X2_FWD_WAVES;
 constexpr int KS0 = 3;                 // layer-1 k-steps of 16 columns
 constexpr int LDFS = 33;               // [row][32 features] transpose of the centre rows' outputs
-constexpr int XF_COL_B = 64, XF_PART_B = 48 * XF_COL_B, XF_IMG_B = 2 * XF_PART_B;
+constexpr int XF_COL_B = 64, XF_PART_B = 48 * XF_COL_B;
+template <int NP> constexpr int xf_img_b() { return (NP * XF_PART_B > 32 * 33 * 4) ? NP * XF_PART_B : 32 * 33 * 4 + 128; }   // (>= the [32][33] fp32 transpose)
 
 // H = 128: W0 + W1 alone are 88 KB of the 160: the last layer's feature rows are not staged -- the kernel writes the centre
 // rows' second hidden layer (h2c) and the entry point runs one per-layer product on it (mlp_coop.hip's lean forward did
 // the same).  With three bf16 parts per weight (135 KB) this width needed the cooperative register partition of
 // mlp_coop.hip; with two parts every wave can again hold the whole network through LDS.
-template <int H>
+template <int H, int NP>
 struct SmemF {
     static constexpr int NT = H / 32;
     static constexpr bool W2_IN_LDS = H <= 64;
@@ -179,9 +194,9 @@ struct SmemF {
     static constexpr int W1_PART = NT * NT * 2 * 2 * 32;         // [nt][kt][s][hf][c]
     static constexpr int W2_PART = W2_IN_LDS ? 2 * NT * 2 * 2 * 32 : 0;   // [n2 tile (2)][kt][s][hf][c]
     static constexpr int W0 = 0;
-    static constexpr int W1 = W0 + 2 * W0_PART;
-    static constexpr int W2 = W1 + 2 * W1_PART;
-    static constexpr int END_U4 = W2 + 2 * W2_PART;
+    static constexpr int W1 = W0 + NP * W0_PART;
+    static constexpr int W2 = W1 + NP * W1_PART;
+    static constexpr int END_U4 = W2 + NP * W2_PART;
     static constexpr int B1 = 0;          // [H]   b1 * T2
     static constexpr int B2 = B1 + H;     // [64]  b2 (unscaled)
     static constexpr int W2R0 = B2 + 64;  // [H]   row 0 of W2 / SH: the taps' SDF dot on the vector ALU
@@ -190,18 +205,18 @@ struct SmemF {
 };
 template <int H>
 constexpr int fwd_waves() { return H <= 64 ? FWD_WAVES : 8; }       // H = 128: 88 KB of weights + 8 x 6 KB of images, ~230 registers
-template <int H>
-size_t fwd_lds() { return SmemF<H>::SHARED_BYTES + (size_t)fwd_waves<H>() * XF_IMG_B; }
+template <int H, int NP>
+size_t fwd_lds() { return SmemF<H, NP>::SHARED_BYTES + (size_t)fwd_waves<H>() * xf_img_b<NP>(); }
 
 // k of element j of lane half hf in k-step s of a 32-feature activation tile (the accumulator's register order)
 __device__ __forceinline__ int frag_k(int s, int hf, int j) { return 16 * s + 8 * (j >> 2) + 4 * hf + (j & 3); }
 
-template <int H>
+template <int H, int NP>
 __device__ __forceinline__ void stage_weights_fwd(unsigned char *smem, const float *__restrict__ w0, const float *__restrict__ b0,
                                                   const float *__restrict__ w1, const float *__restrict__ b1,
                                                   const float *__restrict__ w2, const float *__restrict__ b2, int K0, int N2)
 {
-    using S = SmemF<H>;
+    using S = SmemF<H, NP>;
     constexpr int NT = S::NT;
     unsigned short *e16 = reinterpret_cast<unsigned short *>(smem);
     const int NTHR = blockDim.x;
@@ -210,17 +225,17 @@ __device__ __forceinline__ void stage_weights_fwd(unsigned char *smem, const flo
         const int j = e & 7, c = (e >> 3) & 31, hf = (e >> 8) & 1, s = (e >> 9) % KS0, nt = (e >> 9) / KS0;
         const int n = 32 * nt + c, k = 16 * s + 8 * hf + j;
         const float w = k < 32 ? (k < K0 - 3 ? w0[n * K0 + 3 + k] : 0.0f) : (k < 35 ? w0[n * K0 + (k - 32)] : (k == 35 ? b0[n] : 0.0f));
-        store2(e16 + (size_t)S::W0 * 8, (size_t)S::W0_PART * 8, e, w * SW);
+        store2<NP>(e16 + (size_t)S::W0 * 8, (size_t)S::W0_PART * 8, e, w * SW);
     }
     for (int e = threadIdx.x; e < NT * NT * 2 * 2 * 32 * 8; e += NTHR) {
         const int j = e & 7, c = (e >> 3) & 31, hf = (e >> 8) & 1, s = (e >> 9) & 1, kt = (e >> 10) % NT, nt = (e >> 10) / NT;
         const int n = 32 * nt + c, k = 32 * kt + frag_k(s, hf, j);
-        store2(e16 + (size_t)S::W1 * 8, (size_t)S::W1_PART * 8, e, w1[n * H + k] * SW);
+        store2<NP>(e16 + (size_t)S::W1 * 8, (size_t)S::W1_PART * 8, e, w1[n * H + k] * SW);
     }
     for (int e = threadIdx.x; S::W2_IN_LDS && e < 2 * NT * 2 * 2 * 32 * 8; e += NTHR) {
         const int j = e & 7, c = (e >> 3) & 31, hf = (e >> 8) & 1, s = (e >> 9) & 1, kt = (e >> 10) % NT, nt = (e >> 10) / NT;
         const int n = 32 * nt + c, k = 32 * kt + frag_k(s, hf, j);
-        store2(e16 + (size_t)S::W2 * 8, (size_t)S::W2_PART * 8, e, n < N2 ? w2[n * H + k] * SW : 0.0f);
+        store2<NP>(e16 + (size_t)S::W2 * 8, (size_t)S::W2_PART * 8, e, n < N2 ? w2[n * H + k] * SW : 0.0f);
     }
     float *tail = reinterpret_cast<float *>(smem + (size_t)S::END_U4 * 16);
     for (int e = threadIdx.x; e < H; e += NTHR) {
@@ -234,26 +249,32 @@ __device__ __forceinline__ void stage_weights_fwd(unsigned char *smem, const flo
 // third load of a part needs 16 lanes only (columns 32..35) -- the other lanes read on into what follows (the image is
 // allocated with 1 KB of slack for the very last one) and do not store
 struct PreX2 { u32x4 a0, a1, a2, b0, b1, b2; };
+template <int NP>
 __device__ __forceinline__ void fetch_x2(PreX2 &pre, const SrcX2 &src, int64_t tile, int tap, int lane)
 {
-    const unsigned char *tb = src.x2 + tile * X2_TILE_B + tap * X2_TAP_B + lane * 16;
+    const unsigned char *tb = src.x2 + tile * x2_tile_b<NP>() + tap * x2_tap_b<NP>() + lane * 16;
     pre.a0 = *reinterpret_cast<const u32x4 *>(tb);
     pre.a1 = *reinterpret_cast<const u32x4 *>(tb + 1024);
     pre.a2 = *reinterpret_cast<const u32x4 *>(tb + 2048);
-    pre.b0 = *reinterpret_cast<const u32x4 *>(tb + X2_PART_B);
-    pre.b1 = *reinterpret_cast<const u32x4 *>(tb + X2_PART_B + 1024);
-    pre.b2 = *reinterpret_cast<const u32x4 *>(tb + X2_PART_B + 2048);
+    if (NP == 2) {
+        pre.b0 = *reinterpret_cast<const u32x4 *>(tb + X2_PART_B);
+        pre.b1 = *reinterpret_cast<const u32x4 *>(tb + X2_PART_B + 1024);
+        pre.b2 = *reinterpret_cast<const u32x4 *>(tb + X2_PART_B + 2048);
+    }
 }
+template <int NP>
 __device__ __forceinline__ void store_x2(unsigned char *img, const PreX2 &pre, int lane)
 {
     unsigned char *p = img + lane * 16;
     *reinterpret_cast<u32x4 *>(p) = pre.a0;
     *reinterpret_cast<u32x4 *>(p + 1024) = pre.a1;
-    *reinterpret_cast<u32x4 *>(p + XF_PART_B) = pre.b0;
-    *reinterpret_cast<u32x4 *>(p + XF_PART_B + 1024) = pre.b1;
+    if (NP == 2) {
+        *reinterpret_cast<u32x4 *>(p + XF_PART_B) = pre.b0;
+        *reinterpret_cast<u32x4 *>(p + XF_PART_B + 1024) = pre.b1;
+    }
     if (lane < 16) {
         *reinterpret_cast<u32x4 *>(p + 2048) = pre.a2;
-        *reinterpret_cast<u32x4 *>(p + XF_PART_B + 2048) = pre.b2;
+        if (NP == 2) *reinterpret_cast<u32x4 *>(p + XF_PART_B + 2048) = pre.b2;
     }
 }
 // B fragment of layer-1 k-step s (lane = row c, k = 16 s + 8 hf + j): block rows = columns 16 s + 8 hf + q (+ 4), block
@@ -263,16 +284,17 @@ __device__ __forceinline__ int lane_tr_fwd(int lane)
     const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3, h = g >> 1;
     return (8 * h + q) * XF_COL_B + (((16 * (g & 1) + 4 * p) * 2) ^ (32 * h));
 }
+template <int NP>
 __device__ __forceinline__ Frag2 x_frag_fwd(const unsigned char *img, int lctr, int s)
 {
     const unsigned char *a = img + s * (16 * XF_COL_B) + lctr;
     Frag2 f;
     f.h = tr128(a, 4 * XF_COL_B);
-    f.l = tr128(a + XF_PART_B, 4 * XF_COL_B);
+    f.l = NP == 2 ? tr128(a + XF_PART_B, 4 * XF_COL_B) : u32x4{0u, 0u, 0u, 0u};
     return f;
 }
 
-template <int H>
+template <int H, int NP>
 __global__ void __launch_bounds__(64 * fwd_waves<H>(), fwd_waves<H>() / 4)
 fwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__restrict__ b0, const float *__restrict__ w1,
               const float *__restrict__ b1, const float *__restrict__ w2, const float *__restrict__ b2, int N2,
@@ -280,15 +302,16 @@ fwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
 {
     const int64_t n_samples = src.S;
     const int K0 = 3 + 2 * src.n_levels;
-    using S = SmemF<H>;
+    using S = SmemF<H, NP>;
     constexpr int NT = S::NT;
+    constexpr int XF_IMG_B = xf_img_b<NP>();
     static_assert(XF_IMG_B >= 32 * LDFS * 4, "the feature transpose overlays the image");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 31, hf = lane >> 5;
     float *tail = reinterpret_cast<float *>(smem_b + (size_t)S::END_U4 * 16);
     unsigned char *img = smem_b + S::SHARED_BYTES + (size_t)wave * XF_IMG_B;
     float *Fs = reinterpret_cast<float *>(img);   // [32][LDFS] over the image, which is dead once the first layer has read it
-    stage_weights_fwd<H>(smem_b, w0, b0, w1, b1, w2, b2, K0, N2);
+    stage_weights_fwd<H, NP>(smem_b, w0, b0, w1, b1, w2, b2, K0, N2);
     for (int e = lane; e < XF_IMG_B / 4; e += 64) reinterpret_cast<unsigned *>(img)[e] = 0u;
     __syncthreads();
     const u32x4 *wl = reinterpret_cast<const u32x4 *>(smem_b);
@@ -298,15 +321,15 @@ fwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
     const int64_t n_groups = src.Sp / 32;
     const int64_t g_first = (int64_t)blockIdx.x * fwd_waves<H>() + wave, g_step = (int64_t)gridDim.x * fwd_waves<H>();
     PreX2 pre;
-    if (g_first < n_groups) fetch_x2(pre, src, g_first, 0, lane);
+    if (g_first < n_groups) fetch_x2<NP>(pre, src, g_first, 0, lane);
     for (int64_t g = g_first; g < n_groups; g += g_step) {
         const int64_t s0 = g * 32;
         for (int tap = 0; tap < 7; ++tap) {
-            store_x2(img, pre, lane);
+            store_x2<NP>(img, pre, lane);
             {   // prefetch the next tile of this wave
                 const int ntap = tap == 6 ? 0 : tap + 1;
                 const int64_t ng = tap == 6 ? g + g_step : g;
-                if (ng < n_groups) fetch_x2(pre, src, ng, ntap, lane);
+                if (ng < n_groups) fetch_x2<NP>(pre, src, ng, ntap, lane);
             }
             // ---- layer 1: C = T1 z1
             f32x16 h1[NT], h2[NT];
@@ -316,9 +339,9 @@ fwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
                 for (int r = 0; r < 16; ++r) h1[t][r] = 0.0f;
 #pragma unroll
             for (int s = 0; s < KS0; ++s) {
-                const Frag2 xb = x_frag_fwd(img, lctr, s);
+                const Frag2 xb = x_frag_fwd<NP>(img, lctr, s);
 #pragma unroll
-                for (int t = 0; t < NT; ++t) h1[t] = mma3<S::W0_PART>(wl + S::W0 + ((t * KS0 + s) * 2 + hf) * 32 + c, xb, h1[t]);
+                for (int t = 0; t < NT; ++t) h1[t] = mma3<S::W0_PART, NP>(wl + S::W0 + ((t * KS0 + s) * 2 + hf) * 32 + c, xb, h1[t]);
             }
 #pragma unroll
             for (int t = 0; t < NT; ++t)
@@ -336,11 +359,11 @@ fwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
             for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    const Frag2 hb = split2_frag(h1[kt][8 * s], h1[kt][8 * s + 1], h1[kt][8 * s + 2], h1[kt][8 * s + 3],
+                    const Frag2 hb = split2_frag<NP>(h1[kt][8 * s], h1[kt][8 * s + 1], h1[kt][8 * s + 2], h1[kt][8 * s + 3],
                                                  h1[kt][8 * s + 4], h1[kt][8 * s + 5], h1[kt][8 * s + 6], h1[kt][8 * s + 7]);
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
-                        h2[t] = mma3<S::W1_PART>(wl + S::W1 + (((t * NT + kt) * 2 + s) * 2 + hf) * 32 + c, hb, h2[t]);
+                        h2[t] = mma3<S::W1_PART, NP>(wl + S::W1 + (((t * NT + kt) * 2 + s) * 2 + hf) * 32 + c, hb, h2[t]);
                 }
 #pragma unroll
             for (int t = 0; t < NT; ++t)
@@ -384,12 +407,12 @@ fwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
                 for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
                     for (int ss = 0; ss < 2; ++ss) {
-                        const Frag2 hb = split2_frag(h2[kt][8 * ss], h2[kt][8 * ss + 1], h2[kt][8 * ss + 2], h2[kt][8 * ss + 3],
+                        const Frag2 hb = split2_frag<NP>(h2[kt][8 * ss], h2[kt][8 * ss + 1], h2[kt][8 * ss + 2], h2[kt][8 * ss + 3],
                                                      h2[kt][8 * ss + 4], h2[kt][8 * ss + 5], h2[kt][8 * ss + 6], h2[kt][8 * ss + 7]);
 #pragma unroll
                         for (int t = 0; t < 2; ++t)
                             if (t * 32 < N2)
-                                o[t] = mma3<S::W2_PART>(wl + S::W2 + (((t * NT + kt) * 2 + ss) * 2 + hf) * 32 + c, hb, o[t]);
+                                o[t] = mma3<S::W2_PART, NP>(wl + S::W2 + (((t * NT + kt) * 2 + ss) * 2 + hf) * 32 + c, hb, o[t]);
                     }
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
@@ -420,15 +443,15 @@ fwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
 constexpr int QCS = 512;               // chunk: 32 rows x 16 B
 constexpr int QX_PART = 64 * 64;       // X image part: 64 columns x 64 B (columns 36..63 constant zero)
 
-template <int NW>
+template <int NW, int NP>
 struct QL {
     static constexpr int H = 16 * NW;
     static constexpr int H_PART = (H / 8) * QCS;                  // activation image part
     static constexpr int XI = 0;                                  // two X images (tile parity)
-    static constexpr int H1I = XI + 2 * 2 * QX_PART;
-    static constexpr int DZI = H1I + 2 * H_PART;                  // dz2
-    static constexpr int DZ1 = DZI + 2 * H_PART;                  // dz1 in an image of its own (no barrier between the last
-    static constexpr int RED = DZ1 + 2 * H_PART;                  //   read of dz2 and the write of dz1); 8 floats of scratch
+    static constexpr int H1I = XI + 2 * NP * QX_PART;
+    static constexpr int DZI = H1I + NP * H_PART;                 // dz2
+    static constexpr int DZ1 = DZI + NP * H_PART;                 // dz1 in an image of its own (no barrier between the last
+    static constexpr int RED = DZ1 + NP * H_PART;                 //   read of dz2 and the write of dz1); 8 floats of scratch
     static constexpr int END = RED + 32;
 };
 
@@ -459,18 +482,18 @@ __device__ __forceinline__ LaneQ lane_consts(int w, int lane)
     return c;
 }
 // B fragment of a layer product: lane (k-group g, sample row 16 rh + c16) reads features 32 kb + 8 g .. + 7
-template <int PART>
+template <int PART, int NP>
 __device__ __forceinline__ Frag2 rowq(const unsigned char *img, int kb, int rh, const LaneQ &c)
 {
     const unsigned char *p = img + c.row + kb * (4 * QCS) + rh * 256;
     Frag2 f;
     f.h = ld128(p);
-    f.l = ld128(p + PART);
+    f.l = NP == 2 ? ld128(p + PART) : u32x4{0u, 0u, 0u, 0u};
     return f;
 }
 // fragment whose k dimension is the tile's 32 ROWS: lane (rows 8 g .. 8 g + 7, column 16 ft + c16); A operand (A[i = column]
 // [k = row]) and B operand (B[k = row][j = column]) of the weight-gradient products
-template <int PART>
+template <int PART, int NP>
 __device__ __forceinline__ Frag2 trfq(const unsigned char *img, int ft, const LaneQ &c)
 {
     const unsigned char *a0 = img + c.tr0 + ft * (2 * QCS), *a1 = img + c.tr1 + ft * (2 * QCS);
@@ -479,36 +502,42 @@ __device__ __forceinline__ Frag2 trfq(const unsigned char *img, int ft, const La
     tr64(a0, x0, x1);
     tr64(a1, y0, y1);
     f.h = u32x4{x0, x1, y0, y1};
-    tr64(a0 + PART, x0, x1);
-    tr64(a1 + PART, y0, y1);
-    f.l = u32x4{x0, x1, y0, y1};
+    if (NP == 2) {
+        tr64(a0 + PART, x0, x1);
+        tr64(a1 + PART, y0, y1);
+        f.l = u32x4{x0, x1, y0, y1};
+    } else {
+        f.l = u32x4{0u, 0u, 0u, 0u};
+    }
     return f;
 }
 // this wave's 16 x 16 result (features 16 w + 4 g + r, sample row 16 rh + c16), already scaled -> split once -> image
-template <int PART>
+template <int PART, int NP>
 __device__ __forceinline__ void store_q(unsigned char *img, int rh, const LaneQ &c, const f32x4 &v)
 {
     unsigned h0, l0, h1, l1;
-    split2_pair(v[0], v[1], h0, l0);
-    split2_pair(v[2], v[3], h1, l1);
+    split2_pair<NP>(v[0], v[1], h0, l0);
+    split2_pair<NP>(v[2], v[3], h1, l1);
     unsigned char *p = img + c.st + rh * 256;
     *reinterpret_cast<uint2 *>(p) = uint2{h0, h1};
-    *reinterpret_cast<uint2 *>(p + PART) = uint2{l0, l1};
+    if (NP == 2) *reinterpret_cast<uint2 *>(p + PART) = uint2{l0, l1};
 }
+template <int NP>
 __device__ __forceinline__ Frag2 x_col(const unsigned char *xi, int kb, int rh, const LaneQ &c)
 {
     const unsigned char *a = xi + c.xtr[rh] + kb * (32 * 64);
     Frag2 f;
     f.h = tr128(a, 4 * 64);
-    f.l = tr128(a + QX_PART, 4 * 64);
+    f.l = NP == 2 ? tr128(a + QX_PART, 4 * 64) : u32x4{0u, 0u, 0u, 0u};
     return f;
 }
+template <int NP>
 __device__ __forceinline__ Frag2 x_rows(const unsigned char *xi, int ct, const LaneQ &c)
 {
     const unsigned char *a = xi + c.xrow + ct * (16 * 64);
     Frag2 f;
     f.h = ld128(a);
-    f.l = ld128(a + QX_PART);
+    f.l = NP == 2 ? ld128(a + QX_PART) : u32x4{0u, 0u, 0u, 0u};
     return f;
 }
 __device__ __forceinline__ void wait_vm0() { __builtin_amdgcn_s_waitcnt(0x0F70); }      // s_waitcnt vmcnt(0)
@@ -529,16 +558,12 @@ __device__ __forceinline__ void dma_one(unsigned char *img, const unsigned char 
     if (b < 2) __builtin_amdgcn_global_load_lds((glob_void *)gp, (lds_void *)dst, 16, 0, 0);
     else if (lane < 16) __builtin_amdgcn_global_load_lds((glob_void *)gp, (lds_void *)dst, 16, 0, 0);
 }
-template <int NW>
+template <int NW, int NP>
 __device__ __forceinline__ void dma_tile(unsigned char *img, const SrcX2 &src, int64_t tile, int tap, int ws, int lane)
 {
-    const unsigned char *tb = src.x2 + tile * X2_TILE_B + tap * X2_TAP_B;
-    if (NW == 4) {
-        dma_one(img, tb, ws, lane);
-        if (ws < 2) dma_one(img, tb, ws + 4, lane);
-    } else if (ws < 6) {
-        dma_one(img, tb, ws, lane);
-    }
+    const unsigned char *tb = src.x2 + tile * x2_tile_b<NP>() + tap * x2_tap_b<NP>();
+    if (ws < 3 * NP) dma_one(img, tb, ws, lane);
+    if (NW == 4 && NP == 2 && ws < 2) dma_one(img, tb, ws + 4, lane);
 }
 // 2^e with |v| 2^e < 2^14 for every |v| <= bound (bound = 0, inf or nan: 1)
 __device__ __forceinline__ float grad_scale(float bound)
@@ -551,7 +576,7 @@ __device__ __forceinline__ float grad_scale(float bound)
 
 // NW = 4 (H = 64): two workgroups per CU.  NW = 8 (H = 128): one workgroup of eight waves per CU; the four 16 x 16
 // sub-tiles of d(hash features) go to waves 0..3.
-template <int NW>
+template <int NW, int NP>
 __global__ void __launch_bounds__(64 * NW, NW == 4 ? RSDF_X2_BWD_OCC : 1)
 bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__restrict__ b0, const float *__restrict__ w1,
               const float *__restrict__ b1, const float *__restrict__ w2, const float *__restrict__ d_sdf7,
@@ -559,7 +584,7 @@ bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
               float *__restrict__ d_planes, float *__restrict__ dw0, float *__restrict__ db0, float *__restrict__ dw1,
               float *__restrict__ db1, float *__restrict__ dw2, float *__restrict__ db2)
 {
-    using L = QL<NW>;
+    using L = QL<NW, NP>;
     constexpr int H = L::H, KB = H / 32, HP = L::H_PART, NTHR = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *s_red = reinterpret_cast<float *>(smem + L::RED);
@@ -596,14 +621,14 @@ bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
         const float *p = w1 + (size_t)fw * H + 32 * kb + 8 * g;
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = p[j] * SW;
-        w1f[kb] = split2_frag(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);                                                   // W1[fw][k]
+        w1f[kb] = split2_frag<NP>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);                                                   // W1[fw][k]
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = w1[(size_t)(32 * kb + 8 * g + j) * H + fw] * SW;
-        w1t[kb] = split2_frag(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);                                                   // W1[n][fw]
+        w1t[kb] = split2_frag<NP>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);                                                   // W1[n][fw]
         const int col = 16 * mt + c16;                                              // hash column of the dx sub-tile
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = col < 2 * src.n_levels ? w0[(size_t)(32 * kb + 8 * g + j) * K0 + 3 + col] * SW : 0.0f;
-        w0t[kb] = split2_frag(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);                                                   // W0[n][3 + col]
+        w0t[kb] = split2_frag<NP>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);                                                   // W0[n][3 + col]
     }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -617,7 +642,7 @@ bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
             else if (k == 35) x = b0[fw];
             v[j] = x * SW;
         }
-        w0f[kb] = split2_frag(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+        w0f[kb] = split2_frag<NP>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
     }
     f32x4 b1r, w2r;                                // bias of layer 2 (x T2) / row 0 of W2 for features 16 w + 4 g + r
 #pragma unroll
@@ -636,12 +661,12 @@ bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
     const float k_dz1 = G1 / (SW * G2), k_dx = 1.0f / (SW * G1);
 
     const int64_t n_groups = src.Sp / 32;
-    if ((int64_t)blockIdx.x < n_groups) dma_tile<NW>(smem + L::XI, src, (int64_t)blockIdx.x, 0, ws, lane);
+    if ((int64_t)blockIdx.x < n_groups) dma_tile<NW, NP>(smem + L::XI, src, (int64_t)blockIdx.x, 0, ws, lane);
     int parity = 0;
     for (int64_t gi = blockIdx.x; gi < n_groups; gi += gridDim.x) {
         const int64_t s0 = gi * 32;
         for (int tap = 0; tap < 7; ++tap) {
-            const unsigned char *xi = smem + L::XI + parity * 2 * QX_PART;
+            const unsigned char *xi = smem + L::XI + parity * NP * QX_PART;
             wait_vm0();                            // this wave's share of the tile has landed (and the previous tile's stores retired)
             // every wave's share has landed once all have passed their wait; the OTHER image is free once all have finished
             // the previous tile's dW0 reads: one barrier serves both
@@ -666,18 +691,18 @@ bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
             {
                 const int ntap = tap == 6 ? 0 : tap + 1;
                 const int64_t ng = tap == 6 ? gi + gridDim.x : gi;
-                if (ng < n_groups) dma_tile<NW>(smem + L::XI + parity * 2 * QX_PART, src, ng, ntap, ws, lane);
+                if (ng < n_groups) dma_tile<NW, NP>(smem + L::XI + parity * NP * QX_PART, src, ng, ntap, ws, lane);
             }
             // ---- recompute layer 1 (C = T1 z1) -> SH h1
             f32x4 h1[2], h2[2];
 #pragma unroll
             for (int rh = 0; rh < 2; ++rh) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                acc = mma3q(w0f[0], x_col(xi, 0, rh, lc), acc);
-                acc = mma3q(w0f[1], x_col(xi, 1, rh, lc), acc);
+                acc = mma3q<NP>(w0f[0], x_col<NP>(xi, 0, rh, lc), acc);
+                acc = mma3q<NP>(w0f[1], x_col<NP>(xi, 1, rh, lc), acc);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) h1[rh][r] = softplus_scaled<1>(acc[r]);
-                store_q<HP>(smem + L::H1I, rh, lc, h1[rh]);
+                store_q<HP, NP>(smem + L::H1I, rh, lc, h1[rh]);
             }
             lds_barrier();                                                       // (2) H1 image complete
             // ---- recompute layer 2 (C = T2 z2), then layer 3 backward: dz2 = (W2[0,:] d_sdf + feature part) sigma'(z2)
@@ -685,7 +710,7 @@ bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
             for (int rh = 0; rh < 2; ++rh) {
                 f32x4 acc = b1r;
 #pragma unroll
-                for (int kb = 0; kb < KB; ++kb) acc = mma3q(w1f[kb], rowq<HP>(smem + L::H1I, kb, rh, lc), acc);
+                for (int kb = 0; kb < KB; ++kb) acc = mma3q<NP>(w1f[kb], rowq<HP, NP>(smem + L::H1I, kb, rh, lc), acc);
                 const float dsdf = row_ok[rh] ? dsdf_raw[rh] : 0.0f;
                 if (w == 0 && g == 0) gb2 += dsdf;
                 f32x4 dzs;
@@ -697,7 +722,7 @@ bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
                     gb1p[r] += dz[rh][r];
                     dzs[r] = dz[rh][r] * G2;
                 }
-                store_q<HP>(smem + L::DZI, rh, lc, dzs);
+                store_q<HP, NP>(smem + L::DZI, rh, lc, dzs);
             }
             lds_barrier();                                                       // (3) dz2 image complete
             // ---- layer 2 backward: G1 dz1[own k1] = (W1^T dz2) sigma'(z1) ; dW1[own n][all k] += dz2^T h1 (K = the 32 rows)
@@ -705,23 +730,23 @@ bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
             for (int rh = 0; rh < 2; ++rh) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int kb = 0; kb < KB; ++kb) acc = mma3q(w1t[kb], rowq<HP>(smem + L::DZI, kb, rh, lc), acc);
+                for (int kb = 0; kb < KB; ++kb) acc = mma3q<NP>(w1t[kb], rowq<HP, NP>(smem + L::DZI, kb, rh, lc), acc);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dz[rh][r] = acc[r] * k_dz1 * softplus_grad_scaled(h1[rh][r]);
             }
             {
-                const Frag2 a = trfq<HP>(smem + L::DZI, w, lc);
+                const Frag2 a = trfq<HP, NP>(smem + L::DZI, w, lc);
 #pragma unroll
-                for (int n = 0; n < H / 16; ++n) gw1[n] = mma3q(a, trfq<HP>(smem + L::H1I, n, lc), gw1[n]);   // x G2 SH
+                for (int n = 0; n < H / 16; ++n) gw1[n] = mma3q<NP>(a, trfq<HP, NP>(smem + L::H1I, n, lc), gw1[n]);   // x G2 SH
             }
-            store_q<HP>(smem + L::DZ1, 0, lc, dz[0]);
-            store_q<HP>(smem + L::DZ1, 1, lc, dz[1]);
+            store_q<HP, NP>(smem + L::DZ1, 0, lc, dz[0]);
+            store_q<HP, NP>(smem + L::DZ1, 1, lc, dz[1]);
             lds_barrier();                                                       // (4) dz1 image complete
             // ---- layer 1 backward: d(hash features) sub-tile (16 columns x 16 rows, all 64 features); dW0 += dz1^T X
             if (NW == 4 || ws < 4) {
                 f32x4 dx = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int kb = 0; kb < KB; ++kb) dx = mma3q(w0t[kb], rowq<HP>(smem + L::DZ1, kb, rhx, lc), dx);
+                for (int kb = 0; kb < KB; ++kb) dx = mma3q<NP>(w0t[kb], rowq<HP, NP>(smem + L::DZ1, kb, rhx, lc), dx);
                 // result rows = hash columns 16 mt + 4 g + r = (level 8 mt + 2 g + (r >> 1), feature r & 1); lane column =
                 // sample row 16 rhx + c16: two float2 stores, 16 lanes cover 128 contiguous bytes of a level plane
                 const int64_t row = s0 + 16 * rhx + c16;
@@ -734,9 +759,9 @@ bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
                 }
             }
             {
-                const Frag2 a = trfq<HP>(smem + L::DZ1, w, lc);
+                const Frag2 a = trfq<HP, NP>(smem + L::DZ1, w, lc);
 #pragma unroll
-                for (int ct = 0; ct < 3; ++ct) gw0[ct] = mma3q(a, x_rows(xi, ct, lc), gw0[ct]);           // x G1 SX
+                for (int ct = 0; ct < 3; ++ct) gw0[ct] = mma3q<NP>(a, x_rows<NP>(xi, ct, lc), gw0[ct]);           // x G1 SX
             }
             // no barrier: the next tile's barrier (1) separates these reads from the DMA that overwrites this X image, and
             // its H1 / dz2 / dz1 writes sit behind its barriers (1) .. (3)
@@ -798,7 +823,7 @@ int rsdf_sdfmlp_fd7_x2_supported(int K0, int H, int N2)
     return (K0 >= 5 && K0 <= 35 && (K0 - 3) % 2 == 0 && (H == 32 || H == 64 || H == 128) && N2 >= 1 && N2 <= 64) ? 1 : 0;
 }
 
-int rsdf_sdfmlp_fd7_fwd_x2(const void *x2, int n_levels, int H, int N2, const float *w0, const float *b0, const float *w1,
+int rsdf_sdfmlp_fd7_fwd_x2(const void *x2, int parts, int n_levels, int H, int N2, const float *w0, const float *b0, const float *w1,
                            const float *b1, const float *w2, const float *b2, int64_t n_samples, float *sdf7t, float *feature,
                            float *h2c, void *stream)
 {
@@ -806,6 +831,7 @@ int rsdf_sdfmlp_fd7_fwd_x2(const void *x2, int n_levels, int H, int N2, const fl
     RSDF_CHECK_ARG(n_levels >= 1 && n_levels <= 16, "sdfmlp_fd7_fwd_x2: n_levels must be in [1,16]");
     RSDF_CHECK_ARG(h2c == nullptr || feature != nullptr, "sdfmlp_fd7_fwd_x2: h2c needs feature");
     RSDF_CHECK_ARG(rsdf_sdfmlp_fd7_x2_supported(K0, H, N2), "sdfmlp_fd7_fwd_x2: unsupported layer sizes");
+    RSDF_CHECK_ARG(parts == 1 || parts == 2, "sdfmlp_fd7_fwd_x2: parts must be 1 or 2");
     if (n_samples <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const int64_t Sp = (n_samples + 31) / 32 * 32;
@@ -814,27 +840,30 @@ int rsdf_sdfmlp_fd7_fwd_x2(const void *x2, int n_levels, int H, int N2, const fl
         const int64_t want = (Sp / 32 + waves - 1) / waves;
         return (unsigned)(want < 512 ? want : 512);
     };
+#define RSDF_X2_FWD(HH, NPP)                                                                                                  \
+    do {                                                                                                                      \
+        if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(fwd_x2_kernel<HH, NPP>), fwd_lds<HH, NPP>())) return rc;     \
+        fwd_x2_kernel<HH, NPP><<<grid_of(fwd_waves<HH>()), 64 * fwd_waves<HH>(), fwd_lds<HH, NPP>(), st>>>(                    \
+            src, w0, b0, w1, b1, w2, b2, N2, sdf7t, feature, h2c);                                                            \
+    } while (0)
     if (H == 128) {
         // the feature rows of the last layer are one per-layer product on the centre rows' h2 (see SmemF)
         RSDF_CHECK_ARG(feature == nullptr || h2c != nullptr, "sdfmlp_fd7_fwd_x2: at H = 128 the feature output needs h2c");
-        if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(fwd_x2_kernel<128>), fwd_lds<128>())) return rc;
-        fwd_x2_kernel<128><<<grid_of(fwd_waves<128>()), 64 * fwd_waves<128>(), fwd_lds<128>(), st>>>(src, w0, b0, w1, b1, w2, b2, N2,
-                                                                                                   sdf7t, feature, h2c);
+        if (parts == 2) RSDF_X2_FWD(128, 2); else RSDF_X2_FWD(128, 1);
         if (hipGetLastError() != hipSuccess) { rsdf_set_error("sdfmlp_fd7_fwd_x2: launch failed"); return RSDF_EINVAL; }
         if (feature != nullptr) return rsdf_linear_fwd(h2c, H, w2, b2, n_samples, H, N2, RSDF_ACT_NONE, feature, N2, stream);
         return 0;
     }
     if (H == 64) {
-        if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(fwd_x2_kernel<64>), fwd_lds<64>())) return rc;
-        fwd_x2_kernel<64><<<grid_of(FWD_WAVES), FWD_THREADS, fwd_lds<64>(), st>>>(src, w0, b0, w1, b1, w2, b2, N2, sdf7t, feature, h2c);
+        if (parts == 2) RSDF_X2_FWD(64, 2); else RSDF_X2_FWD(64, 1);
     } else {
-        if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(fwd_x2_kernel<32>), fwd_lds<32>())) return rc;
-        fwd_x2_kernel<32><<<grid_of(FWD_WAVES), FWD_THREADS, fwd_lds<32>(), st>>>(src, w0, b0, w1, b1, w2, b2, N2, sdf7t, feature, h2c);
+        if (parts == 2) RSDF_X2_FWD(32, 2); else RSDF_X2_FWD(32, 1);
     }
+#undef RSDF_X2_FWD
     RSDF_RETURN_LAUNCH();
 }
 
-int rsdf_sdfmlp_fd7_bwd_x2(const void *x2, int n_levels, int n_active_levels, int H, int N2, const float *w0, const float *b0,
+int rsdf_sdfmlp_fd7_bwd_x2(const void *x2, int parts, int n_levels, int n_active_levels, int H, int N2, const float *w0, const float *b0,
                            const float *w1, const float *b1, const float *w2, const float *b2, int64_t n_samples,
                            const float *d_sdf7t, const float *d_feature, float *dh2c_scratch, void *absmax_scratch,
                            float *d_planes, float *dw0, float *db0, float *dw1, float *db1, float *dw2, float *db2, void *stream)
@@ -844,6 +873,7 @@ int rsdf_sdfmlp_fd7_bwd_x2(const void *x2, int n_levels, int n_active_levels, in
     RSDF_CHECK_ARG(n_levels >= 1 && n_levels <= 16, "sdfmlp_fd7_bwd_x2: n_levels must be in [1,16]");
     RSDF_CHECK_ARG((H == 64 || H == 128) && rsdf_sdfmlp_fd7_x2_supported(K0, H, N2), "sdfmlp_fd7_bwd_x2: unsupported layer sizes (H must be 64 or 128)");
     RSDF_CHECK_ARG(absmax_scratch != nullptr, "sdfmlp_fd7_bwd_x2: the 8-byte absmax scratch is required");
+    RSDF_CHECK_ARG(parts == 1 || parts == 2, "sdfmlp_fd7_bwd_x2: parts must be 1 or 2");
     if (n_samples <= 0) return 0;
     if (n_active_levels < 0 || n_active_levels > n_levels) n_active_levels = n_levels;
     hipStream_t st = (hipStream_t)stream;
@@ -861,16 +891,20 @@ int rsdf_sdfmlp_fd7_bwd_x2(const void *x2, int n_levels, int n_active_levels, in
     const SrcX2 src{reinterpret_cast<const unsigned char *>(x2), n_samples, Sp, n_levels, n_active_levels};
     const int64_t groups = Sp / 32;
     const float *dh = d_feature != nullptr ? dh2c_scratch : nullptr;
+#define RSDF_X2_BWD(NWW, NPP, GRID)                                                                                           \
+    do {                                                                                                                      \
+        if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(bwd_x2_kernel<NWW, NPP>), QL<NWW, NPP>::END)) return rc;     \
+        bwd_x2_kernel<NWW, NPP><<<(unsigned)(GRID), 64 * NWW, QL<NWW, NPP>::END, st>>>(                                        \
+            src, w0, b0, w1, b1, w2, d_sdf7t, dh, am, d_planes, dw0, db0, dw1, db1, dw2, db2);                                \
+    } while (0)
+    const int64_t max_wgs = 256 * RSDF_X2_BWD_OCC;                       // H = 64: RSDF_X2_BWD_OCC workgroups per CU
+    const int64_t g4 = groups < max_wgs ? groups : max_wgs, g8 = groups < 256 ? groups : 256;
     if (H == 64) {
-        if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(bwd_x2_kernel<4>), QL<4>::END)) return rc;
-        const int64_t max_wgs = 256 * RSDF_X2_BWD_OCC;                   // RSDF_X2_BWD_OCC workgroups per CU
-        bwd_x2_kernel<4><<<(unsigned)(groups < max_wgs ? groups : max_wgs), 256, QL<4>::END, st>>>(
-            src, w0, b0, w1, b1, w2, d_sdf7t, dh, am, d_planes, dw0, db0, dw1, db1, dw2, db2);
+        if (parts == 2) RSDF_X2_BWD(4, 2, g4); else RSDF_X2_BWD(4, 1, g4);
     } else {
-        if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(bwd_x2_kernel<8>), QL<8>::END)) return rc;
-        bwd_x2_kernel<8><<<(unsigned)(groups < 256 ? groups : 256), 512, QL<8>::END, st>>>(
-            src, w0, b0, w1, b1, w2, d_sdf7t, dh, am, d_planes, dw0, db0, dw1, db1, dw2, db2);
+        if (parts == 2) RSDF_X2_BWD(8, 2, g8); else RSDF_X2_BWD(8, 1, g8);
     }
+#undef RSDF_X2_BWD
     RSDF_RETURN_LAUNCH();
 }
 

@@ -37,11 +37,22 @@ def supported(K0: int, H: int, N2: int, n_hidden_layers: int, hidden_act: str, o
             and bool(lib().rsdf_sdfmlp_fd7_supported(int(K0), int(H), int(N2))))
 
 
+def x2_parts(K0: int, H: int, N2: int, precision: str) -> int:
+    """0: the round-3 kernels on fp32 planes.  2: the two-part fp16 form with the pre-split input image (H = 64 and 128 in
+    fp32: forward + quad backward).  1: the same kernels with ONE fp16 part -- precision 'fp16', the 16-bit mode of this
+    node (``precision: fp16`` in the SDF network's config; the per-layer kernels of such a network use the bf16 build)."""
+    if H not in (64, 128) or not bool(lib().rsdf_sdfmlp_fd7_x2_supported(int(K0), int(H), int(N2))):
+        return 0
+    if precision == "fp16":
+        return 1
+    if (precision == "fp32" and os.environ.get("RSDF_X2", "1") != "0" and os.environ.get("RSDF_MLP_FWD", "") != "coop"
+            and os.environ.get("RSDF_MLP_BWD", "") == ""):
+        return 2
+    return 0
+
+
 def use_x2(K0: int, H: int, N2: int, precision: str) -> bool:
-    """The two-part fp16 form with the pre-split input image serves H = 64 and 128 in fp32 (forward + quad backward)."""
-    return (precision == "fp32" and H in (64, 128) and os.environ.get("RSDF_X2", "1") != "0"
-            and os.environ.get("RSDF_MLP_FWD", "") != "coop" and os.environ.get("RSDF_MLP_BWD", "") == ""
-            and bool(lib().rsdf_sdfmlp_fd7_x2_supported(int(K0), int(H), int(N2))))
+    return x2_parts(K0, H, N2, precision) > 0
 
 
 class _SdfFieldFD7(torch.autograd.Function):
@@ -64,11 +75,15 @@ class _SdfFieldFD7(torch.autograd.Function):
             pts = points.detach().to(torch.float32).contiguous()
             require_device(pts)
             assert pts.shape == (S, 3), "points must be [S,3]"
-        if S > 0 and use_x2(3 + 2 * Lv, H, N2, precision):
-            x2 = torch.empty(int(lib().rsdf_x2_bytes(S)), dtype=torch.uint8, device=dev)
+        parts = x2_parts(3 + 2 * Lv, H, N2, precision) if S > 0 else 0
+        if precision == "fp16" and S > 0 and not parts:
+            raise L.RiseSdfHipError("precision 'fp16' of the fused SDF field needs H = 64 or 128")
+        if parts:
+            x2 = torch.empty(int(lib().rsdf_x2_bytes(S, parts)), dtype=torch.uint8, device=dev)
             check(lib().rsdf_hashgrid_fwd_fd7_x2(None if pts is not None else ptr(xf), ptr(pts), float(radius or 0.0),
                                                  float(eps or 0.0), ptr(tb), ctypes.byref(meta), S, n_active,
-                                                 float(xyz_scale), float(xyz_offset), ptr(x2), st), "hashgrid_fwd_fd7_x2")
+                                                 float(xyz_scale), float(xyz_offset), parts, ptr(x2), st),
+                  "hashgrid_fwd_fd7_x2")
             planes = x2
         else:
             planes = torch.empty(Lv, 7, S, 2, dtype=torch.float32, device=dev)
@@ -86,13 +101,13 @@ class _SdfFieldFD7(torch.autograd.Function):
         feature = torch.empty(S, N2, dtype=torch.float32, device=dev) if want_feature else None
         h2c = torch.empty(S, H, dtype=torch.float32, device=dev) if want_feature else None
         if x2 is not None:
-            check(lib().rsdf_sdfmlp_fd7_fwd_x2(ptr(x2), Lv, H, N2, *[ptr(t) for t in ws], S, ptr(sdf7t), ptr(feature),
+            check(lib().rsdf_sdfmlp_fd7_fwd_x2(ptr(x2), parts, Lv, H, N2, *[ptr(t) for t in ws], S, ptr(sdf7t), ptr(feature),
                                                ptr(h2c), st), "sdfmlp_fd7_fwd_x2")
         else:
             check(L.mlp_fn("rsdf_sdfmlp_fd7_fwd", precision)(ptr(xf), ptr(planes), Lv, n_active, float(xyz_scale),
                                             float(xyz_offset), H, N2, *[ptr(t) for t in ws], S, ptr(sdf7t),
                                             ptr(feature), ptr(h2c), st), "sdfmlp_fd7_fwd")
-        ctx.x2 = x2 is not None
+        ctx.x2 = parts
         ctx.save_for_backward(xf, planes, *ws)
         ctx.h2c = h2c
         ctx.pts, ctx.radius, ctx.eps, ctx.precision = pts, radius, eps, precision
@@ -121,7 +136,7 @@ class _SdfFieldFD7(torch.autograd.Function):
         dh2c = torch.empty(S, H, dtype=torch.float32, device=dev) if gf is not None else None
         if ctx.x2:
             absmax = torch.empty(2, dtype=torch.int32, device=dev)
-            check(lib().rsdf_sdfmlp_fd7_bwd_x2(ptr(planes), Lv, ctx.n_active, H, N2, ptr(w0), ptr(b0), ptr(w1), ptr(b1),
+            check(lib().rsdf_sdfmlp_fd7_bwd_x2(ptr(planes), ctx.x2, Lv, ctx.n_active, H, N2, ptr(w0), ptr(b0), ptr(w1), ptr(b1),
                                                ptr(w2), ptr(b2), S, ptr(g), ptr(gf), ptr(dh2c), ptr(absmax), ptr(d_planes),
                                                ptr(dw0), ptr(db0), ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), st),
                   "sdfmlp_fd7_bwd_x2")
@@ -132,7 +147,7 @@ class _SdfFieldFD7(torch.autograd.Function):
                                             ptr(db1), ptr(dw2), ptr(db2), st), "sdfmlp_fd7_bwd")
         if gf is not None:
             # feature rows of the last layer: dW2 += d_feature^T h2(centre), db2 += colsum(d_feature)
-            check(L.mlp_fn("rsdf_linear_bwd_weight", ctx.precision)(ptr(gf), N2, ptr(ctx.h2c), H, S, H, N2, ptr(dw2),
+            check(L.mlp_fn("rsdf_linear_bwd_weight", "fp32" if ctx.x2 else ctx.precision)(ptr(gf), N2, ptr(ctx.h2c), H, S, H, N2, ptr(dw2),
                                                                     ptr(db2), st),
                   "linear_bwd_weight (feature rows)")
         dt = None

@@ -122,8 +122,8 @@ class VanillaMLP(nn.Module):
         # per-network opt-in key of the network's config node that the reference's yaml simply does not carry
         self._wn_cache = {}     # id(layer) -> ((versions, pointers), W, has_graph): see _normed_weight
         self.precision = str(config.get("precision", "fp32")).lower()
-        if self.precision not in ("fp32", "bf16"):
-            raise ValueError(f"VanillaMLP precision {self.precision!r}: fp32 or bf16")
+        if self.precision not in ("fp32", "bf16", "fp16"):
+            raise ValueError(f"VanillaMLP precision {self.precision!r}: fp32, bf16 or fp16")
         layers = [self.make_linear(dim_in, self.n_neurons, True, False), self.make_activation()]
         for _ in range(self.n_hidden_layers - 1):
             layers += [self.make_linear(self.n_neurons, self.n_neurons, False, False),

@@ -52,10 +52,10 @@ def main():
     st = _lib.stream_ptr()
     P = _lib.ptr
     L = _lib.lib()
-    x2 = torch.empty(int(L.rsdf_x2_bytes(S)), dtype=torch.uint8, device=dev)
+    x2 = torch.empty(int(L.rsdf_x2_bytes(S, 2)), dtype=torch.uint8, device=dev)
     calls = {
         "fwd_x2": lambda: L.rsdf_hashgrid_fwd_fd7_x2(None, P(pts), radius, eps, P(table), ctypes.byref(meta), S, Lv, 2.0, -1.0,
-                                                     P(x2), st),
+                                                     2, P(x2), st),
         "fwd_x7t": lambda: L.rsdf_hashgrid_fwd_fd7(P(x7t), P(table), ctypes.byref(meta), S, Lv, P(planes), st),
         "fwd_pts": lambda: L.rsdf_hashgrid_fwd_fd7_pts(P(pts), radius, eps, P(table), ctypes.byref(meta), S, Lv,
                                                        P(planes), st),
