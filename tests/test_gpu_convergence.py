@@ -33,7 +33,7 @@ def _model(dev, precision, sdf_precision=None):
     """``precision``: the radiance networks'; ``sdf_precision``: the SDF network's (default: the same)."""
     import rise_sdf_amd as R
     torch.manual_seed(0)
-    cfg = split_config(hidden=32, n_levels=6, feat=13, indirect=False)
+    cfg = split_config(hidden=64, n_levels=6, feat=13, indirect=False)      # (H = 64: the shipped x2 kernels, csrc/mlp_x2.hip)
     cfg["curvature"] = False
     cfg["num_samples_per_ray"] = 160
     cfg["geometry"]["mlp_network_config"]["precision"] = sdf_precision or precision
@@ -129,10 +129,10 @@ def _train_oracle(model0, batches, heldout, sgd=False):
     return losses, _psnr(torch.cat(preds), heldout[1].cpu())
 
 
-def _data(dev):
+def _data(dev, seed=11):
     from rise_sdf_amd.synthetic import make_dataset
     ds = make_dataset(n_views=6, W=64, H=64, seed=3, device=dev)
-    batches = _batches(dev, ds, STEPS, N_RAYS, seed=11)
+    batches = _batches(dev, ds, STEPS, N_RAYS, seed=seed)
     held = _batches(dev, ds, 1, 4096, seed=99)[0]
     return batches, (held[0], held[1])
 
@@ -151,21 +151,32 @@ def test_training_steps_match_the_oracle_step_by_step(dev):
         assert lo[-1] != lo[0]
 
 
-def test_convergence_proxy_fp32_bf16_and_oracle(dev):
-    """The statistical part.  Training is chaotic: two runs of the SAME HIP code differ in the last bits of the scatter
-    kernels' atomic sums and end 0.1-0.3 dB apart, so the configs[4] gate's 0.05 dB cannot be resolved by single runs of a
-    proxy this small; what is asserted is that every implementation ends inside that measured spread.  Measured on one
-    MI355X ("Convergence proxy"): HIP fp32 and the oracle within the run-to-run spread; bf16 radiance networks
-    indistinguishable from fp32; a bf16 SDF network costs 0.5-1 dB here, because the finite-difference normal divides
-    a difference of bf16-perturbed SDF values by eps -- which is why the SDF network's precision is a separate key."""
-    batches, heldout = _data(dev)
-    runs = {"hip fp32": [_train_hip(dev, "fp32", batches, heldout)[1] for _ in range(2)],
-            "hip bf16 radiance nets": [_train_hip(dev, "bf16", batches, heldout, sdf_precision="fp32")[1] for _ in range(2)],
-            "hip bf16 all nets": [_train_hip(dev, "bf16", batches, heldout)[1]],
-            "oracle fp32": [_train_oracle(_model(dev, "fp32"), batches, heldout)[1]]}
+def test_convergence_proxy_fp32_16bit_and_oracle(dev):
+    """The statistical part.  Training is chaotic: two runs of the SAME HIP code differ in the last
+    bits of the scatter kernels' atomic sums and end 0.1-0.3 dB apart, so the configs[4] gate's 0.05 dB cannot be resolved by
+    single runs of a proxy this small.  FOUR runs per arm (four batch / jitter seeds, the same four for every arm), compared
+    on the MEAN held-out PSNR with the spread printed:
+      * HIP fp32 (the x2 kernels) against the oracle (one CPU run, seed 0): inside the spread;
+      * 16-bit radiance networks (bf16) with an fp32 SDF network: within 0.15 dB of fp32;
+      * ALL networks 16-bit -- radiance bf16, SDF network precision 'fp16' (one fp16 part: 11 significant bits, so that the
+        finite-difference normal survives; the bf16 SDF network of round 3 cost 0.5-1 dB here): within 0.2 dB of fp32."""
+    seeds = (11, 12, 13, 14)
+    runs = {"hip fp32": [], "hip bf16 radiance nets": [], "hip 16-bit all nets (fp16 SDF)": [], "hip bf16 all nets": []}
+    for i, sd in enumerate(seeds):
+        batches, heldout = _data(dev, sd)
+        runs["hip fp32"].append(_train_hip(dev, "fp32", batches, heldout)[1])
+        runs["hip bf16 radiance nets"].append(_train_hip(dev, "bf16", batches, heldout, sdf_precision="fp32")[1])
+        runs["hip 16-bit all nets (fp16 SDF)"].append(_train_hip(dev, "bf16", batches, heldout, sdf_precision="fp16")[1])
+        if i < 2:
+            runs["hip bf16 all nets"].append(_train_hip(dev, "bf16", batches, heldout)[1])
+        if i == 0:
+            runs["oracle fp32"] = [_train_oracle(_model(dev, "fp32"), batches, heldout)[1]]
     mean = {k: sum(v) / len(v) for k, v in runs.items()}
-    print("held-out PSNR after %d steps: " % STEPS + "; ".join("%s %s" % (k, ["%.2f" % p for p in v]) for k, v in runs.items()))
-    assert min(mean.values()) > 30.0, mean                                   # everything trains
-    assert abs(mean["hip fp32"] - mean["oracle fp32"]) < 0.35, mean         # inside the run-to-run spread
-    assert abs(mean["hip bf16 radiance nets"] - mean["hip fp32"]) < 0.35, mean
-    assert mean["hip bf16 all nets"] > mean["hip fp32"] - 2.0, mean
+    spread = {k: max(v) - min(v) for k, v in runs.items()}
+    print("held-out PSNR after %d steps: " % STEPS + "; ".join(
+        "%s %s (mean %.2f, spread %.2f)" % (k, ["%.2f" % p for p in v], mean[k], spread[k]) for k, v in runs.items()))
+    assert min(mean.values()) > 29.0, mean                                              # everything trains
+    assert abs(runs["hip fp32"][0] - runs["oracle fp32"][0]) < 0.35, runs               # same seed: inside the run-to-run spread
+    assert abs(mean["hip bf16 radiance nets"] - mean["hip fp32"]) < 0.15, mean
+    assert abs(mean["hip 16-bit all nets (fp16 SDF)"] - mean["hip fp32"]) < 0.2, mean
+    assert mean["hip bf16 all nets"] > sum(runs["hip fp32"][:2]) / 2 - 2.5, mean

@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_x2.py -q -s -x 2>&1 | tail -6
+mkdir -p gpurun_out/r04c
+timeout 1500 python -m pytest tests/test_gpu_convergence.py -q -s -x 2>&1 | grep -E "held-out|SGD|Adam|passed|failed" | tee gpurun_out/r04c/convergence.log
