@@ -461,12 +461,14 @@ __device__ __forceinline__ void fd7_fwd_sample(const TapSrc &src, const float2 *
 template <bool DERIVE, bool X3>
 __global__ void __launch_bounds__(F_THREADS, X3 ? RSDF_X2_WAVES : RSDF_FWD_WAVES)
 fd7_fwd_kernel(const TapSrc src, const float *__restrict__ table,
-               const rsdf_grid_meta meta, int64_t S, int n_active, float2 *__restrict__ planes, const X2Out x3)
+               const rsdf_grid_meta meta, int64_t S, int n_active, float2 *__restrict__ planes, const X2Out x3, int group)
 {
-    const int64_t per_group = (int64_t)RSDF_FWD_GROUP * n_active;
+    // group = min(RSDF_FWD_GROUP, tiles of the launch): a training step's 250 k samples are 1 k tiles, and a grid padded to
+    // 4096 tiles x 16 levels spent 1.3 ms per step dispatching empty workgroups
+    const int64_t per_group = (int64_t)group * n_active;
     const int64_t grp = blockIdx.x / per_group, r = blockIdx.x - grp * per_group;
-    const int l = (int)(r / RSDF_FWD_GROUP);
-    const int64_t tile = grp * RSDF_FWD_GROUP + (r - (int64_t)l * RSDF_FWD_GROUP);
+    const int l = (int)(r / group);
+    const int64_t tile = grp * group + (r - (int64_t)l * group);
     const int64_t s = tile * F_THREADS + threadIdx.x;
     if (s >= (X3 ? x3.Sp : S)) return;      // (Sp is a multiple of 32: lane pairs stay whole)
     const LevelGeom g = level_geom(meta, l);
@@ -1078,7 +1080,9 @@ int launch_fwd(const TapSrc &src, const float *table, const rsdf_grid_meta *meta
         RSDF_CHECK_ARG(dense <= meta->size[l] || (meta->size[l] & (meta->size[l] - 1u)) == 0,
                        "hashgrid_fwd_fd7: hashed level sizes must be powers of two");
     }
-    const unsigned n_tiles_f = (rsdf_blocks(x3 ? x3->Sp : n_samples, F_THREADS) + RSDF_FWD_GROUP - 1) / RSDF_FWD_GROUP * RSDF_FWD_GROUP;
+    const unsigned n_tiles_raw = rsdf_blocks(x3 ? x3->Sp : n_samples, F_THREADS);
+    const int group = n_tiles_raw < (unsigned)RSDF_FWD_GROUP ? (int)n_tiles_raw : RSDF_FWD_GROUP;
+    const unsigned n_tiles_f = (n_tiles_raw + group - 1) / group * group;
     // HIP launches in threads: grid.x * block.x must stay below 2^32
     RSDF_CHECK_ARG((uint64_t)n_tiles_f * na * F_THREADS < (1ull << 32), "hashgrid_fwd_fd7: too many samples for one launch");
     float2 *pl = reinterpret_cast<float2 *>(planes);
@@ -1090,16 +1094,16 @@ int launch_fwd(const TapSrc &src, const float *table, const rsdf_grid_meta *meta
             x3_zero_cols_kernel<<<gx, 256, 0, st>>>(*x3, 2 * na);
         }
         if (src.x7t)
-            fd7_fwd_kernel<false, true><<<n_tiles_f * na, F_THREADS, 0, st>>>(src, table, *meta, n_samples, na, nullptr, *x3);
+            fd7_fwd_kernel<false, true><<<n_tiles_f * na, F_THREADS, 0, st>>>(src, table, *meta, n_samples, na, nullptr, *x3, group);
         else
-            fd7_fwd_kernel<true, true><<<n_tiles_f * na, F_THREADS, 0, st>>>(src, table, *meta, n_samples, na, nullptr, *x3);
+            fd7_fwd_kernel<true, true><<<n_tiles_f * na, F_THREADS, 0, st>>>(src, table, *meta, n_samples, na, nullptr, *x3, group);
         RSDF_RETURN_LAUNCH();
     }
     const X2Out none{nullptr, 0, 0.f, 0.f, 2, 0, 0};
     if (src.x7t)
-        fd7_fwd_kernel<false, false><<<n_tiles_f * na, F_THREADS, 0, st>>>(src, table, *meta, n_samples, na, pl, none);
+        fd7_fwd_kernel<false, false><<<n_tiles_f * na, F_THREADS, 0, st>>>(src, table, *meta, n_samples, na, pl, none, group);
     else
-        fd7_fwd_kernel<true, false><<<n_tiles_f * na, F_THREADS, 0, st>>>(src, table, *meta, n_samples, na, pl, none);
+        fd7_fwd_kernel<true, false><<<n_tiles_f * na, F_THREADS, 0, st>>>(src, table, *meta, n_samples, na, pl, none, group);
     RSDF_RETURN_LAUNCH();
 }
 

@@ -332,6 +332,10 @@ class OccGridEstimator(nn.Module):
         n_cand, n_kept = vals[:2]
         self._settle_pending(list(zip(vals[2::2], vals[3::2])))      # (+ the counts of earlier read-free passes)
         self._remember(key, n_cand)
+        bkey = ("blind",) + tuple(key)
+        if bkey not in self._capacity:       # (dropped by sampling_blind when it sent its caller here: re-measured now)
+            self._capacity[bkey] = int(n_cand * 1.5) + 4096
+            self._blind_rays[bkey] = int(rays_o.shape[0])
         self.stats["capped_calls"] += 1
         if n_cand > cap:                                               # truncated: redo exactly (rare)
             self.stats["overflows"] += 1

@@ -235,6 +235,58 @@ def main():
         nsaved["p__" + k] = v
     mg.save("models_neus.npz", **nsaved)
 
+    # ---- the same at the sizes config[2..4] run: L = 16 levels, T = 2^19 entries, 2 x 128 SDF network
+    # with 48 features, 128-wide radiance network -- the fused H = 128 / L = 16 kernels against the reference's own forward_
+    # rather than only the H = 32 per-wave ones.  The 58 MB table is NOT stored: it is regenerated from BIG_TABLE_SEED
+    # (big_table() below; tests/test_gpu_model_fixtures.py calls the same function).
+    bcfg = model_cfg(False, False)
+    bcfg.update({"name": "neus", "variance": {"init_val": 0.45, "modulate": False}, "num_samples_per_ray": 512,
+                 "texture": {"name": "volume-radiance", "input_feature_dim": 48 + 3,
+                             "dir_encoding_config": {"otype": "SphericalHarmonics", "degree": 4},
+                             "mlp_network_config": {"otype": "VanillaMLP", "activation": "ReLU",
+                                                    "output_activation": "none", "n_neurons": 128, "n_hidden_layers": 2},
+                             "color_activation": "sigmoid"}})
+    bcfg.pop("light")
+    bcfg["geometry"] = dict(bcfg["geometry"], feature_dim=48)
+    bcfg["geometry"]["xyz_encoding_config"] = dict(bcfg["geometry"]["xyz_encoding_config"], n_levels=16, log2_hashmap_size=19,
+                                                   base_resolution=32, per_level_scale=1.447269237440378, start_level=16)
+    bcfg["geometry"]["mlp_network_config"] = dict(bcfg["geometry"]["mlp_network_config"], n_neurons=128)
+    torch.manual_seed(7)
+    big = NeuSModel(mg.Cfg(bcfg))
+    brays = camera_rays(16, 16, seed=4)
+    with torch.no_grad():
+        prm = big.geometry.encoding.encoding.encoding.params
+        prm.copy_(big_table(prm.numel()))
+        l0 = big.geometry.network.layers[0]
+        l0.weight_v[:, 3:] = torch.randn_like(l0.weight_v[:, 3:]) * 0.3
+    big.geometry.contraction_type = rgeo.ContractionType.AABB
+    big.eval()
+    big.update_step(0, 0)
+    big.background_color = torch.ones(3)
+    with torch.no_grad():
+        bout = big.forward_(brays)
+    call = big.occupancy_grid.calls[0]
+    print("neus L16 H128 samples", call[0].numel(), "valid rays", int((bout["opacity"][:, 0] > 0.5).sum()))
+    assert int((bout["opacity"][:, 0] > 0.5).sum()) > 20
+    bsaved = {"rays": brays, "shell": np.array(SHELL), "fd_eps": np.array(big.geometry._finite_difference_eps),
+              "render_step_size": np.array(big.render_step_size), "table_seed": np.array(BIG_TABLE_SEED),
+              "n_table": np.array(prm.numel()), "primary_ri": call[0], "primary_ts": call[1], "primary_te": call[2]}
+    for k, v in bout.items():
+        if isinstance(v, torch.Tensor):
+            bsaved["out__" + k] = v
+    for k, v in big.state_dict().items():
+        if not k.endswith("encoding.params"):
+            bsaved["p__" + k] = v
+    mg.save("models_neus_l16_h128.npz", **bsaved)
+
+
+BIG_TABLE_SEED = 77
+
+
+def big_table(n, seed=BIG_TABLE_SEED):
+    """The L = 16, T = 2^19 hash table of the large fixture, from its seed (58 MB: not stored)."""
+    return (torch.rand(n, generator=torch.Generator().manual_seed(seed)) * 2 - 1) * 1e-3
+
 
 if __name__ == "__main__":
     main()

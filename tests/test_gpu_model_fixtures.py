@@ -103,3 +103,60 @@ def test_hip_neus_matches_reference_forward(dev):
         ref = fx["out__" + k]
         assert torch.allclose(out[k].cpu(), ref, rtol=1e-4, atol=2e-5), (k, float((out[k].cpu() - ref).abs().max()))
     assert torch.equal(out["rays_valid_full"].cpu(), fx["out__rays_valid_full"])
+
+
+def test_hip_neus_l16_h128_matches_reference_forward(dev):
+    """The SAME comparison at the sizes config[2..4] run: L = 16 levels, T = 2^19 entries, 2 x 128 SDF
+    network with 48 features, 128-wide radiance network -- the fused H = 128 / L = 16 kernels (csrc/mlp_x2.hip, the stencil
+    gather) against the reference's own ``NeuSModel.forward_`` output (tests/golden/models_neus_l16_h128.npz).  The 58 MB hash
+    table is regenerated from the fixture's seed."""
+    import os
+    import sys
+    import numpy as np
+    import rise_sdf_amd as R
+    from test_gpu_model import model_config
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    z = np.load(os.path.join(here, "golden", "models_neus_l16_h128.npz"))
+    fx = {k: torch.from_numpy(z[k]) for k in z.files}
+    cfg = model_config(hidden=128, n_levels=16, feat=48, grid_prune=True)
+    enc = cfg["geometry"]["xyz_encoding_config"]
+    enc.update({"log2_hashmap_size": 19, "base_resolution": 32, "per_level_scale": 1.447269237440378, "start_level": 16})
+    cfg["variance"]["init_val"] = 0.45
+    cfg["num_samples_per_ray"] = 512
+    cfg["texture"] = {"name": "volume-radiance", "input_feature_dim": 48 + 3,
+                      "dir_encoding_config": {"otype": "SphericalHarmonics", "degree": 4},
+                      "mlp_network_config": {"otype": "VanillaMLP", "activation": "ReLU", "output_activation": "none",
+                                             "n_neurons": 128, "n_hidden_layers": 2},
+                      "color_activation": "sigmoid"}
+    model = R.make("neus", R.Config(dict(cfg))).to(dev)
+    state = {k[3:]: v for k, v in fx.items() if k.startswith("p__")}
+    n_table = int(fx["n_table"])
+    g = torch.Generator().manual_seed(int(fx["table_seed"]))              # make_golden_models.big_table()
+    state["geometry.encoding.encoding.encoding.params"] = (torch.rand(n_table, generator=g) * 2 - 1) * 1e-3
+    missing, unexpected = model.load_state_dict(state, strict=False)
+    assert not unexpected, unexpected
+    assert all("occupancy_grid" in m for m in missing), missing
+    model.occupancy_grid.binaries = sphere_binary(128, *[float(v) for v in fx["shell"]]).to(dev)[None]
+    model.eval()
+    model.update_step(0, 0)
+    # (a model with a radiance network takes NeuSModel's general path; its field queries still go through the fused
+    # stencil node, VolumeSDF.forward -> fused.sdf_field_fd7 -> the x2 kernels at H = 128)
+    assert model.geometry.fused_field_available() and abs(model.geometry._finite_difference_eps - float(fx["fd_eps"])) < 1e-12
+    model.background_color = torch.ones(3, device=dev)
+    with torch.no_grad():
+        out = model.forward_(fx["rays"].to(dev))
+    assert int(out["num_samples"]) == int(fx["out__num_samples"])            # no visibility pruning: the marcher is bit-exact
+    diffs = {k: float((out[k].cpu() - fx["out__" + k]).abs().max()) for k in ("opacity", "depth", "comp_normal", "comp_rgb",
+                                                                             "comp_rgb_full")}
+    print("max abs difference to the reference's forward_:", {k: "%.1e" % v for k, v in diffs.items()})
+    # opacity and depth do not pass through the finite-difference normal: the north star's 1e-4
+    for k in ("opacity", "depth"):
+        assert torch.allclose(out[k].cpu(), fx["out__" + k], rtol=1e-4, atol=2e-5), (k, diffs[k])
+    # At L = 16 the progressive eps is one cell of the 2048-grid, 3.7e-4: the normal divides an fp32 SDF difference by 2 eps,
+    # so ANY two fp32 evaluations of the same network (here: torch's CPU GEMMs in the reference run vs these kernels)
+    # disagree by several 1e-3 in a normal component (tests/test_gpu_x2.py: x2 vs fp64 1.9e-3, torch fp32 vs fp64 2.8e-3), and the
+    # radiance network sees the normal.  The small fixtures (L = 4, eps 50 x larger) hold 1e-4 on every key; here the
+    # normal-dependent keys are held to what fp32 itself resolves.
+    assert diffs["comp_normal"] < 1.5e-2 and diffs["comp_rgb"] < 2e-3 and diffs["comp_rgb_full"] < 2e-3, diffs
+    assert torch.equal(out["rays_valid_full"].cpu(), fx["out__rays_valid_full"])
