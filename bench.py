@@ -311,7 +311,14 @@ def generic_gather_probe(model, rays, jitter, chunk):
     return {"bound": "hbm", "evals": n, "avg_launch_ms": round(ms, 3), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "evals_per_sec": n / (ms / 1e3),
             "note": f"generic per-point gather (rsdf_hashgrid_fwd_staged at this size), 1164 algorithmic B per evaluation, "
-                    f"centre points of one {chunk}-ray chunk"}
+                    f"centre points of one {chunk}-ray chunk",
+            # the stated bound of this kernel: its planes pass issues 72.6 L2 requests per evaluation
+            # (13 hashed levels x 4.5 lines + the dense levels; TCC_REQ, profiles/*/pmc/gather_l2.csv) against the ~2.7e11
+            # requests/s the L2s deliver (tools/gather_pair_bench.hip: 2.5e11 measured) -> <= 3.7e9 evaluations/s = 0.54 of
+            # the 8 TB/s x 1164 B figure: the north star's 0.60 is out of reach for unsorted points with this hash
+            "l2_request_ceiling": {"evals_per_sec": 3.7e9, "frac_of_hbm_roofline": 0.54, "requests_per_eval": 72.6,
+                                   "frac_of_ceiling": round(n / (ms / 1e3) / 3.7e9, 3),
+                                   "source": "DESIGN.md 4 'The generic gather in two passes'; tools/pmc_gather.sh"}}
 
 
 def attach_traffic(roof, path):

@@ -364,7 +364,7 @@ class OccGridEstimator(nn.Module):
         # step early on): scale it by the host-known ratio
         n_rays = int(rays_o.shape[0])
         n_meas = self._blind_rays.get(key, n_rays)
-        if n_rays > n_meas:
+        if n_rays > n_meas + max(8, n_meas // 20):      # (the caller's phantom ray alone is not "more rays")
             cap = int(cap * (n_rays / max(n_meas, 1))) + 4096
         packed, ri, ts, te, total = ops.march_capped(rays_o, rays_d, t_min, t_max, self.aabbs[0], self.binaries[0],
                                                      render_step_size, cap, 0.0)
