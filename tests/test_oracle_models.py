@@ -83,14 +83,26 @@ def load_neus_fixture():
     return {k: torch.from_numpy(z[k]) for k in z.files}
 
 
-def test_oracle_neus_matches_reference_forward():
+NEUS_BIG_GOLDEN = os.path.join(os.path.dirname(NEUS_GOLDEN), "models_neus_l16_h128.npz")
+
+
+@pytest.mark.parametrize("big", [False, True])
+def test_oracle_neus_matches_reference_forward(big):
     """oracle.neus_geometry_render + the radiance network against the reference's own NeuSModel.forward_ (eval mode,
-    occupancy sampling without visibility pruning, volume-radiance texture, white background)."""
+    occupancy sampling without visibility pruning, volume-radiance texture, white background).  ``big``: the fixture at the
+    sizes config[2..4] run (L = 16, T = 2^19, 2 x 128 SDF network, 48 features; table regenerated from its seed)."""
     import torch.nn.functional as F
-    fx = load_neus_fixture()
+    if big:
+        z = np.load(NEUS_BIG_GOLDEN)
+        fx = {k: torch.from_numpy(z[k]) for k in z.files}
+        g = torch.Generator().manual_seed(int(fx["table_seed"]))
+        fx["p__geometry.encoding.encoding.encoding.params"] = (torch.rand(int(fx["n_table"]), generator=g) * 2 - 1) * 1e-3
+    else:
+        fx = load_neus_fixture()
     t = lambda k: fx["p__" + k]   # noqa: E731
-    meta, n_params = oracle.grid_meta(4, 2, 14, 16, 1.5)
+    meta, n_params = oracle.grid_meta(16, 2, 19, 32, 1.447269237440378) if big else oracle.grid_meta(4, 2, 14, 16, 1.5)
     table = t("geometry.encoding.encoding.encoding.params")
+    assert table.numel() == n_params
     mlp = [{"g": t(f"geometry.network.layers.{i}.weight_g"), "v": t(f"geometry.network.layers.{i}.weight_v"),
             "b": t(f"geometry.network.layers.{i}.bias")} for i in (0, 2, 4)]
     tex = [{"w": t(f"texture.network.layers.{i}.weight"), "b": t(f"texture.network.layers.{i}.bias")} for i in (0, 2, 4)]
@@ -112,5 +124,12 @@ def test_oracle_neus_matches_reference_forward():
            "comp_normal": F.normalize(ref["comp_normal"], p=2, dim=-1),
            "comp_rgb_full": comp + 1.0 * (1.0 - ref["opacity"])}
     for k, v in got.items():
-        assert torch.allclose(v, fx["out__" + k], rtol=1e-5, atol=2e-6), (k, float((v - fx["out__" + k]).abs().max()))
-    assert int(fx["out__num_samples_full"]) == ri.numel() and int((fx["out__opacity"][:, 0] > 0.5).sum()) > 50
+        d = float((v - fx["out__" + k]).abs().max())
+        if big and k in ("comp_rgb", "comp_normal", "comp_rgb_full"):
+            # At L = 16 the finite-difference eps is one cell of the 2048-grid (3.7e-4): the normal divides an fp32 SDF
+            # difference by 2 eps, so even two fp32 evaluations on the SAME CPU that batch the seven taps differently (the
+            # reference's forward_ and this oracle) disagree by ~1e-3 in a normal component and 2.5e-4 in the colour
+            assert d < (1e-2 if k == "comp_normal" else 1e-3), (k, d)
+        else:
+            assert torch.allclose(v, fx["out__" + k], rtol=1e-5, atol=2e-6), (k, d)
+    assert int(fx["out__num_samples_full"]) == ri.numel() and int((fx["out__opacity"][:, 0] > 0.5).sum()) > (20 if big else 50)
