@@ -309,7 +309,24 @@ linear_bwd_weight_narrow_kernel(const float *__restrict__ dz, int lddz, const fl
 #pragma unroll
     for (int j = 0; j < NN; ++j) acc[j] = bs[j] = 0.0f;
     const bool kok = k < K;
-    for (int64_t r = r0 + rl; r < r1; r += RL) {
+    int64_t r = r0 + rl;
+    for (; r + 3 * RL < r1; r += 4 * RL) {          // four rows per trip: their loads are in flight together
+        float xv[4], d[4][NN];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            xv[u] = kok ? x[(r + u * RL) * ldx + k] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < NN; ++j) d[u][j] = j < N ? dz[(r + u * RL) * lddz + j] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < NN; ++j) {
+                acc[j] = fmaf(round_operand(d[u][j]), round_operand(xv[u]), acc[j]);
+                bs[j] += d[u][j];
+            }
+    }
+    for (; r < r1; r += RL) {
         const float xv = kok ? round_operand(x[r * ldx + k]) : 0.0f;
 #pragma unroll
         for (int j = 0; j < NN; ++j)
@@ -476,7 +493,9 @@ int RSDF_P(rsdf_linear_bwd_weight)(const float *dz, int lddz, const float *x, in
     RSDF_CHECK_ARG(K >= 1 && K <= 128 && N >= 1 && N <= 128, "linear_bwd_weight: K and N must be in [1,128]");
     RSDF_CHECK_ARG(lddz >= N && ldx >= K, "linear_bwd_weight: row stride smaller than the row");
     if (n <= 0) return 0;
-    if (N <= NARROW_N && !rsdf_env_is("RSDF_BWD_WEIGHT", "mfma")) {
+    // (up to 2^20 rows: a training step's 250 k.  On a whole render chunk -- millions of rows -- the matrix form's persistent
+    //  workgroups stream better: 441 against 276 ms per c2 step when this form took those launches too)
+    if (N <= NARROW_N && n <= (1 << 20) && !rsdf_env_is("RSDF_BWD_WEIGHT", "mfma")) {
         int KP = 32;
         while (KP < K) KP <<= 1;
         const int64_t rows_per_wg = 512;             // >= 2 rows per thread even at KP = 256

@@ -57,12 +57,24 @@ def _scan_scratch(n, device):
 # and the renderer packs them again (lib/nerfacc/pack.py:47-78: a run-boundary pass over all samples + a scan).  The last
 # marcher result is remembered by the IDENTITY of its ray_indices tensor (a weak reference: no address or shape
 # comparison that a recycled allocation could satisfy); pack_info() returns it for that very tensor.
-_LAST_PACKED = [None, None, 0]      # weakref to ray_indices, packed_info, n_rays
+# Thread-local (a second host thread -- a data-parallel replica, a prefetching evaluator -- has its own marcher calls), and the
+# sample count is part of the key.
+import threading as _threading
+
+_LAST_PACKED_TLS = _threading.local()
+
+
+def _last_packed():
+    lp = getattr(_LAST_PACKED_TLS, "v", None)
+    if lp is None:
+        lp = _LAST_PACKED_TLS.v = [None, None, 0, 0]      # weakref to ray_indices, packed_info, n_rays, n_samples
+    return lp
 
 
 def _remember_packed(ray_indices, packed, n_rays):
     import weakref
-    _LAST_PACKED[0], _LAST_PACKED[1], _LAST_PACKED[2] = weakref.ref(ray_indices), packed, int(n_rays)
+    lp = _last_packed()
+    lp[0], lp[1], lp[2], lp[3] = weakref.ref(ray_indices), packed, int(n_rays), int(ray_indices.numel())
 
 
 @torch.no_grad()
@@ -152,9 +164,11 @@ def query_occ(samples, roi, binary, return_cell=False):
 @torch.no_grad()
 def pack_info(ray_indices, n_rays):
     """lib/nerfacc/pack.py:47-78: sorted int64 ray_indices [S] -> packed_info int32 [n_rays, 2]."""
-    ref = _LAST_PACKED[0]
-    if ref is not None and ref() is ray_indices and _LAST_PACKED[2] == int(n_rays) and ray_indices._version == 0:
-        return _LAST_PACKED[1]           # the marcher's own packed_info of this very tensor
+    lp = _last_packed()
+    ref = lp[0]
+    if (ref is not None and ref() is ray_indices and lp[2] == int(n_rays) and lp[3] == int(ray_indices.numel())
+            and ray_indices._version == 0):
+        return lp[1]                     # the marcher's own packed_info of this very tensor
     ri = ray_indices.to(torch.int64).contiguous()
     require_device(ri)
     dev = ri.device
