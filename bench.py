@@ -386,6 +386,8 @@ def brief(res, steps):
         if roof is not None:
             out["dominant_kernel"] = {k: roof.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac",
                                                                "avg_launch_ms")}
+        top = sorted(res["summary"].items(), key=lambda kv: -kv[1]["ms"])[:6]
+        out["top_ms_per_step"] = {k: round(v["ms"] / steps, 2) for k, v in top}
     return out
 
 
@@ -399,7 +401,11 @@ def secondary_measurements(dev, args, rays, jitter, cot):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     extras = {}
 
+    only = [t for t in (getattr(args, "only_extras", "") or "").split(",") if t]
+
     def guarded(name, fn):
+        if only and name not in only:
+            return
         gc.collect()
         torch.cuda.empty_cache()
         try:
@@ -547,6 +553,8 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--time-overlapped", action="store_true",
                     help="also record per-entry-point HIP events inside a two-stream timed region (overlapping times)")
+    ap.add_argument("--only-extras", default="",
+                    help="comma-separated names: run only these `secondary` measurements (e.g. dropin_path,c3_step)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the secondary measurements appended to the line at N = 1 (see secondary_measurements)")
     ap.add_argument("--pmc-summary", default=os.path.join(ROOT, "profiles", "pmc_summary.json"),

@@ -21,6 +21,9 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--only", default="")
     ap.add_argument("--forms", default="x7t,pts,x2")
+    ap.add_argument("--shell", type=float, default=0.0,
+                    help="keep only the samples within this distance of the sphere |p| = 0.5 and shuffle the RAYS first (the "
+                         "training step's sample set: random pixels, visibility-pruned to a thin shell)")
     args = ap.parse_args()
     import bench
     from rise_sdf_amd import _lib, ops
@@ -29,6 +32,8 @@ def main():
     model = bench.build_model(dev, argparse.Namespace(hidden=64))
     rays = orbit_view_rays(800, 800, seed=0, device=dev)
     n0 = (rays.shape[0] // 2 // 800) * 800
+    if args.shell > 0:
+        rays = rays[torch.randperm(rays.shape[0], generator=torch.Generator().manual_seed(1)).to(dev)]
     rays = rays[n0:n0 + args.rays].contiguous()
     u = torch.rand(rays.shape[0], generator=torch.Generator().manual_seed(2)).to(dev)
     geo = model.geometry
@@ -38,6 +43,9 @@ def main():
                                                    cone_angle=0.0, alpha_thre=0.0)
         x7t, pts = ops.fd_points(ro, rd, ri, ts, te, geo.radius, geo._finite_difference_eps, want_positions=True,
                                  tap_major=True)
+    if args.shell > 0:
+        keep = ((pts.norm(dim=-1) - 0.5).abs() < args.shell).nonzero().view(-1)
+        pts, x7t = pts[keep].contiguous(), x7t[:, keep].contiguous()
     S = pts.shape[0]
     grid, _ = geo.encoding._hash()
     meta, table = grid.meta, grid.params.detach()
