@@ -432,7 +432,6 @@ def secondary_measurements(dev, args, rays, jitter, cot):
     # (H = 128: the cooperative kernels hold every register of a CU, a second chunk in flight only adds contention)
     h128_chunk = min(args.chunk, 24576)       # (the H = 128 variants keep the chunk size they were measured at)
     guarded("h128", lambda: c1_variant(128, h128_chunk, streams=1))
-    guarded("h128_two_streams", lambda: c1_variant(128, h128_chunk))
     # config[4]'s opt-in 16-bit MLP modes at the yaml's width (never part of the f32 headline): 'bf16' = the round-3
     # kernels with one bf16 product per k-step; 'fp16' = the x2 kernels with ONE fp16 part (11 significant bits)
     guarded("h128_bf16", lambda: c1_variant(128, h128_chunk, precision="bf16"))
@@ -440,7 +439,9 @@ def secondary_measurements(dev, args, rays, jitter, cot):
     guarded("h64_fp16", lambda: c1_variant(64, args.chunk, precision="fp16"))
     # the per-layer API route (tcnn.Encoding / VanillaMLP shaped calls, one or a few kernels each; INTEGRATION.md's
     # two-line dropin.install()): [7 S, 35] rows through HBM, so a quarter of the view at the reference's chunk size
-    guarded("dropin_path", lambda: c1_variant(args.hidden, 4096, n_rays=rays.shape[0] // 4 // 800 * 800, fused=False))
+    # (one chunk at a time, as the reference's own loop issues it -- and because with two chunks in flight the per-entry-point
+    #  times include the neighbour chunk's share: the round-3 line's "rsdf_linear_bwd_weight 7.3 ms, 0.094" was 2.5 ms alone)
+    guarded("dropin_path", lambda: c1_variant(args.hidden, 4096, n_rays=rays.shape[0] // 4 // 800 * 800, fused=False, streams=1))
 
     def c2(tex_precision="fp32", streams=1):
         from bench_c2 import measure_c2

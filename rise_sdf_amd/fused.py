@@ -79,6 +79,12 @@ class _SdfFieldFD7(torch.autograd.Function):
         if precision == "fp16" and S > 0 and not parts:
             raise L.RiseSdfHipError("precision 'fp16' of the fused SDF field needs H = 64 or 128")
         if parts:
+            if os.environ.get("RSDF_CHECK", "0") == "1":
+                # the x2 form's fp16 range preconditions (csrc/mlp_x2.hip): a violation would show as inf / nan outputs
+                wmax = max(float(t.abs().max()) for t in ws)
+                if not (wmax < 1023.0 and float(tb.abs().max()) < 255.0):
+                    raise L.RiseSdfHipError(f"RSDF_CHECK x2: |weight| {wmax:.3g} must be < 1023 and |table| "
+                                            f"{float(tb.abs().max()):.3g} < 255 (fp16 class scales); use RSDF_X2=0")
             x2 = torch.empty(int(lib().rsdf_x2_bytes(S, parts)), dtype=torch.uint8, device=dev)
             check(lib().rsdf_hashgrid_fwd_fd7_x2(None if pts is not None else ptr(xf), ptr(pts), float(radius or 0.0),
                                                  float(eps or 0.0), ptr(tb), ctypes.byref(meta), S, n_active,

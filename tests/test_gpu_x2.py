@@ -230,3 +230,26 @@ def test_x1_field_is_the_fp16_operand_network(dev, ops, H):
     d_bf16 = float((sb.cpu() - o32).abs().max()) / scale
     print(f"H = {H}: |sdf - fp32| / max|sdf|: fp16 mode {d_mode:.2e}, bf16 mode {d_bf16:.2e}; fp16 vs its oracle {err:.2e}")
     assert d_mode < 0.35 * d_bf16
+
+
+def test_x2_range_preconditions(dev, ops, monkeypatch):
+    """The x2 form's fp16 class scales bound |weight| < 1023 and |input| < 255.  Inside the bounds large values are exact
+    citizens (a weight of 900, a feature of 200 give the fp64 result); outside them the result is inf / nan -- never a
+    silently wrong finite number -- and RSDF_CHECK=1 names the violation up front."""
+    from rise_sdf_amd import _lib, fused
+    H, N2, S = 64, 13, 1000
+    meta, table, ws, x7t, pts, radius, eps = _field_inputs(dev, ops, S, H, N2, seed=33)
+    with torch.no_grad():
+        ws[1][0][3, 5] = 900.0                               # one large hidden weight, still in range
+        sdf_ok, _ = fused.sdf_field_fd7(x7t, table, ws, meta, 16, 2.0, -1.0, eps / (2 * radius), points=pts, radius=radius, eps=eps)
+        monkeypatch.setenv("RSDF_X2", "0")
+        sdf_r3, _ = fused.sdf_field_fd7(x7t, table, ws, meta, 16, 2.0, -1.0, eps / (2 * radius), points=pts, radius=radius, eps=eps)
+        monkeypatch.setenv("RSDF_X2", "1")
+        assert bool(torch.isfinite(sdf_ok).all())
+        assert float((sdf_ok - sdf_r3).abs().max()) < 1e-5 * float(sdf_r3.abs().max())
+        ws[1][0][3, 5] = 5000.0                              # out of range: overflows to inf / nan, visibly
+        sdf_bad, _ = fused.sdf_field_fd7(x7t, table, ws, meta, 16, 2.0, -1.0, eps / (2 * radius), points=pts, radius=radius, eps=eps)
+        assert not bool(torch.isfinite(sdf_bad).all())
+        monkeypatch.setenv("RSDF_CHECK", "1")
+        with pytest.raises(_lib.RiseSdfHipError, match="RSDF_CHECK x2"):
+            fused.sdf_field_fd7(x7t, table, ws, meta, 16, 2.0, -1.0, eps / (2 * radius), points=pts, radius=radius, eps=eps)
