@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+T_PROCESS_START = time.perf_counter()
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: fp32 matrix peak
 MFMA_BF16_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 matrix peak (the sparsity-doubled headline is never used)
@@ -408,8 +409,11 @@ def secondary_measurements(dev, args, rays, jitter, cot):
             return
         gc.collect()
         torch.cuda.empty_cache()
+        t0 = time.perf_counter()
         try:
             extras[name] = fn()
+            if isinstance(extras[name], dict):
+                extras[name]["wall_s"] = round(time.perf_counter() - t0, 1)
         except Exception as e:   # noqa: BLE001  (recorded, not swallowed: the key carries the error)
             extras[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
 
@@ -453,7 +457,7 @@ def secondary_measurements(dev, args, rays, jitter, cot):
         out["workload"] = r["workload"]
         return out
     guarded("c2_800", c2)                                           # one chunk at a time: carries the dominant kernel
-    guarded("c2_800_two_streams", lambda: c2(streams=args.streams))
+    # (two chunks in flight make c2 slower, 5.2e7: allocator pressure -- measured through round 4, no longer run by default)
     # configs[4]'s bf16 mode on the radiance networks only (SDF network fp32: the combination the convergence proxy,
     # tests/test_gpu_convergence.py, finds indistinguishable from fp32)
     guarded("c2_800_bf16_radiance", lambda: c2("bf16"))
@@ -643,8 +647,10 @@ def main():
                     fd7["evals_per_sec"] = round(fd7["achieved"] * 1e9 / 1164.0)
                 roof["other_kernels"]["rsdf_hashgrid_fwd (generic)"] = generic_gather_probe(model, rays, jitter, args.chunk)
         cpu = None
+        t_cpu0 = time.perf_counter()
         if args.cpu_rays > 0 and world == 1:   # reported at N = 1 only
             cpu = cpu_baseline(model, rays_cpu, jitter_cpu, args.cpu_rays)
+        t_cpu = time.perf_counter() - t_cpu0
         line = {
             "metric": "ray-marched SDF samples/sec (fwd+bwd), 800x800 rays, L=16 hashgrid",
             "value": samples / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
@@ -664,9 +670,11 @@ def main():
         }
         if overlapped is not None:
             line["kernel_breakdown_timed_region_overlapped"] = overlapped
+        line["wall_s"] = {"cpu_baseline": round(t_cpu, 1), "until_secondary": round(time.perf_counter() - T_PROCESS_START, 1)}
         if world == 1 and not args.no_extras:
             del model, buckets
             line["secondary"] = secondary_measurements(dev, args, rays, jitter, cot)
+            line["wall_s"]["total"] = round(time.perf_counter() - T_PROCESS_START, 1)
         print(json.dumps(line))
     if world > 1:
         torch.distributed.barrier()

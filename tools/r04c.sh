@@ -1,4 +1,16 @@
 cd $GRAFT_REPO_ROOT
-for cfg in "2 28672" "3 18432" "3 20480" "2 32768" "4 14336"; do set -- $cfg; python bench.py --steps 3 --warmup 1 --cpu-rays 0 --no-extras --no-kernel-timing --streams $1 --chunk $2 2>/dev/null | tail -1 | python3 -c "
-import json,sys
-d=json.loads(sys.stdin.read()); print('streams $1 chunk $2', '%.4g'%d['value'])"; done
+mkdir -p gpurun_out/r04f
+( time python bench.py --steps 20 --warmup 5 > gpurun_out/r04f/bench.json 2> gpurun_out/r04f/bench.err ) 2> gpurun_out/r04f/time.txt; cat gpurun_out/r04f/time.txt
+
+python3 - <<'PY'
+import json
+d=json.loads(open("gpurun_out/r04f/bench.json").read().strip().splitlines()[-1])
+print('%.4g'%d['value'], round(d['ms_per_step'],1))
+for k,v in d['secondary'].items():
+    if isinstance(v,dict): print(k, '%.4g'%v.get('samples_per_s',0), round(v.get('ms_per_step',0),2), v.get('error',''))
+PY
+python3 - <<'PY'
+import json
+d=json.loads(open("gpurun_out/r04f/bench.json").read().strip().splitlines()[-1])
+print(d.get('wall_s')); print({k:v.get('wall_s') for k,v in d['secondary'].items() if isinstance(v,dict)})
+PY
