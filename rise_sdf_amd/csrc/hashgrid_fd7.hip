@@ -17,8 +17,8 @@
 //   1. PRODUCE: one thread per (sample, level) merges the taps' contributions in registers into
 //      the same 8..32 corners, bins the (entry, value) records by table slice (<= 8192 entries, one
 //      LDS image), counting-sorts them by bin inside the workgroup through LDS and appends each bin's
-//      run to its queue in HBM as 20-byte elements of two records (10 bytes per record: inside a bin an
-//      entry needs 13 bits).
+//      run to its queue in HBM as 16-byte elements of two records (8 bytes per record: 13 bits of entry
+//      within the bin + a block-float pair of the two feature gradients, see PairRec).
 //   2. REDUCE: one workgroup per (level, bin, split) streams its queue (4 records in flight per
 //      thread), accumulates into a 128 KiB fp64 LDS image with ds_add_f64 (measured 18x the rate of
 //      ds_add_f32 on gfx950, tools/lds_atomic_bench.hip) and adds the image to dtable
@@ -55,20 +55,66 @@ constexpr int STAGE_CAP = P_THREADS * RSDF_STAGE_RECS;
 #define MERGE_MAX_RUNS 40
 #endif
 constexpr int R_THREADS = 1024;  // reducer
-constexpr int R_UNROLL = 4;
+#ifndef RSDF_R_UNROLL
+#define RSDF_R_UNROLL 8     // 16-byte elements in flight per thread (4: 6.67, 8: 6.56 ms per 18.4 M-sample launch)
+#endif
+constexpr int R_UNROLL = RSDF_R_UNROLL;
 
 struct Record {   // LDS staging form
     uint32_t idx;  // entry index within the level
     float v0, v1;
 };
-// Queue form (round 3): TWO contributions of one bin per 20-byte element.  Inside a bin an entry needs 13 bits, so the
-// two indices share a dword: 10 bytes per contribution instead of 12 (the queues are 2/3 of this backward's HBM traffic).
-// A (bin, round) run with an odd record count ends in a half-empty element (e1 == PAIR_NONE).
+// Queue form.  Round 3: TWO contributions of one bin per 20-byte element (inside a bin an entry needs 13 bits, so the two
+// indices share a dword: 10 bytes per contribution instead of 12; -DRSDF_REC_FP32 keeps that form for A/B runs).
+// Round 4 (default): 8 bytes per contribution, two per 16-BYTE element -- one aligned dwordx4 store / load per lane instead
+// of a 16 + 4 byte pair at a 20-byte stride.  A contribution is (entry, v0, v1) with v0, v1 the two features' gradients of
+// ONE table entry (the same corner weight times the two plane gradients): they are stored as a block-float pair,
+//     bits 0..12 entry within the bin | 13..20 E = the larger value's biased fp32 exponent | 21..41 m0 | 42..62 m1,
+//     v_i = m_i 2^(E - 127 - 19), m_i = rint(v_i 2^(19 - (E - 127))) clamped to +-(2^20 - 1)  (21-bit two's complement),
+// i.e. the larger value keeps 20 significant bits (relative error <= 2^-20 = 9.5e-7 per record, against 2^-24 in fp32) and
+// the smaller one the same ABSOLUTE step.  The reducer still sums in fp64, so an entry that collects N records of one sign
+// ends ~2^-20 / sqrt(3 N) from the exact sum -- closer than an fp32 atomic accumulation from N ~ 20 up, and three orders of
+// magnitude closer than the reference's own table gradient (tiny-cuda-nn accumulates it with __half2 atomics).  E = 255
+// (inf / NaN in either value) decodes to NaN so that a non-finite gradient still poisons its table row; values below 2^-107
+// flush to zero.  A (bin, round) run with an odd record count ends in a half-empty element (second record all zero: it adds
+// 0.0 to entry 0; fp32 form: e1 == PAIR_NONE).
+#ifdef RSDF_REC_FP32
 struct PairRec {
     uint32_t e;    // entry within the bin: first contribution bits 0..15, second 16..31
     float a0, a1, b0, b1;
 };
 constexpr uint32_t PAIR_NONE = 0xffffu;
+#else
+struct __attribute__((aligned(16))) PairRec {
+    unsigned long long r0, r1;
+};
+__device__ __forceinline__ unsigned long long pack_rec(uint32_t entry, float v0, float v1)
+{
+    const uint32_t b0 = __float_as_uint(v0) & 0x7fffffffu, b1 = __float_as_uint(v1) & 0x7fffffffu;
+    const uint32_t E = (b0 > b1 ? b0 : b1) >> 23;
+    if (E < 20u) return (unsigned long long)entry;            // both below 2^-107 (or zero): m0 = m1 = 0, E = 0
+    const float sc = __uint_as_float((273u - E) << 23);       // 2^(19 - (E - 127)); E = 255 -> 2^-109 (inf / NaN stay)
+    int m0 = (int)rintf(v0 * sc), m1 = (int)rintf(v1 * sc);   // cvt saturates; NaN -> 0 (E = 255 carries it)
+    const int lim = (1 << 20) - 1;
+    m0 = m0 < -lim ? -lim : (m0 > lim ? lim : m0);
+    m1 = m1 < -lim ? -lim : (m1 > lim ? lim : m1);
+    return (unsigned long long)(entry | (E << 13) | ((uint32_t)m0 << 21))            // m0's low 11 bits
+           | ((unsigned long long)(((uint32_t)m0 >> 11 & 0x3ffu) | ((uint32_t)m1 & 0x1fffffu) << 10) << 32);
+}
+__device__ __forceinline__ void unpack_rec(unsigned long long r, uint32_t &entry, double &d0, double &d1)
+{
+    const uint32_t lo = (uint32_t)r, hi = (uint32_t)(r >> 32);
+    entry = lo & 0x1fffu;
+    const uint32_t E = lo >> 13 & 0xffu;
+    const int m0 = (int)(((lo >> 21) | (hi << 11)) << 11) >> 11;     // 21-bit two's complement
+    const int m1 = (int)(hi << 1) >> 11;
+    // 2^(E - 127 - 19) as a double: exponent field E - 146 + 1023; E = 255 -> NaN
+    const double sc = E == 255u ? __longlong_as_double(0x7ff8000000000000ll)
+                                : __longlong_as_double((long long)(E + 877u) << 52);
+    d0 = (double)m0 * sc;
+    d1 = (double)m1 * sc;
+}
+#endif
 constexpr uint32_t PAD_IDX = 0xffffffffu;   // staging slot that pads a run to an even length
 
 struct LevelPlan {
@@ -602,9 +648,14 @@ __device__ __forceinline__ void emit_round(uint32_t (&ridx)[ROUND_RECS],
             const bool two = r1.idx != PAD_IDX;
             const int64_t gpos = (int64_t)s_gbase[b] + ((lo + 2 * i - s_off[b]) >> 1);
             if (gpos < cap) {
+#ifdef RSDF_REC_FP32
                 const uint32_t e1 = two ? entry_of(r1.idx, interleaved) : PAIR_NONE;
                 queue[(int64_t)b * cap + gpos] = PairRec{entry_of(r0.idx, interleaved) | (e1 << 16), r0.v0, r0.v1,
                                                         two ? r1.v0 : 0.f, two ? r1.v1 : 0.f};
+#else
+                queue[(int64_t)b * cap + gpos] = PairRec{pack_rec(entry_of(r0.idx, interleaved), r0.v0, r0.v1),
+                                                        two ? pack_rec(entry_of(r1.idx, interleaved), r1.v0, r1.v1) : 0ull};
+#endif
             } else {  // queue full (capacity carries slack; never drop a contribution)
                 atomicAdd(dlevel + 2 * (size_t)r0.idx, r0.v0);
                 atomicAdd(dlevel + 2 * (size_t)r0.idx + 1, r0.v1);
@@ -956,11 +1007,16 @@ fd7_reduce_kernel(const rsdf_grid_meta meta, const LevelPlan plan, const PairRec
 #pragma unroll
         for (int u = 0; u < R_UNROLL; ++u) {
             const int64_t i = i0 + (int64_t)u * R_THREADS;
+#ifdef RSDF_REC_FP32
             rec[u] = i < r1 ? q[i] : PairRec{0u, 0.f, 0.f, 0.f, 0.f};
+#else
+            rec[u] = i < r1 ? q[i] : PairRec{0ull, 0ull};
+#endif
         }
 #pragma unroll
         for (int u = 0; u < R_UNROLL; ++u) {
             if (i0 + (int64_t)u * R_THREADS < r1) {
+#ifdef RSDF_REC_FP32
                 const uint32_t e0 = rec[u].e & 0xffffu, e1 = rec[u].e >> 16;   // entries within the bin (the producer's entry_of)
                 atomicAdd(&s_acc[2 * e0], (double)rec[u].a0);
                 atomicAdd(&s_acc[2 * e0 + 1], (double)rec[u].a1);
@@ -968,6 +1024,18 @@ fd7_reduce_kernel(const rsdf_grid_meta meta, const LevelPlan plan, const PairRec
                     atomicAdd(&s_acc[2 * e1], (double)rec[u].b0);
                     atomicAdd(&s_acc[2 * e1 + 1], (double)rec[u].b1);
                 }
+#else
+                uint32_t e0, e1;
+                double a0, a1, b0, b1;
+                unpack_rec(rec[u].r0, e0, a0, a1);
+                unpack_rec(rec[u].r1, e1, b0, b1);
+                atomicAdd(&s_acc[2 * e0], a0);
+                atomicAdd(&s_acc[2 * e0 + 1], a1);
+                if (rec[u].r1 != 0ull) {   // a run of odd length ends in a half-empty element
+                    atomicAdd(&s_acc[2 * e1], b0);
+                    atomicAdd(&s_acc[2 * e1 + 1], b1);
+                }
+#endif
             }
         }
     }

@@ -502,6 +502,18 @@ def test_neus_alpha_backward(dev, ops):
         assert abs(float(vg.grad) - float(vo.grad)) < 1e-3 * abs(float(vo.grad)) + 1e-4
 
 
+def _same_zero_pattern(got, ref, scale):
+    """The binned table scatter's queue records hold an entry's two feature gradients as a block-float pair with 20
+    significant bits (hashgrid_fd7.hip PairRec): a feature whose contributions are all below 2^-21 of their partner's
+    quantises to exactly zero (with Gaussian gradients: ~6e-7 of the single-record entries).  So the sets of touched
+    entries may differ in a few entries per million, and only where the reference value is itself negligible."""
+    mism = (got != 0) != (ref != 0)
+    n = int(mism.sum())
+    assert n <= max(4, int(2e-5 * int((ref != 0).sum()))), n
+    if n:
+        assert float(ref[mism].abs().max()) <= 1e-5 * scale and float(got[mism].abs().max()) <= 1e-5 * scale
+
+
 # ---- H1b, finite-difference stencil variant (bin + LDS reduce, no per-corner atomics) ----------------
 @pytest.mark.parametrize("gi,eps_unit", [(1, 1.0 / 8192), (1, 1.0 / 1291), (0, 1.0 / 54), (1, 3.0 / 8192)])
 def test_hashgrid_backward_fd7(dev, ops, gi, eps_unit):
@@ -532,7 +544,7 @@ def test_hashgrid_backward_fd7(dev, ops, gi, eps_unit):
     scale = float(t_o.grad.abs().max())
     err = float((t_g.grad.cpu() - t_o.grad).abs().max())
     assert err < 1e-5 * scale + 1e-7, (err, scale)
-    assert int((t_g.grad.cpu() != 0).sum()) == int((t_o.grad != 0).sum())
+    _same_zero_pattern(t_g.grad.cpu(), t_o.grad, scale)
 
 
 def test_hashgrid_forward_fd7_bit_exact(dev, ops):
@@ -648,7 +660,7 @@ def test_hashgrid_fd7_pts_backward(dev, ops, eps_cells):
     (oracle.hashgrid_encode(xc[:, inside].reshape(-1, 3), t_o, meta_o).view(7, Si, 32) * gout).sum().backward()
     scale = float(t_o.grad.abs().max())
     assert float((d_i.cpu() - t_o.grad).abs().max()) < 1e-5 * scale + 1e-7
-    assert int((d_i.cpu() != 0).sum()) == int((t_o.grad != 0).sum())
+    _same_zero_pattern(d_i.cpu(), t_o.grad, scale)
 
 
 # ---- the binned table scatter for plain points (generic backward, and the input gradient's backward) ---------------------
@@ -684,7 +696,51 @@ def test_hashgrid_scatter_binned_matches_atomics(dev, ops, mode):
                                           _lib.stream_ptr()) == 0
     scale = float(ref.abs().max())
     assert scale > 0 and float((got - ref).abs().max()) < 2e-5 * scale
-    assert int(((got != 0) != (ref != 0)).sum()) <= 4          # (an entry whose contributions cancel to exactly 0 in one order)
+    _same_zero_pattern(got, ref, scale)          # (+ an entry whose contributions cancel to exactly 0 in one order)
+
+
+def test_binned_scatter_record_format_bound(dev, ops):
+    """The queue records (hashgrid_fd7.hip PairRec) carry an entry's two feature gradients as a block-float pair: 20
+    significant bits for the larger one, the same absolute step for the smaller.  Per table entry the binned result must
+    therefore lie within 2^-20 (half a step of a value just above a power of two; + three fp32 roundings of 2^-24: the
+    product, the fp64 -> fp32 flush, the table add) x sum over its records of max(|v0|, |v1|) of the fp64 sum -- checked
+    against the oracle with a second backward that yields exactly that bound; a feature 2^-30 of its partner quantises to zero
+    without disturbing the partner; a non-finite gradient still poisons its rows."""
+    import ctypes
+    from rise_sdf_amd import _lib
+    cfg = GRIDS[1]
+    meta_o, n_params = oracle.grid_meta(**cfg)
+    meta_g, _ = _lib.make_grid_meta(**cfg)
+    g = torch.Generator().manual_seed(77)
+    n = 2000
+    x = torch.rand(n, 3, generator=g)
+    dy = torch.randn(n, 32, generator=g) * torch.logspace(-6, 3, n)[:, None]       # nine decades of row magnitudes
+    dy[::7, 1::2] *= 2.0 ** -30                                                        # feature 1 far below feature 0
+    L = _lib.lib()
+
+    def binned(dyt):
+        nbytes = int(L.rsdf_hashgrid_scatter_binned_scratch_bytes(ctypes.byref(meta_g), n, 16))
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        got = torch.zeros(n_params, device=dev)
+        dyd = dyt.to(dev).contiguous()
+        assert L.rsdf_hashgrid_scatter_binned(0, _lib.ptr(x.to(dev)), _lib.ptr(dyd), 32, 0, None, ctypes.byref(meta_g), n, 16,
+                                              _lib.ptr(got), _lib.ptr(scratch), nbytes, _lib.stream_ptr()) == 0
+        return got.cpu()
+
+    got = binned(dy)
+    t = torch.zeros(n_params, dtype=torch.float64, requires_grad=True)
+    (oracle.hashgrid_encode(x, t, meta_o).double() * dy.double()).sum().backward()
+    ref = t.grad.clone()
+    big = torch.maximum(dy[:, 0::2].abs(), dy[:, 1::2].abs()).repeat_interleave(2, dim=1)    # max(|d0|, |d1|) per level
+    t.grad = None
+    (oracle.hashgrid_encode(x, t, meta_o).double() * big.double()).sum().backward()
+    bound = t.grad * 2.0 ** -19.6 + 1e-37
+    assert bool(((got.double() - ref).abs() <= bound).all()), float(((got.double() - ref).abs() / bound).max())
+    assert float((got.double() - ref).abs().max()) > 0            # (it IS a quantised format: not bit-equal to fp64)
+    dy_bad = dy.clone()
+    dy_bad[5, 4] = float("inf")
+    bad = binned(dy_bad)
+    assert int(torch.isnan(bad).sum()) >= 8 and int(torch.isnan(bad).sum()) <= 16     # the 8 corners of level 2, both features
 
 
 def test_large_hashmap_backward_falls_back_to_atomics(dev, ops):

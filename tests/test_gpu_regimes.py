@@ -181,7 +181,7 @@ def test_hash_backward_queue_overflow_path(dev, qscale, tmp_path):
     line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][-1].split()
     err, scale, nz_g, nz_o = float(line[1]), float(line[2]), int(line[3]), int(line[4])
     assert err < 2e-5 * scale + 1e-7, (err, scale)
-    assert nz_g == nz_o
+    assert abs(nz_g - nz_o) <= max(4, int(2e-5 * nz_o))     # (block-float queue records: test_gpu_ops._same_zero_pattern)
 
 
 def test_bench_two_ranks_on_one_gpu(dev):
