@@ -23,6 +23,23 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 constexpr int S_WAVES = 8;                 // two waves per SIMD
 constexpr int S_THREADS = S_WAVES * 64;
+// Column steps whose loads are issued before the first is consumed (round 4; tools/bench_linear.py, 8 M rows, kernels alone):
+// the row loops are bound by load latency at two to four waves per SIMD, not by the matrix pipe (28 % busy at 128 x 128).
+//   forward     1 -> 4 steps:  35x64 1.11 -> 0.99 ms, 64x64 1.17 -> 0.99, 84x128 2.53 -> 1.97, 128x128 2.49 -> 2.35, 128x6 0.96 -> 0.87
+//   input grad  1 -> 4 steps:  35x64 2.38 -> 2.18, 64x64 2.11 -> 1.92, 64x49 (unaligned rows) 4.80 -> 3.16, 84x128 4.06 -> 3.64
+// (8 steps in the forward: no further gain; the wider variants run at one workgroup per CU and are still faster.)
+#ifndef RSDF_LIN_KSU
+#define RSDF_LIN_KSU 4
+#endif
+#ifndef RSDF_LIN_KSU_BI
+#define RSDF_LIN_KSU_BI 4
+#endif
+// Weight gradient of a layer with K <= 64 input columns: capped at 128 registers (24 bytes of scratch) so that two
+// workgroups share a CU: 1.14 -> 0.83 ms (35x64), 1.19 -> 0.91 (64x64).  The wide instantiations spill badly under the same
+// cap (10-15 ms) and keep one workgroup per CU.
+#ifndef RSDF_BWDW_OCC
+#define RSDF_BWDW_OCC 4
+#endif
 
 // LDS weight image (16-byte units): [part 3][out tile OT][k-step KS][hf 2][c 32], then OT*32 floats of bias
 __device__ __forceinline__ f32x16 mma6s(const u32x4 *__restrict__ wa, int part_stride, const Frag3 &b, f32x16 c)
@@ -85,13 +102,23 @@ linear_fwd_kernel(const float *__restrict__ x, int ldx, const float *__restrict_
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = bias[32 * t + (r & 3) + 8 * (r >> 2) + 4 * hf];
-        for (int ks = 0; ks < KS; ++ks) {
-            float v[8];
-            load8(xr, 16 * ks + 8 * hf, ok ? K : 0, vx, v);
-            const Frag3 xb = split_frag(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+        // RSDF_LIN_KSU k-steps of the row are requested before the first of them is consumed: the wave holds KSU x 32 bytes
+        // per lane in flight instead of 32 (the loop is bound by load latency at two workgroups per CU; a k-step beyond K
+        // issues no load)
+        for (int ks0 = 0; ks0 < KS; ks0 += RSDF_LIN_KSU) {
+            float v[RSDF_LIN_KSU][8];
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-                acc[t] = mma6s(wl + ((t * KS + ks) * 2 + hf) * 32 + c, part, xb, acc[t]);
+            for (int u = 0; u < RSDF_LIN_KSU; ++u) load8(xr, 16 * (ks0 + u) + 8 * hf, ok ? K : 0, vx, v[u]);
+#pragma unroll
+            for (int u = 0; u < RSDF_LIN_KSU; ++u) {
+                const int ks = ks0 + u;
+                if (ks < KS) {   // (uniform)
+                    const Frag3 xb = split_frag(v[u][0], v[u][1], v[u][2], v[u][3], v[u][4], v[u][5], v[u][6], v[u][7]);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        acc[t] = mma6s(wl + ((t * KS + ks) * 2 + hf) * 32 + c, part, xb, acc[t]);
+                }
+            }
         }
         if (!ok) continue;
         float *yr = y + row * (int64_t)ldy;
@@ -150,31 +177,42 @@ linear_bwd_input_kernel(const float *dy, const float *__restrict__ y, int lddy,
         for (int t = 0; t < JT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-        for (int ns = 0; ns < NS; ++ns) {
-            const int kk = 16 * ns + 8 * hf;
-            float v[8];
-            load8(dy + rbase, kk, ok ? N : 0, vz, v);
-            if (act != RSDF_ACT_NONE) {
-                float yv[8];
-                load8(y + rbase, kk, ok ? N : 0, vz, yv);
+        // RSDF_LIN_KSU_BI column steps are requested before the first is consumed (dz may alias dy, so the compiler cannot
+        // move a step's loads above the previous step's stores itself; a step only stores the columns it has loaded)
+        for (int ns0 = 0; ns0 < NS; ns0 += RSDF_LIN_KSU_BI) {
+            float vv[RSDF_LIN_KSU_BI][8], yy[RSDF_LIN_KSU_BI][8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] *= act_bwd_from_y(yv[j], act);
+            for (int u = 0; u < RSDF_LIN_KSU_BI; ++u) {
+                const int kk = 16 * (ns0 + u) + 8 * hf;
+                load8(dy + rbase, kk, ok ? N : 0, vz, vv[u]);
+                if (act != RSDF_ACT_NONE) load8(y + rbase, kk, ok ? N : 0, vz, yy[u]);
             }
-            if (dz != nullptr && ok) {
-                if (vz && kk + 8 <= N) {
-                    *reinterpret_cast<float4 *>(dz + rbase + kk) = make_float4(v[0], v[1], v[2], v[3]);
-                    *reinterpret_cast<float4 *>(dz + rbase + kk + 4) = make_float4(v[4], v[5], v[6], v[7]);
-                } else {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (kk + j < N) dz[rbase + kk + j] = v[j];
+            for (int u = 0; u < RSDF_LIN_KSU_BI; ++u) {
+                const int ns = ns0 + u;
+                if (ns >= NS) break;   // (uniform)
+                const int kk = 16 * ns + 8 * hf;
+                float (&v)[8] = vv[u];
+                if (act != RSDF_ACT_NONE) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] *= act_bwd_from_y(yy[u][j], act);
                 }
-            }
-            if (dx) {
-                const Frag3 zb = split_frag(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+                if (dz != nullptr && ok) {
+                    if (vz && kk + 8 <= N) {
+                        *reinterpret_cast<float4 *>(dz + rbase + kk) = make_float4(v[0], v[1], v[2], v[3]);
+                        *reinterpret_cast<float4 *>(dz + rbase + kk + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                    } else {
 #pragma unroll
-                for (int t = 0; t < JT; ++t)
-                    acc[t] = mma6s(wl + ((t * NS + ns) * 2 + hf) * 32 + c, part, zb, acc[t]);
+                        for (int j = 0; j < 8; ++j)
+                            if (kk + j < N) dz[rbase + kk + j] = v[j];
+                    }
+                }
+                if (dx) {
+                    const Frag3 zb = split_frag(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+#pragma unroll
+                    for (int t = 0; t < JT; ++t)
+                        acc[t] = mma6s(wl + ((t * NS + ns) * 2 + hf) * 32 + c, part, zb, acc[t]);
+                }
             }
         }
         if (!dx || !ok) continue;
@@ -204,7 +242,7 @@ linear_bwd_input_kernel(const float *dy, const float *__restrict__ y, int lddy,
 // registers for the whole kernel) and row slab w / NT; workgroups are persistent and flush once with atomics.
 // ------------------------------------------------------------------------------------------------
 template <int KT>
-__global__ void __launch_bounds__(S_THREADS)
+__global__ void __launch_bounds__(S_THREADS, KT <= 2 ? RSDF_BWDW_OCC : 1)
 linear_bwd_weight_kernel(const float *__restrict__ dz, int lddz, const float *__restrict__ x,
                          int ldx, int64_t n, int K, int N, float *__restrict__ dw,
                          float *__restrict__ db)
