@@ -25,6 +25,15 @@ import os
 import sys
 import time
 
+# The step allocates per-chunk buffers of 10-30 GB whose sizes follow the chunk's sample count (+-15 % from chunk to chunk).
+# torch's caching allocator cannot serve a 13.0 GB request from a cached 12.9 GB block, so over the 23 chunks of a view its
+# reserved memory crept up to 276 of the 288 GB (11 GiB free at the lowest point, one secondary variant out of memory);
+# rounding request sizes up to quarter-power-of-two classes makes freed blocks reusable: 169 GiB reserved with two chunks in
+# flight, 85 with one (``config.hbm_gib``).  Expandable segments are not available on this platform.  A value from the
+# environment wins.
+os.environ.setdefault("PYTORCH_HIP_ALLOC_CONF", "roundup_power2_divisions:4")
+os.environ.setdefault("PYTORCH_CUDA_ALLOC_CONF", os.environ["PYTORCH_HIP_ALLOC_CONF"])
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -86,6 +95,41 @@ def side_streams(dev, n):
     if key not in _STREAMS:
         _STREAMS[key] = [torch.cuda.Stream(device=dev) for _ in range(n)]
     return _STREAMS[key]
+
+
+class HbmWatch:
+    """Free device memory sampled from a second thread while a measurement runs: ``report()`` -> GiB free before, at the
+    lowest point, and what torch's caching allocator had reserved then (the rest is outside it: code objects, kernel scratch).
+    The c1 step allocates per-chunk buffers whose sizes follow the chunk's sample count; the allocator's reserved memory is
+    what decides whether two chunks in flight fit the 288 GB."""
+
+    def __init__(self, dev):
+        import threading
+        self.dev, self.stop = dev, False
+        self.free0 = self.lo = torch.cuda.mem_get_info(dev)[0]
+        self.reserved = torch.cuda.memory_reserved(dev)
+        self.th = threading.Thread(target=self._poll, daemon=True)
+
+    def _poll(self):
+        while not self.stop:
+            f = torch.cuda.mem_get_info(self.dev)[0]
+            if f < self.lo:
+                self.lo, self.reserved = f, torch.cuda.memory_reserved(self.dev)
+            time.sleep(0.005)
+
+    def __enter__(self):
+        self.th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop = True
+        self.th.join()
+        return False
+
+    def report(self):
+        g = 2.0 ** 30
+        return {"free_before": round(self.free0 / g, 1), "min_free": round(self.lo / g, 1),
+                "allocator_reserved_then": round(self.reserved / g, 1)}
 
 
 def run_step(model, rays, jitter, cot, chunk, streams=1):
@@ -399,6 +443,7 @@ def secondary_measurements(dev, args, rays, jitter, cot):
     step at the reference's 262,144-samples operating point.  Untimed for ``value``; each entry is guarded so that a
     failure is recorded instead of losing the headline line."""
     import gc
+    from rise_sdf_amd import _lib as _lib_mod
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     extras = {}
 
@@ -408,14 +453,19 @@ def secondary_measurements(dev, args, rays, jitter, cot):
         if only and name not in only:
             return
         gc.collect()
+        torch.cuda.synchronize()
+        _lib_mod.free_workspaces()
         torch.cuda.empty_cache()
+        # HBM footprint of the variant (HbmWatch)
         t0 = time.perf_counter()
-        try:
-            extras[name] = fn()
-            if isinstance(extras[name], dict):
-                extras[name]["wall_s"] = round(time.perf_counter() - t0, 1)
-        except Exception as e:   # noqa: BLE001  (recorded, not swallowed: the key carries the error)
-            extras[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        with HbmWatch(dev) as hw:
+            try:
+                extras[name] = fn()
+            except Exception as e:   # noqa: BLE001  (recorded, not swallowed: the key carries the error)
+                extras[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        if isinstance(extras[name], dict):
+            extras[name]["wall_s"] = round(time.perf_counter() - t0, 1)
+            extras[name]["hbm_gib"] = hw.report()
 
     def c1_variant(hidden, chunk, n_rays=None, fused=True, steps=1, warmup=1, precision="fp32", streams=None):
         a = argparse.Namespace(hidden=hidden, precision=precision)
@@ -595,9 +645,10 @@ def main():
 
     # per-entry-point HIP events inside the timed region only when the step runs on one stream: with two chunks in flight
     # those times overlap and are not used (the roofline object then comes from a one-stream pass below)
-    res = measure_c1(model, rays, jitter, cot, args.chunk, args.steps, args.warmup, world, buckets,
-                     timing=(rank == 0 and not args.no_kernel_timing and (args.streams == 1 or args.time_overlapped)),
-                     streams=args.streams)
+    with HbmWatch(dev) as hbm_watch:
+        res = measure_c1(model, rays, jitter, cot, args.chunk, args.steps, args.warmup, world, buckets,
+                         timing=(rank == 0 and not args.no_kernel_timing and (args.streams == 1 or args.time_overlapped)),
+                         streams=args.streams)
     dt, samples = res["dt"], res["samples"]
 
     tt = torch.tensor([dt, float(samples)], dtype=torch.float64, device=dev)
@@ -664,7 +715,7 @@ def main():
                        "rccl_ranks": torch.distributed.get_world_size() if world > 1 else 1,
                        "dist_backend": torch.distributed.get_backend() if world > 1 else None,
                        "rays_per_gpu": n_rays, "chunk_rays": args.chunk, "hip_streams": args.streams,
-                       "samples_per_step": samples / args.steps,
+                       "samples_per_step": samples / args.steps, "hbm_gib": hbm_watch.report(),
                        "field_evals_per_sec": 7 * samples / dt, "parallelism": f"ray-parallel x{world}"},
             "roofline": roof, "cpu_baseline": cpu, "kernel_breakdown": breakdown,
         }

@@ -270,6 +270,45 @@ def stream_ptr():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# ---- transient workspaces -----------------------------------------------------------------------------------------------
+# The fused SDF field's backward needs three large buffers that live only inside one backward call: the gradient planes
+# (896 B per sample), the hash backward's record queues (~1.9 KB per sample) and d(h2) (4 H B per sample) -- 48 of the ~88
+# GB a 28672-ray chunk allocates.  Their sizes follow the chunk's sample count, which differs from chunk to chunk, and
+# torch's caching allocator cannot reuse a cached 12.9 GB block for a 13.0 GB request: over the 23 chunks of a view its
+# reserved memory grew to 257-276 GiB of the 288 (measured: bench.py ``secondary.*.hbm_gib``), one variant of the default
+# bench run ended in an out-of-memory error after a size change elsewhere, and expandable segments are not available on this
+# platform.  These buffers therefore come from one growing arena per (tag, device, stream): kernels of a stream run in
+# order, so the next backward call on that stream may overwrite them.  Only buffers that are produced AND consumed inside one
+# autograd backward call may use it -- anything saved for a later call stays with the allocator.
+_WORKSPACES = {}
+
+
+def workspace(tag: str, nbytes: int, device) -> "torch.Tensor":
+    """-> uint8 [nbytes] view of the (tag, device, current stream) arena, valid until the next request with this key."""
+    import torch
+    dev = torch.device(device)
+    key = (tag, dev.index if dev.index is not None else torch.cuda.current_device(), int(stream_ptr().value or 0))
+    buf = _WORKSPACES.get(key)
+    if buf is None or buf.numel() < nbytes:
+        _WORKSPACES.pop(key, None)
+        buf = None                                            # (released before the larger one is requested)
+        buf = torch.empty(int(nbytes * 1.25) + (1 << 20), dtype=torch.uint8, device=dev)
+        _WORKSPACES[key] = buf
+    return buf[:nbytes]
+
+
+def workspace_f32(tag: str, shape, device) -> "torch.Tensor":
+    n = 1
+    for d in shape:
+        n *= int(d)
+    return workspace(tag, 4 * n, device).view(__import__("torch").float32).view(*shape)
+
+
+def free_workspaces():
+    """Releases the arenas (tcnn.free_temporary_memory() of the drop-in calls this)."""
+    _WORKSPACES.clear()
+
+
 def require_device(*tensors):
     """Same contract as the reference's CHECK_INPUT (helpers_cuda.h:20-25): device + contiguous."""
     for t in tensors:

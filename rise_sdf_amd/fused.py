@@ -135,11 +135,12 @@ class _SdfFieldFD7(torch.autograd.Function):
             else g_sdf7t.detach().to(torch.float32).contiguous()
         gf = None if g_feature is None else g_feature.detach().to(torch.float32).contiguous()
         need_table = ctx.needs_input_grad[1]
-        d_planes = torch.empty(Lv, 7, S, 2, dtype=torch.float32, device=dev) if need_table else None
+        # (backward-transient buffers come from the per-stream arena, _lib.workspace: sizes follow the chunk's sample count)
+        d_planes = L.workspace_f32("fd7.d_planes", (Lv, 7, S, 2), dev) if need_table else None
         dw0, db0 = torch.zeros_like(w0), torch.zeros_like(b0)
         dw1, db1 = torch.zeros_like(w1), torch.zeros_like(b1)
         dw2, db2 = torch.zeros_like(w2), torch.zeros_like(b2)
-        dh2c = torch.empty(S, H, dtype=torch.float32, device=dev) if gf is not None else None
+        dh2c = L.workspace_f32("fd7.dh2c", (S, H), dev) if gf is not None else None
         if ctx.x2:
             absmax = torch.empty(2, dtype=torch.int32, device=dev)
             check(lib().rsdf_sdfmlp_fd7_bwd_x2(ptr(planes), ctx.x2, Lv, ctx.n_active, H, N2, ptr(w0), ptr(b0), ptr(w1), ptr(b1),
@@ -163,7 +164,7 @@ class _SdfFieldFD7(torch.autograd.Function):
                                                                    ctx.n_active, ctx.eps_unit))
             if nbytes < 0:
                 raise L.RiseSdfHipError("hashgrid_bwd_fd7: unsupported level layout")
-            scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            scratch = L.workspace("fd7.queues", nbytes, dev)
             if ctx.pts is not None:
                 check(lib().rsdf_hashgrid_bwd_fd7_pts(ptr(ctx.pts), float(ctx.radius), float(ctx.eps), ptr(d_planes),
                                                       ctypes.byref(ctx.meta), S, ctx.n_active, ctx.eps_unit, ptr(dt),

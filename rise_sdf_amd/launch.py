@@ -31,6 +31,20 @@ REGISTRY_NAMES = ("volume-sdf", "neus", "split-mixed-occ", "volume-mixed-mip-spl
                   "envlight-mip-cube")
 
 
+def _allocator_size_classes():
+    """Full-image renders allocate per-chunk buffers whose sizes follow the chunk's sample count; without size classes the
+    caching allocator's reserved memory creeps towards the whole HBM ("HBM footprint").  Same setting as
+    bench.py; a PYTORCH_HIP_ALLOC_CONF / PYTORCH_CUDA_ALLOC_CONF from the environment wins."""
+    if os.environ.get("PYTORCH_HIP_ALLOC_CONF") or os.environ.get("PYTORCH_CUDA_ALLOC_CONF"):
+        return
+    try:
+        import torch
+        setter = getattr(torch._C, "_accelerator_setAllocatorSettings", None) or torch.cuda.memory._set_allocator_settings
+        setter("roundup_power2_divisions:4")
+    except Exception:   # noqa: BLE001  (an allocator without this knob: nothing to do)
+        pass
+
+
 def prepare(script: str, fused: bool = True):
     """Everything ``main`` does before handing over to the script; returns the reference root."""
     from . import dropin
@@ -41,6 +55,7 @@ def prepare(script: str, fused: bool = True):
     if root not in sys.path[:1]:
         sys.path.insert(0, root)            # `python launch.py` puts the script's directory first
     dropin.install()
+    _allocator_size_classes()
     if fused:
         import importlib
         ref_models = importlib.import_module("models")        # the reference's registry module

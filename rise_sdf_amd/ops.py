@@ -519,7 +519,7 @@ class _HashGrid(torch.autograd.Function):
                                                                    ctx.n_active, float(ctx.fd7)))
             if nbytes < 0:
                 raise L.RiseSdfHipError("hashgrid_bwd_fd7: unsupported level layout")
-            scratch = torch.empty(nbytes, dtype=torch.uint8, device=xf.device)
+            scratch = L.workspace("fd7.queues", nbytes, xf.device)
             # this entry point keeps the interleaved [S,7] row layout of the reference-shaped API;
             # re-lay out to the tap-major planes the stencil kernels consume (the fused field path
             # produces them directly)
@@ -564,7 +564,7 @@ def _scatter_binned(mode, xf, g, ld, col, gd, meta, n_active, dt):
     nbytes = int(lib().rsdf_hashgrid_scatter_binned_scratch_bytes(ctypes.byref(meta), n, n_active))
     if nbytes < 0:
         raise L.RiseSdfHipError("hashgrid_scatter_binned: unsupported level layout")
-    scratch = torch.empty(nbytes, dtype=torch.uint8, device=xf.device)
+    scratch = L.workspace("scatter.queues", nbytes, xf.device)       # (consumed inside this call)
     check(lib().rsdf_hashgrid_scatter_binned(mode, ptr(xf), ptr(g), ld, col, ptr(gd), ctypes.byref(meta), n, n_active,
                                              ptr(dt), ptr(scratch), nbytes, stream_ptr()), "hashgrid_scatter_binned")
 

@@ -103,6 +103,8 @@ _OTYPES = {"hashgrid": HashGridEncoding, "grid": HashGridEncoding,
 
 
 def free_temporary_memory():
-    """tcnn keeps a private scratch arena; this build allocates scratch through torch's caching
-    allocator, so there is nothing to release."""
+    """tcnn keeps a private scratch arena; here the backward-transient workspaces of the fused field and of the binned
+    table scatter do (rise_sdf_amd._lib.workspace): released here, everything else goes through torch's caching allocator."""
+    from . import _lib
+    _lib.free_workspaces()
     return None
