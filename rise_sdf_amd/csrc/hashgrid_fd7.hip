@@ -653,8 +653,14 @@ __device__ __forceinline__ void emit_round(uint32_t (&ridx)[ROUND_RECS],
                 queue[(int64_t)b * cap + gpos] = PairRec{entry_of(r0.idx, interleaved) | (e1 << 16), r0.v0, r0.v1,
                                                         two ? r1.v0 : 0.f, two ? r1.v1 : 0.f};
 #else
-                queue[(int64_t)b * cap + gpos] = PairRec{pack_rec(entry_of(r0.idx, interleaved), r0.v0, r0.v1),
-                                                        two ? pack_rec(entry_of(r1.idx, interleaved), r1.v0, r1.v1) : 0ull};
+                const PairRec pr{pack_rec(entry_of(r0.idx, interleaved), r0.v0, r0.v1),
+                                 two ? pack_rec(entry_of(r1.idx, interleaved), r1.v0, r1.v1) : 0ull};
+#ifdef RSDF_Q_NT_STORE
+                __builtin_nontemporal_store(pr.r0, &queue[(int64_t)b * cap + gpos].r0);
+                __builtin_nontemporal_store(pr.r1, &queue[(int64_t)b * cap + gpos].r1);
+#else
+                queue[(int64_t)b * cap + gpos] = pr;
+#endif
 #endif
             } else {  // queue full (capacity carries slack; never drop a contribution)
                 atomicAdd(dlevel + 2 * (size_t)r0.idx, r0.v0);
@@ -1010,7 +1016,16 @@ fd7_reduce_kernel(const rsdf_grid_meta meta, const LevelPlan plan, const PairRec
 #ifdef RSDF_REC_FP32
             rec[u] = i < r1 ? q[i] : PairRec{0u, 0.f, 0.f, 0.f, 0.f};
 #else
+#ifdef RSDF_Q_NT_LOAD
+            if (i < r1) {
+                rec[u].r0 = __builtin_nontemporal_load(&q[i].r0);
+                rec[u].r1 = __builtin_nontemporal_load(&q[i].r1);
+            } else {
+                rec[u] = PairRec{0ull, 0ull};
+            }
+#else
             rec[u] = i < r1 ? q[i] : PairRec{0ull, 0ull};
+#endif
 #endif
         }
 #pragma unroll
@@ -1069,7 +1084,10 @@ int make_plan(const rsdf_grid_meta *meta, int64_t S, int n_active, float eps_uni
     double total_exp = 0.0;
     for (int l = 0; l < n_active; ++l) total_exp += (double)S * expected_records(meta->scale[l], eps_unit);
     // aim at ~3 reducer workgroups per CU, each with the same number of records
-    double per_wg = total_exp / 768.0;
+#ifndef RSDF_R_WGS
+#define RSDF_R_WGS 768
+#endif
+    double per_wg = total_exp / (double)RSDF_R_WGS;
     if (per_wg < 65536.0) per_wg = 65536.0;
     for (int l = 0; l < n_active; ++l) {
         const uint32_t size = meta->size[l];
