@@ -349,8 +349,15 @@ __device__ __forceinline__ void x2_store_features(unsigned char *p, bool odd, fl
 {
     unsigned h, lo;
     x2_split(f0 * X2_SCALE, f1 * X2_SCALE, h, lo);
+    // the image (1008 B per sample, 16 GB per launch) is read back by the MLP forward a whole launch later: streaming stores
+    // leave the L2 / MALL to the table and the centres (gather 12.9 -> 12.1 ms per launch; -DRSDF_X2_PLAIN_IMAGE for A/B)
+#ifndef RSDF_X2_PLAIN_IMAGE
+    __builtin_nontemporal_store(x2_pair_exchange(h, odd), reinterpret_cast<unsigned *>(p));
+    if (parts == 2) __builtin_nontemporal_store(x2_pair_exchange(lo, odd), reinterpret_cast<unsigned *>(p + X2_PART_B));
+#else
     *reinterpret_cast<unsigned *>(p) = x2_pair_exchange(h, odd);
     if (parts == 2) *reinterpret_cast<unsigned *>(p + X2_PART_B) = x2_pair_exchange(lo, odd);    // (uniform)
+#endif
 }
 // unit-cube coordinates of the 7 stencil points, as rsdf_fd_points writes them (neus.hip fd_points_kernel), * scale + offset,
 // and the bias column: written as two more "levels" -- (x, y) into columns 32 / 33 and (z, 1) into 34 / 35 -- through the
@@ -562,6 +569,17 @@ struct StamperP {
 #define RSDF_PSTAMP(st, i)
 #endif
 
+// d_planes are read once per launch by phase 1 (the displaced taps of phase 2 re-read a few of them from L2)
+__device__ __forceinline__ float2 ld_dplane(const float2 *p)
+{
+#ifdef RSDF_DPL_NT_LOAD
+    const unsigned long long v = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(p));
+    return make_float2(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
+#else
+    return *p;
+#endif
+}
+
 // ------------------------------------------------------------------------------------------------
 // backward: produce
 // ------------------------------------------------------------------------------------------------
@@ -655,7 +673,8 @@ __device__ __forceinline__ void emit_round(uint32_t (&ridx)[ROUND_RECS],
 #else
                 const PairRec pr{pack_rec(entry_of(r0.idx, interleaved), r0.v0, r0.v1),
                                  two ? pack_rec(entry_of(r1.idx, interleaved), r1.v0, r1.v1) : 0ull};
-#ifdef RSDF_Q_NT_STORE
+    // (streaming stores: the queues are read back by the reducer a whole launch later; producer 21.2 -> 20.5 ms)
+#ifndef RSDF_Q_PLAIN_STORE
                 __builtin_nontemporal_store(pr.r0, &queue[(int64_t)b * cap + gpos].r0);
                 __builtin_nontemporal_store(pr.r1, &queue[(int64_t)b * cap + gpos].r1);
 #else
@@ -735,7 +754,7 @@ fd7_produce_kernel(const TapSrc src, const float2 *__restrict__ dplanes,
         load_stencil<DERIVE>(src, S, s, g.scale, cf);
         {
             c0 = cf[0];
-            const float2 gr = pg[0];
+            const float2 gr = ld_dplane(pg);
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const float w = corner_weight(c0, c);
@@ -747,7 +766,7 @@ fd7_produce_kernel(const TapSrc src, const float2 *__restrict__ dplanes,
         for (int t = 1; t < 7; ++t) {
             const int a = (t - 1) >> 1;
             const CellFrac ct = cf[t];
-            const float2 gr = pg[(int64_t)t * S];
+            const float2 gr = ld_dplane(pg + (int64_t)t * S);
             const int32_t da = (int32_t)(ct.c[a] - c0.c[a]);
             if (da == 0) {
 #pragma unroll
@@ -1085,7 +1104,7 @@ int make_plan(const rsdf_grid_meta *meta, int64_t S, int n_active, float eps_uni
     for (int l = 0; l < n_active; ++l) total_exp += (double)S * expected_records(meta->scale[l], eps_unit);
     // aim at ~3 reducer workgroups per CU, each with the same number of records
 #ifndef RSDF_R_WGS
-#define RSDF_R_WGS 768
+#define RSDF_R_WGS 1536     // (768: 6.56, 1536: 6.11, 2048: 6.33, 3072: 6.11 ms per 18.4 M-sample launch)
 #endif
     double per_wg = total_exp / (double)RSDF_R_WGS;
     if (per_wg < 65536.0) per_wg = 65536.0;

@@ -253,14 +253,21 @@ template <int NP>
 __device__ __forceinline__ void fetch_x2(PreX2 &pre, const SrcX2 &src, int64_t tile, int tap, int lane)
 {
     const unsigned char *tb = src.x2 + tile * x2_tile_b<NP>() + tap * x2_tap_b<NP>() + lane * 16;
-    pre.a0 = *reinterpret_cast<const u32x4 *>(tb);
-    pre.a1 = *reinterpret_cast<const u32x4 *>(tb + 1024);
-    pre.a2 = *reinterpret_cast<const u32x4 *>(tb + 2048);
+// (non-temporal loads of the image, here and in the backward's LDS-DMA: measured, no effect -- the streaming STORES are what matter)
+#ifdef RSDF_X2_NT_LOAD
+#define RSDF_LDX2(p) __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p))
+#else
+#define RSDF_LDX2(p) (*reinterpret_cast<const u32x4 *>(p))
+#endif
+    pre.a0 = RSDF_LDX2(tb);
+    pre.a1 = RSDF_LDX2(tb + 1024);
+    pre.a2 = RSDF_LDX2(tb + 2048);
     if (NP == 2) {
-        pre.b0 = *reinterpret_cast<const u32x4 *>(tb + X2_PART_B);
-        pre.b1 = *reinterpret_cast<const u32x4 *>(tb + X2_PART_B + 1024);
-        pre.b2 = *reinterpret_cast<const u32x4 *>(tb + X2_PART_B + 2048);
+        pre.b0 = RSDF_LDX2(tb + X2_PART_B);
+        pre.b1 = RSDF_LDX2(tb + X2_PART_B + 1024);
+        pre.b2 = RSDF_LDX2(tb + X2_PART_B + 2048);
     }
+#undef RSDF_LDX2
 }
 template <int NP>
 __device__ __forceinline__ void store_x2(unsigned char *img, const PreX2 &pre, int lane)
@@ -555,8 +562,13 @@ __device__ __forceinline__ void dma_one(unsigned char *img, const unsigned char 
     const int part = i / 3, b = i - 3 * part;
     const unsigned char *gp = tb + part * X2_PART_B + b * 1024 + lane * 16;
     unsigned char *dst = img + part * QX_PART + b * 1024;
-    if (b < 2) __builtin_amdgcn_global_load_lds((glob_void *)gp, (lds_void *)dst, 16, 0, 0);
-    else if (lane < 16) __builtin_amdgcn_global_load_lds((glob_void *)gp, (lds_void *)dst, 16, 0, 0);
+#ifdef RSDF_X2_NT_DMA
+    constexpr int AUX = 2;     // cache policy nt (the SLC position of the aux operand): the image is read once
+#else
+    constexpr int AUX = 0;
+#endif
+    if (b < 2) __builtin_amdgcn_global_load_lds((glob_void *)gp, (lds_void *)dst, 16, 0, AUX);
+    else if (lane < 16) __builtin_amdgcn_global_load_lds((glob_void *)gp, (lds_void *)dst, 16, 0, AUX);
 }
 template <int NW, int NP>
 __device__ __forceinline__ void dma_tile(unsigned char *img, const SrcX2 &src, int64_t tile, int tap, int ws, int lane)
@@ -564,6 +576,18 @@ __device__ __forceinline__ void dma_tile(unsigned char *img, const SrcX2 &src, i
     const unsigned char *tb = src.x2 + tile * x2_tile_b<NP>() + tap * x2_tap_b<NP>();
     if (ws < 3 * NP) dma_one(img, tb, ws, lane);
     if (NW == 4 && NP == 2 && ws < 2) dma_one(img, tb, ws + 4, lane);
+}
+// d_planes (896 B per sample, 13-17 GB per launch) are written once here and read once by the hash backward's producer, a
+// whole launch later: a streaming (non-temporal) store keeps them out of the caches' way (22.0 -> 21.6 ms per launch;
+// -DRSDF_X2_PLAIN_DPLANES for A/B)
+__device__ __forceinline__ void st_dplane(float *p, float a, float b)
+{
+#ifndef RSDF_X2_PLAIN_DPLANES
+    __builtin_nontemporal_store(((unsigned long long)__float_as_uint(b) << 32) | (unsigned long long)__float_as_uint(a),
+                                reinterpret_cast<unsigned long long *>(p));
+#else
+    *reinterpret_cast<float2 *>(p) = float2{a, b};
+#endif
 }
 // 2^e with |v| 2^e < 2^14 for every |v| <= bound (bound = 0, inf or nan: 1)
 __device__ __forceinline__ float grad_scale(float bound)
@@ -753,9 +777,9 @@ bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
                 if (d_planes != nullptr && row < src.S) {
                     const int lev = 8 * mt + 2 * g;
                     if (lev < src.n_active)
-                        *reinterpret_cast<float2 *>(d_planes + (((int64_t)lev * 7 + tap) * src.S + row) * 2) = float2{dx[0] * k_dx, dx[1] * k_dx};
+                        st_dplane(d_planes + (((int64_t)lev * 7 + tap) * src.S + row) * 2, dx[0] * k_dx, dx[1] * k_dx);
                     if (lev + 1 < src.n_active)
-                        *reinterpret_cast<float2 *>(d_planes + (((int64_t)(lev + 1) * 7 + tap) * src.S + row) * 2) = float2{dx[2] * k_dx, dx[3] * k_dx};
+                        st_dplane(d_planes + (((int64_t)(lev + 1) * 7 + tap) * src.S + row) * 2, dx[2] * k_dx, dx[3] * k_dx);
                 }
             }
             {
