@@ -154,3 +154,53 @@ def test_fused_mlp_is_fp32_accurate(dev):
         fd = lambda s: 0.5 * (s.view(-1, 7)[:, 1::2] - s.view(-1, 7)[:, 2::2]) / eps   # noqa: E731
         e_n = float((fd(fs) - fd(ref)).abs().max())
         assert e_n < 2.0 * e_fused / eps + 1e-6 and e_n < 2e-3, (hidden, e_n, e_fused / eps)
+
+
+def test_transient_workspaces(dev):
+    """_lib.workspace: one growing arena per (tag, device, stream) for buffers produced and consumed inside one backward
+    call (the fused field's gradient planes, record queues, d(h2)): a second request of the same or a smaller size returns
+    the same memory, a larger one a new buffer, another stream its own; tcnn.free_temporary_memory() of the drop-in
+    releases them; the fused field's table gradient does not depend on what an earlier, larger call left in the arena."""
+    from rise_sdf_amd import _lib, tinycudann
+    _lib.free_workspaces()
+    a = _lib.workspace("t.test", 1 << 20, dev)
+    assert a.dtype == torch.uint8 and a.numel() == 1 << 20 and a.data_ptr() % 256 == 0
+    b = _lib.workspace("t.test", 1 << 19, dev)
+    assert b.data_ptr() == a.data_ptr() and b.numel() == 1 << 19
+    f = _lib.workspace_f32("t.test", (16, 7, 100, 2), dev)
+    assert f.dtype == torch.float32 and f.shape == (16, 7, 100, 2) and f.data_ptr() == a.data_ptr()
+    c = _lib.workspace("t.test", 1 << 24, dev)
+    assert c.numel() == 1 << 24
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        d = _lib.workspace("t.test", 1 << 20, dev)
+    assert d.data_ptr() != c.data_ptr()
+    assert len([k for k in _lib._WORKSPACES if k[0] == "t.test"]) == 2
+    tinycudann.free_temporary_memory()
+    assert not _lib._WORKSPACES
+
+    # a backward that finds a larger call's leftovers in the arena gives what a fresh arena gives
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from helpers import camera_rays
+    import argparse
+    model = bench.build_model(dev, argparse.Namespace(hidden=64))     # (non-zero hash-feature columns in the first layer)
+    rays = camera_rays(48, 48, seed=3).to(dev)
+    u = torch.rand(rays.shape[0], generator=torch.Generator().manual_seed(5)).to(dev)
+
+    def table_grad(n):
+        for p in model.parameters():
+            p.grad = None
+        s0 = (rays.shape[0] - n) // 2                        # (the middle of the view: rays that meet the surface)
+        out = model.forward_(rays[s0:s0 + n], stratified_u=u[s0:s0 + n])
+        (out["opacity"].sum() + out["depth"].sum() + out["comp_normal_raw"].sum()).backward()
+        return model.geometry.encoding.encoding.encoding.params.grad.clone()
+
+    table_grad(2304)                      # the larger call: grows the arenas
+    assert any(k[0].startswith("fd7.") for k in _lib._WORKSPACES)
+    reused = table_grad(500)
+    _lib.free_workspaces()
+    fresh = table_grad(500)
+    scale = float(fresh.abs().max())
+    assert scale > 0 and float((reused - fresh).abs().max()) <= 2e-6 * scale      # (fp32 flush order only)

@@ -151,3 +151,24 @@ def test_launcher_prepares_the_reference_tree():
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d.pop("root") == "/root/reference"
     assert all(v.startswith("rise_sdf_amd.") for v in d.values()), d
+
+
+def test_launcher_allocator_size_classes_respect_the_environment(monkeypatch):
+    """prepare() switches torch's caching allocator to quarter-power-of-two size classes (full-image renders allocate
+    buffers whose sizes follow the chunk's sample count: DESIGN 6, "HBM footprint") -- unless the environment already
+    configures the allocator."""
+    from rise_sdf_amd import launch
+    calls = []
+    import torch
+    name = "_accelerator_setAllocatorSettings"
+    if hasattr(torch._C, name):
+        monkeypatch.setattr(torch._C, name, lambda s: calls.append(s))
+    else:
+        monkeypatch.setattr(torch.cuda.memory, "_set_allocator_settings", lambda s: calls.append(s))
+    monkeypatch.delenv("PYTORCH_HIP_ALLOC_CONF", raising=False)
+    monkeypatch.delenv("PYTORCH_CUDA_ALLOC_CONF", raising=False)
+    launch._allocator_size_classes()
+    assert calls == ["roundup_power2_divisions:4"]
+    monkeypatch.setenv("PYTORCH_HIP_ALLOC_CONF", "max_split_size_mb:512")
+    launch._allocator_size_classes()
+    assert calls == ["roundup_power2_divisions:4"]          # the user's setting wins: nothing more was set
