@@ -183,7 +183,11 @@ int rsdf_hashgrid_bwd(const float *x, const float *dout, const rsdf_grid_meta *m
  *      interpolations from registers; bit-identical to rsdf_hashgrid_fwd on the same points.
  * bwd: merges the taps' contributions in registers, bins them by table slice through LDS and reduces
  *      in LDS: no per-corner global atomics.  eps_unit = eps / (2*radius) only sizes the queues.
- *      scratch >= rsdf_hashgrid_bwd_fd7_scratch_bytes(...) bytes; dtable is accumulated into. */
+ *      scratch >= rsdf_hashgrid_bwd_fd7_scratch_bytes(...) bytes; dtable is accumulated into.
+ *      The queues carry a table entry's two feature gradients as an 8-byte block-float record (20 significant bits for
+ *      the larger value, fp64 accumulation in LDS, one fp32 flush): per entry within 2^-20 of the sum of its records'
+ *      larger components of the exact sum (csrc/hashgrid_fd7.hip PairRec; a library built with -DRSDF_REC_FP32 keeps fp32
+ *      record values at 10 bytes per record). */
 int rsdf_hashgrid_fwd_fd7(const float *x7t, const float *table, const rsdf_grid_meta *meta /*host*/,
                           int64_t n_samples, int n_active_levels, float *planes, void *stream);
 int64_t rsdf_hashgrid_bwd_fd7_scratch_bytes(const rsdf_grid_meta *meta /*host*/, int64_t n_samples,
