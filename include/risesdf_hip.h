@@ -195,6 +195,20 @@ int64_t rsdf_hashgrid_bwd_fd7_scratch_bytes(const rsdf_grid_meta *meta /*host*/,
 int rsdf_hashgrid_bwd_fd7(const float *x7t, const float *dplanes, const rsdf_grid_meta *meta /*host*/,
                           int64_t n_samples, int n_active_levels, float eps_unit, float *dtable,
                           void *scratch, int64_t scratch_bytes, void *stream);
+/* Layout conversions between the reference-shaped tensors of the stencil path and the tap-major buffers above, for callers
+ * that hold the [n, 7] stencil interleaved, as tcnn.Encoding.forward receives it from VolumeSDF.forward
+ * (models/geometry.py:229-244 -> models/network_utils.py:47-59):
+ *   points_tap_major: x7 [n][7][3] -> x7t [7][n][3]
+ *   planes_to_rows:   planes [L][7][n][2] (+ x7 for the xyz columns) -> rows out[(7 s + t)][col_off + 2 l + f], and, with
+ *                     write_xyz, out[..][col_off - 3 + d] = x7 * xyz_scale + xyz_offset; levels >= n_active_levels are zeros
+ *   rows_to_planes:   g[(7 s + t)][col_off + 2 l + f] -> dplanes [L][7][n][2]   (the backward's re-layout)
+ * Pure data movement (bit-identical to the permuted copies they replace). */
+int rsdf_stencil_points_tap_major(const float *x7, int64_t n_samples, float *x7t, void *stream);
+int rsdf_stencil_planes_to_rows(const float *planes, const float *x7, int64_t n_samples, int n_levels, int n_active_levels,
+                                float *out, int ld_out, int col_off, int write_xyz, float xyz_scale, float xyz_offset,
+                                void *stream);
+int rsdf_stencil_rows_to_planes(const float *g, int ld, int col_off, int64_t n_samples, int n_levels, float *dplanes,
+                                void *stream);
 /* The same two kernels with the stencil DERIVED in-kernel from each sample's world-space centre points [n][3]
  * (what rsdf_fd_points returns as `positions`): x +- eps e_k, clamp(-radius, radius), AABB contraction, in exactly
  * rsdf_fd_points' arithmetic (models/geometry.py:229-244), so cells and weights are bit-identical to the x7t form.

@@ -95,6 +95,9 @@ _SIGNATURES = {
     "rsdf_sdfmlp_fd7_supported": [_I, _I, _I],
     "rsdf_x2_rows": [_L],
     "rsdf_x2_bytes": [_L, _I],
+    "rsdf_stencil_points_tap_major": [_P, _L, _P, _P],
+    "rsdf_stencil_planes_to_rows": [_P, _P, _L, _I, _I, _P, _I, _I, _I, _F, _F, _P],
+    "rsdf_stencil_rows_to_planes": [_P, _I, _I, _L, _I, _P, _P],
     "rsdf_hashgrid_fwd_fd7_x2": [_P, _P, _F, _F, _P, ctypes.POINTER(GridMeta), _L, _I, _F, _F, _I, _P, _P],
     "rsdf_sdfmlp_fd7_x2_supported": [_I, _I, _I],
     "rsdf_sdfmlp_fd7_fwd_x2": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P],

@@ -1085,6 +1085,81 @@ fd7_reduce_kernel(const rsdf_grid_meta meta, const LevelPlan plan, const PairRec
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Layout conversions for the reference-shaped entry of the stencil path (tcnn.Encoding.forward on [S, 7] interleaved points,
+// models/geometry.py:229-244 through models/network_utils.py:47-59): rows [7 S][ld] <-> tap-major planes [L][7][S][2], and
+// interleaved points [S][7][3] -> tap-major [7][S][3].  As permuted torch copies these were 30 % of the per-layer route's
+// step (83 launches, 0.9 ms each on a 200 x 200 view); here a workgroup moves 32 samples x 7 taps through an LDS tile
+// whose rows have an odd stride: 256-byte plane runs on one side, the tile's contiguous rows on the other.
+// ------------------------------------------------------------------------------------------------
+constexpr int ST_SAMPLES = 32, ST_ROWS = ST_SAMPLES * 7, ST_THREADS = 256;
+
+__global__ void __launch_bounds__(ST_THREADS)
+stencil_planes_to_rows_kernel(const float2 *__restrict__ planes, const float *__restrict__ x7, int64_t S, int n_levels,
+                              int n_active, float *__restrict__ out, int ld_out, int col_off, int write_xyz, float xyz_scale,
+                              float xyz_offset)
+{
+    extern __shared__ float s_rows[];
+    const int nx = write_xyz ? 3 : 0, tw = nx + 2 * n_levels, stride = tw | 1, c0 = col_off - nx;
+    const int64_t s0 = (int64_t)blockIdx.x * ST_SAMPLES;
+    const int ns = (int)min((int64_t)ST_SAMPLES, S - s0);
+    for (int i = threadIdx.x; i < n_levels * 7 * ST_SAMPLES; i += ST_THREADS) {
+        const int s = i & (ST_SAMPLES - 1), lt = i >> 5, l = lt / 7, t = lt - 7 * l;
+        float2 v = make_float2(0.f, 0.f);
+        if (s < ns && l < n_active) v = planes[((int64_t)l * 7 + t) * S + s0 + s];
+        float *row = s_rows + (s * 7 + t) * stride + nx + 2 * l;
+        row[0] = v.x;
+        row[1] = v.y;
+    }
+    if (write_xyz)
+        for (int i = threadIdx.x; i < ns * 21; i += ST_THREADS) {
+            const int r = i / 3, d = i - 3 * r;
+            s_rows[r * stride + d] = x7[(s0 * 7 + r) * 3 + d] * xyz_scale + xyz_offset;
+        }
+    __syncthreads();
+    const int total = ns * 7 * tw;
+    const float inv_tw = 1.0f / (float)tw;     // i / tw exactly: (i + 0.5) / tw is >= 0.5 / tw from an integer, i < 2^13
+    for (int i = threadIdx.x; i < total; i += ST_THREADS) {
+        const int rr = (int)(((float)i + 0.5f) * inv_tw), c = i - rr * tw;
+        out[(s0 * 7 + rr) * ld_out + c0 + c] = s_rows[rr * stride + c];
+    }
+}
+
+__global__ void __launch_bounds__(ST_THREADS)
+stencil_rows_to_planes_kernel(const float *__restrict__ g, int ld, int col_off, int64_t S, int n_levels,
+                              float2 *__restrict__ dplanes)
+{
+    extern __shared__ float s_rows[];
+    const int tw = 2 * n_levels, stride = tw | 1;
+    const int64_t s0 = (int64_t)blockIdx.x * ST_SAMPLES;
+    const int ns = (int)min((int64_t)ST_SAMPLES, S - s0);
+    const int total = ns * 7 * tw;
+    const float inv_tw = 1.0f / (float)tw;
+    for (int i = threadIdx.x; i < total; i += ST_THREADS) {
+        const int rr = (int)(((float)i + 0.5f) * inv_tw), c = i - rr * tw;
+        s_rows[rr * stride + c] = g[(s0 * 7 + rr) * ld + col_off + c];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_levels * 7 * ST_SAMPLES; i += ST_THREADS) {
+        const int s = i & (ST_SAMPLES - 1), lt = i >> 5, l = lt / 7, t = lt - 7 * l;
+        if (s < ns) {
+            const float *row = s_rows + (s * 7 + t) * stride + 2 * l;
+            dplanes[((int64_t)l * 7 + t) * S + s0 + s] = make_float2(row[0], row[1]);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(ST_THREADS)
+stencil_points_tap_major_kernel(const float *__restrict__ x7, int64_t S, float *__restrict__ x7t)
+{
+    const int64_t o = (int64_t)blockIdx.x * ST_THREADS + threadIdx.x;     // output element [t][s][d]
+    if (o >= 21 * S) return;
+    const int64_t ts = o / 3;
+    const int d = (int)(o - 3 * ts);
+    const int64_t t = ts / S, s = ts - t * S;
+    x7t[o] = x7[(s * 7 + t) * 3 + d];
+}
+
 // Expected records per (sample, level): 8 for the centre cell + 4 per displaced tap, a tap being
 // displaced with probability ~min(1, eps_unit * scale).
 double expected_records(float scale, float eps_unit)
@@ -1349,6 +1424,46 @@ int rsdf_hashgrid_fwd_fd7_pts(const float *points, float radius, float eps, cons
     RSDF_CHECK_ARG(points != nullptr || n_samples <= 0, "hashgrid_fwd_fd7_pts: points is NULL");
     RSDF_CHECK_ARG(radius > 0.f, "hashgrid_fwd_fd7_pts: radius must be > 0");
     return launch_fwd(TapSrc{nullptr, points, radius, eps}, table, meta, n_samples, n_active_levels, planes, stream);
+}
+
+int rsdf_stencil_points_tap_major(const float *x7, int64_t n_samples, float *x7t, void *stream)
+{
+    if (n_samples <= 0) return 0;
+    RSDF_CHECK_ARG(x7 != nullptr && x7t != nullptr, "stencil_points_tap_major: NULL pointer");
+    RSDF_CHECK_ARG((uint64_t)n_samples * 21 < (1ull << 40), "stencil_points_tap_major: too many samples");
+    stencil_points_tap_major_kernel<<<rsdf_blocks(21 * n_samples, ST_THREADS), ST_THREADS, 0, (hipStream_t)stream>>>(x7, n_samples,
+                                                                                                                       x7t);
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_stencil_planes_to_rows(const float *planes, const float *x7, int64_t n_samples, int n_levels, int n_active_levels,
+                                float *out, int ld_out, int col_off, int write_xyz, float xyz_scale, float xyz_offset,
+                                void *stream)
+{
+    if (n_samples <= 0) return 0;
+    RSDF_CHECK_ARG(n_levels >= 1 && n_levels <= RSDF_MAX_LEVELS, "stencil_planes_to_rows: bad level count");
+    RSDF_CHECK_ARG(planes != nullptr && out != nullptr && (!write_xyz || x7 != nullptr), "stencil_planes_to_rows: NULL pointer");
+    RSDF_CHECK_ARG(col_off >= (write_xyz ? 3 : 0) && ld_out >= col_off + 2 * n_levels, "stencil_planes_to_rows: bad row layout");
+    if (n_active_levels < 0 || n_active_levels > n_levels) n_active_levels = n_levels;
+    const int tw = (write_xyz ? 3 : 0) + 2 * n_levels;
+    const size_t lds = (size_t)ST_ROWS * (tw | 1) * sizeof(float);
+    stencil_planes_to_rows_kernel<<<rsdf_blocks(n_samples, ST_SAMPLES), ST_THREADS, lds, (hipStream_t)stream>>>(
+        reinterpret_cast<const float2 *>(planes), x7, n_samples, n_levels, n_active_levels, out, ld_out, col_off, write_xyz,
+        xyz_scale, xyz_offset);
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_stencil_rows_to_planes(const float *g, int ld, int col_off, int64_t n_samples, int n_levels, float *dplanes,
+                                void *stream)
+{
+    if (n_samples <= 0) return 0;
+    RSDF_CHECK_ARG(n_levels >= 1 && n_levels <= RSDF_MAX_LEVELS, "stencil_rows_to_planes: bad level count");
+    RSDF_CHECK_ARG(g != nullptr && dplanes != nullptr && col_off >= 0 && ld >= col_off + 2 * n_levels,
+                   "stencil_rows_to_planes: bad arguments");
+    const size_t lds = (size_t)ST_ROWS * ((2 * n_levels) | 1) * sizeof(float);
+    stencil_rows_to_planes_kernel<<<rsdf_blocks(n_samples, ST_SAMPLES), ST_THREADS, lds, (hipStream_t)stream>>>(
+        g, ld, col_off, n_samples, n_levels, reinterpret_cast<float2 *>(dplanes));
+    RSDF_RETURN_LAUNCH();
 }
 
 int64_t rsdf_x2_rows(int64_t n_samples) { return (n_samples + 31) / 32 * 32; }

@@ -476,16 +476,19 @@ class _HashGrid(torch.autograd.Function):
             # instead of 56, bit-identical values) and lay the level planes out as the reference-shaped rows
             S = n // 7
             Lv = meta.n_levels
-            x7t = xf.view(S, 7, 3).permute(1, 0, 2).contiguous()
-            planes = torch.empty(Lv, 7, S, 2, dtype=torch.float32, device=xf.device)
-            if n_active < Lv:
-                planes[n_active:].zero_()
-            check(lib().rsdf_hashgrid_fwd_fd7(ptr(x7t), ptr(tb), ctypes.byref(meta), S, n_active, ptr(planes),
-                                              stream_ptr()), "hashgrid_fwd_fd7")
+            st = stream_ptr()
+            # [S,7,3] interleaved -> tap-major, planes -> rows: layout kernels (as permuted torch copies these were 30 % of
+            # the per-layer route's step)
+            x7t = torch.empty(7, S, 3, dtype=torch.float32, device=xf.device)
+            check(lib().rsdf_stencil_points_tap_major(ptr(xf), S, ptr(x7t), st), "stencil_points_tap_major")
+            planes = L.workspace_f32("fd7.planes", (Lv, 7, S, 2), xf.device)     # (consumed by the rows kernel below)
+            check(lib().rsdf_hashgrid_fwd_fd7(ptr(x7t), ptr(tb), ctypes.byref(meta), S, n_active, ptr(planes), st),
+                  "hashgrid_fwd_fd7")
             out = torch.empty(n, col + LF, dtype=torch.float32, device=xf.device)
-            out[:, col:].view(S, 7, Lv, 2).copy_(planes.permute(2, 1, 0, 3))
-            if include_xyz:
-                out[:, :3] = xf * xyz_scale + xyz_offset
+            check(lib().rsdf_stencil_planes_to_rows(ptr(planes), ptr(xf), S, Lv, n_active, ptr(out), col + LF, col,
+                                                    int(include_xyz), float(xyz_scale), float(xyz_offset), st),
+                  "stencil_planes_to_rows")
+            ctx.x7t = x7t
         else:
             out = torch.empty(n, col + LF, dtype=torch.float32, device=xf.device)
             if _use_staged_gather(n):
@@ -524,8 +527,13 @@ class _HashGrid(torch.autograd.Function):
             # re-lay out to the tap-major planes the stencil kernels consume (the fused field path
             # produces them directly)
             Lv = ctx.meta.n_levels
-            x7t = xf.view(S, 7, 3).permute(1, 0, 2).contiguous()
-            dpl = g[:, ctx.col:ctx.col + 2 * Lv].reshape(S, 7, Lv, 2).permute(2, 1, 0, 3).contiguous()
+            x7t = getattr(ctx, "x7t", None)
+            if x7t is None:
+                x7t = torch.empty(7, S, 3, dtype=torch.float32, device=xf.device)
+                check(lib().rsdf_stencil_points_tap_major(ptr(xf), S, ptr(x7t), stream_ptr()), "stencil_points_tap_major")
+            dpl = L.workspace_f32("fd7.d_planes", (Lv, 7, S, 2), xf.device)
+            check(lib().rsdf_stencil_rows_to_planes(ptr(g), g.shape[1], ctx.col, S, Lv, ptr(dpl), stream_ptr()),
+                  "stencil_rows_to_planes")
             check(lib().rsdf_hashgrid_bwd_fd7(ptr(x7t), ptr(dpl), ctypes.byref(ctx.meta), S, ctx.n_active,
                                               float(ctx.fd7), ptr(dt), ptr(scratch), nbytes,
                                               stream_ptr()), "hashgrid_bwd_fd7")
@@ -691,9 +699,11 @@ class _Linear(torch.autograd.Function):
             check(fn("rsdf_linear_bwd_fused")(ptr(gy), ptr(y), N, ptr(xf), K, ptr(wf), n, K, N, ctx.act, k0, kout,
                                               dx_win, K, L.ACT_IDS["none"], ptr(dw), ptr(db), st), "linear_bwd_fused")
             return dx, dw, db, None, None, None
-        dz = torch.empty_like(gy)
-        check(fn("rsdf_linear_bwd_input")(ptr(gy), ptr(y), N, ptr(wf), n, K, N, ctx.act, k0, kout,
-                                          ptr(dz), dx_win, K, st), "linear_bwd_input")
+        # (no activation: dz IS dy -- nothing to write; an unaligned 49-column dz cost the drop-in route 0.1 s per step)
+        dz = gy if ctx.act == L.ACT_IDS["none"] else torch.empty_like(gy)
+        if dz is not gy or dx_win is not None:
+            check(fn("rsdf_linear_bwd_input")(ptr(gy), ptr(y), N, ptr(wf), n, K, N, ctx.act, k0, kout,
+                                              None if dz is gy else ptr(dz), dx_win, K, st), "linear_bwd_input")
         if dw is not None:
             check(fn("rsdf_linear_bwd_weight")(ptr(dz), N, ptr(xf), K, n, K, N, ptr(dw), ptr(db), st),
                   "linear_bwd_weight")
@@ -807,9 +817,8 @@ class _MLPChain(torch.autograd.Function):
                     dx[:, k0 + kout:].zero_()
                 dx_win = ctypes.c_void_p(dx.data_ptr() + 4 * k0)
             if not need_w[i]:
-                if need_dx:
-                    dz = torch.empty_like(g)
-                    check(fn("rsdf_linear_bwd_input")(ptr(g), ptr(yarg), N, ptr(w), n, K, N, act, k0, kout, ptr(dz),
+                if need_dx:       # (dz is not needed by anyone here: not written)
+                    check(fn("rsdf_linear_bwd_input")(ptr(g), ptr(yarg), N, ptr(w), n, K, N, act, k0, kout, None,
                                                       dx_win, K, st), "linear_bwd_input")
                 g, g_is_dz = dx, False
                 if i == 0:
@@ -834,9 +843,10 @@ class _MLPChain(torch.autograd.Function):
                                                      dx_win, K, relu if prev_relu else none, ptr(dw), ptr(db), ptr(wsp),
                                                      ws_bytes, st), "linear_bwd_fused")
             else:
-                dz = torch.empty_like(g)
-                check(fn("rsdf_linear_bwd_input")(ptr(g), ptr(yarg), N, ptr(w), n, K, N, act, k0, kout, ptr(dz), dx_win,
-                                                  K, st), "linear_bwd_input")
+                dz = g if act == none else torch.empty_like(g)          # (no activation: dz is dy, nothing to write)
+                if dz is not g or dx_win is not None:
+                    check(fn("rsdf_linear_bwd_input")(ptr(g), ptr(yarg), N, ptr(w), n, K, N, act, k0, kout,
+                                                      None if dz is g else ptr(dz), dx_win, K, st), "linear_bwd_input")
                 check(fn("rsdf_linear_bwd_weight")(ptr(dz), N, ptr(xin), K, n, K, N, ptr(dw), ptr(db), st),
                       "linear_bwd_weight")
             grads[2 * i], grads[2 * i + 1] = dw, db

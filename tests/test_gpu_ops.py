@@ -547,6 +547,38 @@ def test_hashgrid_backward_fd7(dev, ops, gi, eps_unit):
     _same_zero_pattern(t_g.grad.cpu(), t_o.grad, scale)
 
 
+@pytest.mark.parametrize("S,n_levels,n_active,write_xyz", [(1, 16, 16, 1), (33, 16, 9, 1), (1000, 4, 4, 0), (4097, 16, 16, 1)])
+def test_stencil_layout_kernels_are_the_permuted_copies(dev, S, n_levels, n_active, write_xyz):
+    """rsdf_stencil_points_tap_major / _planes_to_rows / _rows_to_planes against the torch expressions they replace in the
+    reference-shaped stencil entry (ops._HashGrid): bit-identical, ragged sample counts, masked levels, with and without
+    the xyz columns, rows wider than the written window."""
+    import ctypes
+    from rise_sdf_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(S)
+    x7 = torch.rand(S, 7, 3, generator=g).to(dev)
+    x7t = torch.empty(7, S, 3, device=dev)
+    assert L.rsdf_stencil_points_tap_major(_lib.ptr(x7), S, _lib.ptr(x7t), _lib.stream_ptr()) == 0
+    assert torch.equal(x7t, x7.permute(1, 0, 2).contiguous())
+    planes = torch.randn(n_levels, 7, S, 2, generator=g).to(dev)
+    col = 3 if write_xyz else 2                     # (a column offset that is not the xyz width either)
+    ld = col + 2 * n_levels + 1
+    out = torch.full((7 * S, ld), -7.0, device=dev)
+    assert L.rsdf_stencil_planes_to_rows(_lib.ptr(planes), _lib.ptr(x7), S, n_levels, n_active, _lib.ptr(out), ld, col,
+                                         write_xyz, 2.0, -1.0, _lib.stream_ptr()) == 0
+    want = torch.full((7 * S, ld), -7.0, device=dev)
+    pm = planes.clone()
+    pm[n_active:] = 0.0
+    want[:, col:col + 2 * n_levels] = pm.permute(2, 1, 0, 3).reshape(7 * S, 2 * n_levels)
+    if write_xyz:
+        want[:, :3] = x7.view(-1, 3) * 2.0 + -1.0
+    assert torch.equal(out, want)
+    grad = torch.randn(7 * S, ld, generator=g).to(dev)
+    dpl = torch.empty(n_levels, 7, S, 2, device=dev)
+    assert L.rsdf_stencil_rows_to_planes(_lib.ptr(grad), ld, col, S, n_levels, _lib.ptr(dpl), _lib.stream_ptr()) == 0
+    assert torch.equal(dpl, grad[:, col:col + 2 * n_levels].reshape(S, 7, n_levels, 2).permute(2, 1, 0, 3).contiguous())
+
+
 def test_hashgrid_forward_fd7_bit_exact(dev, ops):
     """Stencil-merged forward (one gather of the centre cell + 4 corners per displaced tap) must equal
     the generic per-point encoding bit for bit, including taps clamped at the box and eps > one cell."""
