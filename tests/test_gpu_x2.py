@@ -237,6 +237,7 @@ def test_x2_range_preconditions(dev, ops, monkeypatch):
     citizens (a weight of 900, a feature of 200 give the fp64 result); outside them the result is inf / nan -- never a
     silently wrong finite number -- and RSDF_CHECK=1 names the violation up front."""
     from rise_sdf_amd import _lib, fused
+    monkeypatch.delenv("RSDF_CHECK", raising=False)          # (the suite may itself run under RSDF_CHECK=1)
     H, N2, S = 64, 13, 1000
     meta, table, ws, x7t, pts, radius, eps = _field_inputs(dev, ops, S, H, N2, seed=33)
     with torch.no_grad():
