@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RSDF_ABI_VERSION 2
+#define RSDF_ABI_VERSION 3
 #define RSDF_EINVAL 10001
 #define RSDF_MAX_LEVELS 32
 #define RSDF_TAP_MAJOR (-1)
@@ -38,6 +38,17 @@ extern "C" {
 
 int rsdf_abi_version(void);
 const char *rsdf_last_error(void);
+
+/* ---- sticky device-side status words ------------------------------------------------------------
+ * Kernels never synchronise, so conditions only the device can see are COUNTED into a caller-owned int32
+ * [RSDF_STATUS_WORDS] device array (zeroed by the caller, nullable everywhere) that the host reads whenever it reads
+ * anything else (rise_sdf_amd/_lib.py::poll_status: next to the marcher's sample count). */
+#define RSDF_STATUS_WORDS 8
+#define RSDF_STATUS_X2_FWD_NONFINITE 0 /* waves of rsdf_sdfmlp_fd7_fwd_x2 that produced an inf / nan output: an operand
+                                          left the x2 format's fp16 class range (|input| < 255, |weight| < 1023,
+                                          |hidden activation| < 1023), where the reference's fp32 MLP stays finite */
+#define RSDF_STATUS_X2_BWD_REROUTED 1  /* rsdf_sdfmlp_fd7_bwd_x2 launches that ran on the range-free kernels */
+#define RSDF_STATUS_X2_BWD_GUARDED 2   /* rsdf_sdfmlp_fd7_bwd_x2 launches that the range guard examined */
 
 /* ---- M1: ray/AABB slab test ----------------------------------------------------------------
  * replaces _C.ray_aabb_intersect  (lib/nerfacc/cuda/csrc/intersection.cu:93-133, pybind.cu) and
@@ -331,10 +342,19 @@ int rsdf_sdfmlp_fd7_bwd(const float *x7t, const float *planes, int n_levels, int
  * centres points [n][3] with radius / eps (x7t = NULL), exactly as rsdf_hashgrid_fwd_fd7 / _pts do; hi + lo == the value
  * those write, times 2^8, to 2^-24.  The MLP entry points replace (x7t, planes, xyz_scale, xyz_offset) by x2: forward
  * H <= 64, backward H = 64 (rsdf_sdfmlp_fd7_x2_supported); same outputs and gradient contract as rsdf_sdfmlp_fd7_fwd / _bwd.
- * bwd additionally needs absmax_scratch (8 bytes of device memory): it scans d_sdf7t (and d_feature's d(h2)) for their
+ * bwd additionally needs guard_scratch (32 bytes of device memory): it scans d_sdf7t (and d_feature's d(h2)) for their
  * largest magnitude first, from which the kernel derives the power-of-two scale of its fp16 gradient images.
- * Preconditions (fp16 range; a violation overflows to inf / nan, never silently): |input| < 255, |weight| < 1023,
- * |hidden activation| < 1023.
+ * Preconditions of the FORWARD (fp16 range): |input| < 255, |weight| < 1023, |hidden activation| < 1023.  A violation
+ * overflows to inf / nan, never to a wrong finite number, and is counted in status[RSDF_STATUS_X2_FWD_NONFINITE]
+ * (the reference's fp32 network, models/network_utils.py:109-157, stays finite there: the Python side raises, naming
+ * RSDF_X2=0, the range-free kernels above).
+ * Dynamic range of the BACKWARD: the gradient images share one power-of-two scale per launch, so a row keeps 22 bits down to
+ * 2^-15 of the launch's largest row, 11 bits to 2^-28, nothing below 2^-38 of it.  With reroute = 1 (needs parts = 2,
+ * d_planes and x7t_scratch [7][n][3] floats) every launch is guarded on the device: it counts the non-zero rows of d_sdf7t and
+ * those within 2^-20 of the launch bound, and when fewer than 1 / 1024 of them are (the bound was set by outliers, e.g.
+ * saturated samples behind lib/nerfacc/cuda/csrc/render_weight.cu:139-151's 1 / max(1 - alpha, 1e-10)) THAT launch runs on
+ * the range-free kernels of rsdf_sdfmlp_fd7_bwd instead, from planes rebuilt out of the image in place of d_planes -- no host
+ * read either way (status[RSDF_STATUS_X2_BWD_REROUTED] counts them).
  * parts = 2 is the fp32-equivalent form above.  parts = 1 is the 16-bit mode of BASELINE.json configs[4] ("bf16 MLP on
  * MFMA") for this node: the lo parts are dropped everywhere -- operands rounded ONCE to fp16 (11 significant bits against
  * bf16's 8: the finite-difference normal divides a difference of these values by eps), one matrix instruction per
@@ -347,12 +367,15 @@ int rsdf_hashgrid_fwd_fd7_x2(const float *x7t /*or NULL*/, const float *points /
 int rsdf_sdfmlp_fd7_x2_supported(int K0, int H, int N2);
 int rsdf_sdfmlp_fd7_fwd_x2(const void *x2, int parts, int n_levels, int H, int N2, const float *w0, const float *b0,
                            const float *w1, const float *b1, const float *w2, const float *b2, int64_t n_samples,
-                           float *sdf7t, float *feature, float *h2c, void *stream);
+                           float *sdf7t, float *feature, float *h2c, int *status /*nullable*/, void *stream);
 int rsdf_sdfmlp_fd7_bwd_x2(const void *x2, int parts, int n_levels, int n_active_levels, int H, int N2, const float *w0,
                            const float *b0, const float *w1, const float *b1, const float *w2, const float *b2,
                            int64_t n_samples, const float *d_sdf7t, const float *d_feature,
-                           float *dh2c_scratch /*nullable*/, void *absmax_scratch /*8 bytes*/, float *d_planes,
-                           float *dw0, float *db0, float *dw1, float *db1, float *dw2, float *db2, void *stream);
+                           float *dh2c_scratch /*nullable*/, void *guard_scratch /*32 bytes*/,
+                           float *x7t_scratch /*[7][n][3]; nullable when reroute = 0*/,
+                           int reroute /*0 never, 1 guarded (decided per launch on the device), 2 always*/, float *d_planes,
+                           float *dw0, float *db0, float *dw1, float *db1, float *dw2, float *db2, int *status /*nullable*/,
+                           void *stream);
 /* ---- config[4]'s "bf16 MLP on MFMA" (BASELINE.json configs[4]; models/network_utils.py:109-157 at reduced matrix
  * precision): the same entry points with the suffix _bf16.  Same arguments, layouts and fp32 tensors; every matrix
  * operand (weights, activations, gradients) is rounded ONCE to bf16 (round to nearest even) and each k-step is ONE

@@ -12,6 +12,16 @@ Layout (only what the path needs):
 """
 from .registry import make, models, register  # noqa: F401
 from .config import Config, config_to_primitive, load_yaml  # noqa: F401
+from ._lib import RiseSdfHipError  # noqa: F401
+
+
+def check_status(device=None) -> dict:
+    """Reads the kernels' sticky status words (one small device-to-host copy; blocks on the device).  Raises
+    RiseSdfHipError if the fused SDF field left the range of its two-part fp16 number format since the last check;
+    returns the counters (``x2_bwd_rerouted``: backward launches the range guard ran on the range-free kernels).  The
+    samplers call this themselves behind the host reads they make anyway; call it after a loop that makes none."""
+    from . import _lib
+    return _lib.poll_status(device)
 
 
 def _register_all():

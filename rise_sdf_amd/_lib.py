@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # of overwriting the shipped library)
 SO_PATH = os.environ.get("RSDF_LIB") or os.path.join(_HERE, "librisesdf_hip.so")
 MAX_LEVELS = 32
+ABI_VERSION = 3
 
 ACT_NONE, ACT_RELU, ACT_SOFTPLUS100, ACT_SIGMOID = 0, 1, 2, 3
 ACT_IDS = {"none": ACT_NONE, None: ACT_NONE, "relu": ACT_RELU, "softplus100": ACT_SOFTPLUS100,
@@ -100,9 +101,9 @@ _SIGNATURES = {
     "rsdf_stencil_rows_to_planes": [_P, _I, _I, _L, _I, _P, _P],
     "rsdf_hashgrid_fwd_fd7_x2": [_P, _P, _F, _F, _P, ctypes.POINTER(GridMeta), _L, _I, _F, _F, _I, _P, _P],
     "rsdf_sdfmlp_fd7_x2_supported": [_I, _I, _I],
-    "rsdf_sdfmlp_fd7_fwd_x2": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P],
-    "rsdf_sdfmlp_fd7_bwd_x2": [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
-                               _P],
+    "rsdf_sdfmlp_fd7_fwd_x2": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P],
+    "rsdf_sdfmlp_fd7_bwd_x2": [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P,
+                               _P, _P, _P, _P],
     "rsdf_sdfmlp_fd7_fwd": [_P, _P, _I, _I, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P],
     "rsdf_sdfmlp_fd7_bwd": [_P, _P, _I, _I, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P,
                             _P, _P, _P, _P, _P, _P, _P],
@@ -197,7 +198,7 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = argtypes
             fn.restype = _RESTYPES.get(name, ctypes.c_int)
-        if l.rsdf_abi_version() != 2:
+        if l.rsdf_abi_version() != ABI_VERSION:
             raise RiseSdfHipError("librisesdf_hip.so ABI version mismatch")
         _lib = l
     if _timer is not None:
@@ -310,6 +311,67 @@ def workspace_f32(tag: str, shape, device) -> "torch.Tensor":
 def free_workspaces():
     """Releases the arenas (tcnn.free_temporary_memory() of the drop-in calls this)."""
     _WORKSPACES.clear()
+
+
+# ---- sticky device-side status words (include/risesdf_hip.h RSDF_STATUS_*) ------------------------------------------------
+# Kernels never synchronise; what only the device can see is counted into one int32 [STATUS_WORDS] tensor per device and read
+# by the host whenever it blocks on the device anyway (the marcher's sample count, a compaction count, the training step's
+# two sampler counts): ``poll_status`` right behind such a read costs one more 32-byte copy on an already drained stream.
+STATUS_WORDS = 8
+ST_X2_FWD_NONFINITE, ST_X2_BWD_REROUTED, ST_X2_BWD_GUARDED = 0, 1, 2
+_STATUS = {}
+_STATUS_TOTALS = {"x2_bwd_rerouted": 0, "x2_bwd_guarded": 0}
+
+
+def status(device) -> "torch.Tensor":
+    """The device's status words (created zeroed on first use)."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    t = _STATUS.get(idx)
+    if t is None:
+        t = torch.zeros(STATUS_WORDS, dtype=torch.int32, device=torch.device("cuda", idx))
+        _STATUS[idx] = t
+    return t
+
+
+def poll_status(device=None, raise_on_error=True) -> dict:
+    """Reads (one small device-to-host copy: call it where the host blocks anyway) and clears the status words of ``device``
+    (default: every device that has any).  Returns the running totals; raises RiseSdfHipError when a kernel of the x2 form
+    produced a non-finite output since the last poll, i.e. an operand left the format's fp16 class range where the
+    reference's fp32 network (models/network_utils.py:109-157) stays finite."""
+    keys = list(_STATUS) if device is None else [torch.device(device).index if torch.device(device).index is not None
+                                                 else torch.cuda.current_device()]
+    bad = 0
+    for idx in keys:
+        t = _STATUS.get(idx)
+        if t is not None:
+            bad += consume_status(t, t.tolist(), raise_on_error=False)["x2_fwd_nonfinite"]
+    return _status_result(bad, raise_on_error)
+
+
+def consume_status(t, vals, raise_on_error=True) -> dict:
+    """``vals``: the words of status tensor ``t`` as the caller has just read them together with its own counts (the
+    capacity-mode sampler concatenates them into its one host read per step)."""
+    if any(vals):
+        t.zero_()
+    _STATUS_TOTALS["x2_bwd_rerouted"] += vals[ST_X2_BWD_REROUTED]
+    _STATUS_TOTALS["x2_bwd_guarded"] += vals[ST_X2_BWD_GUARDED]
+    return _status_result(vals[ST_X2_FWD_NONFINITE], raise_on_error)
+
+
+def _status_result(bad, raise_on_error):
+    if bad and raise_on_error:
+        raise RiseSdfHipError(
+            f"the fused SDF field's x2 kernels produced non-finite outputs ({bad} tiles since the last check): an operand "
+            "left the two-part fp16 format's range -- |hash feature| or |xyz| >= 255, |effective weight| >= 1023 or a hidden "
+            "activation >= 1023 (csrc/mlp_x2.hip) -- where the reference's fp32 MLP stays finite.  Set RSDF_X2=0 to run the "
+            "SDF network on the range-free kernels (three bf16 parts, fp32's exponent range).")
+    return dict(_STATUS_TOTALS, x2_fwd_nonfinite=bad)
+
+
+def status_totals() -> dict:
+    """Totals accumulated by the polls so far (no device access)."""
+    return dict(_STATUS_TOTALS)
 
 
 def require_device(*tensors):

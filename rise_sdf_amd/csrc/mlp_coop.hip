@@ -684,10 +684,12 @@ coop_bwd_kernel(const Src src, const float *__restrict__ w0, const float *__rest
                 const float *__restrict__ b1, const float *__restrict__ w2, const float *__restrict__ d_sdf7,
                 const float *__restrict__ dh2c, float *__restrict__ d_planes, float *__restrict__ dw0,
                 float *__restrict__ db0, float *__restrict__ dw1, float *__restrict__ db1, float *__restrict__ dw2,
-                float *__restrict__ db2)
+                float *__restrict__ db2, const unsigned *__restrict__ run_if)
 {
     using L = G<NT>;
     constexpr int H = L::H;
+    // (mlp_x2.hip's range guard launches this kernel as the range-free route of a backward call: it runs iff the word is set)
+    if (run_if != nullptr && *run_if == 0u) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 31, hf = lane >> 5;
     const int K0 = 3 + 2 * src.n_levels;
@@ -971,14 +973,14 @@ __attribute__((visibility("hidden"))) int RSDF_P(rsdf_coop_fwd)(int NT, const fl
 __attribute__((visibility("hidden"))) int RSDF_P(rsdf_coop_bwd)(int NT, const float *x7t, const float *planes, int n_levels, int n_active, float xyz_scale,
                   float xyz_offset, const float *w0, const float *b0, const float *w1, const float *b1, const float *w2,
                   int64_t n_samples, const float *d_sdf7t, const float *dh2c, float *d_planes, float *dw0, float *db0,
-                  float *dw1, float *db1, float *dw2, float *db2, hipStream_t st)
+                  float *dw1, float *db1, float *dw2, float *db2, hipStream_t st, const unsigned *run_if)
 {
     const Src src{x7t, planes, n_samples, n_levels, n_active, xyz_scale, xyz_offset};
     int rc;
 #define RSDF_COOP_BWD(N)                                                                                             \
     if ((rc = coop_set_lds(coop_bwd_kernel<N>, G<N>::END))) return rc;                                               \
     coop_bwd_kernel<N><<<coop_grid<N>(n_samples), 64 * N, G<N>::END, st>>>(src, w0, b0, w1, b1, w2, d_sdf7t, dh2c,    \
-                                                                            d_planes, dw0, db0, dw1, db1, dw2, db2)
+                                                                            d_planes, dw0, db0, dw1, db1, dw2, db2, run_if)
     if (NT == 4) { RSDF_COOP_BWD(4); }
     else if (NT == 2) { RSDF_COOP_BWD(2); }
     else { RSDF_COOP_BWD(1); }

@@ -789,13 +789,13 @@ __attribute__((visibility("hidden"))) int RSDF_P(rsdf_coop_fwd)(int NT, const fl
 __attribute__((visibility("hidden"))) int RSDF_P(rsdf_coop_bwd)(int NT, const float *x7t, const float *planes, int n_levels, int n_active, float xyz_scale,
                   float xyz_offset, const float *w0, const float *b0, const float *w1, const float *b1, const float *w2,
                   int64_t n_samples, const float *d_sdf7t, const float *dh2c, float *d_planes, float *dw0, float *db0,
-                  float *dw1, float *db1, float *dw2, float *db2, hipStream_t st);
+                  float *dw1, float *db1, float *dw2, float *db2, hipStream_t st, const unsigned *run_if);
 
 // quad kernel (mlp_quad.hip): H = 64 backward on 16-feature wave tiles, two waves per SIMD
 __attribute__((visibility("hidden"))) int RSDF_P(rsdf_quad_bwd)(int H, const float *x7t, const float *planes, int n_levels, int n_active, float xyz_scale, float xyz_offset,
                   const float *w0, const float *b0, const float *w1, const float *b1, const float *w2, int64_t n_samples,
                   const float *d_sdf7t, const float *dh2c, float *d_planes, float *dw0, float *db0, float *dw1, float *db1,
-                  float *dw2, float *db2, hipStream_t st);
+                  float *dw2, float *db2, hipStream_t st, const unsigned *run_if);
 
 extern "C" {
 
@@ -863,10 +863,10 @@ int RSDF_P(rsdf_sdfmlp_fd7_bwd)(const float *x7t, const float *planes, int n_lev
         if (H == 64 && !env_is("RSDF_MLP_BWD", "coop"))
             return RSDF_P(rsdf_quad_bwd)(H, x7t, planes, n_levels, n_active_levels, xyz_scale, xyz_offset, w0, b0, w1, b1, w2,
                                  n_samples, d_sdf7t, d_feature != nullptr ? dh2c_scratch : nullptr, d_planes, dw0, db0,
-                                 dw1, db1, dw2, db2, st);
+                                 dw1, db1, dw2, db2, st, nullptr);
         return RSDF_P(rsdf_coop_bwd)(H / 32, x7t, planes, n_levels, n_active_levels, xyz_scale, xyz_offset, w0, b0, w1, b1, w2,
                              n_samples, d_sdf7t, d_feature != nullptr ? dh2c_scratch : nullptr, d_planes, dw0, db0, dw1,
-                             db1, dw2, db2, st);
+                             db1, dw2, db2, st, nullptr);
     }
     const unsigned grid = persistent_grid(n_samples, BWD_WAVES);
     const TileSrc src{x7t, planes, n_samples, n_levels, n_active_levels, xyz_scale, xyz_offset};

@@ -277,11 +277,13 @@ quad_bwd_kernel(const SrcQ src, const float *__restrict__ w0, const float *__res
                 const float *__restrict__ b1, const float *__restrict__ w2, const float *__restrict__ d_sdf7,
                 const float *__restrict__ dh2c, float *__restrict__ d_planes, float *__restrict__ dw0,
                 float *__restrict__ db0, float *__restrict__ dw1, float *__restrict__ db1, float *__restrict__ dw2,
-                float *__restrict__ db2)
+                float *__restrict__ db2, const unsigned *__restrict__ run_if)
 {
     using L = Q<NW>;
     constexpr int H = L::H;
     constexpr int KB = H / 32;                     // k-blocks of a hidden-layer product
+    // (mlp_x2.hip's range guard launches this kernel as the range-free route of a backward call: it runs iff the word is set)
+    if (run_if != nullptr && *run_if == 0u) return;
     static_assert(NW == 4, "the d(hash features) sub-tile assignment below is written for four waves (H = 64)");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
@@ -503,7 +505,7 @@ extern "C" int rsdf_debug_read_qstamps(unsigned long long *out16)
 __attribute__((visibility("hidden"))) int RSDF_P(rsdf_quad_bwd)(int H, const float *x7t, const float *planes, int n_levels, int n_active, float xyz_scale, float xyz_offset,
                   const float *w0, const float *b0, const float *w1, const float *b1, const float *w2, int64_t n_samples,
                   const float *d_sdf7t, const float *dh2c, float *d_planes, float *dw0, float *db0, float *dw1, float *db1,
-                  float *dw2, float *db2, hipStream_t st)
+                  float *dw2, float *db2, hipStream_t st, const unsigned *run_if)
 {
     RSDF_CHECK_ARG(H == 64, "quad backward: H must be 64");
     const SrcQ src{x7t, planes, n_samples, n_levels, n_active, xyz_scale, xyz_offset};
@@ -519,6 +521,6 @@ __attribute__((visibility("hidden"))) int RSDF_P(rsdf_quad_bwd)(int H, const flo
     const int64_t groups = (n_samples + 31) / 32;
     const unsigned grid = (unsigned)(groups < 512 ? (groups > 0 ? groups : 1) : 512);     // two workgroups per CU
     quad_bwd_kernel<4><<<grid, 256, Q<4>::END, st>>>(src, w0, b0, w1, b1, w2, d_sdf7t, dh2c, d_planes, dw0, db0, dw1, db1,
-                                                      dw2, db2);
+                                                      dw2, db2, run_if);
     RSDF_RETURN_LAUNCH();
 }

@@ -44,6 +44,10 @@ constexpr float T1 = SW * SX, T2 = SW * SH;                 // accumulator scale
 constexpr float K100 = 144.26950408889634f;                 // 100 log2(e)
 constexpr float LN2_100 = 0.0069314718055994531f;           // ln(2) / 100
 
+// words of a backward launch's guard scratch ("the backward's range guard" below)
+constexpr int GUARD_MAX_DSDF = 0, GUARD_MAX_DH2C = 1, GUARD_NONZERO = 2, GUARD_WITHIN = 3, GUARD_DECISION = 4, GUARD_TICKET = 5;
+constexpr int GUARD_WORDS = 8;
+
 struct Frag2 { u32x4 h, l; };
 
 __device__ __forceinline__ unsigned pack_f16(float a, float b)       // v_cvt_pk_f16_f32 (round to nearest even); a -> low half
@@ -305,9 +309,12 @@ template <int H, int NP>
 __global__ void __launch_bounds__(64 * fwd_waves<H>(), fwd_waves<H>() / 4)
 fwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__restrict__ b0, const float *__restrict__ w1,
               const float *__restrict__ b1, const float *__restrict__ w2, const float *__restrict__ b2, int N2,
-              float *__restrict__ sdf7, float *__restrict__ feature, float *__restrict__ h2c)
+              float *__restrict__ sdf7, float *__restrict__ feature, float *__restrict__ h2c, int *__restrict__ status)
 {
     const int64_t n_samples = src.S;
+    // range guard: an operand beyond its fp16 class range (header) becomes inf in a hi part and reaches the SDF output as
+    // inf / nan (every product and the vector-ALU dot keep non-finite values non-finite); nothing in the steady state but a
+    // compare and a scalar branch per tap, one atomic per offending tile (no state carried: the kernel sits at its register cap)
     const int K0 = 3 + 2 * src.n_levels;
     using S = SmemF<H, NP>;
     constexpr int NT = S::NT;
@@ -390,6 +397,8 @@ fwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
                     acc = fmaf(w.w, h2[t][4 * q + 3], acc);
                 }
             acc += __shfl_xor(acc, 32, 64);
+            if (__builtin_amdgcn_ballot_w64(!(fabsf(acc) < 3.0e38f)) != 0ull && lane == 0 && status != nullptr)
+                atomicAdd(&status[RSDF_STATUS_X2_FWD_NONFINITE], 1);
             if (hf == 0 && s < n_samples) sdf7[(int64_t)tap * n_samples + s] = acc + b2_0;
             if (tap == 0 && (S::W2_IN_LDS ? feature != nullptr : h2c != nullptr)) {
                 if (h2c != nullptr) {   // second hidden layer of the centre rows (unscaled), for the dW2 of the feature rows
@@ -427,10 +436,15 @@ fwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
                     if (nc <= 0) break;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) Fs[c * LDFS + (r & 3) + 8 * (r >> 2) + 4 * hf] = o[t][r] * (1.0f / T2);
+                    bool fbad = false;         // (h2 >= 1023 overflows the split of THIS product only: the SDF dot reads fp32 h2)
                     for (int e = lane; e < 32 * nc; e += 64) {
                         const int r = e / nc, cc = e - r * nc;
-                        if (s0 + r < n_samples) feature[(s0 + r) * N2 + 32 * t + cc] = Fs[r * LDFS + cc];
+                        const float v = Fs[r * LDFS + cc];
+                        fbad |= !(fabsf(v) < 3.0e38f);
+                        if (s0 + r < n_samples) feature[(s0 + r) * N2 + 32 * t + cc] = v;
                     }
+                    if (__builtin_amdgcn_ballot_w64(fbad) != 0ull && lane == 0 && status != nullptr)
+                        atomicAdd(&status[RSDF_STATUS_X2_FWD_NONFINITE], 1);
                 }
                 }
                 // the transpose has overwritten the hi part (and the head of the lo part, which the next tile's store
@@ -604,12 +618,13 @@ template <int NW, int NP>
 __global__ void __launch_bounds__(64 * NW, NW == 4 ? RSDF_X2_BWD_OCC : 1)
 bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__restrict__ b0, const float *__restrict__ w1,
               const float *__restrict__ b1, const float *__restrict__ w2, const float *__restrict__ d_sdf7,
-              const float *__restrict__ dh2c, const unsigned *__restrict__ absmax /* [2]: bits of max|d_sdf7|, max|dh2c| */,
+              const float *__restrict__ dh2c, const unsigned *__restrict__ absmax /* the guard words: bits of max|d_sdf7|, max|dh2c|, .., decision */,
               float *__restrict__ d_planes, float *__restrict__ dw0, float *__restrict__ db0, float *__restrict__ dw1,
               float *__restrict__ db1, float *__restrict__ dw2, float *__restrict__ db2)
 {
     using L = QL<NW, NP>;
     constexpr int H = L::H, KB = H / 32, HP = L::H_PART, NTHR = 64 * NW;
+    if (absmax[GUARD_DECISION] != 0u) return;      // this launch runs on the range-free kernels (spread_kernel below)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *s_red = reinterpret_cast<float *>(smem + L::RED);
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
@@ -838,7 +853,126 @@ absmax_kernel(const float *__restrict__ v, int64_t n, unsigned *__restrict__ out
     if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(out, __float_as_uint(m));
 }
 
+// ---- the backward's range guard -------------------------------------------------------------------------------------
+// The gradient images share ONE power-of-two scale per launch (grad_scale of the launch bound): a row keeps the full two-part
+// precision down to 2^-15 of the bound, 11 bits down to 2^-28, nothing below 2^-38 -- an ABSOLUTE floor of bound 2^-38 where
+// the reference's fp32 network (models/network_utils.py:109-157) keeps 24 bits of every row.  That is harmless while the
+// rows that carry the gradient sit within ~2^20 of the largest one (every configuration measured: the spread inside a chunk
+// is 2^10 .. 2^20) and wrong when a few outliers set the bound -- one saturated sample behind render_weight.cu:139-151's
+// 1 / max(1 - alpha, 1e-10) would flush the d(hash features) of every ordinary row.  The guard measures it per launch, on the
+// device: spread_kernel counts the non-zero rows of d_sdf7t and those within 2^-SPREAD of the launch bound; when fewer than
+// 1 / BULK_INV of the non-zero rows are (the maximum is an outlier relative to the bulk), the launch's decision word is set,
+// bwd_x2_kernel returns at once and the same launch runs on the range-free round-3 kernels (three bf16 parts: fp32's
+// exponent range) from planes rebuilt out of the x2 image -- no host read, two idle launches in the steady state.
+#ifndef RSDF_X2_SPREAD_LOG2
+#define RSDF_X2_SPREAD_LOG2 20
+#endif
+#ifndef RSDF_X2_BULK_INV
+#define RSDF_X2_BULK_INV 1024u
+#endif
+
+// mode 1: decide from the counts; mode 2: reroute unconditionally (tests, RSDF_X2_REROUTE=force)
+__global__ void __launch_bounds__(256)
+spread_kernel(const float *__restrict__ v, int64_t n, const float *__restrict__ w2, int H, int spread_log2, int mode,
+              unsigned *__restrict__ guard, int *__restrict__ status)
+{
+    __shared__ float s_m2[4];
+    __shared__ unsigned s_cnt[8];
+    float m2 = 0.0f;
+    for (int e = threadIdx.x; e < H; e += 256) m2 = fmaxf(m2, fabsf(w2[e]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m2 = fmaxf(m2, __shfl_xor(m2, o, 64));
+    if ((threadIdx.x & 63) == 0) s_m2[threadIdx.x >> 6] = m2;
+    __syncthreads();
+    m2 = fmaxf(fmaxf(s_m2[0], s_m2[1]), fmaxf(s_m2[2], s_m2[3]));
+    // a tap row's own bound is m2 |d_sdf|; the launch bound is m2 max|d_sdf| + max|dh2c| (bwd_x2_kernel's bound2)
+    const float bound = m2 * __uint_as_float(guard[GUARD_MAX_DSDF]) + __uint_as_float(guard[GUARD_MAX_DH2C]);
+    const float thr = (bound > 0.0f && bound < 3.0e38f && m2 > 0.0f) ? ldexpf(bound, -spread_log2) / m2 : 0.0f;
+    unsigned nz = 0, in = 0;
+    const int64_t n4 = n / 4;
+    const float4 *v4 = reinterpret_cast<const float4 *>(v);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 t = v4[i];
+        const float a = fabsf(t.x), b = fabsf(t.y), c = fabsf(t.z), d = fabsf(t.w);
+        nz += (a > 0.0f) + (b > 0.0f) + (c > 0.0f) + (d > 0.0f);
+        in += (a > 0.0f && a >= thr) + (b > 0.0f && b >= thr) + (c > 0.0f && c >= thr) + (d > 0.0f && d >= thr);
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float a = fabsf(v[i]);
+        nz += a > 0.0f;
+        in += a > 0.0f && a >= thr;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        nz += __shfl_xor(nz, o, 64);
+        in += __shfl_xor(in, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { s_cnt[threadIdx.x >> 6] = nz; s_cnt[4 + (threadIdx.x >> 6)] = in; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&guard[GUARD_NONZERO], s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3]);
+        atomicAdd(&guard[GUARD_WITHIN], s_cnt[4] + s_cnt[5] + s_cnt[6] + s_cnt[7]);
+        __threadfence();
+        if (atomicAdd(&guard[GUARD_TICKET], 1u) == gridDim.x - 1) {          // the last workgroup decides for the launch
+            const unsigned tnz = atomicAdd(&guard[GUARD_NONZERO], 0u), tin = atomicAdd(&guard[GUARD_WITHIN], 0u);
+            const bool reroute = mode == 2 || (tnz > 0u && (unsigned long long)tin * RSDF_X2_BULK_INV < (unsigned long long)tnz);
+            if (reroute) {
+                atomicExch(&guard[GUARD_DECISION], 1u);
+                if (status != nullptr) atomicAdd(&status[RSDF_STATUS_X2_BWD_REROUTED], 1);
+            }
+            if (status != nullptr) atomicAdd(&status[RSDF_STATUS_X2_BWD_GUARDED], 1);
+        }
+    }
+}
+
+// the rerouted launch's inputs: planes [L][7][S][2] and x7t [7][S][3] (already scaled: the round-3 kernels get xyz_scale 1,
+// offset 0) back out of the image, (hi + lo) / 2^8 -- the value the fp32 gather would have written, to 2^-24.  One workgroup
+// per tile and iteration; runs only when the launch's decision word is set.
+__global__ void __launch_bounds__(256)
+x2_to_planes_kernel(const SrcX2 src, const unsigned *__restrict__ run_if, float *__restrict__ planes, float *__restrict__ x7t)
+{
+    if (*run_if == 0u) return;
+    const int64_t n_tiles = src.Sp / 32;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const unsigned char *tb = src.x2 + tile * x2_tile_b<2>();
+        for (int e = threadIdx.x; e < 7 * 18 * 32; e += 256) {
+            const int r = e & 31, cp = (e >> 5) % 18, tap = (e >> 5) / 18;      // column pair cp = columns 2 cp, 2 cp + 1
+            const int64_t s = tile * 32 + r;
+            if (s >= src.S) continue;
+            float val[2];
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                const int col = 2 * cp + f;
+                const int rr = r ^ (((col >> 3) & 1) * 16);
+                const unsigned char *p = tb + tap * x2_tap_b<2>() + col * 64 + rr * 2;
+                const float hi = (float)*reinterpret_cast<const _Float16 *>(p);
+                const float lo = (float)*reinterpret_cast<const _Float16 *>(p + X2_PART_B);
+                val[f] = (hi + lo) * (1.0f / SX);
+            }
+            if (cp < 16) {
+                if (cp < src.n_levels)
+                    *reinterpret_cast<float2 *>(planes + (((int64_t)cp * 7 + tap) * src.S + s) * 2) = float2{val[0], val[1]};
+            } else if (cp == 16) {
+                x7t[((int64_t)tap * src.S + s) * 3 + 0] = val[0];
+                x7t[((int64_t)tap * src.S + s) * 3 + 1] = val[1];
+            } else {
+                x7t[((int64_t)tap * src.S + s) * 3 + 2] = val[0];
+            }
+        }
+    }
+}
+
 }  // namespace
+
+// the range-free route (mlp_quad.hip, mlp_coop.hip)
+__attribute__((visibility("hidden"))) int rsdf_coop_bwd(int NT, const float *x7t, const float *planes, int n_levels, int n_active, float xyz_scale,
+                  float xyz_offset, const float *w0, const float *b0, const float *w1, const float *b1, const float *w2,
+                  int64_t n_samples, const float *d_sdf7t, const float *dh2c, float *d_planes, float *dw0, float *db0,
+                  float *dw1, float *db1, float *dw2, float *db2, hipStream_t st, const unsigned *run_if);
+__attribute__((visibility("hidden"))) int rsdf_quad_bwd(int H, const float *x7t, const float *planes, int n_levels, int n_active, float xyz_scale, float xyz_offset,
+                  const float *w0, const float *b0, const float *w1, const float *b1, const float *w2, int64_t n_samples,
+                  const float *d_sdf7t, const float *dh2c, float *d_planes, float *dw0, float *db0, float *dw1, float *db1,
+                  float *dw2, float *db2, hipStream_t st, const unsigned *run_if);
 
 extern "C" {
 
@@ -849,7 +983,7 @@ int rsdf_sdfmlp_fd7_x2_supported(int K0, int H, int N2)
 
 int rsdf_sdfmlp_fd7_fwd_x2(const void *x2, int parts, int n_levels, int H, int N2, const float *w0, const float *b0, const float *w1,
                            const float *b1, const float *w2, const float *b2, int64_t n_samples, float *sdf7t, float *feature,
-                           float *h2c, void *stream)
+                           float *h2c, int *status, void *stream)
 {
     const int K0 = 3 + 2 * n_levels;
     RSDF_CHECK_ARG(n_levels >= 1 && n_levels <= 16, "sdfmlp_fd7_fwd_x2: n_levels must be in [1,16]");
@@ -868,7 +1002,7 @@ int rsdf_sdfmlp_fd7_fwd_x2(const void *x2, int parts, int n_levels, int H, int N
     do {                                                                                                                      \
         if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(fwd_x2_kernel<HH, NPP>), fwd_lds<HH, NPP>())) return rc;     \
         fwd_x2_kernel<HH, NPP><<<grid_of(fwd_waves<HH>()), 64 * fwd_waves<HH>(), fwd_lds<HH, NPP>(), st>>>(                    \
-            src, w0, b0, w1, b1, w2, b2, N2, sdf7t, feature, h2c);                                                            \
+            src, w0, b0, w1, b1, w2, b2, N2, sdf7t, feature, h2c, status);                                                    \
     } while (0)
     if (H == 128) {
         // the feature rows of the last layer are one per-layer product on the centre rows' h2 (see SmemF)
@@ -889,20 +1023,24 @@ int rsdf_sdfmlp_fd7_fwd_x2(const void *x2, int parts, int n_levels, int H, int N
 
 int rsdf_sdfmlp_fd7_bwd_x2(const void *x2, int parts, int n_levels, int n_active_levels, int H, int N2, const float *w0, const float *b0,
                            const float *w1, const float *b1, const float *w2, const float *b2, int64_t n_samples,
-                           const float *d_sdf7t, const float *d_feature, float *dh2c_scratch, void *absmax_scratch,
-                           float *d_planes, float *dw0, float *db0, float *dw1, float *db1, float *dw2, float *db2, void *stream)
+                           const float *d_sdf7t, const float *d_feature, float *dh2c_scratch, void *guard_scratch,
+                           float *x7t_scratch, int reroute, float *d_planes, float *dw0, float *db0, float *dw1, float *db1,
+                           float *dw2, float *db2, int *status, void *stream)
 {
     const int K0 = 3 + 2 * n_levels;
     (void)b2;
     RSDF_CHECK_ARG(n_levels >= 1 && n_levels <= 16, "sdfmlp_fd7_bwd_x2: n_levels must be in [1,16]");
     RSDF_CHECK_ARG((H == 64 || H == 128) && rsdf_sdfmlp_fd7_x2_supported(K0, H, N2), "sdfmlp_fd7_bwd_x2: unsupported layer sizes (H must be 64 or 128)");
-    RSDF_CHECK_ARG(absmax_scratch != nullptr, "sdfmlp_fd7_bwd_x2: the 8-byte absmax scratch is required");
+    RSDF_CHECK_ARG(guard_scratch != nullptr, "sdfmlp_fd7_bwd_x2: the 32-byte guard scratch is required");
     RSDF_CHECK_ARG(parts == 1 || parts == 2, "sdfmlp_fd7_bwd_x2: parts must be 1 or 2");
+    RSDF_CHECK_ARG(reroute >= 0 && reroute <= 2, "sdfmlp_fd7_bwd_x2: reroute must be 0 (never), 1 (guarded) or 2 (always)");
+    RSDF_CHECK_ARG(reroute == 0 || (parts == 2 && x7t_scratch != nullptr && d_planes != nullptr),
+                   "sdfmlp_fd7_bwd_x2: the range-free route needs parts = 2, d_planes and the x7t scratch");
     if (n_samples <= 0) return 0;
     if (n_active_levels < 0 || n_active_levels > n_levels) n_active_levels = n_levels;
     hipStream_t st = (hipStream_t)stream;
-    unsigned *am = reinterpret_cast<unsigned *>(absmax_scratch);
-    (void)hipMemsetAsync(am, 0, 8, st);
+    unsigned *am = reinterpret_cast<unsigned *>(guard_scratch);
+    (void)hipMemsetAsync(am, 0, GUARD_WORDS * 4, st);
     absmax_kernel<<<1024, 256, 0, st>>>(d_sdf7t, 7 * n_samples, am);
     if (d_feature != nullptr) {
         RSDF_CHECK_ARG(dh2c_scratch != nullptr, "sdfmlp_fd7_bwd_x2: d_feature needs the [n, H] dh2c scratch");
@@ -915,6 +1053,11 @@ int rsdf_sdfmlp_fd7_bwd_x2(const void *x2, int parts, int n_levels, int n_active
     const SrcX2 src{reinterpret_cast<const unsigned char *>(x2), n_samples, Sp, n_levels, n_active_levels};
     const int64_t groups = Sp / 32;
     const float *dh = d_feature != nullptr ? dh2c_scratch : nullptr;
+    // the range guard: only the fp32-labelled form with a table gradient has a parity contract the launch scale can break,
+    // and the range-free route needs somewhere to rebuild its inputs (planes in place of d_planes, x7t in the scratch)
+    const int mode = reroute;
+    if (mode != 0)
+        spread_kernel<<<1024, 256, 0, st>>>(d_sdf7t, 7 * n_samples, w2, H, RSDF_X2_SPREAD_LOG2, mode, am, status);
 #define RSDF_X2_BWD(NWW, NPP, GRID)                                                                                           \
     do {                                                                                                                      \
         if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(bwd_x2_kernel<NWW, NPP>), QL<NWW, NPP>::END)) return rc;     \
@@ -929,6 +1072,17 @@ int rsdf_sdfmlp_fd7_bwd_x2(const void *x2, int parts, int n_levels, int n_active
         if (parts == 2) RSDF_X2_BWD(8, 2, g8); else RSDF_X2_BWD(8, 1, g8);
     }
 #undef RSDF_X2_BWD
+    if (mode != 0) {
+        if (hipGetLastError() != hipSuccess) { rsdf_set_error("sdfmlp_fd7_bwd_x2: launch failed"); return RSDF_EINVAL; }
+        // (both return at once unless the decision word is set; the round-3 kernels read the planes of a (tile, tap) before they
+        // write its d_planes and no other workgroup touches that (tile, tap): in place)
+        x2_to_planes_kernel<<<(unsigned)(groups < 2048 ? groups : 2048), 256, 0, st>>>(src, am + GUARD_DECISION, d_planes, x7t_scratch);
+        if (H == 64)
+            return rsdf_quad_bwd(64, x7t_scratch, d_planes, n_levels, n_active_levels, 1.0f, 0.0f, w0, b0, w1, b1, w2, n_samples,
+                                 d_sdf7t, dh, d_planes, dw0, db0, dw1, db1, dw2, db2, st, am + GUARD_DECISION);
+        return rsdf_coop_bwd(4, x7t_scratch, d_planes, n_levels, n_active_levels, 1.0f, 0.0f, w0, b0, w1, b1, w2, n_samples,
+                             d_sdf7t, dh, d_planes, dw0, db0, dw1, db1, dw2, db2, st, am + GUARD_DECISION);
+    }
     RSDF_RETURN_LAUNCH();
 }
 

@@ -51,6 +51,13 @@ def x2_parts(K0: int, H: int, N2: int, precision: str) -> int:
     return 0
 
 
+def x2_reroute_mode() -> int:
+    """The x2 backward's range guard: 1 (default) = decided per launch on the device (a launch whose largest gradient row is
+    an outlier relative to the bulk runs on the range-free kernels), ``RSDF_X2_REROUTE=0`` never, ``=force`` always."""
+    v = os.environ.get("RSDF_X2_REROUTE", "1")
+    return 0 if v == "0" else (2 if v == "force" else 1)
+
+
 def use_x2(K0: int, H: int, N2: int, precision: str) -> bool:
     return x2_parts(K0, H, N2, precision) > 0
 
@@ -107,8 +114,10 @@ class _SdfFieldFD7(torch.autograd.Function):
         feature = torch.empty(S, N2, dtype=torch.float32, device=dev) if want_feature else None
         h2c = torch.empty(S, H, dtype=torch.float32, device=dev) if want_feature else None
         if x2 is not None:
+            # (range guard: a non-finite output is counted in the device's status words; _lib.poll_status raises at the
+            # next host read, naming RSDF_X2=0)
             check(lib().rsdf_sdfmlp_fd7_fwd_x2(ptr(x2), parts, Lv, H, N2, *[ptr(t) for t in ws], S, ptr(sdf7t), ptr(feature),
-                                               ptr(h2c), st), "sdfmlp_fd7_fwd_x2")
+                                               ptr(h2c), ptr(L.status(dev)), st), "sdfmlp_fd7_fwd_x2")
         else:
             check(L.mlp_fn("rsdf_sdfmlp_fd7_fwd", precision)(ptr(xf), ptr(planes), Lv, n_active, float(xyz_scale),
                                             float(xyz_offset), H, N2, *[ptr(t) for t in ws], S, ptr(sdf7t),
@@ -142,11 +151,16 @@ class _SdfFieldFD7(torch.autograd.Function):
         dw2, db2 = torch.zeros_like(w2), torch.zeros_like(b2)
         dh2c = L.workspace_f32("fd7.dh2c", (S, H), dev) if gf is not None else None
         if ctx.x2:
-            absmax = torch.empty(2, dtype=torch.int32, device=dev)
+            guard = torch.empty(8, dtype=torch.int32, device=dev)
+            # the backward's range guard (csrc/mlp_x2.hip): a launch whose largest gradient row is an outlier relative to the
+            # bulk runs on the range-free kernels instead, decided on the device; that route rebuilds x7t here and the planes
+            # in place of d_planes
+            reroute = x2_reroute_mode() if (need_table and ctx.x2 == 2) else 0
+            x7s = L.workspace_f32("fd7.x7t_reroute", (7, S, 3), dev) if reroute else None
             check(lib().rsdf_sdfmlp_fd7_bwd_x2(ptr(planes), ctx.x2, Lv, ctx.n_active, H, N2, ptr(w0), ptr(b0), ptr(w1), ptr(b1),
-                                               ptr(w2), ptr(b2), S, ptr(g), ptr(gf), ptr(dh2c), ptr(absmax), ptr(d_planes),
-                                               ptr(dw0), ptr(db0), ptr(dw1), ptr(db1), ptr(dw2), ptr(db2), st),
-                  "sdfmlp_fd7_bwd_x2")
+                                               ptr(w2), ptr(b2), S, ptr(g), ptr(gf), ptr(dh2c), ptr(guard), ptr(x7s), reroute,
+                                               ptr(d_planes), ptr(dw0), ptr(db0), ptr(dw1), ptr(db1), ptr(dw2), ptr(db2),
+                                               ptr(L.status(dev)), st), "sdfmlp_fd7_bwd_x2")
         else:
             check(L.mlp_fn("rsdf_sdfmlp_fd7_bwd", ctx.precision)(ptr(xf), ptr(planes), Lv, ctx.n_active, ctx.xyz[0], ctx.xyz[1],
                                             H, N2, ptr(w0), ptr(b0), ptr(w1), ptr(b1), ptr(w2), ptr(b2), S,

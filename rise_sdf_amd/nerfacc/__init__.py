@@ -24,6 +24,7 @@ from typing import Callable, List, Optional, Union
 import torch
 import torch.nn as nn
 
+from .. import _lib as L
 from .. import ops
 from ..ops import (accumulate_along_rays, pack_info,  # noqa: F401
                    render_transmittance_from_alpha, render_visibility, render_weight_from_alpha,
@@ -328,7 +329,10 @@ class OccGridEstimator(nn.Module):
                                  zero_init=True)
         cnt = []
         ri_o, ts_o, te_o = ops.compact_samples(keep, ri, ts, te, count_out=cnt)
-        vals = torch.cat([total, cnt[0]] + [p[2] for p in self._pending]).tolist()   # the one host read of this call
+        st = L.status(total.device)          # (the kernels' sticky status words ride along with the counts)
+        vals = torch.cat([total, cnt[0]] + [p[2] for p in self._pending] + [st]).tolist()   # the one host read of this call
+        vals, st_vals = vals[:-L.STATUS_WORDS], vals[-L.STATUS_WORDS:]
+        L.consume_status(st, st_vals)
         n_cand, n_kept = vals[:2]
         self._settle_pending(list(zip(vals[2::2], vals[3::2])))      # (+ the counts of earlier read-free passes)
         self._remember(key, n_cand)

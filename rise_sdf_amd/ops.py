@@ -100,6 +100,7 @@ def march(rays_o, rays_d, t_min, t_max, roi, binary, step_size, cone_angle=0.0):
     check(lib().rsdf_pack_from_counts(ptr(counts), n, ptr(packed), ptr(total), ptr(scratch), st),
           "pack_from_counts")
     S = int(total.item())
+    L.poll_status(dev)                 # (the stream is drained: the kernels' sticky status words ride along with this read)
     ri = torch.empty(S, dtype=torch.int64, device=dev)
     ts = torch.empty(S, dtype=torch.float32, device=dev)
     te = torch.empty(S, dtype=torch.float32, device=dev)
@@ -215,6 +216,7 @@ def compact_samples(keep, ray_indices, t_starts, t_ends, count_out=None, fill_ra
         count_out.append(cnt)
         return ri_o, ts_o, te_o
     m = int(cnt.item())
+    L.poll_status(ri.device)
     return ri_o[:m], ts_o[:m], te_o[:m]
 
 

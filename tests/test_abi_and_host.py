@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(l, n), f"{n} declared in include/risesdf_hip.h but not exported"
     # and the ctypes table binds exactly the declared set
     assert sorted(_lib.EXPORTS) == names
-    assert _lib.lib().rsdf_abi_version() == 2
+    assert _lib.lib().rsdf_abi_version() == 3
 
 
 def test_no_cpu_fallback():

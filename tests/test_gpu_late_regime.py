@@ -1,0 +1,276 @@
+"""The default fp32 SDF field (the two-part fp16 "x2" kernels, csrc/mlp_x2.hip) where a 40k-step run ends up, and its guards.
+
+The reference's SDF network is plain fp32 with fp32's range (models/network_utils.py:109-157); the x2 form has a forward
+range (|input| < 255, |weight| < 1023, |activation| < 1023) and a backward dynamic range (one power-of-two scale per launch
+for the gradient images).  Tests here:
+  * the c1 model at L = 16 / T = 2^19, H = 64 and 128, against the ORACLE at variance 0.6 and 0.75 (inv_s 403 and 1808), a
+    field sharp enough that alpha saturates to exactly 1, jitter on -- with RSDF_X2 unset (the shipped path);
+  * one launch with a single d_sdf row at 2^30 times the typical magnitude: every other row's d(hash features) must equal the
+    range-free kernels' at 1e-4 (the range guard reroutes the launch on the device);
+  * the guard does NOT reroute an ordinary launch, and a forced reroute equals RSDF_X2=0;
+  * a forward range violation produces the named error at the next host read instead of NaN losses."""
+import ctypes
+import sys
+import os
+
+import pytest
+import torch
+
+import oracle
+from helpers import camera_rays, rel_err
+from test_gpu_x2 import _field_inputs
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from rise_sdf_amd import ops as o
+    return o
+
+
+@pytest.mark.parametrize("variance", [0.6, 0.75])
+@pytest.mark.parametrize("hidden", [64, 128])
+def test_c1_late_training_regime_vs_oracle(dev, hidden, variance, monkeypatch):
+    """test_gpu_regimes.py's c1 composition (bench.py's model: 16 levels, 2^19 entries, base 32, fused x2 kernels) at the END of
+    a training run instead of its start: inv_s = exp(10 variance) = 403 / 1808 (the reference's VarianceNetwork,
+    models/split_mixed_occ.py:21-56, learns it upwards from 20), so that alpha = clip((p - n + 1e-5) / (p + 1e-5)) saturates
+    to exactly 1 at the surface crossing and the weight backward's 1 / max(1 - alpha, 1e-10)
+    (lib/nerfacc/cuda/csrc/render_weight.cu:139-151) is exercised; stratified jitter on.  Gates: SURVEY 8(d)'s."""
+    import rise_sdf_amd as R
+    from rise_sdf_amd import _lib, fused
+    monkeypatch.delenv("RSDF_X2", raising=False)
+    monkeypatch.delenv("RSDF_X2_REROUTE", raising=False)
+    sys.path.insert(0, ROOT)
+    import bench
+    torch.manual_seed(0)
+    cfg = bench.c1_config(hidden=hidden)
+    cfg["num_samples_per_ray"] = 256
+    model = R.make("neus", cfg).to(dev)
+    enc = model.geometry.encoding.encoding.encoding
+    gen = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        enc.params.copy_(((torch.rand(enc.params.numel(), generator=gen) * 2 - 1) * 3e-2).to(dev))
+        l0 = model.geometry.network.layers[0]
+        l0.weight_v[:, 3:] = (torch.randn(l0.weight_v[:, 3:].shape, generator=gen) * 0.3).to(dev)
+        model.variance.variance.fill_(variance)
+    model.train()
+    model.geometry.update_step(0, 0)
+    model.cos_anneal_ratio = 1.0
+    assert model._fused_ok() and fused.x2_parts(35, hidden, 48, "fp32") == 2
+    rays = camera_rays(48, 48, seed=21)
+    u = torch.rand(rays.shape[0], generator=torch.Generator().manual_seed(22))
+    out = model.forward_(rays.to(dev), stratified_u=u.to(dev))
+    roi = torch.tensor([-1.5, -1.5, -1.5, 1.5, 1.5, 1.5])
+    ri, ts, te = oracle.ray_marching(rays[:, :3].contiguous(), rays[:, 3:].contiguous(), scene_aabb=roi, near_plane=0.0,
+                                     far_plane=1e10, render_step_size=model.render_step_size, stratified_u=u)
+    assert torch.equal(out["ray_indices"].cpu(), ri) and ri.numel() > 200000
+    from test_gpu_model import assert_grads_tight, hip_sdf7, oracle_params
+    eps = model.geometry._finite_difference_eps
+    # the oracle on the HIP path's own stencil values (test_gpu_regimes.py: at eps = 3.7e-4 an fp32 ulp of SDF is amplified
+    # by 1 / eps before it reaches anything else, and here by inv_s on top)
+    sdf7 = hip_sdf7(model, rays, ri, ts, te)
+    meta, table, mlp, var = oracle_params(model)
+    ref_free = oracle.neus_geometry_render(rays, ri, ts, te, table, meta, mlp, var, radius=1.5, fd_eps=eps)
+    assert rel_err(sdf7, ref_free["sdf7"]) < 3e-6
+    assert rel_err(out["sdf_samples"], ref_free["sdf"]) < 1e-5
+    meta2, table2, mlp2, var2 = oracle_params(model)
+    ref = oracle.neus_geometry_render(rays, ri, ts, te, table2, meta2, mlp2, var2, radius=1.5, fd_eps=eps, sdf7_given=sdf7)
+    # the regime itself: the sharp field saturates samples
+    alpha = ref["alphas"].detach()
+    assert int((alpha == 1.0).sum()) > 0, "no alpha saturated to exactly 1: not the late-training regime"
+    print(f"H = {hidden}, inv_s = {float(torch.exp(torch.tensor(10.0 * variance))):.0f}: {int((alpha == 1.0).sum())} of "
+          f"{alpha.numel()} alphas are exactly 1, {int((alpha > 0.999).sum())} above 0.999")
+    for k in ("opacity", "depth"):
+        assert torch.allclose(out[k].cpu(), ref[k].detach(), rtol=1e-4, atol=3e-6), (k, float((out[k].cpu() - ref[k].detach()).abs().max()))
+    assert float((out["sdf_grad_samples"].cpu() - ref["sdf_grad"].detach()).abs().max()) < 1e-4
+    g = torch.Generator().manual_seed(23)
+    go, gd = torch.randn(ref["opacity"].shape, generator=g), torch.randn(ref["depth"].shape, generator=g)
+    ((ref["opacity"] * go).sum() + (ref["depth"] * gd).sum()).backward()
+    ((out["opacity"] * go.to(dev)).sum() + (out["depth"] * gd.to(dev)).sum()).backward()
+    torch.cuda.synchronize()
+    gt = enc.params.grad
+    assert bool(torch.isfinite(gt).all())
+    lin = [m for m in model.geometry.network.layers if isinstance(m, torch.nn.Linear)]
+    hip_named, ref_named = {}, {}
+    for i, (m, p) in enumerate(zip(lin, mlp2)):
+        for name, key in (("weight_v", "v"), ("weight_g", "g"), ("bias", "b")):
+            hip_named[f"{i}.{name}"], ref_named[f"{i}.{name}"] = getattr(m, name).grad, p[key].grad
+    hip_named["variance"], ref_named["variance"] = model.variance.variance.grad.reshape(1), var2.grad.reshape(1)
+    assert_grads_tight(hip_named, ref_named, gt, table2.grad)
+    st = _lib.poll_status(dev)
+    print(f"range guard: {st}")
+
+
+def _x2_backward(dev, meta, table, ws, x7t, pts, radius, eps, d_sdf, H, N2, reroute, n_active=16):
+    """One launch of the shipped backward through the C ABI: gather -> x2 image, rsdf_sdfmlp_fd7_bwd_x2 -> d_planes and the
+    weight gradients."""
+    from rise_sdf_amd import _lib
+    L = _lib.lib()
+    S = x7t.shape[1]
+    p = _lib.ptr
+    st = _lib.stream_ptr()
+    x2 = torch.empty(int(L.rsdf_x2_bytes(S, 2)), dtype=torch.uint8, device=dev)
+    _lib.check(L.rsdf_hashgrid_fwd_fd7_x2(None, p(pts), radius, eps, p(table.detach()), ctypes.byref(meta), S, n_active, 2.0, -1.0, 2,
+                                          p(x2), st), "gather")
+    flat = [t.detach().contiguous() for wb in ws for t in wb]
+    d_planes = torch.full((16, 7, S, 2), float("nan"), device=dev)
+    grads = [torch.zeros_like(t) for t in flat]
+    guard = torch.empty(8, dtype=torch.int32, device=dev)
+    x7s = torch.empty(7, S, 3, device=dev) if reroute else None
+    _lib.check(L.rsdf_sdfmlp_fd7_bwd_x2(p(x2), 2, 16, n_active, H, N2, *[p(t) for t in flat], S, p(d_sdf), None, None, p(guard),
+                                        p(x7s), reroute, p(d_planes), *[p(t) for t in grads], p(_lib.status(dev)), st), "bwd_x2")
+    torch.cuda.synchronize()
+    return d_planes, grads, guard.tolist()
+
+
+def _round3_backward(dev, meta, table, ws, x7t, pts, radius, eps, d_sdf, H, N2, n_active=16):
+    from rise_sdf_amd import _lib
+    L = _lib.lib()
+    S = x7t.shape[1]
+    p = _lib.ptr
+    st = _lib.stream_ptr()
+    planes = torch.zeros(16, 7, S, 2, device=dev)
+    _lib.check(L.rsdf_hashgrid_fwd_fd7_pts(p(pts), radius, eps, p(table.detach()), ctypes.byref(meta), S, n_active, p(planes), st), "gather")
+    flat = [t.detach().contiguous() for wb in ws for t in wb]
+    d_planes = torch.full((16, 7, S, 2), float("nan"), device=dev)
+    grads = [torch.zeros_like(t) for t in flat]
+    _lib.check(L.rsdf_sdfmlp_fd7_bwd(p(x7t), p(planes), 16, n_active, 2.0, -1.0, H, N2, *[p(t) for t in flat], S, p(d_sdf), None, None,
+                                     p(d_planes), *[p(t) for t in grads], st), "bwd round 3")
+    torch.cuda.synchronize()
+    return d_planes, grads
+
+
+@pytest.mark.parametrize("H", [64, 128])
+def test_outlier_gradient_row_does_not_flush_the_others(dev, ops, H):
+    """A single d_sdf row at 2^30 times the typical magnitude sets the launch scale of the x2 gradient images: unguarded,
+    every ordinary row's d(hash features) is flushed (shown first, reroute = 0); guarded (the default), the launch is rerouted
+    on the device to the range-free kernels and every row agrees with them at 1e-4 of the ordinary rows' largest entry."""
+    from rise_sdf_amd import _lib
+    N2, S = 13, 6000
+    meta, table, ws, x7t, pts, radius, eps = _field_inputs(dev, ops, S, H, N2, seed=41)
+    g = torch.Generator().manual_seed(5)
+    d_sdf = (torch.randn(7, S, generator=g) * 1e-3).to(dev)
+    d_sdf[3, 777] = 1e-3 * 2.0 ** 30
+    ref, ref_g = _round3_backward(dev, meta, table, ws, x7t, pts, radius, eps, d_sdf, H, N2)
+    others = torch.ones(7, S, dtype=torch.bool, device=dev)
+    others[3, 777] = False
+    scale = float(ref[:, others].abs().max())
+    assert scale > 0
+    # unguarded: the ordinary rows are lost
+    raw, _, _ = _x2_backward(dev, meta, table, ws, x7t, pts, radius, eps, d_sdf, H, N2, reroute=0)
+    lost = float((raw[:, others] - ref[:, others]).abs().max()) / scale
+    assert lost > 1e-2, f"the outlier no longer flushes the ordinary rows ({lost:.2e}): is this test still testing anything?"
+    # guarded: the launch runs on the range-free kernels
+    _lib.poll_status(dev, raise_on_error=False)
+    before = _lib.status_totals()
+    got, got_g, guard = _x2_backward(dev, meta, table, ws, x7t, pts, radius, eps, d_sdf, H, N2, reroute=1)
+    after = _lib.poll_status(dev)
+    assert guard[4] == 1 and after["x2_bwd_rerouted"] - before["x2_bwd_rerouted"] == 1, (guard, before, after)
+    err = float((got[:, others] - ref[:, others]).abs().max()) / scale
+    print(f"H = {H}: ordinary rows vs the range-free kernels: unguarded {lost:.2e}, guarded {err:.2e} (guard words {guard})")
+    assert err < 1e-4
+    assert float((got[:, 3, 777] - ref[:, 3, 777]).abs().max()) < 1e-4 * float(ref[:, 3, 777].abs().max())
+    for a, b in zip(got_g, ref_g):
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-30
+
+
+@pytest.mark.parametrize("H", [64, 128])
+def test_ordinary_launch_is_not_rerouted_and_forced_reroute_equals_round3(dev, ops, H):
+    """(a) gradients spread over six decades (the spread measured inside bench chunks) leave the decision word
+    clear; (b) reroute = 2 runs the range-free route unconditionally: d_planes and weight gradients equal the round-3 entry
+    point's on fp32 planes to the 2^-24 of the image's hi + lo reconstruction."""
+    from rise_sdf_amd import _lib
+    N2, S = 13, 5000
+    meta, table, ws, x7t, pts, radius, eps = _field_inputs(dev, ops, S, H, N2, seed=43)
+    g = torch.Generator().manual_seed(6)
+    mag = 10.0 ** (torch.rand(7, S, generator=g) * 6.0 - 6.0)
+    d_sdf = (torch.randn(7, S, generator=g).sign() * mag).to(dev)
+    ref, ref_g = _round3_backward(dev, meta, table, ws, x7t, pts, radius, eps, d_sdf, H, N2)
+    _lib.poll_status(dev, raise_on_error=False)
+    before = _lib.status_totals()
+    got, got_g, guard = _x2_backward(dev, meta, table, ws, x7t, pts, radius, eps, d_sdf, H, N2, reroute=1)
+    after = _lib.poll_status(dev)
+    assert guard[4] == 0 and guard[2] == 7 * S and after["x2_bwd_rerouted"] == before["x2_bwd_rerouted"]
+    assert after["x2_bwd_guarded"] - before["x2_bwd_guarded"] == 1
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) < 3e-5 * scale
+    forced, forced_g, guard2 = _x2_backward(dev, meta, table, ws, x7t, pts, radius, eps, d_sdf, H, N2, reroute=2)
+    assert guard2[4] == 1
+    assert float((forced - ref).abs().max()) < 2e-6 * scale, float((forced - ref).abs().max()) / scale
+    for a, b in zip(forced_g, ref_g):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-30
+
+
+def test_forced_reroute_through_the_autograd_node(dev, ops, monkeypatch):
+    """RSDF_X2_REROUTE=force through rise_sdf_amd.fused.sdf_field_fd7 (the in-place planes, the x7t workspace, the feature
+    branch's dh2c): table and weight gradients equal RSDF_X2=0."""
+    from rise_sdf_amd import fused
+    H, N2, S = 64, 13, 4133
+    meta, table, ws, x7t, pts, radius, eps = _field_inputs(dev, ops, S, H, N2, seed=47)
+    outs = {}
+    for name, env in (("r3", {"RSDF_X2": "0"}), ("forced", {"RSDF_X2_REROUTE": "force"})):
+        monkeypatch.delenv("RSDF_X2", raising=False)
+        monkeypatch.delenv("RSDF_X2_REROUTE", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for t in [table] + [p for wb in ws for p in wb]:
+            t.grad = None
+        sdf7t, feat = fused.sdf_field_fd7(x7t, table, ws, meta, 16, 2.0, -1.0, eps / (2 * radius), want_feature=True, points=pts,
+                                          radius=radius, eps=eps)
+        gs = torch.randn(sdf7t.shape, generator=torch.Generator().manual_seed(1)).to(dev)
+        gf = torch.randn(feat.shape, generator=torch.Generator().manual_seed(2)).to(dev)
+        ((sdf7t * gs).sum() + (feat * gf).sum()).backward()
+        outs[name] = [t.grad.clone() for t in [table] + [p for wb in ws for p in wb]]
+    for n, a, b in zip(["table", "w0", "b0", "w1", "b1", "w2", "b2"], outs["r3"], outs["forced"]):
+        scale = float(a.abs().max())
+        assert scale > 0 and float((a - b).abs().max()) < 1e-5 * scale, (n, float((a - b).abs().max()) / scale)
+
+
+def test_forward_range_violation_raises_the_named_error(dev, ops, monkeypatch):
+    """A hidden weight of 5000 (weight_g is a free parameter; the reference's fp32 network stays finite) overflows the x2
+    format: the forward counts it on the device and the next host read raises a RiseSdfHipError that names the bound and
+    RSDF_X2=0 -- instead of NaN losses a few hundred steps later.  Inside the range nothing trips."""
+    import rise_sdf_amd as R
+    from rise_sdf_amd import _lib, fused
+    monkeypatch.delenv("RSDF_CHECK", raising=False)
+    monkeypatch.delenv("RSDF_X2", raising=False)
+    for H in (64, 128):
+        N2, S = 13, 1000
+        meta, table, ws, x7t, pts, radius, eps = _field_inputs(dev, ops, S, H, N2, seed=33)
+        with torch.no_grad():
+            ws[1][0][3, 5] = 900.0
+            fused.sdf_field_fd7(x7t, table, ws, meta, 16, 2.0, -1.0, eps / (2 * radius), want_feature=True, points=pts, radius=radius, eps=eps)
+            assert R.check_status(dev)["x2_fwd_nonfinite"] == 0
+            ws[1][0][3, 5] = 5000.0
+            sdf_bad, _ = fused.sdf_field_fd7(x7t, table, ws, meta, 16, 2.0, -1.0, eps / (2 * radius), want_feature=True, points=pts,
+                                             radius=radius, eps=eps)
+            assert not bool(torch.isfinite(sdf_bad).all())
+            with pytest.raises(_lib.RiseSdfHipError, match="RSDF_X2=0"):
+                R.check_status(dev)
+            assert R.check_status(dev)["x2_fwd_nonfinite"] == 0          # reported once, then cleared
+            # the same through a host read the path makes anyway: the marcher's sample count
+            fused.sdf_field_fd7(x7t, table, ws, meta, 16, 2.0, -1.0, eps / (2 * radius), points=pts, radius=radius, eps=eps)
+            rays = camera_rays(8, 8, seed=1).to(dev)
+            from rise_sdf_amd import ops as O
+            tmin, tmax = O.ray_aabb_intersect(rays[:, :3].contiguous(), rays[:, 3:].contiguous(),
+                                              torch.tensor([-1.5, -1.5, -1.5, 1.5, 1.5, 1.5], device=dev))[:2]
+            with pytest.raises(_lib.RiseSdfHipError, match="1023"):
+                O.march(rays[:, :3].contiguous(), rays[:, 3:].contiguous(), tmin, tmax,
+                        torch.tensor([-1.5, -1.5, -1.5, 1.5, 1.5, 1.5], device=dev),
+                        torch.ones(1, 1, 1, dtype=torch.bool, device=dev), 0.05, 0.0)
+            # a table value beyond the input range (|hash feature| >= 255)
+            ws[1][0][3, 5] = 1.0
+            t2 = table.detach().clone()
+            t2[12345] = 300.0
+            t2[::7] = 300.0
+            fused.sdf_field_fd7(x7t, t2, ws, meta, 16, 2.0, -1.0, eps / (2 * radius), points=pts, radius=radius, eps=eps)
+            with pytest.raises(_lib.RiseSdfHipError, match="255"):
+                R.check_status(dev)

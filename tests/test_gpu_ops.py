@@ -24,7 +24,7 @@ def ops():
 
 def test_library_is_loaded(dev):
     from rise_sdf_amd import _lib
-    assert _lib.lib().rsdf_abi_version() == 2
+    assert _lib.lib().rsdf_abi_version() == 3
 
 
 # ---- M1 -------------------------------------------------------------------------------------------
