@@ -544,10 +544,13 @@ def occ_grid_update(occs, indices, occ, resolution, occ_thre=0.01, ema_decay=0.9
 # --------------------------------------------------------------------------------------
 def neus_geometry_render(rays, ray_indices, t_starts, t_ends, table, meta, mlp_params,
                          variance, *, radius, fd_eps, cos_anneal_ratio=1.0,
-                         n_active_levels=None, sdf7_given=None):
+                         n_active_levels=None, sdf7_given=None, alphas_given=None):
     """Field query + NeuS alpha + composite for an already-marched sample set.
-    Returns dict(opacity [N,1], depth [N,1], comp_normal [N,3], weights, alphas, sdf, sdf_grad, sdf7 (own values)).
-    ``sdf7_given``: see volume_sdf."""
+    Returns dict(opacity [N,1], depth [N,1], comp_normal [N,3], weights, alphas, sdf, sdf_grad, sdf7 (own values),
+    alphas_own).  ``sdf7_given``: see volume_sdf.  ``alphas_given`` [S]: the VALUES of alpha are replaced by these (the
+    gradient still flows through this function's own get_alpha): the weight backward of render_weight.cu:139-151 divides a
+    rounding residue by max(1 - alpha, 1e-10), so an implementation under test can only be compared downstream of it on
+    bit-identical alphas (tests/test_gpu_late_regime.py)."""
     n_rays = rays.shape[0]
     rays_o, rays_d = rays[:, 0:3], rays[:, 3:6]
     ri = ray_indices.to(torch.int64)
@@ -560,13 +563,16 @@ def neus_geometry_render(rays, ray_indices, t_starts, t_ends, table, meta, mlp_p
                                           sdf7_given=sdf7_given, return_sdf7=True)
     normal = F.normalize(grad, p=2, dim=-1, eps=1e-6)
     alphas = get_alpha(sdf, normal, t_d, dists, inv_s_from_variance(variance), cos_anneal_ratio)
+    alphas_own = alphas.detach().clone()
+    if alphas_given is not None:
+        alphas = alphas + (alphas_given.to(alphas.dtype) - alphas).detach()
     weights, trans = render_weight_from_alpha(alphas, ray_indices=ri, n_rays=n_rays)
     opacity = accumulate_along_rays(weights, None, ray_indices=ri, n_rays=n_rays)
     depth = accumulate_along_rays(weights, mid, ray_indices=ri, n_rays=n_rays)
     comp_normal = accumulate_along_rays(weights, normal, ray_indices=ri, n_rays=n_rays)
     return {"opacity": opacity, "depth": depth, "comp_normal": comp_normal, "weights": weights,
             "trans": trans, "alphas": alphas, "sdf": sdf, "sdf_grad": grad, "feature": feature,
-            "normal": normal, "sdf7": own7}
+            "normal": normal, "sdf7": own7, "alphas_own": alphas_own}
 
 
 # --------------------------------------------------------------------------------------

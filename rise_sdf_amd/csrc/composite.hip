@@ -18,62 +18,132 @@ constexpr int THREADS = 256;  // 4 rays per workgroup
 
 __device__ __forceinline__ int64_t ray_of_wave() { return ((int64_t)blockIdx.x * THREADS + threadIdx.x) >> 6; }
 
-// MODE 0: weights + trans; MODE 1: visibility mask
+// ---- C1 in the REFERENCE'S ORDER OF OPERATIONS ---------------------------------------------------------------------------
+// render_weight.cu:86-153 runs one thread per ray: T *= (1 - a) left to right, and in the backward a running total that is
+// first summed and then DECREMENTED left to right,
+//     accum = sum_j gw_j w_j;   ga_j = (gw_j T - accum) / max(1 - a_j, 1e-10);   accum -= gw_j w_j;   T *= (1 - a_j).
+// Once a ray has saturated (late training: inv_s in the hundreds to thousands, alpha exactly 1 at the surface crossing) accum
+// should be 0 and IS the rounding residue of that subtraction chain, and max(1 - a_j, 1e-10) multiplies it by up to 1e10: the
+// reference's gradient there is a deterministic function of its order of operations.  A suffix scan (rounds 1-4 here) evaluates
+// the same closed form without the residue -- and therefore differs from the reference by exactly that term (measured with the
+// oracle, 48 x 48 rays, visibility-pruned, inv_s 1808: |d_alpha| up to 9.7e3 where the closed form gives 10; 1.6e-3 of the
+// largest table-gradient row).  Parity with the reference means its order: these kernels keep one LANE per ray for the
+// arithmetic (the identical sequence of fp32 roundings: bit-exact against oracle/risesdf_oracle.c, no contraction) and the
+// whole wave for the memory side -- a wavefront owns 64 consecutive rays, stages 64 samples of each through LDS with
+// coalesced 256-byte runs, and every lane then walks its own ray's row.  The dependent chain is ~2 x steps x a few cycles per
+// wave and all waves run at once (448 for a 28672-ray chunk): 20-40 us per launch, below the kernels' memory time.
+constexpr int SEQ_LD = 65;                       // row stride of a [64 rays][64 samples] LDS tile (conflict-free both ways)
+
+struct SeqRays {
+    int base, steps, max_steps;
+};
+__device__ __forceinline__ SeqRays seq_rays(const int32_t *__restrict__ packed, int64_t n_rays)
+{
+    const int64_t r = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    SeqRays s;
+    s.base = r < n_rays ? packed[2 * r] : 0;
+    s.steps = r < n_rays ? packed[2 * r + 1] : 0;
+    int m = s.steps;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+    s.max_steps = m;
+    return s;
+}
+// tile[rr][lane] <- src[base_rr + c + lane] for the wave's 64 rays (rows past a ray's end are left as they are: never read)
+__device__ __forceinline__ void seq_stage(float *tile, const float *__restrict__ src, const SeqRays &s, int c)
+{
+    const int lane = threadIdx.x;
+#pragma unroll 8
+    for (int rr = 0; rr < 64; ++rr) {
+        const int b = __shfl(s.base, rr, 64), n = __shfl(s.steps, rr, 64);
+        if (c + lane < n) tile[rr * SEQ_LD + lane] = src[(int64_t)b + c + lane];
+    }
+}
+__device__ __forceinline__ void seq_unstage(float *__restrict__ dst, const float *tile, const SeqRays &s, int c)
+{
+    const int lane = threadIdx.x;
+#pragma unroll 8
+    for (int rr = 0; rr < 64; ++rr) {
+        const int b = __shfl(s.base, rr, 64), n = __shfl(s.steps, rr, 64);
+        if (c + lane < n) dst[(int64_t)b + c + lane] = tile[rr * SEQ_LD + lane];
+    }
+}
+
+// MODE 0: weights + trans; MODE 1: visibility mask (lib/nerfacc/vol_rendering.py:503-520 on the same sequential T)
 template <int MODE>
-__global__ void __launch_bounds__(THREADS)
+__global__ void __launch_bounds__(64)
 weight_fwd_kernel(const int32_t *__restrict__ packed, const float *__restrict__ alphas,
                   int64_t n_rays, float *__restrict__ weights, float *__restrict__ trans,
                   float eps, float alpha_thre, uint8_t *__restrict__ keep)
 {
-    const int64_t r = ray_of_wave();
-    if (r >= n_rays) return;
-    const int base = packed[2 * r], steps = packed[2 * r + 1];
-    const int lane = lane_id();
-    float carry = 1.0f;
-    for (int c = 0; c < steps; c += 64) {
-        const int j = c + lane;
-        const float a = j < steps ? alphas[base + j] : 0.0f;
-        const float incl = wave_incl_prod(1.0f - a);
-        float excl = __shfl_up(incl, 1, 64);
-        if (lane == 0) excl = 1.0f;
-        const float T = carry * excl;
-        if (j < steps) {
+    __shared__ float s_a[64 * SEQ_LD], s_t[64 * SEQ_LD];
+    const SeqRays s = seq_rays(packed, n_rays);
+    const int lane = threadIdx.x;
+    float T = 1.0f;
+    for (int c = 0; c < s.max_steps; c += 64) {
+        seq_stage(s_a, alphas, s, c);
+        __syncthreads();
+        const int n = min(64, s.steps - c);
+        for (int j = 0; j < n; ++j) {
+            const float a = s_a[lane * SEQ_LD + j];
             if (MODE == 0) {
-                weights[base + j] = a * T;
-                if (trans) trans[base + j] = T;
+                s_a[lane * SEQ_LD + j] = a * T;                  // weights[j] = alpha * T      (render_weight.cu:108-111)
+                s_t[lane * SEQ_LD + j] = T;
             } else {
                 bool v = T >= eps;
                 if (alpha_thre > 0.0f) v = v && (a >= alpha_thre);
-                keep[base + j] = v ? 1 : 0;
+                s_t[lane * SEQ_LD + j] = v ? 1.0f : 0.0f;
+            }
+            T *= (1.0f - a);                                     // T *= (1.f - alpha)
+        }
+        __syncthreads();
+        if (MODE == 0) {
+            seq_unstage(weights, s_a, s, c);
+            if (trans) seq_unstage(trans, s_t, s, c);
+        } else {
+#pragma unroll 8
+            for (int rr = 0; rr < 64; ++rr) {
+                const int b = __shfl(s.base, rr, 64), nn = __shfl(s.steps, rr, 64);
+                if (c + lane < nn) keep[(int64_t)b + c + lane] = s_t[rr * SEQ_LD + lane] != 0.0f ? 1 : 0;
             }
         }
-        carry *= __shfl(incl, 63, 64);
+        __syncthreads();
     }
 }
 
-// ga_j = (gw_j T_j - sum_{k>=j} gw_k w_k) / max(1 - a_j, 1e-10)   (render_weight.cu:139-151)
-__global__ void __launch_bounds__(THREADS)
+// render_weight.cu:114-153, statement for statement per lane (``trans`` of the forward is not read: the reference recomputes T)
+__global__ void __launch_bounds__(64)
 weight_bwd_kernel(const int32_t *__restrict__ packed, const float *__restrict__ alphas,
-                  const float *__restrict__ weights, const float *__restrict__ trans,
-                  const float *__restrict__ gw, int64_t n_rays, float *__restrict__ ga)
+                  const float *__restrict__ weights, const float *__restrict__ gw, int64_t n_rays, float *__restrict__ ga)
 {
-    const int64_t r = ray_of_wave();
-    if (r >= n_rays) return;
-    const int base = packed[2 * r], steps = packed[2 * r + 1];
-    const int lane = lane_id();
-    float carry = 0.0f;  // sum over later chunks
-    const int n_chunks = (steps + 63) >> 6;
-    for (int ci = n_chunks - 1; ci >= 0; --ci) {
-        const int j = ci * 64 + lane;
-        const bool ok = j < steps;
-        const float g = ok ? gw[base + j] : 0.0f;
-        const float w = ok ? weights[base + j] : 0.0f;
-        const float suf = wave_suffix_sum(g * w);
-        if (ok) {
-            const float a = alphas[base + j];
-            ga[base + j] = (g * trans[base + j] - (suf + carry)) / fmaxf(1.0f - a, 1e-10f);
+    __shared__ float s_g[64 * SEQ_LD], s_w[64 * SEQ_LD], s_a[64 * SEQ_LD];
+    const SeqRays s = seq_rays(packed, n_rays);
+    const int lane = threadIdx.x;
+    float accum = 0.0f;
+    for (int c = 0; c < s.max_steps; c += 64) {                  // accum += grad_weights[j] * weights[j]
+        seq_stage(s_g, gw, s, c);
+        seq_stage(s_w, weights, s, c);
+        __syncthreads();
+        const int n = min(64, s.steps - c);
+        for (int j = 0; j < n; ++j) accum += s_g[lane * SEQ_LD + j] * s_w[lane * SEQ_LD + j];
+        __syncthreads();
+    }
+    float T = 1.0f;
+    for (int c = 0; c < s.max_steps; c += 64) {
+        seq_stage(s_g, gw, s, c);
+        seq_stage(s_w, weights, s, c);
+        seq_stage(s_a, alphas, s, c);
+        __syncthreads();
+        const int n = min(64, s.steps - c);
+        for (int j = 0; j < n; ++j) {
+            const float a = s_a[lane * SEQ_LD + j], g = s_g[lane * SEQ_LD + j];
+            s_a[lane * SEQ_LD + j] = (g * T - accum) / fmaxf(1.0f - a, 1e-10f);
+            accum -= g * s_w[lane * SEQ_LD + j];
+            T *= (1.0f - a);
         }
-        carry += __shfl(suf, 0, 64);
+        __syncthreads();
+        seq_unstage(ga, s_a, s, c);
+        __syncthreads();
     }
 }
 
@@ -323,7 +393,7 @@ int rsdf_weight_from_alpha_fwd(const int32_t *packed_info, const float *alphas, 
                                float *weights, float *trans, void *stream)
 {
     if (n_rays <= 0) return 0;
-    weight_fwd_kernel<0><<<rsdf_blocks(n_rays * 64, THREADS), THREADS, 0, (hipStream_t)stream>>>(
+    weight_fwd_kernel<0><<<rsdf_blocks(n_rays, 64), 64, 0, (hipStream_t)stream>>>(
         packed_info, alphas, n_rays, weights, trans, 0.f, 0.f, nullptr);
     RSDF_RETURN_LAUNCH();
 }
@@ -332,7 +402,7 @@ int rsdf_visibility_from_alpha(const int32_t *packed_info, const float *alphas, 
                                float early_stop_eps, float alpha_thre, uint8_t *keep, void *stream)
 {
     if (n_rays <= 0) return 0;
-    weight_fwd_kernel<1><<<rsdf_blocks(n_rays * 64, THREADS), THREADS, 0, (hipStream_t)stream>>>(
+    weight_fwd_kernel<1><<<rsdf_blocks(n_rays, 64), 64, 0, (hipStream_t)stream>>>(
         packed_info, alphas, n_rays, nullptr, nullptr, early_stop_eps, alpha_thre, keep);
     RSDF_RETURN_LAUNCH();
 }
@@ -343,8 +413,9 @@ int rsdf_weight_from_alpha_bwd(const int32_t *packed_info, const float *alphas,
                                void *stream)
 {
     if (n_rays <= 0) return 0;
-    weight_bwd_kernel<<<rsdf_blocks(n_rays * 64, THREADS), THREADS, 0, (hipStream_t)stream>>>(
-        packed_info, alphas, weights, trans, grad_weights, n_rays, grad_alphas);
+    (void)trans;          // (the reference's backward recomputes T in its own order, render_weight.cu:141-151)
+    weight_bwd_kernel<<<rsdf_blocks(n_rays, 64), 64, 0, (hipStream_t)stream>>>(
+        packed_info, alphas, weights, grad_weights, n_rays, grad_alphas);
     RSDF_RETURN_LAUNCH();
 }
 
