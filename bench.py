@@ -38,7 +38,6 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 T_PROCESS_START = time.perf_counter()
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
@@ -177,12 +176,11 @@ def cpu_baseline(model, rays_cpu, jitter_cpu, max_rays, budget_s=5.0, reps=5):
     must stay within minutes); the line says when it was shrunk."""
     import statistics
     import oracle
-    from test_gpu_model import oracle_params
     import ctypes
     gomp = ctypes.CDLL("libgomp.so.1")
     n = rays_cpu.shape[0]
     s0 = (n // 2 // 800) * 800
-    meta, table, mlp, var = oracle_params(model)
+    meta, table, mlp, var = oracle.params_from_model(model)
     roi = torch.tensor([-1.5, -1.5, -1.5, 1.5, 1.5, 1.5])
 
     def one(n_rays):
@@ -275,6 +273,44 @@ def roofline_from(summary, steps):
             return "mfma", 2.0 * a[2] * a[3] * a[4]
         return None, 0.0
 
+    def pipe_products(name, a):
+        """MFMA products the kernel EXECUTES per algorithmic fp32 product, on the 16-bit matrix pipe it runs on: the x2
+        kernels carry every operand as two fp16 parts and evaluate three partial products (one in the 16-bit mode), the
+        round 1-3 kernels and the per-layer kernels three bf16 parts and six, the _bf16 build one."""
+        if name.endswith("_bf16"):
+            return 1
+        if name in ("rsdf_sdfmlp_fd7_fwd_x2", "rsdf_sdfmlp_fd7_bwd_x2"):
+            return 1 if (a and a[0] == 1) else 3
+        return 6
+
+    def price(name, v):
+        """-> the roofline entry of one entry point.  MFMA-bound entries are priced against the pipe they execute on:
+        ``achieved`` stays the ALGORITHMIC (fp32-equivalent) TFLOP/s, ``executed`` = achieved x products per fp32 product,
+        ``frac`` = executed / the dense f16 / bf16 MFMA peak (a fraction of the fp32-MFMA peak can exceed 1 for a kernel that
+        does not run on that pipe, and did).  The stencil gather is priced on the bytes it cannot avoid moving (SURVEY 8d's
+        7 x 1164 B describes 56 corner fetches per level; the kernel merges them from an L2 / MALL-resident table)."""
+        b, _ = cost(name, v["args"][0])
+        if b is None:
+            return None
+        wk = sum(cost(name, a)[1] for a in v["args"])
+        secs = v["ms"] / 1e3
+        if b == "hbm":
+            e = {"bound": "hbm", "achieved": round(wk / secs / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+            if name in ("rsdf_hashgrid_fwd_fd7_x2", "rsdf_hashgrid_fwd_fd7_pts", "rsdf_hashgrid_fwd_fd7"):
+                # centre 12 B + planes 896 B per sample -- the x2 image: 1008 B with its xyz / bias columns
+                nb = 1020 if name == "rsdf_hashgrid_fwd_fd7_x2" else 908
+                e["survey_8d_GBps"] = e["achieved"]          # 7 evaluations x 1164 B: not a bound for a merged stencil gather
+                e["evals_per_sec"] = round(e["achieved"] * 1e9 / 1164.0)
+                e["necessary_bytes_per_sample"] = nb
+                e["achieved"] = round(e["achieved"] * nb / (7 * 1164.0), 1)
+            e["frac"] = round(e["achieved"] / HBM_PEAK_GBS, 4)
+            return e
+        m = pipe_products(name, v["args"][0])
+        ach = wk / secs / 1e12
+        return {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                "products_per_fp32_product": m, "executed": round(m * ach, 1),
+                "frac": round(m * ach / MFMA_BF16_PEAK_TF, 4)}
+
     def samples_of(name, a):
         if name.endswith("_fd7_pts") or name == "rsdf_hashgrid_fwd_fd7_x2":
             return a[2]
@@ -292,42 +328,22 @@ def roofline_from(summary, steps):
     if bound is None:
         return {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
                 "traffic": None, "kernel": name}, breakdown
-    work = sum(cost(name, a)[1] for a in d["args"])
-    secs = d["ms"] / 1e3
-    if bound == "hbm":
-        ach, peak, unit = work / secs / 1e9, HBM_PEAK_GBS, "GB/s"
-    else:
-        ach, peak, unit = work / secs / 1e12, (MFMA_BF16_PEAK_TF if bound == "mfma_bf16" else MFMA_F32_PEAK_TF), "TFLOP/s"
-    bf16 = bound == "mfma_bf16"
-    bound = "mfma" if bf16 else bound
-    out = {"bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
-           "frac": round(ach / peak, 4), "traffic": None, "kernel": name,
-           "avg_launch_ms": round(d["ms"] / d["calls"], 4), "launches": d["calls"],
-           "samples_per_launch": round(sum(samples_of(name, a) for a in d["args"]) / d["calls"])}
+    out = price(name, d)
+    out.update({"traffic": None, "kernel": name, "avg_launch_ms": round(d["ms"] / d["calls"], 4), "launches": d["calls"],
+                "samples_per_launch": round(sum(samples_of(name, a) for a in d["args"]) / d["calls"])})
     # the same pricing for the other heavy entry points (the north star quotes the hash gather separately)
     others = {}
     for k, v in summary.items():
-        b, _ = cost(k, v["args"][0])
-        if b is None or k == name or v["ms"] < 0.02 * d["ms"]:
+        if k == name or v["ms"] < 0.02 * d["ms"]:
             continue
-        wk = sum(cost(k, a)[1] for a in v["args"])
-        a_, p_, u_ = (wk / (v["ms"] / 1e3) / 1e9, HBM_PEAK_GBS, "GB/s") if b == "hbm" else \
-            (wk / (v["ms"] / 1e3) / 1e12, MFMA_BF16_PEAK_TF if b == "mfma_bf16" else MFMA_F32_PEAK_TF, "TFLOP/s")
-        others[k] = {"bound": "mfma" if b == "mfma_bf16" else b, "achieved": round(a_, 2), "peak": p_, "unit": u_,
-                     "frac": round(a_ / p_, 4)}
+        e = price(k, v)
+        if e is not None:
+            others[k] = e
     out["other_kernels"] = others
-    if bf16:
-        out["note"] = "one bf16 x bf16 MFMA product per k-step, fp32 accumulate; peak = dense bf16 MFMA"
-    elif name.endswith("_x2"):
-        # algorithmic fp32 flops against the fp32 MFMA peak; the kernel evaluates each fp32 product as three
-        # f16 x f16 partial products of two-part operands on v_mfma_f32_*_f16, whose own ceiling
-        # for fp32-equivalent work is 2500 / 3 = 833 TFLOP/s
-        out["note"] = "fp32-equivalent flops (two-part fp16 operands, 3 MFMA products); peak = fp32 MFMA dense"
-    elif name.startswith("rsdf_sdfmlp_fd7"):
-        # algorithmic fp32 flops against the fp32 MFMA peak; the kernel evaluates each fp32 product as six
-        # bf16 x bf16 partial products on v_mfma_f32_32x32x16_bf16, whose own ceiling for
-        # fp32-equivalent work is 2500 / 6 = 417 TFLOP/s
-        out["note"] = "fp32-equivalent flops (3-way split bf16 MFMA); peak = fp32 MFMA dense"
+    if out["bound"] == "mfma":
+        out["note"] = ("achieved = algorithmic fp32-equivalent TFLOP/s; executed = achieved x the matrix products the kernel "
+                       "issues per fp32 product (x2: two fp16 parts, 3; round-3 / per-layer: three bf16 parts, 6; 16-bit "
+                       "modes: 1); frac = executed / dense f16-bf16 MFMA peak, the pipe the kernel runs on")
     return out, breakdown
 
 
@@ -683,19 +699,6 @@ def main():
                                                                   / max(overlapped[k]["calls"], 1), 4)
             attach_traffic(roof, args.pmc_summary)
             if roof is not None and "other_kernels" in roof:
-                fd7 = roof["other_kernels"].get("rsdf_hashgrid_fwd_fd7_x2") or \
-                    roof["other_kernels"].get("rsdf_hashgrid_fwd_fd7_pts") or \
-                    roof["other_kernels"].get("rsdf_hashgrid_fwd_fd7")
-                if fd7 is not None:
-                    # the stencil gather priced two ways: SURVEY 8d's algorithmic bytes (7 evaluations x 1164 B; a
-                    # fraction >= 1 only says that it fetches far fewer corners than 56 per level), and the bytes it
-                    # cannot avoid moving through HBM (centre 12 B + planes 896 B per sample -- the x2 image: 1008 B with its
-                    # xyz / bias columns; the table is L2 / MALL resident)
-                    nb = 1020 if "rsdf_hashgrid_fwd_fd7_x2" in roof["other_kernels"] else 908
-                    fd7["necessary_bytes_per_sample"] = nb
-                    fd7["achieved_necessary"] = round(fd7["achieved"] * nb / (7 * 1164.0), 1)
-                    fd7["frac_necessary"] = round(fd7["achieved_necessary"] / HBM_PEAK_GBS, 4)
-                    fd7["evals_per_sec"] = round(fd7["achieved"] * 1e9 / 1164.0)
                 roof["other_kernels"]["rsdf_hashgrid_fwd (generic)"] = generic_gather_probe(model, rays, jitter, args.chunk)
         cpu = None
         t_cpu0 = time.perf_counter()

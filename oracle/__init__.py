@@ -607,3 +607,25 @@ def loss_tail(out, batch, lambdas, sparsity_scale=1.0, has_mask=True, stage=0):
         t["curvature"] = out["sdf_laplace_samples"].abs().mean()
         loss = loss + t["curvature"] * lam("curvature")
     return loss, t
+
+
+# --------------------------------------------------------------------------------------
+# checker-side plumbing: a model under test -> the plain structures the functions above take
+# --------------------------------------------------------------------------------------
+def params_from_model(model):
+    """(meta, table, mlp, variance) of a NeuS-shaped model (``geometry.encoding`` = CompositeEncoding ->
+    ProgressiveBandHashGrid -> tcnn.Encoding, ``geometry.network`` = VanillaMLP with weight_norm, ``variance``), as detached
+    CPU leaves that require grad.  Used by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg."""
+    geo = model.geometry
+    enc = geo.encoding.encoding.encoding
+    meta, n_params = grid_meta(enc.n_levels, enc.n_features_per_level, enc.log2_hashmap_size,
+                               enc.base_resolution, enc.per_level_scale)
+    table = enc.params.detach().cpu().clone().requires_grad_(True)
+    mlp = []
+    for m in geo.network.layers:
+        if isinstance(m, torch.nn.Linear):
+            mlp.append({"g": m.weight_g.detach().cpu().clone().requires_grad_(True),
+                        "v": m.weight_v.detach().cpu().clone().requires_grad_(True),
+                        "b": m.bias.detach().cpu().clone().requires_grad_(True)})
+    var = model.variance.variance.detach().cpu().clone().requires_grad_(True)
+    return meta, table, mlp, var

@@ -44,19 +44,7 @@ def model_config(n_levels=4, hidden=32, feat=13, grid_prune=False, base=16, log2
 
 def oracle_params(model):
     """Pull the HIP model's parameters into the oracle's plain structures."""
-    geo = model.geometry
-    enc = geo.encoding.encoding.encoding  # CompositeEncoding -> ProgressiveBandHashGrid -> tcnn.Encoding
-    meta, n_params = oracle.grid_meta(enc.n_levels, enc.n_features_per_level, enc.log2_hashmap_size,
-                                      enc.base_resolution, enc.per_level_scale)
-    table = enc.params.detach().cpu().clone().requires_grad_(True)
-    mlp = []
-    for m in geo.network.layers:
-        if isinstance(m, torch.nn.Linear):
-            mlp.append({"g": m.weight_g.detach().cpu().clone().requires_grad_(True),
-                        "v": m.weight_v.detach().cpu().clone().requires_grad_(True),
-                        "b": m.bias.detach().cpu().clone().requires_grad_(True)})
-    var = model.variance.variance.detach().cpu().clone().requires_grad_(True)
-    return meta, table, mlp, var
+    return oracle.params_from_model(model)
 
 
 def hip_sdf7(model, rays, ri, ts, te):

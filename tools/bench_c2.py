@@ -11,7 +11,6 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def measure_c2(dev, width=800, height=800, chunk=16384, stage=1, tex_hidden=128, steps=1, hidden=64, tex_precision="fp32",
