@@ -2,7 +2,8 @@
 """Golden vectors for the ASSEMBLED models, by running the reference's own classes in the build container
 (VERDICT r02 item 7):
 
-    python tests/golden/make_golden_models.py          ->  tests/golden/models_split_mixed_occ.npz, models_neus.npz
+    python tests/golden/make_golden_models.py          ->  tests/golden/models_split_mixed_occ.npz, models_neus.npz,
+                                                            models_neus_l16_h128.npz, models_split_mixed_occ_l16_h128.npz
 
 The reference's ``SplitMixedOCCModel.forward_`` (models/split_mixed_occ.py:224-443, incl. compute_indirect_radiance
 :179-222 and the relighting branch :320-331) and ``NeuSModel.forward_`` (models/neus.py:227-317) are EXECUTED, on the CPU, in
@@ -95,8 +96,8 @@ class NoDev:
         return False
 
 
-def model_cfg(indirect, stage1):
-    mlp = lambda n: {"otype": "VanillaMLP", "activation": "ReLU", "output_activation": "none", "n_neurons": 64,   # noqa: E731
+def model_cfg(indirect, stage1, tex_hidden=64):
+    mlp = lambda n: {"otype": "VanillaMLP", "activation": "ReLU", "output_activation": "none", "n_neurons": tex_hidden,   # noqa: E731
                      "n_hidden_layers": n}
     return mg.Cfg({
         "name": "split-mixed-occ", "radius": 1.5, "num_samples_per_ray": 1024, "num_samples_per_secondary_ray": 24,
@@ -156,6 +157,8 @@ def main():
     rays = camera_rays(18, 18, seed=2)
     saved = {"rays": rays, "shell": np.array(SHELL), "lut_res": np.array(LUT_RES)}
     state = None
+    if "--only-pbr-l16" in sys.argv:          # (development shortcut: the other fixtures are left untouched)
+        return pbr_l16_h128(SplitMixedOCCModel)
     for tag, (indirect, stage1, relighting) in {"s0": (False, False, False), "s0_indirect": (True, False, False),
                                                 "s1_indirect": (True, True, False), "s1_relight": (True, True, True)}.items():
         torch.manual_seed(5)
@@ -279,8 +282,70 @@ def main():
             bsaved["p__" + k] = v
     mg.save("models_neus_l16_h128.npz", **bsaved)
 
+    pbr_l16_h128(SplitMixedOCCModel)
+
+
+def pbr_l16_h128(SplitMixedOCCModel):
+    # ---- the FULL PBR model at the sizes the shipped kernel family runs: SplitMixedOCCModel.forward_,
+    # stage 1 with secondary-ray occlusion, L = 16 levels, T = 2^19 entries (table from its seed), 2 x 128 SDF network with
+    # 48 features, 128-wide radiance networks (albedo / env / secondary 4 hidden layers, roughness / metallic 2), 256 rays.
+    # The small fixtures above (L = 4, H = 32, 64-wide radiance networks) run the round-1 per-wave SDF kernels and per-layer
+    # kernels of another width; this one runs the x2 SDF kernels at H = 128, the L = 16 stencil gather and the 128-wide layer
+    # kernels against the reference's own forward_.
+    pcfg = model_cfg(True, True, tex_hidden=128)
+    pcfg["geometry"] = dict(pcfg["geometry"], feature_dim=48)
+    pcfg["geometry"]["xyz_encoding_config"] = dict(pcfg["geometry"]["xyz_encoding_config"], n_levels=16, log2_hashmap_size=19,
+                                                   base_resolution=32, per_level_scale=1.447269237440378, start_level=16)
+    pcfg["geometry"]["mlp_network_config"] = dict(pcfg["geometry"]["mlp_network_config"], n_neurons=128)
+    pcfg["texture"] = dict(pcfg["texture"], input_feature_dim=48)
+    pcfg["variance"] = {"init_val": 0.45, "modulate": False}
+    torch.manual_seed(8)
+    pbr = SplitMixedOCCModel(mg.Cfg(pcfg))
+    prays = camera_rays(16, 16, seed=4)
+    with torch.no_grad():
+        prm = pbr.geometry.encoding.encoding.encoding.params
+        prm.copy_(big_table(prm.numel()))
+        l0 = pbr.geometry.network.layers[0]
+        l0.weight_v[:, 3:] = torch.randn_like(l0.weight_v[:, 3:]) * 0.3
+        # (with the hash columns un-zeroed, weight_norm flattens the sphere init until the whole box is inside the surface:
+        # shifted so that the rays cross sdf = 0 inside the occupied shell)
+        pbr.geometry.network.layers[-1].bias[0] += 0.25
+        pbr.texture.FG_LUT = otex.synthetic_fg_lut(LUT_RES)
+        # (the environment map from a seed of its own instead of the constructor's draw: regenerated by the tests, not stored)
+        pbr.emitter.base.copy_(big_envmap(pbr.emitter.base.shape))
+    pbr.eval()
+    pbr.update_step(0, 0)
+    assert pbr.stage == 1
+    pbr.background_color = torch.ones(3)
+    with torch.no_grad():
+        pbr.emitter.build_mips()
+        pout = pbr.forward_(prays, relighting=False)
+    calls = pbr.occupancy_grid.calls
+    n_valid = int((pout["opacity"][:, 0] > 0.5).sum())
+    print("split-mixed-occ L16 H128: samples", calls[0][0].numel(), "valid rays", n_valid, "secondary samples",
+          calls[1][0].numel())
+    assert n_valid > 30 and calls[1][0].numel() > 100
+    psaved = {"rays": prays, "shell": np.array(SHELL), "lut_res": np.array(LUT_RES), "table_seed": np.array(BIG_TABLE_SEED),
+              "n_table": np.array(prm.numel()), "envmap_seed": np.array(BIG_ENVMAP_SEED),
+              "fd_eps": np.array(pbr.geometry._finite_difference_eps), "render_step_size": np.array(pbr.render_step_size),
+              "primary_ri": calls[0][0], "primary_ts": calls[0][1], "primary_te": calls[0][2],
+              "secondary_ri": calls[1][0], "secondary_ts": calls[1][1], "secondary_te": calls[1][2]}
+    for k, v in pout.items():
+        if isinstance(v, torch.Tensor) and v.dtype in (torch.float32, torch.bool, torch.int32) and not k.endswith("_bg"):
+            psaved["out__" + k] = v
+    for k, v in pbr.state_dict().items():
+        if not (k.endswith("encoding.params") or k.endswith("FG_LUT") or k == "emitter.base"):
+            psaved["p__" + k] = v
+    mg.save("models_split_mixed_occ_l16_h128.npz", **psaved)
+
 
 BIG_TABLE_SEED = 77
+BIG_ENVMAP_SEED = 78
+
+
+def big_envmap(shape, seed=BIG_ENVMAP_SEED):
+    """The environment map of the large PBR fixture, from its seed (lib/pbr/light.py:139's rand * 0.5 + 0.25 draw)."""
+    return torch.rand(tuple(shape), generator=torch.Generator().manual_seed(seed)) * 0.5 + 0.25
 
 
 def big_table(n, seed=BIG_TABLE_SEED):

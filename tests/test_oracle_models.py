@@ -31,10 +31,24 @@ def relight_base():
     return torch.rand(6, 64, 64, 3, generator=torch.Generator().manual_seed(9)) * 2.0
 
 
-def oracle_params_from_fixture(fx, relighting=False, grad=False):
+BIG_GOLDEN = os.path.join(os.path.dirname(GOLDEN), "models_split_mixed_occ_l16_h128.npz")
+
+
+def load_big_fixture():
+    """models_split_mixed_occ_l16_h128.npz plus what it regenerates from seeds (tests/golden/make_golden_models.py
+    big_table / big_envmap): the 58 MB hash table and the environment map."""
+    z = np.load(BIG_GOLDEN)
+    fx = {k: torch.from_numpy(z[k]) for k in z.files}
+    g = torch.Generator().manual_seed(int(fx["table_seed"]))
+    fx["p__geometry.encoding.encoding.encoding.params"] = (torch.rand(int(fx["n_table"]), generator=g) * 2 - 1) * 1e-3
+    fx["p__emitter.base"] = torch.rand(6, 64, 64, 3, generator=torch.Generator().manual_seed(int(fx["envmap_seed"]))) * 0.5 + 0.25
+    return fx
+
+
+def oracle_params_from_fixture(fx, relighting=False, grad=False, big=False):
     """The fixture's state_dict (the reference's parameter names) as the oracle's plain structures."""
     t = lambda k: fx["p__" + k].clone().requires_grad_(grad)   # noqa: E731
-    meta, n_params = oracle.grid_meta(4, 2, 14, 16, 1.5)
+    meta, n_params = oracle.grid_meta(16, 2, 19, 32, 1.447269237440378) if big else oracle.grid_meta(4, 2, 14, 16, 1.5)
     table = t("geometry.encoding.encoding.encoding.params")
     assert table.numel() == n_params
     mlp = [{"g": t(f"geometry.network.layers.{i}.weight_g"), "v": t(f"geometry.network.layers.{i}.weight_v"),
@@ -72,6 +86,53 @@ def test_oracle_model_matches_reference_forward(tag):
     assert int((fx[f"{tag}__opacity"][:, 0] > 0.5).sum()) == out["valid_indices"].numel() > 30
     if relighting:
         assert int(out["rmask"].sum()) > 0, "the relighting fixture must exercise the third bounce"
+
+
+TIGHT_L16 = ("comp_diffuse_rgb", "comp_blend", "opacity", "depth", "comp_albedo", "comp_metallic", "comp_roughness",
+             "comp_diffuse_rgb_phys")
+
+
+def check_against_big_fixture(out, fx, who):
+    """Gates shared by the oracle (CPU) and the HIP model (GPU) against the reference-run fixture at L = 16 / H = 128.
+
+    At L = 16 the progressive FD eps is one cell of the finest grid (3.7e-4): the normal divides an fp32 SDF difference by
+    2 eps, so ANY two fp32 evaluations of the same network -- here torch's CPU GEMMs on other batch shapes -- disagree by up to
+    ~1e-3 in a normal component.  In the full PBR model that reaches further than in NeuS: the secondary (reflection) rays start
+    at the composited depth along the composited normal, their visibility-pruned sample sets differ in a few borderline
+    samples (14 of 312 between the oracle and the reference run), and ``tr`` of such a ray moves the specular term of its pixel
+    by up to 0.06.  So: outputs that do not pass through a normal at the north star's 1e-4 (up to two borderline pixels);
+    the normal map at what fp32 resolves; the specular-dependent outputs within 1e-3 on all but a bounded number of pixels."""
+    key = lambda r, t: set(zip(r.tolist(), t.contiguous().view(torch.int32).tolist()))   # noqa: E731
+    dprim = len(key(*out["own_primary"][:2]) ^ key(fx["primary_ri"], fx["primary_ts"]))
+    dsec = len(key(*out["own_secondary"][:2]) ^ key(fx["secondary_ri"], fx["secondary_ts"]))
+    print(f"{who}: primary samples differing {dprim} of {fx['primary_ri'].numel()}, secondary {dsec} of {fx['secondary_ri'].numel()}")
+    assert dprim <= 6 and dsec <= 40
+    rows = []
+    for k in KEYS1:
+        ref, got = fx["out__" + k], out[k]
+        d = (got - ref).abs()
+        n4 = int((~torch.isclose(got, ref, rtol=1e-4, atol=2e-5).all(-1)).sum())
+        n3 = int((d.max(-1).values > 1e-3).sum())
+        rows.append(f"{k} max {float(d.max()):.1e} px>1e-4 {n4} px>1e-3 {n3}")
+        if k in TIGHT_L16:
+            assert n4 <= 2 + dprim and float(d.max()) < 1e-3, (who, k, n4, float(d.max()))
+        elif k == "comp_normal":
+            assert float(d.max()) < 3e-3, (who, k, float(d.max()))
+        else:
+            assert n3 <= 48 and float(d.max()) < 0.15 and float(d.median()) < 1e-5, (who, k, n3, float(d.max()), float(d.median()))
+    print(f"{who} vs the reference's forward_: " + "; ".join(rows))
+
+
+def test_oracle_model_matches_reference_forward_l16_h128():
+    """The same at the sizes the shipped kernel family runs (tests/golden/models_split_mixed_occ_l16_h128.npz: L = 16,
+    T = 2^19, 2 x 128 SDF network with 48 features, 128-wide radiance networks, stage 1 with secondary-ray occlusion)."""
+    fx = load_big_fixture()
+    P = oracle_params_from_fixture(fx, big=True)
+    with torch.no_grad():
+        out = OS.render(fx["rays"], P, stage=1, indirect=True, relighting=False, stratified_u=None)
+    assert torch.equal(out["own_primary"][0], fx["primary_ri"]) and torch.equal(out["own_primary"][1], fx["primary_ts"])
+    check_against_big_fixture(out, fx, "oracle")
+    assert abs(int((fx["out__opacity"][:, 0] > 0.5).sum()) - out["valid_indices"].numel()) <= 1 and out["valid_indices"].numel() > 30
 
 
 # ---- NeuSModel (models/neus.py:227-317) --------------------------------------------------------------------------------
