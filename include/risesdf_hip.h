@@ -376,6 +376,36 @@ int rsdf_sdfmlp_fd7_bwd_x2(const void *x2, int parts, int n_levels, int n_active
                            int reroute /*0 never, 1 guarded (decided per launch on the device), 2 always*/, float *d_planes,
                            float *dw0, float *db0, float *dw1, float *db1, float *dw2, float *db2, int *status /*nullable*/,
                            void *stream);
+/* ---- T3, layer PAIRS of the 128-wide radiance networks (models/texture.py:237-327: Linear(K,128) ReLU Linear(128,128) ReLU
+ * ... ; csrc/mlp_pair.hip): two layers per kernel in the x2 number format above.  The odd activation never leaves the CU
+ * (forward) or is recomputed from the pair's input (backward); a pair's input and output cross HBM once each way as the
+ * "pair image": [tile = row / 32][part 2][chunk = column / 8 (16)][row ^ 12 (chunk & 1)][8 columns] fp16, values x 2^6, 16 KB
+ * per 32-row tile (rsdf_pair_image_bytes), the same 4 bytes per value as fp32 rows.
+ *   rsdf_pair_pack    fp32 rows x [n][ldx] (columns [0, K), K <= 128) -> image (columns >= K: zeros)
+ *   rsdf_pair_unpack  image -> fp32 rows [n][128]
+ *   rsdf_pair_fwd     hb = relu(Wb relu(Wa x + ba) + bb); Wa [128][K], Wb [128][128] row-major (nn.Linear.weight); out_image
+ *                     (for the next pair) and / or out_rows [n][128] (for the per-layer kernels of the narrow output layer)
+ *   rsdf_pair_bwd     g = d hb [n][128] fp32 rows (g_masked != 0: already multiplied by hb > 0, as a pair above writes it);
+ *                     ``bound``: device word(s) holding the bits of a float >= max |g| (rsdf_pair_bound_from_rows scans g;
+ *                     rsdf_pair_bound_from_out_layer derives it from the narrow output layer's dz [n][N2] and weights, 8 bytes
+ *                     of scratch; a pair's own dx_absmax output serves the pair below); dx [n][lddx] columns [0, kout)
+ *                     (nullable), multiplied by (x > 0) when x_relu != 0 (x is the ReLU output of the pair below, so that dx
+ *                     IS that pair's masked gradient); dWa [128][K], dba, dWb, dbb are ACCUMULATED into (zero them first).
+ * Ranges: |x|, |activation|, |weight| < 1023 (fp16 class scales 2^6); a violation gives inf / nan outputs and is counted in
+ * status[RSDF_STATUS_X2_FWD_NONFINITE].  The gradient images share one power-of-two scale per launch (from ``bound``). */
+int rsdf_pair_supported(int K, int Na, int Nb);
+int64_t rsdf_pair_image_bytes(int64_t n_rows);
+int rsdf_pair_pack(const float *x, int ldx, int K, int64_t n, void *image, void *stream);
+int rsdf_pair_unpack(const void *image, int64_t n, float *rows, void *stream);
+int rsdf_pair_fwd(const void *x_image, int K, const float *wa, const float *ba, const float *wb, const float *bb, int64_t n,
+                  void *out_image /*nullable*/, float *out_rows /*nullable*/, int *status /*nullable*/, void *stream);
+int rsdf_pair_bound_from_rows(const float *g, int64_t count, void *bound /*4 bytes*/, void *stream);
+int rsdf_pair_bound_from_out_layer(const float *dz_out, int64_t n, int N2, const float *w_out /*[N2][128]*/,
+                                   void *bound /*8 bytes*/, void *stream);
+int rsdf_pair_bwd(const void *x_image, int K, const float *wa, const float *ba, const float *wb, const float *bb, int64_t n,
+                  const float *g, int g_masked, const void *bound, float *dx /*nullable*/, int lddx, int kout, int x_relu,
+                  void *dx_absmax /*nullable, 4 bytes, zeroed by the caller*/, float *dwa, float *dba, float *dwb, float *dbb,
+                  void *stream);
 /* ---- config[4]'s "bf16 MLP on MFMA" (BASELINE.json configs[4]; models/network_utils.py:109-157 at reduced matrix
  * precision): the same entry points with the suffix _bf16.  Same arguments, layouts and fp32 tensors; every matrix
  * operand (weights, activations, gradients) is rounded ONCE to bf16 (round to nearest even) and each k-step is ONE

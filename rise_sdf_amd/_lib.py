@@ -104,6 +104,14 @@ _SIGNATURES = {
     "rsdf_sdfmlp_fd7_fwd_x2": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P],
     "rsdf_sdfmlp_fd7_bwd_x2": [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P,
                                _P, _P, _P, _P],
+    "rsdf_pair_supported": [_I, _I, _I],
+    "rsdf_pair_image_bytes": [_L],
+    "rsdf_pair_pack": [_P, _I, _I, _L, _P, _P],
+    "rsdf_pair_unpack": [_P, _L, _P, _P],
+    "rsdf_pair_fwd": [_P, _I, _P, _P, _P, _P, _L, _P, _P, _P, _P],
+    "rsdf_pair_bound_from_rows": [_P, _L, _P, _P],
+    "rsdf_pair_bound_from_out_layer": [_P, _L, _I, _P, _P, _P],
+    "rsdf_pair_bwd": [_P, _I, _P, _P, _P, _P, _L, _P, _I, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "rsdf_sdfmlp_fd7_fwd": [_P, _P, _I, _I, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P],
     "rsdf_sdfmlp_fd7_bwd": [_P, _P, _I, _I, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P,
                             _P, _P, _P, _P, _P, _P, _P],
@@ -167,7 +175,7 @@ def mlp_fn(name, precision="fp32"):
 
 
 _RESTYPES = {"rsdf_last_error": ctypes.c_char_p, "rsdf_scan_scratch_bytes": ctypes.c_int64,
-             "rsdf_x2_rows": ctypes.c_int64, "rsdf_x2_bytes": ctypes.c_int64,
+             "rsdf_x2_rows": ctypes.c_int64, "rsdf_x2_bytes": ctypes.c_int64, "rsdf_pair_image_bytes": ctypes.c_int64,
              "rsdf_grid_meta_init": ctypes.c_int64,
              "rsdf_hashgrid_bwd_fd7_scratch_bytes": ctypes.c_int64,
              "rsdf_hashgrid_scatter_binned_scratch_bytes": ctypes.c_int64,
@@ -362,10 +370,12 @@ def consume_status(t, vals, raise_on_error=True) -> dict:
 def _status_result(bad, raise_on_error):
     if bad and raise_on_error:
         raise RiseSdfHipError(
-            f"the fused SDF field's x2 kernels produced non-finite outputs ({bad} tiles since the last check): an operand "
-            "left the two-part fp16 format's range -- |hash feature| or |xyz| >= 255, |effective weight| >= 1023 or a hidden "
-            "activation >= 1023 (csrc/mlp_x2.hip) -- where the reference's fp32 MLP stays finite.  Set RSDF_X2=0 to run the "
-            "SDF network on the range-free kernels (three bf16 parts, fp32's exponent range).")
+            f"kernels of the two-part fp16 (x2) number format produced non-finite outputs ({bad} tiles since the last check): "
+            "an operand left the format's range -- fused SDF field (csrc/mlp_x2.hip): |hash feature| or |xyz| >= 255, "
+            "|effective weight| >= 1023 or a hidden activation >= 1023; radiance-network layer pairs (csrc/mlp_pair.hip): "
+            "|input|, |weight| or a hidden activation >= 1023 -- where the reference's fp32 MLPs stay finite.  Set RSDF_X2=0 "
+            "(SDF network) / RSDF_PAIR=0 (radiance networks) to run on the range-free kernels (three bf16 parts, fp32's "
+            "exponent range).")
     return dict(_STATUS_TOTALS, x2_fwd_nonfinite=bad)
 
 

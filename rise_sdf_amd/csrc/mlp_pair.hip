@@ -1,0 +1,625 @@
+// T3, layer PAIRS: two 128-wide ReLU layers of a radiance network (models/texture.py:237-327: albedo / env / secondary
+// 4 hidden layers, roughness / metallic 2; models/network_utils.py:109-157 without weight_norm) per kernel, forward and
+// backward, in the two-part fp16 ("x2") number format of mlp_x2.hip.
+//
+//     forward :  x -> ha = relu(Wa x + ba) -> hb = relu(Wb ha + bb)           ha never leaves the CU
+//     backward:  (x, d hb) -> recompute ha, hb -> dz_b = d hb (hb > 0) -> dWb, dbb, d ha -> dz_a = d ha (ha > 0)
+//                -> dWa, dba, dx [ (x > 0) when x is itself a ReLU output ]     nothing but x and d hb is read
+//
+// The per-layer kernels (mlp.hip, mlp_layer_bwd.hip) are at the memory system's rate: forward 1 KB per row and layer,
+// one-pass backward 1.5-2 KB.  A 4-hidden-layer network moves 12.5 KB per row through HBM forward + backward, of which 1 KB is
+// its input and output.  Here the odd activation of a pair stays on the chip (forward) or is recomputed from the pair's input
+// (backward: two more products on a matrix pipe that the per-layer kernels leave 70 % idle), and a pair's input crosses HBM
+// once each way: 1 KB per row and pair forward, 1.5 KB backward.
+//
+// Form: mlp_x2.hip's backward (a workgroup is 8 waves, wave w owns features 16 w .. 16 w + 15 of every layer, every product
+// is three v_mfma_f32_16x16x32_f16 of two-part operands with fp32 accumulation) generalised from the 36-column stencil image
+// to a 128-column input.  What had to move: Wb^T (the A operand of d ha = Wb^T dz_b) lives in LDS -- with Wa, Wa^T, Wb and
+// both weight-gradient accumulators the register file holds no fourth fragment set -- as a [feature][k] image whose 16-byte
+// units are XOR-swizzled with the feature index (a 16-lane pass of a ds_read_b128 then covers all 64 banks once).
+//
+// Activation images, in LDS and in HBM alike ("the pair image"):
+//     [tile = row / 32][part 2 (hi, lo)][chunk = column / 8 (16)][row ^ 12 (chunk & 1)][8 columns] fp16, values x 2^6
+// 16 KB per 32-row tile, the same 4 bytes per value as fp32 rows; a tile lands in LDS by linear LDS-DMA.  rsdf_pair_pack
+// writes it from fp32 rows (the network's input), the forward writes hb in it for the next pair; the last pair of a network
+// writes fp32 rows for the (narrow) output layer's per-layer kernels.  Rows >= n of the last tile hold finite values that
+// no result depends on (their gradients are masked to zero).
+//
+// Ranges (class scales 2^6 for activations and weights): |x|, |activation| < 1023, |weight| < 1023; a violation shows as inf /
+// nan in the forward's outputs and is counted in status[RSDF_STATUS_X2_FWD_NONFINITE].  The backward's gradient images share
+// one power-of-two scale per launch derived from a caller-supplied bound on |d hb| (rsdf_pair_bound*).
+#include "common.h"
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+typedef short v4i16 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4i16 lds_v4i16;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void glob_void;
+
+constexpr int H = 128, NW = 8, NTHR = 64 * NW, KB = H / 32;
+constexpr float SA = 64.0f, SW = 64.0f, T = SA * SW;     // class scales: activations (incl. the input), weights; accumulator
+constexpr int QCS = 512;                                  // chunk: 32 rows x 16 B
+constexpr int PART = (H / 8) * QCS;                       // one part of an image: 8 KB
+constexpr int IMG = 2 * PART;                             // 16 KB per 32-row tile
+// LDS map
+constexpr int XI = 0;                                     // two X images (tile parity)
+constexpr int H1I = XI + 2 * IMG;
+constexpr int DZI = H1I + IMG;                            // dz_b (backward) / the output image (forward)
+constexpr int DZ1 = DZI + IMG;                            // dz_a
+constexpr int WTI = DZ1 + IMG;                            // Wb^T image: [part 2][feature 128][k 128] fp16, swizzled 16-byte units
+constexpr int WT_PART = H * H * 2;
+constexpr int RED = WTI + 2 * WT_PART;                    // 16 floats of scratch
+constexpr int LDS_FWD = DZ1;                              // the forward needs X x 2, H1, O
+constexpr int LDS_BWD = RED + 64;
+
+struct Frag2 { u32x4 h, l; };
+
+__device__ __forceinline__ unsigned pack_f16(float a, float b)
+{
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, f16x2));
+}
+__device__ __forceinline__ float resid_lo(float a, unsigned hi)
+{
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hi), "v"(a));
+    return r;
+}
+__device__ __forceinline__ float resid_hi(float b, unsigned hi)
+{
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hi), "v"(b));
+    return r;
+}
+__device__ __forceinline__ void split2_pair(float a, float b, unsigned &h, unsigned &l)
+{
+    h = pack_f16(a, b);
+    l = pack_f16(resid_lo(a, h), resid_hi(b, h));
+}
+__device__ __forceinline__ Frag2 split2_frag(const float *v)
+{
+    unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+    split2_pair(v[0], v[1], h0, l0);
+    split2_pair(v[2], v[3], h1, l1);
+    split2_pair(v[4], v[5], h2, l2);
+    split2_pair(v[6], v[7], h3, l3);
+    Frag2 f;
+    f.h = u32x4{h0, h1, h2, h3};
+    f.l = u32x4{l0, l1, l2, l3};
+    return f;
+}
+__device__ __forceinline__ f32x4 mma16(u32x4 a, u32x4 b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mma3q(const Frag2 &a, const Frag2 &b, f32x4 c)     // small terms first
+{
+    c = mma16(a.l, b.h, c);
+    c = mma16(a.h, b.l, c);
+    c = mma16(a.h, b.h, c);
+    return c;
+}
+__device__ __forceinline__ u32x4 ld128(const unsigned char *p) { return *reinterpret_cast<const u32x4 *>(p); }
+__device__ __forceinline__ void tr64(const unsigned char *p, unsigned &a, unsigned &b)
+{
+    const v4i16 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16 *)p);
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, r);
+    a = (unsigned)u;
+    b = (unsigned)(u >> 32);
+}
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);      // s_waitcnt lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void wait_vm0() { __builtin_amdgcn_s_waitcnt(0x0F70); }      // s_waitcnt vmcnt(0)
+
+// byte offset of (row, col) inside one part of an image
+__host__ __device__ __forceinline__ int qoff(int row, int col)
+{
+    const int ch = col >> 3;
+    return ch * QCS + ((row ^ ((ch & 1) * 12)) << 4) + (col & 7) * 2;
+}
+struct LaneQ {
+    int row;     // B fragment of a layer product: chunk 4 kb + g, row 16 rh + c16
+    int tr0;     // transposed fragment: rows 8 g + q, columns 16 ft + 4 p ..
+    int tr1;     //   rows + 4
+    int st;      // this wave's result slab: row 16 rh + c16, columns 16 w + 4 g ..
+};
+__device__ __forceinline__ LaneQ lane_consts(int w, int lane)
+{
+    const int g = lane >> 4, c16 = lane & 15, q = c16 >> 2, p = lane & 3;
+    LaneQ c;
+    c.row = g * QCS + ((c16 ^ (12 * (g & 1))) << 4);
+    c.tr0 = (p >> 1) * QCS + (((8 * g + q) ^ (12 * (p >> 1))) << 4) + (p & 1) * 8;
+    c.tr1 = (p >> 1) * QCS + (((8 * g + 4 + q) ^ (12 * (p >> 1))) << 4) + (p & 1) * 8;
+    c.st = (2 * w + (g >> 1)) * QCS + ((c16 ^ (12 * (g >> 1))) << 4) + (g & 1) * 8;
+    return c;
+}
+// B fragment of a layer product: lane (k-group g, sample row 16 rh + c16) reads columns 32 kb + 8 g .. + 7
+__device__ __forceinline__ Frag2 rowq(const unsigned char *img, int kb, int rh, const LaneQ &c)
+{
+    const unsigned char *p = img + c.row + kb * (4 * QCS) + rh * 256;
+    Frag2 f;
+    f.h = ld128(p);
+    f.l = ld128(p + PART);
+    return f;
+}
+// fragment whose k dimension is the tile's 32 ROWS: lane (rows 8 g .. 8 g + 7, column 16 ft + c16)
+__device__ __forceinline__ Frag2 trfq(const unsigned char *img, int ft, const LaneQ &c)
+{
+    const unsigned char *a0 = img + c.tr0 + ft * (2 * QCS), *a1 = img + c.tr1 + ft * (2 * QCS);
+    Frag2 f;
+    unsigned x0, x1, y0, y1;
+    tr64(a0, x0, x1);
+    tr64(a1, y0, y1);
+    f.h = u32x4{x0, x1, y0, y1};
+    tr64(a0 + PART, x0, x1);
+    tr64(a1 + PART, y0, y1);
+    f.l = u32x4{x0, x1, y0, y1};
+    return f;
+}
+// this wave's 16 x 16 result (columns 16 w + 4 g + r, sample row 16 rh + c16), already scaled -> split once -> image
+__device__ __forceinline__ void store_q(unsigned char *img, int rh, const LaneQ &c, const f32x4 &v)
+{
+    unsigned h0, l0, h1, l1;
+    split2_pair(v[0], v[1], h0, l0);
+    split2_pair(v[2], v[3], h1, l1);
+    unsigned char *p = img + c.st + rh * 256;
+    *reinterpret_cast<uint2 *>(p) = uint2{h0, h1};
+    *reinterpret_cast<uint2 *>(p + PART) = uint2{l0, l1};
+}
+// one tile (16 KB, linear) by LDS-DMA: 16 instructions of 1 KB, two per wave
+__device__ __forceinline__ void dma_tile(unsigned char *img, const unsigned char *x, int64_t tile, int ws, int lane)
+{
+    const unsigned char *tb = x + tile * IMG + lane * 16;
+    __builtin_amdgcn_global_load_lds((glob_void *)(tb + ws * 1024), (lds_void *)(img + ws * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glob_void *)(tb + (ws + 8) * 1024), (lds_void *)(img + (ws + 8) * 1024), 16, 0, 0);
+}
+// 2^e with |v| 2^e < 2^14 for every |v| <= bound (bound = 0, inf or nan: 1)
+__device__ __forceinline__ float grad_scale(float bound)
+{
+    if (!(bound > 0.0f) || !(bound < 3.0e38f)) return 1.0f;
+    int e = 13 - ilogbf(bound);
+    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    return ldexpf(1.0f, e);
+}
+__device__ __forceinline__ bool f16_pos(unsigned h) { return (h & 0x8000u) == 0u && (h & 0x7fffu) != 0u; }
+
+struct PairArgs {
+    const unsigned char *x;          // input image
+    int64_t n, tiles;
+    const float *wa, *ba;            // [128][K], [128]
+    const float *wb, *bb;            // [128][128], [128]
+    int K;                           // real columns of x / of Wa (<= 128; image columns >= K hold zeros)
+    // forward outputs
+    unsigned char *out_img;          // nullable
+    float *out_rows;                 // nullable, [n][128]
+    int *status;
+    // backward
+    const float *g;                  // d hb, [n][128] fp32 rows
+    int g_masked;                    // g is already dz_b (the producer applied the ReLU mask)
+    const unsigned *bound;           // bits of a bound on |g|
+    float *dx;                       // nullable, [n][lddx]: columns [0, kout)
+    int lddx, kout, x_relu;          // x_relu: write dx (x > 0) -- x is the ReLU output of the layer below
+    unsigned *dx_absmax;             // nullable: atomicMax of |dx| (the next launch's bound)
+    float *dwa, *dba, *dwb, *dbb;
+};
+
+// MASKED (backward only): g is already dz_b, so hb is not recomputed and Wb's own fragments are not held
+template <bool BWD, bool MASKED>
+__global__ void __launch_bounds__(NTHR, 1)
+pair_kernel(const PairArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c16 = lane & 15;
+    const int ws = __builtin_amdgcn_readfirstlane(w);
+    const int fw = 16 * w + c16;                   // the feature (or dx column) this lane addresses in an A fragment of its wave
+    const LaneQ lc = lane_consts(w, lane);
+    const int K = a.K;
+
+    // ---- weight fragments (A operands: lane = (row c16 of the wave's 16-row block, k-group g), 8 consecutive k), x SW
+    Frag2 waf[KB], wbf[MASKED ? 1 : KB], wat[BWD ? KB : 1];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 32 * kb + 8 * g + j;
+            v[j] = k < K ? a.wa[(size_t)fw * K + k] * SW : 0.0f;
+        }
+        waf[kb] = split2_frag(v);                                                   // Wa[fw][k]
+        if (!MASKED) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = a.wb[(size_t)fw * H + 32 * kb + 8 * g + j] * SW;
+            wbf[kb] = split2_frag(v);                                               // Wb[fw][k]
+        }
+        if (BWD) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fw < K ? a.wa[(size_t)(32 * kb + 8 * g + j) * K + fw] * SW : 0.0f;
+            wat[kb] = split2_frag(v);                                               // Wa[n][fw]: dx column fw
+        }
+    }
+    f32x4 bar, bbr;                                // biases (x T) of features 16 w + 4 g + r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        bar[r] = a.ba[16 * w + 4 * g + r] * T;
+        bbr[r] = a.bb[16 * w + 4 * g + r] * T;
+    }
+    float G2 = 1.0f, G1 = 1.0f;
+    if (BWD) {
+        // Wb^T image: unit u (8 consecutive k of Wb[k][f], i.e. of row f of Wb^T) of feature f at unit u ^ (f & 15)
+        unsigned short *e16 = reinterpret_cast<unsigned short *>(smem + WTI);
+        for (int e = threadIdx.x; e < H * H; e += NTHR) {
+            const int f = e & (H - 1), k = e >> 7;                                  // coalesced read of Wb[k][f]
+            unsigned hh, ll;
+            split2_pair(a.wb[(size_t)k * H + f] * SW, 0.0f, hh, ll);
+            const int idx = f * H + ((((k >> 3) ^ (f & 15)) << 3) | (k & 7));
+            e16[idx] = (unsigned short)(hh & 0xffffu);
+            e16[idx + WT_PART / 2] = (unsigned short)(ll & 0xffffu);
+        }
+        // gradient-image scales: |dz_b| <= bound, |dz_a| <= max_k sum_n |Wb[n][k]| bound
+        float cs = 0.0f;
+        float *s_red = reinterpret_cast<float *>(smem + RED);
+        if (threadIdx.x < H)
+            for (int n = 0; n < H; ++n) cs += fabsf(a.wb[(size_t)n * H + threadIdx.x]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cs = fmaxf(cs, __shfl_xor(cs, o, 64));
+        if (lane == 0 && w < 2) s_red[w] = cs;
+        __syncthreads();
+        const float bound2 = __uint_as_float(a.bound[0]);
+        G2 = grad_scale(bound2);
+        G1 = grad_scale(fmaxf(s_red[0], s_red[1]) * bound2);
+    }
+    __syncthreads();
+
+    f32x4 gwb[H / 16], gwa[H / 16], gbbp = {0.f, 0.f, 0.f, 0.f}, gbap = {0.f, 0.f, 0.f, 0.f};
+    if (BWD) {
+#pragma unroll
+        for (int n = 0; n < H / 16; ++n) gwb[n] = gwa[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float k_dz1 = G1 / (SW * G2), k_dx = 1.0f / (SW * G1);
+    float dxmax = 0.0f;
+    bool bad = false;
+
+    if ((int64_t)blockIdx.x < a.tiles) dma_tile(smem + XI, a.x, (int64_t)blockIdx.x, ws, lane);
+    int parity = 0;
+    for (int64_t ti = blockIdx.x; ti < a.tiles; ti += gridDim.x) {
+        const int64_t s0 = ti * 32;
+        const unsigned char *xi = smem + XI + parity * IMG;
+        wait_vm0();                            // this wave's share of the tile has landed (and the previous tile's stores retired)
+        lds_barrier();                         // (1) every share has landed; the other X image and the H1 / DZ images are free
+        parity ^= 1;
+        f32x4 dz[2];
+        bool row_ok[2];
+        if (BWD) {
+#pragma unroll
+            for (int rh = 0; rh < 2; ++rh) {
+                const int64_t row = s0 + 16 * rh + c16;
+                row_ok[rh] = row < a.n;
+                const int64_t rowc = row_ok[rh] ? row : a.n - 1;
+                const float4 v = *reinterpret_cast<const float4 *>(a.g + rowc * H + 16 * w + 4 * g);
+                dz[rh] = f32x4{v.x, v.y, v.z, v.w};
+            }
+        }
+        if (ti + gridDim.x < a.tiles) dma_tile(smem + XI + parity * IMG, a.x, ti + gridDim.x, ws, lane);
+        // ---- layer a: C = T za -> SA ha
+        f32x4 ha[2];
+#pragma unroll
+        for (int rh = 0; rh < 2; ++rh) {
+            f32x4 acc = bar;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) acc = mma3q(waf[kb], rowq(xi, kb, rh, lc), acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ha[rh][r] = fmaxf(acc[r], 0.0f) * (SA / T);
+            store_q(smem + H1I, rh, lc, ha[rh]);
+        }
+        lds_barrier();                         // (2) H1 image complete
+        // ---- layer b: C = T zb
+#pragma unroll
+        for (int rh = 0; rh < 2; ++rh) {
+            f32x4 acc = bbr;
+            if (!MASKED) {                     // (backward on an already masked gradient: hb is not needed at all)
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) acc = mma3q(wbf[kb], rowq(smem + H1I, kb, rh, lc), acc);
+            }
+            if (!BWD) {
+                f32x4 hb;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    hb[r] = fmaxf(acc[r], 0.0f) * (SA / T);
+                    bad |= !(hb[r] < 3.0e38f);
+                }
+                if (a.out_img != nullptr) store_q(smem + DZI, rh, lc, hb);
+                const int64_t row = s0 + 16 * rh + c16;
+                if (a.out_rows != nullptr && row < a.n)
+                    *reinterpret_cast<float4 *>(a.out_rows + row * H + 16 * w + 4 * g) =
+                        float4{hb[0] * (1.0f / SA), hb[1] * (1.0f / SA), hb[2] * (1.0f / SA), hb[3] * (1.0f / SA)};
+            } else {
+                f32x4 dzs;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool on = row_ok[rh] && (MASKED || acc[r] > 0.0f);
+                    dz[rh][r] = on ? dz[rh][r] : 0.0f;
+                    gbbp[r] += dz[rh][r];
+                    dzs[r] = dz[rh][r] * G2;
+                }
+                store_q(smem + DZI, rh, lc, dzs);
+            }
+        }
+        lds_barrier();                         // (3) dz_b image (forward: the output image) complete
+        if (!BWD) {
+            if (a.out_img != nullptr) {        // 16 KB, linear: 32 bytes per thread
+                unsigned char *ob = a.out_img + ti * IMG + threadIdx.x * 16;
+                const unsigned char *ib = smem + DZI + threadIdx.x * 16;
+                *reinterpret_cast<u32x4 *>(ob) = ld128(ib);
+                *reinterpret_cast<u32x4 *>(ob + NTHR * 16) = ld128(ib + NTHR * 16);
+            }
+            continue;                          // (the next tile's barrier (1) orders these reads before its stores)
+        }
+        // ---- layer b backward: G1 dz_a[own k] = (Wb^T dz_b) (ha > 0) ; dWb[own n][all k] += dz_b^T ha (K = the 32 rows)
+        {
+            const unsigned char *wt = smem + WTI + fw * (H * 2);
+            Frag2 wbt[KB];
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                const int u = ((4 * kb + g) ^ c16) << 4;
+                wbt[kb].h = ld128(wt + u);
+                wbt[kb].l = ld128(wt + WT_PART + u);
+            }
+#pragma unroll
+            for (int rh = 0; rh < 2; ++rh) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) acc = mma3q(wbt[kb], rowq(smem + DZI, kb, rh, lc), acc);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    dz[rh][r] = ha[rh][r] > 0.0f ? acc[r] * k_dz1 : 0.0f;              // x G1
+                    gbap[r] += dz[rh][r];
+                }
+            }
+        }
+        {
+            const Frag2 af = trfq(smem + DZI, w, lc);
+#pragma unroll
+            for (int n = 0; n < H / 16; ++n) gwb[n] = mma3q(af, trfq(smem + H1I, n, lc), gwb[n]);       // x G2 SA
+        }
+        store_q(smem + DZ1, 0, lc, dz[0]);
+        store_q(smem + DZ1, 1, lc, dz[1]);
+        lds_barrier();                         // (4) dz_a image complete
+        // ---- layer a backward: dx slab (columns 16 w .. 16 w + 15, all 32 rows); dWa += dz_a^T X
+        if (a.dx != nullptr && 16 * ws < a.kout) {
+#pragma unroll
+            for (int rh = 0; rh < 2; ++rh) {
+                f32x4 dx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) dx = mma3q(wat[kb], rowq(smem + DZ1, kb, rh, lc), dx);
+                const int64_t row = s0 + 16 * rh + c16;
+                const int col = 16 * w + 4 * g;
+                float o[4];
+                if (a.x_relu) {                // x > 0 from the hi part of the X image (same sign; zero only for x < 2^-31)
+                    const uint2 xh = *reinterpret_cast<const uint2 *>(xi + lc.st + rh * 256);
+                    o[0] = f16_pos(xh.x) ? dx[0] * k_dx : 0.0f;
+                    o[1] = f16_pos(xh.x >> 16) ? dx[1] * k_dx : 0.0f;
+                    o[2] = f16_pos(xh.y) ? dx[2] * k_dx : 0.0f;
+                    o[3] = f16_pos(xh.y >> 16) ? dx[3] * k_dx : 0.0f;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = dx[r] * k_dx;
+                }
+                if (row < a.n) {
+                    float *p = a.dx + row * a.lddx + col;
+                    if (col + 3 < a.kout && (a.lddx & 3) == 0) {
+                        *reinterpret_cast<float4 *>(p) = float4{o[0], o[1], o[2], o[3]};
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (col + r < a.kout) p[r] = o[r];
+                    }
+                    dxmax = fmaxf(fmaxf(dxmax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+                }
+            }
+        }
+        {
+            const Frag2 af = trfq(smem + DZ1, w, lc);
+#pragma unroll
+            for (int ct = 0; ct < H / 16; ++ct) gwa[ct] = mma3q(af, trfq(xi, ct, lc), gwa[ct]);          // x G1 SA
+        }
+        // no barrier: the next tile's barrier (1) separates these reads from the DMA that overwrites this X image
+    }
+
+    if (!BWD) {
+        if (__builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0 && a.status != nullptr)
+            atomicAdd(&a.status[RSDF_STATUS_X2_FWD_NONFINITE], 1);
+        return;
+    }
+    // ---- flush: gwb[n][r] = G2 SA dWb[16 w + 4 g + r][16 n + c16]; gwa[ct][r] = G1 SA dWa[..][16 ct + c16]
+    const float ub = 1.0f / (G2 * SA), ua = 1.0f / (G1 * SA);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int f = 16 * w + 4 * g + r;
+#pragma unroll
+        for (int n = 0; n < H / 16; ++n) atomicAdd(&a.dwb[(size_t)f * H + 16 * n + c16], gwb[n][r] * ub);
+#pragma unroll
+        for (int ct = 0; ct < H / 16; ++ct)
+            if (16 * ct + c16 < K) atomicAdd(&a.dwa[(size_t)f * K + 16 * ct + c16], gwa[ct][r] * ua);
+        float s = gbbp[r], t = gbap[r];            // per-lane partials -> sum over the 16 sample columns
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            s += __shfl_xor(s, o, 64);
+            t += __shfl_xor(t, o, 64);
+        }
+        if (c16 == 0) {
+            atomicAdd(&a.dbb[f], s);
+            atomicAdd(&a.dba[f], t * (1.0f / G1));
+        }
+    }
+    if (a.dx_absmax != nullptr) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dxmax = fmaxf(dxmax, __shfl_xor(dxmax, o, 64));
+        if (lane == 0 && dxmax > 0.0f) atomicMax(a.dx_absmax, __float_as_uint(dxmax));
+    }
+}
+
+// fp32 rows [n][ld] (columns [0, K)) -> the pair image (columns >= K and rows >= n: zeros)
+__global__ void __launch_bounds__(256)
+pack_kernel(const float *__restrict__ x, int ld, int K, int64_t n, int64_t tiles, unsigned char *__restrict__ img)
+{
+    const int64_t total = tiles * 32 * 16;                                         // (row, chunk) pairs
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int ch = (int)(e & 15);
+        const int64_t row = e >> 4;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int col = 8 * ch + j;
+            v[j] = (row < n && col < K) ? x[row * ld + col] * SA : 0.0f;
+        }
+        const Frag2 f = split2_frag(v);
+        unsigned char *p = img + (row >> 5) * IMG + ch * QCS + ((((int)(row & 31)) ^ ((ch & 1) * 12)) << 4);
+        *reinterpret_cast<u32x4 *>(p) = f.h;
+        *reinterpret_cast<u32x4 *>(p + PART) = f.l;
+    }
+}
+
+// the pair image -> fp32 rows [n][128] (tests; callers that need an even activation as rows)
+__global__ void __launch_bounds__(256)
+unpack_kernel(const unsigned char *__restrict__ img, int64_t n, float *__restrict__ rows)
+{
+    const int64_t total = n * 16;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int ch = (int)(e & 15);
+        const int64_t row = e >> 4;
+        const unsigned char *p = img + (row >> 5) * IMG + ch * QCS + ((((int)(row & 31)) ^ ((ch & 1) * 12)) << 4);
+        const f16x8 h = *reinterpret_cast<const f16x8 *>(p), l = *reinterpret_cast<const f16x8 *>(p + PART);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rows[row * H + 8 * ch + j] = ((float)h[j] + (float)l[j]) * (1.0f / SA);
+    }
+}
+
+// bound on |d h| of the layer below a narrow output layer: max|dz_out| * max_k sum_q |W_out[q][k]|
+__global__ void __launch_bounds__(128)
+out_bound_kernel(const unsigned *__restrict__ absmax_dz, const float *__restrict__ w_out, int N2, unsigned *__restrict__ bound)
+{
+    float cs = 0.0f;
+    for (int q = 0; q < N2; ++q) cs += fabsf(w_out[(size_t)q * H + threadIdx.x]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cs = fmaxf(cs, __shfl_xor(cs, o, 64));
+    __shared__ float s[2];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = cs;
+    __syncthreads();
+    if (threadIdx.x == 0) bound[0] = __float_as_uint(fmaxf(s[0], s[1]) * __uint_as_float(absmax_dz[0]));
+}
+
+__global__ void __launch_bounds__(256)
+absmax_kernel(const float *__restrict__ v, int64_t n, unsigned *__restrict__ out)
+{
+    float m = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(v[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(out, __float_as_uint(m));
+}
+
+}  // namespace
+
+extern "C" {
+
+int rsdf_pair_supported(int K, int Na, int Nb) { return (K >= 1 && K <= 128 && Na == 128 && Nb == 128) ? 1 : 0; }
+
+int64_t rsdf_pair_image_bytes(int64_t n_rows) { return ((n_rows + 31) / 32) * (int64_t)IMG + 1024; }
+
+int rsdf_pair_pack(const float *x, int ldx, int K, int64_t n, void *image, void *stream)
+{
+    RSDF_CHECK_ARG(K >= 1 && K <= 128 && ldx >= K, "pair_pack: K must be in [1,128] and ldx >= K");
+    if (n <= 0) return 0;
+    const int64_t tiles = (n + 31) / 32, work = tiles * 32 * 16;
+    const unsigned grid = (unsigned)((work + 255) / 256 < 65536 ? (work + 255) / 256 : 65536);
+    pack_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, ldx, K, n, tiles, reinterpret_cast<unsigned char *>(image));
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_pair_unpack(const void *image, int64_t n, float *rows, void *stream)
+{
+    if (n <= 0) return 0;
+    const int64_t work = n * 16;
+    const unsigned grid = (unsigned)((work + 255) / 256 < 65536 ? (work + 255) / 256 : 65536);
+    unpack_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(reinterpret_cast<const unsigned char *>(image), n, rows);
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_pair_fwd(const void *x_image, int K, const float *wa, const float *ba, const float *wb, const float *bb, int64_t n,
+                  void *out_image, float *out_rows, int *status, void *stream)
+{
+    RSDF_CHECK_ARG(K >= 1 && K <= 128, "pair_fwd: K must be in [1,128]");
+    RSDF_CHECK_ARG(out_image != nullptr || out_rows != nullptr, "pair_fwd: no output");
+    if (n <= 0) return 0;
+    PairArgs a{};
+    a.x = reinterpret_cast<const unsigned char *>(x_image);
+    a.n = n;
+    a.tiles = (n + 31) / 32;
+    a.wa = wa, a.ba = ba, a.wb = wb, a.bb = bb, a.K = K;
+    a.out_img = reinterpret_cast<unsigned char *>(out_image);
+    a.out_rows = out_rows;
+    a.status = status;
+    if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(pair_kernel<false, false>), LDS_FWD)) return rc;
+    const unsigned grid = (unsigned)(a.tiles < 256 ? a.tiles : 256);
+    pair_kernel<false, false><<<grid, NTHR, LDS_FWD, (hipStream_t)stream>>>(a);
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_pair_bound_from_rows(const float *g, int64_t count, void *bound, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    (void)hipMemsetAsync(bound, 0, 4, st);
+    if (count > 0) absmax_kernel<<<1024, 256, 0, st>>>(g, count, reinterpret_cast<unsigned *>(bound));
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_pair_bound_from_out_layer(const float *dz_out, int64_t n, int N2, const float *w_out, void *bound, void *stream)
+{
+    RSDF_CHECK_ARG(N2 >= 1, "pair_bound_from_out_layer: N2 must be >= 1");
+    hipStream_t st = (hipStream_t)stream;
+    unsigned *b = reinterpret_cast<unsigned *>(bound);
+    (void)hipMemsetAsync(b, 0, 8, st);
+    if (n > 0) absmax_kernel<<<256, 256, 0, st>>>(dz_out, n * N2, b + 1);
+    out_bound_kernel<<<1, 128, 0, st>>>(b + 1, w_out, N2, b);
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_pair_bwd(const void *x_image, int K, const float *wa, const float *ba, const float *wb, const float *bb, int64_t n,
+                  const float *g, int g_masked, const void *bound, float *dx, int lddx, int kout, int x_relu, void *dx_absmax,
+                  float *dwa, float *dba, float *dwb, float *dbb, void *stream)
+{
+    RSDF_CHECK_ARG(K >= 1 && K <= 128, "pair_bwd: K must be in [1,128]");
+    RSDF_CHECK_ARG(g != nullptr && bound != nullptr, "pair_bwd: g and its bound are required");
+    RSDF_CHECK_ARG(dx == nullptr || (kout >= 1 && kout <= K && lddx >= kout), "pair_bwd: bad dx window");
+    if (n <= 0) return 0;
+    PairArgs a{};
+    a.x = reinterpret_cast<const unsigned char *>(x_image);
+    a.n = n;
+    a.tiles = (n + 31) / 32;
+    a.wa = wa, a.ba = ba, a.wb = wb, a.bb = bb, a.K = K;
+    a.g = g, a.g_masked = g_masked, a.bound = reinterpret_cast<const unsigned *>(bound);
+    a.dx = dx, a.lddx = lddx, a.kout = kout, a.x_relu = x_relu;
+    a.dx_absmax = reinterpret_cast<unsigned *>(dx_absmax);
+    a.dwa = dwa, a.dba = dba, a.dwb = dwb, a.dbb = dbb;
+    const unsigned grid = (unsigned)(a.tiles < 256 ? a.tiles : 256);
+    if (g_masked) {
+        if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(pair_kernel<true, true>), LDS_BWD)) return rc;
+        pair_kernel<true, true><<<grid, NTHR, LDS_BWD, (hipStream_t)stream>>>(a);
+    } else {
+        if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(pair_kernel<true, false>), LDS_BWD)) return rc;
+        pair_kernel<true, false><<<grid, NTHR, LDS_BWD, (hipStream_t)stream>>>(a);
+    }
+    RSDF_RETURN_LAUNCH();
+}
+
+}  // extern "C"

@@ -858,14 +858,121 @@ class _MLPChain(torch.autograd.Function):
         return (dx_in, None, None, None, *grads)
 
 
+class _MLPPairChain(torch.autograd.Function):
+    """A radiance network (models/texture.py:237-327: Linear(K,128) ReLU [Linear(128,128) ReLU]x1|3 Linear(128,N2) [act]) on the
+    layer-PAIR kernels (csrc/mlp_pair.hip): two hidden layers per kernel in the x2 number format, the odd activation never
+    written (forward) and recomputed (backward), a pair's input / output through HBM once each way as a pair image.  The narrow
+    output layer stays on the per-layer kernels, on fp32 rows of the last hidden activation.  Per row of a 4-hidden-layer
+    network: ~2.5 KB forward + ~4 KB backward against 3.9 + 8 with one kernel per layer."""
+
+    @staticmethod
+    def forward(ctx, x, dx_cols, acts, *wb):
+        xf = _f32c(x)
+        ws = [_f32c(t) for t in wb[0::2]]
+        bs = [_f32c(t) for t in wb[1::2]]
+        require_device(xf, *ws, *bs)
+        n, K = xf.shape
+        dev, st = xf.device, stream_ptr()
+        nh = len(ws) - 1                                  # hidden layers: 2 or 4
+        stt = ptr(L.status(dev))
+        img_bytes = int(lib().rsdf_pair_image_bytes(n))
+        imgs = [torch.empty(img_bytes, dtype=torch.uint8, device=dev)]
+        check(lib().rsdf_pair_pack(ptr(xf), K, K, n, ptr(imgs[0]), st), "pair_pack")
+        h_last = torch.empty(n, 128, dtype=torch.float32, device=dev)
+        for p in range(nh // 2):
+            last = p == nh // 2 - 1
+            out_img = None if last else torch.empty(img_bytes, dtype=torch.uint8, device=dev)
+            check(lib().rsdf_pair_fwd(ptr(imgs[p]), K if p == 0 else 128, ptr(ws[2 * p]), ptr(bs[2 * p]), ptr(ws[2 * p + 1]),
+                                      ptr(bs[2 * p + 1]), n, ptr(out_img), ptr(h_last) if last else None, stt, st), "pair_fwd")
+            if not last:
+                imgs.append(out_img)
+        N2 = ws[-1].shape[0]
+        y = torch.empty(n, N2, dtype=torch.float32, device=dev)
+        check(lib().rsdf_linear_fwd(ptr(h_last), 128, ptr(ws[-1]), ptr(bs[-1]), n, 128, N2, acts[-1], ptr(y), N2, st),
+              "linear_fwd")
+        ctx.save_for_backward(*imgs, h_last, y, *ws, *bs)
+        ctx.n_imgs, ctx.nh, ctx.K, ctx.acts, ctx.dx_cols = len(imgs), nh, K, tuple(acts), dx_cols
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        sv = ctx.saved_tensors
+        ni, nh, K = ctx.n_imgs, ctx.nh, ctx.K
+        imgs, h_last, y = sv[:ni], sv[ni], sv[ni + 1]
+        ws, bs = sv[ni + 2:ni + 2 + nh + 1], sv[ni + 3 + nh:]
+        n = h_last.shape[0]
+        dev, st = h_last.device, stream_ptr()
+        g = _f32c(gy)
+        N2 = ws[-1].shape[0]
+        # ONE zero-fill for every weight / bias gradient accumulator of the network (the kernels accumulate)
+        sizes = []
+        for w in ws:
+            sizes += [(w.numel() + 3) // 4 * 4, (w.shape[0] + 3) // 4 * 4]
+        pool = torch.zeros(sum(sizes) + 4, dtype=torch.float32, device=dev)
+        grads, o = [], 0
+        for w, sw, sb in zip(ws, sizes[0::2], sizes[1::2]):
+            grads += [pool[o:o + w.numel()].view_as(w), pool[o + sw:o + sw + w.shape[0]]]
+            o += sw + sb
+        bounds = pool[o:o + 4].view(torch.int32)          # [0..1]: the top pair's bound + scratch, [2]: the lower pair's
+        # ---- narrow output layer on the per-layer kernels: dz_out, d h_last [n,128] rows, dW_out, db_out
+        dzo = g if ctx.acts[-1] == L.ACT_IDS["none"] else torch.empty_like(g)
+        dh = torch.empty(n, 128, dtype=torch.float32, device=dev)
+        check(lib().rsdf_linear_bwd_input(ptr(g), ptr(y), N2, ptr(ws[-1]), n, 128, N2, ctx.acts[-1], 0, 128,
+                                          None if dzo is g else ptr(dzo), ptr(dh), 128, st), "linear_bwd_input")
+        check(lib().rsdf_linear_bwd_weight(ptr(dzo), N2, ptr(h_last), 128, n, 128, N2, ptr(grads[-2]), ptr(grads[-1]), st),
+              "linear_bwd_weight")
+        check(lib().rsdf_pair_bound_from_out_layer(ptr(dzo), n, N2, ptr(ws[-1]), ptr(bounds), st), "pair_bound")
+        # ---- the pairs, top down
+        need_dx = ctx.needs_input_grad[0]
+        k0, kout = (0, K) if ctx.dx_cols is None else ctx.dx_cols
+        dx_in = None
+        gcur, masked, bound = dh, 0, bounds
+        for p in range(nh // 2 - 1, -1, -1):
+            Kp = K if p == 0 else 128
+            if p > 0:
+                dx = torch.empty(n, 128, dtype=torch.float32, device=dev)
+                win, ld, ko, relu, amax = ptr(dx), 128, 128, 1, ctypes.c_void_p(bounds.data_ptr() + 8)
+            elif need_dx:
+                dx = torch.empty(n, K, dtype=torch.float32, device=dev)
+                if k0 + kout < K:
+                    dx[:, k0 + kout:].zero_()
+                win, ld, ko, relu, amax = ptr(dx), K, k0 + kout, 0, None
+            else:
+                dx, win, ld, ko, relu, amax = None, None, 0, 0, 0, None
+            check(lib().rsdf_pair_bwd(ptr(imgs[p]), Kp, ptr(ws[2 * p]), ptr(bs[2 * p]), ptr(ws[2 * p + 1]), ptr(bs[2 * p + 1]), n,
+                                      ptr(gcur), masked, ptr(bound) if masked == 0 else ctypes.c_void_p(bounds.data_ptr() + 8),
+                                      win, ld, ko, relu, amax, ptr(grads[4 * p]), ptr(grads[4 * p + 1]), ptr(grads[4 * p + 2]),
+                                      ptr(grads[4 * p + 3]), st), "pair_bwd")
+            if p == 0:
+                if dx is not None and k0 > 0:
+                    dx[:, :k0].zero_()
+                dx_in = dx
+            gcur, masked = dx, 1
+        return (dx_in, None, None, *grads)
+
+
+def pair_chain_ok(x, ws, bs, acts, precision):
+    """The radiance networks of models/texture.py:237-327 as the reference builds them: 2 or 4 hidden layers of 128 with ReLU
+    and biases, at most 128 inputs, fp32.  ``RSDF_PAIR=0`` keeps one kernel per layer."""
+    relu = L.ACT_IDS["relu"]
+    nh = len(ws) - 1
+    return (precision in (None, "fp32") and os.environ.get("RSDF_PAIR", "1") != "0" and nh in (2, 4)
+            and os.environ.get("RSDF_LAYER_BWD") != "split"
+            and x.dim() == 2 and x.shape[0] > 0 and 1 <= x.shape[1] <= 128 and ws[0].shape == (128, x.shape[1])
+            and all(tuple(w.shape) == (128, 128) for w in ws[1:nh]) and ws[nh].shape[1] == 128
+            and all(b is not None for b in bs) and all(a == relu for a in acts[:nh]) and x.is_cuda)
+
+
 def mlp_chain(x, layers, acts, dx_cols=None, precision="fp32"):
     """``layers`` = [(W [out,in], b [out] or None)], ``acts`` = activation name per layer; see _MLPChain.
     ``precision``: 'fp32' (fp32-equivalent split products) or 'bf16' (one bf16 product, fp32 accumulate; opt-in)."""
     flat = []
     for w, b in layers:
         flat += [w, b]
-    return _MLPChain.apply(x, dx_cols, tuple(L.ACT_IDS[a] if not isinstance(a, int) else a for a in acts), precision,
-                           *flat)
+    act_ids = tuple(L.ACT_IDS[a] if not isinstance(a, int) else a for a in acts)
+    if pair_chain_ok(x, [w for w, _ in layers], [b for _, b in layers], act_ids, precision):
+        return _MLPPairChain.apply(x.float(), dx_cols, act_ids, *flat)
+    return _MLPChain.apply(x, dx_cols, act_ids, precision, *flat)
 
 
 class _WeightNorm(torch.autograd.Function):

@@ -1,0 +1,119 @@
+"""The layer-pair kernels of the 128-wide radiance networks (csrc/mlp_pair.hip: rsdf_pair_pack / _fwd / _bwd; models/texture.py:237-327)
+against the per-layer kernels (RSDF_PAIR=0: split-bf16 products, one kernel per layer) and against an fp64 evaluation of the
+same network: the pair path must be as accurate as an fp32 GEMM chain, forward and backward."""
+import pytest
+import torch
+
+import oracle  # noqa: F401  (conftest path)
+
+pytestmark = pytest.mark.gpu
+
+
+def _net(dev, K, nh, N2, seed):
+    g = torch.Generator().manual_seed(seed)
+    dims = [K] + [128] * nh + [N2]
+    layers = []
+    for i in range(len(dims) - 1):
+        bound = (6.0 / dims[i]) ** 0.5                    # kaiming_uniform_(relu), as the reference initialises these networks
+        w = ((torch.rand(dims[i + 1], dims[i], generator=g) * 2 - 1) * bound).to(dev).requires_grad_(True)
+        b = ((torch.rand(dims[i + 1], generator=g) * 2 - 1) * 0.1).to(dev).requires_grad_(True)
+        layers.append((w, b))
+    return layers
+
+
+def _run(ops, x, layers, acts, go, dx_cols=None):
+    for w, b in layers:
+        w.grad = b.grad = None
+    x = x.detach().clone().requires_grad_(x.requires_grad)
+    y = ops.mlp_chain(x, layers, acts, dx_cols=dx_cols)
+    (y * go).sum().backward()
+    return y.detach(), x.grad, [t.grad.clone() for wb in layers for t in wb]
+
+
+def test_pair_image_round_trip(dev):
+    from rise_sdf_amd import _lib
+    L = _lib.lib()
+    n, K = 1000, 84
+    x = (torch.randn(n, K, generator=torch.Generator().manual_seed(0)) * 3).to(dev)
+    img = torch.full((int(L.rsdf_pair_image_bytes(n)),), 0x7F, dtype=torch.uint8, device=dev)
+    rows = torch.empty(n, 128, device=dev)
+    assert L.rsdf_pair_pack(_lib.ptr(x), K, K, n, _lib.ptr(img), _lib.stream_ptr()) == 0
+    assert L.rsdf_pair_unpack(_lib.ptr(img), n, _lib.ptr(rows), _lib.stream_ptr()) == 0
+    torch.cuda.synchronize()
+    # hi + lo reproduces the value to one fp32 ulp (two 11-bit roundings of the x 2^6 value); columns >= K are zeros
+    assert float((rows[:, :K] - x).abs().max()) <= float(x.abs().max()) * 2.0 ** -23
+    assert bool((rows[:, K:] == 0).all())
+
+
+@pytest.mark.parametrize("K,nh,N2,n,out_act", [(84, 4, 6, 4133, "sigmoid"), (73, 4, 3, 1000, "sigmoid"), (84, 2, 1, 2048, "sigmoid"),
+                                               (84, 2, 2, 31, "none"), (128, 4, 3, 777, "none"), (17, 2, 5, 65, "none"),
+                                               (76, 4, 3, 33, "none")])
+def test_pair_chain_matches_per_layer_kernels_and_fp64(dev, K, nh, N2, n, out_act, monkeypatch):
+    from rise_sdf_amd import ops
+    layers = _net(dev, K, nh, N2, seed=K + nh)
+    acts = ["relu"] * nh + [out_act]
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, K, generator=g).to(dev).requires_grad_(True)
+    go = torch.randn(n, N2, generator=g).to(dev)
+    monkeypatch.setenv("RSDF_PAIR", "0")
+    ref = _run(ops, x, layers, acts, go)
+    monkeypatch.setenv("RSDF_PAIR", "1")
+    assert ops.pair_chain_ok(x, [w for w, _ in layers], [b for _, b in layers], tuple(ops.L.ACT_IDS[a] for a in acts), "fp32")
+    got = _run(ops, x, layers, acts, go)
+    # fp64 evaluation of the same network
+    l64 = [(w.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)) for w, b in layers]
+    x64 = x.detach().double().requires_grad_(True)
+    h = x64
+    for i, (w, b) in enumerate(l64):
+        h = h @ w.T + b
+        h = torch.relu(h) if i < nh else (torch.sigmoid(h) if out_act == "sigmoid" else h)
+    (h * go.double()).sum().backward()
+    g64 = [t.grad for wb in l64 for t in wb]
+    sc = float(h.abs().max())
+    e_pair, e_layer = float((got[0].double() - h).abs().max()) / sc, float((ref[0].double() - h).abs().max()) / sc
+    print(f"K {K} nh {nh} N2 {N2} n {n}: output error / max: pair {e_pair:.1e}, per-layer {e_layer:.1e}")
+    assert e_pair < max(3e-7 * nh, 3 * e_layer)
+    names = [f"{'wb'[j]}{i}" for i in range(nh + 1) for j in range(2)]
+    worst = 0.0
+    for name, a, b, c in zip(["dx"] + names, [got[1]] + got[2], [ref[1]] + ref[2], [x64.grad] + g64):
+        s = float(c.abs().max())
+        ea, eb = float((a.double() - c).abs().max()) / s, float((b.double() - c).abs().max()) / s
+        worst = max(worst, ea)
+        assert ea < max(2e-6, 4 * eb), (name, ea, eb)
+    print(f"   gradients vs fp64, worst tensor: {worst:.1e}")
+
+
+def test_pair_chain_input_window_and_frozen_input(dev, monkeypatch):
+    """dx_cols (only a window of the input columns needs a gradient) and an input that needs none."""
+    from rise_sdf_amd import ops
+    K, nh, N2, n = 84, 4, 6, 1500
+    layers = _net(dev, K, nh, N2, seed=3)
+    acts = ["relu"] * nh + ["none"]
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(n, K, generator=g).to(dev).requires_grad_(True)
+    go = torch.randn(n, N2, generator=g).to(dev)
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("RSDF_PAIR", flag)
+        res[flag] = _run(ops, x, layers, acts, go, dx_cols=(0, 48)), _run(ops, x.detach(), layers, acts, go)
+    (a_win, a_noin), (b_win, b_noin) = res["0"], res["1"]
+    assert b_noin[1] is None and bool((b_win[1][:, 48:] == 0).all())
+    assert float((a_win[1] - b_win[1]).abs().max()) < 3e-5 * float(a_win[1].abs().max())
+    for ga, gb in zip(a_noin[2], b_noin[2]):
+        assert float((ga - gb).abs().max()) < 3e-5 * float(ga.abs().max())
+
+
+def test_pair_forward_range_violation_is_counted(dev):
+    """An activation beyond the fp16 class range (|h| >= 1023) gives non-finite outputs, never a wrong finite number, and the
+    forward counts it in the device's status words."""
+    import rise_sdf_amd as R
+    from rise_sdf_amd import _lib, ops
+    layers = _net(dev, 84, 2, 3, seed=9)
+    with torch.no_grad():
+        layers[0][1][5] = 3000.0                             # a bias that drives one hidden activation past 1023
+        x = torch.randn(500, 84, generator=torch.Generator().manual_seed(1)).to(dev)
+        R.check_status(dev)
+        y = ops.mlp_chain(x, layers, ["relu", "relu", "none"])
+        assert not bool(torch.isfinite(y).all())
+        with pytest.raises(_lib.RiseSdfHipError, match="RSDF_X2=0"):
+            R.check_status(dev)
