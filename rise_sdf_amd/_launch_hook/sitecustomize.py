@@ -26,17 +26,42 @@ def _prepare():
     script = os.environ.get("RSDF_LAUNCH_SCRIPT")
     if not script:
         return
-    argv = getattr(sys, "orig_argv", None) or getattr(sys, "argv", [])
-    # only the interpreter that runs the script itself (python [opts] <script> ...), not every helper process
-    if not any(os.path.abspath(a) == script for a in argv[1:3] if not a.startswith("-")):
-        return
-    if "rise_sdf_amd.launch" in " ".join(argv[:4]):       # rank 0 goes through launch.main() itself
+    argv = list(getattr(sys, "orig_argv", None) or getattr(sys, "argv", []))
+    # only the interpreter that runs the script itself (python [opts] <script> ...), not every helper process: the FIRST
+    # non-option argument, skipping the values of the options that take one (python -u -X faulthandler -W ignore launch.py)
+    first, i = None, 1
+    while i < len(argv):
+        a = argv[i]
+        if a in ("-c", "-m"):             # python -c ... / -m module: not a script run (rank 0 is `-m rise_sdf_amd.launch`)
+            return
+        if a in ("-W", "-X", "--check-hash-based-pycs"):
+            i += 2
+            continue
+        if a.startswith("-") and a != "-":
+            i += 1
+            continue
+        first = a
+        break
+    if first is None or os.path.abspath(first) != script:
         return
     pkg_root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     if pkg_root not in sys.path:
         sys.path.insert(1, pkg_root)
     from rise_sdf_amd import launch
     launch.prepare(script, os.environ.get("RSDF_LAUNCH_FUSED", "1") != "0")
+    # this interpreter is set up; processes IT starts that are not Lightning ranks of the same script (dataloader workers fork
+    # and inherit the modules; tools the script spawns start clean) need neither the hook nor the variables.  Lightning's rank
+    # children are created from os.environ as it is when the Trainer launches them, so the launcher's variables are kept
+    # while LOCAL_RANK is unset (this is a rank that may still spawn its siblings) and dropped in a spawned rank.
+    if os.environ.get("LOCAL_RANK") not in (None, "0"):
+        here = os.path.dirname(os.path.abspath(__file__))
+        pp = [q for q in os.environ.get("PYTHONPATH", "").split(os.pathsep) if q and os.path.abspath(q) != here]
+        if pp:
+            os.environ["PYTHONPATH"] = os.pathsep.join(pp)
+        else:
+            os.environ.pop("PYTHONPATH", None)
+        os.environ.pop("RSDF_LAUNCH_SCRIPT", None)
+        os.environ.pop("RSDF_LAUNCH_FUSED", None)
 
 
 try:

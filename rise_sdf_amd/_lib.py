@@ -291,20 +291,34 @@ def stream_ptr():
 # bench run ended in an out-of-memory error after a size change elsewhere, and expandable segments are not available on this
 # platform.  These buffers therefore come from one growing arena per (tag, device, stream): kernels of a stream run in
 # order, so the next backward call on that stream may overwrite them.  Only buffers that are produced AND consumed inside one
-# autograd backward call may use it -- anything saved for a later call stays with the allocator.
+# autograd call may use it (the fused field's backward, and the reroute scratch of its range guard) -- anything saved for a
+# later call stays with the allocator.  The arenas live OUTSIDE the caching allocator's reach (empty_cache() cannot reclaim a
+# tensor that is referenced), so: an arena shrinks when a request needs less than a quarter of it (a training step after a
+# full-view render), all arenas are released and the request retried when torch runs out of memory, and
+# ``free_workspaces()`` (the drop-in's tcnn.free_temporary_memory()) drops them.  The key carries the host thread: two
+# threads enqueueing on one stream would otherwise alias each other's buffers between their kernel sequences.
 _WORKSPACES = {}
 
 
 def workspace(tag: str, nbytes: int, device) -> "torch.Tensor":
-    """-> uint8 [nbytes] view of the (tag, device, current stream) arena, valid until the next request with this key."""
+    """-> uint8 [nbytes] view of the (tag, device, current stream, host thread) arena, valid until the next request with this
+    key."""
+    import threading
     import torch
     dev = torch.device(device)
-    key = (tag, dev.index if dev.index is not None else torch.cuda.current_device(), int(stream_ptr().value or 0))
+    key = (tag, dev.index if dev.index is not None else torch.cuda.current_device(), int(stream_ptr().value or 0),
+           threading.get_ident())
     buf = _WORKSPACES.get(key)
-    if buf is None or buf.numel() < nbytes:
+    if buf is None or buf.numel() < nbytes or (buf.numel() > (64 << 20) and nbytes < buf.numel() // 4):
         _WORKSPACES.pop(key, None)
-        buf = None                                            # (released before the larger one is requested)
-        buf = torch.empty(int(nbytes * 1.25) + (1 << 20), dtype=torch.uint8, device=dev)
+        buf = None                                            # (released before the new one is requested)
+        want = int(nbytes * 1.25) + (1 << 20)
+        try:
+            buf = torch.empty(want, dtype=torch.uint8, device=dev)
+        except torch.OutOfMemoryError:
+            free_workspaces()                                 # the other arenas are only scratch: give them back and retry
+            torch.cuda.empty_cache()
+            buf = torch.empty(want, dtype=torch.uint8, device=dev)
         _WORKSPACES[key] = buf
     return buf[:nbytes]
 

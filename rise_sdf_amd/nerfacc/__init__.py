@@ -252,8 +252,11 @@ class OccGridEstimator(nn.Module):
         self._capacity = {}
         self._pending = []
         self._blind_rays = {}            # ray count each read-free capacity was measured at
-        self._blind_exact_next = False   # take the exact path once (grid updated / the last blind pass overflowed)
-        self.stats = {"capped_calls": 0, "overflows": 0, "blind_calls": 0, "blind_overflows": 0}
+        self._blind_stale = set()        # blind keys that take the exact path once (grid updated / their last pass overflowed)
+        self._blind_all_stale = False    # ... every key, including ones not seen yet (set by a grid update)
+        self._blind_seen = set()
+        self.stats = {"capped_calls": 0, "overflows": 0, "blind_calls": 0, "blind_overflows": 0,
+                      "last_blind_overflow": None}     # (key, candidates, capacity) of the last truncated read-free pass
 
     @property
     def device(self):
@@ -358,10 +361,14 @@ class OccGridEstimator(nn.Module):
         cap = self._capacity.get(key)
         t_min = torch.clamp(t_min, min=float(near_plane))
         t_max = torch.clamp(t_max, max=float(far_plane))
-        if cap is None or self._blind_exact_next:
-            # no capacity yet, the grid has just been updated, or the last blind pass overflowed: the caller takes the
-            # exact (read-ful) path once, which also re-measures the capacity
-            self._blind_exact_next = False
+        if self._blind_all_stale:          # a grid update invalidates EVERY key's capacity, not only the next caller's
+            self._blind_stale |= self._blind_seen
+            self._blind_all_stale = False
+        self._blind_seen.add(key)
+        if cap is None or key in self._blind_stale:
+            # no capacity yet, the grid has just been updated, or this key's last blind pass overflowed: the caller takes
+            # the exact (read-ful) path once, which also re-measures the capacity
+            self._blind_stale.discard(key)
             self._capacity.pop(key, None)
             return None
         # the capacity was measured for another ray count (dynamic_ray_sampling ramps train_num_rays by up to ~3x per
@@ -392,7 +399,8 @@ class OccGridEstimator(nn.Module):
                 # that pass ran on a truncated sample set (its tail rays saw transmittance 1): it cannot be redone after
                 # the fact, so say so and take the exact path next time
                 self.stats["blind_overflows"] += 1
-                self._blind_exact_next = True
+                self.stats["last_blind_overflow"] = (key, int(n_cand), int(cap))     # (TrainStep reports it with the step)
+                self._blind_stale.add(key)
                 import warnings
                 warnings.warn(f"rise_sdf_amd.nerfacc: a read-free secondary sampling pass outgrew its buffers "
                               f"({n_cand} candidates > capacity {cap}); its tail rays were left unoccluded for that one "
@@ -421,7 +429,7 @@ class OccGridEstimator(nn.Module):
         occ = occ_eval_fn(x).squeeze(-1)
         ops.occ_update(self.occs, self.binaries.view(torch.uint8).view(-1), None if all_cells else indices, occ,
                        ema_decay, occ_thre)
-        self._blind_exact_next = True      # the occupied set has changed: re-measure the read-free pass's capacity
+        self._blind_all_stale = True       # the occupied set has changed: every read-free pass re-measures its capacity
 
     @torch.no_grad()
     def update_every_n_steps(self, step: int, occ_eval_fn: Callable, occ_thre: float = 1e-2,

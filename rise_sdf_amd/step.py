@@ -127,7 +127,17 @@ class TrainStep:
         if handles:
             self.buckets.finish(handles, self.world)
         self.opt.step()
-        return {"loss": loss.detach(), "terms": terms, "num_samples": ns, "num_rays": n_rays, "out": out}
+        res = {"loss": loss.detach(), "terms": terms, "num_samples": ns, "num_rays": n_rays, "out": out}
+        # a read-free (blind) secondary sampling pass that outgrew its buffers ran truncated (its tail rays unoccluded): the
+        # caller can skip or redo the step instead of relying on the sampler's RuntimeWarning (shown once per location)
+        grid = getattr(self.model, "occupancy_grid", None)
+        st = getattr(grid, "stats", None)
+        if st is not None:
+            n_over = st.get("blind_overflows", 0)
+            if n_over != getattr(self, "_seen_blind_overflows", 0):
+                res["blind_overflow"] = st.get("last_blind_overflow")
+                self._seen_blind_overflows = n_over
+        return res
 
 
 def build_synthetic_training(dev, *, stage=1, hidden=128, views=8, res=200, seed=0, rank=0, world=1, indirect=True,
