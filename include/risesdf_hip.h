@@ -395,7 +395,7 @@ int rsdf_sdfmlp_fd7_bwd_x2(const void *x2, int parts, int n_levels, int n_active
  * status[RSDF_STATUS_X2_FWD_NONFINITE].  The gradient images share one power-of-two scale per launch (from ``bound``). */
 int rsdf_pair_supported(int K, int Na, int Nb);
 int64_t rsdf_pair_image_bytes(int64_t n_rows);
-int rsdf_pair_pack(const float *x, int ldx, int K, int64_t n, void *image, void *stream);
+int rsdf_pair_pack(const float *x, int ldx, int K, int64_t n, void *image, int *status /*nullable*/, void *stream);
 int rsdf_pair_unpack(const void *image, int64_t n, float *rows, void *stream);
 int rsdf_pair_fwd(const void *x_image, int K, const float *wa, const float *ba, const float *wb, const float *bb, int64_t n,
                   void *out_image /*nullable*/, float *out_rows /*nullable*/, int *status /*nullable*/, void *stream);

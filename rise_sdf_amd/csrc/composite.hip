@@ -49,22 +49,33 @@ __device__ __forceinline__ SeqRays seq_rays(const int32_t *__restrict__ packed, 
     s.max_steps = m;
     return s;
 }
-// tile[rr][lane] <- src[base_rr + c + lane] for the wave's 64 rays (rows past a ray's end are left as they are: never read)
-__device__ __forceinline__ void seq_stage(float *tile, const float *__restrict__ src, const SeqRays &s, int c)
+// tile_k[rr][lane] <- src_k[base_rr + c + lane] for the wave's 64 rays and N arrays at once: ALL 64 N loads are issued before
+// the first is consumed (rows past a ray's end are left as they are: never read).  A first version staged with an 8-deep
+// unrolled load -> LDS-write loop: eight global-memory round trips per array and 64-sample step, ~30 us per step and wave
+// while every wave of the launch runs at once -- 1.6 ms per 28672-ray launch for the backward, 0.5 for the forward.
+template <int N>
+__device__ __forceinline__ void seq_stage(float *const (&tile)[N], const float *const (&src)[N], const SeqRays &s, int c)
 {
     const int lane = threadIdx.x;
-#pragma unroll 8
+    float v[N][64];
+#pragma unroll
     for (int rr = 0; rr < 64; ++rr) {
-        const int b = __shfl(s.base, rr, 64), n = __shfl(s.steps, rr, 64);
-        if (c + lane < n) tile[rr * SEQ_LD + lane] = src[(int64_t)b + c + lane];
+        const int b = __builtin_amdgcn_readlane(s.base, rr), n = __builtin_amdgcn_readlane(s.steps, rr);
+        const bool ok = c + lane < n;
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k][rr] = ok ? src[k][(int64_t)b + c + lane] : 0.0f;
     }
+#pragma unroll
+    for (int rr = 0; rr < 64; ++rr)
+#pragma unroll
+        for (int k = 0; k < N; ++k) tile[k][rr * SEQ_LD + lane] = v[k][rr];
 }
 __device__ __forceinline__ void seq_unstage(float *__restrict__ dst, const float *tile, const SeqRays &s, int c)
 {
     const int lane = threadIdx.x;
-#pragma unroll 8
+#pragma unroll
     for (int rr = 0; rr < 64; ++rr) {
-        const int b = __shfl(s.base, rr, 64), n = __shfl(s.steps, rr, 64);
+        const int b = __builtin_amdgcn_readlane(s.base, rr), n = __builtin_amdgcn_readlane(s.steps, rr);
         if (c + lane < n) dst[(int64_t)b + c + lane] = tile[rr * SEQ_LD + lane];
     }
 }
@@ -81,29 +92,32 @@ weight_fwd_kernel(const int32_t *__restrict__ packed, const float *__restrict__ 
     const int lane = threadIdx.x;
     float T = 1.0f;
     for (int c = 0; c < s.max_steps; c += 64) {
-        seq_stage(s_a, alphas, s, c);
+        seq_stage<1>({s_a}, {alphas}, s, c);
         __syncthreads();
-        const int n = min(64, s.steps - c);
-        for (int j = 0; j < n; ++j) {
+        const int n = s.steps - c;
+#pragma unroll 8
+        for (int j = 0; j < 64; ++j) {                           // (fixed trip count: the LDS reads of a group are issued ahead)
             const float a = s_a[lane * SEQ_LD + j];
-            if (MODE == 0) {
-                s_a[lane * SEQ_LD + j] = a * T;                  // weights[j] = alpha * T      (render_weight.cu:108-111)
-                s_t[lane * SEQ_LD + j] = T;
-            } else {
-                bool v = T >= eps;
-                if (alpha_thre > 0.0f) v = v && (a >= alpha_thre);
-                s_t[lane * SEQ_LD + j] = v ? 1.0f : 0.0f;
+            if (j < n) {
+                if (MODE == 0) {
+                    s_a[lane * SEQ_LD + j] = a * T;              // weights[j] = alpha * T      (render_weight.cu:108-111)
+                    s_t[lane * SEQ_LD + j] = T;
+                } else {
+                    bool v = T >= eps;
+                    if (alpha_thre > 0.0f) v = v && (a >= alpha_thre);
+                    s_t[lane * SEQ_LD + j] = v ? 1.0f : 0.0f;
+                }
+                T *= (1.0f - a);                                 // T *= (1.f - alpha)
             }
-            T *= (1.0f - a);                                     // T *= (1.f - alpha)
         }
         __syncthreads();
         if (MODE == 0) {
             seq_unstage(weights, s_a, s, c);
             if (trans) seq_unstage(trans, s_t, s, c);
         } else {
-#pragma unroll 8
+#pragma unroll
             for (int rr = 0; rr < 64; ++rr) {
-                const int b = __shfl(s.base, rr, 64), nn = __shfl(s.steps, rr, 64);
+                const int b = __builtin_amdgcn_readlane(s.base, rr), nn = __builtin_amdgcn_readlane(s.steps, rr);
                 if (c + lane < nn) keep[(int64_t)b + c + lane] = s_t[rr * SEQ_LD + lane] != 0.0f ? 1 : 0;
             }
         }
@@ -121,25 +135,29 @@ weight_bwd_kernel(const int32_t *__restrict__ packed, const float *__restrict__ 
     const int lane = threadIdx.x;
     float accum = 0.0f;
     for (int c = 0; c < s.max_steps; c += 64) {                  // accum += grad_weights[j] * weights[j]
-        seq_stage(s_g, gw, s, c);
-        seq_stage(s_w, weights, s, c);
+        seq_stage<2>({s_g, s_w}, {gw, weights}, s, c);
         __syncthreads();
-        const int n = min(64, s.steps - c);
-        for (int j = 0; j < n; ++j) accum += s_g[lane * SEQ_LD + j] * s_w[lane * SEQ_LD + j];
+        const int n = s.steps - c;
+#pragma unroll 8
+        for (int j = 0; j < 64; ++j) {
+            const float p = s_g[lane * SEQ_LD + j] * s_w[lane * SEQ_LD + j];
+            if (j < n) accum += p;
+        }
         __syncthreads();
     }
     float T = 1.0f;
     for (int c = 0; c < s.max_steps; c += 64) {
-        seq_stage(s_g, gw, s, c);
-        seq_stage(s_w, weights, s, c);
-        seq_stage(s_a, alphas, s, c);
+        seq_stage<3>({s_g, s_w, s_a}, {gw, weights, alphas}, s, c);
         __syncthreads();
-        const int n = min(64, s.steps - c);
-        for (int j = 0; j < n; ++j) {
-            const float a = s_a[lane * SEQ_LD + j], g = s_g[lane * SEQ_LD + j];
-            s_a[lane * SEQ_LD + j] = (g * T - accum) / fmaxf(1.0f - a, 1e-10f);
-            accum -= g * s_w[lane * SEQ_LD + j];
-            T *= (1.0f - a);
+        const int n = s.steps - c;
+#pragma unroll 8
+        for (int j = 0; j < 64; ++j) {
+            const float a = s_a[lane * SEQ_LD + j], g = s_g[lane * SEQ_LD + j], p = g * s_w[lane * SEQ_LD + j];
+            if (j < n) {
+                s_a[lane * SEQ_LD + j] = (g * T - accum) / fmaxf(1.0f - a, 1e-10f);
+                accum -= p;
+                T *= (1.0f - a);
+            }
         }
         __syncthreads();
         seq_unstage(ga, s_a, s, c);

@@ -226,6 +226,7 @@ pair_kernel(const PairArgs a)
     const int K = a.K;
 
     // ---- weight fragments (A operands: lane = (row c16 of the wave's 16-row block, k-group g), 8 consecutive k), x SW
+    bool bad0 = false;                             // a weight beyond the class range
     Frag2 waf[KB], wbf[MASKED ? 1 : KB], wat[BWD ? KB : 1];
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
@@ -235,10 +236,18 @@ pair_kernel(const PairArgs a)
             const int k = 32 * kb + 8 * g + j;
             v[j] = k < K ? a.wa[(size_t)fw * K + k] * SW : 0.0f;
         }
+        if (!BWD) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bad0 |= !(fabsf(v[j]) < 65504.0f);
+        }
         waf[kb] = split2_frag(v);                                                   // Wa[fw][k]
         if (!MASKED) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = a.wb[(size_t)fw * H + 32 * kb + 8 * g + j] * SW;
+            if (!BWD) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bad0 |= !(fabsf(v[j]) < 65504.0f);
+            }
             wbf[kb] = split2_frag(v);                                               // Wb[fw][k]
         }
         if (BWD) {
@@ -287,7 +296,7 @@ pair_kernel(const PairArgs a)
     }
     const float k_dz1 = G1 / (SW * G2), k_dx = 1.0f / (SW * G1);
     float dxmax = 0.0f;
-    bool bad = false;
+    bool bad = bad0;
 
     if ((int64_t)blockIdx.x < a.tiles) dma_tile(smem + XI, a.x, (int64_t)blockIdx.x, ws, lane);
     int parity = 0;
@@ -318,7 +327,11 @@ pair_kernel(const PairArgs a)
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) acc = mma3q(waf[kb], rowq(xi, kb, rh, lc), acc);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ha[rh][r] = fmaxf(acc[r], 0.0f) * (SA / T);
+            for (int r = 0; r < 4; ++r) {
+                ha[rh][r] = fmaxf(acc[r], 0.0f) * (SA / T);
+                // (range guard at the split point: fmaxf would swallow the NaN an overflowed operand makes downstream)
+                if (!BWD) bad |= !(acc[r] < 65504.0f * (T / SA));
+            }
             store_q(smem + H1I, rh, lc, ha[rh]);
         }
         lds_barrier();                         // (2) H1 image complete
@@ -335,7 +348,7 @@ pair_kernel(const PairArgs a)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     hb[r] = fmaxf(acc[r], 0.0f) * (SA / T);
-                    bad |= !(hb[r] < 3.0e38f);
+                    bad |= !(acc[r] < 65504.0f * (T / SA));
                 }
                 if (a.out_img != nullptr) store_q(smem + DZI, rh, lc, hb);
                 const int64_t row = s0 + 16 * rh + c16;
@@ -470,9 +483,11 @@ pair_kernel(const PairArgs a)
 
 // fp32 rows [n][ld] (columns [0, K)) -> the pair image (columns >= K and rows >= n: zeros)
 __global__ void __launch_bounds__(256)
-pack_kernel(const float *__restrict__ x, int ld, int K, int64_t n, int64_t tiles, unsigned char *__restrict__ img)
+pack_kernel(const float *__restrict__ x, int ld, int K, int64_t n, int64_t tiles, unsigned char *__restrict__ img,
+            int *__restrict__ status)
 {
     const int64_t total = tiles * 32 * 16;                                         // (row, chunk) pairs
+    bool bad = false;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         const int ch = (int)(e & 15);
         const int64_t row = e >> 4;
@@ -481,12 +496,15 @@ pack_kernel(const float *__restrict__ x, int ld, int K, int64_t n, int64_t tiles
         for (int j = 0; j < 8; ++j) {
             const int col = 8 * ch + j;
             v[j] = (row < n && col < K) ? x[row * ld + col] * SA : 0.0f;
+            bad |= !(fabsf(v[j]) < 65504.0f);
         }
         const Frag2 f = split2_frag(v);
         unsigned char *p = img + (row >> 5) * IMG + ch * QCS + ((((int)(row & 31)) ^ ((ch & 1) * 12)) << 4);
         *reinterpret_cast<u32x4 *>(p) = f.h;
         *reinterpret_cast<u32x4 *>(p + PART) = f.l;
     }
+    if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0 && status != nullptr)
+        atomicAdd(&status[RSDF_STATUS_X2_FWD_NONFINITE], 1);
 }
 
 // the pair image -> fp32 rows [n][128] (tests; callers that need an even activation as rows)
@@ -536,13 +554,13 @@ int rsdf_pair_supported(int K, int Na, int Nb) { return (K >= 1 && K <= 128 && N
 
 int64_t rsdf_pair_image_bytes(int64_t n_rows) { return ((n_rows + 31) / 32) * (int64_t)IMG + 1024; }
 
-int rsdf_pair_pack(const float *x, int ldx, int K, int64_t n, void *image, void *stream)
+int rsdf_pair_pack(const float *x, int ldx, int K, int64_t n, void *image, int *status, void *stream)
 {
     RSDF_CHECK_ARG(K >= 1 && K <= 128 && ldx >= K, "pair_pack: K must be in [1,128] and ldx >= K");
     if (n <= 0) return 0;
     const int64_t tiles = (n + 31) / 32, work = tiles * 32 * 16;
     const unsigned grid = (unsigned)((work + 255) / 256 < 65536 ? (work + 255) / 256 : 65536);
-    pack_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, ldx, K, n, tiles, reinterpret_cast<unsigned char *>(image));
+    pack_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, ldx, K, n, tiles, reinterpret_cast<unsigned char *>(image), status);
     RSDF_RETURN_LAUNCH();
 }
 

@@ -877,7 +877,7 @@ class _MLPPairChain(torch.autograd.Function):
         stt = ptr(L.status(dev))
         img_bytes = int(lib().rsdf_pair_image_bytes(n))
         imgs = [torch.empty(img_bytes, dtype=torch.uint8, device=dev)]
-        check(lib().rsdf_pair_pack(ptr(xf), K, K, n, ptr(imgs[0]), st), "pair_pack")
+        check(lib().rsdf_pair_pack(ptr(xf), K, K, n, ptr(imgs[0]), stt, st), "pair_pack")
         h_last = torch.empty(n, 128, dtype=torch.float32, device=dev)
         for p in range(nh // 2):
             last = p == nh // 2 - 1

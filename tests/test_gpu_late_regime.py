@@ -116,7 +116,10 @@ def test_c1_late_training_regime_vs_oracle(dev, hidden, variance, monkeypatch):
     n_sat = int((alphas_hip == 1.0).sum())
     print(f"H = {hidden}, inv_s = {float(torch.exp(torch.tensor(10.0 * variance))):.0f}: {ri.numel()} of {ci.numel()} candidates "
           f"kept, {n_sat} alphas exactly 1, {int((alphas_hip > 0.999).sum())} above 0.999")
-    assert n_sat > 100 and float(ref["sdf"].min()) < -0.005 and float(ref["sdf"].max()) > 0.005, \
+    # (inv_s 1808: alphas reach exactly 1 at every crossing; inv_s 403 with this step: they come within 1e-3 of it, and whether
+    # some round to exactly 1 depends on the network's width)
+    assert (n_sat > 100 if variance > 0.7 else int((alphas_hip > 0.999).sum()) > 100) \
+        and float(ref["sdf"].min()) < -0.005 and float(ref["sdf"].max()) > 0.005, \
         "no zero crossing with saturated alphas: not the late-training regime"
     # the HIP alpha kernel against torch's chain on the same stencil values (get_alpha, models/split_mixed_occ.py:151-177):
     # sigmoid arguments reach +-100, one ulp of a CDF near 1 is 6e-8 absolute
@@ -158,7 +161,7 @@ def test_c1_late_training_regime_vs_oracle(dev, hidden, variance, monkeypatch):
     # alphas themselves bit-identical.  That is the reference's own conditioning, not a property of the kernels under test
     # (tools/debug/late_modes.py: the range-free round-3 kernels sit at the same level), so the gate carries that term.
     inv_s = float(torch.exp(torch.tensor(10.0 * variance)))
-    noise = 4.0 * float(ref["alphas"].grad.abs().max()) * 2.0 ** -24 * inv_s / float(nz.max())
+    noise = 1.0 * float(ref["alphas"].grad.abs().max()) * 2.0 ** -24 * inv_s / float(nz.max())
     print(f"  noise floor of the reference's weight backward in this case: {noise:.1e}")
     assert_grads_tight(hip_named, ref_named, gt, table2.grad, mlp_tol=max(3e-4, noise), table_tol=max(1e-3, noise))
     if float(ref["alphas"].grad.abs().max()) < 100.0:

@@ -37,7 +37,7 @@ def test_pair_image_round_trip(dev):
     x = (torch.randn(n, K, generator=torch.Generator().manual_seed(0)) * 3).to(dev)
     img = torch.full((int(L.rsdf_pair_image_bytes(n)),), 0x7F, dtype=torch.uint8, device=dev)
     rows = torch.empty(n, 128, device=dev)
-    assert L.rsdf_pair_pack(_lib.ptr(x), K, K, n, _lib.ptr(img), _lib.stream_ptr()) == 0
+    assert L.rsdf_pair_pack(_lib.ptr(x), K, K, n, _lib.ptr(img), None, _lib.stream_ptr()) == 0
     assert L.rsdf_pair_unpack(_lib.ptr(img), n, _lib.ptr(rows), _lib.stream_ptr()) == 0
     torch.cuda.synchronize()
     # hi + lo reproduces the value to one fp32 ulp (two 11-bit roundings of the x 2^6 value); columns >= K are zeros
@@ -113,7 +113,19 @@ def test_pair_forward_range_violation_is_counted(dev):
         layers[0][1][5] = 3000.0                             # a bias that drives one hidden activation past 1023
         x = torch.randn(500, 84, generator=torch.Generator().manual_seed(1)).to(dev)
         R.check_status(dev)
-        y = ops.mlp_chain(x, layers, ["relu", "relu", "none"])
-        assert not bool(torch.isfinite(y).all())
-        with pytest.raises(_lib.RiseSdfHipError, match="RSDF_X2=0"):
+        ops.mlp_chain(x, layers, ["relu", "relu", "none"])
+        # (ReLU's max() swallows the NaN that the overflowed operand makes downstream: the outputs may well be finite, which is
+        # why the guard sits at the split points and not at the outputs)
+        with pytest.raises(_lib.RiseSdfHipError, match="RSDF_PAIR=0"):
             R.check_status(dev)
+        layers[0][1][5] = 0.1
+        layers[1][0][7, 9] = 2000.0                          # a weight beyond the class range
+        ops.mlp_chain(x, layers, ["relu", "relu", "none"])
+        with pytest.raises(_lib.RiseSdfHipError, match="RSDF_PAIR=0"):
+            R.check_status(dev)
+        layers[1][0][7, 9] = 0.1
+        ops.mlp_chain(x * 2000.0, layers, ["relu", "relu", "none"])      # inputs beyond it
+        with pytest.raises(_lib.RiseSdfHipError, match="RSDF_PAIR=0"):
+            R.check_status(dev)
+        ops.mlp_chain(x, layers, ["relu", "relu", "none"])
+        assert R.check_status(dev)["x2_fwd_nonfinite"] == 0
