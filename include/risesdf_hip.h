@@ -385,7 +385,8 @@ int rsdf_sdfmlp_fd7_bwd_x2(const void *x2, int parts, int n_levels, int n_active
  *   rsdf_pair_unpack  image -> fp32 rows [n][128]
  *   rsdf_pair_fwd     hb = relu(Wb relu(Wa x + ba) + bb); Wa [128][K], Wb [128][128] row-major (nn.Linear.weight); out_image
  *                     (for the next pair) and / or out_rows [n][128] (for the per-layer kernels of the narrow output layer)
- *   rsdf_pair_bwd     g = d hb [n][128] fp32 rows (g_masked != 0: already multiplied by hb > 0, as a pair above writes it);
+ *   rsdf_pair_bwd     g = d hb [n][128] fp32 rows (g_masked != 0: already multiplied by hb > 0, as a pair above writes it;
+ *                     hb_rows != NULL: the forward's own hb as fp32 rows supplies that mask; neither: hb is recomputed);
  *                     ``bound``: device word(s) holding the bits of a float >= max |g| (rsdf_pair_bound_from_rows scans g;
  *                     rsdf_pair_bound_from_out_layer derives it from the narrow output layer's dz [n][N2] and weights, 8 bytes
  *                     of scratch; a pair's own dx_absmax output serves the pair below); dx [n][lddx] columns [0, kout)
@@ -403,9 +404,9 @@ int rsdf_pair_bound_from_rows(const float *g, int64_t count, void *bound /*4 byt
 int rsdf_pair_bound_from_out_layer(const float *dz_out, int64_t n, int N2, const float *w_out /*[N2][128]*/,
                                    void *bound /*8 bytes*/, void *stream);
 int rsdf_pair_bwd(const void *x_image, int K, const float *wa, const float *ba, const float *wb, const float *bb, int64_t n,
-                  const float *g, int g_masked, const void *bound, float *dx /*nullable*/, int lddx, int kout, int x_relu,
-                  void *dx_absmax /*nullable, 4 bytes, zeroed by the caller*/, float *dwa, float *dba, float *dwb, float *dbb,
-                  void *stream);
+                  const float *g, int g_masked, const float *hb_rows /*nullable*/, const void *bound, float *dx /*nullable*/,
+                  int lddx, int kout, int x_relu, void *dx_absmax /*nullable, 4 bytes, zeroed by the caller*/, float *dwa,
+                  float *dba, float *dwb, float *dbb, void *stream);
 /* ---- config[4]'s "bf16 MLP on MFMA" (BASELINE.json configs[4]; models/network_utils.py:109-157 at reduced matrix
  * precision): the same entry points with the suffix _bf16.  Same arguments, layouts and fp32 tensors; every matrix
  * operand (weights, activations, gradients) is rounded ONCE to bf16 (round to nearest even) and each k-step is ONE

@@ -80,6 +80,30 @@ __device__ __forceinline__ void seq_unstage(float *__restrict__ dst, const float
     }
 }
 
+// split staging: issue the loads of a step (seq_load), write them to LDS later (seq_put) -- the forward prefetches step c + 64
+// while it works on step c
+template <int N>
+__device__ __forceinline__ void seq_load(float (&v)[N][64], const float *const (&src)[N], const SeqRays &s, int c)
+{
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int rr = 0; rr < 64; ++rr) {
+        const int b = __builtin_amdgcn_readlane(s.base, rr), n = __builtin_amdgcn_readlane(s.steps, rr);
+        const bool ok = c + lane < n;
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k][rr] = ok ? src[k][(int64_t)b + c + lane] : 0.0f;
+    }
+}
+template <int N>
+__device__ __forceinline__ void seq_put(float *const (&tile)[N], const float (&v)[N][64])
+{
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int rr = 0; rr < 64; ++rr)
+#pragma unroll
+        for (int k = 0; k < N; ++k) tile[k][rr * SEQ_LD + lane] = v[k][rr];
+}
+
 // MODE 0: weights + trans; MODE 1: visibility mask (lib/nerfacc/vol_rendering.py:503-520 on the same sequential T)
 template <int MODE>
 __global__ void __launch_bounds__(64)
@@ -91,13 +115,19 @@ weight_fwd_kernel(const int32_t *__restrict__ packed, const float *__restrict__ 
     const SeqRays s = seq_rays(packed, n_rays);
     const int lane = threadIdx.x;
     float T = 1.0f;
+    float nxt[1][64];
+    seq_load<1>(nxt, {alphas}, s, 0);
     for (int c = 0; c < s.max_steps; c += 64) {
-        seq_stage<1>({s_a}, {alphas}, s, c);
+        seq_put<1>({s_a}, nxt);
         __syncthreads();
+        if (c + 64 < s.max_steps) seq_load<1>(nxt, {alphas}, s, c + 64);      // in flight while this step's chain runs
         const int n = s.steps - c;
-#pragma unroll 8
-        for (int j = 0; j < 64; ++j) {                           // (fixed trip count: the LDS reads of a group are issued ahead)
-            const float a = s_a[lane * SEQ_LD + j];
+        float av[64];                                            // the lane's own row: the chain runs on registers
+#pragma unroll
+        for (int j = 0; j < 64; ++j) av[j] = s_a[lane * SEQ_LD + j];
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            const float a = av[j];
             if (j < n) {
                 if (MODE == 0) {
                     s_a[lane * SEQ_LD + j] = a * T;              // weights[j] = alpha * T      (render_weight.cu:108-111)
@@ -134,29 +164,41 @@ weight_bwd_kernel(const int32_t *__restrict__ packed, const float *__restrict__ 
     const SeqRays s = seq_rays(packed, n_rays);
     const int lane = threadIdx.x;
     float accum = 0.0f;
-    for (int c = 0; c < s.max_steps; c += 64) {                  // accum += grad_weights[j] * weights[j]
-        seq_stage<2>({s_g, s_w}, {gw, weights}, s, c);
-        __syncthreads();
-        const int n = s.steps - c;
-#pragma unroll 8
-        for (int j = 0; j < 64; ++j) {
-            const float p = s_g[lane * SEQ_LD + j] * s_w[lane * SEQ_LD + j];
-            if (j < n) accum += p;
+    {
+        float nxt[2][64];
+        seq_load<2>(nxt, {gw, weights}, s, 0);
+        for (int c = 0; c < s.max_steps; c += 64) {              // accum += grad_weights[j] * weights[j]
+            seq_put<2>({s_g, s_w}, nxt);
+            __syncthreads();
+            if (c + 64 < s.max_steps) seq_load<2>(nxt, {gw, weights}, s, c + 64);
+            const int n = s.steps - c;
+            float pv[64];
+#pragma unroll
+            for (int j = 0; j < 64; ++j) pv[j] = s_g[lane * SEQ_LD + j] * s_w[lane * SEQ_LD + j];
+#pragma unroll
+            for (int j = 0; j < 64; ++j)
+                if (j < n) accum += pv[j];
+            __syncthreads();
         }
-        __syncthreads();
     }
     float T = 1.0f;
     for (int c = 0; c < s.max_steps; c += 64) {
         seq_stage<3>({s_g, s_w, s_a}, {gw, weights, alphas}, s, c);
         __syncthreads();
         const int n = s.steps - c;
-#pragma unroll 8
+        float av[64], gv[64], pv[64];
+#pragma unroll
         for (int j = 0; j < 64; ++j) {
-            const float a = s_a[lane * SEQ_LD + j], g = s_g[lane * SEQ_LD + j], p = g * s_w[lane * SEQ_LD + j];
+            av[j] = s_a[lane * SEQ_LD + j];
+            gv[j] = s_g[lane * SEQ_LD + j];
+            pv[j] = gv[j] * s_w[lane * SEQ_LD + j];
+        }
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
             if (j < n) {
-                s_a[lane * SEQ_LD + j] = (g * T - accum) / fmaxf(1.0f - a, 1e-10f);
-                accum -= p;
-                T *= (1.0f - a);
+                s_a[lane * SEQ_LD + j] = (gv[j] * T - accum) / fmaxf(1.0f - av[j], 1e-10f);
+                accum -= pv[j];
+                T *= (1.0f - av[j]);
             }
         }
         __syncthreads();

@@ -205,7 +205,8 @@ struct PairArgs {
     int *status;
     // backward
     const float *g;                  // d hb, [n][128] fp32 rows
-    int g_masked;                    // g is already dz_b (the producer applied the ReLU mask)
+    int g_masked;                    // g is already dz_b (the producer applied the ReLU mask) ...
+    const float *hmask;              // ... or becomes it here: hb [n][128] fp32 rows (nullable), dz_b = g (hb > 0)
     const unsigned *bound;           // bits of a bound on |g|
     float *dx;                       // nullable, [n][lddx]: columns [0, kout)
     int lddx, kout, x_relu;          // x_relu: write dx (x > 0) -- x is the ReLU output of the layer below
@@ -316,6 +317,13 @@ pair_kernel(const PairArgs a)
                 const int64_t rowc = row_ok[rh] ? row : a.n - 1;
                 const float4 v = *reinterpret_cast<const float4 *>(a.g + rowc * H + 16 * w + 4 * g);
                 dz[rh] = f32x4{v.x, v.y, v.z, v.w};
+                if (MASKED && a.hmask != nullptr) {    // the mask from the forward's own hb rows instead of a recompute
+                    const float4 m = *reinterpret_cast<const float4 *>(a.hmask + rowc * H + 16 * w + 4 * g);
+                    dz[rh][0] = m.x > 0.0f ? dz[rh][0] : 0.0f;
+                    dz[rh][1] = m.y > 0.0f ? dz[rh][1] : 0.0f;
+                    dz[rh][2] = m.z > 0.0f ? dz[rh][2] : 0.0f;
+                    dz[rh][3] = m.w > 0.0f ? dz[rh][3] : 0.0f;
+                }
             }
         }
         if (ti + gridDim.x < a.tiles) dma_tile(smem + XI + parity * IMG, a.x, ti + gridDim.x, ws, lane);
@@ -613,8 +621,8 @@ int rsdf_pair_bound_from_out_layer(const float *dz_out, int64_t n, int N2, const
 }
 
 int rsdf_pair_bwd(const void *x_image, int K, const float *wa, const float *ba, const float *wb, const float *bb, int64_t n,
-                  const float *g, int g_masked, const void *bound, float *dx, int lddx, int kout, int x_relu, void *dx_absmax,
-                  float *dwa, float *dba, float *dwb, float *dbb, void *stream)
+                  const float *g, int g_masked, const float *hb_rows, const void *bound, float *dx, int lddx, int kout, int x_relu,
+                  void *dx_absmax, float *dwa, float *dba, float *dwb, float *dbb, void *stream)
 {
     RSDF_CHECK_ARG(K >= 1 && K <= 128, "pair_bwd: K must be in [1,128]");
     RSDF_CHECK_ARG(g != nullptr && bound != nullptr, "pair_bwd: g and its bound are required");
@@ -625,12 +633,13 @@ int rsdf_pair_bwd(const void *x_image, int K, const float *wa, const float *ba, 
     a.n = n;
     a.tiles = (n + 31) / 32;
     a.wa = wa, a.ba = ba, a.wb = wb, a.bb = bb, a.K = K;
-    a.g = g, a.g_masked = g_masked, a.bound = reinterpret_cast<const unsigned *>(bound);
+    a.g = g, a.g_masked = (g_masked || hb_rows != nullptr) ? 1 : 0, a.hmask = g_masked ? nullptr : hb_rows;
+    a.bound = reinterpret_cast<const unsigned *>(bound);
     a.dx = dx, a.lddx = lddx, a.kout = kout, a.x_relu = x_relu;
     a.dx_absmax = reinterpret_cast<unsigned *>(dx_absmax);
     a.dwa = dwa, a.dba = dba, a.dwb = dwb, a.dbb = dbb;
     const unsigned grid = (unsigned)(a.tiles < 256 ? a.tiles : 256);
-    if (g_masked) {
+    if (a.g_masked) {
         if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(pair_kernel<true, true>), LDS_BWD)) return rc;
         pair_kernel<true, true><<<grid, NTHR, LDS_BWD, (hipStream_t)stream>>>(a);
     } else {

@@ -858,6 +858,9 @@ class _MLPChain(torch.autograd.Function):
         return (dx_in, None, None, None, *grads)
 
 
+_PAIR_PACK_CACHE = {}      # "last": (key, weakref to the input rows, image): see _MLPPairChain.forward
+
+
 class _MLPPairChain(torch.autograd.Function):
     """A radiance network (models/texture.py:237-327: Linear(K,128) ReLU [Linear(128,128) ReLU]x1|3 Linear(128,N2) [act]) on the
     layer-PAIR kernels (csrc/mlp_pair.hip): two hidden layers per kernel in the x2 number format, the odd activation never
@@ -876,8 +879,16 @@ class _MLPPairChain(torch.autograd.Function):
         nh = len(ws) - 1                                  # hidden layers: 2 or 4
         stt = ptr(L.status(dev))
         img_bytes = int(lib().rsdf_pair_image_bytes(n))
-        imgs = [torch.empty(img_bytes, dtype=torch.uint8, device=dev)]
-        check(lib().rsdf_pair_pack(ptr(xf), K, K, n, ptr(imgs[0]), stt, st), "pair_pack")
+        # the albedo / roughness / metallic networks of models/texture.py:303-324 read the SAME input tensor: one image serves them
+        key = (xf.data_ptr(), xf._version, n, K, dev.index, int(st.value or 0))
+        hit = _PAIR_PACK_CACHE.get("last")
+        if hit is not None and hit[0] == key and hit[1]() is xf:
+            imgs = [hit[2]]
+        else:
+            imgs = [torch.empty(img_bytes, dtype=torch.uint8, device=dev)]
+            check(lib().rsdf_pair_pack(ptr(xf), K, K, n, ptr(imgs[0]), stt, st), "pair_pack")
+            import weakref
+            _PAIR_PACK_CACHE["last"] = (key, weakref.ref(xf, lambda _r: _PAIR_PACK_CACHE.pop("last", None)), imgs[0])
         h_last = torch.empty(n, 128, dtype=torch.float32, device=dev)
         for p in range(nh // 2):
             last = p == nh // 2 - 1
@@ -939,8 +950,10 @@ class _MLPPairChain(torch.autograd.Function):
                 win, ld, ko, relu, amax = ptr(dx), K, k0 + kout, 0, None
             else:
                 dx, win, ld, ko, relu, amax = None, None, 0, 0, 0, None
+            # (the top pair takes its ReLU mask from the forward's own h_last rows: no hb recompute, the lean kernel variant)
             check(lib().rsdf_pair_bwd(ptr(imgs[p]), Kp, ptr(ws[2 * p]), ptr(bs[2 * p]), ptr(ws[2 * p + 1]), ptr(bs[2 * p + 1]), n,
-                                      ptr(gcur), masked, ptr(bound) if masked == 0 else ctypes.c_void_p(bounds.data_ptr() + 8),
+                                      ptr(gcur), masked, ptr(h_last) if masked == 0 else None,
+                                      ptr(bound) if masked == 0 else ctypes.c_void_p(bounds.data_ptr() + 8),
                                       win, ld, ko, relu, amax, ptr(grads[4 * p]), ptr(grads[4 * p + 1]), ptr(grads[4 * p + 2]),
                                       ptr(grads[4 * p + 3]), st), "pair_bwd")
             if p == 0:

@@ -83,6 +83,40 @@ def test_pair_chain_matches_per_layer_kernels_and_fp64(dev, K, nh, N2, n, out_ac
     print(f"   gradients vs fp64, worst tensor: {worst:.1e}")
 
 
+def test_pair_backward_mask_sources_agree(dev):
+    """rsdf_pair_bwd takes the ReLU mask of the pair's upper layer three ways: recomputed from x (one more product), from the
+    forward's own hb rows, or already applied to g by the producer.  Same dx and weight gradients."""
+    from rise_sdf_amd import _lib
+    L = _lib.lib()
+    p, st = _lib.ptr, _lib.stream_ptr()
+    n, K = 3000, 84
+    (wa, ba), (wb, bb) = [(w.detach().contiguous(), b.detach().contiguous()) for w, b in _net(dev, K, 2, 1, seed=21)[:2]]
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(n, K, generator=g).to(dev)
+    gy = torch.randn(n, 128, generator=g).to(dev)
+    img = torch.empty(int(L.rsdf_pair_image_bytes(n)), dtype=torch.uint8, device=dev)
+    hb = torch.empty(n, 128, device=dev)
+    assert L.rsdf_pair_pack(p(x), K, K, n, p(img), None, st) == 0
+    assert L.rsdf_pair_fwd(p(img), K, p(wa), p(ba), p(wb), p(bb), n, None, p(hb), None, st) == 0
+    ref = torch.relu(torch.relu(x.double() @ wa.double().T + ba.double()) @ wb.double().T + bb.double())
+    assert float((hb.double() - ref).abs().max()) < 3e-7 * float(ref.abs().max())
+    bound = torch.zeros(2, dtype=torch.int32, device=dev)
+    assert L.rsdf_pair_bound_from_rows(p(gy), gy.numel(), p(bound), st) == 0
+    outs = []
+    for mode in ("recompute", "hb_rows", "premasked"):
+        dx = torch.full((n, K), float("nan"), device=dev)
+        gr = [torch.zeros_like(t) for t in (wa, ba, wb, bb)]
+        gin = gy * (hb > 0) if mode == "premasked" else gy
+        _lib.check(L.rsdf_pair_bwd(p(img), K, p(wa), p(ba), p(wb), p(bb), n, p(gin.contiguous()), int(mode == "premasked"),
+                                   p(hb) if mode == "hb_rows" else None, p(bound), p(dx), K, K, 0, None, *[p(t) for t in gr], st),
+                   "pair_bwd")
+        torch.cuda.synchronize()
+        outs.append([dx] + gr)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert float((a - b).abs().max()) < 2e-6 * float(a.abs().max())
+
+
 def test_pair_chain_input_window_and_frozen_input(dev, monkeypatch):
     """dx_cols (only a window of the input columns needs a gradient) and an input that needs none."""
     from rise_sdf_amd import ops
@@ -104,8 +138,8 @@ def test_pair_chain_input_window_and_frozen_input(dev, monkeypatch):
 
 
 def test_pair_forward_range_violation_is_counted(dev):
-    """An activation beyond the fp16 class range (|h| >= 1023) gives non-finite outputs, never a wrong finite number, and the
-    forward counts it in the device's status words."""
+    """An operand beyond the fp16 class range (|input|, |weight| or |hidden activation| >= 1023) is counted in the device's status
+    words at the point where it would be split, and the next check raises the named error."""
     import rise_sdf_amd as R
     from rise_sdf_amd import _lib, ops
     layers = _net(dev, 84, 2, 3, seed=9)
