@@ -497,8 +497,9 @@ def secondary_measurements(dev, args, rays, jitter, cot):
                          "fused_stencil_kernels": bool(m._fused_ok())}
         return out
 
-    guarded("chunk4096", lambda: c1_variant(args.hidden, 4096))
-    guarded("one_stream", lambda: c1_variant(args.hidden, args.chunk, streams=1))     # the round-2 issue order
+    guarded("chunk4096", lambda: c1_variant(args.hidden, 4096, streams=2))          # the reference's ray_chunk; ~31 GiB
+    # two chunks in flight on alternating HIP streams (rounds 3-4's default: +1-2 % for twice the footprint)
+    guarded("two_streams", lambda: c1_variant(args.hidden, args.chunk, streams=2, steps=3, warmup=2))
     # (H = 128: the cooperative kernels hold every register of a CU, a second chunk in flight only adds contention)
     h128_chunk = min(args.chunk, 24576)       # (the H = 128 variants keep the chunk size they were measured at)
     guarded("h128", lambda: c1_variant(128, h128_chunk, streams=1))
@@ -600,6 +601,16 @@ def run_c3(args, rank, local, world, dev):
         torch.distributed.destroy_process_group()
 
 
+def _lib_status_totals(dev):
+    """The sticky status counters after the run (rise_sdf_amd._lib.poll_status): forward range violations raise; backward
+    launches the range guard rerouted to the range-free kernels are reported."""
+    from rise_sdf_amd import _lib
+    try:
+        return _lib.poll_status(dev)
+    except Exception as e:   # noqa: BLE001  (recorded, not swallowed)
+        return {"error": str(e)[:200]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -608,11 +619,12 @@ def main():
     ap.add_argument("--workload", default="c1", choices=["c1", "c3"],
                     help="c1 = BASELINE.json config[1] (the metric); c3 = the occupancy-pruned N-rank training step")
     ap.add_argument("--chunk", type=int, default=28672,
-                    help="rays per forward/backward chunk (~5 KB of HBM scratch per sample and stream in flight: "
-                         "28672 rays x 2 streams = ~170 GB of the 288 GB; three such streams do not fit and the caching "
-                         "allocator then thrashes)")
-    ap.add_argument("--streams", type=int, default=2,
-                    help="HIP streams the chunks of a step alternate over (run_step); 1 = one chunk at a time")
+                    help="rays per forward/backward chunk (~5 KB of HBM scratch per sample and chunk in flight: 28672 rays = "
+                         "~87 GiB reserved with one chunk in flight)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="HIP streams the chunks of a step alternate over (run_step).  Default 1 = one chunk at a time "
+                         "(~87 GiB reserved); 2 = two chunks in flight (+1-2 %% throughput for ~173 GiB: the "
+                         "`secondary.two_streams` entry of the default run)")
     ap.add_argument("--width", type=int, default=800)
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--hidden", type=int, default=64)
@@ -718,6 +730,13 @@ def main():
                        "rccl_ranks": torch.distributed.get_world_size() if world > 1 else 1,
                        "dist_backend": torch.distributed.get_backend() if world > 1 else None,
                        "rays_per_gpu": n_rays, "chunk_rays": args.chunk, "hip_streams": args.streams,
+                       # the number formats behind dtype f32: two-part fp16 operands with range guards;
+                       # hash-backward queue records with 20 significant bits; range-guard activity during this run
+                       "sdf_mlp_format": ("x2: two fp16 parts per fp32 operand, 3 MFMA products, fp32 accumulate; forward range "
+                                          "and backward dynamic range guarded on the device" if args.precision == "fp32" and
+                                          os.environ.get("RSDF_X2", "1") != "0" else args.precision),
+                       "hash_bwd_records": "20-bit block-float pairs (8 bytes), fp64 reduction",
+                       "x2_guard": _lib_status_totals(dev),
                        "samples_per_step": samples / args.steps, "hbm_gib": hbm_watch.report(),
                        "field_evals_per_sec": 7 * samples / dt, "parallelism": f"ray-parallel x{world}"},
             "roofline": roof, "cpu_baseline": cpu, "kernel_breakdown": breakdown,
