@@ -331,8 +331,13 @@ def workspace_f32(tag: str, shape, device) -> "torch.Tensor":
 
 
 def free_workspaces():
-    """Releases the arenas (tcnn.free_temporary_memory() of the drop-in calls this)."""
+    """Releases the arenas (tcnn.free_temporary_memory() of the drop-in calls this) and the pair kernels' cached input image."""
     _WORKSPACES.clear()
+    try:
+        from . import ops
+        ops._PAIR_PACK_CACHE.clear()
+    except Exception:   # noqa: BLE001  (during interpreter shutdown / partial import)
+        pass
 
 
 # ---- sticky device-side status words (include/risesdf_hip.h RSDF_STATUS_*) ------------------------------------------------

@@ -880,15 +880,17 @@ class _MLPPairChain(torch.autograd.Function):
         stt = ptr(L.status(dev))
         img_bytes = int(lib().rsdf_pair_image_bytes(n))
         # the albedo / roughness / metallic networks of models/texture.py:303-324 read the SAME input tensor: one image serves them
+        # (inside an autograd Function every call sees a fresh alias of the caller's tensor: the key is the storage address, the
+        # shared version counter and the shape; the entry pins the rows it was packed from, so the address cannot be reused
+        # while it is cached, and the next pack replaces it)
         key = (xf.data_ptr(), xf._version, n, K, dev.index, int(st.value or 0))
         hit = _PAIR_PACK_CACHE.get("last")
-        if hit is not None and hit[0] == key and hit[1]() is xf:
+        if hit is not None and hit[0] == key:
             imgs = [hit[2]]
         else:
             imgs = [torch.empty(img_bytes, dtype=torch.uint8, device=dev)]
             check(lib().rsdf_pair_pack(ptr(xf), K, K, n, ptr(imgs[0]), stt, st), "pair_pack")
-            import weakref
-            _PAIR_PACK_CACHE["last"] = (key, weakref.ref(xf, lambda _r: _PAIR_PACK_CACHE.pop("last", None)), imgs[0])
+            _PAIR_PACK_CACHE["last"] = (key, xf, imgs[0])
         h_last = torch.empty(n, 128, dtype=torch.float32, device=dev)
         for p in range(nh // 2):
             last = p == nh // 2 - 1

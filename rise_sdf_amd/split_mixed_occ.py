@@ -132,7 +132,8 @@ class SplitMixedOCCModel(BaseModel):
                     if blind is not None:
                         acc_map, depth_map, _ = secondary_rendering(blind[1], blind[2], ray_indices=blind[0],
                                                                     n_rays=n_rays + 1, alpha_fn=a_fn,
-                                                                    chunk_size=self.secondary_shader_chunk)
+                                                                    chunk_size=self.secondary_shader_chunk,
+                                                                    phantom_last_ray=True)
                         return 1.0 - acc_map[:n_rays], depth_map[:n_rays]
             ray_indices, t_starts, t_ends = self.occupancy_grid.sampling(
                 rays_o, rays_d, alpha_fn=alpha_fn, near_plane=self.secondary_near_plane,

@@ -67,9 +67,12 @@ def rendering_with_normals_sdf(t_starts: Tensor, t_ends: Tensor, ray_indices: Op
 
 @torch.no_grad()
 def secondary_rendering(t_starts: Tensor, t_ends: Tensor, ray_indices: Tensor, n_rays: int,
-                        alpha_fn: Callable, chunk_size: int = 160000):
+                        alpha_fn: Callable, chunk_size: int = 160000, phantom_last_ray: bool = False):
     """Opacity / depth of the secondary (reflection) rays (volrend.py:18-127): alpha in chunks, then
-    weights and two accumulations.  -> (opacities [N,1], depths [N,1], extras)."""
+    weights and two accumulations.  -> (opacities [N,1], depths [N,1], extras).
+    ``phantom_last_ray``: the last ray only owns the unused tail of capacity-sized sample arrays (the read-free sampling pass of
+    models/split_mixed_occ.py's mirror); it gets an empty range, so that the per-ray kernels -- C1 walks a ray's samples in the
+    reference's sequential order -- do not composite a hundred thousand dummy samples for a result nobody reads."""
     dev = t_starts.device
     if t_starts.shape[0] != 0:
         alphas = torch.cat([alpha_fn(t_starts[i:i + chunk_size], t_ends[i:i + chunk_size],
@@ -78,6 +81,9 @@ def secondary_rendering(t_starts: Tensor, t_ends: Tensor, ray_indices: Tensor, n
     else:
         alphas = torch.empty((0,), device=dev)
     packed = ops.pack_info(ray_indices, n_rays)
+    if phantom_last_ray and n_rays > 0:
+        packed = packed.clone()
+        packed[n_rays - 1, 1] = 0
     weights, trans = ops.render_weight_from_alpha(alphas, packed_info=packed)
     opacities, depths = ops.accumulate_opacity_depth(weights, t_starts, t_ends, packed_info=packed)
     return opacities, depths, {"weights": weights, "trans": trans, "alphas": alphas}
