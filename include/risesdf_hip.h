@@ -399,12 +399,17 @@ int64_t rsdf_pair_image_bytes(int64_t n_rows);
 int rsdf_pair_pack(const float *x, int ldx, int K, int64_t n, void *image, int *status /*nullable*/, void *stream);
 int rsdf_pair_unpack(const void *image, int64_t n, float *rows, void *stream);
 int rsdf_pair_fwd(const void *x_image, int K, const float *wa, const float *ba, const float *wb, const float *bb, int64_t n,
-                  void *out_image /*nullable*/, float *out_rows /*nullable*/, int *status /*nullable*/, void *stream);
+                  void *out_image /*nullable*/, float *out_rows /*nullable*/, const float *w_out /*[N2][128], nullable*/,
+                  const float *b_out, int N2 /*<= 8*/, int out_act /*RSDF_ACT_NONE | RSDF_ACT_SIGMOID*/,
+                  float *y_out /*[n][N2], nullable: the network's narrow output layer folded in*/, int *status /*nullable*/,
+                  void *stream);
 int rsdf_pair_bound_from_rows(const float *g, int64_t count, void *bound /*4 bytes*/, void *stream);
 int rsdf_pair_bound_from_out_layer(const float *dz_out, int64_t n, int N2, const float *w_out /*[N2][128]*/,
                                    void *bound /*8 bytes*/, void *stream);
 int rsdf_pair_bwd(const void *x_image, int K, const float *wa, const float *ba, const float *wb, const float *bb, int64_t n,
-                  const float *g, int g_masked, const float *hb_rows /*nullable*/, const void *bound, float *dx /*nullable*/,
+                  const float *g /*nullable with dz_out*/, int g_masked, const float *hb_rows /*nullable*/,
+                  const float *dz_out /*[n][N2], nullable: g = dz_out @ w_out is formed in the kernel*/,
+                  const float *w_out /*[N2][128]*/, int N2 /*<= 8*/, const void *bound, float *dx /*nullable*/,
                   int lddx, int kout, int x_relu, void *dx_absmax /*nullable, 4 bytes, zeroed by the caller*/, float *dwa,
                   float *dba, float *dwb, float *dbb, void *stream);
 /* ---- config[4]'s "bf16 MLP on MFMA" (BASELINE.json configs[4]; models/network_utils.py:109-157 at reduced matrix

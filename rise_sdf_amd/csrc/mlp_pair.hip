@@ -55,8 +55,14 @@ constexpr int DZ1 = DZI + IMG;                            // dz_a
 constexpr int WTI = DZ1 + IMG;                            // Wb^T image: [part 2][feature 128][k 128] fp16, swizzled 16-byte units
 constexpr int WT_PART = H * H * 2;
 constexpr int RED = WTI + 2 * WT_PART;                    // 16 floats of scratch
-constexpr int LDS_FWD = DZ1;                              // the forward needs X x 2, H1, O
-constexpr int LDS_BWD = RED + 64;
+// the network's narrow output layer folded into its last pair (N2 <= 8): W_out [8][128] + b_out [8] fp32, and in the forward the
+// eight waves' partial dot products [8 waves][32 rows][8] (summed in a fixed order: deterministic)
+constexpr int OUT_W = 8 * H * 4 + 64;
+constexpr int OUT_PART = NW * 32 * 8 * 4;
+constexpr int FWD_WO = DZ1, FWD_PART = FWD_WO + OUT_W;
+constexpr int LDS_FWD = FWD_PART + OUT_PART;              // the forward needs X x 2, H1, O (+ the output layer)
+constexpr int BWD_WO = RED + 64;
+constexpr int LDS_BWD = BWD_WO + OUT_W;
 
 struct Frag2 { u32x4 h, l; };
 
@@ -212,6 +218,11 @@ struct PairArgs {
     int lddx, kout, x_relu;          // x_relu: write dx (x > 0) -- x is the ReLU output of the layer below
     unsigned *dx_absmax;             // nullable: atomicMax of |dx| (the next launch's bound)
     float *dwa, *dba, *dwb, *dbb;
+    // the narrow output layer on top of this pair (N2 <= 8), folded in
+    const float *w_out, *b_out;      // [N2][128], [N2]
+    int n_out, out_act;              // forward: y = act(W_out hb + b_out) -> y_out [n][N2] (RSDF_ACT_NONE / RSDF_ACT_SIGMOID)
+    float *y_out;
+    const float *dz_out;             // backward: g = dz_out [n][N2] @ W_out formed here instead of being read
 };
 
 // MASKED (backward only): g is already dz_b, so hb is not recomputed and Wb's own fragments are not held
@@ -256,6 +267,11 @@ pair_kernel(const PairArgs a)
             for (int j = 0; j < 8; ++j) v[j] = fw < K ? a.wa[(size_t)(32 * kb + 8 * g + j) * K + fw] * SW : 0.0f;
             wat[kb] = split2_frag(v);                                               // Wa[n][fw]: dx column fw
         }
+    }
+    float *s_wo = reinterpret_cast<float *>(smem + (BWD ? BWD_WO : FWD_WO));
+    if (a.n_out > 0) {
+        for (int e = threadIdx.x; e < 8 * H; e += NTHR) s_wo[e] = e < a.n_out * H ? a.w_out[e] : 0.0f;
+        if (threadIdx.x < 8) s_wo[8 * H + threadIdx.x] = (!BWD && threadIdx.x < a.n_out) ? a.b_out[threadIdx.x] : 0.0f;
     }
     f32x4 bar, bbr;                                // biases (x T) of features 16 w + 4 g + r
 #pragma unroll
@@ -315,8 +331,24 @@ pair_kernel(const PairArgs a)
                 const int64_t row = s0 + 16 * rh + c16;
                 row_ok[rh] = row < a.n;
                 const int64_t rowc = row_ok[rh] ? row : a.n - 1;
-                const float4 v = *reinterpret_cast<const float4 *>(a.g + rowc * H + 16 * w + 4 * g);
-                dz[rh] = f32x4{v.x, v.y, v.z, v.w};
+                if (MASKED && a.dz_out != nullptr) {   // d hb = dz_out W_out, formed from 4 N2 bytes per row instead of 512 read
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        if (q < a.n_out) {
+                            const float dq = a.dz_out[rowc * a.n_out + q];
+                            const float4 wq = *reinterpret_cast<const float4 *>(s_wo + q * H + 16 * w + 4 * g);
+                            acc[0] = fmaf(dq, wq.x, acc[0]);
+                            acc[1] = fmaf(dq, wq.y, acc[1]);
+                            acc[2] = fmaf(dq, wq.z, acc[2]);
+                            acc[3] = fmaf(dq, wq.w, acc[3]);
+                        }
+                    }
+                    dz[rh] = acc;
+                } else {
+                    const float4 v = *reinterpret_cast<const float4 *>(a.g + rowc * H + 16 * w + 4 * g);
+                    dz[rh] = f32x4{v.x, v.y, v.z, v.w};
+                }
                 if (MASKED && a.hmask != nullptr) {    // the mask from the forward's own hb rows instead of a recompute
                     const float4 m = *reinterpret_cast<const float4 *>(a.hmask + rowc * H + 16 * w + 4 * g);
                     dz[rh][0] = m.x > 0.0f ? dz[rh][0] : 0.0f;
@@ -359,6 +391,19 @@ pair_kernel(const PairArgs a)
                     bad |= !(acc[r] < 65504.0f * (T / SA));
                 }
                 if (a.out_img != nullptr) store_q(smem + DZI, rh, lc, hb);
+                if (a.n_out > 0) {             // this wave's share of y = W_out hb: 16 features, reduced over the four k-groups
+                    float *part = reinterpret_cast<float *>(smem + FWD_PART) + (w * 32 + 16 * rh + c16) * 8;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        if (q < a.n_out) {
+                            const float4 wq = *reinterpret_cast<const float4 *>(s_wo + q * H + 16 * w + 4 * g);
+                            float pq = (wq.x * hb[0] + wq.y * hb[1] + wq.z * hb[2] + wq.w * hb[3]) * (1.0f / SA);
+                            pq += __shfl_xor(pq, 16, 64);
+                            pq += __shfl_xor(pq, 32, 64);
+                            if (g == 0) part[q] = pq;
+                        }
+                    }
+                }
                 const int64_t row = s0 + 16 * rh + c16;
                 if (a.out_rows != nullptr && row < a.n)
                     *reinterpret_cast<float4 *>(a.out_rows + row * H + 16 * w + 4 * g) =
@@ -377,6 +422,17 @@ pair_kernel(const PairArgs a)
         }
         lds_barrier();                         // (3) dz_b image (forward: the output image) complete
         if (!BWD) {
+            if (a.n_out > 0 && threadIdx.x < 32 * 8) {     // y[row][q]: the eight waves' partials in a fixed order, bias, activation
+                const int r = threadIdx.x >> 3, q = threadIdx.x & 7;
+                if (q < a.n_out && s0 + r < a.n) {
+                    const float *part = reinterpret_cast<const float *>(smem + FWD_PART) + r * 8 + q;
+                    float y = s_wo[8 * H + q];
+#pragma unroll
+                    for (int ww = 0; ww < NW; ++ww) y += part[ww * 32 * 8];
+                    if (a.out_act == RSDF_ACT_SIGMOID) y = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y * -1.4426950408889634f));
+                    a.y_out[(s0 + r) * a.n_out + q] = y;
+                }
+            }
             if (a.out_img != nullptr) {        // 16 KB, linear: 32 bytes per thread
                 unsigned char *ob = a.out_img + ti * IMG + threadIdx.x * 16;
                 const unsigned char *ib = smem + DZI + threadIdx.x * 16;
@@ -582,10 +638,14 @@ int rsdf_pair_unpack(const void *image, int64_t n, float *rows, void *stream)
 }
 
 int rsdf_pair_fwd(const void *x_image, int K, const float *wa, const float *ba, const float *wb, const float *bb, int64_t n,
-                  void *out_image, float *out_rows, int *status, void *stream)
+                  void *out_image, float *out_rows, const float *w_out, const float *b_out, int N2, int out_act, float *y_out,
+                  int *status, void *stream)
 {
     RSDF_CHECK_ARG(K >= 1 && K <= 128, "pair_fwd: K must be in [1,128]");
-    RSDF_CHECK_ARG(out_image != nullptr || out_rows != nullptr, "pair_fwd: no output");
+    RSDF_CHECK_ARG(out_image != nullptr || out_rows != nullptr || y_out != nullptr, "pair_fwd: no output");
+    RSDF_CHECK_ARG(y_out == nullptr || (w_out != nullptr && b_out != nullptr && N2 >= 1 && N2 <= 8 &&
+                                        (out_act == RSDF_ACT_NONE || out_act == RSDF_ACT_SIGMOID)),
+                   "pair_fwd: the folded output layer needs W_out, b_out, 1 <= N2 <= 8 and activation none / sigmoid");
     if (n <= 0) return 0;
     PairArgs a{};
     a.x = reinterpret_cast<const unsigned char *>(x_image);
@@ -595,6 +655,7 @@ int rsdf_pair_fwd(const void *x_image, int K, const float *wa, const float *ba, 
     a.out_img = reinterpret_cast<unsigned char *>(out_image);
     a.out_rows = out_rows;
     a.status = status;
+    if (y_out != nullptr) a.w_out = w_out, a.b_out = b_out, a.n_out = N2, a.out_act = out_act, a.y_out = y_out;
     if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(pair_kernel<false, false>), LDS_FWD)) return rc;
     const unsigned grid = (unsigned)(a.tiles < 256 ? a.tiles : 256);
     pair_kernel<false, false><<<grid, NTHR, LDS_FWD, (hipStream_t)stream>>>(a);
@@ -621,11 +682,14 @@ int rsdf_pair_bound_from_out_layer(const float *dz_out, int64_t n, int N2, const
 }
 
 int rsdf_pair_bwd(const void *x_image, int K, const float *wa, const float *ba, const float *wb, const float *bb, int64_t n,
-                  const float *g, int g_masked, const float *hb_rows, const void *bound, float *dx, int lddx, int kout, int x_relu,
+                  const float *g, int g_masked, const float *hb_rows, const float *dz_out, const float *w_out, int N2,
+                  const void *bound, float *dx, int lddx, int kout, int x_relu,
                   void *dx_absmax, float *dwa, float *dba, float *dwb, float *dbb, void *stream)
 {
     RSDF_CHECK_ARG(K >= 1 && K <= 128, "pair_bwd: K must be in [1,128]");
-    RSDF_CHECK_ARG(g != nullptr && bound != nullptr, "pair_bwd: g and its bound are required");
+    RSDF_CHECK_ARG((g != nullptr || dz_out != nullptr) && bound != nullptr, "pair_bwd: g (or dz_out) and its bound are required");
+    RSDF_CHECK_ARG(dz_out == nullptr || (hb_rows != nullptr && w_out != nullptr && N2 >= 1 && N2 <= 8),
+                   "pair_bwd: the folded output layer needs hb_rows, W_out and 1 <= N2 <= 8");
     RSDF_CHECK_ARG(dx == nullptr || (kout >= 1 && kout <= K && lddx >= kout), "pair_bwd: bad dx window");
     if (n <= 0) return 0;
     PairArgs a{};
@@ -635,6 +699,7 @@ int rsdf_pair_bwd(const void *x_image, int K, const float *wa, const float *ba, 
     a.wa = wa, a.ba = ba, a.wb = wb, a.bb = bb, a.K = K;
     a.g = g, a.g_masked = (g_masked || hb_rows != nullptr) ? 1 : 0, a.hmask = g_masked ? nullptr : hb_rows;
     a.bound = reinterpret_cast<const unsigned *>(bound);
+    if (dz_out != nullptr) a.dz_out = dz_out, a.w_out = w_out, a.n_out = N2;
     a.dx = dx, a.lddx = lddx, a.kout = kout, a.x_relu = x_relu;
     a.dx_absmax = reinterpret_cast<unsigned *>(dx_absmax);
     a.dwa = dwa, a.dba = dba, a.dwb = dwb, a.dbb = dbb;

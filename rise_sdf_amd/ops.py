@@ -892,19 +892,26 @@ class _MLPPairChain(torch.autograd.Function):
             check(lib().rsdf_pair_pack(ptr(xf), K, K, n, ptr(imgs[0]), stt, st), "pair_pack")
             _PAIR_PACK_CACHE["last"] = (key, xf, imgs[0])
         h_last = torch.empty(n, 128, dtype=torch.float32, device=dev)
+        N2 = ws[-1].shape[0]
+        y = torch.empty(n, N2, dtype=torch.float32, device=dev)
+        # the narrow output layer rides in the last pair's kernel (N2 <= 8, no activation or the sigmoid the texture networks
+        # fuse into it): no pass over the last hidden activation for it, forward (y) or backward (d h_last)
+        fold = N2 <= 8 and acts[-1] in (L.ACT_IDS["none"], L.ACT_IDS["sigmoid"])
         for p in range(nh // 2):
             last = p == nh // 2 - 1
             out_img = None if last else torch.empty(img_bytes, dtype=torch.uint8, device=dev)
+            lf = last and fold
             check(lib().rsdf_pair_fwd(ptr(imgs[p]), K if p == 0 else 128, ptr(ws[2 * p]), ptr(bs[2 * p]), ptr(ws[2 * p + 1]),
-                                      ptr(bs[2 * p + 1]), n, ptr(out_img), ptr(h_last) if last else None, stt, st), "pair_fwd")
+                                      ptr(bs[2 * p + 1]), n, ptr(out_img), ptr(h_last) if last else None,
+                                      ptr(ws[-1]) if lf else None, ptr(bs[-1]) if lf else None, N2 if lf else 0,
+                                      acts[-1] if lf else 0, ptr(y) if lf else None, stt, st), "pair_fwd")
             if not last:
                 imgs.append(out_img)
-        N2 = ws[-1].shape[0]
-        y = torch.empty(n, N2, dtype=torch.float32, device=dev)
-        check(lib().rsdf_linear_fwd(ptr(h_last), 128, ptr(ws[-1]), ptr(bs[-1]), n, 128, N2, acts[-1], ptr(y), N2, st),
-              "linear_fwd")
+        if not fold:
+            check(lib().rsdf_linear_fwd(ptr(h_last), 128, ptr(ws[-1]), ptr(bs[-1]), n, 128, N2, acts[-1], ptr(y), N2, st),
+                  "linear_fwd")
         ctx.save_for_backward(*imgs, h_last, y, *ws, *bs)
-        ctx.n_imgs, ctx.nh, ctx.K, ctx.acts, ctx.dx_cols = len(imgs), nh, K, tuple(acts), dx_cols
+        ctx.n_imgs, ctx.nh, ctx.K, ctx.acts, ctx.dx_cols, ctx.fold = len(imgs), nh, K, tuple(acts), dx_cols, fold
         return y
 
     @staticmethod
@@ -929,9 +936,11 @@ class _MLPPairChain(torch.autograd.Function):
         bounds = pool[o:o + 4].view(torch.int32)          # [0..1]: the top pair's bound + scratch, [2]: the lower pair's
         # ---- narrow output layer on the per-layer kernels: dz_out, d h_last [n,128] rows, dW_out, db_out
         dzo = g if ctx.acts[-1] == L.ACT_IDS["none"] else torch.empty_like(g)
-        dh = torch.empty(n, 128, dtype=torch.float32, device=dev)
-        check(lib().rsdf_linear_bwd_input(ptr(g), ptr(y), N2, ptr(ws[-1]), n, 128, N2, ctx.acts[-1], 0, 128,
-                                          None if dzo is g else ptr(dzo), ptr(dh), 128, st), "linear_bwd_input")
+        fold = ctx.fold
+        dh = None if fold else torch.empty(n, 128, dtype=torch.float32, device=dev)
+        if dzo is not g or dh is not None:       # (folded: only dz_out = g act'(y), [n, N2]; d h_last is formed inside the pair kernel)
+            check(lib().rsdf_linear_bwd_input(ptr(g), ptr(y), N2, ptr(ws[-1]), n, 128, N2, ctx.acts[-1], 0, 128,
+                                              None if dzo is g else ptr(dzo), ptr(dh), 128, st), "linear_bwd_input")
         check(lib().rsdf_linear_bwd_weight(ptr(dzo), N2, ptr(h_last), 128, n, 128, N2, ptr(grads[-2]), ptr(grads[-1]), st),
               "linear_bwd_weight")
         check(lib().rsdf_pair_bound_from_out_layer(ptr(dzo), n, N2, ptr(ws[-1]), ptr(bounds), st), "pair_bound")
@@ -953,8 +962,10 @@ class _MLPPairChain(torch.autograd.Function):
             else:
                 dx, win, ld, ko, relu, amax = None, None, 0, 0, 0, None
             # (the top pair takes its ReLU mask from the forward's own h_last rows: no hb recompute, the lean kernel variant)
+            top_fold = masked == 0 and fold
             check(lib().rsdf_pair_bwd(ptr(imgs[p]), Kp, ptr(ws[2 * p]), ptr(bs[2 * p]), ptr(ws[2 * p + 1]), ptr(bs[2 * p + 1]), n,
-                                      ptr(gcur), masked, ptr(h_last) if masked == 0 else None,
+                                      None if top_fold else ptr(gcur), masked, ptr(h_last) if masked == 0 else None,
+                                      ptr(dzo) if top_fold else None, ptr(ws[-1]) if top_fold else None, N2 if top_fold else 0,
                                       ptr(bound) if masked == 0 else ctypes.c_void_p(bounds.data_ptr() + 8),
                                       win, ld, ko, relu, amax, ptr(grads[4 * p]), ptr(grads[4 * p + 1]), ptr(grads[4 * p + 2]),
                                       ptr(grads[4 * p + 3]), st), "pair_bwd")

@@ -47,7 +47,7 @@ def test_pair_image_round_trip(dev):
 
 @pytest.mark.parametrize("K,nh,N2,n,out_act", [(84, 4, 6, 4133, "sigmoid"), (73, 4, 3, 1000, "sigmoid"), (84, 2, 1, 2048, "sigmoid"),
                                                (84, 2, 2, 31, "none"), (128, 4, 3, 777, "none"), (17, 2, 5, 65, "none"),
-                                               (76, 4, 3, 33, "none")])
+                                               (76, 4, 3, 33, "none"), (84, 2, 13, 500, "none"), (84, 4, 8, 700, "sigmoid")])
 def test_pair_chain_matches_per_layer_kernels_and_fp64(dev, K, nh, N2, n, out_act, monkeypatch):
     from rise_sdf_amd import ops
     layers = _net(dev, K, nh, N2, seed=K + nh)
@@ -97,7 +97,7 @@ def test_pair_backward_mask_sources_agree(dev):
     img = torch.empty(int(L.rsdf_pair_image_bytes(n)), dtype=torch.uint8, device=dev)
     hb = torch.empty(n, 128, device=dev)
     assert L.rsdf_pair_pack(p(x), K, K, n, p(img), None, st) == 0
-    assert L.rsdf_pair_fwd(p(img), K, p(wa), p(ba), p(wb), p(bb), n, None, p(hb), None, st) == 0
+    assert L.rsdf_pair_fwd(p(img), K, p(wa), p(ba), p(wb), p(bb), n, None, p(hb), None, None, 0, 0, None, None, st) == 0
     ref = torch.relu(torch.relu(x.double() @ wa.double().T + ba.double()) @ wb.double().T + bb.double())
     assert float((hb.double() - ref).abs().max()) < 3e-7 * float(ref.abs().max())
     bound = torch.zeros(2, dtype=torch.int32, device=dev)
@@ -108,7 +108,8 @@ def test_pair_backward_mask_sources_agree(dev):
         gr = [torch.zeros_like(t) for t in (wa, ba, wb, bb)]
         gin = gy * (hb > 0) if mode == "premasked" else gy
         _lib.check(L.rsdf_pair_bwd(p(img), K, p(wa), p(ba), p(wb), p(bb), n, p(gin.contiguous()), int(mode == "premasked"),
-                                   p(hb) if mode == "hb_rows" else None, p(bound), p(dx), K, K, 0, None, *[p(t) for t in gr], st),
+                                   p(hb) if mode == "hb_rows" else None, None, None, 0, p(bound), p(dx), K, K, 0, None,
+                                   *[p(t) for t in gr], st),
                    "pair_bwd")
         torch.cuda.synchronize()
         outs.append([dx] + gr)
