@@ -897,17 +897,21 @@ class _MLPPairChain(torch.autograd.Function):
         # the narrow output layer rides in the last pair's kernel (N2 <= 8, no activation or the sigmoid the texture networks
         # fuse into it): no pass over the last hidden activation for it, forward (y) or backward (d h_last)
         fold = N2 <= 8 and acts[-1] in (L.ACT_IDS["none"], L.ACT_IDS["sigmoid"])
+        # (measured on the c2 step: the backward fold pays -- 194 ms of d h_last writes and reads gone for +94 ms in the pair
+        # kernel -- the forward fold does not: the cross-wave dot product costs the memory-bound forward kernel +130 ms against
+        # the 113 ms pass it replaces.  RSDF_PAIR_FOLD_FWD=1 enables it for A/B and for its test.)
+        fold_fwd = fold and os.environ.get("RSDF_PAIR_FOLD_FWD", "0") == "1"
         for p in range(nh // 2):
             last = p == nh // 2 - 1
             out_img = None if last else torch.empty(img_bytes, dtype=torch.uint8, device=dev)
-            lf = last and fold
+            lf = last and fold_fwd
             check(lib().rsdf_pair_fwd(ptr(imgs[p]), K if p == 0 else 128, ptr(ws[2 * p]), ptr(bs[2 * p]), ptr(ws[2 * p + 1]),
                                       ptr(bs[2 * p + 1]), n, ptr(out_img), ptr(h_last) if last else None,
                                       ptr(ws[-1]) if lf else None, ptr(bs[-1]) if lf else None, N2 if lf else 0,
                                       acts[-1] if lf else 0, ptr(y) if lf else None, stt, st), "pair_fwd")
             if not last:
                 imgs.append(out_img)
-        if not fold:
+        if not fold_fwd:
             check(lib().rsdf_linear_fwd(ptr(h_last), 128, ptr(ws[-1]), ptr(bs[-1]), n, 128, N2, acts[-1], ptr(y), N2, st),
                   "linear_fwd")
         ctx.save_for_backward(*imgs, h_last, y, *ws, *bs)

@@ -83,7 +83,7 @@ def secondary_rendering(t_starts: Tensor, t_ends: Tensor, ray_indices: Tensor, n
     packed = ops.pack_info(ray_indices, n_rays)
     if phantom_last_ray and n_rays > 0:
         packed = packed.clone()
-        packed[n_rays - 1, 1] = 0
+        packed[n_rays - 1:, 1].zero_()           # (a fill on the device: indexing with a Python scalar would be a host copy)
     weights, trans = ops.render_weight_from_alpha(alphas, packed_info=packed)
     opacities, depths = ops.accumulate_opacity_depth(weights, t_starts, t_ends, packed_info=packed)
     return opacities, depths, {"weights": weights, "trans": trans, "alphas": alphas}

@@ -83,6 +83,24 @@ def test_pair_chain_matches_per_layer_kernels_and_fp64(dev, K, nh, N2, n, out_ac
     print(f"   gradients vs fp64, worst tensor: {worst:.1e}")
 
 
+@pytest.mark.parametrize("N2,out_act", [(6, "sigmoid"), (1, "none"), (8, "sigmoid")])
+def test_pair_forward_output_layer_fold(dev, N2, out_act, monkeypatch):
+    """RSDF_PAIR_FOLD_FWD=1: the narrow output layer computed inside the last pair's forward kernel (a deterministic sum of the
+    eight waves' partial dot products) against the per-layer kernel on the same h_last."""
+    from rise_sdf_amd import ops
+    layers = _net(dev, 84, 4, N2, seed=31)
+    acts = ["relu"] * 4 + [out_act]
+    x = torch.randn(3000, 84, generator=torch.Generator().manual_seed(2)).to(dev)
+    with torch.no_grad():
+        monkeypatch.setenv("RSDF_PAIR_FOLD_FWD", "0")
+        a = ops.mlp_chain(x, layers, acts)
+        monkeypatch.setenv("RSDF_PAIR_FOLD_FWD", "1")
+        b = ops.mlp_chain(x, layers, acts)
+        c = ops.mlp_chain(x, layers, acts)
+    assert torch.equal(b, c), "the folded output layer must be deterministic"
+    assert float((a - b).abs().max()) < 2e-6 * max(float(a.abs().max()), 1.0)
+
+
 def test_pair_backward_mask_sources_agree(dev):
     """rsdf_pair_bwd takes the ReLU mask of the pair's upper layer three ways: recomputed from x (one more product), from the
     forward's own hb rows, or already applied to g by the producer.  Same dx and weight gradients."""
