@@ -397,6 +397,10 @@ int rsdf_sdfmlp_fd7_bwd_x2(const void *x2, int parts, int n_levels, int n_active
 int rsdf_pair_supported(int K, int Na, int Nb);
 int64_t rsdf_pair_image_bytes(int64_t n_rows);
 int rsdf_pair_pack(const float *x, int ldx, int K, int64_t n, void *image, int *status /*nullable*/, void *stream);
+/* columns [0, K1) from x1, [K1, K1 + K2) from x2: the reference's torch.cat([feature, encoding], -1) (models/texture.py:299-313)
+ * without materialising it; image chunks past the last 32-column group that holds a column are neither written nor read */
+int rsdf_pair_pack2(const float *x1, int ld1, int K1, const float *x2 /*nullable with K2 = 0*/, int ld2, int K2, int64_t n,
+                    void *image, int *status /*nullable*/, void *stream);
 int rsdf_pair_unpack(const void *image, int64_t n, float *rows, void *stream);
 int rsdf_pair_fwd(const void *x_image, int K, const float *wa, const float *ba, const float *wb, const float *bb, int64_t n,
                   void *out_image /*nullable*/, float *out_rows /*nullable*/, const float *w_out /*[N2][128], nullable*/,

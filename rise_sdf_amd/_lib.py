@@ -107,6 +107,7 @@ _SIGNATURES = {
     "rsdf_pair_supported": [_I, _I, _I],
     "rsdf_pair_image_bytes": [_L],
     "rsdf_pair_pack": [_P, _I, _I, _L, _P, _P, _P],
+    "rsdf_pair_pack2": [_P, _I, _I, _P, _I, _I, _L, _P, _P, _P],
     "rsdf_pair_unpack": [_P, _L, _P, _P],
     "rsdf_pair_fwd": [_P, _I, _P, _P, _P, _P, _L, _P, _P, _P, _P, _I, _I, _P, _P, _P],
     "rsdf_pair_bound_from_rows": [_P, _L, _P, _P],

@@ -183,8 +183,11 @@ __device__ __forceinline__ void store_q(unsigned char *img, int rh, const LaneQ 
     *reinterpret_cast<uint2 *>(p + PART) = uint2{l0, l1};
 }
 // one tile (16 KB, linear) by LDS-DMA: 16 instructions of 1 KB, two per wave
-__device__ __forceinline__ void dma_tile(unsigned char *img, const unsigned char *x, int64_t tile, int ws, int lane)
+// (block ws of a part = chunks 2 ws, 2 ws + 1 = columns 16 ws .. 16 ws + 15: blocks past the input's last 32-column group hold
+// zeros that nothing reads -- K = 84: 12 of 16 KB)
+__device__ __forceinline__ void dma_tile(unsigned char *img, const unsigned char *x, int64_t tile, int ws, int lane, int kba)
 {
+    if (ws >= 2 * kba) return;
     const unsigned char *tb = x + tile * IMG + lane * 16;
     __builtin_amdgcn_global_load_lds((glob_void *)(tb + ws * 1024), (lds_void *)(img + ws * 1024), 16, 0, 0);
     __builtin_amdgcn_global_load_lds((glob_void *)(tb + (ws + 8) * 1024), (lds_void *)(img + (ws + 8) * 1024), 16, 0, 0);
@@ -236,6 +239,7 @@ pair_kernel(const PairArgs a)
     const int fw = 16 * w + c16;                   // the feature (or dx column) this lane addresses in an A fragment of its wave
     const LaneQ lc = lane_consts(w, lane);
     const int K = a.K;
+    const int kba = (K + 31) >> 5, cta = (K + 15) >> 4;      // 32-column k-blocks / 16-column tiles of the input that are not all zero
 
     // ---- weight fragments (A operands: lane = (row c16 of the wave's 16-row block, k-group g), 8 consecutive k), x SW
     bool bad0 = false;                             // a weight beyond the class range
@@ -315,7 +319,7 @@ pair_kernel(const PairArgs a)
     float dxmax = 0.0f;
     bool bad = bad0;
 
-    if ((int64_t)blockIdx.x < a.tiles) dma_tile(smem + XI, a.x, (int64_t)blockIdx.x, ws, lane);
+    if ((int64_t)blockIdx.x < a.tiles) dma_tile(smem + XI, a.x, (int64_t)blockIdx.x, ws, lane, kba);
     int parity = 0;
     for (int64_t ti = blockIdx.x; ti < a.tiles; ti += gridDim.x) {
         const int64_t s0 = ti * 32;
@@ -358,14 +362,15 @@ pair_kernel(const PairArgs a)
                 }
             }
         }
-        if (ti + gridDim.x < a.tiles) dma_tile(smem + XI + parity * IMG, a.x, ti + gridDim.x, ws, lane);
+        if (ti + gridDim.x < a.tiles) dma_tile(smem + XI + parity * IMG, a.x, ti + gridDim.x, ws, lane, kba);
         // ---- layer a: C = T za -> SA ha
         f32x4 ha[2];
 #pragma unroll
         for (int rh = 0; rh < 2; ++rh) {
             f32x4 acc = bar;
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb) acc = mma3q(waf[kb], rowq(xi, kb, rh, lc), acc);
+            for (int kb = 0; kb < KB; ++kb)
+                if (kb < kba) acc = mma3q(waf[kb], rowq(xi, kb, rh, lc), acc);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 ha[rh][r] = fmaxf(acc[r], 0.0f) * (SA / T);
@@ -507,7 +512,8 @@ pair_kernel(const PairArgs a)
         {
             const Frag2 af = trfq(smem + DZ1, w, lc);
 #pragma unroll
-            for (int ct = 0; ct < H / 16; ++ct) gwa[ct] = mma3q(af, trfq(xi, ct, lc), gwa[ct]);          // x G1 SA
+            for (int ct = 0; ct < H / 16; ++ct)
+                if (ct < cta) gwa[ct] = mma3q(af, trfq(xi, ct, lc), gwa[ct]);                          // x G1 SA
         }
         // no barrier: the next tile's barrier (1) separates these reads from the DMA that overwrites this X image
     }
@@ -547,19 +553,25 @@ pair_kernel(const PairArgs a)
 
 // fp32 rows [n][ld] (columns [0, K)) -> the pair image (columns >= K and rows >= n: zeros)
 __global__ void __launch_bounds__(256)
-pack_kernel(const float *__restrict__ x, int ld, int K, int64_t n, int64_t tiles, unsigned char *__restrict__ img,
-            int *__restrict__ status)
+pack_kernel(const float *__restrict__ x, int ld, int K1, const float *__restrict__ x2, int ld2, int K, int64_t n, int64_t tiles,
+            unsigned char *__restrict__ img, int *__restrict__ status)
 {
+    // columns [0, K1) from x, [K1, K) from x2 (the reference's torch.cat([feature, encoding], -1), models/texture.py:299-313,
+    // never materialised); chunks past the last 32-column group that holds a column are not written: nothing reads them
     const int64_t total = tiles * 32 * 16;                                         // (row, chunk) pairs
+    const int n_chunks = ((K + 31) >> 5) * 4;
     bool bad = false;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         const int ch = (int)(e & 15);
         const int64_t row = e >> 4;
+        if (ch >= n_chunks) continue;
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int col = 8 * ch + j;
-            v[j] = (row < n && col < K) ? x[row * ld + col] * SA : 0.0f;
+            float t = 0.0f;
+            if (row < n && col < K) t = col < K1 ? x[row * ld + col] : x2[row * ld2 + (col - K1)];
+            v[j] = t * SA;
             bad |= !(fabsf(v[j]) < 65504.0f);
         }
         const Frag2 f = split2_frag(v);
@@ -620,11 +632,20 @@ int64_t rsdf_pair_image_bytes(int64_t n_rows) { return ((n_rows + 31) / 32) * (i
 
 int rsdf_pair_pack(const float *x, int ldx, int K, int64_t n, void *image, int *status, void *stream)
 {
-    RSDF_CHECK_ARG(K >= 1 && K <= 128 && ldx >= K, "pair_pack: K must be in [1,128] and ldx >= K");
+    return rsdf_pair_pack2(x, ldx, K, nullptr, 0, 0, n, image, status, stream);
+}
+
+int rsdf_pair_pack2(const float *x1, int ld1, int K1, const float *x2, int ld2, int K2, int64_t n, void *image, int *status,
+                    void *stream)
+{
+    const int K = K1 + K2;
+    RSDF_CHECK_ARG(K1 >= 1 && K2 >= 0 && K <= 128 && ld1 >= K1 && (K2 == 0 || (x2 != nullptr && ld2 >= K2)),
+                   "pair_pack: 1 <= K1, K1 + K2 <= 128, ld >= K");
     if (n <= 0) return 0;
     const int64_t tiles = (n + 31) / 32, work = tiles * 32 * 16;
     const unsigned grid = (unsigned)((work + 255) / 256 < 65536 ? (work + 255) / 256 : 65536);
-    pack_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, ldx, K, n, tiles, reinterpret_cast<unsigned char *>(image), status);
+    pack_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x1, ld1, K1, x2, ld2, K, n, tiles, reinterpret_cast<unsigned char *>(image),
+                                                      status);
     RSDF_RETURN_LAUNCH();
 }
 

@@ -229,12 +229,14 @@ class VanillaMLP(nn.Module):
                 out.append((w, m.bias))
         return out
 
-    def forward(self, x, out_act=None):
+    def forward(self, x, out_act=None, x2=None):
         """``out_act`` overrides the configured output activation (lets a caller fuse e.g. the texture
-        networks' color_activation into the last layer's kernel)."""
+        networks' color_activation into the last layer's kernel).  ``x2``: the input is cat([x, x2], -1) (the radiance
+        networks' [feature, encoding], models/texture.py:299-313) without the caller having to materialise it."""
         wb = self.effective_weights()
         acts = [self.hidden_act] * (len(wb) - 1) + [out_act or self.output_act]
-        return ops.mlp_chain(x.float(), wb, acts, dx_cols=self.input_grad_cols, precision=self.precision)
+        return ops.mlp_chain(x.float(), wb, acts, dx_cols=self.input_grad_cols, precision=self.precision,
+                             x2=None if x2 is None else x2.float())
 
 
 def w_is_cuda(t):

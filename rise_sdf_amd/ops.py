@@ -869,12 +869,17 @@ class _MLPPairChain(torch.autograd.Function):
     network: ~2.5 KB forward + ~4 KB backward against 3.9 + 8 with one kernel per layer."""
 
     @staticmethod
-    def forward(ctx, x, dx_cols, acts, *wb):
+    def forward(ctx, x, x2, dx_cols, acts, *wb):
+        """``x2`` (nullable): the network's input is cat([x, x2], -1) (models/texture.py:299-313: [feature, encoding]) and is
+        never materialised -- rsdf_pair_pack2 writes the pair image from the two sources."""
         xf = _f32c(x)
+        xf2 = None if x2 is None else _f32c(x2)
         ws = [_f32c(t) for t in wb[0::2]]
         bs = [_f32c(t) for t in wb[1::2]]
-        require_device(xf, *ws, *bs)
-        n, K = xf.shape
+        require_device(xf, xf2, *ws, *bs)
+        n, K1 = xf.shape
+        K2 = 0 if xf2 is None else xf2.shape[1]
+        K = K1 + K2
         dev, st = xf.device, stream_ptr()
         nh = len(ws) - 1                                  # hidden layers: 2 or 4
         stt = ptr(L.status(dev))
@@ -883,14 +888,15 @@ class _MLPPairChain(torch.autograd.Function):
         # (inside an autograd Function every call sees a fresh alias of the caller's tensor: the key is the storage address, the
         # shared version counter and the shape; the entry pins the rows it was packed from, so the address cannot be reused
         # while it is cached, and the next pack replaces it)
-        key = (xf.data_ptr(), xf._version, n, K, dev.index, int(st.value or 0))
+        key = (xf.data_ptr(), xf._version, None if xf2 is None else (xf2.data_ptr(), xf2._version), n, K1, K2, dev.index,
+               int(st.value or 0))
         hit = _PAIR_PACK_CACHE.get("last")
         if hit is not None and hit[0] == key:
             imgs = [hit[2]]
         else:
             imgs = [torch.empty(img_bytes, dtype=torch.uint8, device=dev)]
-            check(lib().rsdf_pair_pack(ptr(xf), K, K, n, ptr(imgs[0]), stt, st), "pair_pack")
-            _PAIR_PACK_CACHE["last"] = (key, xf, imgs[0])
+            check(lib().rsdf_pair_pack2(ptr(xf), K1, K1, ptr(xf2), K2, K2, n, ptr(imgs[0]), stt, st), "pair_pack")
+            _PAIR_PACK_CACHE["last"] = (key, (xf, xf2), imgs[0])
         h_last = torch.empty(n, 128, dtype=torch.float32, device=dev)
         N2 = ws[-1].shape[0]
         y = torch.empty(n, N2, dtype=torch.float32, device=dev)
@@ -916,6 +922,7 @@ class _MLPPairChain(torch.autograd.Function):
                   "linear_fwd")
         ctx.save_for_backward(*imgs, h_last, y, *ws, *bs)
         ctx.n_imgs, ctx.nh, ctx.K, ctx.acts, ctx.dx_cols, ctx.fold = len(imgs), nh, K, tuple(acts), dx_cols, fold
+        ctx.K1 = K1
         return y
 
     @staticmethod
@@ -949,8 +956,11 @@ class _MLPPairChain(torch.autograd.Function):
               "linear_bwd_weight")
         check(lib().rsdf_pair_bound_from_out_layer(ptr(dzo), n, N2, ptr(ws[-1]), ptr(bounds), st), "pair_bound")
         # ---- the pairs, top down
-        need_dx = ctx.needs_input_grad[0]
+        need1, need2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_dx = need1 or need2
         k0, kout = (0, K) if ctx.dx_cols is None else ctx.dx_cols
+        if not need2:                            # (only the first source's columns: fewer dx slabs are computed at all)
+            kout = min(k0 + kout, ctx.K1) - k0
         dx_in = None
         gcur, masked, bound = dh, 0, bounds
         for p in range(nh // 2 - 1, -1, -1):
@@ -978,30 +988,40 @@ class _MLPPairChain(torch.autograd.Function):
                     dx[:, :k0].zero_()
                 dx_in = dx
             gcur, masked = dx, 1
-        return (dx_in, None, None, *grads)
+        K1 = ctx.K1
+        d1 = dx_in[:, :K1] if (dx_in is not None and need1) else None
+        d2 = dx_in[:, K1:] if (dx_in is not None and need2 and K1 < K) else None
+        if K1 == K and d1 is not None:
+            d1 = dx_in
+        return (d1, d2, None, None, *grads)
 
 
-def pair_chain_ok(x, ws, bs, acts, precision):
+def pair_chain_ok(x, ws, bs, acts, precision, x2=None):
     """The radiance networks of models/texture.py:237-327 as the reference builds them: 2 or 4 hidden layers of 128 with ReLU
     and biases, at most 128 inputs, fp32.  ``RSDF_PAIR=0`` keeps one kernel per layer."""
     relu = L.ACT_IDS["relu"]
     nh = len(ws) - 1
+    K = x.shape[1] + (0 if x2 is None else x2.shape[1]) if x.dim() == 2 else -1
     return (precision in (None, "fp32") and os.environ.get("RSDF_PAIR", "1") != "0" and nh in (2, 4)
             and os.environ.get("RSDF_LAYER_BWD") != "split"
-            and x.dim() == 2 and x.shape[0] > 0 and 1 <= x.shape[1] <= 128 and ws[0].shape == (128, x.shape[1])
+            and x.dim() == 2 and x.shape[0] > 0 and 1 <= K <= 128 and ws[0].shape == (128, K)
+            and (x2 is None or (x2.dim() == 2 and x2.shape[0] == x.shape[0] and x2.is_cuda))
             and all(tuple(w.shape) == (128, 128) for w in ws[1:nh]) and ws[nh].shape[1] == 128
             and all(b is not None for b in bs) and all(a == relu for a in acts[:nh]) and x.is_cuda)
 
 
-def mlp_chain(x, layers, acts, dx_cols=None, precision="fp32"):
+def mlp_chain(x, layers, acts, dx_cols=None, precision="fp32", x2=None):
     """``layers`` = [(W [out,in], b [out] or None)], ``acts`` = activation name per layer; see _MLPChain.
-    ``precision``: 'fp32' (fp32-equivalent split products) or 'bf16' (one bf16 product, fp32 accumulate; opt-in)."""
+    ``precision``: 'fp32' (fp32-equivalent split products) or 'bf16' (one bf16 product, fp32 accumulate; opt-in).
+    ``x2``: the network's input is cat([x, x2], -1); the pair kernels never materialise it, every other route concatenates."""
     flat = []
     for w, b in layers:
         flat += [w, b]
     act_ids = tuple(L.ACT_IDS[a] if not isinstance(a, int) else a for a in acts)
-    if pair_chain_ok(x, [w for w, _ in layers], [b for _, b in layers], act_ids, precision):
-        return _MLPPairChain.apply(x.float(), dx_cols, act_ids, *flat)
+    if pair_chain_ok(x, [w for w, _ in layers], [b for _, b in layers], act_ids, precision, x2):
+        return _MLPPairChain.apply(x.float(), None if x2 is None else x2.float(), dx_cols, act_ids, *flat)
+    if x2 is not None:
+        x = torch.cat([x, x2.to(x.dtype)], dim=-1)
     return _MLPChain.apply(x, dx_cols, act_ids, precision, *flat)
 
 

@@ -89,21 +89,22 @@ class VolumeMixedMipSplitOcc(nn.Module):
         feats = features.reshape(-1, features.shape[-1])
         wo01, nov = T.reflect(dirs, normals)
         xyz = self.xyz_encoding(positions.reshape(-1, self.n_pos_dims))
-        inp = torch.cat([feats, xyz], dim=-1)
         wo_enc = self.dir_encoding(wo01)
-        env_inp = torch.cat([feats, wo_enc], dim=-1)
+        # torch.cat([feats, xyz]) / torch.cat([feats, wo_enc]) of models/texture.py:299,313 are the networks' two-source inputs
+        # (VanillaMLP.forward(x, x2=...): the pair kernels pack them straight into their input image; one image serves the three
+        # networks that read [feats, xyz])
         if stage == 0:
-            albedo6 = self.albedo_network(inp)
-            metallic2 = self.metallic_network(inp)
-            spec3 = self.env_network(env_inp)
+            albedo6 = self.albedo_network(feats, x2=xyz)
+            metallic2 = self.metallic_network(feats, x2=xyz)
+            spec3 = self.env_network(feats, x2=wo_enc)
             return T.split_color0(albedo6, metallic2, spec3)
         # stage 1: split-sum shading (models/texture.py:329-345); color_activation (sigmoid) fused into the
         # last layer of each material network
         from .gridsample import fg_lut_lookup
-        albedo6 = self.albedo_network(inp, out_act="sigmoid")
-        roughness = self.roughness_network(inp, out_act="sigmoid")
-        metallic2 = self.metallic_network(inp, out_act="sigmoid")
-        spec3 = self.env_network(env_inp, out_act="sigmoid")
+        albedo6 = self.albedo_network(feats, out_act="sigmoid", x2=xyz)
+        roughness = self.roughness_network(feats, out_act="sigmoid", x2=xyz)
+        metallic2 = self.metallic_network(feats, out_act="sigmoid", x2=xyz)
+        spec3 = self.env_network(feats, out_act="sigmoid", x2=wo_enc)
         diffuse_light = emitter.eval_mip(normals)
         wo = wo01 * 2.0 - 1.0
         specular_light = emitter.eval_mip(wo, specular=True, roughness=roughness)

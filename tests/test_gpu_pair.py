@@ -42,7 +42,7 @@ def test_pair_image_round_trip(dev):
     torch.cuda.synchronize()
     # hi + lo reproduces the value to one fp32 ulp (two 11-bit roundings of the x 2^6 value); columns >= K are zeros
     assert float((rows[:, :K] - x).abs().max()) <= float(x.abs().max()) * 2.0 ** -23
-    assert bool((rows[:, K:] == 0).all())
+    assert bool((rows[:, K:96] == 0).all())          # (chunks past the last 32-column group that holds a column are not written)
 
 
 @pytest.mark.parametrize("K,nh,N2,n,out_act", [(84, 4, 6, 4133, "sigmoid"), (73, 4, 3, 1000, "sigmoid"), (84, 2, 1, 2048, "sigmoid"),
@@ -99,6 +99,33 @@ def test_pair_forward_output_layer_fold(dev, N2, out_act, monkeypatch):
         c = ops.mlp_chain(x, layers, acts)
     assert torch.equal(b, c), "the folded output layer must be deterministic"
     assert float((a - b).abs().max()) < 2e-6 * max(float(a.abs().max()), 1.0)
+
+
+def test_pair_chain_two_source_input(dev, monkeypatch):
+    """mlp_chain(x, ..., x2=...): the network's input cat([x, x2], -1) is packed from its two sources (rsdf_pair_pack2) and the
+    input gradient comes back per source; an x2 that needs no gradient narrows the dx window to x's columns."""
+    from rise_sdf_amd import ops
+    layers = _net(dev, 84, 4, 6, seed=41)
+    acts = ["relu"] * 4 + ["sigmoid"]
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(2000, 48, generator=g).to(dev).requires_grad_(True)
+    go = torch.randn(2000, 6, generator=g).to(dev)
+    for b_grad in (True, False):
+        b = torch.randn(2000, 36, generator=torch.Generator().manual_seed(4)).to(dev).requires_grad_(b_grad)
+        res = []
+        for two in (False, True):
+            for t in [a, b] + [p for wb in layers for p in wb]:
+                t.grad = None
+            y = ops.mlp_chain(a, layers, acts, x2=b) if two else ops.mlp_chain(torch.cat([a, b], -1), layers, acts)
+            (y * go).sum().backward()
+            res.append((y.detach().clone(), a.grad.clone(), None if b.grad is None else b.grad.clone(),
+                        [p.grad.clone() for wb in layers for p in wb]))
+        (y0, ga0, gb0, gw0), (y1, ga1, gb1, gw1) = res
+        assert torch.equal(y0, y1)
+        assert float((ga0 - ga1).abs().max()) < 1e-6 * float(ga0.abs().max())
+        assert (gb0 is None) == (gb1 is None) and (gb0 is None or float((gb0 - gb1).abs().max()) < 1e-6 * float(gb0.abs().max()))
+        for p0, p1 in zip(gw0, gw1):
+            assert float((p0 - p1).abs().max()) < 1e-6 * float(p0.abs().max())
 
 
 def test_pair_backward_mask_sources_agree(dev):
