@@ -143,13 +143,47 @@ def run_step(model, rays, jitter, cot, chunk, streams=1):
     is ordered by autograd's own stream synchronisation, and everything is joined before the gradients are used."""
     n = rays.shape[0]
     total = 0
-    if streams <= 1:
+    if streams <= 1 and os.environ.get("RSDF_BENCH_PREFETCH", "1") == "0":
         for s in range(0, n, chunk):
             e = min(s + chunk, n)
             out = model.forward_(rays[s:e], stratified_u=jitter[s:e])
             total += int(out["ray_indices"].numel())
             torch.autograd.backward([out["opacity"], out["depth"], out["comp_normal_raw"]],
                                     [cot[0][s:e], cot[1][s:e], cot[2][s:e]])
+        return total
+    if streams <= 1:
+        # One chunk in flight, its successor's SAMPLING prefetched: the marcher of chunk i + 1 (two small kernels and the
+        # reference's one host read of the sample count, ray_marching.cu:261) is issued on a side stream while chunk i's
+        # forward + backward are queued on the main one, so the host read drains the side stream only and the main stream
+        # never runs dry between chunks.  Same kernels, same order per chunk, everything inside the timed region; the extra
+        # footprint is the next chunk's sample arrays (16 B per sample).
+        main = torch.cuda.current_stream()
+        side = side_streams(rays.device, 1)[0]
+
+        def sample(s, e):
+            with torch.cuda.stream(side):
+                with torch.no_grad():
+                    ro, rd = rays[s:e, :3].contiguous(), rays[s:e, 3:].contiguous()
+                    ri, ts, te = model.occupancy_grid.sampling(ro, rd, render_step_size=model.render_step_size,
+                                                               stratified_u=jitter[s:e], cone_angle=0.0, alpha_thre=0.0)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            return ro, rd, ri, ts, te, ev
+
+        side.wait_stream(main)
+        bounds = [(s, min(s + chunk, n)) for s in range(0, n, chunk)]
+        nxt = sample(*bounds[0])
+        for k, (s, e) in enumerate(bounds):
+            ro, rd, ri, ts, te, ev = nxt
+            main.wait_event(ev)
+            for t in (ro, rd, ri, ts, te):
+                t.record_stream(main)
+            out = model.render_samples(ro, rd, ri, ts, te, e - s)
+            total += int(ri.numel())
+            torch.autograd.backward([out["opacity"], out["depth"], out["comp_normal_raw"]],
+                                    [cot[0][s:e], cot[1][s:e], cot[2][s:e]])
+            if k + 1 < len(bounds):
+                nxt = sample(*bounds[k + 1])
         return total
     main = torch.cuda.current_stream()
     pool = side_streams(rays.device, streams)

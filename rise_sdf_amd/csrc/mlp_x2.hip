@@ -891,16 +891,18 @@ spread_kernel(const float *__restrict__ v, int64_t n, const float *__restrict__ 
     unsigned nz = 0, in = 0;
     const int64_t n4 = n / 4;
     const float4 *v4 = reinterpret_cast<const float4 *>(v);
-    // the decision is a FRACTION of the rows: large launches are sampled (every 8th 16-byte group: 1.4e7 of a bench chunk's
-    // 1.1e8 rows, 0.02 instead of 0.15 ms per launch); the maximum above is exact
-    const int64_t stride = n4 > (int64_t)1 << 22 ? 8 : 1;
-    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * stride; i < n4; i += (int64_t)gridDim.x * 256 * stride) {
+    // the decision is a FRACTION of the rows: large launches are sampled -- one 16 KB block of every eight (whole cache lines:
+    // a strided 16 bytes of every 128 would still move every line), 1.4e7 of a bench chunk's 1.1e8 rows; the maximum above is exact
+    const bool sampled = n4 > (int64_t)1 << 22;
+    const int64_t work = sampled ? (n4 >> 13) << 10 : n4;        // float4 groups visited
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < work; j += (int64_t)gridDim.x * 256) {
+        const int64_t i = sampled ? ((j >> 10) << 13) + (j & 1023) : j;
         const float4 t = v4[i];
         const float a = fabsf(t.x), b = fabsf(t.y), c = fabsf(t.z), d = fabsf(t.w);
         nz += (a > 0.0f) + (b > 0.0f) + (c > 0.0f) + (d > 0.0f);
         in += (a > 0.0f && a >= thr) + (b > 0.0f && b >= thr) + (c > 0.0f && c >= thr) + (d > 0.0f && d >= thr);
     }
-    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n && !sampled; i += (int64_t)gridDim.x * 256) {
         const float a = fabsf(v[i]);
         nz += a > 0.0f;
         in += a > 0.0f && a >= thr;
