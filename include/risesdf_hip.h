@@ -413,7 +413,9 @@ int rsdf_pair_bound_from_out_layer(const float *dz_out, int64_t n, int N2, const
 int rsdf_pair_bwd(const void *x_image, int K, const float *wa, const float *ba, const float *wb, const float *bb, int64_t n,
                   const float *g /*nullable with dz_out*/, int g_masked, const float *hb_rows /*nullable*/,
                   const float *dz_out /*[n][N2], nullable: g = dz_out @ w_out is formed in the kernel*/,
-                  const float *w_out /*[N2][128]*/, int N2 /*<= 8*/, const void *bound, float *dx /*nullable*/,
+                  const float *w_out /*[N2][128]*/, int N2 /*<= 8*/,
+                  float *dw_out /*nullable: dW_out [N2][128] += dz_out^T hb_rows, accumulated*/, const void *bound,
+                  float *dx /*nullable*/,
                   int lddx, int kout, int x_relu, void *dx_absmax /*nullable, 4 bytes, zeroed by the caller*/, float *dwa,
                   float *dba, float *dwb, float *dbb, void *stream);
 /* ---- config[4]'s "bf16 MLP on MFMA" (BASELINE.json configs[4]; models/network_utils.py:109-157 at reduced matrix

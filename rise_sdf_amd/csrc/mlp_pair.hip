@@ -55,14 +55,15 @@ constexpr int DZ1 = DZI + IMG;                            // dz_a
 constexpr int WTI = DZ1 + IMG;                            // Wb^T image: [part 2][feature 128][k 128] fp16, swizzled 16-byte units
 constexpr int WT_PART = H * H * 2;
 constexpr int RED = WTI + 2 * WT_PART;                    // 16 floats of scratch
-// the network's narrow output layer folded into its last pair (N2 <= 8): W_out [8][128] + b_out [8] fp32, and in the forward the
-// eight waves' partial dot products [8 waves][32 rows][8] (summed in a fixed order: deterministic)
+// the network's narrow output layer folded into its last pair (N2 <= 8): W_out [8][128] + b_out [8] fp32 in LDS; the backward
+// also keeps the tile's dz_out as a 16-column image (two chunks x two parts) for the dW_out product
 constexpr int OUT_W = 8 * H * 4 + 64;
-constexpr int OUT_PART = NW * 32 * 8 * 4;
-constexpr int FWD_WO = DZ1, FWD_PART = FWD_WO + OUT_W;
-constexpr int LDS_FWD = FWD_PART + OUT_PART;              // the forward needs X x 2, H1, O (+ the output layer)
+constexpr int FWD_WO = DZ1;
+constexpr int LDS_FWD = FWD_WO + OUT_W;                   // the forward needs X x 2, H1, O (+ the output layer's bias)
 constexpr int BWD_WO = RED + 64;
-constexpr int LDS_BWD = BWD_WO + OUT_W;
+constexpr int DZO = BWD_WO + OUT_W;                       // [part 2][chunk 2][32 rows][8 columns] fp16
+constexpr int DZO_PART = 2 * QCS;
+constexpr int LDS_BWD = DZO + 2 * DZO_PART;
 
 struct Frag2 { u32x4 h, l; };
 
@@ -159,7 +160,7 @@ __device__ __forceinline__ Frag2 rowq(const unsigned char *img, int kb, int rh, 
     return f;
 }
 // fragment whose k dimension is the tile's 32 ROWS: lane (rows 8 g .. 8 g + 7, column 16 ft + c16)
-__device__ __forceinline__ Frag2 trfq(const unsigned char *img, int ft, const LaneQ &c)
+__device__ __forceinline__ Frag2 trfq(const unsigned char *img, int ft, const LaneQ &c, int part = PART)
 {
     const unsigned char *a0 = img + c.tr0 + ft * (2 * QCS), *a1 = img + c.tr1 + ft * (2 * QCS);
     Frag2 f;
@@ -167,8 +168,8 @@ __device__ __forceinline__ Frag2 trfq(const unsigned char *img, int ft, const La
     tr64(a0, x0, x1);
     tr64(a1, y0, y1);
     f.h = u32x4{x0, x1, y0, y1};
-    tr64(a0 + PART, x0, x1);
-    tr64(a1 + PART, y0, y1);
+    tr64(a0 + part, x0, x1);
+    tr64(a1 + part, y0, y1);
     f.l = u32x4{x0, x1, y0, y1};
     return f;
 }
@@ -226,10 +227,13 @@ struct PairArgs {
     int n_out, out_act;              // forward: y = act(W_out hb + b_out) -> y_out [n][N2] (RSDF_ACT_NONE / RSDF_ACT_SIGMOID)
     float *y_out;
     const float *dz_out;             // backward: g = dz_out [n][N2] @ W_out formed here instead of being read
+    float *dw_out;                   // backward (nullable): dW_out [N2][128] += dz_out^T hb, from the hb rows that supply the mask
 };
 
-// MASKED (backward only): g is already dz_b, so hb is not recomputed and Wb's own fragments are not held
-template <bool BWD, bool MASKED>
+// MASKED (backward only): g is already dz_b, so hb is not recomputed and Wb's own fragments are not held.
+// TOP (backward, MASKED): the pair under the network's narrow output layer -- g is formed from dz_out, the mask comes from the
+// forward's hb rows, dW_out is accumulated here (a variant of its own: the pairs below keep the lean register budget)
+template <bool BWD, bool MASKED, bool TOP = false>
 __global__ void __launch_bounds__(NTHR, 1)
 pair_kernel(const PairArgs a)
 {
@@ -277,6 +281,18 @@ pair_kernel(const PairArgs a)
         for (int e = threadIdx.x; e < 8 * H; e += NTHR) s_wo[e] = e < a.n_out * H ? a.w_out[e] : 0.0f;
         if (threadIdx.x < 8) s_wo[8 * H + threadIdx.x] = (!BWD && threadIdx.x < a.n_out) ? a.b_out[threadIdx.x] : 0.0f;
     }
+    Frag2 wof[(!BWD) ? KB : 1];                    // forward fold: W_out rows q = c16 (zero rows >= N2), x SW
+    if (!BWD && a.n_out > 0) {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = c16 < a.n_out ? a.w_out[(size_t)c16 * H + 32 * kb + 8 * g + j] * SW : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bad0 |= !(fabsf(v[j]) < 65504.0f);
+            wof[kb] = split2_frag(v);
+        }
+    }
     f32x4 bar, bbr;                                // biases (x T) of features 16 w + 4 g + r
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -284,6 +300,9 @@ pair_kernel(const PairArgs a)
         bbr[r] = a.bb[16 * w + 4 * g + r] * T;
     }
     float G2 = 1.0f, G1 = 1.0f;
+    if (TOP) {
+        for (int e = threadIdx.x; e < 2 * DZO_PART / 4; e += NTHR) reinterpret_cast<unsigned *>(smem + DZO)[e] = 0u;
+    }
     if (BWD) {
         // Wb^T image: unit u (8 consecutive k of Wb[k][f], i.e. of row f of Wb^T) of feature f at unit u ^ (f & 15)
         unsigned short *e16 = reinterpret_cast<unsigned short *>(smem + WTI);
@@ -311,6 +330,7 @@ pair_kernel(const PairArgs a)
     __syncthreads();
 
     f32x4 gwb[H / 16], gwa[H / 16], gbbp = {0.f, 0.f, 0.f, 0.f}, gbap = {0.f, 0.f, 0.f, 0.f};
+    f32x4 gwo = {0.f, 0.f, 0.f, 0.f};             // folded output layer: G2 SA dW_out[4 g + r][16 w + c16]
     if (BWD) {
 #pragma unroll
         for (int n = 0; n < H / 16; ++n) gwb[n] = gwa[n] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -335,12 +355,19 @@ pair_kernel(const PairArgs a)
                 const int64_t row = s0 + 16 * rh + c16;
                 row_ok[rh] = row < a.n;
                 const int64_t rowc = row_ok[rh] ? row : a.n - 1;
-                if (MASKED && a.dz_out != nullptr) {   // d hb = dz_out W_out, formed from 4 N2 bytes per row instead of 512 read
+                if (TOP && a.dz_out != nullptr) {      // d hb = dz_out W_out, formed from 4 N2 bytes per row instead of 512 read
                     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    unsigned short *pz = reinterpret_cast<unsigned short *>(smem + DZO + ((16 * rh + c16) << 4));
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         if (q < a.n_out) {
-                            const float dq = a.dz_out[rowc * a.n_out + q];
+                            const float dq = row_ok[rh] ? a.dz_out[rowc * a.n_out + q] : 0.0f;
+                            if (a.dw_out != nullptr && ws == 0 && g == 0) {    // dz_out as a 16-column image (x G2: |dz_out| <= bound)
+                                unsigned hh, ll;
+                                split2_pair(dq * G2, 0.0f, hh, ll);
+                                pz[q] = (unsigned short)(hh & 0xffffu);
+                                pz[DZO_PART / 2 + q] = (unsigned short)(ll & 0xffffu);
+                            }
                             const float4 wq = *reinterpret_cast<const float4 *>(s_wo + q * H + 16 * w + 4 * g);
                             acc[0] = fmaf(dq, wq.x, acc[0]);
                             acc[1] = fmaf(dq, wq.y, acc[1]);
@@ -353,12 +380,18 @@ pair_kernel(const PairArgs a)
                     const float4 v = *reinterpret_cast<const float4 *>(a.g + rowc * H + 16 * w + 4 * g);
                     dz[rh] = f32x4{v.x, v.y, v.z, v.w};
                 }
-                if (MASKED && a.hmask != nullptr) {    // the mask from the forward's own hb rows instead of a recompute
+                if (TOP ? true : (MASKED && a.hmask != nullptr)) {    // the mask from the forward's own hb rows instead of a recompute
                     const float4 m = *reinterpret_cast<const float4 *>(a.hmask + rowc * H + 16 * w + 4 * g);
                     dz[rh][0] = m.x > 0.0f ? dz[rh][0] : 0.0f;
                     dz[rh][1] = m.y > 0.0f ? dz[rh][1] : 0.0f;
                     dz[rh][2] = m.z > 0.0f ? dz[rh][2] : 0.0f;
                     dz[rh][3] = m.w > 0.0f ? dz[rh][3] : 0.0f;
+                    if (TOP && a.dw_out != nullptr) {
+                        // dW_out += dz_out^T hb needs hb as a k = rows operand: its image goes where dz_a will go later in this
+                        // tile (free until barrier (3))
+                        const f32x4 hs = row_ok[rh] ? f32x4{m.x * SA, m.y * SA, m.z * SA, m.w * SA} : f32x4{0.f, 0.f, 0.f, 0.f};
+                        store_q(smem + DZ1, rh, lc, hs);
+                    }
                 }
             }
         }
@@ -395,20 +428,7 @@ pair_kernel(const PairArgs a)
                     hb[r] = fmaxf(acc[r], 0.0f) * (SA / T);
                     bad |= !(acc[r] < 65504.0f * (T / SA));
                 }
-                if (a.out_img != nullptr) store_q(smem + DZI, rh, lc, hb);
-                if (a.n_out > 0) {             // this wave's share of y = W_out hb: 16 features, reduced over the four k-groups
-                    float *part = reinterpret_cast<float *>(smem + FWD_PART) + (w * 32 + 16 * rh + c16) * 8;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        if (q < a.n_out) {
-                            const float4 wq = *reinterpret_cast<const float4 *>(s_wo + q * H + 16 * w + 4 * g);
-                            float pq = (wq.x * hb[0] + wq.y * hb[1] + wq.z * hb[2] + wq.w * hb[3]) * (1.0f / SA);
-                            pq += __shfl_xor(pq, 16, 64);
-                            pq += __shfl_xor(pq, 32, 64);
-                            if (g == 0) part[q] = pq;
-                        }
-                    }
-                }
+                if (a.out_img != nullptr || a.n_out > 0) store_q(smem + DZI, rh, lc, hb);
                 const int64_t row = s0 + 16 * rh + c16;
                 if (a.out_rows != nullptr && row < a.n)
                     *reinterpret_cast<float4 *>(a.out_rows + row * H + 16 * w + 4 * g) =
@@ -425,17 +445,26 @@ pair_kernel(const PairArgs a)
                 store_q(smem + DZI, rh, lc, dzs);
             }
         }
+        if (TOP && a.dw_out != nullptr)            // dW_out += dz_out^T hb (k = the 32 rows): both images were written before (2)
+            gwo = mma3q(trfq(smem + DZO, 0, lc, DZO_PART), trfq(smem + DZ1, w, lc), gwo);
         lds_barrier();                         // (3) dz_b image (forward: the output image) complete
         if (!BWD) {
-            if (a.n_out > 0 && threadIdx.x < 32 * 8) {     // y[row][q]: the eight waves' partials in a fixed order, bias, activation
-                const int r = threadIdx.x >> 3, q = threadIdx.x & 7;
-                if (q < a.n_out && s0 + r < a.n) {
-                    const float *part = reinterpret_cast<const float *>(smem + FWD_PART) + r * 8 + q;
-                    float y = s_wo[8 * H + q];
+            if (a.n_out > 0 && ws < 2) {       // y = act(W_out hb + b_out): waves 0 / 1 take the tile's row halves, hb from its image
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int ww = 0; ww < NW; ++ww) y += part[ww * 32 * 8];
-                    if (a.out_act == RSDF_ACT_SIGMOID) y = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y * -1.4426950408889634f));
-                    a.y_out[(s0 + r) * a.n_out + q] = y;
+                for (int kb = 0; kb < KB; ++kb) acc = mma3q(wof[kb], rowq(smem + DZI, kb, ws, lc), acc);
+                const int64_t row = s0 + 16 * ws + c16;
+                if (row < a.n) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int q = 4 * g + r;               // C[i = q][j = row c16]
+                        if (q < a.n_out) {
+                            float y = acc[r] * (1.0f / T) + s_wo[8 * H + q];
+                            if (a.out_act == RSDF_ACT_SIGMOID)
+                                y = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y * -1.4426950408889634f));
+                            a.y_out[row * a.n_out + q] = y;
+                        }
+                    }
                 }
             }
             if (a.out_img != nullptr) {        // 16 KB, linear: 32 bytes per thread
@@ -543,6 +572,11 @@ pair_kernel(const PairArgs a)
             atomicAdd(&a.dbb[f], s);
             atomicAdd(&a.dba[f], t * (1.0f / G1));
         }
+    }
+    if (TOP && a.dw_out != nullptr) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (4 * g + r < a.n_out) atomicAdd(&a.dw_out[(size_t)(4 * g + r) * H + 16 * w + c16], gwo[r] * ub);
     }
     if (a.dx_absmax != nullptr) {
 #pragma unroll
@@ -704,7 +738,7 @@ int rsdf_pair_bound_from_out_layer(const float *dz_out, int64_t n, int N2, const
 
 int rsdf_pair_bwd(const void *x_image, int K, const float *wa, const float *ba, const float *wb, const float *bb, int64_t n,
                   const float *g, int g_masked, const float *hb_rows, const float *dz_out, const float *w_out, int N2,
-                  const void *bound, float *dx, int lddx, int kout, int x_relu,
+                  float *dw_out, const void *bound, float *dx, int lddx, int kout, int x_relu,
                   void *dx_absmax, float *dwa, float *dba, float *dwb, float *dbb, void *stream)
 {
     RSDF_CHECK_ARG(K >= 1 && K <= 128, "pair_bwd: K must be in [1,128]");
@@ -720,12 +754,15 @@ int rsdf_pair_bwd(const void *x_image, int K, const float *wa, const float *ba, 
     a.wa = wa, a.ba = ba, a.wb = wb, a.bb = bb, a.K = K;
     a.g = g, a.g_masked = (g_masked || hb_rows != nullptr) ? 1 : 0, a.hmask = g_masked ? nullptr : hb_rows;
     a.bound = reinterpret_cast<const unsigned *>(bound);
-    if (dz_out != nullptr) a.dz_out = dz_out, a.w_out = w_out, a.n_out = N2;
+    if (dz_out != nullptr) a.dz_out = dz_out, a.w_out = w_out, a.n_out = N2, a.dw_out = dw_out;
     a.dx = dx, a.lddx = lddx, a.kout = kout, a.x_relu = x_relu;
     a.dx_absmax = reinterpret_cast<unsigned *>(dx_absmax);
     a.dwa = dwa, a.dba = dba, a.dwb = dwb, a.dbb = dbb;
     const unsigned grid = (unsigned)(a.tiles < 256 ? a.tiles : 256);
-    if (a.g_masked) {
+    if (a.dz_out != nullptr) {
+        if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(pair_kernel<true, true, true>), LDS_BWD)) return rc;
+        pair_kernel<true, true, true><<<grid, NTHR, LDS_BWD, (hipStream_t)stream>>>(a);
+    } else if (a.g_masked) {
         if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(pair_kernel<true, true>), LDS_BWD)) return rc;
         pair_kernel<true, true><<<grid, NTHR, LDS_BWD, (hipStream_t)stream>>>(a);
     } else {

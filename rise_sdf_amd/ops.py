@@ -903,10 +903,10 @@ class _MLPPairChain(torch.autograd.Function):
         # the narrow output layer rides in the last pair's kernel (N2 <= 8, no activation or the sigmoid the texture networks
         # fuse into it): no pass over the last hidden activation for it, forward (y) or backward (d h_last)
         fold = N2 <= 8 and acts[-1] in (L.ACT_IDS["none"], L.ACT_IDS["sigmoid"])
-        # (measured on the c2 step: the backward fold pays -- 194 ms of d h_last writes and reads gone for +94 ms in the pair
-        # kernel -- the forward fold does not: the cross-wave dot product costs the memory-bound forward kernel +130 ms against
-        # the 113 ms pass it replaces.  RSDF_PAIR_FOLD_FWD=1 enables it for A/B and for its test.)
-        fold_fwd = fold and os.environ.get("RSDF_PAIR_FOLD_FWD", "0") == "1"
+        # (forward: two waves form y = W_out hb from hb's LDS image with 12 matrix instructions per tile -- a first version on the
+        # vector ALU with a cross-wave sum cost the memory-bound kernel more (+130 ms of a c2 step) than the pass it replaced
+        # (113 ms).  RSDF_PAIR_FOLD_FWD=0: the per-layer kernel, for A/B and tests.)
+        fold_fwd = fold and os.environ.get("RSDF_PAIR_FOLD_FWD", "1") != "0"
         for p in range(nh // 2):
             last = p == nh // 2 - 1
             out_img = None if last else torch.empty(img_bytes, dtype=torch.uint8, device=dev)
@@ -952,8 +952,11 @@ class _MLPPairChain(torch.autograd.Function):
         if dzo is not g or dh is not None:       # (folded: only dz_out = g act'(y), [n, N2]; d h_last is formed inside the pair kernel)
             check(lib().rsdf_linear_bwd_input(ptr(g), ptr(y), N2, ptr(ws[-1]), n, 128, N2, ctx.acts[-1], 0, 128,
                                               None if dzo is g else ptr(dzo), ptr(dh), 128, st), "linear_bwd_input")
-        check(lib().rsdf_linear_bwd_weight(ptr(dzo), N2, ptr(h_last), 128, n, 128, N2, ptr(grads[-2]), ptr(grads[-1]), st),
-              "linear_bwd_weight")
+        if fold:       # dW_out rides in the top pair's kernel (it reads h_last for the ReLU mask anyway); db_out = column sums
+            grads[-1].copy_(dzo.sum(dim=0))
+        else:
+            check(lib().rsdf_linear_bwd_weight(ptr(dzo), N2, ptr(h_last), 128, n, 128, N2, ptr(grads[-2]), ptr(grads[-1]), st),
+                  "linear_bwd_weight")
         check(lib().rsdf_pair_bound_from_out_layer(ptr(dzo), n, N2, ptr(ws[-1]), ptr(bounds), st), "pair_bound")
         # ---- the pairs, top down
         need1, need2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
@@ -980,6 +983,7 @@ class _MLPPairChain(torch.autograd.Function):
             check(lib().rsdf_pair_bwd(ptr(imgs[p]), Kp, ptr(ws[2 * p]), ptr(bs[2 * p]), ptr(ws[2 * p + 1]), ptr(bs[2 * p + 1]), n,
                                       None if top_fold else ptr(gcur), masked, ptr(h_last) if masked == 0 else None,
                                       ptr(dzo) if top_fold else None, ptr(ws[-1]) if top_fold else None, N2 if top_fold else 0,
+                                      ptr(grads[-2]) if top_fold else None,
                                       ptr(bound) if masked == 0 else ctypes.c_void_p(bounds.data_ptr() + 8),
                                       win, ld, ko, relu, amax, ptr(grads[4 * p]), ptr(grads[4 * p + 1]), ptr(grads[4 * p + 2]),
                                       ptr(grads[4 * p + 3]), st), "pair_bwd")

@@ -85,8 +85,8 @@ def test_pair_chain_matches_per_layer_kernels_and_fp64(dev, K, nh, N2, n, out_ac
 
 @pytest.mark.parametrize("N2,out_act", [(6, "sigmoid"), (1, "none"), (8, "sigmoid")])
 def test_pair_forward_output_layer_fold(dev, N2, out_act, monkeypatch):
-    """RSDF_PAIR_FOLD_FWD=1: the narrow output layer computed inside the last pair's forward kernel (a deterministic sum of the
-    eight waves' partial dot products) against the per-layer kernel on the same h_last."""
+    """The narrow output layer computed inside the last pair's forward kernel (two waves, hb from its LDS image) against the
+    per-layer kernel on the same h_last (RSDF_PAIR_FOLD_FWD=0)."""
     from rise_sdf_amd import ops
     layers = _net(dev, 84, 4, N2, seed=31)
     acts = ["relu"] * 4 + [out_act]
@@ -153,7 +153,7 @@ def test_pair_backward_mask_sources_agree(dev):
         gr = [torch.zeros_like(t) for t in (wa, ba, wb, bb)]
         gin = gy * (hb > 0) if mode == "premasked" else gy
         _lib.check(L.rsdf_pair_bwd(p(img), K, p(wa), p(ba), p(wb), p(bb), n, p(gin.contiguous()), int(mode == "premasked"),
-                                   p(hb) if mode == "hb_rows" else None, None, None, 0, p(bound), p(dx), K, K, 0, None,
+                                   p(hb) if mode == "hb_rows" else None, None, None, 0, None, p(bound), p(dx), K, K, 0, None,
                                    *[p(t) for t in gr], st),
                    "pair_bwd")
         torch.cuda.synchronize()
