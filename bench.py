@@ -635,6 +635,11 @@ def run_c3(args, rank, local, world, dev):
         torch.distributed.destroy_process_group()
 
 
+def _workspace_stats():
+    from rise_sdf_amd import _lib
+    return _lib.workspace_stats()
+
+
 def _lib_status_totals(dev):
     """The sticky status counters after the run (rise_sdf_amd._lib.poll_status): forward range violations raise; backward
     launches the range guard rerouted to the range-free kernels are reported."""
@@ -770,7 +775,7 @@ def main():
                                           "and backward dynamic range guarded on the device" if args.precision == "fp32" and
                                           os.environ.get("RSDF_X2", "1") != "0" else args.precision),
                        "hash_bwd_records": "20-bit block-float pairs (8 bytes), fp64 reduction",
-                       "x2_guard": _lib_status_totals(dev),
+                       "x2_guard": _lib_status_totals(dev), "workspace_gib": _workspace_stats(),
                        "samples_per_step": samples / args.steps, "hbm_gib": hbm_watch.report(),
                        "field_evals_per_sec": 7 * samples / dt, "parallelism": f"ray-parallel x{world}"},
             "roofline": roof, "cpu_baseline": cpu, "kernel_breakdown": breakdown,

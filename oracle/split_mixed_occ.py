@@ -59,8 +59,10 @@ def render(rays, P, *, stage, indirect, relighting=False, stratified_u=None, ove
                                alpha_fn=alpha_fn_for(ro, rd))
     ri, ts, te = override.get("primary", own_primary)
     # override["sdf7"] [S,7]: the stencil VALUES of the implementation under test (oracle.volume_sdf, sdf7_given)
+    # override["alphas"] [S]: the alpha VALUES of the implementation under test (neus_geometry_render, alphas_given): in a sharp
+    # field the reference's weight backward amplifies an ulp of alpha (render_weight.cu:139-151)
     ref = neus_geometry_render(rays, ri, ts, te, P["table"], P["meta"], P["mlp"], P["var"], **field,
-                               sdf7_given=override.get("sdf7"))
+                               sdf7_given=override.get("sdf7"), alphas_given=override.get("alphas"))
     pos = ro[ri] + rd[ri] * ((ts + te) / 2.0)[:, None]
     if stage == 0:
         colors = T.texture_stage0(ref["feature"], rd[ri], ref["normal"], pos, P["nets"])

@@ -266,7 +266,16 @@ def set_timer(timer):
     _timer = timer
 
 
+_DEBUG_SYNC = os.environ.get("RSDF_DEBUG_SYNC", "")      # a file path: every entry point is logged there, then waited for
+
+
 def check(rc: int, what: str):
+    if _DEBUG_SYNC:
+        # debug aid for GPU memory faults (they abort the process from another thread, asynchronously): name the entry point
+        # BEFORE waiting for it, so that the last line of the file is the launch that faulted
+        with open(_DEBUG_SYNC, "a") as f:
+            f.write(what + "\n")
+        torch.cuda.synchronize()
     if rc != 0:
         msg = lib().rsdf_last_error()
         raise RiseSdfHipError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
@@ -329,6 +338,16 @@ def workspace_f32(tag: str, shape, device) -> "torch.Tensor":
     for d in shape:
         n *= int(d)
     return workspace(tag, 4 * n, device).view(__import__("torch").float32).view(*shape)
+
+
+def workspace_stats() -> dict:
+    """{tag: GiB held} summed over devices / streams / threads, and the arena count (bench.py reports it)."""
+    out, n = {}, 0
+    for (tag, *_), buf in _WORKSPACES.items():
+        out[tag] = round(out.get(tag, 0.0) + buf.numel() / 2.0 ** 30, 2)
+        n += 1
+    out["arenas"] = n
+    return out
 
 
 def free_workspaces():

@@ -67,7 +67,7 @@ _LAST_PACKED_TLS = _threading.local()
 def _last_packed():
     lp = getattr(_LAST_PACKED_TLS, "v", None)
     if lp is None:
-        lp = _LAST_PACKED_TLS.v = [None, None, 0, 0]      # weakref to ray_indices, packed_info, n_rays, n_samples
+        lp = _LAST_PACKED_TLS.v = [None, None, 0, 0, None]   # weakref to ray_indices, packed_info, n_rays, n_samples, stream
     return lp
 
 
@@ -75,6 +75,7 @@ def _remember_packed(ray_indices, packed, n_rays):
     import weakref
     lp = _last_packed()
     lp[0], lp[1], lp[2], lp[3] = weakref.ref(ray_indices), packed, int(n_rays), int(ray_indices.numel())
+    lp[4] = torch.cuda.current_stream(packed.device) if packed.is_cuda else None
 
 
 @torch.no_grad()
@@ -169,7 +170,15 @@ def pack_info(ray_indices, n_rays):
     ref = lp[0]
     if (ref is not None and ref() is ray_indices and lp[2] == int(n_rays) and lp[3] == int(ray_indices.numel())
             and ray_indices._version == 0):
-        return lp[1]                     # the marcher's own packed_info of this very tensor
+        # the marcher's own packed_info of this very tensor.  A consumer on ANOTHER stream (a sampling pass prefetched on a side
+        # stream, bench.py) must tell the allocator: the cache entry is the tensor's only owner, and once the next marcher call
+        # replaces it the block would be handed out again on the producing stream while this stream's kernels still read it
+        # (a GPU memory fault in a prefetching bench run: garbage offsets)
+        if lp[4] is not None:
+            cur = torch.cuda.current_stream(lp[1].device)
+            if cur != lp[4]:
+                lp[1].record_stream(cur)
+        return lp[1]
     ri = ray_indices.to(torch.int64).contiguous()
     require_device(ri)
     dev = ri.device

@@ -113,6 +113,10 @@ def _run(dev, model, rays, u, P, stage, relighting):
     # the primary stencil VALUES of the HIP path (oracle.volume_sdf, sdf7_given): removes the 1/eps amplification of forward
     # ulps, so that the gradients below are held to SURVEY 8(d)'s 1e-4 / 1e-3 instead of a cosine
     ov["sdf7"] = hip_sdf7(model, rays, *ov["primary"])
+    # ... and its alpha VALUES: these models run at inv_s = 403 (variance 0.6), where the reference's weight backward turns an
+    # ulp of alpha into O(1) of d_alpha on saturated rays (tests/test_gpu_late_regime.py); C1 itself is bit-exact on equal alphas
+    with torch.no_grad():
+        ov["alphas"] = model._alpha_fn(ro_d, rd_d)(prim[1], prim[2], prim[0]).cpu()
     ref = OS.render(rays, P, stage=stage, indirect=True, relighting=relighting, stratified_u=u, override=ov)
     assert rel_err(ov["sdf7"], ref["sdf7"]) < 3e-6                     # ... and the stencil itself agrees to fp32 rounding
     # the oracle's OWN sampling / secondary rays agree with the HIP path's up to borderline samples and fp32 depth;
