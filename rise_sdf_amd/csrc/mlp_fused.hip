@@ -197,7 +197,9 @@ __device__ __forceinline__ void fetch_tile4(float (&v)[20], const TileSrc &src, 
             src.planes + (((int64_t)(l < src.n_active ? l : 0) * 7 + tap) * src.S + s0 + 2 * (lane & 15)) * 2);
         v[4 * k] = t[0]; v[4 * k + 1] = t[1]; v[4 * k + 2] = t[2]; v[4 * k + 3] = t[3];
     }
-    const int xl = lane < 24 ? lane : lane - 24;
+    // (lanes 24 .. 63 re-read one of the 24 valid 16-byte pieces; `lane - 24` alone sent lanes 48 .. 63 up to 256 bytes past
+    // the tile, i.e. past the END of x7t on the last tap of the last full tile: tests/test_gpu_guard_pages.py)
+    const int xl = lane < 24 ? lane : (lane < 48 ? lane - 24 : lane - 48);
     const f32x4u t = *reinterpret_cast<const f32x4u *>(src.x7t + ((int64_t)tap * src.S + s0) * 3 + 4 * xl);
     v[16] = t[0]; v[17] = t[1]; v[18] = t[2]; v[19] = t[3];
 }

@@ -103,15 +103,6 @@ class _SdfFieldFD7(torch.autograd.Function):
         if x2 is not None:
             pass
         elif points is not None:
-            if os.environ.get("RSDF_DEBUG_PTRS") == "1":
-                import sys
-                torch.cuda.synchronize()
-                print("before rsdf_hashgrid_fwd_fd7_pts", dict(S=S, Lv=Lv, n_active=n_active, radius=radius, eps=eps),
-                      "pts", hex(pts.data_ptr()), pts.shape, "finite", bool(torch.isfinite(pts).all()),
-                      "min", float(pts.min()), "max", float(pts.max()), "table", hex(tb.data_ptr()), tb.numel(),
-                      "planes", hex(planes.data_ptr()), planes.numel(),
-                      "meta", [int(meta.res[i]) for i in range(Lv)], [int(meta.size[i]) for i in range(Lv)],
-                      [int(meta.offset[i]) for i in range(Lv)], file=sys.stderr, flush=True)
             # the hash kernels derive the stencil from the world-space centres (12 instead of 84 bytes per sample and
             # level); x7t still feeds the xyz columns of the MLP kernels, which read it once
             check(lib().rsdf_hashgrid_fwd_fd7_pts(ptr(pts), float(radius), float(eps), ptr(tb), ctypes.byref(meta), S,
@@ -128,14 +119,12 @@ class _SdfFieldFD7(torch.autograd.Function):
             check(lib().rsdf_sdfmlp_fd7_fwd_x2(ptr(x2), parts, Lv, H, N2, *[ptr(t) for t in ws], S, ptr(sdf7t), ptr(feature),
                                                ptr(h2c), ptr(L.status(dev)), st), "sdfmlp_fd7_fwd_x2")
         else:
-            if os.environ.get("RSDF_DEBUG_PTRS") == "1":      # (debug aid: which buffer does a fault address fall behind?)
-                import sys
-                torch.cuda.synchronize()
-                print("rsdf_sdfmlp_fd7_fwd", dict(S=S, Lv=Lv, n_active=n_active, H=H, N2=N2, want_feature=bool(want_feature)),
-                      {n: (hex(t.data_ptr()), t.numel() * t.element_size(), hex(t.data_ptr() + t.numel() * t.element_size()))
-                       for n, t in dict(xf=xf, planes=planes, sdf7t=sdf7t, w0=ws[0], b0=ws[1], w1=ws[2], b1=ws[3], w2=ws[4],
-                                        b2=ws[5]).items()},
-                      "finite", bool(torch.isfinite(xf).all()), bool(torch.isfinite(planes).all()), file=sys.stderr, flush=True)
+            if L._DEBUG_SYNC:           # (debug aid: the arguments of the launch that a fault is about to be pinned on)
+                with open(L._DEBUG_SYNC, "a") as f:
+                    f.write(f"  sdfmlp_fd7_fwd args: S={S} Lv={Lv} n_active={n_active} H={H} N2={N2} feature={want_feature} "
+                            f"xf={tuple(xf.shape)}@{xf.data_ptr():#x} planes={tuple(planes.shape)}@{planes.data_ptr():#x} "
+                            f"pts={None if pts is None else tuple(pts.shape)} ws={[tuple(t.shape) for t in ws]} "
+                            f"ws_ptr={[hex(t.data_ptr()) for t in ws]}\n")
             check(L.mlp_fn("rsdf_sdfmlp_fd7_fwd", precision)(ptr(xf), ptr(planes), Lv, n_active, float(xyz_scale),
                                             float(xyz_offset), H, N2, *[ptr(t) for t in ws], S, ptr(sdf7t),
                                             ptr(feature), ptr(h2c), st), "sdfmlp_fd7_fwd")

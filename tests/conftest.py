@@ -11,6 +11,14 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    if os.environ.get("RSDF_GUARD_ALLOC") == "1":
+        # every device allocation of this run ends flush against an unmapped page (tests/guard_alloc.cpp): an access past
+        # the end of ANY tensor faults on the spot instead of landing in the caching allocator's neighbouring block
+        import torch
+        so = os.path.join(ROOT, "tests", "_guard_alloc.so")
+        assert os.path.exists(so), "RSDF_GUARD_ALLOC=1 needs tests/_guard_alloc.so (__graft_entry__.build())"
+        torch.cuda.memory.change_current_allocator(
+            torch.cuda.memory.CUDAPluggableAllocator(so, "guard_malloc", "guard_free"))
 
 
 @pytest.fixture(scope="session")
