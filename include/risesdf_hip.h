@@ -49,6 +49,8 @@ const char *rsdf_last_error(void);
                                           |hidden activation| < 1023), where the reference's fp32 MLP stays finite */
 #define RSDF_STATUS_X2_BWD_REROUTED 1  /* rsdf_sdfmlp_fd7_bwd_x2 launches that ran on the range-free kernels */
 #define RSDF_STATUS_X2_BWD_GUARDED 2   /* rsdf_sdfmlp_fd7_bwd_x2 launches that the range guard examined */
+#define RSDF_STATUS_PAIR_PACK_NONFINITE 3 /* of word 0's count: waves of rsdf_pair_pack / _pack2 (a network INPUT out of range) */
+#define RSDF_STATUS_PAIR_FWD_NONFINITE 4  /* of word 0's count: workgroups of rsdf_pair_fwd (a weight or hidden activation) */
 
 /* ---- M1: ray/AABB slab test ----------------------------------------------------------------
  * replaces _C.ray_aabb_intersect  (lib/nerfacc/cuda/csrc/intersection.cu:93-133, pybind.cu) and

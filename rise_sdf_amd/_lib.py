@@ -375,7 +375,7 @@ def free_workspaces():
 # by the host whenever it blocks on the device anyway (the marcher's sample count, a compaction count, the training step's
 # two sampler counts): ``poll_status`` right behind such a read costs one more 32-byte copy on an already drained stream.
 STATUS_WORDS = 8
-ST_X2_FWD_NONFINITE, ST_X2_BWD_REROUTED, ST_X2_BWD_GUARDED = 0, 1, 2
+ST_X2_FWD_NONFINITE, ST_X2_BWD_REROUTED, ST_X2_BWD_GUARDED, ST_PAIR_PACK_NONFINITE, ST_PAIR_FWD_NONFINITE = 0, 1, 2, 3, 4
 _STATUS = {}
 _STATUS_TOTALS = {"x2_bwd_rerouted": 0, "x2_bwd_guarded": 0}
 
@@ -398,12 +398,14 @@ def poll_status(device=None, raise_on_error=True) -> dict:
     reference's fp32 network (models/network_utils.py:109-157) stays finite."""
     keys = list(_STATUS) if device is None else [torch.device(device).index if torch.device(device).index is not None
                                                  else torch.cuda.current_device()]
-    bad = 0
+    bad, sites = 0, [0, 0]
     for idx in keys:
         t = _STATUS.get(idx)
         if t is not None:
-            bad += consume_status(t, t.tolist(), raise_on_error=False)["x2_fwd_nonfinite"]
-    return _status_result(bad, raise_on_error)
+            vals = t.tolist()
+            bad += consume_status(t, vals, raise_on_error=False)["x2_fwd_nonfinite"]
+            sites = [a + b for a, b in zip(sites, vals[ST_PAIR_PACK_NONFINITE:ST_PAIR_FWD_NONFINITE + 1])]
+    return _status_result(bad, raise_on_error, sites)
 
 
 def consume_status(t, vals, raise_on_error=True) -> dict:
@@ -413,13 +415,16 @@ def consume_status(t, vals, raise_on_error=True) -> dict:
         t.zero_()
     _STATUS_TOTALS["x2_bwd_rerouted"] += vals[ST_X2_BWD_REROUTED]
     _STATUS_TOTALS["x2_bwd_guarded"] += vals[ST_X2_BWD_GUARDED]
-    return _status_result(vals[ST_X2_FWD_NONFINITE], raise_on_error)
+    return _status_result(vals[ST_X2_FWD_NONFINITE], raise_on_error, vals[ST_PAIR_PACK_NONFINITE:ST_PAIR_FWD_NONFINITE + 1])
 
 
-def _status_result(bad, raise_on_error):
+def _status_result(bad, raise_on_error, sites=(0, 0)):
     if bad and raise_on_error:
+        where = (f"{bad - sites[0] - sites[1]} in the fused SDF field, {sites[0]} in the radiance networks' input pack, "
+                 f"{sites[1]} in their layer pairs")
         raise RiseSdfHipError(
-            f"kernels of the two-part fp16 (x2) number format produced non-finite outputs ({bad} tiles since the last check): "
+            f"kernels of the two-part fp16 (x2) number format produced non-finite outputs ({bad} tiles since the last check: "
+            f"{where}): "
             "an operand left the format's range -- fused SDF field (csrc/mlp_x2.hip): |hash feature| or |xyz| >= 255, "
             "|effective weight| >= 1023 or a hidden activation >= 1023; radiance-network layer pairs (csrc/mlp_pair.hip): "
             "|input|, |weight| or a hidden activation >= 1023 -- where the reference's fp32 MLPs stay finite.  Set RSDF_X2=0 "

@@ -299,7 +299,7 @@ pair_kernel(const PairArgs a)
         bar[r] = a.ba[16 * w + 4 * g + r] * T;
         bbr[r] = a.bb[16 * w + 4 * g + r] * T;
     }
-    float G2 = 1.0f, G1 = 1.0f;
+    float G2 = 1.0f, G1 = 1.0f, GZ = 1.0f;
     if (TOP) {
         for (int e = threadIdx.x; e < 2 * DZO_PART / 4; e += NTHR) reinterpret_cast<unsigned *>(smem + DZO)[e] = 0u;
     }
@@ -326,11 +326,16 @@ pair_kernel(const PairArgs a)
         const float bound2 = __uint_as_float(a.bound[0]);
         G2 = grad_scale(bound2);
         G1 = grad_scale(fmaxf(s_red[0], s_red[1]) * bound2);
+        // the dz_out image of the folded dW_out product has its OWN scale, from max|dz_out| (bound[1], written next to bound[0] by
+        // rsdf_pair_bound_from_out_layer): bound[0] = max|dz_out| x (largest column sum of |W_out|) is BELOW max|dz_out| when
+        // the output weights are small (a fresh 1 x 128 roughness layer: column sums ~0.05), and dz_out x G2 then left fp16's
+        // range -- inf in the image, NaN in dW_out after one training step (the bench's c3_step, round 5)
+        if (TOP) GZ = grad_scale(__uint_as_float(a.bound[1]));
     }
     __syncthreads();
 
     f32x4 gwb[H / 16], gwa[H / 16], gbbp = {0.f, 0.f, 0.f, 0.f}, gbap = {0.f, 0.f, 0.f, 0.f};
-    f32x4 gwo = {0.f, 0.f, 0.f, 0.f};             // folded output layer: G2 SA dW_out[4 g + r][16 w + c16]
+    f32x4 gwo = {0.f, 0.f, 0.f, 0.f};             // folded output layer: GZ SA dW_out[4 g + r][16 w + c16]
     if (BWD) {
 #pragma unroll
         for (int n = 0; n < H / 16; ++n) gwb[n] = gwa[n] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -362,9 +367,9 @@ pair_kernel(const PairArgs a)
                     for (int q = 0; q < 8; ++q) {
                         if (q < a.n_out) {
                             const float dq = row_ok[rh] ? a.dz_out[rowc * a.n_out + q] : 0.0f;
-                            if (a.dw_out != nullptr && ws == 0 && g == 0) {    // dz_out as a 16-column image (x G2: |dz_out| <= bound)
+                            if (a.dw_out != nullptr && ws == 0 && g == 0) {    // dz_out as a 16-column image (x GZ)
                                 unsigned hh, ll;
-                                split2_pair(dq * G2, 0.0f, hh, ll);
+                                split2_pair(dq * GZ, 0.0f, hh, ll);
                                 pz[q] = (unsigned short)(hh & 0xffffu);
                                 pz[DZO_PART / 2 + q] = (unsigned short)(ll & 0xffffu);
                             }
@@ -548,8 +553,10 @@ pair_kernel(const PairArgs a)
     }
 
     if (!BWD) {
-        if (__builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0 && a.status != nullptr)
+        if (__builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0 && a.status != nullptr) {
             atomicAdd(&a.status[RSDF_STATUS_X2_FWD_NONFINITE], 1);
+            atomicAdd(&a.status[RSDF_STATUS_PAIR_FWD_NONFINITE], 1);
+        }
         return;
     }
     // ---- flush: gwb[n][r] = G2 SA dWb[16 w + 4 g + r][16 n + c16]; gwa[ct][r] = G1 SA dWa[..][16 ct + c16]
@@ -576,7 +583,8 @@ pair_kernel(const PairArgs a)
     if (TOP && a.dw_out != nullptr) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            if (4 * g + r < a.n_out) atomicAdd(&a.dw_out[(size_t)(4 * g + r) * H + 16 * w + c16], gwo[r] * ub);
+            if (4 * g + r < a.n_out)
+                atomicAdd(&a.dw_out[(size_t)(4 * g + r) * H + 16 * w + c16], gwo[r] * (1.0f / (GZ * SA)));
     }
     if (a.dx_absmax != nullptr) {
 #pragma unroll
@@ -613,8 +621,10 @@ pack_kernel(const float *__restrict__ x, int ld, int K1, const float *__restrict
         *reinterpret_cast<u32x4 *>(p) = f.h;
         *reinterpret_cast<u32x4 *>(p + PART) = f.l;
     }
-    if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0 && status != nullptr)
+    if (__builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0 && status != nullptr) {
         atomicAdd(&status[RSDF_STATUS_X2_FWD_NONFINITE], 1);
+        atomicAdd(&status[RSDF_STATUS_PAIR_PACK_NONFINITE], 1);
+    }
 }
 
 // the pair image -> fp32 rows [n][128] (tests; callers that need an even activation as rows)

@@ -83,6 +83,29 @@ def test_pair_chain_matches_per_layer_kernels_and_fp64(dev, K, nh, N2, n, out_ac
     print(f"   gradients vs fp64, worst tensor: {worst:.1e}")
 
 
+@pytest.mark.parametrize("N2,scale", [(1, 0.05), (1, 1e-4), (2, 0.02), (6, 2.0)])
+def test_pair_backward_output_layer_of_any_magnitude(dev, N2, scale, monkeypatch):
+    """The folded dW_out product scales its dz_out image by max|dz_out|, not by the bound on |d hb| (= max|dz_out| x the largest
+    column sum of |W_out|, BELOW max|dz_out| for small output weights): a fresh 1 x 128 roughness layer (models/texture.py:
+    316-319, torch's default Linear init: |w| <= 0.088) sent dz_out x scale past fp16 and dW_out to NaN after one step."""
+    from rise_sdf_amd import ops
+    layers = _net(dev, 84, 2, N2, seed=3)
+    with torch.no_grad():
+        layers[-1][0].mul_(scale / 0.2)
+    acts = ["relu", "relu", "sigmoid"]
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(3000, 84, generator=g).to(dev).requires_grad_(True)
+    go = torch.randn(3000, N2, generator=g).to(dev)
+    monkeypatch.setenv("RSDF_PAIR", "0")
+    ref = _run(ops, x, layers, acts, go)
+    monkeypatch.setenv("RSDF_PAIR", "1")
+    got = _run(ops, x, layers, acts, go)
+    for name, a, b in zip(["y", "dx"] + [f"{'wb'[j]}{i}" for i in range(3) for j in range(2)], [got[0], got[1]] + got[2],
+                          [ref[0], ref[1]] + ref[2]):
+        assert bool(torch.isfinite(a).all()), name
+        assert float((a - b).abs().max()) <= 3e-6 * float(b.abs().max()) + 1e-30, (name, float((a - b).abs().max()), float(b.abs().max()))
+
+
 @pytest.mark.parametrize("N2,out_act", [(6, "sigmoid"), (1, "none"), (8, "sigmoid")])
 def test_pair_forward_output_layer_fold(dev, N2, out_act, monkeypatch):
     """The narrow output layer computed inside the last pair's forward kernel (two waves, hb from its LDS image) against the
