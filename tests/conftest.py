@@ -21,6 +21,40 @@ def pytest_configure(config):
             torch.cuda.memory.CUDAPluggableAllocator(so, "guard_malloc", "guard_free"))
 
 
+def _trace_backward(path):
+    """RSDF_TRACE_BACKWARD=<file> (debug aid for GPU memory faults inside a backward pass, which abort the process from a
+    runtime thread): every autograd node of every ``Tensor.backward()`` call is named in <file> and the device drained BEFORE it
+    runs, so the last line of the file is the node whose kernels faulted (rsdf entry points: RSDF_DEBUG_SYNC)."""
+    import torch
+    orig = torch.Tensor.backward
+
+    def pre(name):
+        def hook(_grads):
+            torch.cuda.synchronize()
+            with open(path, "a") as f:
+                f.write(name + "\n")
+        return hook
+
+    def backward(self, *a, **kw):
+        seen, stack = set(), [self.grad_fn]
+        while stack:
+            n = stack.pop()
+            if n is None or n in seen:
+                continue
+            seen.add(n)
+            n.register_prehook(pre(n.name()))
+            stack += [fn for fn, _ in n.next_functions]
+        with open(path, "a") as f:
+            f.write(f"-- backward over {len(seen)} nodes\n")
+        return orig(self, *a, **kw)
+
+    torch.Tensor.backward = backward
+
+
+if os.environ.get("RSDF_TRACE_BACKWARD"):
+    _trace_backward(os.environ["RSDF_TRACE_BACKWARD"])
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

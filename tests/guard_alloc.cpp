@@ -69,7 +69,9 @@ extern "C" void *guard_malloc(ssize_t size, int device, hipStream_t)
         (e = hipMemGetAllocationGranularity(&g_gran, &prop, hipMemAllocationGranularityMinimum)) != hipSuccess)
         die("hipMemGetAllocationGranularity", e);
     Block b;
-    b.mapped = ((size_t)size + 15 + g_gran - 1) / g_gran * g_gran;
+    static const char *slack_env0 = std::getenv("RSDF_GUARD_SLACK");
+    const size_t slack0 = slack_env0 ? (size_t)std::atol(slack_env0) : 0;
+    b.mapped = ((size_t)size + slack0 + 15 + g_gran - 1) / g_gran * g_gran;
     b.reserved = b.mapped + g_gran;                     // the last granule stays reserved and unmapped: the fence
     if ((e = hipMemAddressReserve(&b.base, b.reserved, g_gran, nullptr, 0)) != hipSuccess) die("hipMemAddressReserve", e);
     hipMemGenericAllocationHandle_t h;
@@ -90,7 +92,13 @@ extern "C" void *guard_malloc(ssize_t size, int device, hipStream_t)
     acc.location = prop.location;
     acc.flags = hipMemAccessFlagsProtReadWrite;
     if ((e = hipMemSetAccess(b.base, b.mapped, &acc, 1)) != hipSuccess) die("hipMemSetAccess", e);
-    const uintptr_t end = (uintptr_t)b.base + b.mapped;
+    // RSDF_GUARD_SLACK=<bytes>: mapped bytes left behind every allocation.  torch's own IndexBackward0 (index_put_ with
+    // accumulate=True, the sort-based kernel) reads past the end of its operands (tools/debug/guard_torch_index_repro.py: pure
+    // torch, faults at slack 0), so test files whose models index with torch run with a slack that covers torch's over-read
+    // and still catch every larger one.
+    static const char *slack_env = std::getenv("RSDF_GUARD_SLACK");
+    static const size_t slack = slack_env ? (size_t)std::atol(slack_env) : 0;
+    const uintptr_t end = (uintptr_t)b.base + b.mapped - slack;
     void *p = (void *)((end - (size_t)size) & ~(uintptr_t)15);          // 16-byte aligned, flush against the fence
     g_live.emplace(p, b);
     return p;
@@ -110,7 +118,9 @@ extern "C" void guard_free(void *p, ssize_t, int, hipStream_t)
     g_live.erase(it);
     static const char *park_env = std::getenv("RSDF_GUARD_PARK");     // blocks parked before a release round (0: never release)
     static const size_t park = park_env ? (size_t)std::atol(park_env) : 512;
-    if ((park != 0 && g_parked.size() >= park) || g_parked_bytes > ((size_t)16 << 30)) {
+    static const char *gib_env = std::getenv("RSDF_GUARD_PARK_GIB");  // ... or this much parked memory (default 16 GiB)
+    static const size_t park_bytes = (size_t)(gib_env ? std::atol(gib_env) : 16) << 30;
+    if ((park != 0 && g_parked.size() >= park) || g_parked_bytes > park_bytes) {
         hipDeviceSynchronize();
         for (const Block &b : g_parked) release(b);
         g_parked.clear();
