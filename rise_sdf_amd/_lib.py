@@ -329,9 +329,16 @@ def workspace(tag: str, nbytes: int, device) -> "torch.Tensor":
     _WORKSPACE_SMALL[key] = _WORKSPACE_SMALL.get(key, 0) + 1 if small else 0
     if buf is None or buf.numel() < nbytes or _WORKSPACE_SMALL[key] >= _SHRINK_AFTER:
         _WORKSPACE_SMALL[key] = 0
-        _WORKSPACES.pop(key, None)
-        buf = None                                            # (released before the new one is requested)
-        want = int(nbytes * 1.25) + (1 << 20)
+        old = _WORKSPACES.pop(key, None)
+        big = old is not None and old.numel() >= (1 << 30)
+        old = buf = None                                      # (released before the new one is requested)
+        if big:
+            # a GiB-sized arena that is being replaced goes back to the DEVICE, not to the caching allocator's free list: no
+            # later request has its size, so the cached block would only double the footprint (rare: a few times per run)
+            torch.cuda.empty_cache()
+        # headroom for the next, slightly larger request: a quarter for small arenas, an eighth above 1 GiB (the headline's
+        # 31 GiB of hash-backward queues: 39 -> 35 GiB held)
+        want = nbytes + (nbytes // 8 if nbytes >= (1 << 30) else nbytes // 4) + (1 << 20)
         try:
             buf = torch.empty(want, dtype=torch.uint8, device=dev)
         except torch.OutOfMemoryError:
