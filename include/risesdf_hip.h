@@ -410,8 +410,10 @@ int rsdf_pair_fwd(const void *x_image, int K, const float *wa, const float *ba, 
                   float *y_out /*[n][N2], nullable: the network's narrow output layer folded in*/, int *status /*nullable*/,
                   void *stream);
 int rsdf_pair_bound_from_rows(const float *g, int64_t count, void *bound /*4 bytes*/, void *stream);
+/* db_out (nullable, N2 <= 8): the output layer's bias gradient, the column sums of dz_out, ACCUMULATED into db_out [N2] by the
+ * same pass over dz_out that finds its maximum (one torch column reduction per network and chunk less) */
 int rsdf_pair_bound_from_out_layer(const float *dz_out, int64_t n, int N2, const float *w_out /*[N2][128]*/,
-                                   void *bound /*8 bytes*/, void *stream);
+                                   void *bound /*8 bytes*/, float *db_out /*nullable*/, void *stream);
 int rsdf_pair_bwd(const void *x_image, int K, const float *wa, const float *ba, const float *wb, const float *bb, int64_t n,
                   const float *g /*nullable with dz_out*/, int g_masked, const float *hb_rows /*nullable*/,
                   const float *dz_out /*[n][N2], nullable: g = dz_out @ w_out is formed in the kernel*/,

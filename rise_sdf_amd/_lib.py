@@ -111,7 +111,7 @@ _SIGNATURES = {
     "rsdf_pair_unpack": [_P, _L, _P, _P],
     "rsdf_pair_fwd": [_P, _I, _P, _P, _P, _P, _L, _P, _P, _P, _P, _I, _I, _P, _P, _P],
     "rsdf_pair_bound_from_rows": [_P, _L, _P, _P],
-    "rsdf_pair_bound_from_out_layer": [_P, _L, _I, _P, _P, _P],
+    "rsdf_pair_bound_from_out_layer": [_P, _L, _I, _P, _P, _P, _P],
     "rsdf_pair_bwd": [_P, _I, _P, _P, _P, _P, _L, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "rsdf_sdfmlp_fd7_fwd": [_P, _P, _I, _I, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P],
     "rsdf_sdfmlp_fd7_bwd": [_P, _P, _I, _I, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P,
@@ -336,9 +336,10 @@ def workspace(tag: str, nbytes: int, device) -> "torch.Tensor":
             # a GiB-sized arena that is being replaced goes back to the DEVICE, not to the caching allocator's free list: no
             # later request has its size, so the cached block would only double the footprint (rare: a few times per run)
             torch.cuda.empty_cache()
-        # headroom for the next, slightly larger request: a quarter for small arenas, an eighth above 1 GiB (the headline's
-        # 31 GiB of hash-backward queues: 39 -> 35 GiB held)
-        want = nbytes + (nbytes // 8 if nbytes >= (1 << 30) else nbytes // 4) + (1 << 20)
+        # headroom for the next, slightly larger request: a quarter for small arenas; 1/64 above 1 GiB, where a re-request is
+        # cheap against the kernels that fill the arena and a quarter is gigabytes (the headline's 31 GiB of hash-backward
+        # queues: 39 -> 32 GiB held; the arenas reach their final size within the first rendered view)
+        want = nbytes + (nbytes // 64 if nbytes >= (1 << 30) else nbytes // 4) + (1 << 20)
         try:
             buf = torch.empty(want, dtype=torch.uint8, device=dev)
         except torch.OutOfMemoryError:

@@ -666,6 +666,42 @@ absmax_kernel(const float *__restrict__ v, int64_t n, unsigned *__restrict__ out
     if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(out, __float_as_uint(m));
 }
 
+// max |dz_out| and the column sums of dz_out [n][N2] (N2 <= 8) in one pass: a thread walks rows, a workgroup adds its sums once
+__global__ void __launch_bounds__(256)
+absmax_colsum_kernel(const float *__restrict__ v, int64_t n, int N2, unsigned *__restrict__ out, float *__restrict__ colsum)
+{
+    float m = 0.0f, s[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s[q] = 0.0f;
+    for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < n; row += (int64_t)gridDim.x * 256) {
+        const float *p = v + row * N2;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (q < N2) {
+                const float t = p[q];
+                m = fmaxf(m, fabsf(t));
+                s[q] += t;
+            }
+    }
+    __shared__ float red[4][8];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        m = fmaxf(m, __shfl_xor(m, o, 64));
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s[q] += __shfl_xor(s[q], o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (m > 0.0f) atomicMax(out, __float_as_uint(m));
+#pragma unroll
+        for (int q = 0; q < 8; ++q) red[threadIdx.x >> 6][q] = s[q];
+    }
+    __syncthreads();
+    if (threadIdx.x < N2) {
+        const int q = threadIdx.x;
+        atomicAdd(&colsum[q], (red[0][q] + red[1][q]) + (red[2][q] + red[3][q]));
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -735,13 +771,16 @@ int rsdf_pair_bound_from_rows(const float *g, int64_t count, void *bound, void *
     RSDF_RETURN_LAUNCH();
 }
 
-int rsdf_pair_bound_from_out_layer(const float *dz_out, int64_t n, int N2, const float *w_out, void *bound, void *stream)
+int rsdf_pair_bound_from_out_layer(const float *dz_out, int64_t n, int N2, const float *w_out, void *bound, float *db_out,
+                                   void *stream)
 {
     RSDF_CHECK_ARG(N2 >= 1, "pair_bound_from_out_layer: N2 must be >= 1");
+    RSDF_CHECK_ARG(db_out == nullptr || N2 <= 8, "pair_bound_from_out_layer: db_out needs N2 <= 8");
     hipStream_t st = (hipStream_t)stream;
     unsigned *b = reinterpret_cast<unsigned *>(bound);
     (void)hipMemsetAsync(b, 0, 8, st);
-    if (n > 0) absmax_kernel<<<256, 256, 0, st>>>(dz_out, n * N2, b + 1);
+    if (n > 0 && db_out != nullptr) absmax_colsum_kernel<<<256, 256, 0, st>>>(dz_out, n, N2, b + 1, db_out);
+    else if (n > 0) absmax_kernel<<<256, 256, 0, st>>>(dz_out, n * N2, b + 1);
     out_bound_kernel<<<1, 128, 0, st>>>(b + 1, w_out, N2, b);
     RSDF_RETURN_LAUNCH();
 }

@@ -961,12 +961,13 @@ class _MLPPairChain(torch.autograd.Function):
         if dzo is not g or dh is not None:       # (folded: only dz_out = g act'(y), [n, N2]; d h_last is formed inside the pair kernel)
             check(lib().rsdf_linear_bwd_input(ptr(g), ptr(y), N2, ptr(ws[-1]), n, 128, N2, ctx.acts[-1], 0, 128,
                                               None if dzo is g else ptr(dzo), ptr(dh), 128, st), "linear_bwd_input")
-        if fold:       # dW_out rides in the top pair's kernel (it reads h_last for the ReLU mask anyway); db_out = column sums
-            grads[-1].copy_(dzo.sum(dim=0))
-        else:
+        if not fold:
             check(lib().rsdf_linear_bwd_weight(ptr(dzo), N2, ptr(h_last), 128, n, 128, N2, ptr(grads[-2]), ptr(grads[-1]), st),
                   "linear_bwd_weight")
-        check(lib().rsdf_pair_bound_from_out_layer(ptr(dzo), n, N2, ptr(ws[-1]), ptr(bounds), st), "pair_bound")
+        # (folded: dW_out rides in the top pair's kernel, which reads h_last for the ReLU mask anyway, and db_out = the column
+        #  sums of dz_out come out of the pass that finds its maximum)
+        check(lib().rsdf_pair_bound_from_out_layer(ptr(dzo), n, N2, ptr(ws[-1]), ptr(bounds), ptr(grads[-1]) if fold else None,
+                                                   st), "pair_bound")
         # ---- the pairs, top down
         need1, need2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         need_dx = need1 or need2
@@ -981,10 +982,15 @@ class _MLPPairChain(torch.autograd.Function):
                 dx = torch.empty(n, 128, dtype=torch.float32, device=dev)
                 win, ld, ko, relu, amax = ptr(dx), 128, 128, 1, ctypes.c_void_p(bounds.data_ptr() + 8)
             elif need_dx:
-                dx = torch.empty(n, K, dtype=torch.float32, device=dev)
-                if k0 + kout < K:
+                # only the first source wants a gradient (the radiance networks' [feature | encoding] input: the encodings carry
+                # none): its columns as a CONTIGUOUS [n, K1] tensor -- autograd sums the three material networks' gradients of
+                # the shared feature tensor, and on a [:, :K1] view of [n, K] rows that sum (and the zero-fill of the unused
+                # columns) ran on torch's strided elementwise kernels: 190 ms of a 4.5 s config[2] step
+                Kd = K if need2 else ctx.K1
+                dx = torch.empty(n, Kd, dtype=torch.float32, device=dev)
+                if k0 + kout < Kd:
                     dx[:, k0 + kout:].zero_()
-                win, ld, ko, relu, amax = ptr(dx), K, k0 + kout, 0, None
+                win, ld, ko, relu, amax = ptr(dx), Kd, k0 + kout, 0, None
             else:
                 dx, win, ld, ko, relu, amax = None, None, 0, 0, 0, None
             # (the top pair takes its ReLU mask from the forward's own h_last rows: no hb recompute, the lean kernel variant)
@@ -1004,7 +1010,7 @@ class _MLPPairChain(torch.autograd.Function):
         K1 = ctx.K1
         d1 = dx_in[:, :K1] if (dx_in is not None and need1) else None
         d2 = dx_in[:, K1:] if (dx_in is not None and need2 and K1 < K) else None
-        if K1 == K and d1 is not None:
+        if d1 is not None and dx_in.shape[1] == K1:
             d1 = dx_in
         return (d1, d2, None, None, *grads)
 

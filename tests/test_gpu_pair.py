@@ -103,7 +103,9 @@ def test_pair_backward_output_layer_of_any_magnitude(dev, N2, scale, monkeypatch
     for name, a, b in zip(["y", "dx"] + [f"{'wb'[j]}{i}" for i in range(3) for j in range(2)], [got[0], got[1]] + got[2],
                           [ref[0], ref[1]] + ref[2]):
         assert bool(torch.isfinite(a).all()), name
-        assert float((a - b).abs().max()) <= 3e-6 * float(b.abs().max()) + 1e-30, (name, float((a - b).abs().max()), float(b.abs().max()))
+        # (y: a sigmoid of logits up to +-20 x the output scale turns 2e-7 of the largest logit into up to 1e-5 of the output)
+        tol = 1e-5 if name == "y" else 3e-6
+        assert float((a - b).abs().max()) <= tol * float(b.abs().max()) + 1e-30, (name, float((a - b).abs().max()), float(b.abs().max()))
 
 
 @pytest.mark.parametrize("N2,out_act", [(6, "sigmoid"), (1, "none"), (8, "sigmoid")])
