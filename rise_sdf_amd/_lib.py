@@ -281,9 +281,21 @@ def check(rc: int, what: str):
         raise RiseSdfHipError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
 
 
+class _Ptr(ctypes.c_void_p):
+    """A device pointer that keeps its tensor alive for as long as the pointer object lives, i.e. until the entry point it
+    is an argument of has returned (= has enqueued its kernels): ``ptr(make_scratch())`` with a temporary used to free the
+    tensor BEFORE the launch -- harmless under the caching allocator's stream-ordered reuse, a dangling pointer in
+    principle, and a GPU memory fault under the guard-page allocator of the test suite."""
+    _keep = None
+
+
 def ptr(t):
     """Device pointer of a tensor (None -> NULL)."""
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+    if t is None:
+        return None
+    p = _Ptr(t.data_ptr())
+    p._keep = t
+    return p
 
 
 def stream_ptr():

@@ -131,7 +131,8 @@ def march_capped(rays_o, rays_d, t_min, t_max, roi, binary, step_size, capacity,
     st = stream_ptr()
     check(lib().rsdf_march_count(ptr(o), ptr(d), ptr(tn), ptr(tf), ptr(r), ptr(b), rx, ry, rz, float(step_size),
                                  float(cone_angle), n, ptr(counts), st), "march_count")
-    check(lib().rsdf_pack_from_counts(ptr(counts), n, ptr(packed), ptr(total), ptr(_scan_scratch(n, dev)), st),
+    scratch = _scan_scratch(n, dev)
+    check(lib().rsdf_pack_from_counts(ptr(counts), n, ptr(packed), ptr(total), ptr(scratch), st),
           "pack_from_counts")
     cap = int(capacity)
     packed[:, 1] = torch.minimum(packed[:, 1], (cap - packed[:, 0]).clamp_(min=0))
@@ -218,8 +219,9 @@ def compact_samples(keep, ray_indices, t_starts, t_ends, count_out=None, fill_ra
         ri_o, ts_o, te_o = torch.empty_like(ri), torch.empty_like(ts), torch.empty_like(te)
     else:   # entries past the (device-side) count read as empty samples of ray ``fill_ray`` (a phantom last ray)
         ri_o, ts_o, te_o = torch.full_like(ri, int(fill_ray)), torch.zeros_like(ts), torch.zeros_like(te)
+    scratch = _scan_scratch(n, dev)          # (a named local: alive until the kernels that use it are enqueued)
     check(lib().rsdf_compact_samples(ptr(k), ptr(ri), ptr(ts), ptr(te), n, ptr(off), ptr(cnt),
-                                     ptr(_scan_scratch(n, dev)), ptr(ri_o), ptr(ts_o), ptr(te_o),
+                                     ptr(scratch), ptr(ri_o), ptr(ts_o), ptr(te_o),
                                      stream_ptr()), "compact_samples")
     if count_out is not None:          # capacity mode: the caller reads this count together with the marcher's total
         count_out.append(cnt)
