@@ -566,8 +566,8 @@ def secondary_measurements(dev, args, rays, jitter, cot):
     def c3(**kw):
         from bench_step import measure
         r = measure(dev, stage=1, steps=30, settle=80, syncs=True, **kw)
-        return {k: r[k] for k in ("ms_per_step", "rays_per_step", "samples_per_step", "samples_per_s",
-                                  "rsdf_kernel_ms_per_step", "rsdf_kernel_ms_note", "host_syncs_per_step", "sampler_stats", "top",
+        return {k: r[k] for k in ("ms_per_step", "ms_per_step_with_entry_point_events", "rays_per_step", "samples_per_step",
+                                  "samples_per_s", "rsdf_kernel_ms_per_step", "rsdf_kernel_ms_note", "host_syncs_per_step", "sampler_stats", "top",
                                   "hidden",
                                   "stage")}
     guarded("c3_step", c3)
@@ -659,10 +659,10 @@ def main():
                     help="c1 = BASELINE.json config[1] (the metric); c3 = the occupancy-pruned N-rank training step")
     ap.add_argument("--chunk", type=int, default=28672,
                     help="rays per forward/backward chunk (~5 KB of HBM scratch per sample and chunk in flight: 28672 rays = "
-                         "~87 GiB reserved with one chunk in flight)")
+                         "~89 GiB reserved with one chunk in flight)")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams the chunks of a step alternate over (run_step).  Default 1 = one chunk at a time "
-                         "(~87 GiB reserved); 2 = two chunks in flight (+1-2 %% throughput for ~173 GiB: the "
+                         "(~89 GiB reserved); 2 = two chunks in flight (+0-1 %% throughput for ~174 GiB: the "
                          "`secondary.two_streams` entry of the default run)")
     ap.add_argument("--width", type=int, default=800)
     ap.add_argument("--height", type=int, default=800)
