@@ -12,8 +12,8 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 steps = 120.0 + 3   # settle + measured (+ the sync-count step): per-step figures are approximate
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 print("kernel time per step ~ %.2f ms over %d kernels" % (tot / 1e6 / steps, len(rows)))
-for r in rows[:60]:
-    name = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")[:64]
-    print("%-66s calls/step %6.1f  avg %8.1f us  ms/step %6.3f" % (name, float(r["Calls"]) / steps, float(r["AverageNs"]) / 1e3,
+for r in rows[:70]:
+    name = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")[:150]
+    print("%-152s calls/step %6.1f  avg %8.1f us  ms/step %6.3f" % (name, float(r["Calls"]) / steps, float(r["AverageNs"]) / 1e3,
                                                               float(r["TotalDurationNs"]) / 1e6 / steps))
 PY
