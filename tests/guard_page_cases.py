@@ -79,6 +79,53 @@ def sdf_bwd(H, precision="fp32", env=None):
                 assert torch.isfinite(d_planes).all()
 
 
+def _guard_every_allocation():
+    """Installs tests/guard_alloc.cpp for this process: inputs, outputs, saved tensors and scratch of every kernel end flush
+    against an unmapped page (must run before the first device allocation)."""
+    so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_guard_alloc.so")
+    assert os.path.exists(so), "tests/_guard_alloc.so is missing (__graft_entry__.build())"
+    torch.cuda.memory.change_current_allocator(torch.cuda.memory.CUDAPluggableAllocator(so, "guard_malloc", "guard_free"))
+
+
+RAGGED_VIEWS = [(1, 1), (3, 5), (8, 8), (17, 13), (33, 31), (64, 50), (96, 67)]
+
+
+def model_c1(hidden):
+    """The c1 model (L = 16, T = 2^19, 2 x ``hidden`` SDF network: the x2 kernels, stencil gather, hash backward, alpha, C1,
+    accumulation) forward + backward on views whose ray and sample counts are not multiples of any tile size."""
+    import types
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from rise_sdf_amd.ray_utils import orbit_view_rays
+    model = bench.build_model(DEV, types.SimpleNamespace(hidden=hidden, precision="fp32"))
+    g = torch.Generator().manual_seed(3)
+    for w, h in RAGGED_VIEWS:
+        rays = orbit_view_rays(w, h, seed=w, device=DEV)
+        n = rays.shape[0]
+        u = torch.rand(n, generator=g).to(DEV)
+        for p in model.parameters():
+            p.grad = None
+        out = model.forward_(rays, stratified_u=u)
+        say(f"model_c1 H={hidden} view {w}x{h}: {n} rays, {int(out['ray_indices'].numel())} samples")
+        torch.autograd.backward([out["opacity"], out["depth"], out["comp_normal_raw"]],
+                                [torch.randn(n, 1, generator=g).to(DEV), torch.randn(n, 1, generator=g).to(DEV),
+                                 torch.randn(n, 3, generator=g).to(DEV)])
+        torch.cuda.synchronize()
+        assert all(bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.grad is not None)
+
+
+def model_c2():
+    """config[2] (split-sum model: + the layer-pair radiance networks, texture chain, environment prefilter and lookups)
+    forward + backward on ragged views, chunked so that the last chunk is a ragged tail."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench_c2
+    for w, h, chunk in [(3, 5, 16384), (17, 13, 100), (40, 30, 777)]:
+        say(f"model_c2 view {w}x{h} chunk {chunk}")
+        r = bench_c2.measure_c2(DEV, width=w, height=h, chunk=chunk, steps=1)
+        say(f"   {r['samples_per_step']:.0f} samples")
+
+
 CASES = {
     "sdf_fwd_h32": lambda: sdf_fwd(32),
     "sdf_fwd_h64": lambda: sdf_fwd(64),
@@ -89,6 +136,9 @@ CASES = {
     "sdf_bwd_h64": lambda: sdf_bwd(64),
     "sdf_bwd_h128": lambda: sdf_bwd(128),
     "sdf_bwd_h64_legacy": lambda: sdf_bwd(64, env={"RSDF_MLP_BWD": "legacy"}),
+    "model_c1_h64": lambda: model_c1(64),
+    "model_c1_h128": lambda: model_c1(128),
+    "model_c2": model_c2,
 }
 
 
@@ -97,5 +147,7 @@ if __name__ == "__main__":
     if name == "--list":
         print("\n".join(CASES))
         sys.exit(0)
+    if name.startswith("model_"):
+        _guard_every_allocation()
     CASES[name]()
     say(f"{name}: ok")

@@ -17,7 +17,7 @@ def _case_names():
     # the names only (the module imports torch and the library; listing must work without a GPU)
     import re
     src = open(os.path.join(HERE, "guard_page_cases.py")).read()
-    return re.findall(r'^    "(\w+)": lambda', src, flags=re.M)
+    return re.findall(r'^    "(\w+)": (?:lambda|\w+,)', src, flags=re.M)
 
 
 @pytest.mark.parametrize("case", _case_names())
