@@ -543,6 +543,12 @@ int rsdf_split_color0_bwd(const float *albedo6, const float *metallic2, const fl
                           float *d_spec3, void *stream);
 int rsdf_rgb_to_srgb_fwd(const float *x, int64_t n, float *y, void *stream);
 int rsdf_rgb_to_srgb_bwd(const float *x, const float *dy, int64_t n, float *dx, void *stream);
+/* H4, the analytic-gradient sweep (models/geometry.py:224-228 obtains it through autograd of the Softplus(beta=100) network,
+ * models/network_utils.py:128-134): h = softplus(z, beta = 100, threshold = 20) and slope = sigmoid(100 z) = dh/dz of n floats in
+ * one pass; backward dz = dh slope + dslope 100 slope (1 - slope) (dh / dslope nullable, not both). */
+int rsdf_softplus100_slope_fwd(const float *z, int64_t n, float *h, float *slope, void *stream);
+int rsdf_softplus100_slope_bwd(const float *slope, const float *dh /*nullable*/, const float *dslope /*nullable*/, int64_t n,
+                               float *dz, void *stream);
 /* O1, models/split_mixed_occ.py:405-436: y [n,3] = clamp(rgb_to_srgb(comp [n,3] + bg [3] * (1 - opacity [n])), 0, 1) in one
  * pass; backward writes d_comp [n,3] and d_opacity [n] (nullable).  Same values as the unfused chain. */
 int rsdf_compose_srgb_fwd(const float *comp, const float *bg, const float *opacity, int64_t n, float *y, void *stream);

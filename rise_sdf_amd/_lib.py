@@ -133,6 +133,8 @@ _SIGNATURES = {
     "rsdf_split_color0_bwd": [_P, _P, _P, _P, _L, _P, _P, _P, _P],
     "rsdf_rgb_to_srgb_fwd": [_P, _L, _P, _P],
     "rsdf_rgb_to_srgb_bwd": [_P, _P, _L, _P, _P],
+    "rsdf_softplus100_slope_fwd": [_P, _L, _P, _P, _P],
+    "rsdf_softplus100_slope_bwd": [_P, _P, _P, _L, _P, _P],
     "rsdf_compose_srgb_fwd": [_P, _P, _P, _L, _P, _P],
     "rsdf_compose_srgb_bwd": [_P, _P, _P, _P, _L, _P, _P, _P],
     "rsdf_split_shade1_fwd": [_P, _P, _P, _P, _P, _P, _P, _L, _P, _P],

@@ -360,6 +360,32 @@ compose_srgb_bwd_kernel(const float *__restrict__ comp, const float *__restrict_
     if (d_opacity != nullptr) d_opacity[row] = dop;
 }
 
+// H4 (models/geometry.py:224-228 through autograd; here rise_sdf_amd/geometry.py::field_with_analytic_grad): a hidden layer of the
+// analytic-gradient sweep needs the activation AND its slope, h = softplus(z, beta = 100) (torch: z for 100 z > 20, else
+// log1p(exp(100 z)) / 100) and s = sigmoid(100 z) = dh/dz.  One kernel each way instead of torch's softplus + mul + sigmoid and
+// their four backward kernels on [n, 128] rows (0.3 ms of an 18 ms training step):  dz = dh s + ds 100 s (1 - s).
+__global__ void __launch_bounds__(THREADS)
+softplus100_slope_fwd_kernel(const float *__restrict__ z, int64_t n, float *__restrict__ h, float *__restrict__ s)
+{
+    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= n) return;
+    const float bz = z[i] * 100.0f;
+    h[i] = bz > 20.0f ? z[i] : log1pf(expf(bz)) / 100.0f;
+    s[i] = 1.0f / (1.0f + expf(-bz));
+}
+
+__global__ void __launch_bounds__(THREADS)
+softplus100_slope_bwd_kernel(const float *__restrict__ s, const float *__restrict__ dh, const float *__restrict__ ds, int64_t n,
+                             float *__restrict__ dz)
+{
+    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (i >= n) return;
+    const float si = s[i];
+    float g = dh != nullptr ? dh[i] * si : 0.0f;
+    if (ds != nullptr) g += ds[i] * (100.0f * (si * (1.0f - si)));
+    dz[i] = g;
+}
+
 }  // namespace
 
 #define LAUNCH1D(kern, n, ...) kern<<<rsdf_blocks(n, THREADS), THREADS, 0, (hipStream_t)stream>>>(__VA_ARGS__)
@@ -474,6 +500,21 @@ int rsdf_rgb_to_srgb_bwd(const float *x, const float *dy, int64_t n, float *dx, 
 {
     if (n <= 0) return 0;
     LAUNCH1D(srgb_bwd_kernel, n, x, dy, n, dx);
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_softplus100_slope_fwd(const float *z, int64_t n, float *h, float *slope, void *stream)
+{
+    if (n <= 0) return 0;
+    LAUNCH1D(softplus100_slope_fwd_kernel, n, z, n, h, slope);
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_softplus100_slope_bwd(const float *slope, const float *dh, const float *dslope, int64_t n, float *dz, void *stream)
+{
+    RSDF_CHECK_ARG(dh != nullptr || dslope != nullptr, "softplus100_slope_bwd: both gradients are NULL");
+    if (n <= 0) return 0;
+    LAUNCH1D(softplus100_slope_bwd_kernel, n, slope, dh, dslope, n, dz);
     RSDF_RETURN_LAUNCH();
 }
 

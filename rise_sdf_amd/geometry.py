@@ -112,6 +112,10 @@ class VolumeSDF(BaseModel):
         from . import fused
         x7t, pts = ops.fd_points(rays_o, rays_d, ray_indices, t_starts, t_ends, self.radius,
                                  self._finite_difference_eps, want_positions=True, tap_major=True)
+        # the sample midpoints o + d (t0 + t1) / 2, formed by the kernel exactly as the reference's torch expression forms
+        # them (models/split_mixed_occ.py:256-257): the caller's texture / curvature query takes them from here instead of
+        # five more elementwise kernels (positions carry no graph under finite-difference normals)
+        self._last_points = (ray_indices, pts)
         grid, n_active = self.encoding._hash()
         return fused.sdf_field_fd7(
             x7t, grid.params, self.network.effective_weights(), grid.meta,
@@ -119,6 +123,12 @@ class VolumeSDF(BaseModel):
             self.encoding.xyz_offset, self._eps_unit(), want_feature,
             points=pts, radius=self.radius, eps=self._finite_difference_eps,
             precision=getattr(self.network, "precision", "fp32"))
+
+    def last_points(self, ray_indices):
+        """The world-space midpoints of the samples of the last ``sdf7_from_rays(…, ray_indices, …)`` call, or None when the
+        last call was for another sample set (identity of the index tensor, not its values)."""
+        lp = getattr(self, "_last_points", None)
+        return lp[1] if lp is not None and lp[0] is ray_indices else None
 
     def _eps_unit(self):
         return self._finite_difference_eps / (2.0 * self.radius)
@@ -141,7 +151,10 @@ class VolumeSDF(BaseModel):
         slopes = []
         for w, b in wb[:-1]:
             z = ops.linear(h, w, b, act="none", precision=net.precision)
-            if net.hidden_act == "softplus100":
+            if net.hidden_act == "softplus100" and z.is_cuda and z.dtype == torch.float32:
+                from .texture_ops import softplus100_slope
+                h, sl = softplus100_slope(z)          # (one kernel each way for activation + slope and their backward)
+            elif net.hidden_act == "softplus100":
                 h, sl = F.softplus(z, beta=100), torch.sigmoid(100.0 * z)
             else:
                 h, sl = F.relu(z), (z > 0).to(z.dtype)

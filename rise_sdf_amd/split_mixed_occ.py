@@ -159,7 +159,9 @@ class SplitMixedOCCModel(BaseModel):
             sdf, sdf_grad, normal, alphas, feature = self._stencil(rays_o, rays_d, ray_indices, t_starts,
                                                                    t_ends, True)
             t_dirs = rays_d[ray_indices]
-            positions = rays_o[ray_indices] + t_dirs * (t_starts + t_ends)[..., None] / 2.0
+            positions = self.geometry.last_points(ray_indices) if hasattr(self.geometry, "last_points") else None
+            if positions is None:      # (the stencil kernels' own midpoints are these values bit for bit: geometry.sdf7_from_rays)
+                positions = rays_o[ray_indices] + t_dirs * (t_starts + t_ends)[..., None] / 2.0
             colors = self.texture(feature, t_dirs, normal, positions, self.emitter, self.stage)
             if has_laplace:
                 return colors, normal, alphas, sdf, sdf_grad, self.geometry.curvature(positions, sdf_grad,

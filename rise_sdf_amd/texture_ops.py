@@ -133,6 +133,38 @@ def rgb_to_srgb(x):
     return _Srgb.apply(x)
 
 
+class _Softplus100Slope(torch.autograd.Function):
+    """z -> (softplus(z, beta=100), sigmoid(100 z)) in one kernel each way (rise_sdf_amd/geometry.py, the analytic-gradient
+    sweep: the slope is the activation's derivative, and both are trained through)."""
+
+    @staticmethod
+    def forward(ctx, z):
+        zf = _f(z)
+        require_device(zf)
+        h, s = torch.empty_like(zf), torch.empty_like(zf)
+        check(lib().rsdf_softplus100_slope_fwd(ptr(zf), zf.numel(), ptr(h), ptr(s), stream_ptr()), "softplus100_slope_fwd")
+        ctx.save_for_backward(s)
+        ctx.set_materialize_grads(False)
+        return h, s
+
+    @staticmethod
+    def backward(ctx, gh, gs):
+        if gh is None and gs is None:
+            return None
+        (s,) = ctx.saved_tensors
+        gh = None if gh is None else _f(gh)
+        gs = None if gs is None else _f(gs)
+        dz = torch.empty_like(s)
+        check(lib().rsdf_softplus100_slope_bwd(ptr(s), ptr(gh), ptr(gs), s.numel(), ptr(dz), stream_ptr()),
+              "softplus100_slope_bwd")
+        return dz
+
+
+def softplus100_slope(z):
+    """-> (F.softplus(z, beta=100), torch.sigmoid(100 * z)), same values, one kernel each way."""
+    return _Softplus100Slope.apply(z)
+
+
 class _ComposeSrgb(torch.autograd.Function):
     @staticmethod
     def forward(ctx, comp, bg, opacity):

@@ -139,3 +139,30 @@ def test_volume_sdf_analytic_grad_type(dev):
     sdf, grad, feat = model.geometry(pts, with_grad=True, with_feature=True)
     ((grad.norm(dim=-1) - 1.0) ** 2).mean().backward()
     assert model.geometry.network.layers[0].weight_v.grad is not None
+
+
+def test_softplus100_with_slope_is_torchs_pair(dev):
+    """rise_sdf_amd/geometry.py's analytic sweep takes (softplus(z, beta=100), sigmoid(100 z)) from one kernel each way:
+    values equal torch's two ops to an ulp (same libm calls), gradients of both outputs to 1e-6 -- over the threshold at
+    100 z = 20, the saturated tails and zero."""
+    import torch.nn.functional as F
+    from rise_sdf_amd.texture_ops import softplus100_slope
+    g = torch.Generator().manual_seed(0)
+    z = torch.cat([torch.randn(4099, generator=g) * 0.05, torch.tensor([0.0, 0.2, 0.2000001, 0.3, -0.3, 5.0, -5.0, 1e-8])])
+    z = z.to(dev).reshape(-1, 1).repeat(1, 3).contiguous()
+    gh, gs = torch.randn(z.shape, generator=g).to(dev), torch.randn(z.shape, generator=g).to(dev)
+    za = z.clone().requires_grad_(True)
+    h, s = softplus100_slope(za)
+    (h * gh + s * gs).sum().backward()
+    zb = z.clone().requires_grad_(True)
+    h_t, s_t = F.softplus(zb, beta=100), torch.sigmoid(100.0 * zb)
+    (h_t * gh + s_t * gs).sum().backward()
+    assert float((h - h_t).abs().max()) <= 2e-7 * float(h_t.abs().max())
+    assert float((s - s_t).abs().max()) <= 2e-7
+    assert float((za.grad - zb.grad).abs().max()) <= 2e-6 * float(zb.grad.abs().max())
+    # one of the two outputs unused downstream
+    zc = z.clone().requires_grad_(True)
+    (softplus100_slope(zc)[0] * gh).sum().backward()
+    zd = z.clone().requires_grad_(True)
+    (F.softplus(zd, beta=100) * gh).sum().backward()
+    assert float((zc.grad - zd.grad).abs().max()) <= 2e-6 * float(zd.grad.abs().max())
