@@ -78,6 +78,19 @@ int rsdf_march_write(const float *rays_o, const float *rays_d, const float *t_mi
                      int res_y, int res_z, float step_size, float cone_angle, int64_t n_rays,
                      const int32_t *packed_info, int64_t *ray_indices, float *t_starts,
                      float *t_ends, void *stream);
+/* STAGED form of the same two passes (ray_marching.cu:257-289 marches every ray twice; a pass is bound by the serial
+ * recurrence, not by its stores): the count pass also parks each ray's (t0, t1) pairs in a slot of ``stride`` samples
+ * (stage_t0 / stage_t1: float [n_rays][stride]); the write pass copies the rays whose count fits their slot and marches the
+ * others again.  Same samples, same values, same order as rsdf_march_count + rsdf_march_write for every stride >= 1. */
+int rsdf_march_count_staged(const float *rays_o, const float *rays_d, const float *t_min, const float *t_max,
+                            const float *roi, const uint8_t *binary, int res_x, int res_y, int res_z, float step_size,
+                            float cone_angle, int64_t n_rays, int32_t *num_steps, int64_t stride, float *stage_t0,
+                            float *stage_t1, void *stream);
+int rsdf_march_write_staged(const float *rays_o, const float *rays_d, const float *t_min, const float *t_max,
+                            const float *roi, const uint8_t *binary, int res_x, int res_y, int res_z, float step_size,
+                            float cone_angle, int64_t n_rays, const int32_t *packed_info, const int32_t *num_steps,
+                            int64_t stride, const float *stage_t0, const float *stage_t1, int64_t *ray_indices,
+                            float *t_starts, float *t_ends, void *stream);
 /* replaces _C.query_occ (ray_marching.cu:295-358); cell (nullable) gets the linear cell index,
  * -1 outside the box. */
 int rsdf_query_occ(const float *samples, const float *roi, const uint8_t *binary, int res_x,

@@ -48,6 +48,8 @@ _SIGNATURES = {
     "rsdf_scan_scratch_bytes": [_L],
     "rsdf_pack_from_counts": [_P, _L, _P, _P, _P, _P],
     "rsdf_march_write": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _L, _P, _P, _P, _P, _P],
+    "rsdf_march_count_staged": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _L, _P, _L, _P, _P, _P],
+    "rsdf_march_write_staged": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _L, _P, _P, _L, _P, _P, _P, _P, _P, _P],
     "rsdf_query_occ": [_P, _P, _P, _I, _I, _I, _L, _P, _P, _P],
     "rsdf_counts_from_ray_indices": [_P, _L, _L, _P, _P],
     "rsdf_unpack_info": [_P, _L, _P, _P],

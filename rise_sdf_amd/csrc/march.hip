@@ -336,6 +336,18 @@ namespace {
 // step at the reference's 4096-ray chunks); round 3's first cut (8 speculative steps per thread) 0.24.
 constexpr int MARCH_THREADS = 256;     // four rays per workgroup
 
+// STAGED marching (round 5): the reference's two passes march every ray TWICE (count, then write: ray_marching.cu:257-289), and
+// a pass is bound by the serial recurrence, not by its stores (0.37 + 0.83 ms per 28672-ray chunk, 2 x 0.21 ms per 4096-ray
+// training batch).  With ``stage`` the COUNT pass also parks each ray's (t0, t1) pairs in a per-ray slot of ``stride`` samples;
+// the WRITE pass of a ray whose count fits its slot is then a coalesced copy into the packed arrays -- the same values, produced
+// by the same instruction sequence, once.  A ray with more samples than its slot (the caller's stride is a hint, not a
+// bound) is marched again as before.
+struct MarchStage {
+    float *t0, *t1;          // [n_rays][stride] each (nullptr: plain two-pass marching)
+    int64_t stride;
+    const int32_t *counts;   // WRITE pass: the count pass's per-ray sample counts
+};
+
 template <bool WRITE>
 __global__ void __launch_bounds__(MARCH_THREADS)
 march_entry(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
@@ -343,12 +355,26 @@ march_entry(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
             float step_size, float cone_angle, int64_t n_rays,
             const int32_t *__restrict__ packed_info, int32_t *__restrict__ num_steps,
             int64_t *__restrict__ ray_indices, float *__restrict__ t_starts,
-            float *__restrict__ t_ends)
+            float *__restrict__ t_ends, const MarchStage stage)
 {
     const Grid g = load_grid(gd);
     const int64_t i = ((int64_t)blockIdx.x * MARCH_THREADS + threadIdx.x) >> 6;     // ray = wavefront
     if (i >= n_rays) return;                                                        // (wave-uniform)
     const int lane = lane_id();
+    if (WRITE && stage.t0 != nullptr && (int64_t)stage.counts[i] <= stage.stride) {
+        // every sample of this ray is parked: copy (at most packed_info's clamped count of them)
+        const int64_t base = packed_info[2 * i];
+        const int limit = packed_info[2 * i + 1];
+        const float *p0 = stage.t0 + i * stage.stride, *p1 = stage.t1 + i * stage.stride;
+        for (int k = lane; k < limit; k += 64) {
+            t_starts[base + k] = p0[k];
+            t_ends[base + k] = p1[k];
+            ray_indices[base + k] = i;
+        }
+        return;
+    }
+    float *const s0 = (!WRITE && stage.t0 != nullptr) ? stage.t0 + i * stage.stride : nullptr;
+    float *const s1 = (!WRITE && stage.t0 != nullptr) ? stage.t1 + i * stage.stride : nullptr;
     const float ox = rays_o[3 * i], oy = rays_o[3 * i + 1], oz = rays_o[3 * i + 2];
     const float dx = rays_d[3 * i], dy = rays_d[3 * i + 1], dz = rays_d[3 * i + 2];
     const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
@@ -389,6 +415,10 @@ march_entry(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
             t_starts[base + j + lane] = l0;
             t_ends[base + j + lane] = l1;
             ray_indices[base + j + lane] = i;
+        }
+        if (!WRITE && s0 != nullptr && lane < m && (int64_t)(j + lane) < stage.stride) {
+            s0[j + lane] = l0;
+            s1[j + lane] = l1;
         }
         j += m;
         if (m > 0) {   // the ray's state after m occupied steps = the successor of lane m - 1's state
@@ -445,7 +475,23 @@ int rsdf_march_count(const float *rays_o, const float *rays_d, const float *t_mi
     GridDev gd{roi, {res_x, res_y, res_z}, binary};
     march_entry<false><<<rsdf_blocks(n_rays * 64, MARCH_THREADS), MARCH_THREADS, 0, (hipStream_t)stream>>>(
         rays_o, rays_d, t_min, t_max, gd, step_size, cone_angle, n_rays, nullptr, num_steps, nullptr,
-        nullptr, nullptr);
+        nullptr, nullptr, MarchStage{nullptr, nullptr, 0, nullptr});
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_march_count_staged(const float *rays_o, const float *rays_d, const float *t_min, const float *t_max,
+                            const float *roi, const uint8_t *binary, int res_x, int res_y, int res_z, float step_size,
+                            float cone_angle, int64_t n_rays, int32_t *num_steps, int64_t stride, float *stage_t0,
+                            float *stage_t1, void *stream)
+{
+    RSDF_CHECK_ARG(res_x > 0 && res_y > 0 && res_z > 0, "march_count_staged: bad grid resolution");
+    RSDF_CHECK_ARG(step_size > 0.f, "march_count_staged: step_size must be > 0");
+    RSDF_CHECK_ARG(stride >= 1 && stage_t0 != nullptr && stage_t1 != nullptr, "march_count_staged: bad staging buffers");
+    if (n_rays <= 0) return 0;
+    GridDev gd{roi, {res_x, res_y, res_z}, binary};
+    march_entry<false><<<rsdf_blocks(n_rays * 64, MARCH_THREADS), MARCH_THREADS, 0, (hipStream_t)stream>>>(
+        rays_o, rays_d, t_min, t_max, gd, step_size, cone_angle, n_rays, nullptr, num_steps, nullptr, nullptr, nullptr,
+        MarchStage{stage_t0, stage_t1, stride, nullptr});
     RSDF_RETURN_LAUNCH();
 }
 
@@ -461,7 +507,25 @@ int rsdf_march_write(const float *rays_o, const float *rays_d, const float *t_mi
     GridDev gd{roi, {res_x, res_y, res_z}, binary};
     march_entry<true><<<rsdf_blocks(n_rays * 64, MARCH_THREADS), MARCH_THREADS, 0, (hipStream_t)stream>>>(
         rays_o, rays_d, t_min, t_max, gd, step_size, cone_angle, n_rays, packed_info, nullptr,
-        ray_indices, t_starts, t_ends);
+        ray_indices, t_starts, t_ends, MarchStage{nullptr, nullptr, 0, nullptr});
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_march_write_staged(const float *rays_o, const float *rays_d, const float *t_min, const float *t_max,
+                            const float *roi, const uint8_t *binary, int res_x, int res_y, int res_z, float step_size,
+                            float cone_angle, int64_t n_rays, const int32_t *packed_info, const int32_t *num_steps,
+                            int64_t stride, const float *stage_t0, const float *stage_t1, int64_t *ray_indices,
+                            float *t_starts, float *t_ends, void *stream)
+{
+    RSDF_CHECK_ARG(res_x > 0 && res_y > 0 && res_z > 0, "march_write_staged: bad grid resolution");
+    RSDF_CHECK_ARG(step_size > 0.f, "march_write_staged: step_size must be > 0");
+    RSDF_CHECK_ARG(stride >= 1 && stage_t0 != nullptr && stage_t1 != nullptr && num_steps != nullptr,
+                   "march_write_staged: bad staging buffers");
+    if (n_rays <= 0) return 0;
+    GridDev gd{roi, {res_x, res_y, res_z}, binary};
+    march_entry<true><<<rsdf_blocks(n_rays * 64, MARCH_THREADS), MARCH_THREADS, 0, (hipStream_t)stream>>>(
+        rays_o, rays_d, t_min, t_max, gd, step_size, cone_angle, n_rays, packed_info, nullptr, ray_indices, t_starts, t_ends,
+        MarchStage{const_cast<float *>(stage_t0), const_cast<float *>(stage_t1), stride, num_steps});
     RSDF_RETURN_LAUNCH();
 }
 

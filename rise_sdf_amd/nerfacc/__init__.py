@@ -240,6 +240,9 @@ class OccGridEstimator(nn.Module):
         self.cells_per_lvl = int(resolution.prod().item())
         self.register_buffer("resolution", resolution)
         self.register_buffer("aabbs", roi_aabb[None, :].clone())
+        # the ROI's diagonal, known on the host: the longest [t_min, t_max) of a unit-direction ray, which sizes the staged
+        # marcher's per-ray slots (ops.march; a performance hint -- rays that need more are marched twice, as the reference)
+        self._t_range_hint = float((roi_aabb[3:] - roi_aabb[:3]).norm())
         self.register_buffer("occs", torch.zeros(self.cells_per_lvl))
         self.register_buffer("binaries", torch.zeros([1] + resolution.tolist(), dtype=torch.bool))
         self.register_buffer("grid_coords", _meshgrid3d(resolution).reshape(self.cells_per_lvl, 3),
@@ -287,7 +290,7 @@ class OccGridEstimator(nn.Module):
                 return out
         packed_info, ray_indices, t_starts, t_ends = ops.march(
             rays_o, rays_d, t_min, t_max, self.aabbs[0], self.binaries[0], render_step_size,
-            cone_angle)
+            cone_angle, t_range_hint=self._t_range_hint)
         if self.capacity_mode:
             if self._pending:        # (an exact call -- first step, or after an overflow -- settles them with a read of its own)
                 vals = torch.cat([p[2] for p in self._pending]).tolist()
@@ -326,7 +329,7 @@ class OccGridEstimator(nn.Module):
         if cap is None:
             return None
         packed, ri, ts, te, total = ops.march_capped(rays_o, rays_d, t_min, t_max, self.aabbs[0], self.binaries[0],
-                                                     render_step_size, cap, cone_angle)
+                                                     render_step_size, cap, cone_angle, t_range_hint=self._t_range_hint)
         alphas = alpha_fn(ts, te, ri)
         keep = render_visibility(alphas, packed_info=packed, early_stop_eps=early_stop_eps, alpha_thre=alpha_thre,
                                  zero_init=True)
@@ -378,7 +381,7 @@ class OccGridEstimator(nn.Module):
         if n_rays > n_meas + max(8, n_meas // 20):      # (the caller's phantom ray alone is not "more rays")
             cap = int(cap * (n_rays / max(n_meas, 1))) + 4096
         packed, ri, ts, te, total = ops.march_capped(rays_o, rays_d, t_min, t_max, self.aabbs[0], self.binaries[0],
-                                                     render_step_size, cap, 0.0)
+                                                     render_step_size, cap, 0.0, t_range_hint=self._t_range_hint)
         alphas = alpha_fn(ts, te, ri)
         keep = render_visibility(alphas, packed_info=packed, early_stop_eps=early_stop_eps, alpha_thre=alpha_thre,
                                  zero_init=True)

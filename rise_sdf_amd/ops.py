@@ -78,25 +78,65 @@ def _remember_packed(ray_indices, packed, n_rays):
     lp[4] = torch.cuda.current_stream(packed.device) if packed.is_cuda else None
 
 
+_STAGE_BYTES_MAX = 2 << 30      # staging slots beyond this (n_rays x stride x 8 bytes) are not worth their footprint
+
+
+def _march_stage(n, t_range_hint, step_size, dev):
+    """-> (stride, t0 slots, t1 slots) for the staged marcher, or (0, None, None): the per-ray slot holds every step a ray
+    can take over ``t_range_hint`` (the caller's bound on t_max - t_min: the ROI's diagonal for unit directions); a ray that
+    takes more is marched twice as before, so the hint is a performance parameter, not a correctness one.  RSDF_MARCH=two_pass
+    keeps the reference's two marching passes (A/B, tests)."""
+    if t_range_hint is None or n == 0 or os.environ.get("RSDF_MARCH") == "two_pass":
+        return 0, None, None
+    stride = int(float(t_range_hint) / float(step_size)) + 4
+    if stride < 1 or n * stride * 8 > _STAGE_BYTES_MAX:
+        return 0, None, None
+    buf = L.workspace("march.stage", n * stride * 8, dev).view(torch.float32)
+    return stride, buf[:n * stride], buf[n * stride:]
+
+
+def _march_count(o, d, tn, tf, r, b, step_size, cone_angle, counts, stage, st):
+    rx, ry, rz = b.shape
+    n = o.shape[0]
+    if stage[0]:
+        check(lib().rsdf_march_count_staged(ptr(o), ptr(d), ptr(tn), ptr(tf), ptr(r), ptr(b), rx, ry, rz, float(step_size),
+                                            float(cone_angle), n, ptr(counts), stage[0], ptr(stage[1]), ptr(stage[2]), st),
+              "march_count_staged")
+    else:
+        check(lib().rsdf_march_count(ptr(o), ptr(d), ptr(tn), ptr(tf), ptr(r), ptr(b), rx, ry, rz, float(step_size),
+                                     float(cone_angle), n, ptr(counts), st), "march_count")
+
+
+def _march_write(o, d, tn, tf, r, b, step_size, cone_angle, packed, counts, stage, ri, ts, te, st):
+    rx, ry, rz = b.shape
+    n = o.shape[0]
+    if stage[0]:
+        check(lib().rsdf_march_write_staged(ptr(o), ptr(d), ptr(tn), ptr(tf), ptr(r), ptr(b), rx, ry, rz, float(step_size),
+                                            float(cone_angle), n, ptr(packed), ptr(counts), stage[0], ptr(stage[1]),
+                                            ptr(stage[2]), ptr(ri), ptr(ts), ptr(te), st), "march_write_staged")
+    else:
+        check(lib().rsdf_march_write(ptr(o), ptr(d), ptr(tn), ptr(tf), ptr(r), ptr(b), rx, ry, rz, float(step_size),
+                                     float(cone_angle), n, ptr(packed), ptr(ri), ptr(ts), ptr(te), st), "march_write")
+
+
 @torch.no_grad()
-def march(rays_o, rays_d, t_min, t_max, roi, binary, step_size, cone_angle=0.0):
+def march(rays_o, rays_d, t_min, t_max, roi, binary, step_size, cone_angle=0.0, t_range_hint=None):
     """The two-pass marcher of lib/nerfacc/cuda/csrc/ray_marching.cu:194-289.
     Returns packed_info int32 [N,2], ray_indices int64 [S], t_starts [S], t_ends [S].
-    One host read-back of the sample total, as in the reference (:261)."""
+    One host read-back of the sample total, as in the reference (:261).  ``t_range_hint`` (a host float >= t_max - t_min of
+    the typical ray): the rays are marched ONCE, the count pass parks their samples for the write pass (_march_stage)."""
     o, d, tn, tf, r = _f32c(rays_o), _f32c(rays_d), _f32c(t_min), _f32c(t_max), _f32c(roi)
     b = _u8(binary)
     require_device(o, d, tn, tf, r, b)
     assert b.dim() == 3, "grid_binary must be [res_x, res_y, res_z]"
     n = o.shape[0]
     dev = o.device
-    rx, ry, rz = b.shape
     counts = torch.empty(n, dtype=torch.int32, device=dev)
     packed = torch.empty(n, 2, dtype=torch.int32, device=dev)
     total = torch.zeros(1, dtype=torch.int32, device=dev)
     st = stream_ptr()
-    check(lib().rsdf_march_count(ptr(o), ptr(d), ptr(tn), ptr(tf), ptr(r), ptr(b), rx, ry, rz,
-                                 float(step_size), float(cone_angle), n, ptr(counts), st),
-          "march_count")
+    stage = _march_stage(n, t_range_hint, step_size, dev)
+    _march_count(o, d, tn, tf, r, b, step_size, cone_angle, counts, stage, st)
     scratch = _scan_scratch(n, dev)
     check(lib().rsdf_pack_from_counts(ptr(counts), n, ptr(packed), ptr(total), ptr(scratch), st),
           "pack_from_counts")
@@ -106,15 +146,13 @@ def march(rays_o, rays_d, t_min, t_max, roi, binary, step_size, cone_angle=0.0):
     ts = torch.empty(S, dtype=torch.float32, device=dev)
     te = torch.empty(S, dtype=torch.float32, device=dev)
     if S > 0:
-        check(lib().rsdf_march_write(ptr(o), ptr(d), ptr(tn), ptr(tf), ptr(r), ptr(b), rx, ry, rz,
-                                     float(step_size), float(cone_angle), n, ptr(packed), ptr(ri),
-                                     ptr(ts), ptr(te), st), "march_write")
+        _march_write(o, d, tn, tf, r, b, step_size, cone_angle, packed, counts, stage, ri, ts, te, st)
     _remember_packed(ri, packed, n)
     return packed, ri, ts, te
 
 
 @torch.no_grad()
-def march_capped(rays_o, rays_d, t_min, t_max, roi, binary, step_size, capacity, cone_angle=0.0):
+def march_capped(rays_o, rays_d, t_min, t_max, roi, binary, step_size, capacity, cone_angle=0.0, t_range_hint=None):
     """The marcher WITHOUT its host read: count -> device scan -> write into buffers of ``capacity`` samples that the
     caller sized from an earlier call.  packed_info is clamped to the capacity on the device (a ray whose samples would
     not fit keeps the ones that do), the tail of the buffers is a harmless dummy sample (ray 0, t = 0) that no ray's
@@ -124,13 +162,12 @@ def march_capped(rays_o, rays_d, t_min, t_max, roi, binary, step_size, capacity,
     b = _u8(binary)
     require_device(o, d, tn, tf, r, b)
     n, dev = o.shape[0], o.device
-    rx, ry, rz = b.shape
     counts = torch.empty(n, dtype=torch.int32, device=dev)
     packed = torch.empty(n, 2, dtype=torch.int32, device=dev)
     total = torch.zeros(1, dtype=torch.int32, device=dev)
     st = stream_ptr()
-    check(lib().rsdf_march_count(ptr(o), ptr(d), ptr(tn), ptr(tf), ptr(r), ptr(b), rx, ry, rz, float(step_size),
-                                 float(cone_angle), n, ptr(counts), st), "march_count")
+    stage = _march_stage(n, t_range_hint, step_size, dev)
+    _march_count(o, d, tn, tf, r, b, step_size, cone_angle, counts, stage, st)
     scratch = _scan_scratch(n, dev)
     check(lib().rsdf_pack_from_counts(ptr(counts), n, ptr(packed), ptr(total), ptr(scratch), st),
           "pack_from_counts")
@@ -142,8 +179,7 @@ def march_capped(rays_o, rays_d, t_min, t_max, roi, binary, step_size, capacity,
     ts = torch.zeros(cap, dtype=torch.float32, device=dev)
     te = torch.zeros(cap, dtype=torch.float32, device=dev)
     if cap > 0:
-        check(lib().rsdf_march_write(ptr(o), ptr(d), ptr(tn), ptr(tf), ptr(r), ptr(b), rx, ry, rz, float(step_size),
-                                     float(cone_angle), n, ptr(packed), ptr(ri), ptr(ts), ptr(te), st), "march_write")
+        _march_write(o, d, tn, tf, r, b, step_size, cone_angle, packed, counts, stage, ri, ts, te, st)
     return packed, ri, ts, te, total
 
 

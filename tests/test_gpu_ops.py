@@ -826,6 +826,34 @@ def test_curvature_path_uses_binned_scatter_and_matches(dev, ops, monkeypatch):
     assert float((res[0] - res[1]).abs().max()) < 2e-5 * scale
 
 
+@pytest.mark.parametrize("res,fill,step,cone", [(32, 0.3, 0.00507421875, 0.0), (16, 0.5, 0.02, 0.004), (1, 1.0, 0.00507421875, 0.0)])
+def test_staged_marcher_equals_the_two_passes(dev, ops, res, fill, step, cone):
+    """ops.march / march_capped with a ``t_range_hint`` march every ray ONCE (the count pass parks the samples, the write pass
+    copies them): same packed_info, ray_indices and (t0, t1) bit for bit as the reference-shaped two passes -- for a hint that
+    covers every ray (the ROI diagonal), one that covers only the short rays (the others are marched again) and a useless one;
+    through the capacity path with a truncating capacity too."""
+    rays = camera_rays(40, 40, seed=res + 3)
+    o, d = rays[:, :3].contiguous().to(dev), rays[:, 3:].contiguous().to(dev)
+    roi = torch.tensor([-1.5, -1.5, -1.5, 1.5, 1.5, 1.5]).to(dev)
+    g = torch.Generator().manual_seed(res)
+    binary = (torch.rand(res, res, res, generator=g) < fill).to(dev)
+    tn, tf = ops.ray_aabb_intersect(o, d, roi)
+    tn = tn + torch.rand(o.shape[0], generator=g).to(dev) * step
+    ref = ops.march(o, d, tn, tf, roi, binary, step, cone)
+    assert ref[1].numel() > 2000
+    for hint in (5.2, 1.0, 1e-3):
+        got = ops.march(o, d, tn, tf, roi, binary, step, cone, t_range_hint=hint)
+        for a, b, name in zip(got, ref, ("packed_info", "ray_indices", "t_starts", "t_ends")):
+            assert torch.equal(a, b), (name, hint)
+    total = ref[1].numel()
+    for cap in (total + 100, total // 2):
+        base = ops.march_capped(o, d, tn, tf, roi, binary, step, cap, cone)
+        for hint in (5.2, 1.0):
+            got = ops.march_capped(o, d, tn, tf, roi, binary, step, cap, cone, t_range_hint=hint)
+            for a, b, name in zip(got, base, ("packed_info", "ray_indices", "t_starts", "t_ends", "total")):
+                assert torch.equal(a, b), (name, hint, cap)
+
+
 @pytest.mark.parametrize("res,fill,step,cone", [(32, 0.3, 0.00507421875, 0.0), (64, 0.08, 0.0152631578947, 0.0),
                                                 (16, 0.5, 0.02, 0.004), (128, 0.02, 0.00507421875, 0.0)])
 def test_marcher_bit_exact_fragmented_grid(dev, ops, res, fill, step, cone):
