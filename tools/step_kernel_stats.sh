@@ -9,11 +9,12 @@ f=$(find /tmp/sks -name "*kernel_stats.csv")
 python3 - "$f" <<'PY' > ${1:-/dev/stdout}
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-steps = 120.0 + 3   # settle + measured (+ the sync-count step): per-step figures are approximate
+steps = 80.0 + 40 + 40 + 1   # settle + measured + instrumented (+ the sync-count step): per-step figures are approximate
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 print("kernel time per step ~ %.2f ms over %d kernels" % (tot / 1e6 / steps, len(rows)))
 for r in rows[:70]:
     name = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")[:150]
-    print("%-152s calls/step %6.1f  avg %8.1f us  ms/step %6.3f" % (name, float(r["Calls"]) / steps, float(r["AverageNs"]) / 1e3,
-                                                              float(r["TotalDurationNs"]) / 1e6 / steps))
+    print("%-152s calls/step %6.1f  avg %8.1f us  ms/step %6.3f  min %8.1f max %9.1f us" % (
+        name, float(r["Calls"]) / steps, float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6 / steps,
+        float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
 PY
