@@ -325,7 +325,8 @@ def stream_ptr():
 # threads enqueueing on one stream would otherwise alias each other's buffers between their kernel sequences.
 _WORKSPACES = {}
 _WORKSPACE_SMALL = {}
-_SHRINK_AFTER = 64
+_SHRINK_AFTER = int(os.environ.get("RSDF_WS_SHRINK_AFTER", "64"))
+_WORKSPACE_EVENTS = {"grown": 0, "shrunk": 0, "released_to_device": 0}
 
 
 def workspace(tag: str, nbytes: int, device) -> "torch.Tensor":
@@ -344,9 +345,12 @@ def workspace(tag: str, nbytes: int, device) -> "torch.Tensor":
     small = buf is not None and buf.numel() > (64 << 20) and nbytes < buf.numel() // 4
     _WORKSPACE_SMALL[key] = _WORKSPACE_SMALL.get(key, 0) + 1 if small else 0
     if buf is None or buf.numel() < nbytes or _WORKSPACE_SMALL[key] >= _SHRINK_AFTER:
+        if buf is not None:
+            _WORKSPACE_EVENTS["grown" if buf.numel() < nbytes else "shrunk"] += 1
         _WORKSPACE_SMALL[key] = 0
         old = _WORKSPACES.pop(key, None)
         big = old is not None and old.numel() >= (1 << 30)
+        _WORKSPACE_EVENTS["released_to_device"] += int(big)
         old = buf = None                                      # (released before the new one is requested)
         if big:
             # a GiB-sized arena that is being replaced goes back to the DEVICE, not to the caching allocator's free list: no
@@ -380,6 +384,7 @@ def workspace_stats() -> dict:
         out[tag] = round(out.get(tag, 0.0) + buf.numel() / 2.0 ** 30, 2)
         n += 1
     out["arenas"] = n
+    out.update(_WORKSPACE_EVENTS)
     return out
 
 
