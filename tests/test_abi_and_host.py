@@ -168,3 +168,33 @@ def test_ray_directions_match_reference_golden(golden_dir):
     W, H, f = int(z["W"]), int(z["H"]), float(z["focal"])
     d = get_ray_directions(W, H, f, f, W / 2, H / 2)
     assert torch.equal(d, torch.tensor(z["directions"]))
+
+
+def test_ptr_keeps_its_tensor_alive_and_status_error_names_the_site():
+    """rise_sdf_amd._lib.ptr(t): the pointer object owns a reference to ``t`` until it is dropped, i.e. until the entry point it is
+    an argument of has returned -- ``ptr(make_scratch())`` with a temporary must not free the scratch before the launch (round 5:
+    found by the guard-page allocator).  The range-guard error names where the non-finite count came from."""
+    import ctypes
+    import weakref
+    import torch
+    from rise_sdf_amd import _lib as L
+    t = torch.zeros(8)
+    w = weakref.ref(t)
+    p = L.ptr(t)
+    addr = t.data_ptr()
+    del t
+    assert w() is not None and p.value == addr and isinstance(p, ctypes.c_void_p)
+    echo = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p)(lambda x: x)      # accepted wherever a void* argument is declared
+    assert echo(p) == addr
+    del p
+    assert w() is None
+    assert L.ptr(None) is None
+    try:
+        L._status_result(7, True, [2, 1])
+    except L.RiseSdfHipError as e:
+        msg = str(e)
+        assert "4 in the fused SDF field" in msg and "2 in the radiance networks' input pack" in msg and "1 in their layer pairs" in msg
+        assert "RSDF_X2=0" in msg and "RSDF_PAIR=0" in msg
+    else:
+        raise AssertionError("no error raised")
+    assert L._status_result(0, True)["x2_fwd_nonfinite"] == 0
