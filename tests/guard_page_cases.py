@@ -82,8 +82,12 @@ def sdf_bwd(H, precision="fp32", env=None):
 def _guard_every_allocation():
     """Installs tests/guard_alloc.cpp for this process: inputs, outputs, saved tensors and scratch of every kernel end flush
     against an unmapped page (must run before the first device allocation)."""
-    so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_guard_alloc.so")
-    assert os.path.exists(so), "tests/_guard_alloc.so is missing (__graft_entry__.build())"
+    here = os.path.dirname(os.path.abspath(__file__))
+    so = os.path.join(here, "_guard_alloc.so")
+    if not os.path.exists(so):      # normally built by __graft_entry__.build(); host code only, a second on any box with hipcc
+        import subprocess
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "--offload-arch=gfx950", "-shared", "-fPIC", "-w",
+                               os.path.join(here, "guard_alloc.cpp"), "-o", so])
     torch.cuda.memory.change_current_allocator(torch.cuda.memory.CUDAPluggableAllocator(so, "guard_malloc", "guard_free"))
 
 
