@@ -485,7 +485,8 @@ int rsdf_weight_norm_bwd(const float *g, const float *v, const float *dw, int N,
  * rsdf_fd_points: positions = o[ri] + d[ri]*(t0+t1)/2 (models/split_mixed_occ.py:229-231), the six
  * taps x +- eps*e_k clamped to +-radius (models/geometry.py:229-241) and the AABB contraction
  * (x+r)/(2r) (geometry.py:17-19, models/utils.py:109-114).  x_unit [n,7,3] (tap_major = 0) or
- * [7,n,3] (tap_major = 1): tap 0 = centre, then +x,-x,+y,-y,+z,-z.  positions (nullable) [n,3]. */
+ * [7,n,3] (tap_major = 1): tap 0 = centre, then +x,-x,+y,-y,+z,-z.  positions (nullable) [n,3]; x_unit nullable when
+ * positions are asked for (the *_pts / *_x2 stencil kernels derive the taps from the positions: 12 instead of 96 B per sample). */
 int rsdf_fd_points(const float *rays_o, const float *rays_d, const int64_t *ray_indices,
                    const float *t_starts, const float *t_ends, int64_t n, float radius, float eps,
                    float *x_unit, float *positions, int tap_major, void *stream);

@@ -34,6 +34,7 @@ fd_points_kernel(const float *__restrict__ rays_o, const float *__restrict__ ray
 #pragma unroll
         for (int k = 0; k < 3; ++k) positions[3 * i + k] = p[k];
     }
+    if (xu == nullptr) return;       // positions only: the x2 stencil kernels derive the taps themselves (hashgrid_fd7.hip)
     const float two_r = radius - (-radius);
     // interleaved [n][7][3] or tap-major [7][n][3]
     const int64_t tstride = tap_major ? n * 3 : 3;
@@ -335,6 +336,7 @@ int rsdf_fd_points(const float *rays_o, const float *rays_d, const int64_t *ray_
                    float *x_unit, float *positions, int tap_major, void *stream)
 {
     RSDF_CHECK_ARG(radius > 0.f, "fd_points: radius must be > 0");
+    RSDF_CHECK_ARG(x_unit != nullptr || positions != nullptr, "fd_points: x_unit and positions are both NULL");
     if (n <= 0) return 0;
     fd_points_kernel<<<rsdf_blocks(n, THREADS), THREADS, 0, (hipStream_t)stream>>>(
         rays_o, rays_d, ray_indices, t_starts, t_ends, n, radius, eps, x_unit, positions, tap_major);

@@ -66,15 +66,16 @@ class _SdfFieldFD7(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x7t, table, w0, b0, w1, b1, w2, b2, meta, n_active, xyz_scale, xyz_offset,
                 eps_unit, want_feature, points=None, radius=None, eps=None, precision="fp32"):
-        xf = x7t.detach().to(torch.float32).contiguous()
-        assert xf.dim() == 3 and xf.shape[0] == 7 and xf.shape[2] == 3, "x7t must be [7,S,3]"
+        xf = None if x7t is None else x7t.detach().to(torch.float32).contiguous()     # (None: positions only, the x2 form)
+        assert xf is None or (xf.dim() == 3 and xf.shape[0] == 7 and xf.shape[2] == 3), "x7t must be [7,S,3]"
+        assert xf is not None or points is not None, "x7t or points"
         tb = table.detach()
         ws = [t.detach().to(torch.float32).contiguous() for t in (w0, b0, w1, b1, w2, b2)]
         require_device(xf, tb, *ws)
-        S = xf.shape[1]
+        S = xf.shape[1] if xf is not None else points.shape[0]
         Lv = int(meta.n_levels)
         H, N2 = ws[0].shape[0], ws[4].shape[0]
-        dev = xf.device
+        dev = tb.device
         st = stream_ptr()
         x2 = None
         pts = None
@@ -85,6 +86,8 @@ class _SdfFieldFD7(torch.autograd.Function):
         parts = x2_parts(3 + 2 * Lv, H, N2, precision) if S > 0 else 0
         if precision == "fp16" and S > 0 and not parts:
             raise L.RiseSdfHipError("precision 'fp16' of the fused SDF field needs H = 64 or 128")
+        if xf is None and S > 0 and not parts:
+            raise L.RiseSdfHipError("the fused SDF field without x7t needs the x2 kernels (H = 64 / 128, RSDF_X2 unset)")
         if parts:
             if os.environ.get("RSDF_CHECK", "0") == "1":
                 # the x2 form's fp16 range preconditions (csrc/mlp_x2.hip): a violation would show as inf / nan outputs
@@ -122,7 +125,7 @@ class _SdfFieldFD7(torch.autograd.Function):
             if L._DEBUG_SYNC:           # (debug aid: the arguments of the launch that a fault is about to be pinned on)
                 with open(L._DEBUG_SYNC, "a") as f:
                     f.write(f"  sdfmlp_fd7_fwd args: S={S} Lv={Lv} n_active={n_active} H={H} N2={N2} feature={want_feature} "
-                            f"xf={tuple(xf.shape)}@{xf.data_ptr():#x} planes={tuple(planes.shape)}@{planes.data_ptr():#x} "
+                            f"xf={None if xf is None else (tuple(xf.shape), hex(xf.data_ptr()))} planes={tuple(planes.shape)}@{planes.data_ptr():#x} "
                             f"pts={None if pts is None else tuple(pts.shape)} ws={[tuple(t.shape) for t in ws]} "
                             f"ws_ptr={[hex(t.data_ptr()) for t in ws]}\n")
             check(L.mlp_fn("rsdf_sdfmlp_fd7_fwd", precision)(ptr(xf), ptr(planes), Lv, n_active, float(xyz_scale),
@@ -144,7 +147,7 @@ class _SdfFieldFD7(torch.autograd.Function):
             return (None,) * 18
         xf, planes, w0, b0, w1, b1, w2, b2 = ctx.saved_tensors
         S, Lv, H, N2 = ctx.dims
-        dev = xf.device
+        dev = planes.device
         st = stream_ptr()
         g = torch.zeros(7, S, dtype=torch.float32, device=dev) if g_sdf7t is None \
             else g_sdf7t.detach().to(torch.float32).contiguous()

@@ -110,19 +110,23 @@ class VolumeSDF(BaseModel):
         """Fused fast path: -> (sdf7t [7, S] tap-major SDF stencil, feature [S, feature_dim] or
         None).  Gradients flow through the SDF values only."""
         from . import fused
+        grid, n_active = self.encoding._hash()
+        wts = self.network.effective_weights()
+        precision = getattr(self.network, "precision", "fp32")
+        # the x2 kernels (H = 64 / 128) take everything from the positions: x7t is neither formed nor saved for the backward
+        need_taps = not fused.use_x2(3 + 2 * grid.n_levels, wts[0][0].shape[0], wts[2][0].shape[0], precision)
         x7t, pts = ops.fd_points(rays_o, rays_d, ray_indices, t_starts, t_ends, self.radius,
-                                 self._finite_difference_eps, want_positions=True, tap_major=True)
+                                 self._finite_difference_eps, want_positions=True, tap_major=True, want_taps=need_taps)
         # the sample midpoints o + d (t0 + t1) / 2, formed by the kernel exactly as the reference's torch expression forms
         # them (models/split_mixed_occ.py:256-257): the caller's texture / curvature query takes them from here instead of
         # five more elementwise kernels (positions carry no graph under finite-difference normals)
         self._last_points = (ray_indices, pts)
-        grid, n_active = self.encoding._hash()
         return fused.sdf_field_fd7(
-            x7t, grid.params, self.network.effective_weights(), grid.meta,
+            x7t, grid.params, wts, grid.meta,
             grid.n_levels if n_active is None else n_active, self.encoding.xyz_scale,
             self.encoding.xyz_offset, self._eps_unit(), want_feature,
             points=pts, radius=self.radius, eps=self._finite_difference_eps,
-            precision=getattr(self.network, "precision", "fp32"))
+            precision=precision)
 
     def last_points(self, ray_indices):
         """The world-space midpoints of the samples of the last ``sdf7_from_rays(…, ray_indices, …)`` call, or None when the

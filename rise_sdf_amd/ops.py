@@ -1114,15 +1114,18 @@ def weight_norm(g, v):
 # ------------------------------------------------------------------------------------------------
 @torch.no_grad()
 def fd_points(rays_o, rays_d, ray_indices, t_starts, t_ends, radius, eps, want_positions=False,
-              tap_major=False):
+              tap_major=False, want_taps=True):
     """Sample midpoints + six clamped FD taps, AABB-contracted to [0,1]: x_unit [S,7,3], or the
-    tap-major [7,S,3] the fused stencil kernels consume."""
+    tap-major [7,S,3] the fused stencil kernels consume.  ``want_taps=False`` (with ``want_positions``): -> (None, positions) --
+    the x2 stencil kernels derive the taps from the positions, so the 84 B per sample of x_unit are neither written nor kept
+    for the backward."""
     o, d, ts, te = _f32c(rays_o), _f32c(rays_d), _f32c(t_starts), _f32c(t_ends)
     ri = ray_indices.contiguous()
     require_device(o, d, ri, ts, te)
     n = ri.numel()
+    assert want_taps or want_positions
     shape = (7, n, 3) if tap_major else (n, 7, 3)
-    xu = torch.empty(shape, dtype=torch.float32, device=o.device)
+    xu = torch.empty(shape, dtype=torch.float32, device=o.device) if want_taps else None
     pos = torch.empty(n, 3, dtype=torch.float32, device=o.device) if want_positions else None
     check(lib().rsdf_fd_points(ptr(o), ptr(d), ptr(ri), ptr(ts), ptr(te), n, float(radius), float(eps),
                                ptr(xu), ptr(pos), int(tap_major), stream_ptr()), "fd_points")
