@@ -432,8 +432,11 @@ int rsdf_pair_bwd(const void *x_image, int K, const float *wa, const float *ba, 
                   const float *dz_out /*[n][N2], nullable: g = dz_out @ w_out is formed in the kernel*/,
                   const float *w_out /*[N2][128]*/, int N2 /*<= 8*/,
                   float *dw_out /*nullable: dW_out [N2][128] += dz_out^T hb_rows, accumulated*/, const void *bound,
-                  float *dx /*nullable*/,
-                  int lddx, int kout, int x_relu, void *dx_absmax /*nullable, 4 bytes, zeroed by the caller*/, float *dwa,
+                  float *dx /*nullable*/, int lddx, int kout,
+                  float *dx2 /*nullable: columns [k1, kout) of the input gradient go to dx2 [n][ld2] instead (the two sources of
+                               rsdf_pair_pack2 get their gradients as two contiguous tensors); k1 a multiple of 4*/,
+                  int ld2, int k1,
+                  int x_relu, void *dx_absmax /*nullable, 4 bytes, zeroed by the caller*/, float *dwa,
                   float *dba, float *dwb, float *dbb, void *stream);
 /* ---- config[4]'s "bf16 MLP on MFMA" (BASELINE.json configs[4]; models/network_utils.py:109-157 at reduced matrix
  * precision): the same entry points with the suffix _bf16.  Same arguments, layouts and fp32 tensors; every matrix

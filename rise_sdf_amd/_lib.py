@@ -114,7 +114,8 @@ _SIGNATURES = {
     "rsdf_pair_fwd": [_P, _I, _P, _P, _P, _P, _L, _P, _P, _P, _P, _I, _I, _P, _P, _P],
     "rsdf_pair_bound_from_rows": [_P, _L, _P, _P],
     "rsdf_pair_bound_from_out_layer": [_P, _L, _I, _P, _P, _P, _P],
-    "rsdf_pair_bwd": [_P, _I, _P, _P, _P, _P, _L, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "rsdf_pair_bwd": [_P, _I, _P, _P, _P, _P, _L, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P,
+                      _P],
     "rsdf_sdfmlp_fd7_fwd": [_P, _P, _I, _I, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P],
     "rsdf_sdfmlp_fd7_bwd": [_P, _P, _I, _I, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P,
                             _P, _P, _P, _P, _P, _P, _P],

@@ -220,6 +220,8 @@ struct PairArgs {
     const unsigned *bound;           // bits of a bound on |g|
     float *dx;                       // nullable, [n][lddx]: columns [0, kout)
     int lddx, kout, x_relu;          // x_relu: write dx (x > 0) -- x is the ReLU output of the layer below
+    float *dx2;                      // nullable: columns [k1, kout) go to dx2 [n][ld2] (column - k1) instead -- the gradients of a
+    int ld2, k1;                     // two-source input as two contiguous tensors (k1 a multiple of 4)
     unsigned *dx_absmax;             // nullable: atomicMax of |dx| (the next launch's bound)
     float *dwa, *dba, *dwb, *dbb;
     // the narrow output layer on top of this pair (N2 <= 8), folded in
@@ -531,13 +533,17 @@ pair_kernel(const PairArgs a)
                     for (int r = 0; r < 4; ++r) o[r] = dx[r] * k_dx;
                 }
                 if (row < a.n) {
-                    float *p = a.dx + row * a.lddx + col;
-                    if (col + 3 < a.kout && (a.lddx & 3) == 0) {
+                    // (a group of four columns never straddles k1: both are multiples of 4)
+                    const bool second = a.dx2 != nullptr && col >= a.k1;
+                    float *p = second ? a.dx2 + row * a.ld2 + (col - a.k1) : a.dx + row * a.lddx + col;
+                    const int ld = second ? a.ld2 : a.lddx;
+                    const int lim = (a.dx2 != nullptr && !second) ? a.k1 : a.kout;
+                    if (col + 3 < lim && (ld & 3) == 0) {
                         *reinterpret_cast<float4 *>(p) = float4{o[0], o[1], o[2], o[3]};
                     } else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            if (col + r < a.kout) p[r] = o[r];
+                            if (col + r < lim) p[r] = o[r];
                     }
                     dxmax = fmaxf(fmaxf(dxmax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
                 }
@@ -787,14 +793,16 @@ int rsdf_pair_bound_from_out_layer(const float *dz_out, int64_t n, int N2, const
 
 int rsdf_pair_bwd(const void *x_image, int K, const float *wa, const float *ba, const float *wb, const float *bb, int64_t n,
                   const float *g, int g_masked, const float *hb_rows, const float *dz_out, const float *w_out, int N2,
-                  float *dw_out, const void *bound, float *dx, int lddx, int kout, int x_relu,
+                  float *dw_out, const void *bound, float *dx, int lddx, int kout, float *dx2, int ld2, int k1, int x_relu,
                   void *dx_absmax, float *dwa, float *dba, float *dwb, float *dbb, void *stream)
 {
+    RSDF_CHECK_ARG(dx2 == nullptr || (dx != nullptr && k1 >= 4 && (k1 & 3) == 0 && k1 < kout && ld2 >= kout - k1),
+                   "pair_bwd: the second dx output needs dx, 0 < k1 < kout, k1 a multiple of 4, ld2 >= kout - k1");
     RSDF_CHECK_ARG(K >= 1 && K <= 128, "pair_bwd: K must be in [1,128]");
     RSDF_CHECK_ARG((g != nullptr || dz_out != nullptr) && bound != nullptr, "pair_bwd: g (or dz_out) and its bound are required");
     RSDF_CHECK_ARG(dz_out == nullptr || (hb_rows != nullptr && w_out != nullptr && N2 >= 1 && N2 <= 8),
                    "pair_bwd: the folded output layer needs hb_rows, W_out and 1 <= N2 <= 8");
-    RSDF_CHECK_ARG(dx == nullptr || (kout >= 1 && kout <= K && lddx >= kout), "pair_bwd: bad dx window");
+    RSDF_CHECK_ARG(dx == nullptr || (kout >= 1 && kout <= K && lddx >= (dx2 != nullptr ? k1 : kout)), "pair_bwd: bad dx window");
     if (n <= 0) return 0;
     PairArgs a{};
     a.x = reinterpret_cast<const unsigned char *>(x_image);
@@ -805,6 +813,7 @@ int rsdf_pair_bwd(const void *x_image, int K, const float *wa, const float *ba, 
     a.bound = reinterpret_cast<const unsigned *>(bound);
     if (dz_out != nullptr) a.dz_out = dz_out, a.w_out = w_out, a.n_out = N2, a.dw_out = dw_out;
     a.dx = dx, a.lddx = lddx, a.kout = kout, a.x_relu = x_relu;
+    a.dx2 = dx2, a.ld2 = ld2, a.k1 = k1;
     a.dx_absmax = reinterpret_cast<unsigned *>(dx_absmax);
     a.dwa = dwa, a.dba = dba, a.dwb = dwb, a.dbb = dbb;
     const unsigned grid = (unsigned)(a.tiles < 256 ? a.tiles : 256);

@@ -1012,7 +1012,7 @@ class _MLPPairChain(torch.autograd.Function):
         k0, kout = (0, K) if ctx.dx_cols is None else ctx.dx_cols
         if not need2:                            # (only the first source's columns: fewer dx slabs are computed at all)
             kout = min(k0 + kout, ctx.K1) - k0
-        dx_in = None
+        dx_in = dx_second = None
         gcur, masked, bound = dh, 0, bounds
         for p in range(nh // 2 - 1, -1, -1):
             Kp = K if p == 0 else 128
@@ -1025,12 +1025,19 @@ class _MLPPairChain(torch.autograd.Function):
                 # the shared feature tensor, and on a [:, :K1] view of [n, K] rows that sum (and the zero-fill of the unused
                 # columns) ran on torch's strided elementwise kernels: 190 ms of a 4.5 s config[2] step
                 Kd = K if need2 else ctx.K1
-                dx = torch.empty(n, Kd, dtype=torch.float32, device=dev)
-                if k0 + kout < Kd:
+                # both sources want one (the specular network's [feature | SH(reflected direction)]): two contiguous tensors
+                # from the kernel (dx2), for the same reason -- the feature part joins autograd's sum, the other part goes to
+                # the encoding's backward, which would copy a strided view first
+                split = (need1 and need2 and ctx.dx_cols is None and 0 < ctx.K1 < K and ctx.K1 % 4 == 0
+                         and os.environ.get("RSDF_PAIR_SPLIT_DX", "1") != "0")
+                dx = torch.empty(n, ctx.K1 if split else Kd, dtype=torch.float32, device=dev)
+                dx_second = torch.empty(n, K - ctx.K1, dtype=torch.float32, device=dev) if split else None
+                if not split and k0 + kout < Kd:
                     dx[:, k0 + kout:].zero_()
-                win, ld, ko, relu, amax = ptr(dx), Kd, k0 + kout, 0, None
+                win, ld, ko, relu, amax = ptr(dx), dx.shape[1], k0 + kout, 0, None
             else:
                 dx, win, ld, ko, relu, amax = None, None, 0, 0, 0, None
+            second = dx_second if (p == 0 and need_dx) else None
             # (the top pair takes its ReLU mask from the forward's own h_last rows: no hb recompute, the lean kernel variant)
             top_fold = masked == 0 and fold
             check(lib().rsdf_pair_bwd(ptr(imgs[p]), Kp, ptr(ws[2 * p]), ptr(bs[2 * p]), ptr(ws[2 * p + 1]), ptr(bs[2 * p + 1]), n,
@@ -1038,14 +1045,17 @@ class _MLPPairChain(torch.autograd.Function):
                                       ptr(dzo) if top_fold else None, ptr(ws[-1]) if top_fold else None, N2 if top_fold else 0,
                                       ptr(grads[-2]) if top_fold else None,
                                       ptr(bound) if masked == 0 else ctypes.c_void_p(bounds.data_ptr() + 8),
-                                      win, ld, ko, relu, amax, ptr(grads[4 * p]), ptr(grads[4 * p + 1]), ptr(grads[4 * p + 2]),
-                                      ptr(grads[4 * p + 3]), st), "pair_bwd")
+                                      win, ld, ko, ptr(second), 0 if second is None else second.shape[1],
+                                      0 if second is None else ctx.K1, relu, amax, ptr(grads[4 * p]), ptr(grads[4 * p + 1]),
+                                      ptr(grads[4 * p + 2]), ptr(grads[4 * p + 3]), st), "pair_bwd")
             if p == 0:
                 if dx is not None and k0 > 0:
                     dx[:, :k0].zero_()
                 dx_in = dx
             gcur, masked = dx, 1
         K1 = ctx.K1
+        if dx_in is not None and need_dx and dx_second is not None:
+            return (dx_in, dx_second, None, None, *grads)
         d1 = dx_in[:, :K1] if (dx_in is not None and need1) else None
         d2 = dx_in[:, K1:] if (dx_in is not None and need2 and K1 < K) else None
         if d1 is not None and dx_in.shape[1] == K1:

@@ -126,17 +126,20 @@ def test_pair_forward_output_layer_fold(dev, N2, out_act, monkeypatch):
     assert float((a - b).abs().max()) < 2e-6 * max(float(a.abs().max()), 1.0)
 
 
-def test_pair_chain_two_source_input(dev, monkeypatch):
+@pytest.mark.parametrize("nh,K2", [(4, 36), (2, 25), (4, 25)])
+def test_pair_chain_two_source_input(dev, monkeypatch, nh, K2):
     """mlp_chain(x, ..., x2=...): the network's input cat([x, x2], -1) is packed from its two sources (rsdf_pair_pack2) and the
     input gradient comes back per source; an x2 that needs no gradient narrows the dx window to x's columns."""
     from rise_sdf_amd import ops
-    layers = _net(dev, 84, 4, 6, seed=41)
-    acts = ["relu"] * 4 + ["sigmoid"]
+    layers = _net(dev, 48 + K2, nh, 6, seed=41)
+    acts = ["relu"] * nh + ["sigmoid"]
     g = torch.Generator().manual_seed(3)
-    a = torch.randn(2000, 48, generator=g).to(dev).requires_grad_(True)
-    go = torch.randn(2000, 6, generator=g).to(dev)
+    a = torch.randn(2001, 48, generator=g).to(dev).requires_grad_(True)
+    go = torch.randn(2001, 6, generator=g).to(dev)
     for b_grad in (True, False):
-        b = torch.randn(2000, 36, generator=torch.Generator().manual_seed(4)).to(dev).requires_grad_(b_grad)
+        # (both sources with gradients: the kernel writes them as two contiguous tensors, the second with a row length that
+        #  is not a multiple of four for K2 = 25: the SH(5) encoding of the specular network)
+        b = torch.randn(2001, K2, generator=torch.Generator().manual_seed(4)).to(dev).requires_grad_(b_grad)
         res = []
         for two in (False, True):
             for t in [a, b] + [p for wb in layers for p in wb]:
@@ -178,7 +181,7 @@ def test_pair_backward_mask_sources_agree(dev):
         gr = [torch.zeros_like(t) for t in (wa, ba, wb, bb)]
         gin = gy * (hb > 0) if mode == "premasked" else gy
         _lib.check(L.rsdf_pair_bwd(p(img), K, p(wa), p(ba), p(wb), p(bb), n, p(gin.contiguous()), int(mode == "premasked"),
-                                   p(hb) if mode == "hb_rows" else None, None, None, 0, None, p(bound), p(dx), K, K, 0, None,
+                                   p(hb) if mode == "hb_rows" else None, None, None, 0, None, p(bound), p(dx), K, K, None, 0, 0, 0, None,
                                    *[p(t) for t in gr], st),
                    "pair_bwd")
         torch.cuda.synchronize()
