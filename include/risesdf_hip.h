@@ -105,11 +105,13 @@ int rsdf_counts_from_ray_indices(const int64_t *ray_indices, int64_t n_samples, 
 int rsdf_unpack_info(const int32_t *packed_info, int64_t n_rays, int64_t *ray_indices,
                      void *stream);
 /* keep[i] != 0 -> sample survives.  offsets: int32 [n] scratch (exclusive scan of keep, filled
- * by the call); *n_kept device int32. Outputs sized by the caller (>= n). */
+ * by the call); *n_kept device int32. Outputs sized by the caller (>= n).  extra / extra_out (nullable, together): one more
+ * per-sample float array compacted alongside (the alphas the visibility test was made from: a no-grad renderer of the kept
+ * samples -- models/volrend.py:18-127, the secondary rays -- need not evaluate the field again for the same values). */
 int rsdf_compact_samples(const uint8_t *keep, const int64_t *ray_indices, const float *t_starts,
                          const float *t_ends, int64_t n, int32_t *offsets, int32_t *n_kept,
                          void *scan_scratch, int64_t *ray_indices_out, float *t_starts_out,
-                         float *t_ends_out, void *stream);
+                         float *t_ends_out, const float *extra, float *extra_out, void *stream);
 
 /* ---- C1: transmittance / weights from alpha ---------------------------------------------------
  * replaces nerfacc.render_weight_from_alpha / render_transmittance_from_alpha

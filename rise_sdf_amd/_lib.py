@@ -53,7 +53,7 @@ _SIGNATURES = {
     "rsdf_query_occ": [_P, _P, _P, _I, _I, _I, _L, _P, _P, _P],
     "rsdf_counts_from_ray_indices": [_P, _L, _L, _P, _P],
     "rsdf_unpack_info": [_P, _L, _P, _P],
-    "rsdf_compact_samples": [_P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P],
+    "rsdf_compact_samples": [_P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "rsdf_weight_from_alpha_fwd": [_P, _P, _L, _P, _P, _P],
     "rsdf_weight_from_alpha_bwd": [_P, _P, _P, _P, _P, _L, _P, _P],
     "rsdf_transmittance_from_alpha_bwd": [_P, _P, _P, _P, _L, _P, _P],

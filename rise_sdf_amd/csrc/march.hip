@@ -229,7 +229,8 @@ __global__ void unpack_info_kernel(const int32_t *__restrict__ packed, int64_t n
 __global__ void compact_kernel(const uint8_t *__restrict__ keep, const int32_t *__restrict__ off,
                                const int64_t *__restrict__ ri, const float *__restrict__ ts,
                                const float *__restrict__ te, int64_t n, int64_t *__restrict__ ri_o,
-                               float *__restrict__ ts_o, float *__restrict__ te_o)
+                               float *__restrict__ ts_o, float *__restrict__ te_o, const float *__restrict__ extra,
+                               float *__restrict__ extra_o)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || !keep[i]) return;
@@ -237,6 +238,7 @@ __global__ void compact_kernel(const uint8_t *__restrict__ keep, const int32_t *
     ri_o[o] = ri[i];
     ts_o[o] = ts[i];
     te_o[o] = te[i];
+    if (extra != nullptr) extra_o[o] = extra[i];
 }
 
 int scan_i32(const int32_t *in, int64_t n, int32_t *out, int mode, int32_t *total, void *scratch,
@@ -302,9 +304,10 @@ int rsdf_unpack_info(const int32_t *packed_info, int64_t n_rays, int64_t *ray_in
 int rsdf_compact_samples(const uint8_t *keep, const int64_t *ray_indices, const float *t_starts,
                          const float *t_ends, int64_t n, int32_t *offsets, int32_t *n_kept,
                          void *scan_scratch, int64_t *ray_indices_out, float *t_starts_out,
-                         float *t_ends_out, void *stream)
+                         float *t_ends_out, const float *extra, float *extra_out, void *stream)
 {
     RSDF_CHECK_ARG(n >= 0 && n_kept && scan_scratch, "compact_samples: bad arguments");
+    RSDF_CHECK_ARG((extra == nullptr) == (extra_out == nullptr), "compact_samples: extra and extra_out go together");
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) {
         (void)hipMemsetAsync(n_kept, 0, sizeof(int32_t), st);
@@ -315,7 +318,7 @@ int rsdf_compact_samples(const uint8_t *keep, const int64_t *ray_indices, const 
     u8_to_i32<<<rsdf_blocks(n, 256), 256, 0, st>>>(keep, n, offsets);
     scan_i32(offsets, n, offsets, 1, n_kept, scan_scratch, st);
     compact_kernel<<<rsdf_blocks(n, 256), 256, 0, st>>>(keep, offsets, ray_indices, t_starts, t_ends,
-                                                        n, ray_indices_out, t_starts_out, t_ends_out);
+                                                        n, ray_indices_out, t_starts_out, t_ends_out, extra, extra_out);
     RSDF_RETURN_LAUNCH();
 }
 

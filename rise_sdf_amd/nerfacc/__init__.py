@@ -269,9 +269,11 @@ class OccGridEstimator(nn.Module):
     def sampling(self, rays_o, rays_d, sigma_fn=None, alpha_fn=None, near_plane: float = 0.0,
                  far_plane: float = 1e10, t_min=None, t_max=None, render_step_size: float = 1e-3,
                  early_stop_eps: float = 1e-4, alpha_thre: float = 0.0, stratified: bool = False,
-                 cone_angle: float = 0.0, stratified_u: Optional[torch.Tensor] = None):
+                 cone_angle: float = 0.0, stratified_u: Optional[torch.Tensor] = None, return_alphas: bool = False):
         """-> (ray_indices int64 [S], t_starts [S], t_ends [S]); ``alpha_fn(t_starts, t_ends,
-        ray_indices) -> [S]`` prunes by visibility exactly like the vendored marcher does."""
+        ray_indices) -> [S]`` prunes by visibility exactly like the vendored marcher does.  ``return_alphas`` (with
+        ``alpha_fn``): a fourth output, the kept samples' alphas as ``alpha_fn`` returned them for the visibility test -- a
+        no-grad renderer of these samples would evaluate the field a second time for the same values."""
         near = None if near_plane is None else float(near_plane)
         far = None if far_plane is None else float(far_plane)
         if t_min is None or t_max is None:
@@ -285,7 +287,8 @@ class OccGridEstimator(nn.Module):
             t_min = t_min + u * render_step_size
         if self.capacity_mode and alpha_fn is not None and sigma_fn is None:
             out = self._sampling_capped(rays_o, rays_d, t_min, t_max, alpha_fn, render_step_size, cone_angle,
-                                        early_stop_eps, alpha_thre, key=(near, far, round(float(render_step_size), 9)))
+                                        early_stop_eps, alpha_thre, key=(near, far, round(float(render_step_size), 9)),
+                                        return_alphas=return_alphas)
             if out is not None:
                 return out
         packed_info, ray_indices, t_starts, t_ends = ops.march(
@@ -310,7 +313,11 @@ class OccGridEstimator(nn.Module):
                 f"alphas must have shape of (N,)! Got {alphas.shape}"
             keep = render_visibility(alphas, packed_info=packed_info,
                                      early_stop_eps=early_stop_eps, alpha_thre=alpha_thre)
+            if return_alphas and alpha_fn is not None:
+                return ops.compact_samples(keep, ray_indices, t_starts, t_ends, extra=alphas)
             ray_indices, t_starts, t_ends = ops.compact_samples(keep, ray_indices, t_starts, t_ends)
+        elif return_alphas:
+            return ray_indices, t_starts, t_ends, torch.zeros_like(t_starts)      # (no samples at all)
         return ray_indices, t_starts, t_ends
 
     # ---- capacity mode (opt-in: ``estimator.capacity_mode = True``; rise_sdf_amd.step.TrainStep switches it on) ----------
@@ -324,7 +331,7 @@ class OccGridEstimator(nn.Module):
         self._capacity[key] = int(n_candidates * 1.15) + 4096
 
     def _sampling_capped(self, rays_o, rays_d, t_min, t_max, alpha_fn, render_step_size, cone_angle, early_stop_eps,
-                         alpha_thre, key):
+                         alpha_thre, key, return_alphas=False):
         cap = self._capacity.get(key)
         if cap is None:
             return None
@@ -334,7 +341,8 @@ class OccGridEstimator(nn.Module):
         keep = render_visibility(alphas, packed_info=packed, early_stop_eps=early_stop_eps, alpha_thre=alpha_thre,
                                  zero_init=True)
         cnt = []
-        ri_o, ts_o, te_o = ops.compact_samples(keep, ri, ts, te, count_out=cnt)
+        res = ops.compact_samples(keep, ri, ts, te, count_out=cnt, extra=alphas if return_alphas else None)
+        ri_o, ts_o, te_o = res[:3]
         st = L.status(total.device)          # (the kernels' sticky status words ride along with the counts)
         vals = torch.cat([total, cnt[0]] + [p[2] for p in self._pending] + [st]).tolist()   # the one host read of this call
         vals, st_vals = vals[:-L.STATUS_WORDS], vals[-L.STATUS_WORDS:]
@@ -350,11 +358,13 @@ class OccGridEstimator(nn.Module):
         if n_cand > cap:                                               # truncated: redo exactly (rare)
             self.stats["overflows"] += 1
             return None
+        if return_alphas:
+            return ri_o[:n_kept], ts_o[:n_kept], te_o[:n_kept], res[3][:n_kept]
         return ri_o[:n_kept], ts_o[:n_kept], te_o[:n_kept]
 
     @torch.no_grad()
     def sampling_blind(self, rays_o, rays_d, alpha_fn, near_plane, far_plane, t_min, t_max, render_step_size,
-                       early_stop_eps: float = 1e-4, alpha_thre: float = 0.0):
+                       early_stop_eps: float = 1e-4, alpha_thre: float = 0.0, return_alphas: bool = False):
         """Capacity mode WITHOUT a host read, for passes whose results are per-ray only (the secondary-ray occlusion
         pass): -> (ray_indices, t_starts, t_ends), all of capacity size; entries past the survivor count are empty samples
         of the LAST ray (the caller appends a phantom ray that owns them), or None when no capacity is known yet.  The
@@ -386,7 +396,8 @@ class OccGridEstimator(nn.Module):
         keep = render_visibility(alphas, packed_info=packed, early_stop_eps=early_stop_eps, alpha_thre=alpha_thre,
                                  zero_init=True)
         cnt = []
-        out = ops.compact_samples(keep, ri, ts, te, count_out=cnt, fill_ray=rays_o.shape[0] - 1)
+        out = ops.compact_samples(keep, ri, ts, te, count_out=cnt, fill_ray=rays_o.shape[0] - 1,
+                                  extra=alphas if return_alphas else None)       # (+ the kept samples' alphas, tail zeros)
         self._pending.append((key, cap, torch.cat([total, cnt[0]]), n_rays))
         self.stats["blind_calls"] += 1
         return out

@@ -242,29 +242,33 @@ def unpack_info(packed_info, n_samples):
 
 
 @torch.no_grad()
-def compact_samples(keep, ray_indices, t_starts, t_ends, count_out=None, fill_ray=None):
+def compact_samples(keep, ray_indices, t_starts, t_ends, count_out=None, fill_ray=None, extra=None):
     """Boolean-mask compaction of lib/nerfacc/ray_marching.py:213-218 (one host read of the count; with ``count_out`` (a
-    list) the device count is appended to it instead and the un-sliced outputs are returned)."""
+    list) the device count is appended to it instead and the un-sliced outputs are returned).  ``extra`` (float [S]): one
+    more per-sample array compacted alongside, returned as a fourth output."""
     k = keep.contiguous().view(torch.uint8) if keep.dtype == torch.bool else keep.contiguous()
     ri, ts, te = ray_indices.contiguous(), _f32c(t_starts), _f32c(t_ends)
     require_device(k, ri, ts, te)
     n, dev = ri.numel(), ri.device
     off = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
     cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    ex = None if extra is None else _f32c(extra).reshape(-1)
     if fill_ray is None:
         ri_o, ts_o, te_o = torch.empty_like(ri), torch.empty_like(ts), torch.empty_like(te)
+        ex_o = None if ex is None else torch.empty_like(ex)
     else:   # entries past the (device-side) count read as empty samples of ray ``fill_ray`` (a phantom last ray)
         ri_o, ts_o, te_o = torch.full_like(ri, int(fill_ray)), torch.zeros_like(ts), torch.zeros_like(te)
+        ex_o = None if ex is None else torch.zeros_like(ex)
     scratch = _scan_scratch(n, dev)          # (a named local: alive until the kernels that use it are enqueued)
     check(lib().rsdf_compact_samples(ptr(k), ptr(ri), ptr(ts), ptr(te), n, ptr(off), ptr(cnt),
-                                     ptr(scratch), ptr(ri_o), ptr(ts_o), ptr(te_o),
+                                     ptr(scratch), ptr(ri_o), ptr(ts_o), ptr(te_o), ptr(ex), ptr(ex_o),
                                      stream_ptr()), "compact_samples")
     if count_out is not None:          # capacity mode: the caller reads this count together with the marcher's total
         count_out.append(cnt)
-        return ri_o, ts_o, te_o
+        return (ri_o, ts_o, te_o) if ex is None else (ri_o, ts_o, te_o, ex_o)
     m = int(cnt.item())
     L.poll_status(ri.device)
-    return ri_o[:m], ts_o[:m], te_o[:m]
+    return (ri_o[:m], ts_o[:m], te_o[:m]) if ex is None else (ri_o[:m], ts_o[:m], te_o[:m], ex_o[:m])
 
 
 # ------------------------------------------------------------------------------------------------

@@ -11,6 +11,8 @@ Relighting (:322-331): third-bounce shading of smooth pixels against a swapped e
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -112,6 +114,11 @@ class SplitMixedOCCModel(BaseModel):
         they march to nothing; the others see exactly the interval the slab test gives them."""
         n_rays = rays_o.shape[0]
         alpha_fn = self._alpha_fn(rays_o, rays_d)
+        # The secondary rays are rendered without gradients from the samples the visibility test has just kept: their alphas
+        # are the sampler's own (the reference evaluates the field again for them, models/volrend.py:60-75 after
+        # lib/nerfacc/ray_marching.py:193-220, and gets the same values; here the same kernels would: bit-identical,
+        # tests/test_gpu_split_model.py).  RSDF_SECONDARY_REUSE_ALPHA=0 evaluates twice.
+        reuse = os.environ.get("RSDF_SECONDARY_REUSE_ALPHA", "1") != "0"
         with torch.no_grad():
             step = (self.secondary_far_plane - self.secondary_near_plane) / (self.num_samples_per_secondary_ray - 1)
             t_min = t_max = None
@@ -128,18 +135,22 @@ class SplitMixedOCCModel(BaseModel):
                     far1 = torch.full_like(t_min[:1], 1e10)
                     blind = self.occupancy_grid.sampling_blind(
                         ro_p, rd_p, a_fn, self.secondary_near_plane, self.secondary_far_plane,
-                        torch.cat([t_min, far1]), torch.cat([t_max, far1]), step)
+                        torch.cat([t_min, far1]), torch.cat([t_max, far1]), step, return_alphas=reuse)
                     if blind is not None:
                         acc_map, depth_map, _ = secondary_rendering(blind[1], blind[2], ray_indices=blind[0],
                                                                     n_rays=n_rays + 1, alpha_fn=a_fn,
                                                                     chunk_size=self.secondary_shader_chunk,
-                                                                    phantom_last_ray=True)
+                                                                    phantom_last_ray=True,
+                                                                    alphas=blind[3] if reuse else None)
                         return 1.0 - acc_map[:n_rays], depth_map[:n_rays]
-            ray_indices, t_starts, t_ends = self.occupancy_grid.sampling(
+            res = self.occupancy_grid.sampling(
                 rays_o, rays_d, alpha_fn=alpha_fn, near_plane=self.secondary_near_plane,
-                far_plane=self.secondary_far_plane, render_step_size=step, stratified=False, t_min=t_min, t_max=t_max)
+                far_plane=self.secondary_far_plane, render_step_size=step, stratified=False, t_min=t_min, t_max=t_max,
+                return_alphas=reuse)
+            ray_indices, t_starts, t_ends = res[:3]
             acc_map, depth_map, _ = secondary_rendering(t_starts, t_ends, ray_indices=ray_indices, n_rays=n_rays,
-                                                        alpha_fn=alpha_fn, chunk_size=self.secondary_shader_chunk)
+                                                        alpha_fn=alpha_fn, chunk_size=self.secondary_shader_chunk,
+                                                        alphas=res[3] if reuse else None)
         return 1.0 - acc_map, depth_map
 
     # ---- one ray batch (:224-443) ------------------------------------------------------------------------------

@@ -67,14 +67,19 @@ def rendering_with_normals_sdf(t_starts: Tensor, t_ends: Tensor, ray_indices: Op
 
 @torch.no_grad()
 def secondary_rendering(t_starts: Tensor, t_ends: Tensor, ray_indices: Tensor, n_rays: int,
-                        alpha_fn: Callable, chunk_size: int = 160000, phantom_last_ray: bool = False):
+                        alpha_fn: Callable, chunk_size: int = 160000, phantom_last_ray: bool = False,
+                        alphas: Optional[Tensor] = None):
     """Opacity / depth of the secondary (reflection) rays (volrend.py:18-127): alpha in chunks, then
     weights and two accumulations.  -> (opacities [N,1], depths [N,1], extras).
     ``phantom_last_ray``: the last ray only owns the unused tail of capacity-sized sample arrays (the read-free sampling pass of
     models/split_mixed_occ.py's mirror); it gets an empty range, so that the per-ray kernels -- C1 walks a ray's samples in the
     reference's sequential order -- do not composite a hundred thousand dummy samples for a result nobody reads."""
     dev = t_starts.device
-    if t_starts.shape[0] != 0:
+    if alphas is not None:
+        # the sampler's own alphas of exactly these samples (OccGridEstimator.sampling(..., return_alphas=True)): the reference
+        # evaluates the field a second time here (volrend.py:60-75) and gets the same numbers
+        assert alphas.shape == t_starts.shape
+    elif t_starts.shape[0] != 0:
         alphas = torch.cat([alpha_fn(t_starts[i:i + chunk_size], t_ends[i:i + chunk_size],
                                      ray_indices[i:i + chunk_size])
                             for i in range(0, t_starts.shape[0], chunk_size)], dim=0)

@@ -91,6 +91,36 @@ def test_masked_secondary_blend_matches_the_gather_path(dev, stage1):
         assert float((g0[n] - g1[n]).abs().max()) < 2e-5 * scale, n     # float atomics: last bits only
 
 
+@pytest.mark.parametrize("masked", [False, True])
+def test_secondary_rays_reuse_the_samplers_alphas_bit_for_bit(dev, monkeypatch, masked):
+    """models/volrend.py:60-75 evaluates the field a second time for the secondary samples the visibility test has just kept;
+    here secondary_rendering takes the sampler's own alphas (compacted alongside the samples): the occlusion maps and every
+    output are bit-identical to the recomputing form (RSDF_SECONDARY_REUSE_ALPHA=0), on the exact, the capped and the read-free
+    sampling paths."""
+    rays = camera_rays(20, 20, seed=2).to(dev)
+    u = torch.rand(rays.shape[0], generator=torch.Generator().manual_seed(3)).to(dev)
+    res = []
+    for reuse in ("0", "1"):
+        monkeypatch.setenv("RSDF_SECONDARY_REUSE_ALPHA", reuse)
+        model = _model(dev, stage1=False)
+        model.masked_secondary = masked
+        model.occupancy_grid.capacity_mode = masked
+        outs = []
+        for _ in range(3 if masked else 1):
+            with torch.no_grad():
+                out = model.forward_(rays, stratified_u=u)
+            outs.append({k: out[k].clone() for k in ("comp_rgb", "comp_spec_rgb", "comp_rgb_full", "opacity")})
+            outs[-1]["tr"] = model._last_secondary["tr"].clone()
+            outs[-1]["sec_depth"] = model._last_secondary["sec_depth"].clone()
+        if masked:
+            assert model.occupancy_grid.stats["blind_calls"] >= 1
+        res.append(outs)
+    assert float(res[0][-1]["tr"].min()) < 0.5                     # some secondary rays ARE occluded
+    for a, b in zip(*res):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+
+
 def test_blind_overflow_warns_and_recovers_on_the_exact_path(dev):
     """a read-free secondary pass whose candidates outgrow the remembered capacity is counted, warned about, and
     the NEXT pass takes the exact path (and re-measures); a larger ray batch scales the capacity instead of overflowing."""
