@@ -107,6 +107,63 @@ def _specular_weights(R, roughness, cutoff, dtype, chunk, cos_shift):
     return torch.cat(rows, 0)
 
 
+def _row_candidates(D, V, cosc, R, B):
+    """(vi, li) pairs that may pass ``V[vi] . D[li] >= cosc``: B x B texel blocks whose centre direction is within the
+    cone's angle + the block's own angular radius of V (a conservative cull; the exact test follows on the pairs)."""
+    nb = R // B
+    Db = D.reshape(6, nb, B, nb, B, 3).permute(0, 1, 3, 2, 4, 5).reshape(6 * nb * nb, B * B, 3)
+    cen = Db.mean(1)
+    cen = cen / cen.norm(dim=-1, keepdim=True)
+    rad = torch.acos((Db * cen[:, None, :]).sum(-1).clamp(-1.0, 1.0)).max(1).values          # [blocks]
+    ang = torch.acos((V @ cen.T).clamp(-1.0, 1.0))                                            # [rows, blocks]
+    vi, bi = torch.nonzero(ang <= math.acos(max(min(cosc, 1.0), -1.0)) + rad[None, :] + 1e-6, as_tuple=True)
+    # texel ids of block bi
+    s_, by, bx = bi // (nb * nb), (bi // nb) % nb, bi % nb
+    oy, ox = torch.meshgrid(torch.arange(B), torch.arange(B), indexing="ij")
+    li = (s_[:, None] * R * R + (by[:, None] * B + oy.reshape(1, -1)) * R + bx[:, None] * B + ox.reshape(1, -1))
+    return vi[:, None].expand_as(li).reshape(-1), li.reshape(-1)
+
+
+def specular_rows(cubemap, roughness, rows, cutoff=0.99, cos_shifts=(0.0,), chunk=256):
+    """The GGX prefilter restricted to the output texels ``rows`` (flat indices into [6RR]): the same elementwise
+    arithmetic as ``_specular_weights`` on the same operands, but only the window members of the selected rows are ever
+    formed, so the sizes the path runs every step -- R = 512 / 256 / 128, lib/pbr/light.py:177-180 -- fit the CPU.
+    One result [len(rows), 3] per entry of ``cos_shifts`` (the tests bracket the fp32 window compare), differentiable in
+    ``cubemap`` (the backward is the transpose of the same sparse rows: cubemap.cu:300-350)."""
+    R = cubemap.shape[1]
+    dtype = cubemap.dtype
+    B = 16 if R >= 64 else (4 if R % 4 == 0 else 1)
+    with torch.no_grad():
+        D = texel_dirs(R, dtype).reshape(-1, 3)
+        area = pixel_area(R, dtype).reshape(1, -1).repeat(1, 6)[0]
+        cosc0 = ndf_cutoff(roughness, cutoff)
+        a2 = (roughness * roughness) ** 2
+        vis, lis, ws, dots = [], [], [], []
+        for i in range(0, len(rows), chunk):
+            V = D[rows[i:i + chunk]]
+            vi, li = _row_candidates(D, V, cosc0 + min(cos_shifts), R, B)
+            Vs, Ls = V[vi], D[li]
+            dot = (Vs * Ls).sum(-1)
+            keep = dot >= cosc0 + min(cos_shifts)
+            vi, li, Vs, Ls, dot = vi[keep], li[keep], Vs[keep], Ls[keep], dot[keep]
+            Hh = Vs + Ls
+            Hh = Hh / Hh.norm(dim=-1, keepdim=True).clamp_min(1e-20)
+            vh = (Hh * Vs).sum(-1).clamp(0.0, 1.0)
+            dd = (vh * a2 - vh) * vh + 1.0
+            ws.append(dot.clamp_min(0.0) * (a2 / (dd * dd * math.pi)) * area[li] / 4.0)
+            vis.append(vi + i)
+            lis.append(li)
+            dots.append(dot)
+        vi, li, w, dot = torch.cat(vis), torch.cat(lis), torch.cat(ws), torch.cat(dots)
+    outs = []
+    for sh in cos_shifts:
+        m = dot >= cosc0 + sh
+        wsum = torch.zeros(len(rows), dtype=dtype).index_add_(0, vi[m], w[m])
+        col = torch.zeros(len(rows), 3, dtype=dtype).index_add(0, vi[m], w[m][:, None] * cubemap.reshape(-1, 3)[li[m]])
+        outs.append(col / wsum[:, None])
+    return outs
+
+
 def specular_cubemap(cubemap, roughness, cutoff=0.99, cos_shift=0.0):
     """GGX prefilter (:246-298 + ops.py:458): weighted sum normalised by the weight sum; differentiable
     in ``cubemap``.  ``cos_shift`` moves the window threshold (tests bracket the fp32 threshold compare of a

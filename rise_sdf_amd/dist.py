@@ -80,9 +80,11 @@ class GradBuckets:
         return 4 * (sum(p.numel() for p in self.big) + self.flat.numel())
 
     @torch.no_grad()
-    def all_reduce_mean(self, world: int, async_op: bool = False):
-        """Sum over ranks / world (DDP semantics).  Missing grads count as zeros."""
-        if world <= 1 or not dist.is_initialized():
+    def all_reduce_mean(self, world: int, async_op: bool = False, single_rank_too: bool = False):
+        """Sum over ranks / world (DDP semantics).  Missing grads count as zeros.  ``single_rank_too`` issues the
+        collectives on a one-rank group as well (a no-op in value; tests/test_gpu_rccl.py and bench.py's ``rccl_selftest``
+        use it to run the RCCL path on a one-GPU box)."""
+        if not dist.is_initialized() or (world <= 1 and not single_rank_too):
             return []
         handles = []
         for p in self.big:

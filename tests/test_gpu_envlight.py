@@ -54,6 +54,54 @@ def test_specular_prefilter(dev, R, roughness):
         assert float((gc.cpu().double() - rc).norm() / rc.norm()) < 2e-2
 
 
+@pytest.mark.parametrize("R,roughness", [(512, 0.08), (256, 0.185), (128, 0.29)])
+def test_specular_prefilter_at_the_sizes_the_step_runs(dev, R, roughness):
+    """E1 at the three levels ``build_mips`` filters every training step (lib/pbr/light.py:177-180: 512 / 256 / 128 at
+    roughness 0.08 / 0.185 / 0.29), forward and backward, against the fp64 oracle restricted to ~2000 random output
+    texels (oracle.envlight.specular_rows); the backward on a cotangent that is non-zero on those texels only."""
+    from rise_sdf_amd.envlight import specular_cubemap
+    g = torch.Generator().manual_seed(R)
+    c = torch.rand(6, R, R, 3, generator=g)
+    n_rows = 2000
+    rows = torch.randperm(6 * R * R, generator=g)[:n_rows].sort().values
+    # corners, edges and face centres too
+    rows[:8] = torch.tensor([0, R - 1, R * R - 1, R * R, 3 * R * R + R // 2, 5 * R * R + (R // 2) * R + R // 2,
+                             6 * R * R - 1, 2 * R * R + R * (R - 1)])
+    rows = rows.unique()
+    go_rows = torch.randn(len(rows), 3, generator=g)
+    go = torch.zeros(6 * R * R, 3)
+    go[rows] = go_rows
+    cg = c.to(dev).requires_grad_(True)
+    out = specular_cubemap(cg, roughness, 0.99)
+    (gc,) = torch.autograd.grad(out, cg, go.view(6, R, R, 3).to(dev))
+    c64 = c.double().requires_grad_(True)
+    ref, lo, hi = E.specular_rows(c64, roughness, rows, 0.99, cos_shifts=(0.0, -3e-7, 3e-7))
+    (rc,) = torch.autograd.grad(ref, c64, go_rows.double())
+    lo, hi = lo.detach(), hi.detach()
+    got = out.detach().cpu().double().reshape(-1, 3)[rows]
+    err = (got - ref.detach()).abs()
+    # a texel whose L.V is within fp32 rounding of the cutoff may fall on either side of the window (see above)
+    assert bool((err <= (lo - hi).abs() + 2e-5 * ref.detach().abs() + 1e-6).all()), float(err.max())
+    border = ((lo - hi).abs() > 0).any(-1)
+    clean = ~border
+    assert int(clean.sum()) >= len(rows) // 3, int(clean.sum())
+    assert float(err[clean].max()) <= 2e-5 * float(ref.detach().abs().max()) + 1e-6
+    # backward: input texels reached only by rows without a borderline window member are exact; the rest within the
+    # weight of one texel of a row's window
+    gcd = gc.cpu().double()
+    if int(border.sum()) == 0:
+        assert rel_err(gcd, rc) < 2e-5
+    else:
+        assert float((gcd - rc).norm() / rc.norm()) < 2e-2
+        c2 = c.double().requires_grad_(True)
+        (ref2,) = E.specular_rows(c2, roughness, rows[clean], 0.99)
+        (rc2,) = torch.autograd.grad(ref2, c2, go_rows.double()[clean])
+        go2 = torch.zeros(6 * R * R, 3)
+        go2[rows[clean]] = go_rows[clean]
+        (gc2,) = torch.autograd.grad(specular_cubemap(cg, roughness, 0.99), cg, go2.view(6, R, R, 3).to(dev))
+        assert rel_err(gc2.cpu().double(), rc2) < 2e-5
+
+
 def test_cubemap_mip(dev):
     from rise_sdf_amd.envlight import cubemap_mip
     g = torch.Generator().manual_seed(1)
