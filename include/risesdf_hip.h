@@ -124,6 +124,12 @@ int rsdf_weight_from_alpha_bwd(const int32_t *packed_info, const float *alphas,
                                const float *weights, const float *trans,
                                const float *grad_weights, int64_t n_rays, float *grad_alphas,
                                void *stream);
+/* The backward in the reference's sequential order (render_weight.cu:114-153), one lane per ray.  fmad != 0: with the
+ * multiply-add contraction nvcc's default --fmad=true applies to that source (the reference binary; what
+ * rsdf_weight_from_alpha_bwd runs); fmad == 0: every source operation rounded once.  Additive entry point (round 6). */
+int rsdf_weight_from_alpha_bwd_seq(const int32_t *packed_info, const float *alphas, const float *weights,
+                                   const float *grad_weights, int64_t n_rays, int fmad, float *grad_alphas,
+                                   void *stream);
 int rsdf_transmittance_from_alpha_bwd(const int32_t *packed_info, const float *alphas,
                                       const float *trans, const float *grad_trans,
                                       int64_t n_rays, float *grad_alphas, void *stream);

@@ -207,6 +207,12 @@ def unpack_info(packed_info, n_samples):
 # --------------------------------------------------------------------------------------
 # C1: render_transmittance.cu:85-145, render_weight.cu:86-153 as autograd Functions
 # --------------------------------------------------------------------------------------
+# The reference binary is nvcc -O3 with the default --fmad=true (lib/nerfacc/cuda/_backend.py:43-44): the weight backward's
+# multiply-add pairs are fused (oracle/risesdf_oracle.c).  False = every source operation rounded once (tests set it to
+# compare both sequences with the HIP kernel's two modes).
+C1_FMAD = True
+
+
 class _WeightFromAlpha(torch.autograd.Function):
     @staticmethod
     def forward(ctx, packed_info, alphas):
@@ -223,7 +229,7 @@ class _WeightFromAlpha(torch.autograd.Function):
         gw = _f32(gw)
         ga = torch.empty_like(a)
         lib().orc_weight_from_alpha_bwd(ctypes.c_int64(packed_info.shape[0]), _p(packed_info),
-                                        _p(a), _p(w), _p(gw), _p(ga))
+                                        _p(a), _p(w), _p(gw), ctypes.c_int(1 if C1_FMAD else 0), _p(ga))
         return None, ga
 
 

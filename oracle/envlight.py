@@ -124,12 +124,52 @@ def _row_candidates(D, V, cosc, R, B):
     return vi[:, None].expand_as(li).reshape(-1), li.reshape(-1)
 
 
-def specular_rows(cubemap, roughness, rows, cutoff=0.99, cos_shifts=(0.0,), chunk=256):
+def _face_vec_xy(s_idx, x, y, R, dtype):
+    """cube_to_dir(x, y, s, R) (cubemap.cu:32-46) for index tensors (x, y may be R: one past the face, as the bounds kernel's
+    tile corners are)."""
+    fx = 2.0 * ((x.to(dtype) + 0.5) / R) - 1.0
+    fy = 2.0 * ((y.to(dtype) + 0.5) / R) - 1.0
+    one = torch.ones_like(fx)
+    comps = [(one, -fy, -fx), (-one, -fy, fx), (fx, one, fy), (fx, -one, -fy), (fx, -fy, one), (-fx, -fy, -one)]
+    d = torch.zeros(fx.shape + (3,), dtype=dtype)
+    for k, c in enumerate(comps):
+        m = s_idx == k
+        if bool(m.any()):
+            d[m] = torch.stack(c, -1)[m]
+    return d / d.norm(dim=-1, keepdim=True)
+
+
+def _tile_pass(V, R, cosc, dtype, TILE=16):
+    """SpecularBoundsKernel's tile culling (cubemap.cu:201-219): per (row V, face, 16 x 16 tile) whether the "blunt interval
+    arithmetic" test max(minx Vx, maxx Vx) + ... >= cutoff passes, with the component intervals taken from the tile's FOUR
+    CORNER directions (corners at tile_end = one texel past the tile).  The test is not conservative -- a direction
+    component can peak inside a tile -- and the reference's window is what it lets through: in-cone texels of a culled
+    tile are dropped unless the bounding box of the surviving ones covers them.  -> (pass [rows, 6 nt nt] bool,
+    margin [rows] = smallest |maxdp - cutoff| of the row, nt)."""
+    nt = (R + TILE - 1) // TILE
+    s_idx, ty, tx = torch.meshgrid(torch.arange(6), torch.arange(nt), torch.arange(nt), indexing="ij")
+    s_idx, ty, tx = s_idx.reshape(-1), ty.reshape(-1), tx.reshape(-1)
+    tsx, tsy = tx * TILE, ty * TILE
+    tex, tey = torch.clamp((tx + 1) * TILE, max=R), torch.clamp((ty + 1) * TILE, max=R)
+    corners = torch.stack([_face_vec_xy(s_idx, tsx, tsy, R, dtype), _face_vec_xy(s_idx, tex, tsy, R, dtype),
+                           _face_vec_xy(s_idx, tsx, tey, R, dtype), _face_vec_xy(s_idx, tex, tey, R, dtype)], 0)
+    lo, hi = corners.min(0).values, corners.max(0).values                    # [tiles, 3]
+    maxdp = torch.maximum(lo[None] * V[:, None, :], hi[None] * V[:, None, :]).sum(-1)      # [rows, tiles]
+    return maxdp >= cosc, (maxdp - cosc).abs().min(1).values, nt
+
+
+def specular_rows(cubemap, roughness, rows, cutoff=0.99, cos_shifts=(0.0,), chunk=256, model_bounds=True,
+                  return_margin=False):
     """The GGX prefilter restricted to the output texels ``rows`` (flat indices into [6RR]): the same elementwise
     arithmetic as ``_specular_weights`` on the same operands, but only the window members of the selected rows are ever
     formed, so the sizes the path runs every step -- R = 512 / 256 / 128, lib/pbr/light.py:177-180 -- fit the CPU.
+    ``model_bounds``: the window is the reference's -- in-cone texels inside the per-face bounding box that
+    SpecularBoundsKernel builds from the tiles its culling test lets through (cubemap.cu:181-244; see _tile_pass) -- which at
+    narrow lobes (R = 512: the cone spans ~1.7 tiles) is a proper subset of the cone for some texels; False = the whole cone
+    (what the dense forms above evaluate; identical at the small resolutions they are used at).
     One result [len(rows), 3] per entry of ``cos_shifts`` (the tests bracket the fp32 window compare), differentiable in
-    ``cubemap`` (the backward is the transpose of the same sparse rows: cubemap.cu:300-350)."""
+    ``cubemap`` (the backward is the transpose of the same sparse rows: cubemap.cu:300-350).  ``return_margin``: also the
+    rows' smallest |tile test - cutoff| (a row within fp32 rounding of flipping a whole tile)."""
     R = cubemap.shape[1]
     dtype = cubemap.dtype
     B = 16 if R >= 64 else (4 if R % 4 == 0 else 1)
@@ -138,7 +178,7 @@ def specular_rows(cubemap, roughness, rows, cutoff=0.99, cos_shifts=(0.0,), chun
         area = pixel_area(R, dtype).reshape(1, -1).repeat(1, 6)[0]
         cosc0 = ndf_cutoff(roughness, cutoff)
         a2 = (roughness * roughness) ** 2
-        vis, lis, ws, dots = [], [], [], []
+        vis, lis, ws, dots, keeps, margins = [], [], [], [], [], []
         for i in range(0, len(rows), chunk):
             V = D[rows[i:i + chunk]]
             vi, li = _row_candidates(D, V, cosc0 + min(cos_shifts), R, B)
@@ -151,16 +191,39 @@ def specular_rows(cubemap, roughness, rows, cutoff=0.99, cos_shifts=(0.0,), chun
             vh = (Hh * Vs).sum(-1).clamp(0.0, 1.0)
             dd = (vh * a2 - vh) * vh + 1.0
             ws.append(dot.clamp_min(0.0) * (a2 / (dd * dd * math.pi)) * area[li] / 4.0)
+            in_box = []
+            if model_bounds:
+                passed, margin, nt = _tile_pass(V, R, cosc0, dtype)
+                margins.append(margin)
+                face, ly, lx = li // (R * R), (li // R) % R, li % R
+                tile = (face * nt + ly // 16) * nt + lx // 16
+                for sh in cos_shifts:
+                    # bounding box per (row, face) of the in-cone texels of the tiles that pass (:222-236) ...
+                    m = passed[vi, tile] & (dot >= cosc0 + sh)
+                    key = vi * 6 + face
+                    n_key = V.shape[0] * 6
+                    big = torch.iinfo(torch.int64).max
+                    mnx = torch.full((n_key,), big).scatter_reduce(0, key[m], lx[m], "amin")
+                    mxx = torch.full((n_key,), -1).scatter_reduce(0, key[m], lx[m], "amax")
+                    mny = torch.full((n_key,), big).scatter_reduce(0, key[m], ly[m], "amin")
+                    mxy = torch.full((n_key,), -1).scatter_reduce(0, key[m], ly[m], "amax")
+                    # ... and every in-cone texel inside it (:263-272)
+                    in_box.append((lx >= mnx[key]) & (lx <= mxx[key]) & (ly >= mny[key]) & (ly <= mxy[key]))
+            else:
+                in_box = [torch.ones_like(dot, dtype=torch.bool) for _ in cos_shifts]
+            keeps.append(torch.stack(in_box, 0))
             vis.append(vi + i)
             lis.append(li)
             dots.append(dot)
-        vi, li, w, dot = torch.cat(vis), torch.cat(lis), torch.cat(ws), torch.cat(dots)
+        vi, li, w, dot, keepm = torch.cat(vis), torch.cat(lis), torch.cat(ws), torch.cat(dots), torch.cat(keeps, 1)
     outs = []
-    for sh in cos_shifts:
-        m = dot >= cosc0 + sh
+    for k, sh in enumerate(cos_shifts):
+        m = (dot >= cosc0 + sh) & keepm[k]
         wsum = torch.zeros(len(rows), dtype=dtype).index_add_(0, vi[m], w[m])
         col = torch.zeros(len(rows), 3, dtype=dtype).index_add(0, vi[m], w[m][:, None] * cubemap.reshape(-1, 3)[li[m]])
         outs.append(col / wsum[:, None])
+    if return_margin:
+        return outs, (torch.cat(margins) if margins else torch.full((len(rows),), float("inf"), dtype=dtype))
     return outs
 
 

@@ -264,20 +264,31 @@ void orc_weight_from_alpha_fwd(int64_t n_rays, const int32_t *packed_info,
     }
 }
 
+/* fmad != 0: the multiply-add pairs contracted the way nvcc's default --fmad=true contracts this source (the reference is
+ * built with extra_cuda_cflags = ["-O3"] only, lib/nerfacc/cuda/_backend.py:43-44): each single-use product feeds the add /
+ * subtract that consumes it as ONE fused operation -- accum += gw*w -> fmaf(gw, w, accum); gw*T - accum -> fmaf(gw, T,
+ * -accum); accum -= gw*w -> fmaf(-gw, w, accum).  fmad == 0: every operation of the source rounded once (this file is
+ * compiled with -ffp-contract=off).  The two differ where the value of accum is its own rounding residue (a saturated ray). */
 void orc_weight_from_alpha_bwd(int64_t n_rays, const int32_t *packed_info,
                                const float *alphas, const float *weights,
-                               const float *grad_weights, float *grad_alphas)
+                               const float *grad_weights, int fmad, float *grad_alphas)
 {
     for (int64_t r = 0; r < n_rays; ++r) {
         int base = packed_info[2 * r], steps = packed_info[2 * r + 1];
         float accum = 0.0f;
-        for (int j = 0; j < steps; ++j) accum += grad_weights[base + j] * weights[base + j];
+        if (fmad) for (int j = 0; j < steps; ++j) accum = fmaf(grad_weights[base + j], weights[base + j], accum);
+        else for (int j = 0; j < steps; ++j) accum += grad_weights[base + j] * weights[base + j];
         float T = 1.0f;
         for (int j = 0; j < steps; ++j) {
             float a = alphas[base + j];
-            grad_alphas[base + j] =
-                (grad_weights[base + j] * T - accum) / fmaxf(1.0f - a, 1e-10f);
-            accum -= grad_weights[base + j] * weights[base + j];
+            if (fmad) {
+                grad_alphas[base + j] = fmaf(grad_weights[base + j], T, -accum) / fmaxf(1.0f - a, 1e-10f);
+                accum = fmaf(-grad_weights[base + j], weights[base + j], accum);
+            } else {
+                grad_alphas[base + j] =
+                    (grad_weights[base + j] * T - accum) / fmaxf(1.0f - a, 1e-10f);
+                accum -= grad_weights[base + j] * weights[base + j];
+            }
             T *= (1.0f - a);
         }
     }

@@ -73,7 +73,7 @@ def render(rays, P, *, stage, indirect, relighting=False, stratified_u=None, ove
     normal_map = ref["comp_normal"]
     acc, depth = ref["opacity"], ref["depth"]
     diff, spec, blend = comp[:, :3], comp[:, 3:6], comp[:, 6:7]
-    out = {"own_primary": own_primary, "primary": (ri, ts, te), "sdf7": ref["sdf7"]}
+    out = {"own_primary": own_primary, "primary": (ri, ts, te), "sdf7": ref["sdf7"], "alphas_own": ref["alphas_own"]}
     if stage != 0:
         diff_pbr, spec_pbr = comp[:, 7:10], comp[:, 10:13]
         spec_ref, spec_light = comp[:, 13:16], comp[:, 16:19]

@@ -56,6 +56,7 @@ _SIGNATURES = {
     "rsdf_compact_samples": [_P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "rsdf_weight_from_alpha_fwd": [_P, _P, _L, _P, _P, _P],
     "rsdf_weight_from_alpha_bwd": [_P, _P, _P, _P, _P, _L, _P, _P],
+    "rsdf_weight_from_alpha_bwd_seq": [_P, _P, _P, _P, _L, _I, _P, _P],
     "rsdf_transmittance_from_alpha_bwd": [_P, _P, _P, _P, _L, _P, _P],
     "rsdf_visibility_from_alpha": [_P, _P, _L, _F, _F, _P, _P],
     "rsdf_accumulate_fwd": [_P, _P, _P, _L, _I, _P, _P],
@@ -407,60 +408,116 @@ def free_workspaces():
 STATUS_WORDS = 8
 ST_X2_FWD_NONFINITE, ST_X2_BWD_REROUTED, ST_X2_BWD_GUARDED, ST_PAIR_PACK_NONFINITE, ST_PAIR_FWD_NONFINITE = 0, 1, 2, 3, 4
 _STATUS = {}
-_STATUS_TOTALS = {"x2_bwd_rerouted": 0, "x2_bwd_guarded": 0}
+_STATUS_SEEN = {}        # device index -> the raw words at the last poll (the device-side words are MONOTONIC: never cleared)
+_STATUS_TOTALS = {"x2_bwd_rerouted": 0, "x2_bwd_guarded": 0, "x2_fwd_nonfinite_total": 0, "range_reroutes": 0}
+
+# What a forward range violation of the two-part fp16 kernels does (the reference's fp32 MLPs have no such limit and simply
+# continue, models/network_utils.py:109-157):
+#   "reroute" (default)  the offending kernel family -- the fused x2 SDF field and / or the radiance networks' layer pairs --
+#                        is switched to the range-free kernels (three bf16 parts, fp32's exponent range) for the rest of
+#                        the process, with one RuntimeWarning; the poll returns ``rerouted_now`` so that a caller holding
+#                        the inputs can recompute (the samplers, rise_sdf_amd.guarded, TrainStep's skipped step);
+#   "raise"              RSDF_RANGE_ERROR=raise: RiseSdfHipError naming the bounds and RSDF_X2=0 / RSDF_PAIR=0 (round 5).
+_RANGE_FREE = {"x2": False, "pair": False}
+
+
+def range_policy() -> str:
+    return "raise" if os.environ.get("RSDF_RANGE_ERROR", "reroute") == "raise" else "reroute"
+
+
+def range_free(kind: str) -> bool:
+    """True once a forward range violation switched kernel family ``kind`` ('x2' or 'pair') to the range-free kernels."""
+    return _RANGE_FREE[kind]
+
+
+def reset_range_free():
+    """Back to the default kernel families (tests; a run that reloaded a saner checkpoint)."""
+    _RANGE_FREE["x2"] = _RANGE_FREE["pair"] = False
 
 
 def status(device) -> "torch.Tensor":
-    """The device's status words (created zeroed on first use)."""
+    """The device's status words (created zeroed on first use).  Kernels only ever atomicAdd to them and the host never
+    writes them again: a count that lands while another stream is being polled cannot be lost."""
     dev = torch.device(device)
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     t = _STATUS.get(idx)
     if t is None:
         t = torch.zeros(STATUS_WORDS, dtype=torch.int32, device=torch.device("cuda", idx))
         _STATUS[idx] = t
+        _STATUS_SEEN[idx] = [0] * STATUS_WORDS
     return t
 
 
+def _status_delta(idx, vals):
+    """Counts since the last poll of device ``idx`` (wrap-around safe), and remember ``vals`` as seen."""
+    seen = _STATUS_SEEN.setdefault(idx, [0] * STATUS_WORDS)
+    d = [((int(v) - int(s)) + (1 << 31)) % (1 << 32) - (1 << 31) for v, s in zip(vals, seen)]
+    _STATUS_SEEN[idx] = [int(v) for v in vals]
+    return d
+
+
 def poll_status(device=None, raise_on_error=True) -> dict:
-    """Reads (one small device-to-host copy: call it where the host blocks anyway) and clears the status words of ``device``
-    (default: every device that has any).  Returns the running totals; raises RiseSdfHipError when a kernel of the x2 form
-    produced a non-finite output since the last poll, i.e. an operand left the format's fp16 class range where the
-    reference's fp32 network (models/network_utils.py:109-157) stays finite."""
+    """Reads the status words of ``device`` (default: every device that has any; one small device-to-host copy: call it where
+    the host blocks anyway) and returns the running totals plus what was counted since the last poll
+    (``x2_fwd_nonfinite``, ``rerouted_now``).  A forward range violation since the last poll switches the offending kernel
+    family to the range-free kernels (``range_policy``; RSDF_RANGE_ERROR=raise: RiseSdfHipError instead)."""
     keys = list(_STATUS) if device is None else [torch.device(device).index if torch.device(device).index is not None
                                                  else torch.cuda.current_device()]
-    bad, sites = 0, [0, 0]
+    bad, sites, rerouted = 0, [0, 0], False
     for idx in keys:
         t = _STATUS.get(idx)
         if t is not None:
-            vals = t.tolist()
-            bad += consume_status(t, vals, raise_on_error=False)["x2_fwd_nonfinite"]
-            sites = [a + b for a, b in zip(sites, vals[ST_PAIR_PACK_NONFINITE:ST_PAIR_FWD_NONFINITE + 1])]
+            r = consume_status(t, t.tolist(), raise_on_error=False, _defer=True)
+            bad += r["x2_fwd_nonfinite"]
+            sites = [a + b for a, b in zip(sites, r["_sites"])]
     return _status_result(bad, raise_on_error, sites)
 
 
-def consume_status(t, vals, raise_on_error=True) -> dict:
+def consume_status(t, vals, raise_on_error=True, _defer=False) -> dict:
     """``vals``: the words of status tensor ``t`` as the caller has just read them together with its own counts (the
     capacity-mode sampler concatenates them into its one host read per step)."""
-    if any(vals):
-        t.zero_()
-    _STATUS_TOTALS["x2_bwd_rerouted"] += vals[ST_X2_BWD_REROUTED]
-    _STATUS_TOTALS["x2_bwd_guarded"] += vals[ST_X2_BWD_GUARDED]
-    return _status_result(vals[ST_X2_FWD_NONFINITE], raise_on_error, vals[ST_PAIR_PACK_NONFINITE:ST_PAIR_FWD_NONFINITE + 1])
+    d = _status_delta(t.device.index, vals)
+    _STATUS_TOTALS["x2_bwd_rerouted"] += d[ST_X2_BWD_REROUTED]
+    _STATUS_TOTALS["x2_bwd_guarded"] += d[ST_X2_BWD_GUARDED]
+    sites = d[ST_PAIR_PACK_NONFINITE:ST_PAIR_FWD_NONFINITE + 1]
+    if _defer:
+        return {"x2_fwd_nonfinite": d[ST_X2_FWD_NONFINITE], "_sites": sites}
+    return _status_result(d[ST_X2_FWD_NONFINITE], raise_on_error, sites)
 
 
-def _status_result(bad, raise_on_error, sites=(0, 0)):
-    if bad and raise_on_error:
-        where = (f"{bad - sites[0] - sites[1]} in the fused SDF field, {sites[0]} in the radiance networks' input pack, "
-                 f"{sites[1]} in their layer pairs")
-        raise RiseSdfHipError(
-            f"kernels of the two-part fp16 (x2) number format produced non-finite outputs ({bad} tiles since the last check: "
+def _range_message(bad, sites):
+    where = (f"{bad - sites[0] - sites[1]} in the fused SDF field, {sites[0]} in the radiance networks' input pack, "
+             f"{sites[1]} in their layer pairs")
+    return (f"kernels of the two-part fp16 (x2) number format produced non-finite outputs ({bad} tiles since the last check: "
             f"{where}): "
             "an operand left the format's range -- fused SDF field (csrc/mlp_x2.hip): |hash feature| or |xyz| >= 255, "
             "|effective weight| >= 1023 or a hidden activation >= 1023; radiance-network layer pairs (csrc/mlp_pair.hip): "
-            "|input|, |weight| or a hidden activation >= 1023 -- where the reference's fp32 MLPs stay finite.  Set RSDF_X2=0 "
-            "(SDF network) / RSDF_PAIR=0 (radiance networks) to run on the range-free kernels (three bf16 parts, fp32's "
-            "exponent range).")
-    return dict(_STATUS_TOTALS, x2_fwd_nonfinite=bad)
+            "|input|, |weight| or a hidden activation >= 1023 -- where the reference's fp32 MLPs stay finite.")
+
+
+def _status_result(bad, raise_on_error, sites=(0, 0)):
+    rerouted = False
+    if bad:
+        _STATUS_TOTALS["x2_fwd_nonfinite_total"] += bad
+        if raise_on_error and range_policy() == "raise":
+            raise RiseSdfHipError(
+                _range_message(bad, sites) + "  Set RSDF_X2=0 (SDF network) / RSDF_PAIR=0 (radiance networks) to run on the "
+                "range-free kernels (three bf16 parts, fp32's exponent range).")
+        if raise_on_error:
+            import warnings
+            kinds = [k for k, n in (("x2", bad - sites[0] - sites[1]), ("pair", sites[0] + sites[1])) if n > 0 and not _RANGE_FREE[k]]
+            for k in kinds:
+                _RANGE_FREE[k] = True
+            if kinds:
+                rerouted = True
+                _STATUS_TOTALS["range_reroutes"] += 1
+                warnings.warn(_range_message(bad, sites) + "  Switched " + " and ".join(
+                    {"x2": "the SDF field (as RSDF_X2=0)", "pair": "the radiance networks (as RSDF_PAIR=0)"}[k] for k in kinds)
+                    + " to the range-free kernels (three bf16 parts, fp32's exponent range) for the rest of this process; the "
+                    "call that overflowed is recomputed where its caller still holds the inputs (samplers, "
+                    "rise_sdf_amd.guarded, TrainStep skips that optimizer step).  RSDF_RANGE_ERROR=raise raises instead.",
+                    RuntimeWarning, stacklevel=3)
+    return dict(_STATUS_TOTALS, x2_fwd_nonfinite=bad, rerouted_now=rerouted)
 
 
 def status_totals() -> dict:

@@ -155,7 +155,17 @@ weight_fwd_kernel(const int32_t *__restrict__ packed, const float *__restrict__ 
     }
 }
 
-// render_weight.cu:114-153, statement for statement per lane (``trans`` of the forward is not read: the reference recomputes T)
+// render_weight.cu:114-153, statement for statement per lane (``trans`` of the forward is not read: the reference recomputes T).
+// FMAD: the reference BINARY is built by nvcc -O3 with its default --fmad=true (lib/nerfacc/cuda/_backend.py:43-44 passes no
+// -fmad flag), which contracts each single-use multiply with the add / subtract that consumes it:
+//     accum += gw*w            ->  accum = fma(gw, w, accum)
+//     gw*T - accum             ->  fma(gw, T, -accum)
+//     accum -= gw*w            ->  accum = fma(-gw, w, accum)
+// (T *= (1 - a) and w = a*T have no multiply-add pair).  In the saturated regime the value of ``accum`` IS its rounding
+// residue, so the two sequences give different d_alpha there; FMAD = true (the default) is the contracted sequence, FMAD =
+// false the source's operations one rounding each (RSDF_C1_FMAD=0).  Both are bit-exact against oracle/risesdf_oracle.c's
+// orc_weight_from_alpha_bwd(..., fmad).
+template <bool FMAD>
 __global__ void __launch_bounds__(64)
 weight_bwd_kernel(const int32_t *__restrict__ packed, const float *__restrict__ alphas,
                   const float *__restrict__ weights, const float *__restrict__ gw, int64_t n_rays, float *__restrict__ ga)
@@ -172,12 +182,24 @@ weight_bwd_kernel(const int32_t *__restrict__ packed, const float *__restrict__ 
             __syncthreads();
             if (c + 64 < s.max_steps) seq_load<2>(nxt, {gw, weights}, s, c + 64);
             const int n = s.steps - c;
-            float pv[64];
+            if (FMAD) {
+                float g_[64], w_[64];
 #pragma unroll
-            for (int j = 0; j < 64; ++j) pv[j] = s_g[lane * SEQ_LD + j] * s_w[lane * SEQ_LD + j];
+                for (int j = 0; j < 64; ++j) {
+                    g_[j] = s_g[lane * SEQ_LD + j];
+                    w_[j] = s_w[lane * SEQ_LD + j];
+                }
 #pragma unroll
-            for (int j = 0; j < 64; ++j)
-                if (j < n) accum += pv[j];
+                for (int j = 0; j < 64; ++j)
+                    if (j < n) accum = __fmaf_rn(g_[j], w_[j], accum);
+            } else {
+                float pv[64];
+#pragma unroll
+                for (int j = 0; j < 64; ++j) pv[j] = s_g[lane * SEQ_LD + j] * s_w[lane * SEQ_LD + j];
+#pragma unroll
+                for (int j = 0; j < 64; ++j)
+                    if (j < n) accum += pv[j];
+            }
             __syncthreads();
         }
     }
@@ -191,13 +213,18 @@ weight_bwd_kernel(const int32_t *__restrict__ packed, const float *__restrict__ 
         for (int j = 0; j < 64; ++j) {
             av[j] = s_a[lane * SEQ_LD + j];
             gv[j] = s_g[lane * SEQ_LD + j];
-            pv[j] = gv[j] * s_w[lane * SEQ_LD + j];
+            pv[j] = FMAD ? s_w[lane * SEQ_LD + j] : gv[j] * s_w[lane * SEQ_LD + j];      // FMAD: the weight itself
         }
 #pragma unroll
         for (int j = 0; j < 64; ++j) {
             if (j < n) {
-                s_a[lane * SEQ_LD + j] = (gv[j] * T - accum) / fmaxf(1.0f - av[j], 1e-10f);
-                accum -= pv[j];
+                if (FMAD) {
+                    s_a[lane * SEQ_LD + j] = __fmaf_rn(gv[j], T, -accum) / fmaxf(1.0f - av[j], 1e-10f);
+                    accum = __fmaf_rn(-gv[j], pv[j], accum);
+                } else {
+                    s_a[lane * SEQ_LD + j] = (gv[j] * T - accum) / fmaxf(1.0f - av[j], 1e-10f);
+                    accum -= pv[j];
+                }
                 T *= (1.0f - av[j]);
             }
         }
@@ -474,8 +501,19 @@ int rsdf_weight_from_alpha_bwd(const int32_t *packed_info, const float *alphas,
 {
     if (n_rays <= 0) return 0;
     (void)trans;          // (the reference's backward recomputes T in its own order, render_weight.cu:141-151)
-    weight_bwd_kernel<<<rsdf_blocks(n_rays, 64), 64, 0, (hipStream_t)stream>>>(
-        packed_info, alphas, weights, grad_weights, n_rays, grad_alphas);
+    return rsdf_weight_from_alpha_bwd_seq(packed_info, alphas, weights, grad_weights, n_rays, 1, grad_alphas, stream);
+}
+
+int rsdf_weight_from_alpha_bwd_seq(const int32_t *packed_info, const float *alphas, const float *weights,
+                                   const float *grad_weights, int64_t n_rays, int fmad, float *grad_alphas, void *stream)
+{
+    if (n_rays <= 0) return 0;
+    if (fmad)
+        weight_bwd_kernel<true><<<rsdf_blocks(n_rays, 64), 64, 0, (hipStream_t)stream>>>(
+            packed_info, alphas, weights, grad_weights, n_rays, grad_alphas);
+    else
+        weight_bwd_kernel<false><<<rsdf_blocks(n_rays, 64), 64, 0, (hipStream_t)stream>>>(
+            packed_info, alphas, weights, grad_weights, n_rays, grad_alphas);
     RSDF_RETURN_LAUNCH();
 }
 

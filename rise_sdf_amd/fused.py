@@ -45,7 +45,8 @@ def x2_parts(K0: int, H: int, N2: int, precision: str) -> int:
         return 0
     if precision == "fp16":
         return 1
-    if (precision == "fp32" and os.environ.get("RSDF_X2", "1") != "0" and os.environ.get("RSDF_MLP_FWD", "") != "coop"
+    if (precision == "fp32" and os.environ.get("RSDF_X2", "1") != "0" and not L.range_free("x2")
+            and os.environ.get("RSDF_MLP_FWD", "") != "coop"
             and os.environ.get("RSDF_MLP_BWD", "") == ""):
         return 2
     return 0

@@ -311,11 +311,21 @@ class OccGridEstimator(nn.Module):
                 alphas = alpha_fn(t_starts, t_ends, ray_indices)
             assert alphas.shape == t_starts.shape, \
                 f"alphas must have shape of (N,)! Got {alphas.shape}"
-            keep = render_visibility(alphas, packed_info=packed_info,
-                                     early_stop_eps=early_stop_eps, alpha_thre=alpha_thre)
+            for _attempt in range(3):
+                n_reroutes = L.status_totals()["range_reroutes"]
+                keep = render_visibility(alphas, packed_info=packed_info,
+                                         early_stop_eps=early_stop_eps, alpha_thre=alpha_thre)
+                res = ops.compact_samples(keep, ray_indices, t_starts, t_ends,
+                                          extra=alphas if (return_alphas and alpha_fn is not None) else None)
+                if L.status_totals()["range_reroutes"] == n_reroutes or sigma_fn is not None:
+                    break
+                # the poll behind the compaction's host read found that alpha_fn left the range of the two-part fp16
+                # kernels and switched them off (_lib.poll_status): these alphas are not the reference's -- again, on the
+                # range-free kernels (models/network_utils.py:109-157: the reference's fp32 MLP just continues)
+                alphas = alpha_fn(t_starts, t_ends, ray_indices)
             if return_alphas and alpha_fn is not None:
-                return ops.compact_samples(keep, ray_indices, t_starts, t_ends, extra=alphas)
-            ray_indices, t_starts, t_ends = ops.compact_samples(keep, ray_indices, t_starts, t_ends)
+                return res
+            ray_indices, t_starts, t_ends = res[:3]
         elif return_alphas:
             return ray_indices, t_starts, t_ends, torch.zeros_like(t_starts)      # (no samples at all)
         return ray_indices, t_starts, t_ends
@@ -346,7 +356,7 @@ class OccGridEstimator(nn.Module):
         st = L.status(total.device)          # (the kernels' sticky status words ride along with the counts)
         vals = torch.cat([total, cnt[0]] + [p[2] for p in self._pending] + [st]).tolist()   # the one host read of this call
         vals, st_vals = vals[:-L.STATUS_WORDS], vals[-L.STATUS_WORDS:]
-        L.consume_status(st, st_vals)
+        rerouted = L.consume_status(st, st_vals)["rerouted_now"]
         n_cand, n_kept = vals[:2]
         self._settle_pending(list(zip(vals[2::2], vals[3::2])))      # (+ the counts of earlier read-free passes)
         self._remember(key, n_cand)
@@ -357,6 +367,8 @@ class OccGridEstimator(nn.Module):
         self.stats["capped_calls"] += 1
         if n_cand > cap:                                               # truncated: redo exactly (rare)
             self.stats["overflows"] += 1
+            return None
+        if rerouted:         # alpha_fn left the x2 kernels' range (they are switched off now): redo on the range-free kernels
             return None
         if return_alphas:
             return ri_o[:n_kept], ts_o[:n_kept], te_o[:n_kept], res[3][:n_kept]

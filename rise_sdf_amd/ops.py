@@ -291,9 +291,10 @@ class _WeightFromAlpha(torch.autograd.Function):
         packed_info, a, w, t = ctx.saved_tensors
         gw = _f32c(gw)
         ga = torch.empty_like(a)
-        check(lib().rsdf_weight_from_alpha_bwd(ptr(packed_info), ptr(a), ptr(w), ptr(t), ptr(gw),
-                                               packed_info.shape[0], ptr(ga), stream_ptr()),
-              "weight_from_alpha_bwd")
+        # RSDF_C1_FMAD=0: the source's operations one rounding each instead of the reference binary's contraction (A/B, tests)
+        check(lib().rsdf_weight_from_alpha_bwd_seq(ptr(packed_info), ptr(a), ptr(w), ptr(gw), packed_info.shape[0],
+                                                   0 if os.environ.get("RSDF_C1_FMAD", "1") == "0" else 1, ptr(ga),
+                                                   stream_ptr()), "weight_from_alpha_bwd")
         return None, ga
 
 
@@ -1073,7 +1074,7 @@ def pair_chain_ok(x, ws, bs, acts, precision, x2=None):
     relu = L.ACT_IDS["relu"]
     nh = len(ws) - 1
     K = x.shape[1] + (0 if x2 is None else x2.shape[1]) if x.dim() == 2 else -1
-    return (precision in (None, "fp32") and os.environ.get("RSDF_PAIR", "1") != "0" and nh in (2, 4)
+    return (precision in (None, "fp32") and os.environ.get("RSDF_PAIR", "1") != "0" and not L.range_free("pair") and nh in (2, 4)
             and os.environ.get("RSDF_LAYER_BWD") != "split"
             and x.dim() == 2 and x.shape[0] > 0 and 1 <= K <= 128 and ws[0].shape == (128, K)
             and (x2 is None or (x2.dim() == 2 and x2.shape[0] == x.shape[0] and x2.is_cuda))

@@ -57,6 +57,9 @@ class TrainStep:
                 grid.capacity_mode = True
             if hasattr(model, "masked_secondary"):
                 model.masked_secondary = True
+        if dev.type == "cuda":
+            from . import _lib
+            self._st_seen = _lib.status(dev).clone()                 # the status words as of the last optimizer step
         if grid is not None and getattr(grid, "rng", 0) is None:     # (a generator already in place is kept)
             grid.rng = torch.Generator(device=dev)
             grid.rng.manual_seed(int(seed) + 7919)
@@ -109,6 +112,38 @@ class TrainStep:
         loss.backward()
         return loss, terms, out
 
+    def _guarded_optimizer_step(self):
+        """the render pass runs AFTER the step's last host read, so a forward range violation of the two-part fp16
+        kernels (inf / nan outputs -> nan loss -> nan gradients) would reach Adam before any poll sees the status words, and
+        one step destroys every parameter and moment.  The optimizer step is therefore made conditional ON THE DEVICE: the
+        status word's movement since the previous step becomes ``found_inf`` of torch's fused Adam (the GradScaler hook: the
+        kernel leaves parameters, moments and step counts untouched when it is set) -- no host read.  The next host read
+        (the next step's sampler) then switches the offending kernel family to the range-free kernels (_lib.poll_status), so
+        the run continues where the reference's fp32 networks would have.  Optimizers without that hook pay one 32-byte read."""
+        from . import _lib
+        if self.dev.type != "cuda":
+            self.opt.step()
+            return
+        st = _lib.status(self.dev)
+        if all(getattr(g, "get", lambda *_: False)("fused", False) for g in self.opt.param_groups):
+            found = (st[_lib.ST_X2_FWD_NONFINITE] != self._st_seen[_lib.ST_X2_FWD_NONFINITE]).to(torch.float32).reshape(())
+            self._st_seen.copy_(st)
+            if self.world > 1 and torch.distributed.is_initialized():      # every replica skips, or none
+                torch.distributed.all_reduce(found, op=torch.distributed.ReduceOp.MAX)
+            self.opt.grad_scale, self.opt.found_inf = None, found
+            try:
+                self.opt.step()
+            finally:
+                self.opt.found_inf = None
+            self.last_found_inf = found                # (a device tensor: reading it is the caller's host read)
+        else:
+            r = _lib.poll_status(self.dev)
+            if r["x2_fwd_nonfinite"]:
+                self.opt.zero_grad(set_to_none=True)   # that forward was not the reference's: skip, the next one is range-free
+                self.skipped_steps = getattr(self, "skipped_steps", 0) + 1
+                return
+            self.opt.step()
+
     def step(self, global_step, batch=None, epoch=0):
         self.model.update_step(epoch, global_step)                # systems/base.py:81-84
         if batch is None:
@@ -126,7 +161,7 @@ class TrainStep:
             self.train_num_rays = min(int(self.train_num_rays * 0.9 + want * 0.1), self.max_train_num_rays)
         if handles:
             self.buckets.finish(handles, self.world)
-        self.opt.step()
+        self._guarded_optimizer_step()
         res = {"loss": loss.detach(), "terms": terms, "num_samples": ns, "num_rays": n_rays, "out": out}
         # a read-free (blind) secondary sampling pass that outgrew its buffers ran truncated (its tail rays unoccluded): the
         # caller can skip or redo the step instead of relying on the sampler's RuntimeWarning (shown once per location)

@@ -80,3 +80,4 @@ def _fresh_status_words(request):
         from rise_sdf_amd import _lib
         if _lib._STATUS:
             _lib.poll_status(raise_on_error=False)
+        _lib.reset_range_free()          # (a test that tripped the forward range guard must not switch the next test's kernels)

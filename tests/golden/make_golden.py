@@ -448,6 +448,61 @@ def main():
     save("texture_stage1.npz", base=light.base, diffuse=light.diffuse, **mips, colors=col1, gcolors=gcol1,
          g_features=t1grads[0], g_normals=t1grads[1], g_base=t1grads[2], **t1g)
 
+    # ---- the same two forwards at the widths that ship (configs/split-mixed-occ-tensoir.yaml:93-120: n_neurons 128,
+    # input_feature_dim 48): reference-run GRADIENT fixtures for the layer-pair kernels (csrc/mlp_pair.hip).  The weights are
+    # regenerated from their names on both sides (tests/helpers.py::seeded_param) and the cotangent has the dynamic range of
+    # composite weights (helpers.composite_like_cotangent), so each fixture holds inputs, outputs and gradients only.
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from helpers import composite_like_cotangent, seeded_param
+    rng_state = torch.get_rng_state()                     # the fixtures below this block keep their random streams
+    mlp128 = lambda n: {"otype": "VanillaMLP", "activation": "ReLU", "output_activation": "none",
+                        "n_neurons": 128, "n_hidden_layers": n}
+    tcfg128 = Cfg({
+        "name": "volume-mixed-mip-split-occ", "input_feature_dim": 48, "other_dim": 3, "sample_size": 8,
+        "dir_encoding_config": {"otype": "SphericalHarmonics", "degree": 5, "reflected": True},
+        "metallic_mlp_network_config": mlp128(2), "albedo_mlp_network_config": mlp128(4),
+        "spec_mlp_network_config": mlp128(4), "roughness_mlp_network_config": mlp128(2),
+        "secondary_mlp_network_config": mlp128(4),
+        "xyz_encoding_config": {"otype": "VanillaFrequency", "n_frequencies": 6},
+        "color_activation": "sigmoid",
+    })
+    np.fromfile = lambda *a, **k: otex.synthetic_fg_lut().numpy().reshape(-1)
+    torch.cuda.device = _NoDev
+    tex128 = rtex.VolumeMixedMipSplitOcc(tcfg128)
+    torch.cuda.device = orig_cuda_device
+    np.fromfile = orig_fromfile
+    with torch.no_grad():
+        for n, p_ in tex128.named_parameters():
+            p_.copy_(seeded_param(n, tuple(p_.shape), seed=128))
+    torch.manual_seed(51)
+    S = 385                                               # 12 full 32-row tiles + a ragged one
+    feats = torch.randn(S, 48, requires_grad=True)
+    dirs = torch.nn.functional.normalize(torch.randn(S, 3), dim=-1)
+    nrm = torch.nn.functional.normalize(torch.randn(S, 3), dim=-1).requires_grad_(True)
+    pos = (torch.rand(S, 3) * 2 - 1) * 1.5
+    col = tex128(feats, dirs, nrm, pos, None, 0)
+    gcol = composite_like_cotangent(tuple(col.shape), seed=52)
+    tgrads = torch.autograd.grad(col, [feats, nrm] + list(tex128.parameters()), gcol, allow_unused=True)
+    tg = {"g__" + n.replace(".", "_"): (g if g is not None else torch.zeros_like(p_))
+          for (n, p_), g in zip(tex128.named_parameters(), tgrads[2:])}
+    save("texture_stage0_n128.npz", features=feats, dirs=dirs, normals=nrm, positions=pos, colors=col, gcolors=gcol,
+         g_features=tgrads[0], g_normals=tgrads[1], **tg)
+    torch.rand, torch.zeros, torch.linspace = _nodev(orig_rand), _nodev(orig_zeros), _nodev(orig_linspace)
+    light128 = rlight.EnvironmentLightMipCube(lcfg)
+    with torch.no_grad():
+        light128.base.copy_(seeded_param("emitter.base", (6, 64, 64, 3), seed=128).abs() * 8.0 + 0.05)
+    light128.build_mips()
+    col1 = tex128(feats, dirs, nrm, pos, light128, 1)
+    assert col1.shape == (S, 24)
+    gcol1 = composite_like_cotangent(tuple(col1.shape), seed=53)
+    t1grads = torch.autograd.grad(col1, [feats, nrm, light128.base] + list(tex128.parameters()), gcol1, allow_unused=True)
+    torch.rand, torch.zeros, torch.linspace = orig_rand, orig_zeros, orig_linspace
+    t1g = {"g__" + n.replace(".", "_"): (g if g is not None else torch.zeros_like(p_))
+           for (n, p_), g in zip(tex128.named_parameters(), t1grads[3:])}
+    save("texture_stage1_n128.npz", colors=col1, gcolors=gcol1, g_features=t1grads[0], g_normals=t1grads[1],
+         g_base=t1grads[2], **t1g)
+    torch.set_rng_state(rng_state)
+
     # ---- N3: state_dict layout of the reference modules (names, shapes) for checkpoint compatibility ----------
     import json
     from models import split_mixed_occ as rsmo

@@ -189,6 +189,21 @@ def test_ptr_keeps_its_tensor_alive_and_status_error_names_the_site():
     del p
     assert w() is None
     assert L.ptr(None) is None
+    # default policy: the offending kernel families are switched to the range-free kernels, with one warning
+    import warnings
+    os.environ.pop("RSDF_RANGE_ERROR", None)
+    L.reset_range_free()
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
+        r = L._status_result(7, True, [2, 1])
+    assert r["rerouted_now"] and L.range_free("x2") and L.range_free("pair") and len(wlist) == 1
+    assert "RSDF_RANGE_ERROR=raise" in str(wlist[0].message) and "4 in the fused SDF field" in str(wlist[0].message)
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
+        assert not L._status_result(3, True, [0, 0])["rerouted_now"] and not wlist      # already range-free: nothing to do
+    L.reset_range_free()
+    assert not L.range_free("x2") and not L.range_free("pair")
+    os.environ["RSDF_RANGE_ERROR"] = "raise"
     try:
         L._status_result(7, True, [2, 1])
     except L.RiseSdfHipError as e:
@@ -197,4 +212,14 @@ def test_ptr_keeps_its_tensor_alive_and_status_error_names_the_site():
         assert "RSDF_X2=0" in msg and "RSDF_PAIR=0" in msg
     else:
         raise AssertionError("no error raised")
+    finally:
+        os.environ.pop("RSDF_RANGE_ERROR", None)
+    assert not L.range_free("x2")
     assert L._status_result(0, True)["x2_fwd_nonfinite"] == 0
+    # the device words are monotonic: what a poll reports is the movement since the previous poll, wrap-around included
+    L._STATUS_SEEN[99] = [0] * L.STATUS_WORDS
+    assert L._status_delta(99, [5, 0, 2, 0, 0, 0, 0, 0])[:3] == [5, 0, 2]
+    assert L._status_delta(99, [7, 0, 2, 0, 0, 0, 0, 0])[:3] == [2, 0, 0]
+    L._STATUS_SEEN[99] = [2 ** 31 - 1] + [0] * 7
+    assert L._status_delta(99, [-2 ** 31 + 1, 0, 0, 0, 0, 0, 0, 0])[0] == 2
+    del L._STATUS_SEEN[99]

@@ -1,0 +1,137 @@
+"""The assembled full-PBR model AT THE SIZES IT SHIPS AT vs the composed oracle: the yaml's model node
+(configs/split-mixed-occ-tensoir.yaml:31-133 -- L = 16, T = 2^19 base-32 grid, SDF 2 x 128 -> 48, five 128-wide radiance
+networks, secondary rays) through ``SplitMixedOCCModel.forward_`` (models/split_mixed_occ.py:224-443), forward AND every
+parameter gradient, with an assertion that the kernels under test are the ones that ran: the layer-pair kernels
+(rsdf_pair_fwd / rsdf_pair_bwd, csrc/mlp_pair.hip) for the radiance networks and the x2 SDF field at H = 128
+(rsdf_sdfmlp_fd7_fwd_x2 / _bwd_x2 = bwd_x2_kernel<8,2>, csrc/mlp_x2.hip).  The 64-wide / H = 32 variants of these tests
+(tests/test_gpu_split_model.py) dispatch to the per-layer and per-wave kernels instead.
+
+Same protocol as the small tests (tests/test_gpu_split_model.py::_run): the oracle's OWN sample sets / secondary rays are
+compared with the HIP path's first, then the oracle runs on the HIP path's sample sets and stencil values and every
+gradient tensor is held to SURVEY 8(d)'s gates.  Two changes this round: the HIP alphas are compared with the
+oracle's OWN alphas before they are handed in, and the entry points are asserted."""
+import pytest
+import torch
+
+from oracle import texture as OT
+from helpers import camera_rays, rel_err, sphere_binary
+from test_gpu_model import assert_grads_tight
+from test_gpu_split_model import LIGHT, _all_param_grads, _params, _run
+
+pytestmark = pytest.mark.gpu
+
+
+def big_config(stage1):
+    """rise_sdf_amd.config.tensoir_model_config (the yaml's sizes) with: all 16 levels active from step 0 (the yaml
+    reaches that at step 11000), no curvature term, 24 secondary samples and a 64^2 environment map (the oracle's
+    prefilters are dense O(texels^2) fp64)."""
+    from rise_sdf_amd.config import tensoir_model_config
+    cfg = tensoir_model_config(n_levels=16, log2_T=19, hidden=128, num_samples_per_secondary_ray=24,
+                               split_sum_kick_in_step=0 if stage1 else 1 << 60, relighting_threshold=0.6,
+                               cos_anneal_end=0, grid_prune=True)
+    enc = cfg["geometry"]["xyz_encoding_config"]
+    enc["start_level"], enc["start_step"], enc["update_steps"] = 16, 0, 1
+    cfg["curvature"] = False
+    cfg["light"] = dict(LIGHT)
+    return cfg
+
+
+def build_big(dev, stage1, seed=0):
+    import rise_sdf_amd as R
+    torch.manual_seed(seed)
+    model = R.make("split-mixed-occ", big_config(stage1)).to(dev)
+    model.train()
+    with torch.no_grad():
+        model.geometry.encoding.encoding.encoding.params.mul_(1000.0)      # lumpy blob: some reflections are occluded
+        l0 = model.geometry.network.layers[0]
+        l0.weight_v[:, 3:] = torch.randn_like(l0.weight_v[:, 3:]) * 0.15
+        model.variance.variance.fill_(0.6)            # sharp surface: opaque pixels, secondary rays fire
+        if stage1:
+            model.texture.FG_LUT = OT.synthetic_fg_lut(64).to(dev)
+    model.occupancy_grid.binaries = sphere_binary(128, 0.2, 0.9).to(dev)[None]
+    model.background_color = torch.ones(3, device=dev)
+    model.update_step(0, 0)
+    assert model.stage == (1 if stage1 else 0)
+    assert model.geometry.network.n_neurons == 128 and model.geometry.encoding.n_output_dims == 35
+    return model
+
+
+class entry_points:
+    """Records which C-ABI entry points a block launched (rise_sdf_amd._lib.KernelTimer)."""
+
+    def __enter__(self):
+        from rise_sdf_amd import _lib
+        self.t = _lib.KernelTimer()
+        _lib.set_timer(self.t)
+        return self
+
+    def __exit__(self, *a):
+        from rise_sdf_amd import _lib
+        _lib.set_timer(None)
+        torch.cuda.synchronize()
+        self.calls = {k: v["calls"] for k, v in self.t.summary().items()}
+
+
+def _assert_shipped_kernels(fwd_calls, bwd_calls, n_pair_networks):
+    # the x2 SDF field at H = 128 and the layer-pair radiance kernels ran, and none of the networks fell back to the
+    # per-layer MLP kernels for its hidden layers or to the round-1..3 SDF kernels
+    assert fwd_calls.get("rsdf_sdfmlp_fd7_fwd_x2", 0) >= 1, fwd_calls
+    assert fwd_calls.get("rsdf_pair_fwd", 0) >= n_pair_networks, fwd_calls
+    assert bwd_calls.get("rsdf_sdfmlp_fd7_bwd_x2", 0) >= 1, bwd_calls
+    assert bwd_calls.get("rsdf_pair_bwd", 0) >= n_pair_networks, bwd_calls
+    for old in ("rsdf_sdfmlp_fd7_fwd", "rsdf_sdfmlp_fd7_bwd", "rsdf_sdfmlp_fd7_fwd_coop", "rsdf_sdfmlp_fd7_bwd_coop",
+                "rsdf_sdfmlp_fd7_bwd_quad", "rsdf_linear_bwd_fused"):
+        assert old not in bwd_calls and old not in fwd_calls, (old, fwd_calls, bwd_calls)
+
+
+def _run_big(dev, stage1, n_side, out_key, keys):
+    import rise_sdf_amd as R
+    model = build_big(dev, stage1)
+    rays = camera_rays(n_side, n_side, seed=2)
+    assert rays.shape[0] <= 256
+    u = torch.rand(rays.shape[0], generator=torch.Generator().manual_seed(3))
+    P = _params(model)
+    if stage1:
+        model.emitter.build_mips()
+    with entry_points() as fwd:
+        out, ref = _run(dev, model, rays, u, P, 1 if stage1 else 0, False)
+    assert int(ref["valid_indices"].numel()) > 20
+    for k in keys:
+        assert torch.allclose(out[k].cpu(), ref[k], rtol=1e-4, atol=2e-5), (k, float((out[k].cpu() - ref[k]).abs().max()))
+    g = torch.randn(ref[out_key].shape, generator=torch.Generator().manual_seed(4))
+    (ref[out_key] * g).sum().backward()
+    with entry_points() as bwd:
+        (out[out_key] * g.to(dev)).sum().backward()
+    # stage 0: albedo, metallic, roughness, env + the secondary network; stage 1 adds nothing new to the set
+    _assert_shipped_kernels(fwd.calls, bwd.calls, n_pair_networks=4)
+    R.check_status()                                       # no range violation, nothing counted
+    gt = model.geometry.encoding.encoding.encoding.params.grad.cpu()
+    hip, ref_g = _all_param_grads(model, P)
+    assert len(ref_g) >= 3 * 3 + 2 * 5 and "secondary0.w" in ref_g
+    report = {k: rel_err(hip[k], ref_g[k]) for k in ref_g if ref_g[k] is not None}
+    worst = max(report, key=report.get)
+    t_err = float((gt - P["table"].grad).abs().max()) / float(P["table"].grad.abs().max())
+    print("big model stage %d: S=%d, worst parameter gradient %s %.2e, table %.2e" %
+          (1 if stage1 else 0, int(out["num_samples"]) if "num_samples" in out else -1, worst, report[worst], t_err))
+    return model, P, hip, ref_g, gt
+
+
+def test_big_secondary_rays_stage0_vs_oracle(dev):
+    """config[2] + R1 at the shipped sizes, stage 0: every parameter gradient at SURVEY 8(d)'s gates."""
+    model, P, hip, ref_g, gt = _run_big(
+        dev, False, 16, "comp_rgb_full",
+        ("comp_rgb", "comp_spec_rgb", "comp_diffuse_rgb", "comp_blend", "opacity", "comp_rgb_full"))
+    assert torch.nn.functional.cosine_similarity(gt[None], P["table"].grad[None]).item() > 0.99999
+    assert_grads_tight(hip, ref_g, gt, P["table"].grad)
+
+
+def test_big_stage1_model_vs_oracle(dev):
+    """The stage-1 (split-sum PBR) model at the shipped sizes, with indirect illumination."""
+    model, P, hip, ref_g, gt = _run_big(
+        dev, True, 16, "comp_rgb_phys_full",
+        ("comp_rgb", "comp_rgb_phys", "comp_diffuse_rgb_phys", "comp_spec_rgb_phys", "comp_spec_rgb", "comp_albedo",
+         "comp_metallic", "comp_roughness", "comp_rgb_full", "comp_rgb_phys_full", "comp_spec_rgb_full",
+         "comp_spec_rgb_phys_full"))
+    assert rel_err(model.emitter.base.grad, P["emitter_base"].grad) < 1e-3
+    # same gate as the 64-wide stage-1 test: the oracle's prefilters / cube lookups are fp64 dense-weight restatements
+    assert_grads_tight(hip, ref_g, gt, P["table"].grad, mlp_tol=2e-3, table_tol=2e-3)

@@ -151,21 +151,59 @@ def test_c1_late_training_regime_vs_oracle(dev, hidden, variance, monkeypatch):
         for name, key in (("weight_v", "v"), ("weight_g", "g"), ("bias", "b")):
             hip_named[f"{i}.{name}"], ref_named[f"{i}.{name}"] = getattr(m, name).grad, p[key].grad
     hip_named["variance"], ref_named["variance"] = model.variance.variance.grad.reshape(1), var2.grad.reshape(1)
+    table_ref = table2.grad
     errs = {k: rel_err(hip_named[k], ref_named[k]) for k in ref_named}
-    errs["table"] = float((gt.cpu() - table2.grad).abs().max() / table2.grad.abs().max())
+    errs["table"] = float((gt.cpu() - table_ref).abs().max() / table_ref.abs().max())
     print("  HIP vs oracle: " + ", ".join(f"{k} {v:.1e}" for k, v in errs.items()))
-    # SURVEY 8(d)'s gates hold as they are while the reference's own d_alpha is the closed form's (|d_alpha| <~ 10: measured
-    # here at H = 64 / inv_s 403, every tensor <= 1.4e-5).  Where its residue amplifier is active (|d_alpha| 6e3 .. 1.5e4 in the
-    # other three cases) that NOISE term multiplies sigmoid'(x) = y (1 - y) formed from a ROUNDED y: one ulp of y near 1 (2^-24
-    # absolute, HIP's hardware exp2 / rcp against torch's expf) moves d_sdf of that sample by |d_alpha| 2^-24 inv_s -- with the
-    # alphas themselves bit-identical.  That is the reference's own conditioning, not a property of the kernels under test
-    # (tools/debug/late_modes.py: the range-free round-3 kernels sit at the same level), so the gate carries that term.
-    inv_s = float(torch.exp(torch.tensor(10.0 * variance)))
-    noise = 1.0 * float(ref["alphas"].grad.abs().max()) * 2.0 ** -24 * inv_s / float(nz.max())
-    print(f"  noise floor of the reference's weight backward in this case: {noise:.1e}")
-    assert_grads_tight(hip_named, ref_named, gt, table2.grad, mlp_tol=max(3e-4, noise), table_tol=max(1e-3, noise))
+    # ---- the gate.  SURVEY 8(d): 1e-4 on MLP parameters (3e-4 here: two fp32 summation orders of 1e4-1e5 terms,
+    # test_gpu_model.assert_grads_tight) and 1e-3 on table rows -- UNLESS the reference's own backward is worse conditioned
+    # than that in this case, which is MEASURED, not derived: the oracle's backward is taken again with every
+    # stencil value moved to its fp32 neighbour (random signs, 3 trials).  Where the weight backward's residue amplifier is
+    # active (render_weight.cu:139-151: |d_alpha| 6e3 .. 1.5e4 at inv_s 1808) its gradients move by 5e-4 .. 4e-3 of each
+    # tensor's largest entry; at inv_s 403 they move by <= 1e-5 and SURVEY's gates stand as they are.  An implementation
+    # cannot agree with the oracle more closely than the oracle agrees with itself one ulp away: the gate is 3 x that.
+    from helpers import oracle_gradient_sensitivity
+    leaves = {"table": table2, "variance": var2}
+    for i, p in enumerate(mlp2):
+        for name, key in (("weight_v", "v"), ("weight_g", "g"), ("bias", "b")):
+            leaves[f"{i}.{name}"] = p[key]
+    _, moved = oracle_gradient_sensitivity(
+        lambda s7: oracle.neus_geometry_render(rays, ri, ts, te, table2, meta2, mlp2, var2, radius=1.5, fd_eps=eps,
+                                               sdf7_given=s7, alphas_given=alphas_hip),
+        leaves, sdf7, {"opacity": go, "depth": gd}, trials=3, seed=24)
+    print("  oracle vs itself one ulp away: " + ", ".join(f"{k} {v:.1e}" for k, v in moved.items()))
+    gates = {k: max(1e-3 if k == "table" else 3e-4, 3.0 * moved[k]) for k in errs}
+    assert all(errs[k] < gates[k] for k in errs), {k: (errs[k], gates[k]) for k in errs if errs[k] >= gates[k]}
     if float(ref["alphas"].grad.abs().max()) < 100.0:
-        assert max(errs.values()) < 1e-4, errs
+        assert max(errs.values()) < 1e-4 and max(moved.values()) < 1e-4, (errs, moved)
+    else:
+        # the regime this test is about: the reference's own backward is conditioned worse than SURVEY's gate
+        assert max(moved.values()) > 3e-4, moved
+    # ---- the range-free round-3 kernels (RSDF_X2=0: three bf16 parts, fp32's exponent range) on the same samples sit at the
+    # same level: what is left is the reference's conditioning, not the x2 number format (was tools/debug/late_modes.py)
+    monkeypatch.setenv("RSDF_X2", "0")
+    for prm in model.parameters():
+        prm.grad = None
+    out3 = model.render_samples(rays_o, rays_d, ri_d, ts_d, te_d, n_rays)
+    ((out3["opacity"] * go.to(dev)).sum() + (out3["depth"] * gd.to(dev)).sum()).backward()
+    torch.cuda.synchronize()
+    sdf7_3 = hip_sdf7(model, rays, ri, ts, te)
+    with torch.no_grad():
+        alphas_3 = alpha_fn(ts_d, te_d, ri_d).cpu()
+    monkeypatch.delenv("RSDF_X2")
+    assert rel_err(sdf7_3, sdf7) < 1e-5 and not torch.equal(sdf7_3, sdf7)       # another kernel family ran
+    meta3, table3, mlp3, var3 = oracle_params(model)
+    ref3 = oracle.neus_geometry_render(rays, ri, ts, te, table3, meta3, mlp3, var3, radius=1.5, fd_eps=eps, sdf7_given=sdf7_3,
+                                       alphas_given=alphas_3)
+    ((ref3["opacity"] * go).sum() + (ref3["depth"] * gd).sum()).backward()
+    errs3 = {}
+    for i, (m, p) in enumerate(zip(lin, mlp3)):
+        for name, key in (("weight_v", "v"), ("weight_g", "g"), ("bias", "b")):
+            errs3[f"{i}.{name}"] = rel_err(getattr(m, name).grad, p[key].grad)
+    errs3["variance"] = rel_err(model.variance.variance.grad.reshape(1), var3.grad.reshape(1))
+    errs3["table"] = float((enc.params.grad.cpu() - table3.grad).abs().max() / table3.grad.abs().max())
+    print("  round-3 kernels vs oracle: " + ", ".join(f"{k} {v:.1e}" for k, v in errs3.items()))
+    assert all(errs3[k] < gates[k] for k in errs3), {k: (errs3[k], gates[k]) for k in errs3 if errs3[k] >= gates[k]}
     st = _lib.poll_status(dev)
     print(f"  range guard: {st}")
 
@@ -295,46 +333,135 @@ def test_forced_reroute_through_the_autograd_node(dev, ops, monkeypatch):
         assert scale > 0 and float((a - b).abs().max()) < 1e-5 * scale, (n, float((a - b).abs().max()) / scale)
 
 
-def test_forward_range_violation_raises_the_named_error(dev, ops, monkeypatch):
-    """A hidden weight of 5000 (weight_g is a free parameter; the reference's fp32 network stays finite) overflows the x2
-    format: the forward counts it on the device and the next host read raises a RiseSdfHipError that names the bound and
-    RSDF_X2=0 -- instead of NaN losses a few hundred steps later.  Inside the range nothing trips."""
+def test_forward_range_violation_reroutes_to_the_range_free_kernels(dev, ops, monkeypatch):
+    """A hidden weight of 5000 (weight_g is a free parameter; the reference's fp32 network stays finite,
+    models/network_utils.py:109-157) overflows the x2 format: the forward counts it on the device, the next host read
+    switches the SDF field to the range-free kernels with a warning, and a caller that still holds the inputs gets the
+    reference's finite values (a 40k-step run must not die where the reference continues).  Inside the
+    range nothing trips; RSDF_RANGE_ERROR=raise keeps round 5's named error."""
+    import warnings
     import rise_sdf_amd as R
     from rise_sdf_amd import _lib, fused
     monkeypatch.delenv("RSDF_CHECK", raising=False)
     monkeypatch.delenv("RSDF_X2", raising=False)
+    monkeypatch.delenv("RSDF_RANGE_ERROR", raising=False)
     for H in (64, 128):
         N2, S = 13, 1000
         meta, table, ws, x7t, pts, radius, eps = _field_inputs(dev, ops, S, H, N2, seed=33)
+        call = lambda tb=table: fused.sdf_field_fd7(x7t, tb, ws, meta, 16, 2.0, -1.0, eps / (2 * radius), want_feature=True,   # noqa: E731
+                                                    points=pts, radius=radius, eps=eps)
         with torch.no_grad():
+            _lib.reset_range_free()
             ws[1][0][3, 5] = 900.0
-            fused.sdf_field_fd7(x7t, table, ws, meta, 16, 2.0, -1.0, eps / (2 * radius), want_feature=True, points=pts, radius=radius, eps=eps)
-            assert R.check_status(dev)["x2_fwd_nonfinite"] == 0
+            call()
+            r = R.check_status(dev)
+            assert r["x2_fwd_nonfinite"] == 0 and not r["rerouted_now"] and not _lib.range_free("x2")
             ws[1][0][3, 5] = 5000.0
-            sdf_bad, _ = fused.sdf_field_fd7(x7t, table, ws, meta, 16, 2.0, -1.0, eps / (2 * radius), want_feature=True, points=pts,
-                                             radius=radius, eps=eps)
+            sdf_bad, _ = call()
             assert not bool(torch.isfinite(sdf_bad).all())
+            # ---- the guard closed around the call: finite, and exactly what RSDF_X2=0 computes
+            _lib.poll_status(dev, raise_on_error=False)
+            assert fused.x2_parts(35, H, N2, "fp32") == 2
+            with warnings.catch_warnings(record=True) as wlist:
+                warnings.simplefilter("always")
+                sdf_ok, feat_ok = R.guarded(call, dev)
+            assert len(wlist) == 1 and "range-free" in str(wlist[0].message) and "1023" in str(wlist[0].message)
+            assert _lib.range_free("x2") and fused.x2_parts(35, H, N2, "fp32") == 0
+            assert bool(torch.isfinite(sdf_ok).all()) and bool(torch.isfinite(feat_ok).all())
+            monkeypatch.setenv("RSDF_X2", "0")
+            sdf_ref, feat_ref = call()
+            monkeypatch.delenv("RSDF_X2")
+            assert torch.equal(sdf_ok, sdf_ref) and torch.equal(feat_ok, feat_ref)
+            # ... and against the reference's plain fp32 chain (fp64 here) the rerouted values are ordinary fp32 results
+            assert _lib.status_totals()["range_reroutes"] >= 1
+            # once switched, nothing counts any more and nothing warns again
+            with warnings.catch_warnings(record=True) as wlist:
+                warnings.simplefilter("always")
+                call()
+                assert R.check_status(dev)["x2_fwd_nonfinite"] == 0 and not wlist
+            # ---- RSDF_RANGE_ERROR=raise: the named error, at an explicit check and behind the marcher's sample-count read
+            _lib.reset_range_free()
+            monkeypatch.setenv("RSDF_RANGE_ERROR", "raise")
+            call()
             with pytest.raises(_lib.RiseSdfHipError, match="RSDF_X2=0"):
                 R.check_status(dev)
-            assert R.check_status(dev)["x2_fwd_nonfinite"] == 0          # reported once, then cleared
-            # the same through a host read the path makes anyway: the marcher's sample count
-            fused.sdf_field_fd7(x7t, table, ws, meta, 16, 2.0, -1.0, eps / (2 * radius), points=pts, radius=radius, eps=eps)
+            assert R.check_status(dev)["x2_fwd_nonfinite"] == 0          # reported once
+            call()
             rays = camera_rays(8, 8, seed=1).to(dev)
             from rise_sdf_amd import ops as O
-            tmin, tmax = O.ray_aabb_intersect(rays[:, :3].contiguous(), rays[:, 3:].contiguous(),
-                                              torch.tensor([-1.5, -1.5, -1.5, 1.5, 1.5, 1.5], device=dev))[:2]
+            box = torch.tensor([-1.5, -1.5, -1.5, 1.5, 1.5, 1.5], device=dev)
+            tmin, tmax = O.ray_aabb_intersect(rays[:, :3].contiguous(), rays[:, 3:].contiguous(), box)[:2]
             with pytest.raises(_lib.RiseSdfHipError, match="1023"):
-                O.march(rays[:, :3].contiguous(), rays[:, 3:].contiguous(), tmin, tmax,
-                        torch.tensor([-1.5, -1.5, -1.5, 1.5, 1.5, 1.5], device=dev),
+                O.march(rays[:, :3].contiguous(), rays[:, 3:].contiguous(), tmin, tmax, box,
                         torch.ones(1, 1, 1, dtype=torch.bool, device=dev), 0.05, 0.0)
             # a table value beyond the input range (|hash feature| >= 255)
             ws[1][0][3, 5] = 1.0
             t2 = table.detach().clone()
             t2[12345] = 300.0
             t2[::7] = 300.0
-            fused.sdf_field_fd7(x7t, t2, ws, meta, 16, 2.0, -1.0, eps / (2 * radius), points=pts, radius=radius, eps=eps)
+            call(t2)
             with pytest.raises(_lib.RiseSdfHipError, match="255"):
                 R.check_status(dev)
+            monkeypatch.delenv("RSDF_RANGE_ERROR")
+            # ... rerouted by default: the range-free kernels take fp32 planes, any table magnitude
+            sdf_t2, _ = R.guarded(lambda: call(t2), dev)
+            assert _lib.range_free("x2") and bool(torch.isfinite(sdf_t2).all())
+    _lib.reset_range_free()
+
+
+def test_sampler_recomputes_an_overflowed_alpha_fn(dev, monkeypatch):
+    """The visibility-pruned sampler is the first forward of a step and makes a host read: when its alpha_fn leaves the x2
+    range, the poll behind that read switches the field to the range-free kernels and the sampler evaluates alpha_fn again
+    -- exact path and capacity mode -- so that the sample set is the one RSDF_X2=0 produces (the reference's fp32 network
+    just continues).  A training step after that runs on the range-free kernels."""
+    import warnings
+    import rise_sdf_amd as R
+    from rise_sdf_amd import _lib
+    monkeypatch.delenv("RSDF_X2", raising=False)
+    monkeypatch.delenv("RSDF_RANGE_ERROR", raising=False)
+    sys.path.insert(0, ROOT)
+    import bench
+    torch.manual_seed(0)
+    cfg = bench.c1_config(hidden=64)
+    cfg["num_samples_per_ray"] = 128
+    cfg["prune_by_visibility"] = True
+    model = R.make("neus", cfg).to(dev)
+    model.train()
+    model.geometry.update_step(0, 0)
+    with torch.no_grad():
+        model.geometry.network.layers[2].weight_g[7] = 3.0e5          # effective |weight| row norm 3e5: beyond 1023
+    rays = camera_rays(24, 24, seed=3).to(dev)
+    ro, rd = rays[:, :3].contiguous(), rays[:, 3:].contiguous()
+    u = torch.rand(rays.shape[0], generator=torch.Generator().manual_seed(4)).to(dev)
+    kw = dict(render_step_size=model.render_step_size, stratified_u=u, cone_angle=0.0, alpha_thre=0.0)
+    monkeypatch.setenv("RSDF_X2", "0")
+    ref = model.occupancy_grid.sampling(ro, rd, alpha_fn=model._alpha_fn(ro, rd), **kw)
+    monkeypatch.delenv("RSDF_X2")
+    assert ref[0].numel() > 1000
+    for capacity in (False, True):
+        _lib.reset_range_free()
+        _lib.poll_status(dev, raise_on_error=False)
+        grid = model.occupancy_grid
+        grid.capacity_mode = capacity
+        if capacity:           # a first call sizes the buffers (on the range-free kernels, so that it does not trip the guard)
+            monkeypatch.setenv("RSDF_X2", "0")
+            grid.sampling(ro, rd, alpha_fn=model._alpha_fn(ro, rd), **kw)
+            monkeypatch.delenv("RSDF_X2")
+        with warnings.catch_warnings(record=True) as wlist:
+            warnings.simplefilter("always")
+            got = grid.sampling(ro, rd, alpha_fn=model._alpha_fn(ro, rd), **kw)
+        assert any("range-free" in str(w.message) for w in wlist), [str(w.message)[:80] for w in wlist]
+        assert _lib.range_free("x2")
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b), capacity
+    grid.capacity_mode = False
+    # the model keeps working: forward + backward on the range-free kernels, finite everywhere
+    out = model.forward_(rays, stratified_u=u)
+    (out["opacity"].sum() + out["depth"].sum()).backward()
+    torch.cuda.synchronize()
+    assert all(bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.grad is not None)
+    assert R.check_status(dev)["x2_fwd_nonfinite"] == 0
+    _lib.reset_range_free()
 
 
 def _saturated_alphas(n_rays, seed):
@@ -360,26 +487,37 @@ def _saturated_alphas(n_rays, seed):
 
 
 @pytest.mark.parametrize("seed", [0, 1])
-def test_weight_from_alpha_is_the_references_order_of_operations_bit_for_bit(dev, ops, seed):
+def test_weight_from_alpha_is_the_references_order_of_operations_bit_for_bit(dev, ops, seed, monkeypatch):
     """C1 (lib/nerfacc/cuda/csrc/render_weight.cu:86-153) in the saturated regime: the reference's backward divides the
     rounding residue of its own running subtraction by max(1 - alpha, 1e-10), so the result is a function of its ORDER of
-    operations -- the HIP kernels keep that order (one lane per ray for the arithmetic) and must equal the oracle's restatement
-    of the loop bit for bit: weights, transmittance, the visibility mask and d(alpha), including the 1e3-1e4 entries."""
+    operations AND of the compiler's multiply-add contraction (the reference binary is nvcc -O3 with the default
+    --fmad=true).  The HIP kernels keep that order (one lane per ray for the arithmetic) in both sequences -- contracted (the
+    default) and one rounding per source operation (RSDF_C1_FMAD=0) -- and must equal the oracle's restatement of each bit for
+    bit: weights, transmittance, the visibility mask and d(alpha), including the 1e3-1e4 entries.  The two sequences
+    themselves differ there (shown), which is why the default follows the binary."""
     packed, alphas = _saturated_alphas(700, seed)
     n_rays = packed.shape[0]
     assert int((alphas == 1.0).sum()) > 1000
-    a_ref = alphas.clone().requires_grad_(True)
-    w_ref, t_ref = oracle.render_weight_from_alpha(a_ref, packed_info=packed)
     gw = torch.randn(alphas.shape, generator=torch.Generator().manual_seed(seed + 10))
-    w_ref.backward(gw)
-    a_hip = alphas.to(dev).requires_grad_(True)
-    w, t = ops.render_weight_from_alpha(a_hip, packed_info=packed.to(dev))
-    w.backward(gw.to(dev))
-    assert torch.equal(w.detach().cpu(), w_ref.detach()) and torch.equal(t.detach().cpu(), t_ref.detach())
-    big = float(a_ref.grad.abs().max())
-    print(f"  largest |d_alpha| {big:.3g} (the closed form is bounded by |gw| ~ 4)")
-    assert big > 1e2, "the residue amplifier is not exercised"
-    assert torch.equal(a_hip.grad.cpu(), a_ref.grad)
+    grads = {}
+    for fmad in (True, False):
+        monkeypatch.setattr(oracle, "C1_FMAD", fmad)
+        monkeypatch.setenv("RSDF_C1_FMAD", "1" if fmad else "0")
+        a_ref = alphas.clone().requires_grad_(True)
+        w_ref, t_ref = oracle.render_weight_from_alpha(a_ref, packed_info=packed)
+        w_ref.backward(gw)
+        a_hip = alphas.to(dev).requires_grad_(True)
+        w, t = ops.render_weight_from_alpha(a_hip, packed_info=packed.to(dev))
+        w.backward(gw.to(dev))
+        assert torch.equal(w.detach().cpu(), w_ref.detach()) and torch.equal(t.detach().cpu(), t_ref.detach())
+        big = float(a_ref.grad.abs().max())
+        print(f"  fmad {fmad}: largest |d_alpha| {big:.3g} (the closed form is bounded by |gw| ~ 4)")
+        assert big > 1e2, "the residue amplifier is not exercised"
+        assert torch.equal(a_hip.grad.cpu(), a_ref.grad), fmad
+        grads[fmad] = a_ref.grad.clone()
+    d = (grads[True] - grads[False]).abs()
+    print(f"  contracted vs uncontracted d_alpha: {int((d > 0).sum())} of {d.numel()} entries differ, by up to {float(d.max()):.3g}")
+    assert float(d.max()) > 1.0, "the two sequences agree: the saturated regime is not exercised"
     keep = ops.render_visibility(alphas.to(dev), packed_info=packed.to(dev), early_stop_eps=1e-4, alpha_thre=0.0)
     keep_ref = oracle.render_visibility(alphas, packed_info=packed, early_stop_eps=1e-4)
     assert torch.equal(keep.cpu().bool(), keep_ref)

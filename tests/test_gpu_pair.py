@@ -211,29 +211,159 @@ def test_pair_chain_input_window_and_frozen_input(dev, monkeypatch):
         assert float((ga - gb).abs().max()) < 3e-5 * float(ga.abs().max())
 
 
-def test_pair_forward_range_violation_is_counted(dev):
+def test_pair_forward_range_violation_is_counted(dev, monkeypatch):
     """An operand beyond the fp16 class range (|input|, |weight| or |hidden activation| >= 1023) is counted in the device's status
-    words at the point where it would be split, and the next check raises the named error."""
+    words at the point where it would be split.  Default policy: the next check switches the radiance networks to the per-layer
+    kernels (fp32's range) and ``rise_sdf_amd.guarded`` hands back what RSDF_PAIR=0 computes; RSDF_RANGE_ERROR=raise: the
+    named error."""
+    import warnings
     import rise_sdf_amd as R
     from rise_sdf_amd import _lib, ops
     layers = _net(dev, 84, 2, 3, seed=9)
+    acts = ["relu", "relu", "none"]
     with torch.no_grad():
-        layers[0][1][5] = 3000.0                             # a bias that drives one hidden activation past 1023
         x = torch.randn(500, 84, generator=torch.Generator().manual_seed(1)).to(dev)
+        monkeypatch.setenv("RSDF_RANGE_ERROR", "raise")
+        layers[0][1][5] = 3000.0                             # a bias that drives one hidden activation past 1023
         R.check_status(dev)
-        ops.mlp_chain(x, layers, ["relu", "relu", "none"])
+        ops.mlp_chain(x, layers, acts)
         # (ReLU's max() swallows the NaN that the overflowed operand makes downstream: the outputs may well be finite, which is
         # why the guard sits at the split points and not at the outputs)
         with pytest.raises(_lib.RiseSdfHipError, match="RSDF_PAIR=0"):
             R.check_status(dev)
         layers[0][1][5] = 0.1
         layers[1][0][7, 9] = 2000.0                          # a weight beyond the class range
-        ops.mlp_chain(x, layers, ["relu", "relu", "none"])
+        ops.mlp_chain(x, layers, acts)
         with pytest.raises(_lib.RiseSdfHipError, match="RSDF_PAIR=0"):
             R.check_status(dev)
         layers[1][0][7, 9] = 0.1
-        ops.mlp_chain(x * 2000.0, layers, ["relu", "relu", "none"])      # inputs beyond it
+        ops.mlp_chain(x * 2000.0, layers, acts)      # inputs beyond it
         with pytest.raises(_lib.RiseSdfHipError, match="RSDF_PAIR=0"):
             R.check_status(dev)
-        ops.mlp_chain(x, layers, ["relu", "relu", "none"])
+        ops.mlp_chain(x, layers, acts)
         assert R.check_status(dev)["x2_fwd_nonfinite"] == 0
+        # ---- default policy: reroute
+        monkeypatch.delenv("RSDF_RANGE_ERROR")
+        layers[0][1][5] = 3000.0
+        monkeypatch.setenv("RSDF_PAIR", "0")
+        ref = ops.mlp_chain(x, layers, acts)
+        monkeypatch.delenv("RSDF_PAIR")
+        assert not _lib.range_free("pair")
+        with warnings.catch_warnings(record=True) as wlist:
+            warnings.simplefilter("always")
+            got = R.guarded(lambda: ops.mlp_chain(x, layers, acts), dev)
+        assert len(wlist) == 1 and "RSDF_PAIR=0" in str(wlist[0].message)
+        assert _lib.range_free("pair") and not _lib.range_free("x2")
+        assert torch.equal(got, ref) and bool(torch.isfinite(got).all())
+        # the fp64 chain: the rerouted values are ordinary fp32 results of the reference's network
+        h = x.double()
+        for i, (w, b) in enumerate(layers):
+            h = h @ w.double().T + b.double()
+            h = torch.relu(h) if i < 2 else h
+        assert float((got.double() - h).abs().max()) < 1e-5 * float(h.abs().max())
+    _lib.reset_range_free()
+
+
+def test_training_step_skips_the_optimizer_when_the_render_pass_overflows(dev, monkeypatch):
+    """the radiance networks run AFTER the step's last host read; a range violation there used to reach Adam as
+    NaN gradients before any poll.  TrainStep now hands the status word's movement to fused Adam as ``found_inf`` on the
+    device: the offending step leaves parameters and moments bit-identical, the next step's sampler read switches the pair
+    kernels off, and training continues with finite parameters."""
+    import warnings
+    from rise_sdf_amd import _lib
+    from rise_sdf_amd.step import build_synthetic_training
+    monkeypatch.delenv("RSDF_RANGE_ERROR", raising=False)
+    _lib.reset_range_free()
+    model, ts = build_synthetic_training(dev, stage=0, hidden=64, views=3, res=48, indirect=False, curvature=False,
+                                         model_overrides={"train_num_rays": 128, "max_train_num_rays": 256})
+    ts.step(0)
+    ts.step(1)
+    assert float(ts.last_found_inf) == 0.0
+    with torch.no_grad():
+        bias = model.texture.albedo_network.layers[0].bias
+        keep = bias[5].clone()
+        bias[5] = 5000.0                                  # a hidden activation past 1023 in the albedo network's first pair
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    moments = [v["exp_avg"].clone() for v in ts.opt.state.values() if "exp_avg" in v]
+    ts.step(2)
+    assert float(ts.last_found_inf) == 1.0
+    for n, p in model.named_parameters():
+        assert torch.equal(p.detach(), before[n]), n       # the step was skipped on the device
+    for a, b in zip(moments, [v["exp_avg"] for v in ts.opt.state.values() if "exp_avg" in v]):
+        assert torch.equal(a, b)
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
+        ts.step(3)                                        # its sampler's host read sees the count: pair kernels off
+    assert any("RSDF_PAIR=0" in str(w.message) for w in wlist)
+    assert _lib.range_free("pair")
+    assert float(ts.last_found_inf) == 0.0
+    ts.step(4)
+    moved = sum(int(not torch.equal(p.detach(), before[n])) for n, p in model.named_parameters())
+    assert moved > 10
+    assert all(bool(torch.isfinite(p).all()) for p in model.parameters())
+    with torch.no_grad():
+        bias[5] = keep
+    _lib.reset_range_free()
+
+
+@pytest.mark.parametrize("K,nh,N2,out_act,dense", [(84, 4, 6, "sigmoid", False), (84, 4, 6, "sigmoid", True),
+                                                   (73, 4, 3, "sigmoid", False), (84, 2, 1, "sigmoid", False),
+                                                   (84, 2, 2, "none", True)])
+def test_pair_backward_with_the_gradient_spread_of_a_render(dev, K, nh, N2, out_act, dense, monkeypatch):
+    """the pair backward shares ONE power-of-two scale per launch (a bound, max|dz_out| x column sums), and rows
+    more than ~2^38 below it are flushed; every other test feeds ``randn`` cotangents of uniform magnitude.  Here the
+    cotangent rows are scaled by what multiplies them in a render -- the composite weights w_i = alpha_i * prod(1 - alpha_j)
+    of marched rays: a *pruned* ray (weights 1e-4 ... 1, its invisible tail removed by the T >= 1e-4 filter) or a *dense*
+    c2 ray (no pruning: weights decay to 1e-8 and to exactly 0 behind the surface).  dW / db / dx against fp64 at 1e-5 of each
+    tensor's largest entry; the rows that carry the gradient dominate every tensor, which is why a shared scale is enough."""
+    from rise_sdf_amd import ops
+    n_rays, per_ray = 96, 64
+    n = n_rays * per_ray
+    g = torch.Generator().manual_seed(11 + K + nh)
+    # a NeuS-like ray: alpha ramps up through the surface crossing; late training makes the ramp a step
+    t = torch.linspace(-1, 1, per_ray)[None, :] + 0.3 * (torch.rand(n_rays, 1, generator=g) - 0.5)
+    sharp = 10.0 ** (1.0 + 2.0 * torch.rand(n_rays, 1, generator=g))
+    alpha = torch.sigmoid(t * sharp).clamp(0, 1) * (0.02 + 0.98 * torch.rand(n_rays, 1, generator=g))
+    T = torch.cumprod(torch.cat([torch.ones(n_rays, 1), 1 - alpha[:, :-1]], 1), 1)
+    w = alpha * T
+    if not dense:
+        w = torch.where(T >= 1e-4, w, torch.zeros_like(w))          # visibility pruning: those samples are not even there
+    w = w.reshape(-1)
+    if not dense:
+        keep = w > 0
+    else:
+        keep = torch.ones_like(w, dtype=torch.bool)
+    w = w[keep]
+    n = int(w.numel())
+    spread = float(w[w > 0].min() / w.max())
+    assert (spread < 1e-7 or bool((w == 0).any())) if dense else spread < 1e-2
+    layers = _net(dev, K, nh, N2, seed=K + nh + 1)
+    acts = ["relu"] * nh + [out_act]
+    x = torch.randn(n, K, generator=g).to(dev).requires_grad_(True)
+    go = (torch.randn(n, N2, generator=g) * w[:, None]).to(dev)
+    monkeypatch.setenv("RSDF_PAIR", "1")
+    assert ops.pair_chain_ok(x, [w_ for w_, _ in layers], [b for _, b in layers], tuple(ops.L.ACT_IDS[a] for a in acts), "fp32")
+    got = _run(ops, x, layers, acts, go)
+    l64 = [(w_.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)) for w_, b in layers]
+    x64 = x.detach().double().requires_grad_(True)
+    h = x64
+    for i, (w_, b) in enumerate(l64):
+        h = h @ w_.T + b
+        h = torch.relu(h) if i < nh else (torch.sigmoid(h) if out_act == "sigmoid" else h)
+    (h * go.double()).sum().backward()
+    g64 = [t_.grad for wb in l64 for t_ in wb]
+    names = ["dx"] + [f"{'wb'[j]}{i}" for i in range(nh + 1) for j in range(2)]
+    worst = ("", 0.0)
+    for name, a, c in zip(names, [got[1]] + got[2], [x64.grad] + g64):
+        assert bool(torch.isfinite(a).all()), name
+        e = float((a.double() - c).abs().max()) / float(c.abs().max())
+        worst = max(worst, (name, e), key=lambda p: p[1])
+        assert e < 1e-5, (name, e)
+    # dx row by row: a row whose cotangent is 1e-6 of the largest still gets a gradient with relative accuracy (the image
+    # keeps 22 bits down to 2^-15 of the bound and 11 bits to 2^-28)
+    rows = (w > 0) & (w > 1e-6 * w.max())
+    dx, dx64 = got[1].double().cpu()[rows], x64.grad.cpu()[rows]
+    rel = (dx - dx64).abs().amax(1) / dx64.abs().amax(1).clamp_min(1e-300)
+    print(f"K {K} nh {nh} N2 {N2} dense {dense}: n {n}, weight spread {spread:.1e}, worst tensor {worst[0]} {worst[1]:.1e}, "
+          f"worst dx row (weights > 1e-6 of the largest) {float(rel.max()):.1e}")
+    assert float(rel.max()) < 2e-2

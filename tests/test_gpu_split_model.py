@@ -118,7 +118,14 @@ def _run(dev, model, rays, u, P, stage, relighting):
     with torch.no_grad():
         ov["alphas"] = model._alpha_fn(ro_d, rd_d)(prim[1], prim[2], prim[0]).cpu()
     ref = OS.render(rays, P, stage=stage, indirect=True, relighting=relighting, stratified_u=u, override=ov)
-    assert rel_err(ov["sdf7"], ref["sdf7"]) < 3e-6                     # ... and the stencil itself agrees to fp32 rounding
+    # ... and the stencil itself agrees to fp32 rounding (relative to max |sdf|; the H = 128 chain sits at 7e-7 of its largest
+    # ACTIVATION, as in tests/test_gpu_late_regime.py)
+    assert rel_err(ov["sdf7"], ref["sdf7"]) < (3e-6 if model.geometry.network.n_neurons <= 64 else 8e-6)
+    # ... and so do the alphas that were handed in (an override that is never compared hides a regression of
+    # the HIP alpha kernel).  With sdf7_given the oracle's OWN alphas are its get_alpha on the same stencil values: what
+    # remains is the fp32 rounding of normalize / sigmoid, amplified by inv_s (403 here) in the sigmoid's argument
+    a_err = (ov["alphas"] - ref["alphas_own"]).abs()
+    assert float(a_err.max()) < 2e-5 and float(a_err.mean()) < 1e-6, (float(a_err.max()), float(a_err.mean()))
     # the oracle's OWN sampling / secondary rays agree with the HIP path's up to borderline samples and fp32 depth;
     # the number of borderline samples that actually differed is reported (no silent slack)
     d_prim = _n_different(ref["own_primary"], ov["primary"])

@@ -106,3 +106,89 @@ def test_compose_srgb_matches_the_unfused_chain_and_the_oracle(dev):
     assert torch.allclose(of.grad, ou.grad, rtol=1e-5, atol=1e-6)
     assert torch.allclose(cf.grad.cpu(), co.grad, rtol=1e-4, atol=1e-5)
     assert torch.allclose(of.grad.cpu(), oo.grad, rtol=1e-4, atol=1e-5)
+
+
+def _seeded_texture_128(dev):
+    """The HIP mirror of VolumeMixedMipSplitOcc at the yaml's widths, filled like the reference module of the ``*_n128``
+    fixtures (tests/golden/make_golden.py): parameters regenerated from their names."""
+    import rise_sdf_amd as R
+    from helpers import seeded_param
+    from oracle import texture as otex
+    mlp = lambda n: {"otype": "VanillaMLP", "activation": "ReLU", "output_activation": "none", "n_neurons": 128,   # noqa: E731
+                     "n_hidden_layers": n}
+    cfg = R.Config({
+        "name": "volume-mixed-mip-split-occ", "input_feature_dim": 48, "other_dim": 3, "sample_size": 8,
+        "dir_encoding_config": {"otype": "SphericalHarmonics", "degree": 5, "reflected": True},
+        "metallic_mlp_network_config": mlp(2), "albedo_mlp_network_config": mlp(4),
+        "spec_mlp_network_config": mlp(4), "roughness_mlp_network_config": mlp(2),
+        "secondary_mlp_network_config": mlp(4),
+        "xyz_encoding_config": {"otype": "VanillaFrequency", "n_frequencies": 6}, "color_activation": "sigmoid"})
+    tex = R.make("volume-mixed-mip-split-occ", cfg).to(dev)
+    with torch.no_grad():
+        for name, p in tex.named_parameters():
+            p.copy_(seeded_param(name, tuple(p.shape), seed=128))
+        tex.FG_LUT.copy_(otex.synthetic_fg_lut())
+    return tex
+
+
+def _check_param_grads(tex, z, tol, skip=()):
+    worst = ("", 0.0)
+    for name, p in tex.named_parameters():
+        ref = z["g__" + name.replace(".", "_")]
+        if any(s in name for s in skip):
+            continue
+        got = torch.zeros_like(ref) if p.grad is None else p.grad.cpu()
+        err = float((got - ref).abs().max()) / (float(ref.abs().max()) + 1e-30)
+        if float(ref.abs().max()) == 0.0:
+            assert float(got.abs().max()) == 0.0, name
+            continue
+        worst = max(worst, (name, err), key=lambda t: t[1])
+        assert err <= tol, (name, err)
+    return worst
+
+
+@pytest.mark.parametrize("stage", [0, 1])
+def test_pair_kernels_vs_reference_run_gradients_n128(dev, golden_dir, stage):
+    """Reference-run GRADIENT fixtures for the layer-pair kernels: the reference's
+    VolumeMixedMipSplitOcc.forward at n_neurons 128 / 48 features (tests/golden/texture_stage{0,1}_n128.npz) against the HIP
+    mirror, whose five networks must run on rsdf_pair_fwd / rsdf_pair_bwd; the cotangent rows span 1e-8 ... 1 with exact
+    zeros (composite weights of a pruned ray), which is what the pair backward's shared gradient-image scale has to survive."""
+    import os
+    import numpy as np
+    import rise_sdf_amd as R
+    from rise_sdf_amd import _lib
+    from helpers import rel_err, seeded_param
+    z0 = {k: torch.tensor(v) for k, v in np.load(os.path.join(golden_dir, "texture_stage0_n128.npz")).items()}
+    z = z0 if stage == 0 else {k: torch.tensor(v) for k, v in
+                               np.load(os.path.join(golden_dir, "texture_stage1_n128.npz")).items()}
+    tex = _seeded_texture_128(dev)
+    light = None
+    if stage == 1:
+        light = R.make("envlight-mip-cube", R.Config(
+            {"envlight_config": {"scale": 0.5, "bias": 0.25, "base_res": 64, "hdr_filepath": None}})).to(dev)
+        with torch.no_grad():
+            light.base.copy_(seeded_param("emitter.base", (6, 64, 64, 3), seed=128).abs() * 8.0 + 0.05)
+        light.build_mips()
+    feats = z0["features"].to(dev).requires_grad_(True)
+    nrm = z0["normals"].to(dev).requires_grad_(True)
+    timer = _lib.KernelTimer()
+    _lib.set_timer(timer)
+    try:
+        col = tex(feats, z0["dirs"].to(dev), nrm, z0["positions"].to(dev), light, stage)
+        (col * z["gcolors"].to(dev)).sum().backward()
+    finally:
+        _lib.set_timer(None)
+    torch.cuda.synchronize()
+    calls = {k: v["calls"] for k, v in timer.summary().items()}
+    n_nets = 3 if stage == 0 else 4                      # albedo, metallic, env (+ roughness at stage 1)
+    assert calls.get("rsdf_pair_fwd", 0) >= n_nets and calls.get("rsdf_pair_bwd", 0) >= n_nets, calls
+    assert torch.allclose(col.cpu(), z["colors"], rtol=1e-4, atol=1e-5), float((col.cpu() - z["colors"]).abs().max())
+    assert rel_err(feats.grad, z["g_features"]) < 1e-4
+    assert rel_err(nrm.grad, z["g_normals"]) < 1e-3
+    if stage == 1:
+        assert rel_err(light.base.grad, z["g_base"]) < 1e-4
+    # SURVEY 8(d): MLP parameter gradients within 1e-4 of the tensor's largest entry
+    worst = _check_param_grads(tex, z, 1e-4)
+    print("stage %d: worst parameter gradient %s %.2e; entry points %s" % (stage, worst[0], worst[1],
+          {k: v for k, v in calls.items() if "pair" in k}))
+    R.check_status()

@@ -180,3 +180,33 @@ def test_hashgrid_is_trilinear_and_gradient_is_adjoint():
     assert abs(lhs - rhs) < 1e-3 * (abs(lhs) + 1)
     idx = oracle.hashgrid_indices(x, meta)
     assert int(idx.min()) >= 0 and int(idx.max()) < n // 2
+
+
+def test_weight_backward_contraction_modes(monkeypatch):
+    """render_weight.cu:139-151 as the nvcc default (--fmad=true) contracts it vs one rounding per source operation
+    (oracle.C1_FMAD): identical where the chain is well conditioned (both within fp32 rounding of the closed form),
+    different in the saturated regime, where d_alpha is the amplified rounding residue of the running subtraction."""
+    g = torch.Generator().manual_seed(0)
+    n_rays, steps = 64, 48
+    packed = torch.stack([torch.arange(n_rays) * steps, torch.full((n_rays,), steps)], 1).to(torch.int32)
+    gw = torch.randn(n_rays * steps, generator=g)
+
+    def grad(alphas, fmad):
+        monkeypatch.setattr(oracle, "C1_FMAD", fmad)
+        a = alphas.clone().requires_grad_(True)
+        w, _ = oracle.render_weight_from_alpha(a, packed_info=packed)
+        w.backward(gw)
+        return a.grad
+
+    soft = torch.rand(n_rays * steps, generator=g) * 0.2
+    a, b = grad(soft, True), grad(soft, False)
+    assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
+    hard = soft.clone().view(n_rays, steps)
+    hard[:, 20] = 1.0                                     # a saturated sample: everything behind it has T = 0
+    hard = hard.reshape(-1)
+    a, b = grad(hard, True), grad(hard, False)
+    assert float(a.abs().max()) > 1e2 and float(b.abs().max()) > 1e2        # the residue / 1e-10
+    assert float((a - b).abs().max()) > 1.0
+    # in front of the saturated sample both agree with the closed form d w_k / d alpha_j to rounding
+    front = torch.arange(n_rays * steps).view(n_rays, steps)[:, :20].reshape(-1)
+    assert float((a[front] - b[front]).abs().max()) <= 1e-4 * float(a[front].abs().max())
