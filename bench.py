@@ -299,6 +299,10 @@ def roofline_from(summary, steps):
         if name == "rsdf_sdfmlp_fd7_bwd":    # algorithmic: input gradient + weight gradient = 2x forward
             K0, H, S = 3 + 2 * a[0], a[4], a[6]   # (the in-kernel recompute of the hidden layers is not counted)
             return "mfma", 2 * 2.0 * 7 * S * (K0 * H + H * H + H)
+        if name == "rsdf_pair_fwd":          # K, n, N2, out_act: two 128-wide layers (+ the folded narrow output layer)
+            return "mfma", 2.0 * a[1] * (a[0] * 128 + 128 * 128 + 128 * a[2])
+        if name == "rsdf_pair_bwd":          # K, n, g_masked, N2, ...: input + weight gradients = 2x forward (recompute not counted)
+            return "mfma", 2 * 2.0 * a[1] * (a[0] * 128 + 128 * 128 + 128 * a[3])
         if name == "rsdf_linear_fwd":        # ldx, n, K, N, act, ldy
             return "mfma", 2.0 * a[1] * a[2] * a[3]
         if name == "rsdf_linear_bwd_input":  # lddy, n, K, N, act, k0, Kout, lddx
@@ -315,6 +319,8 @@ def roofline_from(summary, steps):
             return 1
         if name in ("rsdf_sdfmlp_fd7_fwd_x2", "rsdf_sdfmlp_fd7_bwd_x2"):
             return 1 if (a and a[0] == 1) else 3
+        if name in ("rsdf_pair_fwd", "rsdf_pair_bwd"):     # two fp16 parts, three products (csrc/mlp_pair.hip)
+            return 3
         return 6
 
     def price(name, v):
@@ -352,6 +358,8 @@ def roofline_from(summary, steps):
             return a[4]
         if name == "rsdf_sdfmlp_fd7_bwd_x2":
             return a[5]
+        if name in ("rsdf_pair_fwd", "rsdf_pair_bwd"):
+            return a[1]
         return a[6] if name.startswith("rsdf_sdfmlp_fd7") else a[0]   # (also the _bf16 names)
 
     best = max(summary.items(), key=lambda kv: kv[1]["ms"])

@@ -98,6 +98,11 @@ def render(rays, P, *, stage, indirect, relighting=False, stratified_u=None, ove
         out["own_secondary"], out["secondary"] = own_secondary, (sri, sts, ste)
         with torch.no_grad():
             sal = a_fn(sts, ste, sri) if sri.numel() else torch.zeros(0)
+            out["sec_alphas_own"] = sal
+            # override["sec_alphas"]: the occlusion pass's alpha VALUES of the implementation under test (no gradient flows
+            # through this pass): at L = 16 the FD normal's 1 / eps and inv_s turn fp32 ulps of the stencil into 1e-3 of an
+            # alpha next to a surface, and tr = 1 - sum w is compared at 1e-4 downstream
+            sal = override.get("sec_alphas", sal)
             sw, _ = render_weight_from_alpha(sal, ray_indices=sri, n_rays=valid.numel())
             sacc = accumulate_along_rays(sw, None, ray_indices=sri, n_rays=valid.numel())
             sdepth = accumulate_along_rays(sw, ((sts + ste) / 2.0)[:, None], ray_indices=sri, n_rays=valid.numel())

@@ -46,6 +46,9 @@ class TrainStep:
         # that nothing else draws from (SURVEY 8e option (a): no traffic).
         grid = getattr(model, "occupancy_grid", None)
         self.sync_free = bool(sync_free)
+        import os
+        if os.environ.get("RSDF_PREFILTER_STREAM", "") == "main":      # A/B knob: the prefilter on the step's own stream
+            prefilter_on_side_stream = False
         self.prefilter_stream = (torch.cuda.Stream(device=dev) if (prefilter_on_side_stream and sync_free
                                                                    and dev.type == "cuda") else None)
         if sync_free:

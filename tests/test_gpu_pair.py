@@ -274,7 +274,8 @@ def test_training_step_skips_the_optimizer_when_the_render_pass_overflows(dev, m
     from rise_sdf_amd.step import build_synthetic_training
     monkeypatch.delenv("RSDF_RANGE_ERROR", raising=False)
     _lib.reset_range_free()
-    model, ts = build_synthetic_training(dev, stage=0, hidden=64, views=3, res=48, indirect=False, curvature=False,
+    # (128-wide: the radiance networks run on the layer-pair kernels)
+    model, ts = build_synthetic_training(dev, stage=0, hidden=128, views=3, res=48, indirect=False, curvature=False,
                                          model_overrides={"train_num_rays": 128, "max_train_num_rays": 256})
     ts.step(0)
     ts.step(1)

@@ -107,9 +107,16 @@ def _run(dev, model, rays, u, P, stage, relighting):
         step = (model.secondary_far_plane - model.secondary_near_plane) / (model.num_samples_per_secondary_ray - 1)
         sec = model.occupancy_grid.sampling(so, sd, alpha_fn=model._alpha_fn(so, sd),
                                             near_plane=model.secondary_near_plane, far_plane=model.secondary_far_plane,
-                                            render_step_size=step, stratified=False)
+                                            render_step_size=step, stratified=False, return_alphas=True)
+        sec, sec_alphas = sec[:3], sec[3]
     cpu = lambda t3: tuple(t.cpu() for t in t3)   # noqa: E731
     ov = {"primary": cpu(prim), "sec_rays": (so.cpu(), sd.cpu()), "secondary": cpu(sec)}
+    big = model.geometry.network.n_neurons > 64
+    if big:
+        # L = 16 / H = 128: the occlusion pass's alphas sit behind the same 1 / eps x inv_s amplifier as the primary ones and
+        # have no stencil override of their own: handed in by VALUE (no gradient flows through that pass) after the
+        # comparison with the oracle's own below
+        ov["sec_alphas"] = sec_alphas.cpu()
     # the primary stencil VALUES of the HIP path (oracle.volume_sdf, sdf7_given): removes the 1/eps amplification of forward
     # ulps, so that the gradients below are held to SURVEY 8(d)'s 1e-4 / 1e-3 instead of a cosine
     ov["sdf7"] = hip_sdf7(model, rays, *ov["primary"])
@@ -137,7 +144,12 @@ def _run(dev, model, rays, u, P, stage, relighting):
     assert torch.allclose(ref["own_sec_rays"][0], so.cpu(), rtol=1e-4, atol=2e-5)
     assert torch.allclose(ref["own_sec_rays"][1], sd.cpu(), rtol=1e-3, atol=1e-3)
     assert _same_up_to_borderline(ref["own_secondary"], ov["secondary"], max(3, ov["secondary"][0].numel() // 500))
-    assert torch.allclose(last["tr"].cpu(), ref["tr"], rtol=1e-4, atol=2e-5)
+    if big:
+        sa_err = (ov["sec_alphas"] - ref["sec_alphas_own"]).abs()
+        print("occlusion-pass alphas, HIP vs the oracle's own: max %.2e, mean %.2e, above 1e-3: %d of %d" %
+              (float(sa_err.max()), float(sa_err.mean()), int((sa_err > 1e-3).sum()), sa_err.numel()))
+        assert float(sa_err.mean()) < 1e-4 and int((sa_err > 1e-2).sum()) <= max(2, sa_err.numel() // 200)
+    assert torch.allclose(last["tr"].cpu(), ref["tr"], rtol=1e-4, atol=2e-5), float((last["tr"].cpu() - ref["tr"]).abs().max())
     assert float(ref["tr"].min()) < 0.5 < float(ref["tr"].max()), "scene must have occluded and unoccluded reflections"
     return out, ref
 
