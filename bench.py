@@ -299,6 +299,8 @@ def roofline_from(summary, steps):
         if name == "rsdf_sdfmlp_fd7_bwd":    # algorithmic: input gradient + weight gradient = 2x forward
             K0, H, S = 3 + 2 * a[0], a[4], a[6]   # (the in-kernel recompute of the hidden layers is not counted)
             return "mfma", 2 * 2.0 * 7 * S * (K0 * H + H * H + H)
+        if name in ("rsdf_pair_fwd16", "rsdf_pair_bwd16"):     # the pair kernels' 16-bit mode: same algorithmic flops, one product
+            return cost(name[:-2], a)
         if name == "rsdf_pair_fwd":          # K, n, N2, out_act: two 128-wide layers (+ the folded narrow output layer)
             return "mfma", 2.0 * a[1] * (a[0] * 128 + 128 * 128 + 128 * a[2])
         if name == "rsdf_pair_bwd":          # K, n, g_masked, N2, ...: input + weight gradients = 2x forward (recompute not counted)
@@ -315,7 +317,7 @@ def roofline_from(summary, steps):
         """MFMA products the kernel EXECUTES per algorithmic fp32 product, on the 16-bit matrix pipe it runs on: the x2
         kernels carry every operand as two fp16 parts and evaluate three partial products (one in the 16-bit mode), the
         round 1-3 kernels and the per-layer kernels three bf16 parts and six, the _bf16 build one."""
-        if name.endswith("_bf16"):
+        if name.endswith("_bf16") or name in ("rsdf_pair_fwd16", "rsdf_pair_bwd16"):
             return 1
         if name in ("rsdf_sdfmlp_fd7_fwd_x2", "rsdf_sdfmlp_fd7_bwd_x2"):
             return 1 if (a and a[0] == 1) else 3
@@ -358,7 +360,7 @@ def roofline_from(summary, steps):
             return a[4]
         if name == "rsdf_sdfmlp_fd7_bwd_x2":
             return a[5]
-        if name in ("rsdf_pair_fwd", "rsdf_pair_bwd"):
+        if name in ("rsdf_pair_fwd", "rsdf_pair_bwd", "rsdf_pair_fwd16", "rsdf_pair_bwd16"):
             return a[1]
         return a[6] if name.startswith("rsdf_sdfmlp_fd7") else a[0]   # (also the _bf16 names)
 

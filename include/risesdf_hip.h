@@ -446,6 +446,17 @@ int rsdf_pair_bwd(const void *x_image, int K, const float *wa, const float *ba, 
                   int ld2, int k1,
                   int x_relu, void *dx_absmax /*nullable, 4 bytes, zeroed by the caller*/, float *dwa,
                   float *dba, float *dwb, float *dbb, void *stream);
+/* The 16-bit mode of the layer-pair kernels (round 6; BASELINE.json configs[4] "bf16 MLP on MFMA", the networks of
+ * configs/split-mixed-occ-tensoir.yaml:93-120 with ``precision: fp16 / bf16``): same arguments, images and fp32 tensors as
+ * rsdf_pair_fwd / rsdf_pair_bwd, but every matrix operand is rounded ONCE to fp16 at its class scale (11 significant bits) and
+ * each product is ONE v_mfma_f32_16x16x32_f16 with fp32 accumulation; only the hi part of an image is read or written. */
+int rsdf_pair_fwd16(const void *x_image, int K, const float *wa, const float *ba, const float *wb, const float *bb, int64_t n,
+                    void *out_image, float *out_rows, const float *w_out, const float *b_out, int N2, int out_act, float *y_out,
+                    int *status, void *stream);
+int rsdf_pair_bwd16(const void *x_image, int K, const float *wa, const float *ba, const float *wb, const float *bb, int64_t n,
+                    const float *g, int g_masked, const float *hb_rows, const float *dz_out, const float *w_out, int N2,
+                    float *dw_out, const void *bound, float *dx, int lddx, int kout, float *dx2, int ld2, int k1, int x_relu,
+                    void *dx_absmax, float *dwa, float *dba, float *dwb, float *dbb, void *stream);
 /* ---- config[4]'s "bf16 MLP on MFMA" (BASELINE.json configs[4]; models/network_utils.py:109-157 at reduced matrix
  * precision): the same entry points with the suffix _bf16.  Same arguments, layouts and fp32 tensors; every matrix
  * operand (weights, activations, gradients) is rounded ONCE to bf16 (round to nearest even) and each k-step is ONE

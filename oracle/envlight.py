@@ -159,7 +159,7 @@ def _tile_pass(V, R, cosc, dtype, TILE=16):
 
 
 def specular_rows(cubemap, roughness, rows, cutoff=0.99, cos_shifts=(0.0,), chunk=256, model_bounds=True,
-                  return_margin=False):
+                  return_margin=False, border=None):
     """The GGX prefilter restricted to the output texels ``rows`` (flat indices into [6RR]): the same elementwise
     arithmetic as ``_specular_weights`` on the same operands, but only the window members of the selected rows are ever
     formed, so the sizes the path runs every step -- R = 512 / 256 / 128, lib/pbr/light.py:177-180 -- fit the CPU.
@@ -169,7 +169,8 @@ def specular_rows(cubemap, roughness, rows, cutoff=0.99, cos_shifts=(0.0,), chun
     (what the dense forms above evaluate; identical at the small resolutions they are used at).
     One result [len(rows), 3] per entry of ``cos_shifts`` (the tests bracket the fp32 window compare), differentiable in
     ``cubemap`` (the backward is the transpose of the same sparse rows: cubemap.cu:300-350).  ``return_margin``: also the
-    rows' smallest |tile test - cutoff| (a row within fp32 rounding of flipping a whole tile)."""
+    rows' smallest |tile test - cutoff| (a row within fp32 rounding of flipping a whole tile).  ``border``: also ``slack``
+    [len(rows), 3], a bound on what the texels with |L.V - cutoff| <= border can move the row's output by."""
     R = cubemap.shape[1]
     dtype = cubemap.dtype
     B = 16 if R >= 64 else (4 if R % 4 == 0 else 1)
@@ -181,10 +182,11 @@ def specular_rows(cubemap, roughness, rows, cutoff=0.99, cos_shifts=(0.0,), chun
         vis, lis, ws, dots, keeps, margins = [], [], [], [], [], []
         for i in range(0, len(rows), chunk):
             V = D[rows[i:i + chunk]]
-            vi, li = _row_candidates(D, V, cosc0 + min(cos_shifts), R, B)
+            low = min(min(cos_shifts), -(border or 0.0))
+            vi, li = _row_candidates(D, V, cosc0 + low, R, B)
             Vs, Ls = V[vi], D[li]
             dot = (Vs * Ls).sum(-1)
-            keep = dot >= cosc0 + min(cos_shifts)
+            keep = dot >= cosc0 + low
             vi, li, Vs, Ls, dot = vi[keep], li[keep], Vs[keep], Ls[keep], dot[keep]
             Hh = Vs + Ls
             Hh = Hh / Hh.norm(dim=-1, keepdim=True).clamp_min(1e-20)
@@ -222,9 +224,22 @@ def specular_rows(cubemap, roughness, rows, cutoff=0.99, cos_shifts=(0.0,), chun
         wsum = torch.zeros(len(rows), dtype=dtype).index_add_(0, vi[m], w[m])
         col = torch.zeros(len(rows), 3, dtype=dtype).index_add(0, vi[m], w[m][:, None] * cubemap.reshape(-1, 3)[li[m]])
         outs.append(col / wsum[:, None])
+    if border is not None:
+        # what the texels within ``border`` of the cutoff can move the row's output by, each taken alone and summed (two
+        # borderline texels of opposite effect cancel in a lo / hi bracket, not in this bound): w_b |c_b - out| / wsum over them,
+        # with the smallest window's wsum
+        with torch.no_grad():
+            mb = ((dot - cosc0).abs() <= border) & keepm.any(0)
+            m_in = (dot >= cosc0 + border) & keepm.all(0)
+            wmin = torch.zeros(len(rows), dtype=dtype).index_add_(0, vi[m_in], w[m_in])
+            eff = w[mb][:, None] * (cubemap.detach().reshape(-1, 3)[li[mb]] - outs[0].detach()[vi[mb]]).abs()
+            slack = torch.zeros(len(rows), 3, dtype=dtype).index_add_(0, vi[mb], eff) / wmin.clamp_min(1e-300)[:, None]
+        extra = (slack,)
+    else:
+        extra = ()
     if return_margin:
-        return outs, (torch.cat(margins) if margins else torch.full((len(rows),), float("inf"), dtype=dtype))
-    return outs
+        return (outs, (torch.cat(margins) if margins else torch.full((len(rows),), float("inf"), dtype=dtype))) + extra
+    return outs if not extra else (outs,) + extra
 
 
 def specular_cubemap(cubemap, roughness, cutoff=0.99, cos_shift=0.0):

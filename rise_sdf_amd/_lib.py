@@ -113,6 +113,9 @@ _SIGNATURES = {
     "rsdf_pair_pack2": [_P, _I, _I, _P, _I, _I, _L, _P, _P, _P],
     "rsdf_pair_unpack": [_P, _L, _P, _P],
     "rsdf_pair_fwd": [_P, _I, _P, _P, _P, _P, _L, _P, _P, _P, _P, _I, _I, _P, _P, _P],
+    "rsdf_pair_fwd16": [_P, _I, _P, _P, _P, _P, _L, _P, _P, _P, _P, _I, _I, _P, _P, _P],
+    "rsdf_pair_bwd16": [_P, _I, _P, _P, _P, _P, _L, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P,
+                        _P],
     "rsdf_pair_bound_from_rows": [_P, _L, _P, _P],
     "rsdf_pair_bound_from_out_layer": [_P, _L, _I, _P, _P, _P, _P],
     "rsdf_pair_bwd": [_P, _I, _P, _P, _P, _P, _L, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P,

@@ -83,18 +83,24 @@ __device__ __forceinline__ float resid_hi(float b, unsigned hi)
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hi), "v"(b));
     return r;
 }
+// NP = 2: v S = hi + lo, three products per fp32 product (the fp32-equivalent default).  NP = 1: the 16-bit mode of a network
+// (``precision: fp16 / bf16`` in its config node; BASELINE.json configs[4] "bf16 MLP on MFMA") -- every matrix operand is rounded
+// ONCE to fp16 at its class scale (11 significant bits, three more than bf16) and a product is ONE v_mfma_f32_16x16x32_f16 with
+// fp32 accumulation; the lo parts of the images are neither written nor read.
+template <int NP = 2>
 __device__ __forceinline__ void split2_pair(float a, float b, unsigned &h, unsigned &l)
 {
     h = pack_f16(a, b);
-    l = pack_f16(resid_lo(a, h), resid_hi(b, h));
+    l = NP == 2 ? pack_f16(resid_lo(a, h), resid_hi(b, h)) : 0u;
 }
+template <int NP = 2>
 __device__ __forceinline__ Frag2 split2_frag(const float *v)
 {
     unsigned h0, h1, h2, h3, l0, l1, l2, l3;
-    split2_pair(v[0], v[1], h0, l0);
-    split2_pair(v[2], v[3], h1, l1);
-    split2_pair(v[4], v[5], h2, l2);
-    split2_pair(v[6], v[7], h3, l3);
+    split2_pair<NP>(v[0], v[1], h0, l0);
+    split2_pair<NP>(v[2], v[3], h1, l1);
+    split2_pair<NP>(v[4], v[5], h2, l2);
+    split2_pair<NP>(v[6], v[7], h3, l3);
     Frag2 f;
     f.h = u32x4{h0, h1, h2, h3};
     f.l = u32x4{l0, l1, l2, l3};
@@ -104,10 +110,13 @@ __device__ __forceinline__ f32x4 mma16(u32x4 a, u32x4 b, f32x4 c)
 {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
+template <int NP = 2>
 __device__ __forceinline__ f32x4 mma3q(const Frag2 &a, const Frag2 &b, f32x4 c)     // small terms first
 {
-    c = mma16(a.l, b.h, c);
-    c = mma16(a.h, b.l, c);
+    if (NP == 2) {
+        c = mma16(a.l, b.h, c);
+        c = mma16(a.h, b.l, c);
+    }
     c = mma16(a.h, b.h, c);
     return c;
 }
@@ -151,15 +160,17 @@ __device__ __forceinline__ LaneQ lane_consts(int w, int lane)
     return c;
 }
 // B fragment of a layer product: lane (k-group g, sample row 16 rh + c16) reads columns 32 kb + 8 g .. + 7
+template <int NP = 2>
 __device__ __forceinline__ Frag2 rowq(const unsigned char *img, int kb, int rh, const LaneQ &c)
 {
     const unsigned char *p = img + c.row + kb * (4 * QCS) + rh * 256;
     Frag2 f;
     f.h = ld128(p);
-    f.l = ld128(p + PART);
+    f.l = NP == 2 ? ld128(p + PART) : u32x4{0u, 0u, 0u, 0u};
     return f;
 }
 // fragment whose k dimension is the tile's 32 ROWS: lane (rows 8 g .. 8 g + 7, column 16 ft + c16)
+template <int NP = 2>
 __device__ __forceinline__ Frag2 trfq(const unsigned char *img, int ft, const LaneQ &c, int part = PART)
 {
     const unsigned char *a0 = img + c.tr0 + ft * (2 * QCS), *a1 = img + c.tr1 + ft * (2 * QCS);
@@ -168,30 +179,37 @@ __device__ __forceinline__ Frag2 trfq(const unsigned char *img, int ft, const La
     tr64(a0, x0, x1);
     tr64(a1, y0, y1);
     f.h = u32x4{x0, x1, y0, y1};
-    tr64(a0 + part, x0, x1);
-    tr64(a1 + part, y0, y1);
-    f.l = u32x4{x0, x1, y0, y1};
+    if (NP == 2) {
+        tr64(a0 + part, x0, x1);
+        tr64(a1 + part, y0, y1);
+        f.l = u32x4{x0, x1, y0, y1};
+    } else {
+        f.l = u32x4{0u, 0u, 0u, 0u};
+    }
     return f;
 }
 // this wave's 16 x 16 result (columns 16 w + 4 g + r, sample row 16 rh + c16), already scaled -> split once -> image
+template <int NP = 2>
 __device__ __forceinline__ void store_q(unsigned char *img, int rh, const LaneQ &c, const f32x4 &v)
 {
     unsigned h0, l0, h1, l1;
-    split2_pair(v[0], v[1], h0, l0);
-    split2_pair(v[2], v[3], h1, l1);
+    split2_pair<NP>(v[0], v[1], h0, l0);
+    split2_pair<NP>(v[2], v[3], h1, l1);
     unsigned char *p = img + c.st + rh * 256;
     *reinterpret_cast<uint2 *>(p) = uint2{h0, h1};
-    *reinterpret_cast<uint2 *>(p + PART) = uint2{l0, l1};
+    if (NP == 2) *reinterpret_cast<uint2 *>(p + PART) = uint2{l0, l1};
 }
 // one tile (16 KB, linear) by LDS-DMA: 16 instructions of 1 KB, two per wave
 // (block ws of a part = chunks 2 ws, 2 ws + 1 = columns 16 ws .. 16 ws + 15: blocks past the input's last 32-column group hold
 // zeros that nothing reads -- K = 84: 12 of 16 KB)
+template <int NP = 2>
 __device__ __forceinline__ void dma_tile(unsigned char *img, const unsigned char *x, int64_t tile, int ws, int lane, int kba)
 {
     if (ws >= 2 * kba) return;
     const unsigned char *tb = x + tile * IMG + lane * 16;
     __builtin_amdgcn_global_load_lds((glob_void *)(tb + ws * 1024), (lds_void *)(img + ws * 1024), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((glob_void *)(tb + (ws + 8) * 1024), (lds_void *)(img + (ws + 8) * 1024), 16, 0, 0);
+    if (NP == 2)
+        __builtin_amdgcn_global_load_lds((glob_void *)(tb + (ws + 8) * 1024), (lds_void *)(img + (ws + 8) * 1024), 16, 0, 0);
 }
 // 2^e with |v| 2^e < 2^14 for every |v| <= bound (bound = 0, inf or nan: 1)
 __device__ __forceinline__ float grad_scale(float bound)
@@ -235,7 +253,7 @@ struct PairArgs {
 // MASKED (backward only): g is already dz_b, so hb is not recomputed and Wb's own fragments are not held.
 // TOP (backward, MASKED): the pair under the network's narrow output layer -- g is formed from dz_out, the mask comes from the
 // forward's hb rows, dW_out is accumulated here (a variant of its own: the pairs below keep the lean register budget)
-template <bool BWD, bool MASKED, bool TOP = false>
+template <bool BWD, bool MASKED, bool TOP = false, int NP = 2>
 __global__ void __launch_bounds__(NTHR, 1)
 pair_kernel(const PairArgs a)
 {
@@ -262,7 +280,7 @@ pair_kernel(const PairArgs a)
 #pragma unroll
             for (int j = 0; j < 8; ++j) bad0 |= !(fabsf(v[j]) < 65504.0f);
         }
-        waf[kb] = split2_frag(v);                                                   // Wa[fw][k]
+        waf[kb] = split2_frag<NP>(v);                                                   // Wa[fw][k]
         if (!MASKED) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = a.wb[(size_t)fw * H + 32 * kb + 8 * g + j] * SW;
@@ -270,12 +288,12 @@ pair_kernel(const PairArgs a)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) bad0 |= !(fabsf(v[j]) < 65504.0f);
             }
-            wbf[kb] = split2_frag(v);                                               // Wb[fw][k]
+            wbf[kb] = split2_frag<NP>(v);                                               // Wb[fw][k]
         }
         if (BWD) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = fw < K ? a.wa[(size_t)(32 * kb + 8 * g + j) * K + fw] * SW : 0.0f;
-            wat[kb] = split2_frag(v);                                               // Wa[n][fw]: dx column fw
+            wat[kb] = split2_frag<NP>(v);                                               // Wa[n][fw]: dx column fw
         }
     }
     float *s_wo = reinterpret_cast<float *>(smem + (BWD ? BWD_WO : FWD_WO));
@@ -292,7 +310,7 @@ pair_kernel(const PairArgs a)
             for (int j = 0; j < 8; ++j) v[j] = c16 < a.n_out ? a.w_out[(size_t)c16 * H + 32 * kb + 8 * g + j] * SW : 0.0f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) bad0 |= !(fabsf(v[j]) < 65504.0f);
-            wof[kb] = split2_frag(v);
+            wof[kb] = split2_frag<NP>(v);
         }
     }
     f32x4 bar, bbr;                                // biases (x T) of features 16 w + 4 g + r
@@ -311,10 +329,10 @@ pair_kernel(const PairArgs a)
         for (int e = threadIdx.x; e < H * H; e += NTHR) {
             const int f = e & (H - 1), k = e >> 7;                                  // coalesced read of Wb[k][f]
             unsigned hh, ll;
-            split2_pair(a.wb[(size_t)k * H + f] * SW, 0.0f, hh, ll);
+            split2_pair<NP>(a.wb[(size_t)k * H + f] * SW, 0.0f, hh, ll);
             const int idx = f * H + ((((k >> 3) ^ (f & 15)) << 3) | (k & 7));
             e16[idx] = (unsigned short)(hh & 0xffffu);
-            e16[idx + WT_PART / 2] = (unsigned short)(ll & 0xffffu);
+            if (NP == 2) e16[idx + WT_PART / 2] = (unsigned short)(ll & 0xffffu);
         }
         // gradient-image scales: |dz_b| <= bound, |dz_a| <= max_k sum_n |Wb[n][k]| bound
         float cs = 0.0f;
@@ -346,7 +364,7 @@ pair_kernel(const PairArgs a)
     float dxmax = 0.0f;
     bool bad = bad0;
 
-    if ((int64_t)blockIdx.x < a.tiles) dma_tile(smem + XI, a.x, (int64_t)blockIdx.x, ws, lane, kba);
+    if ((int64_t)blockIdx.x < a.tiles) dma_tile<NP>(smem + XI, a.x, (int64_t)blockIdx.x, ws, lane, kba);
     int parity = 0;
     for (int64_t ti = blockIdx.x; ti < a.tiles; ti += gridDim.x) {
         const int64_t s0 = ti * 32;
@@ -371,9 +389,9 @@ pair_kernel(const PairArgs a)
                             const float dq = row_ok[rh] ? a.dz_out[rowc * a.n_out + q] : 0.0f;
                             if (a.dw_out != nullptr && ws == 0 && g == 0) {    // dz_out as a 16-column image (x GZ)
                                 unsigned hh, ll;
-                                split2_pair(dq * GZ, 0.0f, hh, ll);
+                                split2_pair<NP>(dq * GZ, 0.0f, hh, ll);
                                 pz[q] = (unsigned short)(hh & 0xffffu);
-                                pz[DZO_PART / 2 + q] = (unsigned short)(ll & 0xffffu);
+                                if (NP == 2) pz[DZO_PART / 2 + q] = (unsigned short)(ll & 0xffffu);
                             }
                             const float4 wq = *reinterpret_cast<const float4 *>(s_wo + q * H + 16 * w + 4 * g);
                             acc[0] = fmaf(dq, wq.x, acc[0]);
@@ -397,12 +415,12 @@ pair_kernel(const PairArgs a)
                         // dW_out += dz_out^T hb needs hb as a k = rows operand: its image goes where dz_a will go later in this
                         // tile (free until barrier (3))
                         const f32x4 hs = row_ok[rh] ? f32x4{m.x * SA, m.y * SA, m.z * SA, m.w * SA} : f32x4{0.f, 0.f, 0.f, 0.f};
-                        store_q(smem + DZ1, rh, lc, hs);
+                        store_q<NP>(smem + DZ1, rh, lc, hs);
                     }
                 }
             }
         }
-        if (ti + gridDim.x < a.tiles) dma_tile(smem + XI + parity * IMG, a.x, ti + gridDim.x, ws, lane, kba);
+        if (ti + gridDim.x < a.tiles) dma_tile<NP>(smem + XI + parity * IMG, a.x, ti + gridDim.x, ws, lane, kba);
         // ---- layer a: C = T za -> SA ha
         f32x4 ha[2];
 #pragma unroll
@@ -410,14 +428,14 @@ pair_kernel(const PairArgs a)
             f32x4 acc = bar;
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb)
-                if (kb < kba) acc = mma3q(waf[kb], rowq(xi, kb, rh, lc), acc);
+                if (kb < kba) acc = mma3q<NP>(waf[kb], rowq<NP>(xi, kb, rh, lc), acc);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 ha[rh][r] = fmaxf(acc[r], 0.0f) * (SA / T);
                 // (range guard at the split point: fmaxf would swallow the NaN an overflowed operand makes downstream)
                 if (!BWD) bad |= !(acc[r] < 65504.0f * (T / SA));
             }
-            store_q(smem + H1I, rh, lc, ha[rh]);
+            store_q<NP>(smem + H1I, rh, lc, ha[rh]);
         }
         lds_barrier();                         // (2) H1 image complete
         // ---- layer b: C = T zb
@@ -426,7 +444,7 @@ pair_kernel(const PairArgs a)
             f32x4 acc = bbr;
             if (!MASKED) {                     // (backward on an already masked gradient: hb is not needed at all)
 #pragma unroll
-                for (int kb = 0; kb < KB; ++kb) acc = mma3q(wbf[kb], rowq(smem + H1I, kb, rh, lc), acc);
+                for (int kb = 0; kb < KB; ++kb) acc = mma3q<NP>(wbf[kb], rowq<NP>(smem + H1I, kb, rh, lc), acc);
             }
             if (!BWD) {
                 f32x4 hb;
@@ -435,7 +453,7 @@ pair_kernel(const PairArgs a)
                     hb[r] = fmaxf(acc[r], 0.0f) * (SA / T);
                     bad |= !(acc[r] < 65504.0f * (T / SA));
                 }
-                if (a.out_img != nullptr || a.n_out > 0) store_q(smem + DZI, rh, lc, hb);
+                if (a.out_img != nullptr || a.n_out > 0) store_q<NP>(smem + DZI, rh, lc, hb);
                 const int64_t row = s0 + 16 * rh + c16;
                 if (a.out_rows != nullptr && row < a.n)
                     *reinterpret_cast<float4 *>(a.out_rows + row * H + 16 * w + 4 * g) =
@@ -449,17 +467,17 @@ pair_kernel(const PairArgs a)
                     gbbp[r] += dz[rh][r];
                     dzs[r] = dz[rh][r] * G2;
                 }
-                store_q(smem + DZI, rh, lc, dzs);
+                store_q<NP>(smem + DZI, rh, lc, dzs);
             }
         }
         if (TOP && a.dw_out != nullptr)            // dW_out += dz_out^T hb (k = the 32 rows): both images were written before (2)
-            gwo = mma3q(trfq(smem + DZO, 0, lc, DZO_PART), trfq(smem + DZ1, w, lc), gwo);
+            gwo = mma3q<NP>(trfq<NP>(smem + DZO, 0, lc, DZO_PART), trfq<NP>(smem + DZ1, w, lc), gwo);
         lds_barrier();                         // (3) dz_b image (forward: the output image) complete
         if (!BWD) {
             if (a.n_out > 0 && ws < 2) {       // y = act(W_out hb + b_out): waves 0 / 1 take the tile's row halves, hb from its image
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int kb = 0; kb < KB; ++kb) acc = mma3q(wof[kb], rowq(smem + DZI, kb, ws, lc), acc);
+                for (int kb = 0; kb < KB; ++kb) acc = mma3q<NP>(wof[kb], rowq<NP>(smem + DZI, kb, ws, lc), acc);
                 const int64_t row = s0 + 16 * ws + c16;
                 if (row < a.n) {
 #pragma unroll
@@ -478,7 +496,7 @@ pair_kernel(const PairArgs a)
                 unsigned char *ob = a.out_img + ti * IMG + threadIdx.x * 16;
                 const unsigned char *ib = smem + DZI + threadIdx.x * 16;
                 *reinterpret_cast<u32x4 *>(ob) = ld128(ib);
-                *reinterpret_cast<u32x4 *>(ob + NTHR * 16) = ld128(ib + NTHR * 16);
+                if (NP == 2) *reinterpret_cast<u32x4 *>(ob + NTHR * 16) = ld128(ib + NTHR * 16);      // (NTHR * 16 = PART: the lo part)
             }
             continue;                          // (the next tile's barrier (1) orders these reads before its stores)
         }
@@ -490,13 +508,13 @@ pair_kernel(const PairArgs a)
             for (int kb = 0; kb < KB; ++kb) {
                 const int u = ((4 * kb + g) ^ c16) << 4;
                 wbt[kb].h = ld128(wt + u);
-                wbt[kb].l = ld128(wt + WT_PART + u);
+                wbt[kb].l = NP == 2 ? ld128(wt + WT_PART + u) : u32x4{0u, 0u, 0u, 0u};
             }
 #pragma unroll
             for (int rh = 0; rh < 2; ++rh) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int kb = 0; kb < KB; ++kb) acc = mma3q(wbt[kb], rowq(smem + DZI, kb, rh, lc), acc);
+                for (int kb = 0; kb < KB; ++kb) acc = mma3q<NP>(wbt[kb], rowq<NP>(smem + DZI, kb, rh, lc), acc);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     dz[rh][r] = ha[rh][r] > 0.0f ? acc[r] * k_dz1 : 0.0f;              // x G1
@@ -505,12 +523,12 @@ pair_kernel(const PairArgs a)
             }
         }
         {
-            const Frag2 af = trfq(smem + DZI, w, lc);
+            const Frag2 af = trfq<NP>(smem + DZI, w, lc);
 #pragma unroll
-            for (int n = 0; n < H / 16; ++n) gwb[n] = mma3q(af, trfq(smem + H1I, n, lc), gwb[n]);       // x G2 SA
+            for (int n = 0; n < H / 16; ++n) gwb[n] = mma3q<NP>(af, trfq<NP>(smem + H1I, n, lc), gwb[n]);       // x G2 SA
         }
-        store_q(smem + DZ1, 0, lc, dz[0]);
-        store_q(smem + DZ1, 1, lc, dz[1]);
+        store_q<NP>(smem + DZ1, 0, lc, dz[0]);
+        store_q<NP>(smem + DZ1, 1, lc, dz[1]);
         lds_barrier();                         // (4) dz_a image complete
         // ---- layer a backward: dx slab (columns 16 w .. 16 w + 15, all 32 rows); dWa += dz_a^T X
         if (a.dx != nullptr && 16 * ws < a.kout) {
@@ -518,7 +536,7 @@ pair_kernel(const PairArgs a)
             for (int rh = 0; rh < 2; ++rh) {
                 f32x4 dx = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int kb = 0; kb < KB; ++kb) dx = mma3q(wat[kb], rowq(smem + DZ1, kb, rh, lc), dx);
+                for (int kb = 0; kb < KB; ++kb) dx = mma3q<NP>(wat[kb], rowq<NP>(smem + DZ1, kb, rh, lc), dx);
                 const int64_t row = s0 + 16 * rh + c16;
                 const int col = 16 * w + 4 * g;
                 float o[4];
@@ -550,10 +568,10 @@ pair_kernel(const PairArgs a)
             }
         }
         {
-            const Frag2 af = trfq(smem + DZ1, w, lc);
+            const Frag2 af = trfq<NP>(smem + DZ1, w, lc);
 #pragma unroll
             for (int ct = 0; ct < H / 16; ++ct)
-                if (ct < cta) gwa[ct] = mma3q(af, trfq(xi, ct, lc), gwa[ct]);                          // x G1 SA
+                if (ct < cta) gwa[ct] = mma3q<NP>(af, trfq<NP>(xi, ct, lc), gwa[ct]);                          // x G1 SA
         }
         // no barrier: the next tile's barrier (1) separates these reads from the DMA that overwrites this X image
     }
@@ -744,9 +762,9 @@ int rsdf_pair_unpack(const void *image, int64_t n, float *rows, void *stream)
     RSDF_RETURN_LAUNCH();
 }
 
-int rsdf_pair_fwd(const void *x_image, int K, const float *wa, const float *ba, const float *wb, const float *bb, int64_t n,
-                  void *out_image, float *out_rows, const float *w_out, const float *b_out, int N2, int out_act, float *y_out,
-                  int *status, void *stream)
+static int pair_fwd_impl(int parts, const void *x_image, int K, const float *wa, const float *ba, const float *wb, const float *bb,
+                         int64_t n, void *out_image, float *out_rows, const float *w_out, const float *b_out, int N2, int out_act,
+                         float *y_out, int *status, void *stream)
 {
     RSDF_CHECK_ARG(K >= 1 && K <= 128, "pair_fwd: K must be in [1,128]");
     RSDF_CHECK_ARG(out_image != nullptr || out_rows != nullptr || y_out != nullptr, "pair_fwd: no output");
@@ -763,10 +781,31 @@ int rsdf_pair_fwd(const void *x_image, int K, const float *wa, const float *ba, 
     a.out_rows = out_rows;
     a.status = status;
     if (y_out != nullptr) a.w_out = w_out, a.b_out = b_out, a.n_out = N2, a.out_act = out_act, a.y_out = y_out;
-    if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(pair_kernel<false, false>), LDS_FWD)) return rc;
-    const unsigned grid = (unsigned)(a.tiles < 256 ? a.tiles : 256);
-    pair_kernel<false, false><<<grid, NTHR, LDS_FWD, (hipStream_t)stream>>>(a);
+    // (persistent workgroups, one per CU; the 16-bit forward needs 108 registers and 68 KB of LDS: two fit a CU)
+    const int64_t wgs = parts == 1 ? 512 : 256;
+    const unsigned grid = (unsigned)(a.tiles < wgs ? a.tiles : wgs);
+    if (parts == 1) {
+        if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(pair_kernel<false, false, false, 1>), LDS_FWD)) return rc;
+        pair_kernel<false, false, false, 1><<<grid, NTHR, LDS_FWD, (hipStream_t)stream>>>(a);
+    } else {
+        if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(pair_kernel<false, false>), LDS_FWD)) return rc;
+        pair_kernel<false, false><<<grid, NTHR, LDS_FWD, (hipStream_t)stream>>>(a);
+    }
     RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_pair_fwd(const void *x_image, int K, const float *wa, const float *ba, const float *wb, const float *bb, int64_t n,
+                  void *out_image, float *out_rows, const float *w_out, const float *b_out, int N2, int out_act, float *y_out,
+                  int *status, void *stream)
+{
+    return pair_fwd_impl(2, x_image, K, wa, ba, wb, bb, n, out_image, out_rows, w_out, b_out, N2, out_act, y_out, status, stream);
+}
+
+int rsdf_pair_fwd16(const void *x_image, int K, const float *wa, const float *ba, const float *wb, const float *bb, int64_t n,
+                    void *out_image, float *out_rows, const float *w_out, const float *b_out, int N2, int out_act, float *y_out,
+                    int *status, void *stream)
+{
+    return pair_fwd_impl(1, x_image, K, wa, ba, wb, bb, n, out_image, out_rows, w_out, b_out, N2, out_act, y_out, status, stream);
 }
 
 int rsdf_pair_bound_from_rows(const float *g, int64_t count, void *bound, void *stream)
@@ -791,10 +830,10 @@ int rsdf_pair_bound_from_out_layer(const float *dz_out, int64_t n, int N2, const
     RSDF_RETURN_LAUNCH();
 }
 
-int rsdf_pair_bwd(const void *x_image, int K, const float *wa, const float *ba, const float *wb, const float *bb, int64_t n,
-                  const float *g, int g_masked, const float *hb_rows, const float *dz_out, const float *w_out, int N2,
-                  float *dw_out, const void *bound, float *dx, int lddx, int kout, float *dx2, int ld2, int k1, int x_relu,
-                  void *dx_absmax, float *dwa, float *dba, float *dwb, float *dbb, void *stream)
+static int pair_bwd_impl(int parts, const void *x_image, int K, const float *wa, const float *ba, const float *wb, const float *bb, int64_t n,
+                         const float *g, int g_masked, const float *hb_rows, const float *dz_out, const float *w_out, int N2,
+                         float *dw_out, const void *bound, float *dx, int lddx, int kout, float *dx2, int ld2, int k1, int x_relu,
+                         void *dx_absmax, float *dwa, float *dba, float *dwb, float *dbb, void *stream)
 {
     RSDF_CHECK_ARG(dx2 == nullptr || (dx != nullptr && k1 >= 4 && (k1 & 3) == 0 && k1 < kout && ld2 >= kout - k1),
                    "pair_bwd: the second dx output needs dx, 0 < k1 < kout, k1 a multiple of 4, ld2 >= kout - k1");
@@ -817,17 +856,41 @@ int rsdf_pair_bwd(const void *x_image, int K, const float *wa, const float *ba, 
     a.dx_absmax = reinterpret_cast<unsigned *>(dx_absmax);
     a.dwa = dwa, a.dba = dba, a.dwb = dwb, a.dbb = dbb;
     const unsigned grid = (unsigned)(a.tiles < 256 ? a.tiles : 256);
-    if (a.dz_out != nullptr) {
-        if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(pair_kernel<true, true, true>), LDS_BWD)) return rc;
-        pair_kernel<true, true, true><<<grid, NTHR, LDS_BWD, (hipStream_t)stream>>>(a);
-    } else if (a.g_masked) {
-        if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(pair_kernel<true, true>), LDS_BWD)) return rc;
-        pair_kernel<true, true><<<grid, NTHR, LDS_BWD, (hipStream_t)stream>>>(a);
-    } else {
-        if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(pair_kernel<true, false>), LDS_BWD)) return rc;
-        pair_kernel<true, false><<<grid, NTHR, LDS_BWD, (hipStream_t)stream>>>(a);
-    }
+#define RSDF_PAIR_BWD_LAUNCH(NPP)                                                                                                  \
+    do {                                                                                                                          \
+        if (a.dz_out != nullptr) {                                                                                                \
+            if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(pair_kernel<true, true, true, NPP>), LDS_BWD)) return rc;   \
+            pair_kernel<true, true, true, NPP><<<grid, NTHR, LDS_BWD, (hipStream_t)stream>>>(a);                                  \
+        } else if (a.g_masked) {                                                                                                  \
+            if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(pair_kernel<true, true, false, NPP>), LDS_BWD)) return rc;  \
+            pair_kernel<true, true, false, NPP><<<grid, NTHR, LDS_BWD, (hipStream_t)stream>>>(a);                                 \
+        } else {                                                                                                                  \
+            if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(pair_kernel<true, false, false, NPP>), LDS_BWD)) return rc; \
+            pair_kernel<true, false, false, NPP><<<grid, NTHR, LDS_BWD, (hipStream_t)stream>>>(a);                                \
+        }                                                                                                                         \
+    } while (0)
+    if (parts == 1) RSDF_PAIR_BWD_LAUNCH(1);
+    else RSDF_PAIR_BWD_LAUNCH(2);
+#undef RSDF_PAIR_BWD_LAUNCH
     RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_pair_bwd(const void *x_image, int K, const float *wa, const float *ba, const float *wb, const float *bb, int64_t n,
+                  const float *g, int g_masked, const float *hb_rows, const float *dz_out, const float *w_out, int N2,
+                  float *dw_out, const void *bound, float *dx, int lddx, int kout, float *dx2, int ld2, int k1, int x_relu,
+                  void *dx_absmax, float *dwa, float *dba, float *dwb, float *dbb, void *stream)
+{
+    return pair_bwd_impl(2, x_image, K, wa, ba, wb, bb, n, g, g_masked, hb_rows, dz_out, w_out, N2, dw_out, bound, dx, lddx, kout,
+                            dx2, ld2, k1, x_relu, dx_absmax, dwa, dba, dwb, dbb, stream);
+}
+
+int rsdf_pair_bwd16(const void *x_image, int K, const float *wa, const float *ba, const float *wb, const float *bb, int64_t n,
+                    const float *g, int g_masked, const float *hb_rows, const float *dz_out, const float *w_out, int N2,
+                    float *dw_out, const void *bound, float *dx, int lddx, int kout, float *dx2, int ld2, int k1, int x_relu,
+                    void *dx_absmax, float *dwa, float *dba, float *dwb, float *dbb, void *stream)
+{
+    return pair_bwd_impl(1, x_image, K, wa, ba, wb, bb, n, g, g_masked, hb_rows, dz_out, w_out, N2, dw_out, bound, dx, lddx, kout,
+                            dx2, ld2, k1, x_relu, dx_absmax, dwa, dba, dwb, dbb, stream);
 }
 
 }  // extern "C"

@@ -921,9 +921,11 @@ class _MLPPairChain(torch.autograd.Function):
     network: ~2.5 KB forward + ~4 KB backward against 3.9 + 8 with one kernel per layer."""
 
     @staticmethod
-    def forward(ctx, x, x2, dx_cols, acts, *wb):
+    def forward(ctx, x, x2, dx_cols, acts, parts, *wb):
         """``x2`` (nullable): the network's input is cat([x, x2], -1) (models/texture.py:299-313: [feature, encoding]) and is
-        never materialised -- rsdf_pair_pack2 writes the pair image from the two sources."""
+        never materialised -- rsdf_pair_pack2 writes the pair image from the two sources.  ``parts``: 2 = fp32-equivalent (two
+        fp16 parts, three products), 1 = the network's 16-bit mode (``precision: fp16 / bf16``: operands rounded once to fp16,
+        one product; rsdf_pair_fwd16 / _bwd16)."""
         xf = _f32c(x)
         xf2 = None if x2 is None else _f32c(x2)
         ws = [_f32c(t) for t in wb[0::2]]
@@ -963,10 +965,11 @@ class _MLPPairChain(torch.autograd.Function):
             last = p == nh // 2 - 1
             out_img = None if last else torch.empty(img_bytes, dtype=torch.uint8, device=dev)
             lf = last and fold_fwd
-            check(lib().rsdf_pair_fwd(ptr(imgs[p]), K if p == 0 else 128, ptr(ws[2 * p]), ptr(bs[2 * p]), ptr(ws[2 * p + 1]),
-                                      ptr(bs[2 * p + 1]), n, ptr(out_img), ptr(h_last) if last else None,
-                                      ptr(ws[-1]) if lf else None, ptr(bs[-1]) if lf else None, N2 if lf else 0,
-                                      acts[-1] if lf else 0, ptr(y) if lf else None, stt, st), "pair_fwd")
+            pair_fwd = lib().rsdf_pair_fwd16 if parts == 1 else lib().rsdf_pair_fwd
+            check(pair_fwd(ptr(imgs[p]), K if p == 0 else 128, ptr(ws[2 * p]), ptr(bs[2 * p]), ptr(ws[2 * p + 1]),
+                           ptr(bs[2 * p + 1]), n, ptr(out_img), ptr(h_last) if last else None,
+                           ptr(ws[-1]) if lf else None, ptr(bs[-1]) if lf else None, N2 if lf else 0,
+                           acts[-1] if lf else 0, ptr(y) if lf else None, stt, st), "pair_fwd")
             if not last:
                 imgs.append(out_img)
         if not fold_fwd:
@@ -974,13 +977,14 @@ class _MLPPairChain(torch.autograd.Function):
                   "linear_fwd")
         ctx.save_for_backward(*imgs, h_last, y, *ws, *bs)
         ctx.n_imgs, ctx.nh, ctx.K, ctx.acts, ctx.dx_cols, ctx.fold = len(imgs), nh, K, tuple(acts), dx_cols, fold
-        ctx.K1 = K1
+        ctx.K1, ctx.parts = K1, parts
         return y
 
     @staticmethod
     def backward(ctx, gy):
         sv = ctx.saved_tensors
         ni, nh, K = ctx.n_imgs, ctx.nh, ctx.K
+        pair_bwd = lib().rsdf_pair_bwd16 if ctx.parts == 1 else lib().rsdf_pair_bwd
         imgs, h_last, y = sv[:ni], sv[ni], sv[ni + 1]
         ws, bs = sv[ni + 2:ni + 2 + nh + 1], sv[ni + 3 + nh:]
         n = h_last.shape[0]
@@ -1045,7 +1049,7 @@ class _MLPPairChain(torch.autograd.Function):
             second = dx_second if (p == 0 and need_dx) else None
             # (the top pair takes its ReLU mask from the forward's own h_last rows: no hb recompute, the lean kernel variant)
             top_fold = masked == 0 and fold
-            check(lib().rsdf_pair_bwd(ptr(imgs[p]), Kp, ptr(ws[2 * p]), ptr(bs[2 * p]), ptr(ws[2 * p + 1]), ptr(bs[2 * p + 1]), n,
+            check(pair_bwd(ptr(imgs[p]), Kp, ptr(ws[2 * p]), ptr(bs[2 * p]), ptr(ws[2 * p + 1]), ptr(bs[2 * p + 1]), n,
                                       None if top_fold else ptr(gcur), masked, ptr(h_last) if masked == 0 else None,
                                       ptr(dzo) if top_fold else None, ptr(ws[-1]) if top_fold else None, N2 if top_fold else 0,
                                       ptr(grads[-2]) if top_fold else None,
@@ -1060,21 +1064,25 @@ class _MLPPairChain(torch.autograd.Function):
             gcur, masked = dx, 1
         K1 = ctx.K1
         if dx_in is not None and need_dx and dx_second is not None:
-            return (dx_in, dx_second, None, None, *grads)
+            return (dx_in, dx_second, None, None, None, *grads)
         d1 = dx_in[:, :K1] if (dx_in is not None and need1) else None
         d2 = dx_in[:, K1:] if (dx_in is not None and need2 and K1 < K) else None
         if d1 is not None and dx_in.shape[1] == K1:
             d1 = dx_in
-        return (d1, d2, None, None, *grads)
+        return (d1, d2, None, None, None, *grads)
 
 
 def pair_chain_ok(x, ws, bs, acts, precision, x2=None):
     """The radiance networks of models/texture.py:237-327 as the reference builds them: 2 or 4 hidden layers of 128 with ReLU
-    and biases, at most 128 inputs, fp32.  ``RSDF_PAIR=0`` keeps one kernel per layer."""
+    and biases, at most 128 inputs; fp32 (two fp16 parts) or the network's 16-bit mode (``precision: bf16 / fp16``: one fp16
+    part, round 6).  ``RSDF_PAIR=0`` keeps one kernel per layer, ``RSDF_PAIR16=0`` only for the 16-bit mode."""
     relu = L.ACT_IDS["relu"]
     nh = len(ws) - 1
     K = x.shape[1] + (0 if x2 is None else x2.shape[1]) if x.dim() == 2 else -1
-    return (precision in (None, "fp32") and os.environ.get("RSDF_PAIR", "1") != "0" and not L.range_free("pair") and nh in (2, 4)
+    if precision in ("bf16", "fp16") and os.environ.get("RSDF_PAIR16", "1") == "0":      # A/B: the per-layer _bf16 kernels
+        return False
+    return (precision in (None, "fp32", "bf16", "fp16") and os.environ.get("RSDF_PAIR", "1") != "0" and not L.range_free("pair")
+            and nh in (2, 4)
             and os.environ.get("RSDF_LAYER_BWD") != "split"
             and x.dim() == 2 and x.shape[0] > 0 and 1 <= K <= 128 and ws[0].shape == (128, K)
             and (x2 is None or (x2.dim() == 2 and x2.shape[0] == x.shape[0] and x2.is_cuda))
@@ -1091,7 +1099,8 @@ def mlp_chain(x, layers, acts, dx_cols=None, precision="fp32", x2=None):
         flat += [w, b]
     act_ids = tuple(L.ACT_IDS[a] if not isinstance(a, int) else a for a in acts)
     if pair_chain_ok(x, [w for w, _ in layers], [b for _, b in layers], act_ids, precision, x2):
-        return _MLPPairChain.apply(x.float(), None if x2 is None else x2.float(), dx_cols, act_ids, *flat)
+        return _MLPPairChain.apply(x.float(), None if x2 is None else x2.float(), dx_cols, act_ids,
+                                   1 if precision in ("bf16", "fp16") else 2, *flat)
     if x2 is not None:
         x = torch.cat([x, x2.to(x.dtype)], dim=-1)
     return _MLPChain.apply(x, dx_cols, act_ids, precision, *flat)

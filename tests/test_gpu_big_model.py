@@ -13,6 +13,7 @@ oracle's OWN alphas before they are handed in, and the entry points are asserted
 import pytest
 import torch
 
+from oracle import split_mixed_occ as OS
 from oracle import texture as OT
 from helpers import camera_rays, rel_err, sphere_binary
 from test_gpu_model import assert_grads_tight
@@ -84,7 +85,7 @@ def _assert_shipped_kernels(fwd_calls, bwd_calls, n_pair_networks):
         assert old not in bwd_calls and old not in fwd_calls, (old, fwd_calls, bwd_calls)
 
 
-def _run_big(dev, stage1, n_side, out_key, keys):
+def _run_big(dev, stage1, n_side, out_key, keys, mlp_tol=3e-4, table_tol=1e-3):
     import rise_sdf_amd as R
     model = build_big(dev, stage1)
     rays = camera_rays(n_side, n_side, seed=2)
@@ -99,7 +100,19 @@ def _run_big(dev, stage1, n_side, out_key, keys):
     for k in keys:
         assert torch.allclose(out[k].cpu(), ref[k], rtol=1e-4, atol=2e-5), (k, float((out[k].cpu() - ref[k]).abs().max()))
     g = torch.randn(ref[out_key].shape, generator=torch.Generator().manual_seed(4))
-    (ref[out_key] * g).sum().backward()
+    # the oracle's gradients, and how far they move when its stencil inputs move by one fp32 ulp (helpers.
+    # oracle_gradient_sensitivity; tests/test_oracle_sensitivity.py): at inv_s = 403 with a sharp lumpy surface some rays
+    # saturate and the reference's weight backward (render_weight.cu:139-151) amplifies rounding residues -- the gates below
+    # are SURVEY 8(d)'s unless the oracle itself moves by more than a third of them
+    from helpers import oracle_gradient_sensitivity
+    from test_gpu_split_model import _run_override
+    leaves = _leaves(P)
+    base, moved = oracle_gradient_sensitivity(
+        lambda s7: OS.render(rays, P, stage=1 if stage1 else 0, indirect=True, relighting=False, stratified_u=u,
+                             override=dict(_run_override(model), sdf7=s7)),
+        leaves, _run_override(model)["sdf7"], {out_key: g}, trials=2, seed=5)
+    for name, leaf in leaves.items():
+        leaf.grad = base[name]
     with entry_points() as bwd:
         (out[out_key] * g.to(dev)).sum().backward()
     # stage 0: albedo, metallic, roughness, env + the secondary network; stage 1 adds nothing new to the set
@@ -113,7 +126,27 @@ def _run_big(dev, stage1, n_side, out_key, keys):
     t_err = float((gt - P["table"].grad).abs().max()) / float(P["table"].grad.abs().max())
     print("big model stage %d: S=%d, worst parameter gradient %s %.2e, table %.2e" %
           (1 if stage1 else 0, int(out["num_samples"]) if "num_samples" in out else -1, worst, report[worst], t_err))
+    gates = {k: max(mlp_tol, 3.0 * moved.get(k, 0.0)) for k in ref_g}
+    print("   oracle vs itself one ulp away: worst " + ", ".join(
+        f"{k} {v:.1e}" for k, v in sorted(moved.items(), key=lambda kv: -kv[1])[:4]))
+    bad = {k: (report[k], gates[k]) for k in report if report[k] >= gates[k]}
+    assert not bad, bad
+    assert t_err < max(table_tol, 3.0 * moved["table"]), (t_err, moved["table"])
     return model, P, hip, ref_g, gt
+
+
+def _leaves(P):
+    """name -> oracle leaf tensor, named as test_gpu_split_model._all_param_grads names them."""
+    out = {"table": P["table"], "variance": P["var"]}
+    for i, p in enumerate(P["mlp"]):
+        for name, key in (("weight_v", "v"), ("weight_g", "g"), ("bias", "b")):
+            out[f"sdf{i}.{name}"] = p[key]
+    for net, layers in P["nets"].items():
+        for i, p in enumerate(layers):
+            out[f"{net}{i}.w"], out[f"{net}{i}.b"] = p["w"], p["b"]
+    if "emitter_base" in P and P["emitter_base"].requires_grad:
+        out["emitter_base"] = P["emitter_base"]
+    return out
 
 
 def test_big_secondary_rays_stage0_vs_oracle(dev):
@@ -122,7 +155,6 @@ def test_big_secondary_rays_stage0_vs_oracle(dev):
         dev, False, 16, "comp_rgb_full",
         ("comp_rgb", "comp_spec_rgb", "comp_diffuse_rgb", "comp_blend", "opacity", "comp_rgb_full"))
     assert torch.nn.functional.cosine_similarity(gt[None], P["table"].grad[None]).item() > 0.99999
-    assert_grads_tight(hip, ref_g, gt, P["table"].grad)
 
 
 def test_big_stage1_model_vs_oracle(dev):
@@ -131,7 +163,7 @@ def test_big_stage1_model_vs_oracle(dev):
         dev, True, 16, "comp_rgb_phys_full",
         ("comp_rgb", "comp_rgb_phys", "comp_diffuse_rgb_phys", "comp_spec_rgb_phys", "comp_spec_rgb", "comp_albedo",
          "comp_metallic", "comp_roughness", "comp_rgb_full", "comp_rgb_phys_full", "comp_spec_rgb_full",
-         "comp_spec_rgb_phys_full"))
+         "comp_spec_rgb_phys_full"),
+        # same floor as the 64-wide stage-1 test: the oracle's prefilters / cube lookups are fp64 dense-weight restatements
+        mlp_tol=2e-3, table_tol=2e-3)
     assert rel_err(model.emitter.base.grad, P["emitter_base"].grad) < 1e-3
-    # same gate as the 64-wide stage-1 test: the oracle's prefilters / cube lookups are fp64 dense-weight restatements
-    assert_grads_tight(hip, ref_g, gt, P["table"].grad, mlp_tol=2e-3, table_tol=2e-3)

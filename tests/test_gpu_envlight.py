@@ -77,12 +77,13 @@ def test_specular_prefilter_at_the_sizes_the_step_runs(dev, R, roughness):
     c64 = c.double().requires_grad_(True)
     # the window is the texels with L.V >= cutoff, compared in fp32 by the reference kernel and by ours: a texel whose L.V is
     # within rounding of the cutoff may fall on either side.  At these resolutions the cutoff is within 1e-3 of 1 and both
-    # unit vectors carry their own normalisation rounding: bracket by +-1e-6 (one texel of a 600-texel window moves the
-    # output by ~1e-3, so a bracketed row pins little; the rows WITHOUT a borderline texel -- every sixth at R = 512, most at
-    # R = 128 -- are held to 2e-5, forward and backward)
-    (ref, lo, hi), margin = E.specular_rows(c64, roughness, rows, 0.99, cos_shifts=(0.0, -1e-6, 1e-6), return_margin=True)
+    # unit vectors carry their own normalisation rounding: texels within 1e-6 of it are "borderline", and a row may differ
+    # from the oracle by the summed effect of its borderline texels (one texel of a 200-texel window moves the output by
+    # ~1e-3; a lo / hi bracket of the two extreme windows is NOT a bound -- two borderline texels can cancel in it: found on the
+    # GPU).  The rows WITHOUT a borderline texel -- every sixth at R = 512, most at R = 128 -- are held to 2e-5, both ways.
+    (ref,), margin, slack = E.specular_rows(c64, roughness, rows, 0.99, cos_shifts=(-1e-6, 0.0, 1e-6)[1:2], return_margin=True,
+                                            border=1e-6)
     (rc,) = torch.autograd.grad(ref, c64, go_rows.double())
-    lo, hi = lo.detach(), hi.detach()
     got = out.detach().cpu().double().reshape(-1, 3)[rows]
     err = (got - ref.detach()).abs()
     # SpecularBoundsKernel culls 16 x 16 tiles with an interval test on fp32 corner directions (cubemap.cu:201-219, restated
@@ -92,11 +93,11 @@ def test_specular_prefilter_at_the_sizes_the_step_runs(dev, R, roughness):
     ok = ~tile_edge
     assert int(tile_edge.sum()) <= len(rows) // 50, int(tile_edge.sum())
     assert float((err[tile_edge] / ref.detach().abs()[tile_edge]).max()) < 0.1 if bool(tile_edge.any()) else True
-    assert bool((err[ok] <= ((lo - hi).abs() + 2e-5 * ref.detach().abs() + 1e-6)[ok]).all()), float(err[ok].max())
-    border = ((lo - hi).abs() > 0).any(-1)
+    assert bool((err[ok] <= (1.1 * slack + 2e-5 * ref.detach().abs() + 1e-6)[ok]).all()), float(err[ok].max())
+    border = (slack > 0).any(-1)
     clean = ~border & ok
     print(f"R {R}: {int(clean.sum())} of {len(rows)} rows without a borderline texel ({int(tile_edge.sum())} within rounding of a "
-          f"tile flip); worst clean row {float(err[clean].max()):.2e}, worst bracketed row {float(err[ok].max()):.2e}")
+          f"tile flip); worst clean row {float(err[clean].max()):.2e}, worst borderline row {float(err[ok].max()):.2e}")
     assert int(clean.sum()) >= 100, int(clean.sum())
     assert float(err[clean].max()) <= 2e-5 * float(ref.detach().abs().max()) + 1e-6
     # backward on the clean rows alone: exact transpose of the same windows

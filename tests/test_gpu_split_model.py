@@ -62,6 +62,11 @@ def _params(model):
     return P
 
 
+def _run_override(model):
+    """The override dictionary of the last _run on ``model`` (sample sets, secondary rays, stencil and alpha values)."""
+    return model._last_override
+
+
 def _same_up_to_borderline(a, b, slack):
     key = lambda r, t: set(zip(r.tolist(), t.contiguous().view(torch.int32).tolist()))   # noqa: E731
     return len(key(a[0], a[1]) ^ key(b[0], b[1])) <= slack
@@ -124,6 +129,7 @@ def _run(dev, model, rays, u, P, stage, relighting):
     # ulp of alpha into O(1) of d_alpha on saturated rays (tests/test_gpu_late_regime.py); C1 itself is bit-exact on equal alphas
     with torch.no_grad():
         ov["alphas"] = model._alpha_fn(ro_d, rd_d)(prim[1], prim[2], prim[0]).cpu()
+    model._last_override = ov                              # (tests/test_gpu_big_model.py re-renders the oracle on these)
     ref = OS.render(rays, P, stage=stage, indirect=True, relighting=relighting, stratified_u=u, override=ov)
     # ... and the stencil itself agrees to fp32 rounding (relative to max |sdf|; the H = 128 chain sits at 7e-7 of its largest
     # ACTIVATION, as in tests/test_gpu_late_regime.py)
