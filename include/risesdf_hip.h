@@ -621,6 +621,10 @@ int rsdf_specular_bounds(int R, float cos_cutoff, float *bounds, void *stream);
 int rsdf_cubemap_texel_table(int R, float *table /* [6,R,R,4]: unit direction, solid angle / 4 */, void *stream);
 int rsdf_specular_cubemap_fwd(const float *cubemap, const float *bounds, const float *texel_table /*nullable*/,
                               int R, float roughness, float cos_cutoff, float *out4, void *stream);
+/* The forward with lib/renderutils/ops.py:458's normalisation inside (round 6): out3 [6,R,R,3] = sum w c / sum w, contiguous,
+ * and wsum [6,R,R] = sum w (what the backward divides the incoming gradient by).  Additive entry point. */
+int rsdf_specular_cubemap_fwd_norm(const float *cubemap, const float *bounds, const float *texel_table /*nullable*/, int R,
+                                   float roughness, float cos_cutoff, float *out3, float *wsum, void *stream);
 int rsdf_specular_cubemap_bwd(const float *grad_out, int grad_channels, const float *bounds,
                               const float *texel_table /*nullable*/, int R, float roughness, float cos_cutoff,
                               float *grad_cubemap, void *stream);

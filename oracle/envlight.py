@@ -199,7 +199,7 @@ def specular_rows(cubemap, roughness, rows, cutoff=0.99, cos_shifts=(0.0,), chun
                 margins.append(margin)
                 face, ly, lx = li // (R * R), (li // R) % R, li % R
                 tile = (face * nt + ly // 16) * nt + lx // 16
-                for sh in cos_shifts:
+                for sh in tuple(cos_shifts) + ((-border,) if border is not None else ()):
                     # bounding box per (row, face) of the in-cone texels of the tiles that pass (:222-236) ...
                     m = passed[vi, tile] & (dot >= cosc0 + sh)
                     key = vi * 6 + face
@@ -212,7 +212,7 @@ def specular_rows(cubemap, roughness, rows, cutoff=0.99, cos_shifts=(0.0,), chun
                     # ... and every in-cone texel inside it (:263-272)
                     in_box.append((lx >= mnx[key]) & (lx <= mxx[key]) & (ly >= mny[key]) & (ly <= mxy[key]))
             else:
-                in_box = [torch.ones_like(dot, dtype=torch.bool) for _ in cos_shifts]
+                in_box = [torch.ones_like(dot, dtype=torch.bool) for _ in range(len(cos_shifts) + (border is not None))]
             keeps.append(torch.stack(in_box, 0))
             vis.append(vi + i)
             lis.append(li)
@@ -229,7 +229,7 @@ def specular_rows(cubemap, roughness, rows, cutoff=0.99, cos_shifts=(0.0,), chun
         # borderline texels of opposite effect cancel in a lo / hi bracket, not in this bound): w_b |c_b - out| / wsum over them,
         # with the smallest window's wsum
         with torch.no_grad():
-            mb = ((dot - cosc0).abs() <= border) & keepm.any(0)
+            mb = ((dot - cosc0).abs() <= border) & keepm[-1]      # (the box of the WIDEST window: a borderline texel can extend it)
             m_in = (dot >= cosc0 + border) & keepm.all(0)
             wmin = torch.zeros(len(rows), dtype=dtype).index_add_(0, vi[m_in], w[m_in])
             eff = w[mb][:, None] * (cubemap.detach().reshape(-1, 3)[li[mb]] - outs[0].detach()[vi[mb]]).abs()

@@ -151,6 +151,7 @@ _SIGNATURES = {
     "rsdf_specular_bounds": [_I, _F, _P, _P],
     "rsdf_specular_cubemap_fwd": [_P, _P, _P, _I, _F, _F, _P, _P],
     "rsdf_specular_cubemap_bwd": [_P, _I, _P, _P, _I, _F, _F, _P, _P],
+    "rsdf_specular_cubemap_fwd_norm": [_P, _P, _P, _I, _F, _F, _P, _P, _P],
     "rsdf_cubemap_texel_table": [_I, _P, _P],
     "rsdf_cubemap_avgpool": [_P, _I, _I, _P, _P],
     "rsdf_cube_sample_fwd": [_P, _I, _I, _I, _P, _P, _L, _P, _P],

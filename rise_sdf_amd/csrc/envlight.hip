@@ -167,6 +167,21 @@ __device__ __forceinline__ float ndf_ggx_pair(float a2, V3 A, V3 B)
 // instructions from a per-texel-pair table (v_pk_fma_f32 & co: 0.73 / 1.20 / 0.50 ms -- no faster than two plain
 // instructions, plus the even-x alignment of the window); 16 lanes per texel (1.10 / 0.40 at 256^2 / 128^2).
 struct PairAcc { float c0, c1, c2, wsum; };
+// -DSPEC_DIAG=1: no source-texel loads; 2: no table loads; 3: neither (A/B diagnostics of what bounds the window loops:
+// tools/bench_prefilter.py under tools/ab_unit.sh; results are wrong by construction)
+#ifndef SPEC_DIAG
+#define SPEC_DIAG 0
+#endif
+__device__ __forceinline__ float4 spec_ld_table(const float4 *p, const V3 &A, int i)
+{
+    if (SPEC_DIAG & 2) return make_float4(A.x, A.y - 1e-3f * (float)(i & 15), A.z, 1e-6f);
+    return *p;
+}
+__device__ __forceinline__ float spec_ld_src(const float *p, int k, int i)
+{
+    if (SPEC_DIAG & 1) return 0.25f * (float)(k + 1) + (float)(i & 1);
+    return p[k];
+}
 
 template <bool BWD>
 __device__ __forceinline__ void spec_pair(PairAcc &acc, const V3 &A, float cc, float k1, float a2, float cpi,
@@ -188,7 +203,7 @@ template <bool BWD, int G>     // G lanes per output texel: 1 or 64
 __global__ void __launch_bounds__(THREADS)
 specular_kernel(const float *__restrict__ src, int src_ch, const float *__restrict__ bounds,
                 const float4 *__restrict__ table, int R, float roughness, float cos_cutoff,
-                float *__restrict__ dst)
+                float *__restrict__ dst, float *__restrict__ wsum_out)
 {
     // table (nullable) = per texel (unit direction, solid angle / 4) from texel_table_kernel: one 16-byte load
     // replaces the direction normalisation and the two area factors of every window iteration
@@ -218,9 +233,10 @@ specular_kernel(const float *__restrict__ src, int src_ch, const float *__restri
                     const float *pr = src + (size_t)row * src_ch;
                     int xo = 0;
                     for (; xo + 1 < bw; xo += 2) {                        // two pairs per trip: four loads in flight
-                        const float4 t0 = tr[xo], t1 = tr[xo + 1];
+                        const float4 t0 = spec_ld_table(tr + xo, A, xo), t1 = spec_ld_table(tr + xo + 1, A, xo + 1);
                         const float *q0 = pr + xo * src_ch, *q1 = q0 + src_ch;
-                        const float u0 = q0[0], u1 = q0[1], u2 = q0[2], v0 = q1[0], v1 = q1[1], v2 = q1[2];
+                        const float u0 = spec_ld_src(q0, 0, xo), u1 = spec_ld_src(q0, 1, xo), u2 = spec_ld_src(q0, 2, xo);
+                        const float v0 = spec_ld_src(q1, 0, xo), v1 = spec_ld_src(q1, 1, xo), v2 = spec_ld_src(q1, 2, xo);
                         spec_pair<BWD>(acc, A, cc, k1, a2, cpi, t0, u0, u1, u2);
                         spec_pair<BWD>(acc, A, cc, k1, a2, cpi, t1, v0, v1, v2);
                     }
@@ -242,9 +258,10 @@ specular_kernel(const float *__restrict__ src, int src_ch, const float *__restri
                 int i = sub;
                 for (; i + G < cnt; i += 2 * G) {                         // two pairs per trip: four loads in flight
                     const int ta = texel(i), tb = texel(i + G);
-                    const float4 t0 = table[ta], t1 = table[tb];
+                    const float4 t0 = spec_ld_table(table + ta, A, ta), t1 = spec_ld_table(table + tb, A, tb);
                     const float *q0 = src + (size_t)ta * src_ch, *q1 = src + (size_t)tb * src_ch;
-                    const float u0 = q0[0], u1 = q0[1], u2 = q0[2], v0 = q1[0], v1 = q1[1], v2 = q1[2];
+                    const float u0 = spec_ld_src(q0, 0, ta), u1 = spec_ld_src(q0, 1, ta), u2 = spec_ld_src(q0, 2, ta);
+                    const float v0 = spec_ld_src(q1, 0, tb), v1 = spec_ld_src(q1, 1, tb), v2 = spec_ld_src(q1, 2, tb);
                     spec_pair<BWD>(acc, A, cc, k1, a2, cpi, t0, u0, u1, u2);
                     spec_pair<BWD>(acc, A, cc, k1, a2, cpi, t1, v0, v1, v2);
                 }
@@ -276,6 +293,11 @@ specular_kernel(const float *__restrict__ src, int src_ch, const float *__restri
         const float a = table != nullptr ? table[idx].w : s_side[x0] * s_side[y0] / 4.0f;
         float *o = dst + (size_t)idx * 3;
         o[0] = c0 * a; o[1] = c1 * a; o[2] = c2 * a;
+    } else if (wsum_out != nullptr) {
+        // lib/renderutils/ops.py:458 (out[..., 0:3] / out[..., 3:]) here: contiguous [6,R,R,3] + the weight sums for the backward
+        float *o = dst + (size_t)idx * 3;
+        o[0] = c0 / wsum; o[1] = c1 / wsum; o[2] = c2 / wsum;
+        wsum_out[idx] = wsum;
     } else {
         float *o = dst + (size_t)idx * 4;
         o[0] = c0; o[1] = c1; o[2] = c2; o[3] = wsum;
@@ -290,14 +312,14 @@ specular_kernel(const float *__restrict__ src, int src_ch, const float *__restri
 #endif
 template <bool BWD>
 void launch_specular(const float *src, int src_ch, const float *bounds, const float4 *table, int R, float roughness,
-                     float cos_cutoff, float *dst, hipStream_t st)
+                     float cos_cutoff, float *dst, hipStream_t st, float *wsum_out = nullptr)
 {
     const size_t lds = R * sizeof(float);
     const int64_t n = (int64_t)6 * R * R;
     if (R <= SPEC_G64_MAX_R)
-        specular_kernel<BWD, 64><<<rsdf_blocks(n, THREADS / 64), THREADS, lds, st>>>(src, src_ch, bounds, table, R, roughness, cos_cutoff, dst);
+        specular_kernel<BWD, 64><<<rsdf_blocks(n, THREADS / 64), THREADS, lds, st>>>(src, src_ch, bounds, table, R, roughness, cos_cutoff, dst, wsum_out);
     else
-        specular_kernel<BWD, 1><<<rsdf_blocks(n, THREADS), THREADS, lds, st>>>(src, src_ch, bounds, table, R, roughness, cos_cutoff, dst);
+        specular_kernel<BWD, 1><<<rsdf_blocks(n, THREADS), THREADS, lds, st>>>(src, src_ch, bounds, table, R, roughness, cos_cutoff, dst, wsum_out);
 }
 
 __global__ void __launch_bounds__(THREADS)
@@ -553,6 +575,15 @@ int rsdf_specular_cubemap_fwd(const float *cubemap, const float *bounds, const f
     RSDF_CHECK_ARG(R >= 1 && R <= 4096, "specular_cubemap_fwd: bad resolution");
     launch_specular<false>(cubemap, 3, bounds, reinterpret_cast<const float4 *>(texel_table), R, roughness, cos_cutoff, out4,
                            (hipStream_t)stream);
+    RSDF_RETURN_LAUNCH();
+}
+
+int rsdf_specular_cubemap_fwd_norm(const float *cubemap, const float *bounds, const float *texel_table, int R,
+                                   float roughness, float cos_cutoff, float *out3, float *wsum, void *stream)
+{
+    RSDF_CHECK_ARG(R >= 1 && R <= 4096 && wsum != nullptr, "specular_cubemap_fwd_norm: bad arguments");
+    launch_specular<false>(cubemap, 3, bounds, reinterpret_cast<const float4 *>(texel_table), R, roughness, cos_cutoff, out3,
+                           (hipStream_t)stream, wsum);
     RSDF_RETURN_LAUNCH();
 }
 

@@ -365,6 +365,50 @@ pair_kernel(const PairArgs a)
     bool bad = bad0;
 
     if ((int64_t)blockIdx.x < a.tiles) dma_tile<NP>(smem + XI, a.x, (int64_t)blockIdx.x, ws, lane, kba);
+    // ---- layer a backward, input side: the dx slab (columns 16 w .. 16 w + 15, all 32 rows) of the tile whose dz_a image is in
+    // LDS.  DEFERRED by one tile (round 6; -DRSDF_PAIR_NO_DEFER_DX for A/B): it runs right after barrier (1) of the NEXT tile,
+    // which removes the fourth barrier of a tile (dz_a's only cross-wave reader is this product) and gives the 16 KB of dx
+    // stores a whole tile to retire before the next s_waitcnt vmcnt(0) instead of being issued just before it.  ``pxi``: that
+    // tile's X image (the ReLU mask of dx comes from this wave's OWN slab of it, which only this wave's share of the next
+    // DMA overwrites -- issued after this call in program order).
+    auto emit_dx = [&](int64_t ps0, const unsigned char *pxi) {
+        if (a.dx != nullptr && 16 * ws < a.kout) {
+#pragma unroll
+            for (int rh = 0; rh < 2; ++rh) {
+                f32x4 dx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) dx = mma3q<NP>(wat[kb], rowq<NP>(smem + DZ1, kb, rh, lc), dx);
+                const int64_t row = ps0 + 16 * rh + c16;
+                const int col = 16 * w + 4 * g;
+                float o[4];
+                if (a.x_relu) {                // x > 0 from the hi part of the X image (same sign; zero only for x < 2^-31)
+                    const uint2 xh = *reinterpret_cast<const uint2 *>(pxi + lc.st + rh * 256);
+                    o[0] = f16_pos(xh.x) ? dx[0] * k_dx : 0.0f;
+                    o[1] = f16_pos(xh.x >> 16) ? dx[1] * k_dx : 0.0f;
+                    o[2] = f16_pos(xh.y) ? dx[2] * k_dx : 0.0f;
+                    o[3] = f16_pos(xh.y >> 16) ? dx[3] * k_dx : 0.0f;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = dx[r] * k_dx;
+                }
+                if (row < a.n) {
+                    // (a group of four columns never straddles k1: both are multiples of 4)
+                    const bool second = a.dx2 != nullptr && col >= a.k1;
+                    float *p = second ? a.dx2 + row * a.ld2 + (col - a.k1) : a.dx + row * a.lddx + col;
+                    const int ld = second ? a.ld2 : a.lddx;
+                    const int lim = (a.dx2 != nullptr && !second) ? a.k1 : a.kout;
+                    if (col + 3 < lim && (ld & 3) == 0) {
+                        *reinterpret_cast<float4 *>(p) = float4{o[0], o[1], o[2], o[3]};
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (col + r < lim) p[r] = o[r];
+                    }
+                    dxmax = fmaxf(fmaxf(dxmax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+                }
+            }
+        }
+    };
     int parity = 0;
     for (int64_t ti = blockIdx.x; ti < a.tiles; ti += gridDim.x) {
         const int64_t s0 = ti * 32;
@@ -372,6 +416,14 @@ pair_kernel(const PairArgs a)
         wait_vm0();                            // this wave's share of the tile has landed (and the previous tile's stores retired)
         lds_barrier();                         // (1) every share has landed; the other X image and the H1 / DZ images are free
         parity ^= 1;
+#ifndef RSDF_PAIR_NO_DEFER_DX
+        if (BWD && ti != (int64_t)blockIdx.x) {
+            emit_dx(s0 - (int64_t)gridDim.x * 32, smem + XI + parity * IMG);
+            // TOP parks this tile's hb image in the dz_a buffer right below: every wave must have finished reading the previous
+            // tile's dz_a first (the barrier count of that variant stays four; its stores still retire a tile earlier)
+            if (TOP && a.dw_out != nullptr) lds_barrier();
+        }
+#endif
         f32x4 dz[2];
         bool row_ok[2];
         if (BWD) {
@@ -529,44 +581,18 @@ pair_kernel(const PairArgs a)
         }
         store_q<NP>(smem + DZ1, 0, lc, dz[0]);
         store_q<NP>(smem + DZ1, 1, lc, dz[1]);
+#ifdef RSDF_PAIR_NO_DEFER_DX
         lds_barrier();                         // (4) dz_a image complete
-        // ---- layer a backward: dx slab (columns 16 w .. 16 w + 15, all 32 rows); dWa += dz_a^T X
-        if (a.dx != nullptr && 16 * ws < a.kout) {
-#pragma unroll
-            for (int rh = 0; rh < 2; ++rh) {
-                f32x4 dx = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int kb = 0; kb < KB; ++kb) dx = mma3q<NP>(wat[kb], rowq<NP>(smem + DZ1, kb, rh, lc), dx);
-                const int64_t row = s0 + 16 * rh + c16;
-                const int col = 16 * w + 4 * g;
-                float o[4];
-                if (a.x_relu) {                // x > 0 from the hi part of the X image (same sign; zero only for x < 2^-31)
-                    const uint2 xh = *reinterpret_cast<const uint2 *>(xi + lc.st + rh * 256);
-                    o[0] = f16_pos(xh.x) ? dx[0] * k_dx : 0.0f;
-                    o[1] = f16_pos(xh.x >> 16) ? dx[1] * k_dx : 0.0f;
-                    o[2] = f16_pos(xh.y) ? dx[2] * k_dx : 0.0f;
-                    o[3] = f16_pos(xh.y >> 16) ? dx[3] * k_dx : 0.0f;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = dx[r] * k_dx;
-                }
-                if (row < a.n) {
-                    // (a group of four columns never straddles k1: both are multiples of 4)
-                    const bool second = a.dx2 != nullptr && col >= a.k1;
-                    float *p = second ? a.dx2 + row * a.ld2 + (col - a.k1) : a.dx + row * a.lddx + col;
-                    const int ld = second ? a.ld2 : a.lddx;
-                    const int lim = (a.dx2 != nullptr && !second) ? a.k1 : a.kout;
-                    if (col + 3 < lim && (ld & 3) == 0) {
-                        *reinterpret_cast<float4 *>(p) = float4{o[0], o[1], o[2], o[3]};
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (col + r < lim) p[r] = o[r];
-                    }
-                    dxmax = fmaxf(fmaxf(dxmax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
-                }
-            }
-        }
+        emit_dx(s0, xi);
+#else
+        // no barrier (4): the dWa product below reads only this wave's OWN slab of the dz_a image (what store_q just wrote; LDS
+        // operations of one wave execute in order, the wait makes it explicit); the product that needs every wave's slab runs
+        // after the next tile's barrier (1) (emit_dx)
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xC07F);    // s_waitcnt lgkmcnt(0)
+        asm volatile("" ::: "memory");
+#endif
+        // ---- layer a backward, weight side: dWa += dz_a^T X
         {
             const Frag2 af = trfq<NP>(smem + DZ1, w, lc);
 #pragma unroll
@@ -576,6 +602,13 @@ pair_kernel(const PairArgs a)
         // no barrier: the next tile's barrier (1) separates these reads from the DMA that overwrites this X image
     }
 
+#ifndef RSDF_PAIR_NO_DEFER_DX
+    if (BWD && (int64_t)blockIdx.x < a.tiles) {    // the last tile's input gradient
+        lds_barrier();
+        const int64_t last_ti = (int64_t)blockIdx.x + ((a.tiles - 1 - (int64_t)blockIdx.x) / gridDim.x) * gridDim.x;
+        emit_dx(last_ti * 32, smem + XI + (parity ^ 1) * IMG);
+    }
+#endif
     if (!BWD) {
         if (__builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0 && a.status != nullptr) {
             atomicAdd(&a.status[RSDF_STATUS_X2_FWD_NONFINITE], 1);

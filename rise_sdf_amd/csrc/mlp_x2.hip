@@ -701,6 +701,28 @@ bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
 
     const int64_t n_groups = src.Sp / 32;
     if ((int64_t)blockIdx.x < n_groups) dma_tile<NW, NP>(smem + L::XI, src, (int64_t)blockIdx.x, 0, ws, lane);
+    // ---- layer 1 backward, input side: d(hash features) sub-tile (16 columns x 16 rows, all features) of the tile whose dz1
+    // image is in LDS.  DEFERRED by one tile (round 6, -DRSDF_X2_NO_DEFER_DX for A/B): it runs right after barrier (1) of the
+    // NEXT tile, which (a) removes the fourth barrier of a tile -- dz1's only cross-wave reader is this product -- and (b)
+    // gives the d_planes stores a whole tile to retire before the next s_waitcnt vmcnt(0) (they used to be issued just before
+    // it: stores count in vmcnt, and reads and writes return out of order, so vmcnt(n) cannot skip them).
+    auto emit_dx = [&](int64_t ps0, int ptap) {
+        if (NW == 4 || ws < 4) {
+            f32x4 dx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) dx = mma3q<NP>(w0t[kb], rowq<HP, NP>(smem + L::DZ1, kb, rhx, lc), dx);
+            // result rows = hash columns 16 mt + 4 g + r = (level 8 mt + 2 g + (r >> 1), feature r & 1); lane column =
+            // sample row 16 rhx + c16: two float2 stores, 16 lanes cover 128 contiguous bytes of a level plane
+            const int64_t row = ps0 + 16 * rhx + c16;
+            if (d_planes != nullptr && row < src.S) {
+                const int lev = 8 * mt + 2 * g;
+                if (lev < src.n_active)
+                    st_dplane(d_planes + (((int64_t)lev * 7 + ptap) * src.S + row) * 2, dx[0] * k_dx, dx[1] * k_dx);
+                if (lev + 1 < src.n_active)
+                    st_dplane(d_planes + (((int64_t)(lev + 1) * 7 + ptap) * src.S + row) * 2, dx[2] * k_dx, dx[3] * k_dx);
+            }
+        }
+    };
     int parity = 0;
     for (int64_t gi = blockIdx.x; gi < n_groups; gi += gridDim.x) {
         const int64_t s0 = gi * 32;
@@ -708,9 +730,13 @@ bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
             const unsigned char *xi = smem + L::XI + parity * NP * QX_PART;
             wait_vm0();                            // this wave's share of the tile has landed (and the previous tile's stores retired)
             // every wave's share has landed once all have passed their wait; the OTHER image is free once all have finished
-            // the previous tile's dW0 reads: one barrier serves both
+            // the previous tile's dW0 reads; the previous tile's dz1 image is complete: one barrier serves all three
             lds_barrier();                                                       // (1)
             parity ^= 1;
+#ifndef RSDF_X2_NO_DEFER_DX
+            if (tap > 0) emit_dx(s0, tap - 1);
+            else if (gi != (int64_t)blockIdx.x) emit_dx(s0 - (int64_t)gridDim.x * 32, 6);
+#endif
             bool row_ok[2];
             float dsdf_raw[2];
             f32x4 dz[2];
@@ -780,23 +806,18 @@ bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
             }
             store_q<HP, NP>(smem + L::DZ1, 0, lc, dz[0]);
             store_q<HP, NP>(smem + L::DZ1, 1, lc, dz[1]);
+#ifdef RSDF_X2_NO_DEFER_DX
             lds_barrier();                                                       // (4) dz1 image complete
-            // ---- layer 1 backward: d(hash features) sub-tile (16 columns x 16 rows, all 64 features); dW0 += dz1^T X
-            if (NW == 4 || ws < 4) {
-                f32x4 dx = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int kb = 0; kb < KB; ++kb) dx = mma3q<NP>(w0t[kb], rowq<HP, NP>(smem + L::DZ1, kb, rhx, lc), dx);
-                // result rows = hash columns 16 mt + 4 g + r = (level 8 mt + 2 g + (r >> 1), feature r & 1); lane column =
-                // sample row 16 rhx + c16: two float2 stores, 16 lanes cover 128 contiguous bytes of a level plane
-                const int64_t row = s0 + 16 * rhx + c16;
-                if (d_planes != nullptr && row < src.S) {
-                    const int lev = 8 * mt + 2 * g;
-                    if (lev < src.n_active)
-                        st_dplane(d_planes + (((int64_t)lev * 7 + tap) * src.S + row) * 2, dx[0] * k_dx, dx[1] * k_dx);
-                    if (lev + 1 < src.n_active)
-                        st_dplane(d_planes + (((int64_t)(lev + 1) * 7 + tap) * src.S + row) * 2, dx[2] * k_dx, dx[3] * k_dx);
-                }
-            }
+            emit_dx(s0, tap);
+#else
+            // no barrier (4): the dW0 product below reads only this wave's OWN slab of the dz1 image (columns 16 w ..: what
+            // store_q just wrote; LDS operations of one wave execute in order, the wait makes it explicit); the product
+            // that needs every wave's slab runs after the next tile's barrier (1) (emit_dx above)
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0xC07F);      // s_waitcnt lgkmcnt(0)
+            asm volatile("" ::: "memory");
+#endif
+            // ---- layer 1 backward, weight side: dW0 += dz1^T X
             {
                 const Frag2 a = trfq<HP, NP>(smem + L::DZ1, w, lc);
 #pragma unroll
@@ -807,6 +828,13 @@ bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
         }
     }
 
+#ifndef RSDF_X2_NO_DEFER_DX
+    if ((int64_t)blockIdx.x < n_groups) {          // the last tile's input gradient
+        lds_barrier();
+        const int64_t last_gi = (int64_t)blockIdx.x + ((n_groups - 1 - (int64_t)blockIdx.x) / gridDim.x) * gridDim.x;
+        emit_dx(last_gi * 32, 6);
+    }
+#endif
     // ---- flush: gw1[n][r] = G2 SH dW1[16 w + 4 g + r][16 n + c16]; gw0[ct][r] = G1 SX dW0 image [feature][X column 16 ct + c16]
     const float u1 = 1.0f / (G2 * SH), u0 = 1.0f / (G1 * SX);
 #pragma unroll

@@ -96,13 +96,15 @@ class _SpecularCubemapNormalized(torch.autograd.Function):
         require_device(c, bounds)
         R = c.shape[1]
         table = texel_table(R, c.device)
-        out = torch.empty(6, R, R, 4, dtype=torch.float32, device=c.device)
-        check(lib().rsdf_specular_cubemap_fwd(ptr(c), ptr(bounds), ptr(table), R, float(roughness), float(cosc),
-                                              ptr(out), stream_ptr()), "specular_cubemap_fwd")
-        wsum = out[..., 3:]
+        # (round 6: the kernel normalises -- `out[..., 0:3] / out[..., 3:]` on the strided halves of a [6,R,R,4] tensor was a
+        # broadcasting aten kernel of 100-180 us per level and direction, 1 ms of a 16 ms training step)
+        out = torch.empty(6, R, R, 3, dtype=torch.float32, device=c.device)
+        wsum = torch.empty(6, R, R, 1, dtype=torch.float32, device=c.device)
+        check(lib().rsdf_specular_cubemap_fwd_norm(ptr(c), ptr(bounds), ptr(table), R, float(roughness), float(cosc),
+                                                   ptr(out), ptr(wsum), stream_ptr()), "specular_cubemap_fwd")
         ctx.save_for_backward(bounds, table, wsum)
         ctx.args = (R, float(roughness), float(cosc))
-        return out[..., 0:3] / wsum
+        return out
 
     @staticmethod
     def backward(ctx, dy):

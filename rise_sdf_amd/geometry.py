@@ -166,9 +166,16 @@ class VolumeSDF(BaseModel):
         w_last, b_last = wb[-1]
         out = ops.linear(h, w_last, b_last, act="none", precision=net.precision)
         # reverse sweep for output channel 0: u <- (u * act'(z_i)) @ W_i
-        u = w_last[0:1].expand(out.shape[0], -1)
+        # (the first step's u is the constant row W_last[0]: (u * sl) @ W = sl @ (diag(W_last[0]) W) -- folded into the
+        # [H,H] weight instead of an [S,H] elementwise product forward and two backward)
+        u = None
         for (w, _), sl in zip(reversed(wb[:-1]), reversed(slopes)):
-            u = ops.linear((u * sl).contiguous(), w.t().contiguous(), None, act="none", precision=net.precision)
+            if u is None:
+                u = ops.linear(sl, (w * w_last[0][:, None]).t().contiguous(), None, act="none", precision=net.precision)
+            else:
+                u = ops.linear((u * sl).contiguous(), w.t().contiguous(), None, act="none", precision=net.precision)
+        if u is None:
+            u = w_last[0:1].expand(out.shape[0], -1)
         g_unit = ops.hashgrid_dx(x, grid.params, u, grid.meta, n_active, col)
         if col:
             g_unit = g_unit + u[:, :3] * enc.xyz_scale

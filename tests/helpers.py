@@ -99,7 +99,8 @@ def oracle_gradient_sensitivity(render, leaves, sdf7, cot, trials=3, seed=0):
             t.grad = None
         out = render(s7)
         sum((out[k] * c).sum() for k, c in cot.items()).backward()
-        return {n: leaves[n].grad.detach().clone() for n in names}
+        return {n: (leaves[n].grad.detach().clone() if leaves[n].grad is not None else torch.zeros_like(leaves[n]))
+                for n in names}                         # (a leaf the outputs do not depend on: zeros)
 
     base = grads(sdf7)
     g = torch.Generator().manual_seed(seed)

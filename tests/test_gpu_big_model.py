@@ -112,7 +112,7 @@ def _run_big(dev, stage1, n_side, out_key, keys, mlp_tol=3e-4, table_tol=1e-3):
                              override=dict(_run_override(model), sdf7=s7)),
         leaves, _run_override(model)["sdf7"], {out_key: g}, trials=2, seed=5)
     for name, leaf in leaves.items():
-        leaf.grad = base[name]
+        leaf.grad = base[name] if float(base[name].abs().max()) > 0 else None
     with entry_points() as bwd:
         (out[out_key] * g.to(dev)).sum().backward()
     # stage 0: albedo, metallic, roughness, env + the secondary network; stage 1 adds nothing new to the set
@@ -126,12 +126,14 @@ def _run_big(dev, stage1, n_side, out_key, keys, mlp_tol=3e-4, table_tol=1e-3):
     t_err = float((gt - P["table"].grad).abs().max()) / float(P["table"].grad.abs().max())
     print("big model stage %d: S=%d, worst parameter gradient %s %.2e, table %.2e" %
           (1 if stage1 else 0, int(out["num_samples"]) if "num_samples" in out else -1, worst, report[worst], t_err))
-    gates = {k: max(mlp_tol, 3.0 * moved.get(k, 0.0)) for k in ref_g}
+    # (the measured movement only ever RAISES a gate, and by at most a factor of five: in this scene the table x 1000 makes some
+    # rays saturate and the oracle moves by up to several per cent in single tensors, which must not make the gate vacuous)
+    gates = {k: max(mlp_tol, min(3.0 * moved.get(k, 0.0), 5.0 * mlp_tol)) for k in ref_g}
     print("   oracle vs itself one ulp away: worst " + ", ".join(
         f"{k} {v:.1e}" for k, v in sorted(moved.items(), key=lambda kv: -kv[1])[:4]))
     bad = {k: (report[k], gates[k]) for k in report if report[k] >= gates[k]}
     assert not bad, bad
-    assert t_err < max(table_tol, 3.0 * moved["table"]), (t_err, moved["table"])
+    assert t_err < max(table_tol, min(3.0 * moved["table"], 5.0 * table_tol)), (t_err, moved["table"])
     return model, P, hip, ref_g, gt
 
 
