@@ -16,8 +16,6 @@ def main():
     from rise_sdf_amd import envlight as E
     from rise_sdf_amd._lib import check, lib, ptr, stream_ptr
     dev = torch.device("cuda", 0)
-    light = E.EnvironmentLightMipCube({"envlight_config": {"scale": 0.5, "bias": 0.25, "base_res": 512, "hdr_filepath": None}}).to(dev) \
-        if hasattr(E, "EnvironmentLightMipCube") else None
     levels = [(512, 0.08), (256, 0.185), (128, 0.29), (64, 0.395), (32, 0.5)]
     out = {}
     for R, rough in levels:
