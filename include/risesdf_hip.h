@@ -208,6 +208,13 @@ int rsdf_hashgrid_bwd(const float *x, const float *dout, const rsdf_grid_meta *m
                       int64_t n, int n_active_levels, int ld_dout, int col_off, float *dtable,
                       void *stream);
 
+/* Run-time choice of the hash backward's queue record format for this process (round 6; both forms are compiled in):
+ * 0 = 16-byte elements of two block-float contributions (the larger feature gradient keeps 20 significant bits: the default),
+ * 1 = 20-byte elements of fp32 values (what the reference's fp32 atomics accumulate, models/network_utils.py:47-59).  Scratch
+ * sizes (rsdf_hashgrid_bwd_fd7_scratch_bytes, ..._scatter_binned_scratch_bytes) follow the current setting: set it once, before
+ * the first backward (rise_sdf_amd reads RSDF_REC=fp32 at load). */
+int rsdf_set_record_format(int fp32_values);
+int rsdf_get_record_format(void);
 /* ---- H1/H1b for the finite-difference stencil (models/geometry.py:229-244) -------------------------
  * Tap-major structure-of-arrays layouts (n = number of samples):
  *   x7t    [7][n][3]     tap t of sample s, unit cube; tap 0 = centre, then +x,-x,+y,-y,+z,-z

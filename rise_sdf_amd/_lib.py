@@ -113,6 +113,8 @@ _SIGNATURES = {
     "rsdf_pair_pack2": [_P, _I, _I, _P, _I, _I, _L, _P, _P, _P],
     "rsdf_pair_unpack": [_P, _L, _P, _P],
     "rsdf_pair_fwd": [_P, _I, _P, _P, _P, _P, _L, _P, _P, _P, _P, _I, _I, _P, _P, _P],
+    "rsdf_set_record_format": [_I],
+    "rsdf_get_record_format": [],
     "rsdf_pair_fwd16": [_P, _I, _P, _P, _P, _P, _L, _P, _P, _P, _P, _I, _I, _P, _P, _P],
     "rsdf_pair_bwd16": [_P, _I, _P, _P, _P, _P, _L, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P,
                         _P],
@@ -219,6 +221,11 @@ def lib():
             fn.restype = _RESTYPES.get(name, ctypes.c_int)
         if l.rsdf_abi_version() != ABI_VERSION:
             raise RiseSdfHipError("librisesdf_hip.so ABI version mismatch")
+        rec = os.environ.get("RSDF_REC", "")
+        if rec:      # the hash backward's queue records: 'fp32' values or the default block-float pairs ('bf20')
+            if rec not in ("fp32", "bf20"):
+                raise RiseSdfHipError(f"RSDF_REC={rec!r}: fp32 or bf20")
+            l.rsdf_set_record_format(1 if rec == "fp32" else 0)
         _lib = l
     if _timer is not None:
         return _TimedLib(_lib, _timer)

@@ -78,14 +78,15 @@ struct Record {   // LDS staging form
 // (inf / NaN in either value) decodes to NaN so that a non-finite gradient still poisons its table row; values below 2^-107
 // flush to zero.  A (bin, round) run with an odd record count ends in a half-empty element (second record all zero: it adds
 // 0.0 to entry 0; fp32 form: e1 == PAIR_NONE).
-#ifdef RSDF_REC_FP32
-struct PairRec {
+// BOTH forms are compiled; rsdf_set_record_format() picks one at run time (round 6; the reference's table gradient is plain
+// fp32 atomics, models/network_utils.py:47-59, so the fp32-valued records are the conservative choice and the block-float
+// records the fast default; -DRSDF_REC_FP32 only changes the library's initial setting).
+struct RecF32 {   // fp32 values, 20 bytes per element
     uint32_t e;    // entry within the bin: first contribution bits 0..15, second 16..31
     float a0, a1, b0, b1;
 };
 constexpr uint32_t PAIR_NONE = 0xffffu;
-#else
-struct __attribute__((aligned(16))) PairRec {
+struct __attribute__((aligned(16))) RecBF {   // block-float pairs, 16 bytes per element
     unsigned long long r0, r1;
 };
 __device__ __forceinline__ unsigned long long pack_rec(uint32_t entry, float v0, float v1)
@@ -114,7 +115,55 @@ __device__ __forceinline__ void unpack_rec(unsigned long long r, uint32_t &entry
     d0 = (double)m0 * sc;
     d1 = (double)m1 * sc;
 }
+
+template <typename REC> struct RecOps;
+template <> struct RecOps<RecF32> {
+    static __device__ __forceinline__ void store(RecF32 *q, uint32_t e0, float a0, float a1, bool two, uint32_t e1, float b0, float b1)
+    {
+        *q = RecF32{e0 | ((two ? e1 : PAIR_NONE) << 16), a0, a1, two ? b0 : 0.f, two ? b1 : 0.f};
+    }
+    static __device__ __forceinline__ RecF32 load(const RecF32 *q) { return *q; }
+    static __device__ __forceinline__ RecF32 empty() { return RecF32{0u | (PAIR_NONE << 16), 0.f, 0.f, 0.f, 0.f}; }
+    static __device__ __forceinline__ bool decode(const RecF32 &r, uint32_t &e0, double &a0, double &a1, uint32_t &e1, double &b0,
+                                                  double &b1)
+    {
+        e0 = r.e & 0xffffu, e1 = r.e >> 16;   // entries within the bin (the producer's entry_of)
+        a0 = (double)r.a0, a1 = (double)r.a1, b0 = (double)r.b0, b1 = (double)r.b1;
+        return e1 != PAIR_NONE;
+    }
+};
+template <> struct RecOps<RecBF> {
+    static __device__ __forceinline__ void store(RecBF *q, uint32_t e0, float a0, float a1, bool two, uint32_t e1, float b0, float b1)
+    {
+        const RecBF pr{pack_rec(e0, a0, a1), two ? pack_rec(e1, b0, b1) : 0ull};
+        // (streaming stores: the queues are read back by the reducer a whole launch later; producer 21.2 -> 20.5 ms)
+#ifndef RSDF_Q_PLAIN_STORE
+        __builtin_nontemporal_store(pr.r0, &q->r0);
+        __builtin_nontemporal_store(pr.r1, &q->r1);
+#else
+        *q = pr;
 #endif
+    }
+    static __device__ __forceinline__ RecBF load(const RecBF *q)
+    {
+#ifdef RSDF_Q_NT_LOAD
+        RecBF r;
+        r.r0 = __builtin_nontemporal_load(&q->r0);
+        r.r1 = __builtin_nontemporal_load(&q->r1);
+        return r;
+#else
+        return *q;
+#endif
+    }
+    static __device__ __forceinline__ RecBF empty() { return RecBF{0ull, 0ull}; }
+    static __device__ __forceinline__ bool decode(const RecBF &r, uint32_t &e0, double &a0, double &a1, uint32_t &e1, double &b0,
+                                                  double &b1)
+    {
+        unpack_rec(r.r0, e0, a0, a1);
+        unpack_rec(r.r1, e1, b0, b1);
+        return r.r1 != 0ull;   // a run of odd length ends in a half-empty element
+    }
+};
 constexpr uint32_t PAD_IDX = 0xffffffffu;   // staging slot that pads a run to an even length
 
 struct LevelPlan {
@@ -600,10 +649,11 @@ constexpr int IDX_BITS = 19;
 static_assert((1u << IDX_BITS) == (unsigned)MAX_BINS * BIN_ENTRIES, "entry index + rank must fit 32 bits");
 constexpr uint32_t IDX_MASK = (1u << IDX_BITS) - 1u;
 
+template <typename REC>
 __device__ __forceinline__ void emit_round(uint32_t (&ridx)[ROUND_RECS],
                                            const float2 (&rval)[ROUND_RECS], uint32_t valid_mask,
                                            int n_bins, int interleaved, int64_t cap,
-                                           PairRec *__restrict__ queue, int *__restrict__ qcount,
+                                           REC *__restrict__ queue, int *__restrict__ qcount,
                                            float *__restrict__ dlevel, int *s_cnt, int *s_off,
                                            int *s_gbase, Record *s_stage, StamperP &stp)
 {
@@ -666,21 +716,8 @@ __device__ __forceinline__ void emit_round(uint32_t (&ridx)[ROUND_RECS],
             const bool two = r1.idx != PAD_IDX;
             const int64_t gpos = (int64_t)s_gbase[b] + ((lo + 2 * i - s_off[b]) >> 1);
             if (gpos < cap) {
-#ifdef RSDF_REC_FP32
-                const uint32_t e1 = two ? entry_of(r1.idx, interleaved) : PAIR_NONE;
-                queue[(int64_t)b * cap + gpos] = PairRec{entry_of(r0.idx, interleaved) | (e1 << 16), r0.v0, r0.v1,
-                                                        two ? r1.v0 : 0.f, two ? r1.v1 : 0.f};
-#else
-                const PairRec pr{pack_rec(entry_of(r0.idx, interleaved), r0.v0, r0.v1),
-                                 two ? pack_rec(entry_of(r1.idx, interleaved), r1.v0, r1.v1) : 0ull};
-    // (streaming stores: the queues are read back by the reducer a whole launch later; producer 21.2 -> 20.5 ms)
-#ifndef RSDF_Q_PLAIN_STORE
-                __builtin_nontemporal_store(pr.r0, &queue[(int64_t)b * cap + gpos].r0);
-                __builtin_nontemporal_store(pr.r1, &queue[(int64_t)b * cap + gpos].r1);
-#else
-                queue[(int64_t)b * cap + gpos] = pr;
-#endif
-#endif
+                RecOps<REC>::store(&queue[(int64_t)b * cap + gpos], entry_of(r0.idx, interleaved), r0.v0, r0.v1, two,
+                                   two ? entry_of(r1.idx, interleaved) : 0u, r1.v0, r1.v1);
             } else {  // queue full (capacity carries slack; never drop a contribution)
                 atomicAdd(dlevel + 2 * (size_t)r0.idx, r0.v0);
                 atomicAdd(dlevel + 2 * (size_t)r0.idx + 1, r0.v1);
@@ -697,11 +734,11 @@ __device__ __forceinline__ void emit_round(uint32_t (&ridx)[ROUND_RECS],
 // Work item of the second phase: a displaced tap.  bits 0..9 sample within the workgroup, 10..12 tap - 1, 13 side (1: +1 cell)
 constexpr int MAX_ITEMS = P_THREADS * 6;
 
-template <bool DERIVE>
+template <bool DERIVE, typename REC>
 __global__ void __launch_bounds__(P_THREADS, RSDF_STAGE_RECS <= 4 ? 8 : 4)
 fd7_produce_kernel(const TapSrc src, const float2 *__restrict__ dplanes,
                    const rsdf_grid_meta meta, const LevelPlan plan, int64_t S, int n_active,
-                   PairRec *__restrict__ queues, int *__restrict__ counters,
+                   REC *__restrict__ queues, int *__restrict__ counters,
                    float *__restrict__ dtable)
 {
     __shared__ int s_cnt[MAX_BINS];
@@ -722,7 +759,7 @@ fd7_produce_kernel(const TapSrc src, const float2 *__restrict__ dplanes,
     const int64_t tile_id = grp * RSDF_BWD_GROUP + (rem - (int64_t)l * RSDF_BWD_GROUP);
     const LevelGeom g = level_geom(meta, l);
     float *dlevel = dtable + (size_t)meta.offset[l] * 2;
-    PairRec *queue = queues + plan.queue_off[l];
+    REC *queue = queues + plan.queue_off[l];
     int *qcount = counters + plan.counter_off[l];
     const int n_bins = plan.n_bins[l], interleaved = plan.interleaved[l];
     const int64_t cap = plan.cap[l];
@@ -849,7 +886,7 @@ fd7_produce_kernel(const TapSrc src, const float2 *__restrict__ dplanes,
     uint32_t ridx[ROUND_RECS];
     corner_indices(c0.c[0], c0.c[1], c0.c[2], g, ridx);
     RSDF_PSTAMP(stp, 3);   // corner indices
-    emit_round(ridx, acc, emit0 ? 0xffu : 0u, n_bins, interleaved, cap, queue, qcount, dlevel, s_cnt, s_off,
+    emit_round<REC>(ridx, acc, emit0 ? 0xffu : 0u, n_bins, interleaved, cap, queue, qcount, dlevel, s_cnt, s_off,
                s_gbase, s_stage, stp);   // (its barriers also publish the work list)
 
     // ---- phase 2: dense over the displaced taps, two per thread and round (4 new corners each)
@@ -890,7 +927,7 @@ fd7_produce_kernel(const TapSrc src, const float2 *__restrict__ dplanes,
             }
         }
         RSDF_PSTAMP(stp, 11);  // phase-2 item evaluation
-        emit_round(ridx, acc, mask, n_bins, interleaved, cap, queue, qcount, dlevel, s_cnt, s_off, s_gbase, s_stage, stp);
+        emit_round<REC>(ridx, acc, mask, n_bins, interleaved, cap, queue, qcount, dlevel, s_cnt, s_off, s_gbase, s_stage, stp);
     }
 }
 
@@ -902,11 +939,11 @@ fd7_produce_kernel(const TapSrc src, const float2 *__restrict__ dplanes,
 // side executes ~2e10 scattered atomics per second), as records through the bins they cost what 8 records per (point,
 // level) cost.  x [n,3] unit cube; dy rows [n, ld_dy], level l at columns col_off + 2 l, + 1.
 // ------------------------------------------------------------------------------------------------
-template <int MODE>
+template <int MODE, typename REC>
 __global__ void __launch_bounds__(P_THREADS, RSDF_STAGE_RECS <= 4 ? 8 : 4)
 scatter_produce_kernel(const float *__restrict__ x, const float *__restrict__ dy, int ld_dy, int col_off,
                        const float *__restrict__ gdx, const rsdf_grid_meta meta, const LevelPlan plan, int64_t S,
-                       int n_active, PairRec *__restrict__ queues, int *__restrict__ counters, float *__restrict__ dtable)
+                       int n_active, REC *__restrict__ queues, int *__restrict__ counters, float *__restrict__ dtable)
 {
     __shared__ int s_cnt[MAX_BINS];
     __shared__ int s_off[MAX_BINS + 1];
@@ -920,7 +957,7 @@ scatter_produce_kernel(const float *__restrict__ x, const float *__restrict__ dy
     const int64_t tile_id = grp * RSDF_BWD_GROUP + (rem - (int64_t)l * RSDF_BWD_GROUP);
     const LevelGeom g = level_geom(meta, l);
     float *dlevel = dtable + (size_t)meta.offset[l] * 2;
-    PairRec *queue = queues + plan.queue_off[l];
+    REC *queue = queues + plan.queue_off[l];
     int *qcount = counters + plan.counter_off[l];
     const int n_bins = plan.n_bins[l], interleaved = plan.interleaved[l];
     const int64_t cap = plan.cap[l];
@@ -992,15 +1029,16 @@ scatter_produce_kernel(const float *__restrict__ x, const float *__restrict__ dy
     }
     uint32_t ridx[ROUND_RECS];
     corner_indices(c0.c[0], c0.c[1], c0.c[2], g, ridx);
-    emit_round(ridx, acc, emit0 ? 0xffu : 0u, n_bins, interleaved, cap, queue, qcount, dlevel, s_cnt, s_off, s_gbase,
+    emit_round<REC>(ridx, acc, emit0 ? 0xffu : 0u, n_bins, interleaved, cap, queue, qcount, dlevel, s_cnt, s_off, s_gbase,
                s_stage, stp);
 }
 
 // ------------------------------------------------------------------------------------------------
 // backward: reduce
 // ------------------------------------------------------------------------------------------------
+template <typename REC>
 __global__ void __launch_bounds__(R_THREADS)
-fd7_reduce_kernel(const rsdf_grid_meta meta, const LevelPlan plan, const PairRec *__restrict__ queues,
+fd7_reduce_kernel(const rsdf_grid_meta meta, const LevelPlan plan, const REC *__restrict__ queues,
                   const int *__restrict__ counters, float *__restrict__ dtable)
 {
     extern __shared__ __attribute__((aligned(16))) double s_acc[];  // [BIN_ENTRIES][2], fp64: see below
@@ -1026,50 +1064,26 @@ fd7_reduce_kernel(const rsdf_grid_meta meta, const LevelPlan plan, const PairRec
 
     for (int i = threadIdx.x; i < entries * 2; i += R_THREADS) s_acc[i] = 0.0;
     __syncthreads();
-    const PairRec *q = queues + plan.queue_off[l] + (int64_t)b * cap;
+    const REC *q = queues + plan.queue_off[l] + (int64_t)b * cap;
     for (int64_t i0 = r0 + threadIdx.x; i0 < r1; i0 += (int64_t)R_THREADS * R_UNROLL) {
-        PairRec rec[R_UNROLL];
+        REC rec[R_UNROLL];
 #pragma unroll
         for (int u = 0; u < R_UNROLL; ++u) {
             const int64_t i = i0 + (int64_t)u * R_THREADS;
-#ifdef RSDF_REC_FP32
-            rec[u] = i < r1 ? q[i] : PairRec{0u, 0.f, 0.f, 0.f, 0.f};
-#else
-#ifdef RSDF_Q_NT_LOAD
-            if (i < r1) {
-                rec[u].r0 = __builtin_nontemporal_load(&q[i].r0);
-                rec[u].r1 = __builtin_nontemporal_load(&q[i].r1);
-            } else {
-                rec[u] = PairRec{0ull, 0ull};
-            }
-#else
-            rec[u] = i < r1 ? q[i] : PairRec{0ull, 0ull};
-#endif
-#endif
+            rec[u] = i < r1 ? RecOps<REC>::load(&q[i]) : RecOps<REC>::empty();
         }
 #pragma unroll
         for (int u = 0; u < R_UNROLL; ++u) {
             if (i0 + (int64_t)u * R_THREADS < r1) {
-#ifdef RSDF_REC_FP32
-                const uint32_t e0 = rec[u].e & 0xffffu, e1 = rec[u].e >> 16;   // entries within the bin (the producer's entry_of)
-                atomicAdd(&s_acc[2 * e0], (double)rec[u].a0);
-                atomicAdd(&s_acc[2 * e0 + 1], (double)rec[u].a1);
-                if (e1 != PAIR_NONE) {
-                    atomicAdd(&s_acc[2 * e1], (double)rec[u].b0);
-                    atomicAdd(&s_acc[2 * e1 + 1], (double)rec[u].b1);
-                }
-#else
                 uint32_t e0, e1;
                 double a0, a1, b0, b1;
-                unpack_rec(rec[u].r0, e0, a0, a1);
-                unpack_rec(rec[u].r1, e1, b0, b1);
+                const bool two = RecOps<REC>::decode(rec[u], e0, a0, a1, e1, b0, b1);
                 atomicAdd(&s_acc[2 * e0], a0);
                 atomicAdd(&s_acc[2 * e0 + 1], a1);
-                if (rec[u].r1 != 0ull) {   // a run of odd length ends in a half-empty element
+                if (two) {
                     atomicAdd(&s_acc[2 * e1], b0);
                     atomicAdd(&s_acc[2 * e1 + 1], b1);
                 }
-#endif
             }
         }
     }
@@ -1224,10 +1238,16 @@ int make_plan(const rsdf_grid_meta *meta, int64_t S, int n_active, float eps_uni
     return 0;
 }
 
+// the record format of this process (rsdf_set_record_format): 0 = block-float pairs (16-byte elements), 1 = fp32 values (20)
+#ifdef RSDF_REC_FP32
+int g_rec_fp32 = 1;
+#else
+int g_rec_fp32 = 0;
+#endif
 int64_t scratch_need(int64_t n_rec, int n_cnt)
 {
     const int64_t cbytes = (((int64_t)n_cnt * (int64_t)sizeof(int)) + 255) / 256 * 256;
-    return cbytes + n_rec * (int64_t)sizeof(PairRec) + 256;
+    return cbytes + n_rec * (int64_t)(g_rec_fp32 ? sizeof(RecF32) : sizeof(RecBF)) + 256;
 }
 
 }  // namespace
@@ -1287,19 +1307,35 @@ int launch_fwd(const TapSrc &src, const float *table, const rsdf_grid_meta *meta
     RSDF_RETURN_LAUNCH();
 }
 
-template <bool DERIVE>
+template <bool DERIVE, typename REC>
 void launch_produce(dim3 grid, size_t stage_bytes, hipStream_t st, const TapSrc &src, const float2 *dplanes,
-                    const rsdf_grid_meta &meta, const LevelPlan &plan, int64_t n_samples, int na, PairRec *queues,
+                    const rsdf_grid_meta &meta, const LevelPlan &plan, int64_t n_samples, int na, void *queues,
                     int *counters, float *dtable, int dev)
 {
-    static thread_local unsigned long long attr_set = 0;      // one bit per device (the attribute is per device)
+    static thread_local unsigned long long attr_set = 0;      // one bit per device (the attribute is per device and instantiation)
     if (!(attr_set >> (dev & 63) & 1ull)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fd7_produce_kernel<DERIVE>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fd7_produce_kernel<DERIVE, REC>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_bytes);
         attr_set |= 1ull << (dev & 63);
     }
-    fd7_produce_kernel<DERIVE><<<grid, P_THREADS, stage_bytes, st>>>(src, dplanes, meta, plan, n_samples, na, queues,
-                                                                     counters, dtable);
+    fd7_produce_kernel<DERIVE, REC><<<grid, P_THREADS, stage_bytes, st>>>(src, dplanes, meta, plan, n_samples, na,
+                                                                          reinterpret_cast<REC *>(queues), counters, dtable);
+}
+
+template <typename REC>
+int launch_reduce(const rsdf_grid_meta &meta, const LevelPlan &plan, int na, const void *queues, const int *counters, float *dtable,
+                  hipStream_t st)
+{
+    int max_wgs = 0;
+    for (int l = 0; l < na; ++l) {
+        const int w = plan.n_bins[l] * plan.n_split[l];
+        max_wgs = w > max_wgs ? w : max_wgs;
+    }
+    const size_t lds = (size_t)BIN_ENTRIES * 2 * sizeof(double);
+    if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(fd7_reduce_kernel<REC>), lds)) return rc;
+    fd7_reduce_kernel<REC><<<dim3(max_wgs, na), R_THREADS, lds, st>>>(meta, plan, reinterpret_cast<const REC *>(queues), counters,
+                                                                      dtable);
+    return 0;
 }
 
 int launch_bwd(const TapSrc &src, const float *dplanes, const rsdf_grid_meta *meta, int64_t n_samples,
@@ -1321,7 +1357,7 @@ int launch_bwd(const TapSrc &src, const float *dplanes, const rsdf_grid_meta *me
     hipStream_t st = (hipStream_t)stream;
     int *counters = (int *)scratch;
     const size_t cbytes = (((size_t)n_cnt * sizeof(int)) + 255) / 256 * 256;
-    PairRec *queues = (PairRec *)((char *)scratch + cbytes);
+    void *queues = (char *)scratch + cbytes;
     (void)hipMemsetAsync(counters, 0, cbytes, st);
     const unsigned p_tiles = (rsdf_blocks(n_samples, P_THREADS) + RSDF_BWD_GROUP - 1) / RSDF_BWD_GROUP * RSDF_BWD_GROUP;
     // HIP launches in threads: grid.x * block.x must stay below 2^32
@@ -1331,35 +1367,29 @@ int launch_bwd(const TapSrc &src, const float *dplanes, const rsdf_grid_meta *me
     int dev = 0;
     (void)hipGetDevice(&dev);
     const float2 *dpl = reinterpret_cast<const float2 *>(dplanes);
-    if (src.x7t)
-        launch_produce<false>(pgrid, stage_bytes, st, src, dpl, *meta, plan, n_samples, na, queues, counters, dtable, dev);
+    const bool f32 = g_rec_fp32 != 0;
+    if (src.x7t && f32)
+        launch_produce<false, RecF32>(pgrid, stage_bytes, st, src, dpl, *meta, plan, n_samples, na, queues, counters, dtable, dev);
+    else if (src.x7t)
+        launch_produce<false, RecBF>(pgrid, stage_bytes, st, src, dpl, *meta, plan, n_samples, na, queues, counters, dtable, dev);
+    else if (f32)
+        launch_produce<true, RecF32>(pgrid, stage_bytes, st, src, dpl, *meta, plan, n_samples, na, queues, counters, dtable, dev);
     else
-        launch_produce<true>(pgrid, stage_bytes, st, src, dpl, *meta, plan, n_samples, na, queues, counters, dtable, dev);
-    int max_wgs = 0;
-    for (int l = 0; l < na; ++l) {
-        const int w = plan.n_bins[l] * plan.n_split[l];
-        max_wgs = w > max_wgs ? w : max_wgs;
-    }
-    const size_t lds = (size_t)BIN_ENTRIES * 2 * sizeof(double);
-    static thread_local unsigned long long attr_set = 0;
-    if (!(attr_set >> (dev & 63) & 1ull)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fd7_reduce_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set |= 1ull << (dev & 63);
-    }
-    dim3 rgrid(max_wgs, na);
-    fd7_reduce_kernel<<<rgrid, R_THREADS, lds, st>>>(*meta, plan, queues, counters, dtable);
+        launch_produce<true, RecBF>(pgrid, stage_bytes, st, src, dpl, *meta, plan, n_samples, na, queues, counters, dtable, dev);
+    if (int rc = f32 ? launch_reduce<RecF32>(*meta, plan, na, queues, counters, dtable, st)
+                     : launch_reduce<RecBF>(*meta, plan, na, queues, counters, dtable, st))
+        return rc;
     RSDF_RETURN_LAUNCH();
 }
 
-template <int MODE>
+template <int MODE, typename REC>
 void launch_scatter_produce(dim3 grid, size_t stage_bytes, hipStream_t st, const float *x, const float *dy, int ld_dy,
                             int col_off, const float *gdx, const rsdf_grid_meta &meta, const LevelPlan &plan, int64_t n,
-                            int na, PairRec *queues, int *counters, float *dtable)
+                            int na, void *queues, int *counters, float *dtable)
 {
-    (void)rsdf_func_lds(reinterpret_cast<const void *>(scatter_produce_kernel<MODE>), stage_bytes);
-    scatter_produce_kernel<MODE><<<grid, P_THREADS, stage_bytes, st>>>(x, dy, ld_dy, col_off, gdx, meta, plan, n, na,
-                                                                      queues, counters, dtable);
+    (void)rsdf_func_lds(reinterpret_cast<const void *>(scatter_produce_kernel<MODE, REC>), stage_bytes);
+    scatter_produce_kernel<MODE, REC><<<grid, P_THREADS, stage_bytes, st>>>(x, dy, ld_dy, col_off, gdx, meta, plan, n, na,
+                                                                           reinterpret_cast<REC *>(queues), counters, dtable);
 }
 
 }  // namespace
@@ -1389,26 +1419,34 @@ int rsdf_hashgrid_scatter_binned(int mode, const float *x, const float *dy, int 
     hipStream_t st = (hipStream_t)stream;
     int *counters = (int *)scratch;
     const size_t cbytes = (((size_t)n_cnt * sizeof(int)) + 255) / 256 * 256;
-    PairRec *queues = (PairRec *)((char *)scratch + cbytes);
+    void *queues = (char *)scratch + cbytes;
     (void)hipMemsetAsync(counters, 0, cbytes, st);
     const unsigned p_tiles = (rsdf_blocks(n, P_THREADS) + RSDF_BWD_GROUP - 1) / RSDF_BWD_GROUP * RSDF_BWD_GROUP;
     RSDF_CHECK_ARG((uint64_t)p_tiles * na * P_THREADS < (1ull << 32), "hashgrid_scatter_binned: too many points for one launch");
     const dim3 pgrid(p_tiles * na, 1);
     const size_t stage_bytes = (size_t)STAGE_CAP * sizeof(Record);
-    if (mode == 0)
-        launch_scatter_produce<0>(pgrid, stage_bytes, st, x, dy, ld_dy, col_off, g_dx, *meta, plan, n, na, queues, counters, dtable);
-    else
-        launch_scatter_produce<1>(pgrid, stage_bytes, st, x, dy, ld_dy, col_off, g_dx, *meta, plan, n, na, queues, counters, dtable);
-    int max_wgs = 0;
-    for (int l = 0; l < na; ++l) {
-        const int w = plan.n_bins[l] * plan.n_split[l];
-        max_wgs = w > max_wgs ? w : max_wgs;
-    }
-    const size_t lds = (size_t)BIN_ENTRIES * 2 * sizeof(double);
-    if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(fd7_reduce_kernel), lds)) return rc;
-    fd7_reduce_kernel<<<dim3(max_wgs, na), R_THREADS, lds, st>>>(*meta, plan, queues, counters, dtable);
+    const bool f32 = g_rec_fp32 != 0;
+#define RSDF_SCATTER_LAUNCH(M, R) launch_scatter_produce<M, R>(pgrid, stage_bytes, st, x, dy, ld_dy, col_off, g_dx, *meta, plan, n, na, queues, counters, dtable)
+    if (mode == 0 && f32) RSDF_SCATTER_LAUNCH(0, RecF32);
+    else if (mode == 0) RSDF_SCATTER_LAUNCH(0, RecBF);
+    else if (f32) RSDF_SCATTER_LAUNCH(1, RecF32);
+    else RSDF_SCATTER_LAUNCH(1, RecBF);
+#undef RSDF_SCATTER_LAUNCH
+    if (int rc = f32 ? launch_reduce<RecF32>(*meta, plan, na, queues, counters, dtable, st)
+                     : launch_reduce<RecBF>(*meta, plan, na, queues, counters, dtable, st))
+        return rc;
     RSDF_RETURN_LAUNCH();
 }
+
+/* Run-time choice of the hash backward's queue record format for this process (round 6): 0 = 16-byte elements of two
+ * block-float contributions (20 significant bits; the default), 1 = 20-byte elements of fp32 values.  Not thread safe against
+ * concurrent launches: set it once (rise_sdf_amd reads RSDF_REC=fp32 at import); scratch sizes follow the current setting. */
+int rsdf_set_record_format(int fp32_values)
+{
+    g_rec_fp32 = fp32_values ? 1 : 0;
+    return 0;
+}
+int rsdf_get_record_format(void) { return g_rec_fp32; }
 
 int rsdf_hashgrid_fwd_fd7(const float *x7t, const float *table, const rsdf_grid_meta *meta,
                           int64_t n_samples, int n_active_levels, float *planes, void *stream)

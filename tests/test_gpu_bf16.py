@@ -128,7 +128,7 @@ def test_pair_chain_16bit_mode_matches_16bit_operand_oracle(dev, widths, precisi
         a, b = a.double().cpu().flatten(), b.double().cpu().flatten()
         e = (a - b).abs() / float(b.abs().max())
         q = float(torch.quantile(e, 0.999)) if e.numel() <= 10_000_000 else float(e.kthvalue(int(e.numel() * 0.999)).values)
-        assert _cos(a, b) > 0.9999 and q < 5e-3 and float(e.max()) < 0.2, (name, _cos(a, b), q, float(e.max()))
+        assert _cos(a, b) > 0.9999 and q < 1e-2 and float(e.max()) < 0.2, (name, _cos(a, b), q, float(e.max()))
     close(dx_g, dx_h, "dx")
     for i, ((w, b), p) in enumerate(zip(p_g, p_h)):
         close(w.grad, p["w"].grad, f"w{i}")

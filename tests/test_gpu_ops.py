@@ -7,6 +7,8 @@ oracle.  Tolerances are written at each assert.
 import math
 
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -773,6 +775,66 @@ def test_binned_scatter_record_format_bound(dev, ops):
     dy_bad[5, 4] = float("inf")
     bad = binned(dy_bad)
     assert int(torch.isnan(bad).sum()) >= 8 and int(torch.isnan(bad).sum()) <= 16     # the 8 corners of level 2, both features
+
+
+def test_record_format_is_a_run_time_choice(dev, ops):
+    """the hash backward's queue records -- block-float pairs (20 significant bits, the default) or fp32
+    values (what the reference's fp32 atomics accumulate, models/network_utils.py:47-59) -- are both compiled in and chosen
+    with rsdf_set_record_format / RSDF_REC=fp32, no rebuild.  The plain-point scatter and the stencil backward under both:
+    the fp32 form within fp32 rounding of the fp64 oracle sum (2^-22 of the per-entry sum of |contributions|), the
+    block-float form within its own bound and measurably coarser; scratch sizes follow the format (20 vs 16 bytes)."""
+    import ctypes
+    from rise_sdf_amd import _lib
+    cfg = GRIDS[1]
+    meta_o, n_params = oracle.grid_meta(**cfg)
+    meta_g, _ = _lib.make_grid_meta(**cfg)
+    g = torch.Generator().manual_seed(78)
+    n = 3000
+    x = torch.rand(n, 3, generator=g)
+    dy = torch.randn(n, 32, generator=g) * torch.logspace(-4, 2, n)[:, None]
+    L = _lib.lib()
+    assert L.rsdf_get_record_format() == (1 if os.environ.get("RSDF_REC") == "fp32" else 0)
+    t = torch.zeros(n_params, dtype=torch.float64, requires_grad=True)
+    (oracle.hashgrid_encode(x, t, meta_o).double() * dy.double()).sum().backward()
+    ref = t.grad.clone()
+    t.grad = None
+    (oracle.hashgrid_encode(x, t, meta_o).double() * dy.abs().double()).sum().backward()
+    mass = t.grad.clone()                                # per entry: sum of |contributions|
+    errs, sizes = {}, {}
+    start = L.rsdf_get_record_format()
+    try:
+        for fmt in (0, 1):
+            assert L.rsdf_set_record_format(fmt) == 0 and L.rsdf_get_record_format() == fmt
+            nbytes = int(L.rsdf_hashgrid_scatter_binned_scratch_bytes(ctypes.byref(meta_g), n, 16))
+            sizes[fmt] = nbytes
+            scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            got = torch.zeros(n_params, device=dev)
+            dyd = dy.to(dev).contiguous()
+            assert L.rsdf_hashgrid_scatter_binned(0, _lib.ptr(x.to(dev)), _lib.ptr(dyd), 32, 0, None, ctypes.byref(meta_g), n, 16,
+                                                  _lib.ptr(got), _lib.ptr(scratch), nbytes, _lib.stream_ptr()) == 0
+            torch.cuda.synchronize()
+            e = (got.cpu().double() - ref).abs()
+            errs[fmt] = float((e / (mass + 1e-300)).max())
+            bound = mass * (2.0 ** -22 if fmt else 2.0 ** -19.6) + 1e-37
+            assert bool((e <= bound).all()), (fmt, float((e / bound).max()))
+            # the stencil backward (the fused field's table gradient) under the same setting: against the atomics form
+            from test_gpu_x2 import _field_inputs
+            meta7, table7, ws7, x7t, pts, radius, eps = _field_inputs(dev, ops, 2000, 64, 13, seed=5)
+            dpl = torch.randn(16, 7, 2000, 2, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+            nb7 = int(L.rsdf_hashgrid_bwd_fd7_scratch_bytes(ctypes.byref(meta7), 2000, 16, float(eps / (2 * radius))))
+            sc7 = torch.empty(nb7, dtype=torch.uint8, device=dev)
+            dt = torch.zeros_like(table7.detach())
+            assert L.rsdf_hashgrid_bwd_fd7_pts(_lib.ptr(pts), float(radius), float(eps), _lib.ptr(dpl), ctypes.byref(meta7), 2000, 16,
+                                               float(eps / (2 * radius)), _lib.ptr(dt), _lib.ptr(sc7), nb7, _lib.stream_ptr()) == 0
+            torch.cuda.synchronize()
+            errs[("fd7", fmt)] = dt.clone()
+    finally:
+        L.rsdf_set_record_format(start)
+    assert sizes[1] > sizes[0] and abs((sizes[1] - sizes[0]) / sizes[0] - 0.25) < 0.05, sizes      # 20 against 16 bytes per element
+    print(f"record formats vs the fp64 sum, worst entry / its |mass|: block-float {errs[0]:.2e}, fp32 values {errs[1]:.2e}")
+    assert errs[1] < 2.0 ** -22 and errs[1] < errs[0]
+    a, b = errs[("fd7", 0)], errs[("fd7", 1)]
+    assert float((a - b).abs().max()) <= 2.0 ** -18 * float(b.abs().max()) and float((a - b).abs().max()) > 0
 
 
 def test_large_hashmap_backward_falls_back_to_atomics(dev, ops):
