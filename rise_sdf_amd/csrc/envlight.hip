@@ -187,7 +187,13 @@ template <bool BWD>
 __device__ __forceinline__ void spec_pair(PairAcc &acc, const V3 &A, float cc, float k1, float a2, float cpi,
                                           const float4 t, float p0, float p1, float p2)
 {
+#ifdef SPEC_UNFUSED_DOT
     const float d = t.x * A.x + t.y * A.y + t.z * A.z;
+#else
+    // (round 6: two fma -- the reference's dot(L, VNR) is built by nvcc with its default contraction too; a texel within an ulp
+    // of the cutoff may fall on the other side than bounds_kernel's unfused form puts it: the tests bracket exactly that)
+    const float d = fmaf(t.z, A.z, fmaf(t.y, A.y, t.x * A.x));
+#endif
     const float ex = A.x - t.x, ey = A.y - t.y, ez = A.z - t.z;
     const float e2 = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
     const float dd = fmaf(e2, k1, a2);                                  // sin^2 (1 - a2) + a2, sin^2 = |A - B|^2 / 4
@@ -246,9 +252,9 @@ specular_kernel(const float *__restrict__ src, int src_ch, const float *__restri
                     }
                 }
             } else {
+#ifdef SPEC_G64_FLAT
                 // i / bw without an integer division per pair: (i + 0.5) / bw is at least 0.5 / bw away from an integer and
-                // i < 2^18, so the float product truncates to the exact quotient.  (Carrying (yo, xo) from pair to pair
-                // instead was measured: slower on the small maps, whose windows are narrower than the stride of G.)
+                // i < 2^18, so the float product truncates to the exact quotient.
                 const float inv_bw = 1.0f / (float)bw;
                 const int cnt = bw * bh, base = (s * R + ymin) * R + xmin, wrap = R - bw;
                 auto texel = [&](int i) {
@@ -270,6 +276,43 @@ specular_kernel(const float *__restrict__ src, int src_ch, const float *__restri
                     const float *q0 = src + (size_t)ta * src_ch;
                     spec_pair<BWD>(acc, A, cc, k1, a2, cpi, table[ta], q0[0], q0[1], q0[2]);
                 }
+#else
+                // Round 6: the wave's 64 lanes walk the window as an 8 x 8 block (lane = (ly, lx)), two blocks per trip.  The
+                // flat form above spent ~14 of its ~46 vector instructions per pair on the index (float reciprocal quotient,
+                // mul24, two 64-bit address chains); here a pair costs an add, a min, two compares and a select: a lane outside
+                // the window loads the clamped edge texel and compares against a cutoff of 2 (weight 0).  Measured alone
+                // (tools/bench_prefilter.py): see profiles/r06*.
+                const int lx = sub & 7, ly = sub >> 3;
+                const unsigned tb_bytes = 16u, sb_bytes = 4u * (unsigned)src_ch;
+                const char *tbase = reinterpret_cast<const char *>(table);
+                const char *sbase = reinterpret_cast<const char *>(src);
+                for (int y0 = 0; y0 < bh; y0 += 8) {
+                    const int yy = y0 + ly;
+                    const bool yok = yy < bh;
+                    const int rb = (s * R + ymin + min(yy, bh - 1)) * R + xmin;           // < 6 * 4096^2 < 2^31
+                    int x0 = 0;
+                    for (; x0 + 8 < bw; x0 += 16) {
+                        const int xa = x0 + lx, xb = xa + 8;
+                        const unsigned ta = (unsigned)(rb + min(xa, bw - 1)), tb = (unsigned)(rb + min(xb, bw - 1));
+                        const float4 t0 = spec_ld_table(reinterpret_cast<const float4 *>(tbase + (size_t)(ta * tb_bytes)), A, (int)ta);
+                        const float4 t1 = spec_ld_table(reinterpret_cast<const float4 *>(tbase + (size_t)(tb * tb_bytes)), A, (int)tb);
+                        const float *q0 = reinterpret_cast<const float *>(sbase + (size_t)(ta * sb_bytes));
+                        const float *q1 = reinterpret_cast<const float *>(sbase + (size_t)(tb * sb_bytes));
+                        const float u0 = spec_ld_src(q0, 0, (int)ta), u1 = spec_ld_src(q0, 1, (int)ta), u2 = spec_ld_src(q0, 2, (int)ta);
+                        const float v0 = spec_ld_src(q1, 0, (int)tb), v1 = spec_ld_src(q1, 1, (int)tb), v2 = spec_ld_src(q1, 2, (int)tb);
+                        spec_pair<BWD>(acc, A, (yok && xa < bw) ? cc : 2.0f, k1, a2, cpi, t0, u0, u1, u2);
+                        spec_pair<BWD>(acc, A, (yok && xb < bw) ? cc : 2.0f, k1, a2, cpi, t1, v0, v1, v2);
+                    }
+                    if (x0 < bw) {
+                        const int xa = x0 + lx;
+                        const unsigned ta = (unsigned)(rb + min(xa, bw - 1));
+                        const float4 t0 = spec_ld_table(reinterpret_cast<const float4 *>(tbase + (size_t)(ta * tb_bytes)), A, (int)ta);
+                        const float *q0 = reinterpret_cast<const float *>(sbase + (size_t)(ta * sb_bytes));
+                        const float u0 = spec_ld_src(q0, 0, (int)ta), u1 = spec_ld_src(q0, 1, (int)ta), u2 = spec_ld_src(q0, 2, (int)ta);
+                        spec_pair<BWD>(acc, A, (yok && xa < bw) ? cc : 2.0f, k1, a2, cpi, t0, u0, u1, u2);
+                    }
+                }
+#endif
             }
         } else {   // no cached table: direction and solid angle per pair (API completeness; the mirrors always pass one)
             const float inv_bw = 1.0f / (float)bw;
