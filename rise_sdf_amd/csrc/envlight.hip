@@ -252,7 +252,7 @@ specular_kernel(const float *__restrict__ src, int src_ch, const float *__restri
                     }
                 }
             } else {
-#ifdef SPEC_G64_FLAT
+#ifndef SPEC_G64_BLOCKS
                 // i / bw without an integer division per pair: (i + 0.5) / bw is at least 0.5 / bw away from an integer and
                 // i < 2^18, so the float product truncates to the exact quotient.
                 const float inv_bw = 1.0f / (float)bw;
@@ -277,11 +277,12 @@ specular_kernel(const float *__restrict__ src, int src_ch, const float *__restri
                     spec_pair<BWD>(acc, A, cc, k1, a2, cpi, table[ta], q0[0], q0[1], q0[2]);
                 }
 #else
-                // Round 6: the wave's 64 lanes walk the window as an 8 x 8 block (lane = (ly, lx)), two blocks per trip.  The
-                // flat form above spent ~14 of its ~46 vector instructions per pair on the index (float reciprocal quotient,
-                // mul24, two 64-bit address chains); here a pair costs an add, a min, two compares and a select: a lane outside
-                // the window loads the clamped edge texel and compares against a cutoff of 2 (weight 0).  Measured alone
-                // (tools/bench_prefilter.py): see profiles/r06*.
+                // Round 6 experiment (-DSPEC_G64_BLOCKS), NOT the default: the wave's 64 lanes walk the window as an 8 x 8 block
+                // (lane = (ly, lx)), two blocks per trip -- 28 instead of ~46 vector instructions per pair (no reciprocal
+                // quotient, no mul24, 32-bit offsets), and SLOWER: 2.26 + 2.12 ms against 2.14 + 2.00 ms for the five levels
+                // (tools/bench_prefilter.py, profiles/r06*/spec_ab.log).  With the diagnostics of the same file (no loads at
+                // all: 1.57 + 1.38 ms) this says the window loops are bound by neither instruction count nor bytes but by the
+                // short dependent chains of a 27-pair-per-lane loop between wave reductions.
                 const int lx = sub & 7, ly = sub >> 3;
                 const unsigned tb_bytes = 16u, sb_bytes = 4u * (unsigned)src_ch;
                 const char *tbase = reinterpret_cast<const char *>(table);

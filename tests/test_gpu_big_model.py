@@ -116,7 +116,9 @@ def _run_big(dev, stage1, n_side, out_key, keys, mlp_tol=3e-4, table_tol=1e-3):
     with entry_points() as bwd:
         (out[out_key] * g.to(dev)).sum().backward()
     # stage 0: albedo, metallic, roughness, env + the secondary network; stage 1 adds nothing new to the set
-    _assert_shipped_kernels(fwd.calls, bwd.calls, n_pair_networks=4)
+    import os
+    if os.environ.get("RSDF_TEST_ANY_KERNELS") != "1":        # (debug: compare kernel families with RSDF_PAIR=0 / RSDF_X2=0)
+        _assert_shipped_kernels(fwd.calls, bwd.calls, n_pair_networks=4)
     R.check_status()                                       # no range violation, nothing counted
     gt = model.geometry.encoding.encoding.encoding.params.grad.cpu()
     hip, ref_g = _all_param_grads(model, P)
@@ -126,6 +128,7 @@ def _run_big(dev, stage1, n_side, out_key, keys, mlp_tol=3e-4, table_tol=1e-3):
     t_err = float((gt - P["table"].grad).abs().max()) / float(P["table"].grad.abs().max())
     print("big model stage %d: S=%d, worst parameter gradient %s %.2e, table %.2e" %
           (1 if stage1 else 0, int(out["num_samples"]) if "num_samples" in out else -1, worst, report[worst], t_err))
+    print("   HIP vs oracle, largest: " + ", ".join(f"{k} {v:.1e}" for k, v in sorted(report.items(), key=lambda kv: -kv[1])[:8]))
     # (the measured movement only ever RAISES a gate, and by at most a factor of five: in this scene the table x 1000 makes some
     # rays saturate and the oracle moves by up to several per cent in single tensors, which must not make the gate vacuous)
     gates = {k: max(mlp_tol, min(3.0 * moved.get(k, 0.0), 5.0 * mlp_tol)) for k in ref_g}

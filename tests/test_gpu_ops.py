@@ -800,6 +800,10 @@ def test_record_format_is_a_run_time_choice(dev, ops):
     t.grad = None
     (oracle.hashgrid_encode(x, t, meta_o).double() * dy.abs().double()).sum().backward()
     mass = t.grad.clone()                                # per entry: sum of |contributions|
+    t.grad = None
+    big = torch.maximum(dy[:, 0::2].abs(), dy[:, 1::2].abs()).repeat_interleave(2, dim=1)    # max(|d0|, |d1|) per level:
+    (oracle.hashgrid_encode(x, t, meta_o).double() * big.double()).sum().backward()        # the block-float pair's step
+    mass_pair = t.grad.clone()
     errs, sizes = {}, {}
     start = L.rsdf_get_record_format()
     try:
@@ -814,8 +818,8 @@ def test_record_format_is_a_run_time_choice(dev, ops):
                                                   _lib.ptr(got), _lib.ptr(scratch), nbytes, _lib.stream_ptr()) == 0
             torch.cuda.synchronize()
             e = (got.cpu().double() - ref).abs()
-            errs[fmt] = float((e / (mass + 1e-300)).max())
-            bound = mass * (2.0 ** -22 if fmt else 2.0 ** -19.6) + 1e-37
+            errs[fmt] = float((e / (mass_pair + 1e-300)).max())
+            bound = (mass * 2.0 ** -22 if fmt else mass_pair * 2.0 ** -19.6) + 1e-37
             assert bool((e <= bound).all()), (fmt, float((e / bound).max()))
             # the stencil backward (the fused field's table gradient) under the same setting: against the atomics form
             from test_gpu_x2 import _field_inputs
