@@ -38,15 +38,27 @@ def big_config(stage1):
 
 
 def build_big(dev, stage1, seed=0):
+    """A smooth blob with detail at every level and a near-eikonal gradient (|grad sdf| median 0.8, max 2.7): table x 1000, the
+    first layer's hash columns randn x 0.3 x 0.7^level (equal gradient contribution per level instead of equal amplitude:
+    with equal amplitudes the finest levels make |grad sdf| >> 1, every ray saturates at its first sample and the
+    reference's weight backward amplifies rounding residues, tests/test_oracle_sensitivity.py), output bias + 0.25 (weight_norm
+    over the un-zeroed columns flattens the sphere init), inv_s = 403.  Chosen on the CPU with the oracle alone: ~9 k primary
+    samples for 256 rays, ~60 opaque pixels, half of their reflections occluded, no alpha exactly 1, |d_alpha| <= 2.2.  All
+    random numbers come from CPU generators, so the oracle-side exploration and this model are the same scene."""
     import rise_sdf_amd as R
     torch.manual_seed(seed)
-    model = R.make("split-mixed-occ", big_config(stage1)).to(dev)
+    model = R.make("split-mixed-occ", big_config(stage1))
+    g = torch.Generator().manual_seed(11)
+    with torch.no_grad():
+        model.geometry.encoding.encoding.encoding.params.mul_(1000.0)
+        l0 = model.geometry.network.layers[0]
+        level = torch.arange(l0.weight_v.shape[1] - 3) // 2
+        l0.weight_v[:, 3:] = torch.randn(l0.weight_v[:, 3:].shape, generator=g) * 0.3 * (0.7 ** level.float())[None, :]
+        model.variance.variance.fill_(0.6)            # sharp surface: opaque pixels, secondary rays fire
+        model.geometry.network.layers[-1].bias[0] += 0.25
+    model = model.to(dev)
     model.train()
     with torch.no_grad():
-        model.geometry.encoding.encoding.encoding.params.mul_(1000.0)      # lumpy blob: some reflections are occluded
-        l0 = model.geometry.network.layers[0]
-        l0.weight_v[:, 3:] = torch.randn_like(l0.weight_v[:, 3:]) * 0.15
-        model.variance.variance.fill_(0.6)            # sharp surface: opaque pixels, secondary rays fire
         if stage1:
             model.texture.FG_LUT = OT.synthetic_fg_lut(64).to(dev)
     model.occupancy_grid.binaries = sphere_binary(128, 0.2, 0.9).to(dev)[None]
