@@ -274,6 +274,9 @@ class OccGridEstimator(nn.Module):
         ray_indices) -> [S]`` prunes by visibility exactly like the vendored marcher does.  ``return_alphas`` (with
         ``alpha_fn``): a fourth output, the kept samples' alphas as ``alpha_fn`` returned them for the visibility test -- a
         no-grad renderer of these samples would evaluate the field a second time for the same values."""
+        if return_alphas and alpha_fn is None:
+            raise ValueError("OccGridEstimator.sampling(return_alphas=True) needs alpha_fn: the fourth output is what alpha_fn "
+                             "returned for the kept samples (with sigma_fn or no fn there is nothing to hand back)")
         near = None if near_plane is None else float(near_plane)
         far = None if far_plane is None else float(far_plane)
         if t_min is None or t_max is None:
@@ -327,7 +330,7 @@ class OccGridEstimator(nn.Module):
                 return res
             ray_indices, t_starts, t_ends = res[:3]
         elif return_alphas:
-            return ray_indices, t_starts, t_ends, torch.zeros_like(t_starts)      # (no samples at all)
+            return ray_indices, t_starts, t_ends, torch.zeros_like(t_starts)      # (alpha_fn given, but no samples at all)
         return ray_indices, t_starts, t_ends
 
     # ---- capacity mode (opt-in: ``estimator.capacity_mode = True``; rise_sdf_amd.step.TrainStep switches it on) ----------

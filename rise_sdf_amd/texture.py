@@ -93,10 +93,15 @@ class VolumeMixedMipSplitOcc(nn.Module):
         # torch.cat([feats, xyz]) / torch.cat([feats, wo_enc]) of models/texture.py:299,313 are the networks' two-source inputs
         # (VanillaMLP.forward(x, x2=...): the pair kernels pack them straight into their input image; one image serves the three
         # networks that read [feats, xyz])
+        from . import ops as _ops
         if stage == 0:
             albedo6 = self.albedo_network(feats, x2=xyz)
             metallic2 = self.metallic_network(feats, x2=xyz)
             spec3 = self.env_network(feats, x2=wo_enc)
+            # the shared input image of the material networks is scoped to this forward (the cache pinned the input
+            # rows and a 512 B / row image until the next pack, and its hit test cannot see raw-pointer writes into a reused
+            # buffer); the autograd nodes keep their own reference to the image for the backward
+            _ops._PAIR_PACK_CACHE.clear()
             return T.split_color0(albedo6, metallic2, spec3)
         # stage 1: split-sum shading (models/texture.py:329-345); color_activation (sigmoid) fused into the
         # last layer of each material network
@@ -105,6 +110,7 @@ class VolumeMixedMipSplitOcc(nn.Module):
         roughness = self.roughness_network(feats, out_act="sigmoid", x2=xyz)
         metallic2 = self.metallic_network(feats, out_act="sigmoid", x2=xyz)
         spec3 = self.env_network(feats, out_act="sigmoid", x2=wo_enc)
+        _ops._PAIR_PACK_CACHE.clear()
         diffuse_light = emitter.eval_mip(normals)
         wo = wo01 * 2.0 - 1.0
         specular_light = emitter.eval_mip(wo, specular=True, roughness=roughness)
@@ -116,7 +122,10 @@ class VolumeMixedMipSplitOcc(nn.Module):
         dirs_embd = self.dir_encoding(((rays_d + 1.0) / 2.0).reshape(-1, self.n_dir_dims))
         inp = torch.cat([features.reshape(-1, features.shape[-1]), dirs_embd]
                         + [a.reshape(-1, a.shape[-1]) for a in args], dim=-1)
-        return torch.sigmoid(self.secondary_network(inp))
+        out = torch.sigmoid(self.secondary_network(inp))
+        from . import ops as _ops
+        _ops._PAIR_PACK_CACHE.clear()
+        return out
 
     def secondary_shading_pbr(self, features, dirs, normals, positions, emitter):
         """models/texture.py:386-427: split-sum shading of the third-bounce point seen along ``dirs`` (relighting).
@@ -130,6 +139,8 @@ class VolumeMixedMipSplitOcc(nn.Module):
         albedo6 = self.albedo_network(inp, out_act="sigmoid")
         roughness = self.roughness_network(inp, out_act="sigmoid")
         metallic2 = self.metallic_network(inp, out_act="sigmoid")
+        from . import ops as _ops
+        _ops._PAIR_PACK_CACHE.clear()
         diffuse_light = emitter.eval_mip(normals)
         specular_light = emitter.eval_mip(dirs, specular=True, roughness=roughness)
         fg_uv = torch.cat([torch.clamp(nov, min=0.0, max=1.0), torch.clamp(roughness, min=0.0, max=1.0)], -1)
