@@ -19,7 +19,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29517")
+    os.environ.setdefault("MASTER_PORT", "29517")       # (the test passes a free port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)

@@ -14,7 +14,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_rccl_one_rank_group_runs_the_gradient_exchange(dev):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))                    # a free rendezvous port (the probe's default may be taken on a shared box)
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT=str(port))
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RSDF_DIST_SHARE_GPU", "RSDF_DIST_BACKEND"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_probe.py")], env=env, capture_output=True,
