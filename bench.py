@@ -582,6 +582,28 @@ def secondary_measurements(dev, args, rays, jitter, cot):
                                   "stage")}
     guarded("c3_step", c3)
     guarded("c3_step_bf16_radiance", lambda: c3(tex_precision="bf16"))
+
+    def rccl():
+        """RCCL on this box: a one-rank ``nccl`` group in a CHILD process (this one owns no process group
+        and must not exec over an initialised GPU) drives the gradient exchange of the N-rank step over the real tensors."""
+        import subprocess
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RSDF_DIST_SHARE_GPU", "RSDF_DIST_BACKEND"):
+            env.pop(k, None)
+        import socket
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        env["MASTER_PORT"] = str(sock.getsockname()[1])
+        sock.close()
+        r = subprocess.run([sys.executable, "-m", "rise_sdf_amd.dist", "--selftest"], env=env, cwd=ROOT, capture_output=True,
+                           text=True, timeout=600)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")]
+        if r.returncode != 0 or not lines:
+            raise RuntimeError(f"rccl selftest exit {r.returncode}: {r.stderr[-200:]}")
+        out = json.loads(lines[-1][7:])
+        out["note"] = "one rank on cuda:0: the collectives execute on the device; values unchanged by construction"
+        return out
+    guarded("rccl_selftest", rccl)
     return extras
 
 

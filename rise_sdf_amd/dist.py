@@ -164,3 +164,61 @@ def spawn_ranks(argv: List[str], n: int, timeout: float | None = None) -> int:
         time.sleep(0.05)
     sys.stdout.flush()
     return rc
+
+
+def rccl_selftest(port: int | None = None) -> dict:
+    """RCCL on this box, in THIS process (call it in a fresh one: ``python -m rise_sdf_amd.dist --selftest``): a one-rank
+    ``nccl`` group on cuda:0 drives the gradient exchange of the data-parallel step (launch.py:84-97, Lightning DDP's all-reduce)
+    through GradBuckets on the REAL tensors of the yaml's model -- the 55.4 MiB hash-table gradient and the 18.9 MiB
+    environment map in place, every other parameter through the flat buffer.  A one-rank sum is the identity, so the check is
+    that the collectives execute on the device (async issue + finish, the way TrainStep uses them) and leave every gradient
+    bit-identical.  tests/test_gpu_rccl.py and bench.py's ``secondary.rccl_selftest`` run it."""
+    import time
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1")
+    if port is not None:
+        os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("MASTER_PORT", "29517")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    from . import make
+    from .config import tensoir_model_config
+    torch.manual_seed(0)
+    model = make("split-mixed-occ", tensoir_model_config()).to(dev)      # yaml sizes: L=16 T=2^19, 512^2 cube map
+    g = torch.Generator(device=dev).manual_seed(1)
+    for p in model.parameters():
+        if p.requires_grad:
+            p.grad = torch.randn(p.shape, device=dev, generator=g)
+    before = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    buckets = GradBuckets(model.parameters())
+    res = {"dist_backend": dist.get_backend(), "world": dist.get_world_size(),
+           "in_place_tensors": [int(p.numel()) for p in buckets.big], "flat_elements": int(buckets.flat.numel()),
+           "bytes_per_step": buckets.bytes_per_step()}
+    times = []
+    for _ in range(4):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        handles = buckets.all_reduce_mean(1, async_op=True, single_rank_too=True)
+        assert len(handles) == len(buckets.big) + 1, len(handles)
+        buckets.finish(handles, 1)
+        torch.cuda.synchronize()
+        times.append(round((time.perf_counter() - t0) * 1e3, 3))
+    res["collectives_per_step"] = len(buckets.big) + 1
+    res["ms_per_exchange"] = times
+    res["bit_identical"] = all(torch.equal(p.grad, before[n]) for n, p in model.named_parameters() if p.grad is not None)
+    t = max(model.parameters(), key=lambda p: p.numel()).grad
+    ref = t.clone()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    dist.barrier(device_ids=[0])
+    torch.cuda.synchronize()
+    res["table_sum_identity"] = bool(torch.equal(t, ref))
+    dist.destroy_process_group()
+    return res
+
+
+if __name__ == "__main__":
+    import json
+    import sys
+    if "--selftest" in sys.argv:
+        print("RESULT " + json.dumps(rccl_selftest()), flush=True)
