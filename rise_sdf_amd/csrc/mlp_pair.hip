@@ -221,6 +221,30 @@ __device__ __forceinline__ float grad_scale(float bound)
 }
 __device__ __forceinline__ bool f16_pos(unsigned h) { return (h & 0x8000u) == 0u && (h & 0x7fffu) != 0u; }
 
+// ---- 16-bit mode only (NP = 1): the backward's fp32 ROW stream of a tile -- d hb (g) of a lower pair, or the forward's hb rows
+// that give the top pair its ReLU mask -- lands in LDS by DMA ONE TILE AHEAD, like the X image, instead of per-lane global loads
+// at the top of the tile that are needed a few hundred cycles later (round 6: with a third of the matrix instructions the
+// 16-bit backward's tile is 4.5 us, of which such a load's ~1 us round trip was exposed).  The buffer lives in the second
+// part of the Wb^T image, which the one-part form does not use: two 16 KB tiles (parity).  Slot s (16 bytes) of row r holds
+// column chunk s ^ (r & 31): a 16-lane pass of ds_read_b128 over 16 rows of one chunk then covers all 64 banks once.
+constexpr int GST_TILE = 32 * H * 4;                    // 16 KB
+__device__ __forceinline__ void dma_rows(unsigned char *gst, const float *src, int64_t s0, int64_t n, int ws, int lane)
+{
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = ws + 8 * k;                        // instruction i: rows 2 i, 2 i + 1 of the tile (1 KB)
+        const int r = 2 * i + (lane >> 5), slot = lane & 31;
+        int64_t row = s0 + r;
+        row = row < n ? row : n - 1;
+        const float *gp = src + row * H + 4 * (slot ^ (r & 31));
+        __builtin_amdgcn_global_load_lds((glob_void *)gp, (lds_void *)(gst + i * 1024), 16, 0, 0);
+    }
+}
+__device__ __forceinline__ float4 staged_row4(const unsigned char *gst, int r, int chunk)     // columns 4 chunk .. + 3 of tile row r
+{
+    return *reinterpret_cast<const float4 *>(gst + r * (H * 4) + ((chunk ^ (r & 31)) << 4));
+}
+
 struct PairArgs {
     const unsigned char *x;          // input image
     int64_t n, tiles;
@@ -364,7 +388,14 @@ pair_kernel(const PairArgs a)
     float dxmax = 0.0f;
     bool bad = bad0;
 
-    if ((int64_t)blockIdx.x < a.tiles) dma_tile<NP>(smem + XI, a.x, (int64_t)blockIdx.x, ws, lane, kba);
+    // (16-bit backward: the tile's fp32 row stream by DMA one tile ahead, see dma_rows)
+    const float *rows_src = nullptr;
+    if (BWD && NP == 1) rows_src = TOP ? a.hmask : ((a.g != nullptr && a.hmask == nullptr) ? a.g : nullptr);
+    unsigned char *gst = smem + WTI + WT_PART;
+    if ((int64_t)blockIdx.x < a.tiles) {
+        dma_tile<NP>(smem + XI, a.x, (int64_t)blockIdx.x, ws, lane, kba);
+        if (BWD && NP == 1 && rows_src != nullptr) dma_rows(gst, rows_src, (int64_t)blockIdx.x * 32, a.n, ws, lane);
+    }
     // ---- layer a backward, input side: the dx slab (columns 16 w .. 16 w + 15, all 32 rows) of the tile whose dz_a image is in
     // LDS.  DEFERRED by one tile (round 6; -DRSDF_PAIR_NO_DEFER_DX for A/B): it runs right after barrier (1) of the NEXT tile,
     // which removes the fourth barrier of a tile (dz_a's only cross-wave reader is this product) and gives the 16 KB of dx
@@ -454,11 +485,15 @@ pair_kernel(const PairArgs a)
                     }
                     dz[rh] = acc;
                 } else {
-                    const float4 v = *reinterpret_cast<const float4 *>(a.g + rowc * H + 16 * w + 4 * g);
+                    const float4 v = (NP == 1 && rows_src != nullptr)
+                                         ? staged_row4(gst + (parity ^ 1) * GST_TILE, 16 * rh + c16, 4 * w + g)
+                                         : *reinterpret_cast<const float4 *>(a.g + rowc * H + 16 * w + 4 * g);
                     dz[rh] = f32x4{v.x, v.y, v.z, v.w};
                 }
                 if (TOP ? true : (MASKED && a.hmask != nullptr)) {    // the mask from the forward's own hb rows instead of a recompute
-                    const float4 m = *reinterpret_cast<const float4 *>(a.hmask + rowc * H + 16 * w + 4 * g);
+                    const float4 m = (NP == 1 && TOP && rows_src != nullptr)
+                                         ? staged_row4(gst + (parity ^ 1) * GST_TILE, 16 * rh + c16, 4 * w + g)
+                                         : *reinterpret_cast<const float4 *>(a.hmask + rowc * H + 16 * w + 4 * g);
                     dz[rh][0] = m.x > 0.0f ? dz[rh][0] : 0.0f;
                     dz[rh][1] = m.y > 0.0f ? dz[rh][1] : 0.0f;
                     dz[rh][2] = m.z > 0.0f ? dz[rh][2] : 0.0f;
@@ -472,7 +507,11 @@ pair_kernel(const PairArgs a)
                 }
             }
         }
-        if (ti + gridDim.x < a.tiles) dma_tile<NP>(smem + XI + parity * IMG, a.x, ti + gridDim.x, ws, lane, kba);
+        if (ti + gridDim.x < a.tiles) {
+            dma_tile<NP>(smem + XI + parity * IMG, a.x, ti + gridDim.x, ws, lane, kba);
+            if (BWD && NP == 1 && rows_src != nullptr)
+                dma_rows(gst + parity * GST_TILE, rows_src, (ti + gridDim.x) * 32, a.n, ws, lane);
+        }
         // ---- layer a: C = T za -> SA ha
         f32x4 ha[2];
 #pragma unroll

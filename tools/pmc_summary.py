@@ -22,6 +22,7 @@ ENTRY = {  # kernel name fragment -> C-ABI entry point (first match wins; <true>
     "absmax_kernel": "rsdf_sdfmlp_fd7_bwd_x2",
     "fd7_fwd_kernel<true>": "rsdf_hashgrid_fwd_fd7_pts",
     "fd7_produce_kernel<true>": "rsdf_hashgrid_bwd_fd7_pts",
+    "fd7_produce_kernel<true,": "rsdf_hashgrid_bwd_fd7_pts",     # round 6: <DERIVE, REC> (the record format is a template argument)
     "fd7_reduce_kernel": "rsdf_hashgrid_bwd_fd7_pts",       # (bench.py only runs the _pts form)
     "fd7_fwd_kernel": "rsdf_hashgrid_fwd_fd7",
     "fd7_produce_kernel": "rsdf_hashgrid_bwd_fd7",
