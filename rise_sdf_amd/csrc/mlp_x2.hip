@@ -473,7 +473,12 @@ struct QL {
     static constexpr int DZI = H1I + NP * H_PART;                 // dz2
     static constexpr int DZ1 = DZI + NP * H_PART;                 // dz1 in an image of its own (no barrier between the last
     static constexpr int RED = DZ1 + NP * H_PART;                 //   read of dz2 and the write of dz1); 8 floats of scratch
-    static constexpr int END = RED + 32;
+    // round 6: the tile's per-row gradient inputs land by DMA ONE TILE AHEAD (see dma_grads): d_sdf of the next tile-tap
+    // (32 floats, two buffers) and, for the centre tap, the [32][H] rows of d(h2) (one buffer: consumed six tiles before it
+    // is refilled)
+    static constexpr int DSD = RED + 32;                          // 2 x 128 B
+    static constexpr int DH2 = DSD + 256;                         // 32 rows x H fp32, 16-byte chunks XOR-swizzled by row
+    static constexpr int END = DH2 + 32 * H * 4;
 };
 
 __device__ __forceinline__ int qoff(int row, int col)
@@ -591,6 +596,35 @@ __device__ __forceinline__ void dma_tile(unsigned char *img, const SrcX2 &src, i
     if (ws < 3 * NP) dma_one(img, tb, ws, lane);
     if (NW == 4 && NP == 2 && ws < 2) dma_one(img, tb, ws + 4, lane);
 }
+// The per-row gradient inputs of tile (group, tap) by DMA into LDS: d_sdf7[tap][32 rows] (wave 0, 32 lanes x 4 bytes) and, for
+// tap 0, dh2c[32 rows][H] (1 KB per instruction: 1024 / (4 H) rows each; chunk c of row r at slot c ^ (r & (H / 4 - 1)) so that
+// the 16 rows a lane group reads for one chunk cover all banks).  Rows past the end are clamped to the last sample, as the
+// per-lane loads did; their values are masked by row_ok at the point of use.
+template <int NW>
+__device__ __forceinline__ void dma_grads(unsigned char *dsd, unsigned char *dh2, const float *__restrict__ d_sdf7,
+                                          const float *__restrict__ dh2c, int64_t S, int64_t s0, int tap, int ws, int lane)
+{
+    constexpr int H = 16 * NW, CPR = H / 4;                 // 16-byte chunks per row
+    if (ws == 0 && lane < 32) {
+        int64_t row = s0 + lane;
+        row = row < S ? row : S - 1;
+        __builtin_amdgcn_global_load_lds((glob_void *)(d_sdf7 + (int64_t)tap * S + row), (lds_void *)dsd, 4, 0, 0);
+    }
+    if (tap == 0 && dh2c != nullptr) {
+        constexpr int RPI = 64 / CPR;                       // rows per 1 KB instruction: 4 (H = 64) / 2 (H = 128)
+        constexpr int N_INSTR = 32 / RPI;                   // 8 / 16
+#pragma unroll
+        for (int k = 0; k < N_INSTR / NW; ++k) {
+            const int i = ws + NW * k;
+            const int r = RPI * i + lane / CPR, slot = lane % CPR;
+            int64_t row = s0 + r;
+            row = row < S ? row : S - 1;
+            __builtin_amdgcn_global_load_lds((glob_void *)(dh2c + row * H + 4 * (slot ^ (r & (CPR - 1)))),
+                                             (lds_void *)(dh2 + i * 1024), 16, 0, 0);
+        }
+    }
+}
+
 // d_planes (896 B per sample, 13-17 GB per launch) are written once here and read once by the hash backward's producer, a
 // whole launch later: a streaming (non-temporal) store keeps them out of the caches' way (22.0 -> 21.6 ms per launch;
 // -DRSDF_X2_PLAIN_DPLANES for A/B)
@@ -700,7 +734,14 @@ bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
     const float k_dz1 = G1 / (SW * G2), k_dx = 1.0f / (SW * G1);
 
     const int64_t n_groups = src.Sp / 32;
+#ifndef RSDF_X2_NO_GRAD_DMA
+    if ((int64_t)blockIdx.x < n_groups) {
+        dma_tile<NW, NP>(smem + L::XI, src, (int64_t)blockIdx.x, 0, ws, lane);
+        dma_grads<NW>(smem + L::DSD, smem + L::DH2, d_sdf7, dh2c, src.S, (int64_t)blockIdx.x * 32, 0, ws, lane);
+    }
+#else
     if ((int64_t)blockIdx.x < n_groups) dma_tile<NW, NP>(smem + L::XI, src, (int64_t)blockIdx.x, 0, ws, lane);
+#endif
     // ---- layer 1 backward, input side: d(hash features) sub-tile (16 columns x 16 rows, all features) of the tile whose dz1
     // image is in LDS.  DEFERRED by one tile (round 6, -DRSDF_X2_NO_DEFER_DX for A/B): it runs right after barrier (1) of the
     // NEXT tile, which (a) removes the fourth barrier of a tile -- dz1's only cross-wave reader is this product -- and (b)
@@ -744,11 +785,21 @@ bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
             for (int rh = 0; rh < 2; ++rh) {
                 const int64_t row = s0 + 16 * rh + c16;
                 row_ok[rh] = row < src.S;
+#ifndef RSDF_X2_NO_GRAD_DMA
+                // (after the flip ``parity`` names the NEXT tile's buffers: this tile's d_sdf is in the other one)
+                dsdf_raw[rh] = reinterpret_cast<const float *>(smem + L::DSD + (parity ^ 1) * 128)[16 * rh + c16];
+                if (tap == 0 && dh2c != nullptr) {     // (uniform) centre taps: d(h2) through the feature rows
+                    const int r = 16 * rh + c16;
+                    const float4 v = *reinterpret_cast<const float4 *>(smem + L::DH2 + r * (H * 4) +
+                                                                       (((4 * w + g) ^ (r & (H / 4 - 1))) << 4));
+                    dz[rh] = f32x4{v.x, v.y, v.z, v.w};
+#else
                 const int64_t rowc = row_ok[rh] ? row : src.S - 1;
                 dsdf_raw[rh] = d_sdf7[(int64_t)tap * src.S + rowc];
                 if (tap == 0 && dh2c != nullptr) {     // (uniform) centre taps: d(h2) through the feature rows
                     const float4 v = *reinterpret_cast<const float4 *>(dh2c + rowc * H + 16 * w + 4 * g);
                     dz[rh] = f32x4{v.x, v.y, v.z, v.w};
+#endif
                 } else {
                     dz[rh] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
@@ -756,7 +807,12 @@ bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
             {
                 const int ntap = tap == 6 ? 0 : tap + 1;
                 const int64_t ng = tap == 6 ? gi + gridDim.x : gi;
-                if (ng < n_groups) dma_tile<NW, NP>(smem + L::XI + parity * NP * QX_PART, src, ng, ntap, ws, lane);
+                if (ng < n_groups) {
+                    dma_tile<NW, NP>(smem + L::XI + parity * NP * QX_PART, src, ng, ntap, ws, lane);
+#ifndef RSDF_X2_NO_GRAD_DMA
+                    dma_grads<NW>(smem + L::DSD + parity * 128, smem + L::DH2, d_sdf7, dh2c, src.S, ng * 32, ntap, ws, lane);
+#endif
+                }
             }
             // ---- recompute layer 1 (C = T1 z1) -> SH h1
             f32x4 h1[2], h2[2];
