@@ -63,7 +63,8 @@ constexpr int LDS_FWD = FWD_WO + OUT_W;                   // the forward needs X
 constexpr int BWD_WO = RED + 64;
 constexpr int DZO = BWD_WO + OUT_W;                       // [part 2][chunk 2][32 rows][8 columns] fp16
 constexpr int DZO_PART = 2 * QCS;
-constexpr int LDS_BWD = DZO + 2 * DZO_PART;
+constexpr int DZS = DZO + 2 * DZO_PART;                   // dz_out rows of a tile [32][N2 <= 8] fp32, two buffers (parity): by DMA
+constexpr int LDS_BWD = DZS + 2 * 1024;
 
 struct Frag2 { u32x4 h, l; };
 
@@ -240,6 +241,17 @@ __device__ __forceinline__ void dma_rows(unsigned char *gst, const float *src, i
         __builtin_amdgcn_global_load_lds((glob_void *)gp, (lds_void *)(gst + i * 1024), 16, 0, 0);
     }
 }
+// the tile's dz_out rows [32][n_out] are one contiguous span of the [n][n_out] tensor: four 256-byte DMA instructions (waves 0..3)
+__device__ __forceinline__ void dma_dzo(unsigned char *dst, const float *dz_out, int64_t s0, int64_t n, int n_out, int ws, int lane)
+{
+    if (ws >= 4) return;
+    const int e = 64 * ws + lane;
+    if (e >= 32 * n_out) return;
+    int64_t idx = s0 * n_out + e;
+    const int64_t last = n * n_out - 1;
+    idx = idx < last ? idx : last;                       // (rows past the end: masked by row_ok at the point of use)
+    __builtin_amdgcn_global_load_lds((glob_void *)(dz_out + idx), (lds_void *)(dst + ws * 256), 4, 0, 0);
+}
 __device__ __forceinline__ float4 staged_row4(const unsigned char *gst, int r, int chunk)     // columns 4 chunk .. + 3 of tile row r
 {
     return *reinterpret_cast<const float4 *>(gst + r * (H * 4) + ((chunk ^ (r & 31)) << 4));
@@ -395,6 +407,7 @@ pair_kernel(const PairArgs a)
     if ((int64_t)blockIdx.x < a.tiles) {
         dma_tile<NP>(smem + XI, a.x, (int64_t)blockIdx.x, ws, lane, kba);
         if (BWD && NP == 1 && rows_src != nullptr) dma_rows(gst, rows_src, (int64_t)blockIdx.x * 32, a.n, ws, lane);
+        if (TOP && a.dz_out != nullptr) dma_dzo(smem + DZS, a.dz_out, (int64_t)blockIdx.x * 32, a.n, a.n_out, ws, lane);
     }
     // ---- layer a backward, input side: the dx slab (columns 16 w .. 16 w + 15, all 32 rows) of the tile whose dz_a image is in
     // LDS.  DEFERRED by one tile (round 6; -DRSDF_PAIR_NO_DEFER_DX for A/B): it runs right after barrier (1) of the NEXT tile,
@@ -457,60 +470,32 @@ pair_kernel(const PairArgs a)
 #endif
         f32x4 dz[2];
         bool row_ok[2];
+        // ---- backward: the tile's per-row gradient inputs.  Round 6: the global loads are ISSUED here and CONSUMED after the
+        // layer-a recompute below (which does not depend on them): at the top of the tile their ~1 us round trip was exposed
+        // (one workgroup per CU: nothing else runs).  The 16-bit form takes the row stream from the DMA staging buffer instead
+        // (dma_rows), and the top pair's small dz_out rows come by DMA one tile ahead in both forms (dma_dzo).
+        float4 vg[2], vm[2];
+        const bool top_fold = TOP && a.dz_out != nullptr;
+        const bool need_mask = TOP ? true : (MASKED && a.hmask != nullptr);
+        const bool staged = NP == 1 && rows_src != nullptr;
         if (BWD) {
 #pragma unroll
             for (int rh = 0; rh < 2; ++rh) {
                 const int64_t row = s0 + 16 * rh + c16;
                 row_ok[rh] = row < a.n;
                 const int64_t rowc = row_ok[rh] ? row : a.n - 1;
-                if (TOP && a.dz_out != nullptr) {      // d hb = dz_out W_out, formed from 4 N2 bytes per row instead of 512 read
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                    unsigned short *pz = reinterpret_cast<unsigned short *>(smem + DZO + ((16 * rh + c16) << 4));
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        if (q < a.n_out) {
-                            const float dq = row_ok[rh] ? a.dz_out[rowc * a.n_out + q] : 0.0f;
-                            if (a.dw_out != nullptr && ws == 0 && g == 0) {    // dz_out as a 16-column image (x GZ)
-                                unsigned hh, ll;
-                                split2_pair<NP>(dq * GZ, 0.0f, hh, ll);
-                                pz[q] = (unsigned short)(hh & 0xffffu);
-                                if (NP == 2) pz[DZO_PART / 2 + q] = (unsigned short)(ll & 0xffffu);
-                            }
-                            const float4 wq = *reinterpret_cast<const float4 *>(s_wo + q * H + 16 * w + 4 * g);
-                            acc[0] = fmaf(dq, wq.x, acc[0]);
-                            acc[1] = fmaf(dq, wq.y, acc[1]);
-                            acc[2] = fmaf(dq, wq.z, acc[2]);
-                            acc[3] = fmaf(dq, wq.w, acc[3]);
-                        }
-                    }
-                    dz[rh] = acc;
-                } else {
-                    const float4 v = (NP == 1 && rows_src != nullptr)
-                                         ? staged_row4(gst + (parity ^ 1) * GST_TILE, 16 * rh + c16, 4 * w + g)
-                                         : *reinterpret_cast<const float4 *>(a.g + rowc * H + 16 * w + 4 * g);
-                    dz[rh] = f32x4{v.x, v.y, v.z, v.w};
+                if (!top_fold && !staged) {
+                    vg[rh] = *reinterpret_cast<const float4 *>(a.g + rowc * H + 16 * w + 4 * g);
                 }
-                if (TOP ? true : (MASKED && a.hmask != nullptr)) {    // the mask from the forward's own hb rows instead of a recompute
-                    const float4 m = (NP == 1 && TOP && rows_src != nullptr)
-                                         ? staged_row4(gst + (parity ^ 1) * GST_TILE, 16 * rh + c16, 4 * w + g)
-                                         : *reinterpret_cast<const float4 *>(a.hmask + rowc * H + 16 * w + 4 * g);
-                    dz[rh][0] = m.x > 0.0f ? dz[rh][0] : 0.0f;
-                    dz[rh][1] = m.y > 0.0f ? dz[rh][1] : 0.0f;
-                    dz[rh][2] = m.z > 0.0f ? dz[rh][2] : 0.0f;
-                    dz[rh][3] = m.w > 0.0f ? dz[rh][3] : 0.0f;
-                    if (TOP && a.dw_out != nullptr) {
-                        // dW_out += dz_out^T hb needs hb as a k = rows operand: its image goes where dz_a will go later in this
-                        // tile (free until barrier (3))
-                        const f32x4 hs = row_ok[rh] ? f32x4{m.x * SA, m.y * SA, m.z * SA, m.w * SA} : f32x4{0.f, 0.f, 0.f, 0.f};
-                        store_q<NP>(smem + DZ1, rh, lc, hs);
-                    }
-                }
+                if (need_mask && !(staged && TOP)) vm[rh] = *reinterpret_cast<const float4 *>(a.hmask + rowc * H + 16 * w + 4 * g);
             }
         }
         if (ti + gridDim.x < a.tiles) {
             dma_tile<NP>(smem + XI + parity * IMG, a.x, ti + gridDim.x, ws, lane, kba);
             if (BWD && NP == 1 && rows_src != nullptr)
                 dma_rows(gst + parity * GST_TILE, rows_src, (ti + gridDim.x) * 32, a.n, ws, lane);
+            if (TOP && a.dz_out != nullptr)
+                dma_dzo(smem + DZS + parity * 1024, a.dz_out, (ti + gridDim.x) * 32, a.n, a.n_out, ws, lane);
         }
         // ---- layer a: C = T za -> SA ha
         f32x4 ha[2];
@@ -527,6 +512,51 @@ pair_kernel(const PairArgs a)
                 if (!BWD) bad |= !(acc[r] < 65504.0f * (T / SA));
             }
             store_q<NP>(smem + H1I, rh, lc, ha[rh]);
+        }
+        if (BWD) {
+#pragma unroll
+            for (int rh = 0; rh < 2; ++rh) {
+                if (top_fold) {                        // d hb = dz_out W_out, formed from 4 N2 bytes per row instead of 512 read
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    unsigned short *pz = reinterpret_cast<unsigned short *>(smem + DZO + ((16 * rh + c16) << 4));
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        if (q < a.n_out) {
+                            const float dqv = row_ok[rh] ? reinterpret_cast<const float *>(smem + DZS + (parity ^ 1) * 1024)
+                                                               [(16 * rh + c16) * a.n_out + q] : 0.0f;
+                            if (a.dw_out != nullptr && ws == 0 && g == 0) {    // dz_out as a 16-column image (x GZ)
+                                unsigned hh, ll;
+                                split2_pair<NP>(dqv * GZ, 0.0f, hh, ll);
+                                pz[q] = (unsigned short)(hh & 0xffffu);
+                                if (NP == 2) pz[DZO_PART / 2 + q] = (unsigned short)(ll & 0xffffu);
+                            }
+                            const float4 wq = *reinterpret_cast<const float4 *>(s_wo + q * H + 16 * w + 4 * g);
+                            acc[0] = fmaf(dqv, wq.x, acc[0]);
+                            acc[1] = fmaf(dqv, wq.y, acc[1]);
+                            acc[2] = fmaf(dqv, wq.z, acc[2]);
+                            acc[3] = fmaf(dqv, wq.w, acc[3]);
+                        }
+                    }
+                    dz[rh] = acc;
+                } else {
+                    const float4 v = staged ? staged_row4(gst + (parity ^ 1) * GST_TILE, 16 * rh + c16, 4 * w + g) : vg[rh];
+                    dz[rh] = f32x4{v.x, v.y, v.z, v.w};
+                }
+                if (need_mask) {                       // the mask from the forward's own hb rows instead of a recompute
+                    const float4 m = (staged && TOP) ? staged_row4(gst + (parity ^ 1) * GST_TILE, 16 * rh + c16, 4 * w + g)
+                                                     : vm[rh];
+                    dz[rh][0] = m.x > 0.0f ? dz[rh][0] : 0.0f;
+                    dz[rh][1] = m.y > 0.0f ? dz[rh][1] : 0.0f;
+                    dz[rh][2] = m.z > 0.0f ? dz[rh][2] : 0.0f;
+                    dz[rh][3] = m.w > 0.0f ? dz[rh][3] : 0.0f;
+                    if (TOP && a.dw_out != nullptr) {
+                        // dW_out += dz_out^T hb needs hb as a k = rows operand: its image goes where dz_a will go later in this
+                        // tile (free until barrier (3))
+                        const f32x4 hs = row_ok[rh] ? f32x4{m.x * SA, m.y * SA, m.z * SA, m.w * SA} : f32x4{0.f, 0.f, 0.f, 0.f};
+                        store_q<NP>(smem + DZ1, rh, lc, hs);
+                    }
+                }
+            }
         }
         lds_barrier();                         // (2) H1 image complete
         // ---- layer b: C = T zb

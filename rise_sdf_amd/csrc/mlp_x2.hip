@@ -734,14 +734,17 @@ bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
     const float k_dz1 = G1 / (SW * G2), k_dx = 1.0f / (SW * G1);
 
     const int64_t n_groups = src.Sp / 32;
+    // (H = 64 only: measured 22.07 -> 21.54 ms per launch; at H = 128 the eight-wave kernel has no register to spare -- seven
+    // spills, 52.1 -> 52.4 ms -- and keeps the per-lane loads.  -DRSDF_X2_NO_GRAD_DMA for A/B.)
 #ifndef RSDF_X2_NO_GRAD_DMA
+    constexpr bool GRAD_DMA = NW == 4;
+#else
+    constexpr bool GRAD_DMA = false;
+#endif
     if ((int64_t)blockIdx.x < n_groups) {
         dma_tile<NW, NP>(smem + L::XI, src, (int64_t)blockIdx.x, 0, ws, lane);
-        dma_grads<NW>(smem + L::DSD, smem + L::DH2, d_sdf7, dh2c, src.S, (int64_t)blockIdx.x * 32, 0, ws, lane);
+        if (GRAD_DMA) dma_grads<NW>(smem + L::DSD, smem + L::DH2, d_sdf7, dh2c, src.S, (int64_t)blockIdx.x * 32, 0, ws, lane);
     }
-#else
-    if ((int64_t)blockIdx.x < n_groups) dma_tile<NW, NP>(smem + L::XI, src, (int64_t)blockIdx.x, 0, ws, lane);
-#endif
     // ---- layer 1 backward, input side: d(hash features) sub-tile (16 columns x 16 rows, all features) of the tile whose dz1
     // image is in LDS.  DEFERRED by one tile (round 6, -DRSDF_X2_NO_DEFER_DX for A/B): it runs right after barrier (1) of the
     // NEXT tile, which (a) removes the fourth barrier of a tile -- dz1's only cross-wave reader is this product -- and (b)
@@ -785,21 +788,16 @@ bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
             for (int rh = 0; rh < 2; ++rh) {
                 const int64_t row = s0 + 16 * rh + c16;
                 row_ok[rh] = row < src.S;
-#ifndef RSDF_X2_NO_GRAD_DMA
-                // (after the flip ``parity`` names the NEXT tile's buffers: this tile's d_sdf is in the other one)
-                dsdf_raw[rh] = reinterpret_cast<const float *>(smem + L::DSD + (parity ^ 1) * 128)[16 * rh + c16];
+                const int64_t rowc = row_ok[rh] ? row : src.S - 1;
+                // (GRAD_DMA: after the flip ``parity`` names the NEXT tile's buffers: this tile's d_sdf is in the other one)
+                dsdf_raw[rh] = GRAD_DMA ? reinterpret_cast<const float *>(smem + L::DSD + (parity ^ 1) * 128)[16 * rh + c16]
+                                        : d_sdf7[(int64_t)tap * src.S + rowc];
                 if (tap == 0 && dh2c != nullptr) {     // (uniform) centre taps: d(h2) through the feature rows
                     const int r = 16 * rh + c16;
-                    const float4 v = *reinterpret_cast<const float4 *>(smem + L::DH2 + r * (H * 4) +
-                                                                       (((4 * w + g) ^ (r & (H / 4 - 1))) << 4));
+                    const float4 v = GRAD_DMA ? *reinterpret_cast<const float4 *>(smem + L::DH2 + r * (H * 4) +
+                                                                                  (((4 * w + g) ^ (r & (H / 4 - 1))) << 4))
+                                              : *reinterpret_cast<const float4 *>(dh2c + rowc * H + 16 * w + 4 * g);
                     dz[rh] = f32x4{v.x, v.y, v.z, v.w};
-#else
-                const int64_t rowc = row_ok[rh] ? row : src.S - 1;
-                dsdf_raw[rh] = d_sdf7[(int64_t)tap * src.S + rowc];
-                if (tap == 0 && dh2c != nullptr) {     // (uniform) centre taps: d(h2) through the feature rows
-                    const float4 v = *reinterpret_cast<const float4 *>(dh2c + rowc * H + 16 * w + 4 * g);
-                    dz[rh] = f32x4{v.x, v.y, v.z, v.w};
-#endif
                 } else {
                     dz[rh] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
@@ -809,9 +807,8 @@ bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
                 const int64_t ng = tap == 6 ? gi + gridDim.x : gi;
                 if (ng < n_groups) {
                     dma_tile<NW, NP>(smem + L::XI + parity * NP * QX_PART, src, ng, ntap, ws, lane);
-#ifndef RSDF_X2_NO_GRAD_DMA
-                    dma_grads<NW>(smem + L::DSD + parity * 128, smem + L::DH2, d_sdf7, dh2c, src.S, ng * 32, ntap, ws, lane);
-#endif
+                    if (GRAD_DMA)
+                        dma_grads<NW>(smem + L::DSD + parity * 128, smem + L::DH2, d_sdf7, dh2c, src.S, ng * 32, ntap, ws, lane);
                 }
             }
             // ---- recompute layer 1 (C = T1 z1) -> SH h1
