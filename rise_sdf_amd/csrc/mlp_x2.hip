@@ -600,7 +600,10 @@ __device__ __forceinline__ void dma_tile(unsigned char *img, const SrcX2 &src, i
 // tap 0, dh2c[32 rows][H] (1 KB per instruction: 1024 / (4 H) rows each; chunk c of row r at slot c ^ (r & (H / 4 - 1)) so that
 // the 16 rows a lane group reads for one chunk cover all banks).  Rows past the end are clamped to the last sample, as the
 // per-lane loads did; their values are masked by row_ok at the point of use.
-template <int NW>
+#ifndef RSDF_X2_GRAD_DMA_H128
+#define RSDF_X2_GRAD_DMA_H128 0
+#endif
+template <int NW, bool WITH_DH2 = true>
 __device__ __forceinline__ void dma_grads(unsigned char *dsd, unsigned char *dh2, const float *__restrict__ d_sdf7,
                                           const float *__restrict__ dh2c, int64_t S, int64_t s0, int tap, int ws, int lane)
 {
@@ -610,7 +613,7 @@ __device__ __forceinline__ void dma_grads(unsigned char *dsd, unsigned char *dh2
         row = row < S ? row : S - 1;
         __builtin_amdgcn_global_load_lds((glob_void *)(d_sdf7 + (int64_t)tap * S + row), (lds_void *)dsd, 4, 0, 0);
     }
-    if (tap == 0 && dh2c != nullptr) {
+    if (WITH_DH2 && tap == 0 && dh2c != nullptr) {
         constexpr int RPI = 64 / CPR;                       // rows per 1 KB instruction: 4 (H = 64) / 2 (H = 128)
         constexpr int N_INSTR = 32 / RPI;                   // 8 / 16
 #pragma unroll
@@ -737,13 +740,15 @@ bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
     // (H = 64 only: measured 22.07 -> 21.54 ms per launch; at H = 128 the eight-wave kernel has no register to spare -- seven
     // spills, 52.1 -> 52.4 ms -- and keeps the per-lane loads.  -DRSDF_X2_NO_GRAD_DMA for A/B.)
 #ifndef RSDF_X2_NO_GRAD_DMA
-    constexpr bool GRAD_DMA = NW == 4;
+    constexpr bool GRAD_DMA = NW == 4 || RSDF_X2_GRAD_DMA_H128;     // d_sdf of the next tile-tap
+    constexpr bool GRAD_DMA_DH2 = NW == 4;                          // ... and the centre tap's d(h2) rows
 #else
-    constexpr bool GRAD_DMA = false;
+    constexpr bool GRAD_DMA = false, GRAD_DMA_DH2 = false;
 #endif
     if ((int64_t)blockIdx.x < n_groups) {
         dma_tile<NW, NP>(smem + L::XI, src, (int64_t)blockIdx.x, 0, ws, lane);
-        if (GRAD_DMA) dma_grads<NW>(smem + L::DSD, smem + L::DH2, d_sdf7, dh2c, src.S, (int64_t)blockIdx.x * 32, 0, ws, lane);
+        if (GRAD_DMA)
+            dma_grads<NW, GRAD_DMA_DH2>(smem + L::DSD, smem + L::DH2, d_sdf7, dh2c, src.S, (int64_t)blockIdx.x * 32, 0, ws, lane);
     }
     // ---- layer 1 backward, input side: d(hash features) sub-tile (16 columns x 16 rows, all features) of the tile whose dz1
     // image is in LDS.  DEFERRED by one tile (round 6, -DRSDF_X2_NO_DEFER_DX for A/B): it runs right after barrier (1) of the
@@ -794,7 +799,7 @@ bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
                                         : d_sdf7[(int64_t)tap * src.S + rowc];
                 if (tap == 0 && dh2c != nullptr) {     // (uniform) centre taps: d(h2) through the feature rows
                     const int r = 16 * rh + c16;
-                    const float4 v = GRAD_DMA ? *reinterpret_cast<const float4 *>(smem + L::DH2 + r * (H * 4) +
+                    const float4 v = GRAD_DMA_DH2 ? *reinterpret_cast<const float4 *>(smem + L::DH2 + r * (H * 4) +
                                                                                   (((4 * w + g) ^ (r & (H / 4 - 1))) << 4))
                                               : *reinterpret_cast<const float4 *>(dh2c + rowc * H + 16 * w + 4 * g);
                     dz[rh] = f32x4{v.x, v.y, v.z, v.w};
@@ -808,7 +813,8 @@ bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
                 if (ng < n_groups) {
                     dma_tile<NW, NP>(smem + L::XI + parity * NP * QX_PART, src, ng, ntap, ws, lane);
                     if (GRAD_DMA)
-                        dma_grads<NW>(smem + L::DSD + parity * 128, smem + L::DH2, d_sdf7, dh2c, src.S, ng * 32, ntap, ws, lane);
+                        dma_grads<NW, GRAD_DMA_DH2>(smem + L::DSD + parity * 128, smem + L::DH2, d_sdf7, dh2c, src.S, ng * 32, ntap,
+                                                    ws, lane);
                 }
             }
             // ---- recompute layer 1 (C = T1 z1) -> SH h1
