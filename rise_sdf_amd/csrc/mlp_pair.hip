@@ -412,7 +412,8 @@ pair_kernel(const PairArgs a)
     // ---- layer a backward, input side: the dx slab (columns 16 w .. 16 w + 15, all 32 rows) of the tile whose dz_a image is in
     // LDS.  DEFERRED by one tile (round 6; -DRSDF_PAIR_NO_DEFER_DX for A/B): it runs right after barrier (1) of the NEXT tile,
     // which removes the fourth barrier of a tile (dz_a's only cross-wave reader is this product) and gives the 16 KB of dx
-    // stores a whole tile to retire before the next s_waitcnt vmcnt(0) instead of being issued just before it.  ``pxi``: that
+    // stores a whole tile to retire before the next s_waitcnt vmcnt(0) instead of being issued just before it (they are then
+    // OLDER than the next tile's DMA, which that wait is for).  ``pxi``: that
     // tile's X image (the ReLU mask of dx comes from this wave's OWN slab of it, which only this wave's share of the next
     // DMA overwrites -- issued after this call in program order).
     auto emit_dx = [&](int64_t ps0, const unsigned char *pxi) {
@@ -457,7 +458,22 @@ pair_kernel(const PairArgs a)
     for (int64_t ti = blockIdx.x; ti < a.tiles; ti += gridDim.x) {
         const int64_t s0 = ti * 32;
         const unsigned char *xi = smem + XI + parity * IMG;
-        wait_vm0();                            // this wave's share of the tile has landed (and the previous tile's stores retired)
+        // this wave's share of the tile has landed.  Vector-memory operations retire in issue order (MI355X_MICROARCH.md,
+        // "s_waitcnt vmcnt(N)"), and the FORWARD's stores of the previous tile (out_rows, the output image) were issued after
+        // this tile's DMA: a counted wait leaves them in flight instead of draining them at the top of a 1.2 us tile (round 6).
+        // The backward's stores (emit_dx) are older than its DMA and have had a whole tile: vmcnt(0) costs nothing there.
+        if (!BWD && ti != (int64_t)blockIdx.x) {
+            const int young = (a.out_rows != nullptr ? 2 : 0) + (a.out_img != nullptr ? (NP == 2 ? 2 : 1) : 0);   // per wave, at least
+            switch (young) {
+            case 4: __builtin_amdgcn_s_waitcnt(0x0F74); break;
+            case 3: __builtin_amdgcn_s_waitcnt(0x0F73); break;
+            case 2: __builtin_amdgcn_s_waitcnt(0x0F72); break;
+            case 1: __builtin_amdgcn_s_waitcnt(0x0F71); break;
+            default: wait_vm0(); break;
+            }
+        } else {
+            wait_vm0();
+        }
         lds_barrier();                         // (1) every share has landed; the other X image and the H1 / DZ images are free
         parity ^= 1;
 #ifndef RSDF_PAIR_NO_DEFER_DX

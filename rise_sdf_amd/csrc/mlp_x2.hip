@@ -754,7 +754,7 @@ bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
     // image is in LDS.  DEFERRED by one tile (round 6, -DRSDF_X2_NO_DEFER_DX for A/B): it runs right after barrier (1) of the
     // NEXT tile, which (a) removes the fourth barrier of a tile -- dz1's only cross-wave reader is this product -- and (b)
     // gives the d_planes stores a whole tile to retire before the next s_waitcnt vmcnt(0) (they used to be issued just before
-    // it: stores count in vmcnt, and reads and writes return out of order, so vmcnt(n) cannot skip them).
+    // it, younger than the next tile's DMA only by accident of placement; stores count in vmcnt like loads, in issue order).
     auto emit_dx = [&](int64_t ps0, int ptap) {
         if (NW == 4 || ws < 4) {
             f32x4 dx = {0.f, 0.f, 0.f, 0.f};
