@@ -458,22 +458,10 @@ pair_kernel(const PairArgs a)
     for (int64_t ti = blockIdx.x; ti < a.tiles; ti += gridDim.x) {
         const int64_t s0 = ti * 32;
         const unsigned char *xi = smem + XI + parity * IMG;
-        // this wave's share of the tile has landed.  Vector-memory operations retire in issue order (MI355X_MICROARCH.md,
-        // "s_waitcnt vmcnt(N)"), and the FORWARD's stores of the previous tile (out_rows, the output image) were issued after
-        // this tile's DMA: a counted wait leaves them in flight instead of draining them at the top of a 1.2 us tile (round 6).
-        // The backward's stores (emit_dx) are older than its DMA and have had a whole tile: vmcnt(0) costs nothing there.
-        if (!BWD && ti != (int64_t)blockIdx.x) {
-            const int young = (a.out_rows != nullptr ? 2 : 0) + (a.out_img != nullptr ? (NP == 2 ? 2 : 1) : 0);   // per wave, at least
-            switch (young) {
-            case 4: __builtin_amdgcn_s_waitcnt(0x0F74); break;
-            case 3: __builtin_amdgcn_s_waitcnt(0x0F73); break;
-            case 2: __builtin_amdgcn_s_waitcnt(0x0F72); break;
-            case 1: __builtin_amdgcn_s_waitcnt(0x0F71); break;
-            default: wait_vm0(); break;
-            }
-        } else {
-            wait_vm0();
-        }
+        // this wave's share of the tile has landed.  (Vector-memory operations retire in issue order, and the forward's stores
+        // of the previous tile are younger than this tile's DMA: a counted s_waitcnt vmcnt(n) that leaves them in flight was
+        // measured in round 6 -- rsdf_pair_fwd 510 -> 524 ms per config[2] step, i.e. nothing: the plain wait stays.)
+        wait_vm0();
         lds_barrier();                         // (1) every share has landed; the other X image and the H1 / DZ images are free
         parity ^= 1;
 #ifndef RSDF_PAIR_NO_DEFER_DX
