@@ -330,7 +330,14 @@ specular_kernel(const float *__restrict__ src, int src_ch, const float *__restri
     }
     float c0 = acc.c0, c1 = acc.c1, c2 = acc.c2, wsum = acc.wsum;
     if (G > 1) {
-        c0 = wave_sum(c0); c1 = wave_sum(c1); c2 = wave_sum(c2); wsum = wave_sum(wsum);
+        if (G == 64) {
+            c0 = wave_sum(c0); c1 = wave_sum(c1); c2 = wave_sum(c2); wsum = wave_sum(wsum);
+        } else {                                   // G lanes of a wave share a texel: xor-shuffles inside the group
+#pragma unroll
+            for (int o = G / 2; o > 0; o >>= 1) {
+                c0 += __shfl_xor(c0, o, 64); c1 += __shfl_xor(c1, o, 64); c2 += __shfl_xor(c2, o, 64); wsum += __shfl_xor(wsum, o, 64);
+            }
+        }
         if (sub != 0) return;
     }
     if (BWD) {
@@ -360,8 +367,11 @@ void launch_specular(const float *src, int src_ch, const float *bounds, const fl
 {
     const size_t lds = R * sizeof(float);
     const int64_t n = (int64_t)6 * R * R;
+#ifndef SPEC_G
+#define SPEC_G 64      // lanes per output texel up to SPEC_G64_MAX_R (A/B: 32, 16)
+#endif
     if (R <= SPEC_G64_MAX_R)
-        specular_kernel<BWD, 64><<<rsdf_blocks(n, THREADS / 64), THREADS, lds, st>>>(src, src_ch, bounds, table, R, roughness, cos_cutoff, dst, wsum_out);
+        specular_kernel<BWD, SPEC_G><<<rsdf_blocks(n, THREADS / SPEC_G), THREADS, lds, st>>>(src, src_ch, bounds, table, R, roughness, cos_cutoff, dst, wsum_out);
     else
         specular_kernel<BWD, 1><<<rsdf_blocks(n, THREADS), THREADS, lds, st>>>(src, src_ch, bounds, table, R, roughness, cos_cutoff, dst, wsum_out);
 }
