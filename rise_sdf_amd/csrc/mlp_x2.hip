@@ -818,7 +818,27 @@ bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
                 }
             }
             // ---- recompute layer 1 (C = T1 z1) -> SH h1
+            // (round 6, -DRSDF_X2_SERIAL_RH for A/B: the matrix products of BOTH row halves are issued before the vector work of
+            // either -- written as "product, activation, store" per half the compiler keeps that order, and the second half's
+            // dependent MFMA chain then waits behind the first half's exp2 / log2 instead of running under it)
             f32x4 h1[2], h2[2];
+#ifndef RSDF_X2_SERIAL_RH
+            {
+                f32x4 acc[2];
+#pragma unroll
+                for (int rh = 0; rh < 2; ++rh) {
+                    acc[rh] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    acc[rh] = mma3q<NP>(w0f[0], x_col<NP>(xi, 0, rh, lc), acc[rh]);
+                    acc[rh] = mma3q<NP>(w0f[1], x_col<NP>(xi, 1, rh, lc), acc[rh]);
+                }
+#pragma unroll
+                for (int rh = 0; rh < 2; ++rh) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h1[rh][r] = softplus_scaled<1>(acc[rh][r]);
+                    store_q<HP, NP>(smem + L::H1I, rh, lc, h1[rh]);
+                }
+            }
+#else
 #pragma unroll
             for (int rh = 0; rh < 2; ++rh) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -828,35 +848,55 @@ bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
                 for (int r = 0; r < 4; ++r) h1[rh][r] = softplus_scaled<1>(acc[r]);
                 store_q<HP, NP>(smem + L::H1I, rh, lc, h1[rh]);
             }
+#endif
             lds_barrier();                                                       // (2) H1 image complete
             // ---- recompute layer 2 (C = T2 z2), then layer 3 backward: dz2 = (W2[0,:] d_sdf + feature part) sigma'(z2)
+            {
+                f32x4 acc2[2];
+#ifndef RSDF_X2_SERIAL_RH
 #pragma unroll
-            for (int rh = 0; rh < 2; ++rh) {
-                f32x4 acc = b1r;
+                for (int rh = 0; rh < 2; ++rh) {
+                    acc2[rh] = b1r;
 #pragma unroll
-                for (int kb = 0; kb < KB; ++kb) acc = mma3q<NP>(w1f[kb], rowq<HP, NP>(smem + L::H1I, kb, rh, lc), acc);
-                const float dsdf = row_ok[rh] ? dsdf_raw[rh] : 0.0f;
-                if (w == 0 && g == 0) gb2 += dsdf;
-                f32x4 dzs;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    h2[rh][r] = softplus_scaled<2>(acc[r]);
-                    gw2p[r] = fmaf(dsdf, h2[rh][r], gw2p[r]);                    // (x SH: unscaled at the flush)
-                    dz[rh][r] = row_ok[rh] ? fmaf(w2r[r], dsdf, dz[rh][r]) * softplus_grad_scaled(h2[rh][r]) : 0.0f;
-                    gb1p[r] += dz[rh][r];
-                    dzs[r] = dz[rh][r] * G2;
+                    for (int kb = 0; kb < KB; ++kb) acc2[rh] = mma3q<NP>(w1f[kb], rowq<HP, NP>(smem + L::H1I, kb, rh, lc), acc2[rh]);
                 }
-                store_q<HP, NP>(smem + L::DZI, rh, lc, dzs);
+#endif
+#pragma unroll
+                for (int rh = 0; rh < 2; ++rh) {
+#ifdef RSDF_X2_SERIAL_RH
+                    acc2[rh] = b1r;
+#pragma unroll
+                    for (int kb = 0; kb < KB; ++kb) acc2[rh] = mma3q<NP>(w1f[kb], rowq<HP, NP>(smem + L::H1I, kb, rh, lc), acc2[rh]);
+#endif
+                    const f32x4 acc = acc2[rh];
+                    const float dsdf = row_ok[rh] ? dsdf_raw[rh] : 0.0f;
+                    if (w == 0 && g == 0) gb2 += dsdf;
+                    f32x4 dzs;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        h2[rh][r] = softplus_scaled<2>(acc[r]);
+                        gw2p[r] = fmaf(dsdf, h2[rh][r], gw2p[r]);                    // (x SH: unscaled at the flush)
+                        dz[rh][r] = row_ok[rh] ? fmaf(w2r[r], dsdf, dz[rh][r]) * softplus_grad_scaled(h2[rh][r]) : 0.0f;
+                        gb1p[r] += dz[rh][r];
+                        dzs[r] = dz[rh][r] * G2;
+                    }
+                    store_q<HP, NP>(smem + L::DZI, rh, lc, dzs);
+                }
             }
             lds_barrier();                                                       // (3) dz2 image complete
             // ---- layer 2 backward: G1 dz1[own k1] = (W1^T dz2) sigma'(z1) ; dW1[own n][all k] += dz2^T h1 (K = the 32 rows)
+            {
+                f32x4 acc3[2];
 #pragma unroll
-            for (int rh = 0; rh < 2; ++rh) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                for (int rh = 0; rh < 2; ++rh) {
+                    acc3[rh] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int kb = 0; kb < KB; ++kb) acc = mma3q<NP>(w1t[kb], rowq<HP, NP>(smem + L::DZI, kb, rh, lc), acc);
+                    for (int kb = 0; kb < KB; ++kb) acc3[rh] = mma3q<NP>(w1t[kb], rowq<HP, NP>(smem + L::DZI, kb, rh, lc), acc3[rh]);
+                }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dz[rh][r] = acc[r] * k_dz1 * softplus_grad_scaled(h1[rh][r]);
+                for (int rh = 0; rh < 2; ++rh)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dz[rh][r] = acc3[rh][r] * k_dz1 * softplus_grad_scaled(h1[rh][r]);
             }
             {
                 const Frag2 a = trfq<HP, NP>(smem + L::DZI, w, lc);
