@@ -856,21 +856,9 @@ bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
 #ifndef RSDF_X2_SERIAL_RH
 #pragma unroll
                 for (int rh = 0; rh < 2; ++rh) {
-#ifdef RSDF_X2_SPLIT_K
-                    // two accumulators per row half: dependent chains of KB / 2 x 3 instead of KB x 3 matrix instructions
-                    f32x4 hi2 = {0.f, 0.f, 0.f, 0.f};
-                    acc2[rh] = b1r;
-#pragma unroll
-                    for (int kb = 0; kb < KB / 2; ++kb) {
-                        acc2[rh] = mma3q<NP>(w1f[kb], rowq<HP, NP>(smem + L::H1I, kb, rh, lc), acc2[rh]);
-                        hi2 = mma3q<NP>(w1f[kb + KB / 2], rowq<HP, NP>(smem + L::H1I, kb + KB / 2, rh, lc), hi2);
-                    }
-                    acc2[rh] += hi2;
-#else
                     acc2[rh] = b1r;
 #pragma unroll
                     for (int kb = 0; kb < KB; ++kb) acc2[rh] = mma3q<NP>(w1f[kb], rowq<HP, NP>(smem + L::H1I, kb, rh, lc), acc2[rh]);
-#endif
                 }
 #endif
 #pragma unroll
@@ -902,18 +890,8 @@ bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
 #pragma unroll
                 for (int rh = 0; rh < 2; ++rh) {
                     acc3[rh] = f32x4{0.f, 0.f, 0.f, 0.f};
-#ifdef RSDF_X2_SPLIT_K
-                    f32x4 hi3 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int kb = 0; kb < KB / 2; ++kb) {
-                        acc3[rh] = mma3q<NP>(w1t[kb], rowq<HP, NP>(smem + L::DZI, kb, rh, lc), acc3[rh]);
-                        hi3 = mma3q<NP>(w1t[kb + KB / 2], rowq<HP, NP>(smem + L::DZI, kb + KB / 2, rh, lc), hi3);
-                    }
-                    acc3[rh] += hi3;
-#else
 #pragma unroll
                     for (int kb = 0; kb < KB; ++kb) acc3[rh] = mma3q<NP>(w1t[kb], rowq<HP, NP>(smem + L::DZI, kb, rh, lc), acc3[rh]);
-#endif
                 }
 #pragma unroll
                 for (int rh = 0; rh < 2; ++rh)
