@@ -502,20 +502,28 @@ pair_kernel(const PairArgs a)
                 dma_dzo(smem + DZS + parity * 1024, a.dz_out, (ti + gridDim.x) * 32, a.n, a.n_out, ws, lane);
         }
         // ---- layer a: C = T za -> SA ha
+        // (round 6: the matrix products of BOTH row halves are issued before the vector work of either; written per half, the
+        // compiler keeps "product, activation, split, store" in that order and the second half's chain waits behind it)
         f32x4 ha[2];
+        {
+            f32x4 acca[2];
 #pragma unroll
-        for (int rh = 0; rh < 2; ++rh) {
-            f32x4 acc = bar;
+            for (int rh = 0; rh < 2; ++rh) {
+                acca[rh] = bar;
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb)
-                if (kb < kba) acc = mma3q<NP>(waf[kb], rowq<NP>(xi, kb, rh, lc), acc);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                ha[rh][r] = fmaxf(acc[r], 0.0f) * (SA / T);
-                // (range guard at the split point: fmaxf would swallow the NaN an overflowed operand makes downstream)
-                if (!BWD) bad |= !(acc[r] < 65504.0f * (T / SA));
+                for (int kb = 0; kb < KB; ++kb)
+                    if (kb < kba) acca[rh] = mma3q<NP>(waf[kb], rowq<NP>(xi, kb, rh, lc), acca[rh]);
             }
-            store_q<NP>(smem + H1I, rh, lc, ha[rh]);
+#pragma unroll
+            for (int rh = 0; rh < 2; ++rh) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    ha[rh][r] = fmaxf(acca[rh][r], 0.0f) * (SA / T);
+                    // (range guard at the split point: fmaxf would swallow the NaN an overflowed operand makes downstream)
+                    if (!BWD) bad |= !(acca[rh][r] < 65504.0f * (T / SA));
+                }
+                store_q<NP>(smem + H1I, rh, lc, ha[rh]);
+            }
         }
         if (BWD) {
 #pragma unroll
@@ -564,13 +572,18 @@ pair_kernel(const PairArgs a)
         }
         lds_barrier();                         // (2) H1 image complete
         // ---- layer b: C = T zb
+        f32x4 accb[2];
 #pragma unroll
         for (int rh = 0; rh < 2; ++rh) {
-            f32x4 acc = bbr;
+            accb[rh] = bbr;
             if (!MASKED) {                     // (backward on an already masked gradient: hb is not needed at all)
 #pragma unroll
-                for (int kb = 0; kb < KB; ++kb) acc = mma3q<NP>(wbf[kb], rowq<NP>(smem + H1I, kb, rh, lc), acc);
+                for (int kb = 0; kb < KB; ++kb) accb[rh] = mma3q<NP>(wbf[kb], rowq<NP>(smem + H1I, kb, rh, lc), accb[rh]);
             }
+        }
+#pragma unroll
+        for (int rh = 0; rh < 2; ++rh) {
+            const f32x4 acc = accb[rh];
             if (!BWD) {
                 f32x4 hb;
 #pragma unroll
@@ -635,14 +648,18 @@ pair_kernel(const PairArgs a)
                 wbt[kb].h = ld128(wt + u);
                 wbt[kb].l = NP == 2 ? ld128(wt + WT_PART + u) : u32x4{0u, 0u, 0u, 0u};
             }
+            f32x4 acct[2];
 #pragma unroll
             for (int rh = 0; rh < 2; ++rh) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                acct[rh] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int kb = 0; kb < KB; ++kb) acc = mma3q<NP>(wbt[kb], rowq<NP>(smem + DZI, kb, rh, lc), acc);
+                for (int kb = 0; kb < KB; ++kb) acct[rh] = mma3q<NP>(wbt[kb], rowq<NP>(smem + DZI, kb, rh, lc), acct[rh]);
+            }
+#pragma unroll
+            for (int rh = 0; rh < 2; ++rh) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    dz[rh][r] = ha[rh][r] > 0.0f ? acc[r] * k_dz1 : 0.0f;              // x G1
+                    dz[rh][r] = ha[rh][r] > 0.0f ? acct[rh][r] * k_dz1 : 0.0f;         // x G1
                     gbap[r] += dz[rh][r];
                 }
             }
