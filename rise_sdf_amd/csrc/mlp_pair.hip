@@ -504,18 +504,19 @@ pair_kernel(const PairArgs a)
         // ---- layer a: C = T za -> SA ha
         // (round 6: the matrix products of BOTH row halves are issued before the vector work of either; written per half, the
         // compiler keeps "product, activation, split, store" in that order and the second half's chain waits behind it)
+        // (measured per variant: forward 510 -> 483 ms per config[2] step, 16-bit backward 749 -> 726; the fp32 backward, which
+        // has no register to spare, 1131 -> 1176: it keeps the per-half order)
+        constexpr bool BOTH_FIRST = !BWD || NP == 1;
         f32x4 ha[2];
         {
             f32x4 acca[2];
-#pragma unroll
-            for (int rh = 0; rh < 2; ++rh) {
+            auto prod_a = [&](int rh) {
                 acca[rh] = bar;
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb)
                     if (kb < kba) acca[rh] = mma3q<NP>(waf[kb], rowq<NP>(xi, kb, rh, lc), acca[rh]);
-            }
-#pragma unroll
-            for (int rh = 0; rh < 2; ++rh) {
+            };
+            auto act_a = [&](int rh) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     ha[rh][r] = fmaxf(acca[rh][r], 0.0f) * (SA / T);
@@ -523,7 +524,9 @@ pair_kernel(const PairArgs a)
                     if (!BWD) bad |= !(acca[rh][r] < 65504.0f * (T / SA));
                 }
                 store_q<NP>(smem + H1I, rh, lc, ha[rh]);
-            }
+            };
+            if (BOTH_FIRST) { prod_a(0); prod_a(1); act_a(0); act_a(1); }
+            else { prod_a(0); act_a(0); prod_a(1); act_a(1); }
         }
         if (BWD) {
 #pragma unroll
@@ -649,20 +652,20 @@ pair_kernel(const PairArgs a)
                 wbt[kb].l = NP == 2 ? ld128(wt + WT_PART + u) : u32x4{0u, 0u, 0u, 0u};
             }
             f32x4 acct[2];
-#pragma unroll
-            for (int rh = 0; rh < 2; ++rh) {
+            auto prod_t = [&](int rh) {
                 acct[rh] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb) acct[rh] = mma3q<NP>(wbt[kb], rowq<NP>(smem + DZI, kb, rh, lc), acct[rh]);
-            }
-#pragma unroll
-            for (int rh = 0; rh < 2; ++rh) {
+            };
+            auto act_t = [&](int rh) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     dz[rh][r] = ha[rh][r] > 0.0f ? acct[rh][r] * k_dz1 : 0.0f;         // x G1
                     gbap[r] += dz[rh][r];
                 }
-            }
+            };
+            if (BOTH_FIRST) { prod_t(0); prod_t(1); act_t(0); act_t(1); }
+            else { prod_t(0); act_t(0); prod_t(1); act_t(1); }
         }
         {
             const Frag2 af = trfq<NP>(smem + DZI, w, lc);
