@@ -8,14 +8,14 @@ namespace {
 __device__ __forceinline__ float act_fwd(float z, int act)
 {
     switch (act) {
-    case RSDF_ACT_RELU: return fmaxf(z, 0.0f);
+    case RSDF_ACT_RELU: return max0(z);
     case RSDF_ACT_SOFTPLUS100: {
         // log1p(e^t) / 100 = max(z, 0) + ln2 / 100 * log2(1 + 2^(-|t| log2 e)) on the hardware exp2 / log2 units (v_exp_f32,
         // v_log_f32: ~1 ulp), the form the fused x2 kernels use (mlp_x2.hip softplus_scaled).  The libm-style log1pf(expf(t))
         // was ~60 vector instructions per element -- most of a 64-wide layer's forward; for t > 20 the second term is
         // exactly 0, torch's threshold.  Absolute difference to the libm form <= 1e-9.
         const float e = __builtin_amdgcn_exp2f(fabsf(z) * -144.26950408889634f);
-        return fmaxf(z, 0.0f) + __builtin_amdgcn_logf(1.0f + e) * 0.0069314718055994531f;
+        return max0(z) + __builtin_amdgcn_logf(1.0f + e) * 0.0069314718055994531f;
     }
     case RSDF_ACT_SIGMOID: return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.4426950408889634f));
     default: return z;

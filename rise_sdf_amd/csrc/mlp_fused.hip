@@ -89,7 +89,7 @@ __device__ __forceinline__ void fetch_tile(float (&pre)[18], const TileSrc &src,
 __device__ __forceinline__ float softplus100_fast(float z)
 {
     const float e = __builtin_amdgcn_exp2f(-144.26950408889634f * fabsf(z));
-    return fmaf(__builtin_amdgcn_logf(1.0f + e), 0.0069314718055994531f, fmaxf(z, 0.0f));
+    return fmaf(__builtin_amdgcn_logf(1.0f + e), 0.0069314718055994531f, max0(z));
 }
 // sigmoid(100 z) = 1 - 2^(-100 log2(e) h) from h = softplus(z)
 __device__ __forceinline__ float softplus100_grad_fast(float h)

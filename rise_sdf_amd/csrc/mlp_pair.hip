@@ -519,7 +519,7 @@ pair_kernel(const PairArgs a)
             auto act_a = [&](int rh) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    ha[rh][r] = fmaxf(acca[rh][r], 0.0f) * (SA / T);
+                    ha[rh][r] = max0(acca[rh][r]) * (SA / T);
                     // (range guard at the split point: fmaxf would swallow the NaN an overflowed operand makes downstream)
                     if (!BWD) bad |= !(acca[rh][r] < 65504.0f * (T / SA));
                 }
@@ -591,7 +591,7 @@ pair_kernel(const PairArgs a)
                 f32x4 hb;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    hb[r] = fmaxf(acc[r], 0.0f) * (SA / T);
+                    hb[r] = max0(acc[r]) * (SA / T);
                     bad |= !(acc[r] < 65504.0f * (T / SA));
                 }
                 if (a.out_img != nullptr || a.n_out > 0) store_q<NP>(smem + DZI, rh, lc, hb);

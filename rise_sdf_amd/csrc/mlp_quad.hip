@@ -38,7 +38,7 @@ __device__ __forceinline__ int qoff(int row, int col)
 __device__ __forceinline__ float softplus100q(float z)
 {
     const float e = __builtin_amdgcn_exp2f(-144.26950408889634f * fabsf(z));
-    return fmaf(__builtin_amdgcn_logf(1.0f + e), 0.0069314718055994531f, fmaxf(z, 0.0f));
+    return fmaf(__builtin_amdgcn_logf(1.0f + e), 0.0069314718055994531f, max0(z));
 }
 __device__ __forceinline__ float softplus100q_grad(float h) { return 1.0f - __builtin_amdgcn_exp2f(-144.26950408889634f * h); }
 

@@ -137,7 +137,7 @@ __device__ __forceinline__ float softplus_scaled(float C)
 {
     constexpr float T = LAYER == 1 ? T1 : T2;
     const float e = __builtin_amdgcn_exp2f(fabsf(C) * (-K100 / T));
-    return fmaf(fmaxf(C, 0.0f), SH / T, __builtin_amdgcn_logf(1.0f + e) * (LN2_100 * SH));
+    return fmaf(max0(C), SH / T, __builtin_amdgcn_logf(1.0f + e) * (LN2_100 * SH));
 }
 // sigmoid(100 z) = 1 - 2^(-100 log2(e) h) from hs = SH h, h = softplus(z)
 __device__ __forceinline__ float softplus_grad_scaled(float hs) { return 1.0f - __builtin_amdgcn_exp2f(hs * (-K100 / SH)); }
