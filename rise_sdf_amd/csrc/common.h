@@ -44,15 +44,17 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 // max(x, 0) in ONE instruction.  fmaxf() is llvm.maxnum, which under the IEEE mode bit quiets a possibly-signalling input
 // first: `v_max_f32 x, x, x` in front of every `v_max_f32 0, x` -- 64 of the ~520 vector instructions of an x2 forward tile.
-// Same value for every input that is not a signalling NaN (a quiet NaN still gives 0, as fmaxf does).
+// As a signed-integer maximum of the bit pattern: negative floats (and -0) are negative integers -> +0, positive ones are
+// unchanged.  Same value as fmaxf(x, 0) for every non-NaN input; a NaN with a clear sign bit stays a NaN (torch's relu
+// propagates it too; fmaxf returned 0).  (Not inline assembly: the compiler does not know the wait states between a matrix
+// instruction's result and an instruction it cannot see into, and the first version of this read accumulators too early.)
 __device__ __forceinline__ float max0(float x)
 {
 #ifdef RSDF_NO_MAX0      // A/B: the two-instruction form
     return fmaxf(x, 0.0f);
 #else
-    float r;
-    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
-    return r;
+    const int i = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, i > 0 ? i : 0);
 #endif
 }
 
