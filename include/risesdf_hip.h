@@ -254,6 +254,9 @@ int rsdf_stencil_rows_to_planes(const float *g, int ld, int col_off, int64_t n_s
  * (what rsdf_fd_points returns as `positions`): x +- eps e_k, clamp(-radius, radius), AABB contraction, in exactly
  * rsdf_fd_points' arithmetic (models/geometry.py:229-244), so cells and weights are bit-identical to the x7t form.
  * Both kernels walk the samples once per level; 16 x 84 B of tap positions per sample become 16 x 12 B.
+ * (The contraction's division by 2 r is taken as five multiply-adds that round like the division for 2^-100 < |p + r| <
+ * 2^100: RSDF_EINVAL for a radius outside (2^-101, 2^99); a centre at exactly -r gives +0 where the division gives -0, a
+ * non-finite one NaN where it gives inf -- same cells, same weights, same garbage.)
  * bwd: eps_unit (= eps / (2*radius)) only sizes the queues, as above; pass the value the scratch size was asked for. */
 int rsdf_hashgrid_fwd_fd7_pts(const float *points, float radius, float eps, const float *table,
                               const rsdf_grid_meta *meta /*host*/, int64_t n_samples, int n_active_levels,

@@ -46,6 +46,35 @@ struct CellFrac {
     float w[3];
 };
 
+// x / d for a divisor d that is the same for a whole launch (the AABB contraction's 2 r: models/geometry.py:229-244 through
+// neus.hip fd_points_kernel), CORRECTLY ROUNDED -- the same bits as the IEEE division those kernels perform -- in five
+// multiply-adds instead of the compiler's ~11-instruction division (v_div_scale x 2, v_rcp, five fma, v_div_fmas,
+// v_div_fixup; nine of them per (sample, level)).  With y = RN(1 / d) (computed on the host, one IEEE division per launch):
+// q0 = RN(x y) is within 2 ulp of x / d; r0 = x - q0 d is exact (fma); q1 = RN(q0 + r0 y) is a faithful rounding; r1 = x - q1 d
+// exact; q2 = RN(q1 + r1 y) is the correctly rounded quotient (Markstein's theorem: a faithful q and a y within half an ulp
+// of 1 / d).  Valid where nothing over- or underflows: 2^-100 < |x|, d < 2^100 or x == 0 (the entry points reject other
+// radii; x = p + r with p inside or near the box).  Known differences: x = -0 gives +0 (the same cell and weight); a
+// non-finite x gives NaN instead of +-inf (both index garbage).  tools/unit_div_check.hip sweeps all 2^32 x for 18 divisors
+// against the IEEE division: no other in-contract difference.  -DRSDF_IEEE_UNIT_DIV: the division itself (A/B: gather
+// 12.39 -> 12.30 ms, hash backward 21.9 -> 21.6 per launch; as a launch-uniform BRANCH between the two forms it was slower
+// than either -- nine branches per thread cut the gather's loads out of the schedule).
+struct UnitDiv {
+    float d, y;
+};
+constexpr float UNIT_DIV_MIN = 0x1p-100f, UNIT_DIV_MAX = 0x1p100f;
+__device__ __forceinline__ float unit_div(float x, const UnitDiv &u)
+{
+#ifdef RSDF_IEEE_UNIT_DIV
+    return x / u.d;
+#else
+    const float q0 = x * u.y;
+    const float r0 = fmaf(-q0, u.d, x);
+    const float q1 = fmaf(r0, u.y, q0);
+    const float r1 = fmaf(-q1, u.d, x);
+    return fmaf(r1, u.y, q1);
+#endif
+}
+
 // pos = fmaf(scale, x, 0.5); cell = floor(pos); w = pos - cell   (identical to the oracle)
 __device__ __forceinline__ CellFrac cell_frac(float px, float py, float pz, float scale)
 {

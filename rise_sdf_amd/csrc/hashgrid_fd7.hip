@@ -212,7 +212,8 @@ __device__ __forceinline__ void corner_indices(uint32_t x, uint32_t y, uint32_t 
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const uint32_t v = b + (uint32_t)(c & 1) + ((c >> 1) & 1 ? g.res : 0u) + ((c >> 2) & 1 ? g.res2 : 0u);
-            idx[c] = v >= g.size ? v - g.size : v;
+            idx[c] = min(v, v - g.size);      // (unsigned: v - size wraps above v when v < size; two instructions, no v_cmp ->
+                                              //  s_nop -> v_cndmask chain per corner)
         }
     } else {
         const uint32_t yp0 = y * 2654435761u, zp0 = z * 805459861u;
@@ -251,6 +252,7 @@ struct TapSrc {
     const float *x7t;
     const float *pw;
     float radius, eps;
+    UnitDiv two_r;      // 2 r and RN(1 / 2 r) (hashgrid_common.h unit_div)
 };
 
 __device__ __forceinline__ void cell_frac1(float u, float scale, uint32_t &c, float &w)
@@ -275,11 +277,11 @@ __device__ __forceinline__ CentreUnit centre_unit(const TapSrc &src, int64_t s, 
 {
     CentreUnit cu;
     const float *pp = src.pw + s * 3;
-    const float r = src.radius, two_r = r - (-r);
+    const float r = src.radius;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         cu.p[k] = pp[k];
-        const float u0 = (cu.p[k] - (-r)) / two_r;
+        const float u0 = unit_div(cu.p[k] - (-r), src.two_r);
         cell_frac1(u0, scale, cu.c0.c[k], cu.c0.w[k]);
         cu.cc.c[k] = cu.c0.c[k];
         cu.cc.w[k] = cu.c0.w[k];
@@ -294,10 +296,10 @@ __device__ __forceinline__ CellFrac derived_tap(const TapSrc &src, const CentreU
 {
     const int a = (t - 1) >> 1;
     const float off = ((t - 1) & 1) ? -src.eps : src.eps;
-    const float r = src.radius, two_r = r - (-r);
+    const float r = src.radius;
     CellFrac ct = cu.cc;
     const float q = fminf(fmaxf(cu.p[a] + off, -r), r);
-    cell_frac1((q - (-r)) / two_r, scale, ct.c[a], ct.w[a]);
+    cell_frac1(unit_div(q - (-r), src.two_r), scale, ct.c[a], ct.w[a]);
     return ct;
 }
 
@@ -306,12 +308,12 @@ __device__ __forceinline__ CellFrac derived_tap_rt(const TapSrc &src, const Cent
 {
     const int a = (t - 1) >> 1;
     const float off = ((t - 1) & 1) ? -src.eps : src.eps;
-    const float r = src.radius, two_r = r - (-r);
+    const float r = src.radius;
     const float pa = a == 0 ? cu.p[0] : (a == 1 ? cu.p[1] : cu.p[2]);
     const float q = fminf(fmaxf(pa + off, -r), r);
     uint32_t c;
     float w;
-    cell_frac1((q - (-r)) / two_r, scale, c, w);
+    cell_frac1(unit_div(q - (-r), src.two_r), scale, c, w);
     CellFrac ct = cu.cc;
 #pragma unroll
     for (int k = 0; k < 3; ++k)
@@ -422,20 +424,20 @@ __device__ __forceinline__ void x2_store_points(const X2Out &o, const TapSrc &sr
     const float one = pad ? 0.0f : 1.0f;
     float u[7][3];
     if (DERIVE) {
-        const float r = src.radius, two_r = r - (-r);
+        const float r = src.radius;
         float p[3], uc[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             p[k] = src.pw[sl * 3 + k];
-            u[0][k] = (p[k] - (-r)) / two_r;
-            uc[k] = (fminf(fmaxf(p[k], -r), r) - (-r)) / two_r;
+            u[0][k] = unit_div(p[k] - (-r), src.two_r);
+            uc[k] = unit_div(fminf(fmaxf(p[k], -r), r) - (-r), src.two_r);
         }
 #pragma unroll
         for (int t = 1; t < 7; ++t) {
             const int a = (t - 1) >> 1;
             const float off = ((t - 1) & 1) ? -src.eps : src.eps;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) u[t][k] = k == a ? (fminf(fmaxf(p[k] + off, -r), r) - (-r)) / two_r : uc[k];
+            for (int k = 0; k < 3; ++k) u[t][k] = k == a ? unit_div(fminf(fmaxf(p[k] + off, -r), r) - (-r), src.two_r) : uc[k];
         }
     } else {
 #pragma unroll
@@ -1266,6 +1268,14 @@ extern "C" int rsdf_debug_read_pstamps(unsigned long long *out16, int reset)
 
 namespace {
 
+// the stencil's source and the contraction's divisor (2 r = r - (-r), as the kernels form it) with its reciprocal for unit_div
+TapSrc tap_src(const float *x7t, const float *points, float radius, float eps)
+{
+    const float two_r = radius - (-radius);
+    return TapSrc{x7t, points, radius, eps, UnitDiv{two_r, two_r > 0.f ? 1.0f / two_r : 0.0f}};
+}
+bool radius_ok(float radius) { return radius - (-radius) > UNIT_DIV_MIN && radius - (-radius) < UNIT_DIV_MAX; }
+
 int launch_fwd(const TapSrc &src, const float *table, const rsdf_grid_meta *meta, int64_t n_samples,
                int n_active_levels, float *planes, void *stream, const X2Out *x3 = nullptr)
 {
@@ -1452,7 +1462,7 @@ int rsdf_hashgrid_fwd_fd7(const float *x7t, const float *table, const rsdf_grid_
                           int64_t n_samples, int n_active_levels, float *planes, void *stream)
 {
     RSDF_CHECK_ARG(x7t != nullptr || n_samples <= 0, "hashgrid_fwd_fd7: x7t is NULL");
-    return launch_fwd(TapSrc{x7t, nullptr, 0.f, 0.f}, table, meta, n_samples, n_active_levels, planes, stream);
+    return launch_fwd(tap_src(x7t, nullptr, 0.f, 0.f), table, meta, n_samples, n_active_levels, planes, stream);
 }
 
 int rsdf_hashgrid_fwd_fd7_pts(const float *points, float radius, float eps, const float *table,
@@ -1460,8 +1470,8 @@ int rsdf_hashgrid_fwd_fd7_pts(const float *points, float radius, float eps, cons
                               void *stream)
 {
     RSDF_CHECK_ARG(points != nullptr || n_samples <= 0, "hashgrid_fwd_fd7_pts: points is NULL");
-    RSDF_CHECK_ARG(radius > 0.f, "hashgrid_fwd_fd7_pts: radius must be > 0");
-    return launch_fwd(TapSrc{nullptr, points, radius, eps}, table, meta, n_samples, n_active_levels, planes, stream);
+    RSDF_CHECK_ARG(radius_ok(radius), "hashgrid_fwd_fd7_pts: radius must be in (2^-101, 2^99)");
+    return launch_fwd(tap_src(nullptr, points, radius, eps), table, meta, n_samples, n_active_levels, planes, stream);
 }
 
 int rsdf_stencil_points_tap_major(const float *x7, int64_t n_samples, float *x7t, void *stream)
@@ -1515,12 +1525,12 @@ int rsdf_hashgrid_fwd_fd7_x2(const float *x7t, const float *points, float radius
                              float xyz_offset, int parts, void *x3, void *stream)
 {
     RSDF_CHECK_ARG((x7t != nullptr) != (points != nullptr) || n_samples <= 0, "hashgrid_fwd_fd7_x2: give x7t or points");
-    RSDF_CHECK_ARG(points == nullptr || radius > 0.f, "hashgrid_fwd_fd7_x2: radius must be > 0");
+    RSDF_CHECK_ARG(points == nullptr || radius_ok(radius), "hashgrid_fwd_fd7_x2: radius must be in (2^-101, 2^99)");
     RSDF_CHECK_ARG(x3 != nullptr || n_samples <= 0, "hashgrid_fwd_fd7_x2: x3 is NULL");
     RSDF_CHECK_ARG(parts == 1 || parts == 2, "hashgrid_fwd_fd7_x2: parts must be 1 or 2");
     const X2Out o{reinterpret_cast<unsigned char *>(x3), rsdf_x2_rows(n_samples), xyz_scale, xyz_offset, parts, parts * X2_PART_B,
                   7 * parts * X2_PART_B};
-    return launch_fwd(x7t ? TapSrc{x7t, nullptr, 0.f, 0.f} : TapSrc{nullptr, points, radius, eps}, table, meta, n_samples,
+    return launch_fwd(x7t ? tap_src(x7t, nullptr, 0.f, 0.f) : tap_src(nullptr, points, radius, eps), table, meta, n_samples,
                       n_active_levels, nullptr, stream, &o);
 }
 
@@ -1542,7 +1552,7 @@ int rsdf_hashgrid_bwd_fd7(const float *x7t, const float *dplanes, const rsdf_gri
                           void *scratch, int64_t scratch_bytes, void *stream)
 {
     RSDF_CHECK_ARG(x7t != nullptr || n_samples <= 0, "hashgrid_bwd_fd7: x7t is NULL");
-    return launch_bwd(TapSrc{x7t, nullptr, 0.f, 0.f}, dplanes, meta, n_samples, n_active_levels, eps_unit, dtable,
+    return launch_bwd(tap_src(x7t, nullptr, 0.f, 0.f), dplanes, meta, n_samples, n_active_levels, eps_unit, dtable,
                       scratch, scratch_bytes, stream);
 }
 
@@ -1551,8 +1561,8 @@ int rsdf_hashgrid_bwd_fd7_pts(const float *points, float radius, float eps, cons
                               float *dtable, void *scratch, int64_t scratch_bytes, void *stream)
 {
     RSDF_CHECK_ARG(points != nullptr || n_samples <= 0, "hashgrid_bwd_fd7_pts: points is NULL");
-    RSDF_CHECK_ARG(radius > 0.f, "hashgrid_bwd_fd7_pts: radius must be > 0");
-    return launch_bwd(TapSrc{nullptr, points, radius, eps}, dplanes, meta, n_samples, n_active_levels, eps_unit, dtable,
+    RSDF_CHECK_ARG(radius_ok(radius), "hashgrid_bwd_fd7_pts: radius must be in (2^-101, 2^99)");
+    return launch_bwd(tap_src(nullptr, points, radius, eps), dplanes, meta, n_samples, n_active_levels, eps_unit, dtable,
                       scratch, scratch_bytes, stream);
 }
 
