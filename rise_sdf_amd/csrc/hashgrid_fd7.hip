@@ -467,6 +467,22 @@ __device__ __forceinline__ void x2_store_points(const X2Out &o, const TapSrc &sr
 #ifndef RSDF_BWD_GROUP
 #define RSDF_BWD_GROUP 64      // producer: 64 x 1024 samples (0.8 MB of centres) per group: the 15 re-reads of a group's centres hit
 #endif                         // in the XCD's L2 (256: they come back from the MALL, +150 B per sample of fetch traffic; same time)
+using pk_f32x2 = __attribute__((ext_vector_type(2))) float;
+// acc += w v on both features: the same two fmas, written as a packed one (this file is built with -fno-slp-vectorize:
+// packed fp32 arithmetic that the compiler forms by itself costs more than it saves on gfx950 -- producer 21.8 -> 21.4 ms
+// without it -- but the gather's accumulation is faster packed: 12.26 vs 12.40 ms)
+__device__ __forceinline__ void fma2(float2 &acc, float w, const float2 &v)
+{
+#ifdef RSDF_FWD_SCALAR_FMA
+    acc.x = fmaf(w, v.x, acc.x);
+    acc.y = fmaf(w, v.y, acc.y);
+#else
+    const pk_f32x2 r = __builtin_elementwise_fma(pk_f32x2{w, w}, pk_f32x2{v.x, v.y}, pk_f32x2{acc.x, acc.y});
+    acc.x = r[0];
+    acc.y = r[1];
+#endif
+}
+
 template <bool DERIVE, bool X3>
 __device__ __forceinline__ void fd7_fwd_sample(const TapSrc &src, const float2 *__restrict__ tl,
                                                const LevelGeom &g, int64_t S, int64_t s, int l,
@@ -509,24 +525,21 @@ __device__ __forceinline__ void fd7_fwd_sample(const TapSrc &src, const float2 *
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const float w = corner_weight(cf[t], c);
-                acc.x = fmaf(w, v[c].x, acc.x);
-                acc.y = fmaf(w, v[c].y, acc.y);
+                fma2(acc, w, v[c]);
             }
         } else if (da[t] == 1) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const float w = corner_weight(cf[t], c);
                 const float2 val = (((c >> a) & 1) == 0) ? v[c | (1 << a)] : ex[a][other_bits(c, a)];
-                acc.x = fmaf(w, val.x, acc.x);
-                acc.y = fmaf(w, val.y, acc.y);
+                fma2(acc, w, val);
             }
         } else if (da[t] == -1) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const float w = corner_weight(cf[t], c);
                 const float2 val = (((c >> a) & 1) == 1) ? v[c & ~(1 << a)] : ex[a][4 + other_bits(c, a)];
-                acc.x = fmaf(w, val.x, acc.x);
-                acc.y = fmaf(w, val.y, acc.y);
+                fma2(acc, w, val);
             }
         } else {  // tap more than one cell away: gather its own 8 corners
 #pragma unroll
@@ -534,8 +547,7 @@ __device__ __forceinline__ void fd7_fwd_sample(const TapSrc &src, const float2 *
                 const float w = corner_weight(cf[t], c);
                 const float2 val = tl[entry_index(cf[t].c[0] + (c & 1), cf[t].c[1] + ((c >> 1) & 1),
                                                   cf[t].c[2] + ((c >> 2) & 1), g)];
-                acc.x = fmaf(w, val.x, acc.x);
-                acc.y = fmaf(w, val.y, acc.y);
+                fma2(acc, w, val);
             }
         }
         if (X3) {
@@ -619,6 +631,19 @@ struct StamperP {
 };
 #define RSDF_PSTAMP(st, i)
 #endif
+
+// a += w g, one fma per feature
+__device__ __forceinline__ void axpy2(float2 &a, float w, pk_f32x2 g)
+{
+#ifndef RSDF_AXPY_PACKED      // (as a packed fma the producer needs 54 spilled registers instead of 13: 23.9 vs 21.4 ms)
+    a.x = fmaf(w, g[0], a.x);
+    a.y = fmaf(w, g[1], a.y);
+#else
+    const pk_f32x2 r = __builtin_elementwise_fma(pk_f32x2{w, w}, g, pk_f32x2{a.x, a.y});
+    a.x = r[0];
+    a.y = r[1];
+#endif
+}
 
 // d_planes are read once per launch by phase 1 (the displaced taps of phase 2 re-read a few of them from L2)
 __device__ __forceinline__ float2 ld_dplane(const float2 *p)
@@ -801,6 +826,59 @@ fd7_produce_kernel(const TapSrc src, const float2 *__restrict__ dplanes,
                 acc[c].y = w * gr.y;
             }
         }
+#ifndef RSDF_PRODUCE_PHASE1_R5
+        // (round 6) Axis by axis: the two taps of an axis share the weights of the OTHER two axes (every tap carries the
+        // clamped centre's fractions there), so a tap's eight weights are four shared products times its own pair -- 8
+        // multiplies per tap instead of 15 -- and the accumulation is an fma per feature instead of a multiply and an add
+        // (this file is built with -ffp-contract=off: only explicit fmas fuse).  Against the
+        // round-5 form (-DRSDF_PRODUCE_PHASE1_R5) a weight is (w_o1 w_o2) w_a instead of (w_x w_y) w_z and the sum is fused:
+        // ulp-level differences in a gradient that the records quantise at 2^-20 anyway.  The kernel is vector-issue bound
+        // (0.80 busy at 7.5 waves per SIMD, profiles/r06d_final/pmc/pipes.json).
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int o1 = (a == 0) ? 1 : 0, o2 = (a == 2) ? 1 : 2;
+            float oth[4];
+            {
+                const CellFrac &cp = cf[2 * a + 1];
+                const float u1[2] = {1.0f - cp.w[o1], cp.w[o1]}, u2[2] = {1.0f - cp.w[o2], cp.w[o2]};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) oth[k] = u1[k & 1] * u2[k >> 1];
+            }
+#pragma unroll
+            for (int sd = 0; sd < 2; ++sd) {
+                const int t = 2 * a + 1 + sd;
+                const CellFrac ct = cf[t];
+                const float2 gr = ld_dplane(pg + (int64_t)t * S);
+                const pk_f32x2 g2 = {gr.x, gr.y};
+                const int32_t da = (int32_t)(ct.c[a] - c0.c[a]);
+                const float wa[2] = {1.0f - ct.w[a], ct.w[a]};
+                if (da == 0) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) axpy2(acc[(b << a) | ((k & 1) << o1) | ((k >> 1) << o2)], oth[k] * wa[b], g2);
+                } else if (da == 1) {
+                    // the tap's near face (its corners with bit a == 0) coincides with the centre cell's far face (bit a == 1)
+                    items |= 3u << (2 * (t - 1));
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) axpy2(acc[(1 << a) | ((k & 1) << o1) | ((k >> 1) << o2)], oth[k] * wa[0], g2);
+                } else if (da == -1) {
+                    items |= 1u << (2 * (t - 1));
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) axpy2(acc[((k & 1) << o1) | ((k >> 1) << o2)], oth[k] * wa[1], g2);
+                } else {  // tap more than one cell away (eps larger than a cell): rare slow path
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const float w = corner_weight(ct, c);
+                        const uint32_t idx = entry_index(ct.c[0] + (c & 1), ct.c[1] + ((c >> 1) & 1),
+                                                         ct.c[2] + ((c >> 2) & 1), g);
+                        atomicAdd(dlevel + 2 * (size_t)idx, w * gr.x);
+                        atomicAdd(dlevel + 2 * (size_t)idx + 1, w * gr.y);
+                    }
+                }
+            }
+        }
+#else
 #pragma unroll
         for (int t = 1; t < 7; ++t) {
             const int a = (t - 1) >> 1;
@@ -838,6 +916,7 @@ fd7_produce_kernel(const TapSrc src, const float2 *__restrict__ dplanes,
                 }
             }
         }
+#endif
     }
     RSDF_PSTAMP(stp, 0);   // loads + phase-1 weights
     {   // append this thread's displaced taps to the workgroup's work list
