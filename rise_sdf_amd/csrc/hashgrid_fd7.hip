@@ -722,6 +722,10 @@ __device__ __forceinline__ void emit_round(uint32_t (&ridx)[ROUND_RECS],
     RSDF_PSTAMP(stp, 7);   // barrier B
     const int total = s_off[MAX_BINS];   // even
     if (total == 0) return;  // uniform (no reservation was made: every count was zero)
+    // (measured and not kept, round 6: the bin's absolute queue offset b * cap + gbase published here as a 64-bit LDS word so
+    // that the copy-out forms no 64-bit product per record pair, a 24-bit multiply for the staging stride, a 32 x 32-bit
+    // product for the displaced taps' plane index: 20.9 -> 21.3 ms, +0.0, +0.2 -- the kernel is held to 64 registers and
+    // every one of these moved its spills)
     if (tid < n_bins) s_gbase[tid] = gbase;
     for (int lo = 0; lo < total; lo += STAGE_CAP) {   // uniform; bins stay contiguous: a pass boundary splits one run
         const int n = min(total - lo, STAGE_CAP);     // even
@@ -985,7 +989,8 @@ fd7_produce_kernel(const TapSrc src, const float2 *__restrict__ dplanes,
             if (i < n_items) {
                 const unsigned it = s_items[i];
                 const int64_t s2 = s_block + (it & 1023u);
-                const int t = (int)(it >> 10 & 7u) + 1, a = (t - 1) >> 1, far = (int)(it >> 13 & 1u);
+                const int t = (int)(it >> 10 & 7u) + 1, a = (t - 1) >> 1;
+                const bool far = (it >> 13 & 1u) != 0;
                 CellFrac ct;
                 if (DERIVE) {
                     ct = derived_tap_rt(src, centre_unit(src, s2, g.scale), t, g.scale);
@@ -994,16 +999,52 @@ fd7_produce_kernel(const TapSrc src, const float2 *__restrict__ dplanes,
                     ct = cell_frac(p[0], p[1], p[2], g.scale);
                 }
                 const float2 gr = dplanes[((int64_t)l * 7 + t) * S + s2];
+#ifdef RSDF_PRODUCE_PHASE2_R5
                 const int o1 = (a == 0) ? 1 : 0, o2 = (a == 2) ? 1 : 2;
                 uint32_t cidx[8];
                 corner_indices(ct.c[0], ct.c[1], ct.c[2], g, cidx);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const int c = (far << a) | ((k & 1) << o1) | ((k >> 1) << o2);   // far face: bit a == (da > 0)
+                    const int c = ((int)far << a) | ((k & 1) << o1) | ((k >> 1) << o2);   // far face: bit a == (da > 0)
                     const float w = corner_weight(ct, c);
                     ridx[4 * j + k] = cidx[c];
                     acc[4 * j + k] = make_float2(w * gr.x, w * gr.y);
                 }
+#else
+                // The four corners of the tap's FAR face only (bit a == far; k enumerates the other two axes o1 < o2), the
+                // axis picked by selects on the per-axis terms instead of on eight finished indices / weights: a corner
+                // index is a xor (hashed) or a sum (dense) of one term per axis, a weight a product of one factor per axis.
+                // Same indices as corner_indices(); weights as phase 1 forms them, (u_o1 u_o2) u_a.
+                uint32_t tx[2], ty[2], tz[2];
+                if (g.dense) {
+                    const uint32_t b = ct.c[0] + ct.c[1] * g.res + ct.c[2] * g.res2;
+                    tx[0] = b, tx[1] = b + 1u, ty[0] = 0u, ty[1] = g.res, tz[0] = 0u, tz[1] = g.res2;
+                } else {
+                    const uint32_t yp = ct.c[1] * 2654435761u, zp = ct.c[2] * 805459861u;
+                    tx[0] = ct.c[0], tx[1] = ct.c[0] + 1u, ty[0] = yp, ty[1] = yp + 2654435761u, tz[0] = zp, tz[1] = zp + 805459861u;
+                }
+                const uint32_t fx = far ? tx[1] : tx[0], fy = far ? ty[1] : ty[0], fz = far ? tz[1] : tz[0];
+                const uint32_t A = a == 0 ? fx : (a == 1 ? fy : fz);
+                const uint32_t B[2] = {a == 0 ? ty[0] : tx[0], a == 0 ? ty[1] : tx[1]};      // axis o1
+                const uint32_t C[2] = {a == 2 ? ty[0] : tz[0], a == 2 ? ty[1] : tz[1]};      // axis o2
+                const float w_a = a == 0 ? ct.w[0] : (a == 1 ? ct.w[1] : ct.w[2]);
+                const float w_1 = a == 0 ? ct.w[1] : ct.w[0], w_2 = a == 2 ? ct.w[1] : ct.w[2];
+                const float ua = far ? w_a : 1.0f - w_a;
+                const float u1[2] = {1.0f - w_1, w_1}, u2[2] = {1.0f - w_2, w_2};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    uint32_t idx;
+                    if (g.dense) {
+                        const uint32_t v = A + B[k & 1] + C[k >> 1];
+                        idx = min(v, v - g.size);
+                    } else {
+                        idx = (A ^ B[k & 1] ^ C[k >> 1]) & g.mask;
+                    }
+                    const float w = (u1[k & 1] * u2[k >> 1]) * ua;
+                    ridx[4 * j + k] = idx;
+                    acc[4 * j + k] = make_float2(w * gr.x, w * gr.y);
+                }
+#endif
                 mask |= 0xfu << (4 * j);
             }
         }
