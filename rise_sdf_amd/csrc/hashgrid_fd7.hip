@@ -746,7 +746,7 @@ __device__ __forceinline__ void emit_round(uint32_t (&ridx)[ROUND_RECS],
             const int b = bin_of(r0.idx, n_bins, interleaved);
             const bool two = r1.idx != PAD_IDX;
             const int64_t gpos = (int64_t)s_gbase[b] + ((lo + 2 * i - s_off[b]) >> 1);
-            if (gpos < cap) {
+            if (gpos < cap) {      // (as a 32-bit compare: no change, 20.68 vs 20.69 ms)
                 RecOps<REC>::store(&queue[(int64_t)b * cap + gpos], entry_of(r0.idx, interleaved), r0.v0, r0.v1, two,
                                    two ? entry_of(r1.idx, interleaved) : 0u, r1.v0, r1.v1);
             } else {  // queue full (capacity carries slack; never drop a contribution)

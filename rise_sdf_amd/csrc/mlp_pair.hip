@@ -750,20 +750,49 @@ pack_kernel(const float *__restrict__ x, int ld, int K1, const float *__restrict
 {
     // columns [0, K1) from x, [K1, K) from x2 (the reference's torch.cat([feature, encoding], -1), models/texture.py:299-313,
     // never materialised); chunks past the last 32-column group that holds a column are not written: nothing reads them
+    // (round 6) Sources that allow it (K1 a multiple of 8, 16-byte-aligned rows) are read as two float4 per chunk.  Measured and
+    // not kept (-DRSDF_PACK_ROWS_OVER_LANES): a tile's 32 rows over the lanes and the chunk over the half-waves, so that a
+    // half-wave's stores fill one contiguous 512-byte chunk of the image -- 28.0 vs 24.0 ms per 400 x 400 config[2] step: with
+    // the chunk over the lanes sixteen lanes READ one contiguous row, and that matters more than the scattered 16-byte stores.
     const int64_t total = tiles * 32 * 16;                                         // (row, chunk) pairs
     const int n_chunks = ((K + 31) >> 5) * 4;
+#ifdef RSDF_PACK_SCALAR
+    const bool vec1 = false, vec2 = false;
+#else
+    const bool vec1 = ((K1 | ld) & 3) == 0 && (K1 & 7) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    const bool vec2 = x2 != nullptr && ((ld2 & 3) == 0) && (K1 & 7) == 0 && (reinterpret_cast<uintptr_t>(x2) & 15) == 0;
+#endif
     bool bad = false;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+#ifndef RSDF_PACK_ROWS_OVER_LANES
         const int ch = (int)(e & 15);
         const int64_t row = e >> 4;
+#else
+        const int ch = (int)(e >> 5 & 15);
+        const int64_t row = (e >> 9) * 32 + (e & 31);
+#endif
         if (ch >= n_chunks) continue;
         float v[8];
+        const int c0 = 8 * ch;
+        if (row < n && vec1 && c0 + 8 <= K1) {                       // whole chunk from x (uniform per half-wave but for row < n)
+            const float4 a = *reinterpret_cast<const float4 *>(x + row * ld + c0), b = *reinterpret_cast<const float4 *>(x + row * ld + c0 + 4);
+            v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
+        } else if (row < n && vec2 && c0 >= K1 && c0 + 8 <= K) {     // whole chunk from x2
+            const float *q = x2 + row * ld2 + (c0 - K1);
+            const float4 a = *reinterpret_cast<const float4 *>(q), b = *reinterpret_cast<const float4 *>(q + 4);
+            v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int col = c0 + j;
+                float t = 0.0f;
+                if (row < n && col < K) t = col < K1 ? x[row * ld + col] : x2[row * ld2 + (col - K1)];
+                v[j] = t;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int col = 8 * ch + j;
-            float t = 0.0f;
-            if (row < n && col < K) t = col < K1 ? x[row * ld + col] : x2[row * ld2 + (col - K1)];
-            v[j] = t * SA;
+            v[j] *= SA;
             bad |= !(fabsf(v[j]) < 65504.0f);
         }
         const Frag2 f = split2_frag(v);

@@ -17,5 +17,5 @@ for v in "$@"; do
   (cd ../.. && python tools/bench_c2.py --width 400 --height 400 --chunk 16384 --steps 2 $ARGS 2>/dev/null | tail -1 | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read())
-print(dict(list(d['top'].items())[:6]), '%.4g samples/s' % d['samples_per_s'], '%.1f ms' % d['ms_per_step'])"; echo " <= [$SRC $v] $ARGS")
+print(dict(list(d['top'].items())[:9]), '%.4g samples/s' % d['samples_per_s'], '%.1f ms' % d['ms_per_step'])"; echo " <= [$SRC $v] $ARGS")
 done
