@@ -14,26 +14,44 @@ namespace {
 
 constexpr int THREADS = 256;
 
+// A workgroup's rows [row0, row0 + THREADS) x m columns, one row per thread in LDS ([THREADS][m | 1]: odd stride), written to
+// out[row][col_off .. col_off + m) by consecutive threads along each row (round 6: one thread storing its own row put every
+// store instruction on 64 different rows at the row stride -- the frequency encoder ran at 1 TB/s of its 168 B per row).
+__device__ __forceinline__ void store_rows_staged(const float *s_rows, int m, int64_t row0, int64_t n, float *__restrict__ out, int ld,
+                                                  int col_off)
+{
+    __syncthreads();
+    const int rows = (int)(n - row0 < THREADS ? n - row0 : THREADS), lds = m | 1;
+    for (int e = threadIdx.x; e < rows * m; e += THREADS) {
+        const int r = e / m, c = e - r * m;
+        out[(row0 + r) * ld + col_off + c] = s_rows[r * lds + c];
+    }
+}
+
 __global__ void __launch_bounds__(THREADS)
 freq_encode_kernel(const float *__restrict__ x, int64_t n, int n_freq, float x_scale, float x_offset,
                    const float *__restrict__ mask, float *__restrict__ out, int ld, int col_off)
 {
-    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
-    if (i >= n) return;
-    float v[3];
+    extern __shared__ float s_rows[];      // [THREADS][6 n_freq | 1]
+    const int64_t row0 = (int64_t)blockIdx.x * THREADS, i = row0 + threadIdx.x;
+    const int m6 = 6 * n_freq;
+    if (i < n) {
+        float v[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) v[c] = x[3 * i + c] * x_scale + x_offset;
-    float *o = out + i * ld + col_off;
-    float f = 1.0f;
-    for (int k = 0; k < n_freq; ++k, f *= 2.0f) {
-        const float m = mask ? mask[k] : 1.0f;
+        for (int c = 0; c < 3; ++c) v[c] = x[3 * i + c] * x_scale + x_offset;
+        float *o = s_rows + threadIdx.x * (m6 | 1);
+        float f = 1.0f;
+        for (int k = 0; k < n_freq; ++k, f *= 2.0f) {
+            const float m = mask ? mask[k] : 1.0f;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float a = f * v[c];
-            o[k * 6 + c] = sinf(a) * m;
-            o[k * 6 + 3 + c] = cosf(a) * m;
+            for (int c = 0; c < 3; ++c) {
+                const float a = f * v[c];
+                o[k * 6 + c] = sinf(a) * m;
+                o[k * 6 + 3 + c] = cosf(a) * m;
+            }
         }
     }
+    store_rows_staged(s_rows, m6, row0, n, out, ld, col_off);
 }
 
 // real SH basis, up to 5 bands; u = 2 d01 - 1
@@ -123,15 +141,18 @@ __global__ void __launch_bounds__(THREADS)
 sh_fwd_kernel(const float *__restrict__ d01, int64_t n, int degree, float *__restrict__ out, int ld,
               int col_off)
 {
-    const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
-    if (i >= n) return;
-    float o[25];
-    sh_eval(d01[3 * i] * 2.0f - 1.0f, d01[3 * i + 1] * 2.0f - 1.0f, d01[3 * i + 2] * 2.0f - 1.0f, degree, o);
-    float *dst = out + i * ld + col_off;
+    extern __shared__ float s_rows[];      // [THREADS][degree^2 | 1]
+    const int64_t row0 = (int64_t)blockIdx.x * THREADS, i = row0 + threadIdx.x;
     const int m = degree * degree;
+    if (i < n) {
+        float o[25];
+        sh_eval(d01[3 * i] * 2.0f - 1.0f, d01[3 * i + 1] * 2.0f - 1.0f, d01[3 * i + 2] * 2.0f - 1.0f, degree, o);
+        float *dst = s_rows + threadIdx.x * (m | 1);
 #pragma unroll
-    for (int k = 0; k < 25; ++k)
-        if (k < m) dst[k] = o[k];
+        for (int k = 0; k < 25; ++k)
+            if (k < m) dst[k] = o[k];
+    }
+    store_rows_staged(s_rows, m, row0, n, out, ld, col_off);
 }
 
 __global__ void __launch_bounds__(THREADS)
@@ -397,7 +418,12 @@ int rsdf_freq_encode(const float *x, int64_t n, int n_frequencies, float x_scale
 {
     RSDF_CHECK_ARG(n_frequencies >= 1 && ld_out >= col_off + 6 * n_frequencies, "freq_encode: bad sizes");
     if (n <= 0) return 0;
-    LAUNCH1D(freq_encode_kernel, n, x, n, n_frequencies, x_scale, x_offset, mask, out, ld_out, col_off);
+    RSDF_CHECK_ARG(n_frequencies <= 24, "freq_encode: at most 24 frequencies (the row staging's LDS)");
+    const size_t lds = (size_t)THREADS * ((6 * n_frequencies) | 1) * sizeof(float);
+    if (lds > 65536)
+        if (int rc = rsdf_func_lds(reinterpret_cast<const void *>(freq_encode_kernel), lds)) return rc;
+    freq_encode_kernel<<<rsdf_blocks(n, THREADS), THREADS, lds, (hipStream_t)stream>>>(x, n, n_frequencies, x_scale, x_offset, mask, out,
+                                                                                       ld_out, col_off);
     RSDF_RETURN_LAUNCH();
 }
 
@@ -406,7 +432,8 @@ int rsdf_sh_encode_fwd(const float *d01, int64_t n, int degree, float *out, int 
 {
     RSDF_CHECK_ARG(degree >= 1 && degree <= 5 && ld_out >= col_off + degree * degree, "sh_encode_fwd: bad sizes");
     if (n <= 0) return 0;
-    LAUNCH1D(sh_fwd_kernel, n, d01, n, degree, out, ld_out, col_off);
+    sh_fwd_kernel<<<rsdf_blocks(n, THREADS), THREADS, (size_t)THREADS * ((degree * degree) | 1) * sizeof(float), (hipStream_t)stream>>>(
+        d01, n, degree, out, ld_out, col_off);
     RSDF_RETURN_LAUNCH();
 }
 
