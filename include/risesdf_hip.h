@@ -46,7 +46,7 @@ const char *rsdf_last_error(void);
 #define RSDF_STATUS_WORDS 8
 #define RSDF_STATUS_X2_FWD_NONFINITE 0 /* waves of rsdf_sdfmlp_fd7_fwd_x2 that produced an inf / nan output: an operand
                                           left the x2 format's fp16 class range (|input| < 255, |weight| < 1023,
-                                          |hidden activation| < 1023), where the reference's fp32 MLP stays finite */
+                                          |hidden activation| < 454), where the reference's fp32 MLP stays finite */
 #define RSDF_STATUS_X2_BWD_REROUTED 1  /* rsdf_sdfmlp_fd7_bwd_x2 launches that ran on the range-free kernels */
 #define RSDF_STATUS_X2_BWD_GUARDED 2   /* rsdf_sdfmlp_fd7_bwd_x2 launches that the range guard examined */
 #define RSDF_STATUS_PAIR_PACK_NONFINITE 3 /* of word 0's count: waves of rsdf_pair_pack / _pack2 (a network INPUT out of range) */
@@ -377,7 +377,8 @@ int rsdf_sdfmlp_fd7_bwd(const float *x7t, const float *planes, int n_levels, int
  * H <= 64, backward H = 64 (rsdf_sdfmlp_fd7_x2_supported); same outputs and gradient contract as rsdf_sdfmlp_fd7_fwd / _bwd.
  * bwd additionally needs guard_scratch (32 bytes of device memory): it scans d_sdf7t (and d_feature's d(h2)) for their
  * largest magnitude first, from which the kernel derives the power-of-two scale of its fp16 gradient images.
- * Preconditions of the FORWARD (fp16 range): |input| < 255, |weight| < 1023, |hidden activation| < 1023.  A violation
+ * Preconditions of the FORWARD (fp16 range): |input| < 255, |weight| < 1023, |hidden activation| < 454 (activations are
+ * carried times 100 log2(e) = 144.27: the Softplus(beta = 100) then needs no multiply after its logarithm).  A violation
  * overflows to inf / nan, never to a wrong finite number, and is counted in status[RSDF_STATUS_X2_FWD_NONFINITE]
  * (the reference's fp32 network, models/network_utils.py:109-157, stays finite there: the Python side raises, naming
  * RSDF_X2=0, the range-free kernels above).

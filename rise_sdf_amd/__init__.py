@@ -27,7 +27,7 @@ def check_status(device=None) -> dict:
 
 def guarded(fn, device=None):
     """``fn()`` with the forward range guard of the two-part fp16 kernels closed around it: the call, ONE host read of the
-    status words, and -- if an operand left the format's range in it (|weight| / |activation| >= 1023, |hash feature| >= 255;
+    status words, and -- if an operand left the format's range in it (|weight| >= 1023, |activation| >= 454 in the SDF field / 1023 in the radiance networks, |hash feature| >= 255;
     the reference's fp32 MLPs have no such bound, models/network_utils.py:109-157) -- the call again on the range-free kernels,
     which the poll has switched on for the rest of the process.  For callers that make no host read of their own between a
     forward and the use of its outputs (the samplers and TrainStep guard themselves)."""

@@ -502,7 +502,7 @@ def _range_message(bad, sites):
     return (f"kernels of the two-part fp16 (x2) number format produced non-finite outputs ({bad} tiles since the last check: "
             f"{where}): "
             "an operand left the format's range -- fused SDF field (csrc/mlp_x2.hip): |hash feature| or |xyz| >= 255, "
-            "|effective weight| >= 1023 or a hidden activation >= 1023; radiance-network layer pairs (csrc/mlp_pair.hip): "
+            "|effective weight| >= 1023 or a hidden activation >= 454; radiance-network layer pairs (csrc/mlp_pair.hip): "
             "|input|, |weight| or a hidden activation >= 1023 -- where the reference's fp32 MLPs stay finite.")
 
 

@@ -9,11 +9,12 @@
 // relative -- half an fp32 ulp, what one fp32 rounding of the operand would cost -- as long as lo is a normal fp16 number
 // (|v S| >= 0.5), and to 2^-25 ABSOLUTE below that (fp16 subnormals: the matrix cores keep them, measured with
 // tools/mfma_f16_subnormal.hip; the vector ALU's f16 conversions keep them by the default mode).  The class scales put the
-// values that matter well above that floor: inputs (hash features, xyz, 1) x 2^8, weights x 2^6, activations x 2^6, and the
+// values that matter well above that floor: inputs (hash features, xyz, 1) x 2^8, weights x 2^6, activations x 100 log2(e)
+// (= 144.27, round 6: the scale that leaves the Softplus no multiply after its logarithm; 2^6 before), and the
 // backward's gradient images x a power of two derived per LAUNCH from max|d_sdf|, max|d h2| and the weights' norms (the
 // weight-gradient accumulators live across the whole row loop, so the scale must not change inside a launch).  All scales
-// are powers of two: scaling and unscaling are exact.  Preconditions (overflow to inf otherwise): |input| < 255,
-// |weight| < 1023, |activation| < 1023.
+// but the activations' are powers of two: scaling and unscaling are exact (the activations': one fp32 rounding).
+// Preconditions (overflow to inf otherwise): |input| < 255, |weight| < 1023, |activation| < 454.
 //
 // Against the round 1-3 form (three bf16 parts, six products; split_bf16.h): half the matrix instructions, 2 instead of
 // 5.5 vector instructions per split value, 2/3 of the LDS traffic -- and the pre-split input image costs the SAME bytes as
@@ -39,10 +40,22 @@ typedef __attribute__((address_space(3))) v4i16 lds_v4i16;
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glob_void;
 
-constexpr float SX = 256.0f, SW = 64.0f, SH = 64.0f;       // class scales: inputs, weights, activations
-constexpr float T1 = SW * SX, T2 = SW * SH;                 // accumulator scale of layer 1 / of layers 2 and 3
 constexpr float K100 = 144.26950408889634f;                 // 100 log2(e)
+#ifdef RSDF_X2_SH64
 constexpr float LN2_100 = 0.0069314718055994531f;           // ln(2) / 100
+#endif
+// class scales: inputs, weights, activations.  Round 6: the activations' scale is 100 log2(e) instead of 2^6 -- with
+// t = 100 log2(e) z the scaled Softplus SH softplus(z) is max(t, 0) + log2(1 + 2^-|t|) with no multiply left after the
+// logarithm, and sigmoid(100 z) = 1 - 2^(-hs) needs none before the exponential: 6 instead of 7 and 2 instead of 3 vector
+// instructions per value in kernels that are bound by their vector issue.  The fp16 parts are relative, so a scale that is not
+// a power of two costs nothing but the exactness of the (fp32) scaling multiplications; the activations' range is
+// 65504 / 144.27 = 454 instead of 1023.  -DRSDF_X2_SH64: the round-4..6 scale.
+#ifdef RSDF_X2_SH64
+constexpr float SX = 256.0f, SW = 64.0f, SH = 64.0f;
+#else
+constexpr float SX = 256.0f, SW = 64.0f, SH = K100;
+#endif
+constexpr float T1 = SW * SX, T2 = SW * SH;                 // accumulator scale of layer 1 / of layers 2 and 3
 
 // words of a backward launch's guard scratch ("the backward's range guard" below)
 constexpr int GUARD_MAX_DSDF = 0, GUARD_MAX_DH2C = 1, GUARD_NONZERO = 2, GUARD_WITHIN = 3, GUARD_DECISION = 4, GUARD_TICKET = 5;
@@ -136,11 +149,23 @@ template <int LAYER>
 __device__ __forceinline__ float softplus_scaled(float C)
 {
     constexpr float T = LAYER == 1 ? T1 : T2;
+#ifdef RSDF_X2_SH64
     const float e = __builtin_amdgcn_exp2f(fabsf(C) * (-K100 / T));
     return fmaf(max0(C), SH / T, __builtin_amdgcn_logf(1.0f + e) * (LN2_100 * SH));
+#else
+    const float t = C * (K100 / T);                 // 100 log2(e) z  (layer 2: K100 / T2 = 1 / SW, exact)
+    return max0(t) + __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-fabsf(t)));
+#endif
 }
 // sigmoid(100 z) = 1 - 2^(-100 log2(e) h) from hs = SH h, h = softplus(z)
-__device__ __forceinline__ float softplus_grad_scaled(float hs) { return 1.0f - __builtin_amdgcn_exp2f(hs * (-K100 / SH)); }
+__device__ __forceinline__ float softplus_grad_scaled(float hs)
+{
+#ifdef RSDF_X2_SH64
+    return 1.0f - __builtin_amdgcn_exp2f(hs * (-K100 / SH));
+#else
+    return 1.0f - __builtin_amdgcn_exp2f(-hs);
+#endif
+}
 
 __device__ __forceinline__ u32x4 ld128(const unsigned char *p) { return *reinterpret_cast<const u32x4 *>(p); }
 __device__ __forceinline__ void tr64(const unsigned char *p, unsigned &a, unsigned &b)
@@ -436,7 +461,7 @@ fwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
                     if (nc <= 0) break;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) Fs[c * LDFS + (r & 3) + 8 * (r >> 2) + 4 * hf] = o[t][r] * (1.0f / T2);
-                    bool fbad = false;         // (h2 >= 1023 overflows the split of THIS product only: the SDF dot reads fp32 h2)
+                    bool fbad = false;         // (h2 >= 454 overflows the split of THIS product only: the SDF dot reads fp32 h2)
                     for (int e = lane; e < 32 * nc; e += 64) {
                         const int r = e / nc, cc = e - r * nc;
                         const float v = Fs[r * LDFS + cc];

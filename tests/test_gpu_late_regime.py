@@ -1,7 +1,7 @@
 """The default fp32 SDF field (the two-part fp16 "x2" kernels, csrc/mlp_x2.hip) where a 40k-step run ends up, and its guards.
 
 The reference's SDF network is plain fp32 with fp32's range (models/network_utils.py:109-157); the x2 form has a forward
-range (|input| < 255, |weight| < 1023, |activation| < 1023) and a backward dynamic range (one power-of-two scale per launch
+range (|input| < 255, |weight| < 1023, |activation| < 454) and a backward dynamic range (one power-of-two scale per launch
 for the gradient images).  Tests here:
   * the c1 model at L = 16 / T = 2^19, H = 64 and 128, against the ORACLE at variance 0.6 and 0.75 (inv_s 403 and 1808), a
     field sharp enough that alpha saturates to exactly 1, jitter on -- with RSDF_X2 unset (the shipped path);
@@ -352,7 +352,7 @@ def test_forward_range_violation_reroutes_to_the_range_free_kernels(dev, ops, mo
                                                     points=pts, radius=radius, eps=eps)
         with torch.no_grad():
             _lib.reset_range_free()
-            ws[1][0][3, 5] = 900.0
+            ws[1][0][3, 5] = 400.0         # large and in range: activations reach ~300 of the 454 the format holds
             call()
             r = R.check_status(dev)
             assert r["x2_fwd_nonfinite"] == 0 and not r["rerouted_now"] and not _lib.range_free("x2")

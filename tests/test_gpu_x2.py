@@ -233,8 +233,9 @@ def test_x1_field_is_the_fp16_operand_network(dev, ops, H):
 
 
 def test_x2_range_preconditions(dev, ops, monkeypatch):
-    """The x2 form's fp16 class scales bound |weight| < 1023 and |input| < 255.  Inside the bounds large values are exact
-    citizens (a weight of 900, a feature of 200 give the fp64 result); outside them the result is inf / nan -- never a
+    """The x2 form's fp16 class scales bound |weight| < 1023, |input| < 255 and |activation| < 454.  Inside the bounds large
+    values are exact citizens (a weight of 900 -- without the feature rows, whose product would split an activation of ~600 --
+    gives the range-free kernels' result); outside them the result is inf / nan -- never a
     silently wrong finite number -- and RSDF_CHECK=1 names the violation up front."""
     from rise_sdf_amd import _lib, fused
     monkeypatch.delenv("RSDF_CHECK", raising=False)          # (the suite may itself run under RSDF_CHECK=1)
