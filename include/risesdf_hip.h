@@ -565,7 +565,8 @@ int rsdf_neus_alpha_bwd(const float *sdf, const float *normal, const float *dirs
 
 /* ---- T1/T2/S1/O1: per-sample kernels of the radiance branch -----------------------------------------
  * rsdf_freq_encode: VanillaFrequency (models/network_utils.py:14-40): out[:, col_off + 6k + 3f + c] =
- *   {sin,cos}_f(2^k (x_c*x_scale + x_offset)) * mask[k]   (mask nullable device [n_frequencies]).
+ *   {sin,cos}_f(2^k (x_c*x_scale + x_offset)) * mask[k]   (mask nullable device [n_frequencies]; n_frequencies <= 24: a
+ *   workgroup's rows are staged in LDS and stored along the rows).
  * rsdf_sh_encode_*: tcnn.Encoding(otype SphericalHarmonics, degree <= 5) (models/network_utils.py:98-99;
  *   call sites models/texture.py:312,348): real SH of 2*d01-1, degree^2 outputs; backward w.r.t. d01.
  * rsdf_reflect_*: wi = -dirs, wo = 2(wi.n)n - wi, written as wo01 = (wo+1)/2, nov = n.wi

@@ -25,5 +25,5 @@ for e in prof.key_averages(group_by_input_shape=True):
 rows.sort(reverse=True)
 print("aten ops of one step by self device time (us per step, calls per step, op, input shapes); total %.0f us, %.0f calls" %
       (sum(r[0] for r in rows), sum(r[1] for r in rows)))
-for r in rows[:70]:
+for r in rows[:int(os.environ.get("ATEN_ROWS", "70"))]:
     print("%9.1f %6.1f  %-34s %s" % r)
