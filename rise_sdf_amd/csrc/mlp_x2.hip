@@ -158,6 +158,16 @@ __device__ __forceinline__ float softplus_scaled(float C)
 #endif
 }
 // sigmoid(100 z) = 1 - 2^(-100 log2(e) h) from hs = SH h, h = softplus(z)
+// k sigmoid(100 z) = k - k 2^(-hs) as ONE fma after the exponential (the scale k of the gradient image folded in: a multiply
+// and a subtraction less per value than k * (1 - e))
+__device__ __forceinline__ float softplus_grad_times(float hs, float k)
+{
+#ifdef RSDF_X2_SH64
+    return fmaf(-k, __builtin_amdgcn_exp2f(hs * (-K100 / SH)), k);
+#else
+    return fmaf(-k, __builtin_amdgcn_exp2f(-hs), k);
+#endif
+}
 __device__ __forceinline__ float softplus_grad_scaled(float hs)
 {
 #ifdef RSDF_X2_SH64
@@ -901,9 +911,16 @@ bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
                     for (int r = 0; r < 4; ++r) {
                         h2[rh][r] = softplus_scaled<2>(acc[r]);
                         gw2p[r] = fmaf(dsdf, h2[rh][r], gw2p[r]);                    // (x SH: unscaled at the flush)
+#ifdef RSDF_X2_GRAD_R5
                         dz[rh][r] = row_ok[rh] ? fmaf(w2r[r], dsdf, dz[rh][r]) * softplus_grad_scaled(h2[rh][r]) : 0.0f;
-                        gb1p[r] += dz[rh][r];
+                        gb1p[r] += dz[rh][r] * G2;
                         dzs[r] = dz[rh][r] * G2;
+#else
+                        // (the image's scale G2 rides in the derivative's fma; the bias gradient sums the scaled values and is
+                        // unscaled at the flush: G2 is a power of two)
+                        dzs[r] = row_ok[rh] ? fmaf(w2r[r], dsdf, dz[rh][r]) * softplus_grad_times(h2[rh][r], G2) : 0.0f;
+                        gb1p[r] += dzs[r];
+#endif
                     }
                     store_q<HP, NP>(smem + L::DZI, rh, lc, dzs);
                 }
@@ -921,7 +938,11 @@ bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
 #pragma unroll
                 for (int rh = 0; rh < 2; ++rh)
 #pragma unroll
+#ifdef RSDF_X2_GRAD_R5
                     for (int r = 0; r < 4; ++r) dz[rh][r] = acc3[rh][r] * k_dz1 * softplus_grad_scaled(h1[rh][r]);
+#else
+                    for (int r = 0; r < 4; ++r) dz[rh][r] = acc3[rh][r] * softplus_grad_times(h1[rh][r], k_dz1);
+#endif
             }
             {
                 const Frag2 a = trfq<HP, NP>(smem + L::DZI, w, lc);
@@ -979,7 +1000,7 @@ bwd_x2_kernel(const SrcX2 src, const float *__restrict__ w0, const float *__rest
         }
         if (c16 == 0) {
             atomicAdd(&dw2[f], a * (1.0f / SH));
-            atomicAdd(&db1[f], b);
+            atomicAdd(&db1[f], b * (1.0f / G2));      // (gb1p sums G2 dz2)
         }
     }
     if (w == 0) {
