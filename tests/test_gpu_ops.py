@@ -940,3 +940,38 @@ def test_marcher_bit_exact_fragmented_grid(dev, ops, res, fill, step, cone):
     assert torch.equal(gpk.cpu(), pk), "packed_info differs"
     assert torch.equal(gri.cpu(), ri), "ray_indices differ"
     assert torch.equal(gts.cpu(), ts) and torch.equal(gte.cpu(), te), "sample intervals differ"
+
+
+def test_fd7_points_radius_range_is_checked(dev, ops):
+    """The derived stencil takes the contraction's division by 2 r as multiply-adds that round like the division only while
+    nothing over- or underflows (csrc/hashgrid_common.h unit_div): radii outside (2^-101, 2^99) are RSDF_EINVAL, not garbage."""
+    import ctypes
+    from rise_sdf_amd import _lib
+    L, P = _lib.lib(), _lib.ptr
+    meta, n_params = _lib.make_grid_meta(n_levels=4, n_features=2, log2_hashmap_size=12, base_resolution=8, per_level_scale=1.5)
+    table = torch.zeros(int(n_params), device=dev)
+    pts = torch.zeros(8, 3, device=dev)
+    planes = torch.empty(4, 7, 8, 2, device=dev)
+    for radius in (0.0, 1e-38, 1e38, float("inf")):
+        rc = L.rsdf_hashgrid_fwd_fd7_pts(P(pts), radius, 1e-3, P(table), ctypes.byref(meta), 8, 4, P(planes), _lib.stream_ptr())
+        assert rc != 0 and b"radius" in L.rsdf_last_error()
+    assert L.rsdf_hashgrid_fwd_fd7_pts(P(pts), 1.5, 1e-3, P(table), ctypes.byref(meta), 8, 4, P(planes), _lib.stream_ptr()) == 0
+
+
+def test_unit_div_rounds_like_the_division_exhaustively(dev):
+    """tools/unit_div_check.hip on this GPU: unit_div (five multiply-adds) against the IEEE division for all 2^32 x and 18
+    divisors (2 r of the yamls' radius 1.5 first); exit code 0 = no in-contract difference."""
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "unit_div_check")
+        subprocess.check_call([hipcc, "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-w", "-I", os.path.join(root, "rise_sdf_amd", "csrc"),
+                               "-I", os.path.join(root, "include"), "-o", exe, os.path.join(root, "tools", "unit_div_check.hip")])
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:]
+    assert out.stdout.count("in-contract mismatches 0") == 18

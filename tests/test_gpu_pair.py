@@ -45,6 +45,37 @@ def test_pair_image_round_trip(dev):
     assert bool((rows[:, K:96] == 0).all())          # (chunks past the last 32-column group that holds a column are not written)
 
 
+@pytest.mark.parametrize("K1,K2,ld1,ld2,off1,off2", [(48, 39, 48, 39, 0, 0),    # the material networks' [feature | xyz encoding]
+                                                       (48, 16, 48, 16, 0, 0),    # [feature | SH]: both sources as float4
+                                                       (48, 16, 52, 20, 4, 4),    # rows wider than their columns, aligned windows
+                                                       (48, 16, 49, 17, 1, 1),    # unaligned bases and strides: the scalar path
+                                                       (44, 20, 44, 20, 0, 0),    # K1 not a multiple of 8: a chunk spans both sources
+                                                       (128, 0, 128, 0, 0, 0)])
+def test_pair_pack_two_sources_every_alignment(dev, K1, K2, ld1, ld2, off1, off2):
+    """rsdf_pair_pack2 reads aligned sources as two float4 per 8-column chunk (round 6) and everything else column by column:
+    both paths must write the same image as the values themselves (pack -> unpack round trip, 2^-22 relative)."""
+    from rise_sdf_amd import _lib
+    L = _lib.lib()
+    n = 1003
+    g = torch.Generator().manual_seed(K1 * 131 + ld1)
+    b1 = (torch.randn(n, ld1 + off1, generator=g) * 3).to(dev)
+    b2 = (torch.randn(n, max(ld2 + off2, 1), generator=g) * 3).to(dev)
+    x1 = b1.view(-1)[off1:off1 + (n - 1) * ld1 + K1]            # a window at column off1 of the first row: row stride ld1
+    x2 = b2.view(-1)[off2:off2 + (n - 1) * ld2 + K2] if K2 else None
+    img = torch.full((int(L.rsdf_pair_image_bytes(n)),), 0x7F, dtype=torch.uint8, device=dev)
+    rows = torch.empty(n, 128, device=dev)
+    assert L.rsdf_pair_pack2(_lib.ptr(x1), ld1, K1, _lib.ptr(x2) if K2 else None, ld2, K2, n, _lib.ptr(img), None,
+                             _lib.stream_ptr()) == 0
+    assert L.rsdf_pair_unpack(_lib.ptr(img), n, _lib.ptr(rows), _lib.stream_ptr()) == 0
+    want = torch.zeros(n, 128, device=dev)
+    want[:, :K1] = torch.as_strided(x1, (n, K1), (ld1, 1))
+    if K2:
+        want[:, K1:K1 + K2] = torch.as_strided(x2, (n, K2), (ld2, 1))
+    kw = ((K1 + K2 + 31) // 32) * 32        # (chunks past the last 32-column group that holds a column are not written)
+    assert float((rows[:, :kw] - want[:, :kw]).abs().max()) <= 2.0 ** -21 * float(want.abs().max())
+    assert bool((rows[:, K1 + K2:kw] == 0).all())
+
+
 @pytest.mark.parametrize("K,nh,N2,n,out_act", [(84, 4, 6, 4133, "sigmoid"), (73, 4, 3, 1000, "sigmoid"), (84, 2, 1, 2048, "sigmoid"),
                                                (84, 2, 2, 31, "none"), (128, 4, 3, 777, "none"), (17, 2, 5, 65, "none"),
                                                (76, 4, 3, 33, "none"), (84, 2, 13, 500, "none"), (84, 4, 8, 700, "sigmoid")])

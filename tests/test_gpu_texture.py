@@ -192,3 +192,24 @@ def test_pair_kernels_vs_reference_run_gradients_n128(dev, golden_dir, stage):
     print("stage %d: worst parameter gradient %s %.2e; entry points %s" % (stage, worst[0], worst[1],
           {k: v for k, v in calls.items() if "pair" in k}))
     R.check_status()
+
+
+def test_encoders_store_whole_rows_at_any_width(dev):
+    """The frequency / SH encoders stage a workgroup's rows in LDS and store along the rows (round 6): every row count around
+    the workgroup size, outputs inside a wider matrix (col_off, ld), more than 10 frequencies (more than 64 KB of LDS), and
+    the limit of the staging (24 frequencies) as a named error."""
+    from rise_sdf_amd import _lib
+    from rise_sdf_amd import texture_ops as T
+    for n in (1, 255, 256, 257, 1000):
+        x = torch.rand(n, 3, generator=torch.Generator().manual_seed(n)) * 2 - 1
+        for nf in (1, 6, 12):
+            out = torch.full((n, 6 * nf + 5), 7.0, device=dev)
+            T.freq_encode(x.to(dev), nf, out=out, col_off=3)
+            want = otex.vanilla_frequency(x, nf)
+            assert torch.allclose(out[:, 3:3 + 6 * nf].cpu(), want, rtol=0, atol=2e-4 if nf > 8 else 1e-5)   # (2^11 x: fp32 argument)
+            assert bool((out[:, :3] == 7.0).all()) and bool((out[:, 3 + 6 * nf:] == 7.0).all())
+        d = torch.rand(n, 3, generator=torch.Generator().manual_seed(n + 1))
+        for deg in (1, 3, 4, 5):
+            assert torch.allclose(T.sh_encode(d.to(dev), deg).cpu(), otex.sh_encode(d, deg), rtol=0, atol=1e-5)
+    with pytest.raises(_lib.RiseSdfHipError, match="24 frequencies"):
+        T.freq_encode(torch.zeros(4, 3, device=dev), 25)
